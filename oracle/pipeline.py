@@ -1,0 +1,56 @@
+"""CPU restatement of the two callers of the hot path (TEST INFRASTRUCTURE):
+the DDIM denoising loop of `CameraObjCtrlPipeline.__call__`
+(fmc/pipelines/pipeline_animation_cm_om.py:570-738, minus CLIP / VAE which are
+outside the metric) and the stage-3 loss (train_cam_obj_ctrl.py:861-908)."""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn.functional as F
+from einops import rearrange
+
+
+@torch.no_grad()
+def denoise(unet, scheduler, pose_encoder, text_embeddings, pose_embedding, latents, num_inference_steps=50,
+            guidance_scale=7.5, traj_features: Optional[List[torch.Tensor]] = None, omcm_min_step: int = 0,
+            callback=None):
+    """text_embeddings: `[2B,77,C]` (uncond || cond) when guidance_scale>1 else `[B,77,C]`;
+    pose_embedding `[B,6,F,H,W]`; latents `[B,4,F,h,w]` already scaled by init_noise_sigma.
+    Follows pipeline_animation_cm_om.py:624-720 with `multidiff_total_steps == 1`."""
+    cfg = guidance_scale > 1.0
+    scheduler.set_timesteps(num_inference_steps)
+    bs = pose_embedding.shape[0]
+    pose_feats = [rearrange(x, "(b f) c h w -> b c f h w", b=bs) for x in pose_encoder(pose_embedding)]   # :657-660
+    if cfg:
+        pose_feats = [torch.cat([x, x], dim=0) for x in pose_feats]                                       # :668-669
+        if traj_features is not None:                                                                      # :671-676
+            traj_features = [torch.cat([torch.zeros_like(t), t], dim=0) for t in traj_features]
+    for i, t in enumerate(scheduler.timesteps):
+        traj = traj_features
+        if traj_features is not None and omcm_min_step > 0 and t < omcm_min_step:                        # :682-685
+            traj = None
+        x = torch.cat([latents] * 2) if cfg else latents
+        x = scheduler.scale_model_input(x, t)
+        eps = unet(x, t, encoder_hidden_states=text_embeddings, pose_embedding_features=pose_feats,
+                   traj_features=traj).sample.to(latents.dtype)
+        if cfg:
+            eps_u, eps_c = eps.chunk(2)
+            eps = eps_u + guidance_scale * (eps_c - eps_u)                                                # :711-713
+        latents = scheduler.step(eps, t, latents).prev_sample                                             # :720
+        if callback is not None:
+            callback(i, t, latents)
+    return latents
+
+
+def stage3_loss(model_pred, target, obj_masks, sd_loss_weight=0.3, mask_loss_weight=1.0):
+    """`sd_w * MSE + mask_w * MSE(mask*pred, mask*target)` (train_cam_obj_ctrl.py:878-908).
+    obj_masks: `[B,F,H,W]` bool union of the (hard) object masks at pixel resolution; it is
+    brought to latent resolution with default (nearest) interpolation (:897-899)."""
+    sd = F.mse_loss(model_pred.float(), target.float(), reduction="mean")
+    B = obj_masks.shape[0]
+    m = rearrange(obj_masks.to(model_pred.dtype), "b f h w -> (b f) 1 h w")
+    m = F.interpolate(m, size=model_pred.shape[-2:])
+    m = rearrange(m, "(b f) c h w -> b c f h w", b=B)
+    ml = F.mse_loss((m * model_pred).float(), (m * target).float(), reduction="mean")
+    return mask_loss_weight * ml + sd_loss_weight * sd

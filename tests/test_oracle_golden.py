@@ -1,0 +1,88 @@
+"""The oracle against vectors produced by the reference itself (tests/golden/make_golden.py).
+CPU only.  Tolerances: fp32 round-off of re-associated sums (1e-5 rel-inf unless stated)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import conditioning as C
+from oracle import fmc_modules as M
+
+
+def rel_inf(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def test_g1_plucker(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g1_plucker.npz"))
+    out = C.ray_condition(torch.from_numpy(g["K"]), torch.from_numpy(g["c2w"]), int(g["H"]), int(g["W"]))
+    assert out.shape == g["out"].shape
+    assert rel_inf(out, g["out"]) < 1e-6
+    out_b = C.ray_condition(torch.from_numpy(g["K_b"]), torch.from_numpy(g["c2w_b"]), int(g["H_b"]), int(g["W_b"]))
+    assert rel_inf(out_b[:, :, :: int(g["row_step"])], g["out_b"]) < 1e-6
+
+
+def test_g1_to_plucker_embedding_layout(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g1_plucker.npz"))
+    emb = C.to_plucker_embedding(torch.from_numpy(g["c2w"][:, :, :3]), torch.from_numpy(g["K"]),
+                                 (int(g["H"]), int(g["W"])))
+    assert emb.shape == (2, 4, 6, 16, 24)
+    assert rel_inf(emb.permute(0, 1, 3, 4, 2), g["out"]) < 1e-6
+
+
+def _small_adapter(g):
+    ad = M.Adapter(channels=[16, 32, 64, 64], nums_rb=2, cin=832, sk=True, use_conv=False,
+                   use_pre_zero_conv=True, use_post_zero_conv=True).eval()
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    assert set(sd) == set(ad.state_dict()), "state-dict keys must equal the reference's"
+    ad.load_state_dict(sd, strict=True)
+    return ad
+
+
+def test_g2_adapter(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g2_adapter_small.npz"))
+    ad = _small_adapter(g)
+    with torch.no_grad():
+        fm = ad(torch.from_numpy(g["x"]), torch.from_numpy(g["mask"]))
+        fn = ad(torch.from_numpy(g["x"]), None)
+    for i in range(4):
+        assert rel_inf(fm[i], g[f"out_mask_{i}"]) < 1e-5
+        assert rel_inf(fn[i], g[f"out_nomask_{i}"]) < 1e-5
+
+
+def test_g2_adapter_full_keys(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g2_adapter_full_keys.npz"))
+    with torch.device("meta"):
+        ad = M.Adapter(channels=[320, 640, 1280, 1280], nums_rb=2, cin=832, sk=True, use_conv=False,
+                       use_pre_zero_conv=True, use_post_zero_conv=True)
+    sd = ad.state_dict()
+    assert list(sd.keys()) == list(g["keys"])
+    assert [str(tuple(v.shape)) for v in sd.values()] == list(g["shapes"])
+    assert sum(p.numel() for p in ad.parameters()) == int(g["n_params"]) == 152510656
+
+
+def test_g3_rasterise_and_traj_features(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g3_traj.npz"))
+    g2 = np.load(os.path.join(golden_dir, "g2_adapter_small.npz"))
+    masks = [[torch.from_numpy(g["masks"][b, f]) for f in range(g["masks"].shape[1])]
+             for b in range(g["masks"].shape[0])]
+    infos = [[g["infos"][b, f] for f in range(g["infos"].shape[1])] for b in range(g["infos"].shape[0])]
+    feats, m = C.rasterize_objects(infos, masks)
+    assert torch.equal(m, torch.from_numpy(g["raster_mask"]))
+    assert rel_inf(feats, g["raster"]) < 1e-7
+    # overlapping objects: a later object must overwrite an earlier one
+    both = (g["masks"][0, 0, 0, 0] > 0) & (g["masks"][0, 0, 2, 0] > 0)
+    assert both.any()
+    ad = _small_adapter(g2)
+    with torch.no_grad():
+        out = C.get_traj_features(infos, masks, ad)
+    for i in range(4):
+        assert out[i].shape == g[f"feat_{i}"].shape
+        assert rel_inf(out[i], g[f"feat_{i}"]) < 1e-5
+
+
+def test_g4_relative_pose(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g4_relpose.npz"))
+    rel = C.relative_cam_poses(g["abs_rt"], scale_T=float(g["scale_T"]))
+    assert np.abs(rel - g["rel"]).max() < 1e-12
