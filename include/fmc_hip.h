@@ -1,0 +1,165 @@
+/*
+ * fmc_hip.h -- C ABI of libfmc_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * denoising hot path of FMC (FudanCVL/SynFMC).
+ *
+ * This is the drop-in boundary.  The reference is pure Python and has
+ * no FFI of its own; every entry point below replaces a chain of implicit PyTorch/cuDNN/cuBLAS
+ * calls at the cited reference site (`path:line` relative to the reference root).  The
+ * reference-side binding a maintainer would add is a ctypes stub: see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless named `h_*`;
+ *   - the caller owns every buffer; kernels never allocate, free or synchronise;
+ *   - all work is enqueued on `stream` (a hipStream_t; NULL = the default stream);
+ *   - every function returns 0 on success or a negative FMC_E_* code; `fmc_last_error()`
+ *     returns a thread-local, human readable description of the last failure;
+ *   - `dtype` selects the storage type of activations: FMC_BF16 (bf16 storage, fp32
+ *     accumulate / statistics) or FMC_F32 (fp32 storage; the attention kernels then run the
+ *     matrix products as split-bf16 x3 MFMA so that results agree with an fp32 reference to
+ *     ~1e-5 -- this is the parity mode, not the fast mode);
+ *   - activations are channels-last: an image batch is `[N, H*W, C]` with C contiguous.
+ */
+#ifndef FMC_HIP_H
+#define FMC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMC_VERSION 100 /* 0.1.0 */
+
+enum { FMC_BF16 = 0, FMC_F32 = 1 };
+
+enum {
+    FMC_OK = 0,
+    FMC_E_SHAPE = -1,  /* unsupported / inconsistent shape      -> Python ValueError          */
+    FMC_E_DTYPE = -2,  /* unknown dtype code                    -> Python TypeError           */
+    FMC_E_ALIGN = -3,  /* pointer or stride not 16-byte aligned -> Python ValueError          */
+    FMC_E_LAUNCH = -4, /* hipLaunchKernel failed                -> Python RuntimeError        */
+    FMC_E_NULL = -5    /* NULL where a pointer is required      -> Python ValueError          */
+};
+
+int fmc_version(void);
+const char* fmc_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * GroupNorm (+ optional SiLU), channels-last.
+ * Replaces nn.GroupNorm + SiLU in diffusers' ResnetBlock2D (norm1/norm2; ctor args at
+ * fmc/models/unet_blocks.py:306-317), `conv_norm_out` + `conv_act` (fmc/models/unet.py:284-285,
+ * 749-752), InflatedGroupNorm of the motion modules (fmc/models/resnet.py:27-37, no activation)
+ * and the `norm` of Transformer2DModel (eps 1e-6).
+ *   x, y        : [N, HW, C]  (dtype), y may alias x
+ *   gamma, beta : [C] fp32
+ *   stats       : [N, G, 2] fp32 out (mean, rstd) -- kept for the backward; must not be NULL
+ *   workspace   : fp32 scratch of fmc_groupnorm_workspace_bytes(N, C, G) bytes
+ *   act         : 0 = none, 1 = SiLU
+ * Requires C % 8 == 0 and C % G == 0.
+ * ------------------------------------------------------------------------------------------- */
+int64_t fmc_groupnorm_workspace_bytes(int N, int C, int G);
+int fmc_groupnorm_silu_fwd(const void* x, void* y, const float* gamma, const float* beta, float* stats,
+                           void* workspace, int N, int HW, int C, int G, float eps, int act, int dtype,
+                           void* stream);
+/* dX of the above (frozen gamma/beta: the only case on the FMC training path).
+ *   dy, x, dx : [N, HW, C]; stats from the forward; act as in the forward. */
+int fmc_groupnorm_silu_bwd(const void* dy, const void* x, void* dx, const float* gamma, const float* beta,
+                           const float* stats, void* workspace, int N, int HW, int C, int G, int act,
+                           int dtype, void* stream);
+
+/* LayerNorm over the last dim of a token matrix [M, C] (eps 1e-5 everywhere on the path:
+ * BasicTransformerBlock.norm1-3, TemporalTransformerBlock.norms / ff_norm,
+ * fmc/models/motion_module.py:282-285).  Optional fused positional-encoding add for the temporal
+ * blocks (`pos_encoder(norm(x))`, motion_module.py:355-356): if `pe` != NULL, token row r gets
+ * pe[(r / pe_inner) % pe_frames] added AFTER the normalisation (rows are `[(b f), hw]` ordered:
+ * pe_inner = hw, pe_frames = F).   gamma/beta/pe: fp32. */
+int fmc_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, const float* pe,
+                      int64_t M, int C, float eps, int pe_inner, int pe_frames, int dtype, void* stream);
+
+/* GEGLU gate of diffusers' FeedForward (`a * gelu_erf(g)` with a,g = chunk(proj(x), 2);
+ * fmc/models/motion_module.py:284 and BasicTransformerBlock.ff):  x [M, 2*Cff] -> y [M, Cff]. */
+int fmc_geglu_fwd(const void* x, void* y, int64_t M, int Cff, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Spatial attention: softmax(Q K^T * scale) V per (batch, head), flash style (no S x S tensor).
+ * Replaces head_to_batch_dim + baddbmm + softmax + bmm + batch_to_head_dim in
+ * fmc/models/attention_processor.py:61-67 / 148-154 for `attn1` (self, S_kv = S_q) and `attn2`
+ * (text cross attention, S_kv = 77).
+ *   q : [B, Sq, H*D]  rows `q_row_stride` elements apart, batches `q_batch_stride` apart
+ *   k, v : [Bkv, Skv, H*D] likewise; batch b of q reads kv batch  b / kv_batch_div
+ *          (kv_batch_div = F lets all frames of a clip share one text K/V)
+ *   o : [B, Sq, H*D] with its own strides
+ *   lse : optional [B, H, Sq] fp32 (natural-log-sum-exp of the scaled scores), NULL to skip
+ *   D must be a multiple of 8 and <= 160.  All strides in ELEMENTS, multiples of 8.
+ * ------------------------------------------------------------------------------------------- */
+int fmc_spatial_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H,
+                         int Sq, int Skv, int D, int64_t q_batch_stride, int64_t q_row_stride,
+                         int64_t kv_batch_stride, int64_t kv_row_stride, int64_t o_batch_stride,
+                         int64_t o_row_stride, int kv_batch_div, float scale, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Temporal attention: for every pixel and head, softmax(Q K^T * scale) V over the F frames.
+ * Replaces the same call chain for the motion-module / camera-encoder attention blocks
+ * (fmc/models/attention_processor.py:271-281 and :61-67 reached from
+ * fmc/models/motion_module.py:365-389).
+ * Token (clip n, frame f, pixel p) lives at  base + n*clip_stride + f*frame_stride + p*pix_stride
+ * (elements); the H*D channels of a token are contiguous.  The reference layout `(b h w) f c` is
+ * clip_stride = HW*F*C, pix_stride = F*C, frame_stride = C; the native channels-last layout
+ * `[(b f), hw, c]` is clip_stride = F*HW*C, frame_stride = HW*C, pix_stride = C -- no transposing
+ * copy in either case.  q/k/v share one stride triple (they are slices of one fused QKV row),
+ * o has its own.   F in {16, 32};  D % 8 == 0, D <= 160;  (H*D) % 8 == 0.
+ * ------------------------------------------------------------------------------------------- */
+int fmc_temporal_attn_fwd(const void* q, const void* k, const void* v, void* o, int n_clips, int n_pix,
+                          int F, int H, int D, int64_t clip_stride, int64_t frame_stride,
+                          int64_t pix_stride, int64_t o_clip_stride, int64_t o_frame_stride,
+                          int64_t o_pix_stride, float scale, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pluecker-ray embedding.  Replaces `ray_condition` (fmc/data/dataset.py:930-972) + the permutes
+ * of `to_plucker_embedding` (train_cam_obj_ctrl.py:80-91, :833), which run on the CPU every step.
+ *   K   : [B*F, 4] fp32 (fx, fy, cx, cy)      c2w : [B*F, c2w_rows(3|4), 4] fp32
+ *   layout 0: out [B, F, H, W, 6]   (what ray_condition returns)
+ *   layout 1: out [B, 6, F, H, W]   (what the trainers feed the pose encoder)
+ *   layout 2: out [B*F, H/8, W/8, 384] channels-last, PixelUnshuffle(8) already applied
+ *             (channel = c*64 + dy*8 + dx; input of CameraPoseEncoder.encoder_conv_in,
+ *              fmc/models/pose_adaptor.py:228-232)
+ *   out dtype: FMC_F32 or FMC_BF16.
+ * ------------------------------------------------------------------------------------------- */
+int fmc_plucker_fwd(const float* K, const float* c2w, void* out, int B, int F, int H, int W, int c2w_rows,
+                    int layout, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * OMC rasteriser.  Replaces the Python loops of get_traj_features_v2 (fmc/util.py:158-201).
+ *   poses : [BF, n_obj, 12] fp32      masks : [BF, n_obj, H, W] fp32 (Gaussian circle masks)
+ *   layout 0: feat [BF, 13, H, W], mask_out [BF, 1, H, W]           (the Adapter's reference inputs)
+ *   layout 2: feat [BF, H/8, W/8, 832] channels-last + PixelUnshuffle(8); mask_out [BF, H, W]
+ *   Per pixel the LAST object with mask > 0 wins; feat = (pose*mask, mask) * mask.
+ * ------------------------------------------------------------------------------------------- */
+int fmc_omc_rasterize_fwd(const float* poses, const float* masks, void* feat, float* mask_out, int BF,
+                          int n_obj, int H, int W, int layout, int dtype, void* stream);
+
+/* y[n,i,j,:] = x[n,i,j,:] * mask_in[n, si(i), sj(j)] with PyTorch's nearest rule
+ * si(i) = min(floor(i * (float)Hin/h), Hin-1); also emits the resampled mask for the next level
+ * (the reference cascades: fmc/adapter.py:175-177).  Used for the backward too (dX = mask * dY).
+ *   x, y : [N, h*w, C] (dtype)   mask_in : [N, Hin, Win] fp32   mask_out : [N, h, w] fp32 or NULL */
+int fmc_mask_modulate_fwd(const void* x, const float* mask_in, void* y, float* mask_out, int N, int h, int w,
+                          int C, int Hin, int Win, int dtype, void* stream);
+
+/* OMC injection `hidden + traj_features[idx]` (fmc/modified_modules.py:115-117,172-174) including
+ * the classifier-free-guidance zero half (pipeline_animation_cm_om.py:671-676): the first
+ * `skip_elems` elements of h get nothing added (just copied when out != h).
+ *   h, out : [n_elems] (dtype), out may alias h;   t : [n_elems - skip_elems] (dtype) */
+int fmc_feature_add_fwd(const void* h, const void* t, void* out, int64_t n_elems, int64_t skip_elems,
+                        int dtype, void* stream);
+
+/* CFG combine + DDIM (eta = 0) update, fused (pipeline_animation_cm_om.py:711-720; diffusers
+ * DDIMScheduler.step):  eps = eps_u + g (eps_c - eps_u);  x0 = (x - sqrt(1-a_t) eps)/sqrt(a_t);
+ * x' = sqrt(a_prev) x0 + sqrt(1-a_prev) eps.   eps_uc: [2, n] (dtype) (uncond, cond), or [1, n]
+ * when guidance <= 1 (then pass has_uncond = 0).   x, x_out: [n] fp32 latents. */
+int fmc_cfg_ddim_step(const void* eps_uc, const float* x, float* x_out, int64_t n, int has_uncond,
+                      float guidance, float alpha_t, float alpha_prev, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FMC_HIP_H */

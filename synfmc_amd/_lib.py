@@ -1,0 +1,74 @@
+"""ctypes binding of `libfmc_hip.so` (the C ABI declared in `include/fmc_hip.h`).
+
+The library is the product: there is no CPU or PyTorch fallback.  If it is missing
+or a kernel reports an error, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfmc_hip.so")
+
+FMC_BF16, FMC_F32 = 0, 1
+
+_ERRORS = {-1: ValueError, -2: TypeError, -3: ValueError, -4: RuntimeError, -5: ValueError}
+
+# name -> (restype, argtypes); mirrors include/fmc_hip.h one to one
+SIGNATURES = {
+    "fmc_version": (c_int, []),
+    "fmc_last_error": (c_char_p, []),
+    "fmc_groupnorm_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
+    "fmc_groupnorm_silu_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                       c_int, c_float, c_int, c_int, c_void_p]),
+    "fmc_groupnorm_silu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                       c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fmc_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int,
+                                  c_int, c_int, c_void_p]),
+    "fmc_geglu_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "fmc_spatial_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                     c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_float, c_int,
+                                     c_void_p]),
+    "fmc_temporal_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                      c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_int, c_void_p]),
+    "fmc_plucker_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fmc_omc_rasterize_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                      c_void_p]),
+    "fmc_mask_modulate_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                      c_int, c_void_p]),
+    "fmc_feature_add_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    "fmc_cfg_ddim_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_int,
+                                  c_void_p]),
+}
+
+_lib = None
+
+
+class FmcLibraryMissing(ImportError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load (once) and type the shared library.  Raises `FmcLibraryMissing` when it has not been built
+    (`python -c "import __graft_entry__ as g; g.build()"` or `make -C synfmc_amd/csrc`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise FmcLibraryMissing(
+            f"{LIB_PATH} not found: build it with `make -C synfmc_amd/csrc` (hipcc --offload-arch=gfx950). "
+            "There is no fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().fmc_last_error()
+        raise _ERRORS.get(rc, RuntimeError)(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,106 @@
+// Shared helpers for the gfx950 kernels of libfmc_hip.so (wave = 64 lanes, CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/fmc_hip.h"
+
+// ---- error plumbing (thread-local message, negative status codes) -----------------------------
+void fmc_set_error(const char* fmt, ...);
+
+#define FMC_FAIL(code, ...)          \
+    do {                             \
+        fmc_set_error(__VA_ARGS__);  \
+        return (code);               \
+    } while (0)
+
+#define FMC_CHECK_LAUNCH(name)                                                       \
+    do {                                                                             \
+        hipError_t e__ = hipGetLastError();                                          \
+        if (e__ != hipSuccess) FMC_FAIL(FMC_E_LAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+static inline bool fmc_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- vector / fragment types ---------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+typedef unsigned short bf16_t;  // raw storage
+
+// round-to-nearest-even float -> bf16 (inputs are finite on this path; NaN keeps a quiet pattern)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((unsigned)b) << 16); }
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+// 8 consecutive activations <-> 8 floats, for both storage types
+template <typename T> struct Vec8;
+template <> struct Vec8<bf16_t> {
+    __device__ __forceinline__ static void load(const bf16_t* p, float (&v)[8]) {
+        u32x4 r = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(r[i] << 16);
+            v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+        }
+    }
+    __device__ __forceinline__ static void store(bf16_t* p, const float (&v)[8]) {
+        u32x4 r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = pack_bf2(v[2 * i], v[2 * i + 1]);
+        *reinterpret_cast<u32x4*>(p) = r;
+    }
+};
+template <> struct Vec8<float> {
+    __device__ __forceinline__ static void load(const float* p, float (&v)[8]) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(p);
+        f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+    }
+    __device__ __forceinline__ static void store(float* p, const float (&v)[8]) {
+        f32x4 a, b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+        *reinterpret_cast<f32x4*>(p) = a;
+        *reinterpret_cast<f32x4*>(p + 4) = b;
+    }
+};
+
+// split 8 fp32 values into a bf16 "hi" fragment and the bf16 of the remainder ("lo"):
+// a ~= hi + lo to ~2^-17 relative, so a*b ~= hi*hi' + hi*lo' + lo*hi' on the bf16 MFMA pipe.
+__device__ __forceinline__ void split_bf16x8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+    union { bf16x8 v; bf16_t s[8]; } h, l;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        bf16_t b = f2bf(v[i]);
+        h.s[i] = b;
+        l.s[i] = f2bf(v[i] - bf2f(b));
+    }
+    hi = h.v;
+    lo = l.v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

@@ -1,0 +1,435 @@
+// GroupNorm(+SiLU) fwd/bwd, LayerNorm(+PE), GEGLU -- HBM-bound channels-last passes for gfx950.
+//
+// Layout: activations are [N, HW, C] with C contiguous.  A thread always owns the same 8
+// consecutive channels (one 16-byte bf16 load) and walks rows, so every wave-level load is a run
+// of full rows (coalesced) and the per-channel affine terms live in registers.
+//
+// Roofline: all kernels here are HBM bound.  Algorithmic bytes:
+//   groupnorm_silu_fwd : 2 * N*HW*C * e   (read x + write y; the second read of x for the apply
+//                                          pass is expected to hit L2 / Infinity Cache)
+//   layernorm_fwd      : 2 * M*C * e      geglu_fwd : 3 * M*Cff * e
+#include "common.h"
+
+namespace {
+
+constexpr int GN_MAX_SPLIT = 64;
+constexpr int GN_MAX_G = 64;
+
+struct GnGeom {
+    int tpr;    // threads per row  = C / 8
+    int rpi;    // rows per block iteration
+    int block;  // tpr * rpi
+    int split;  // blocks per sample
+    int rows_per_split;
+};
+
+GnGeom gn_geom(int HW, int C) {
+    GnGeom g;
+    g.tpr = C / 8;
+    g.rpi = 512 / g.tpr;
+    if (g.rpi < 1) g.rpi = 1;
+    if (g.rpi > HW) g.rpi = HW;
+    g.block = g.tpr * g.rpi;
+    int rows_target = 8 * g.rpi;  // every thread sees ~8 rows
+    g.split = (HW + rows_target - 1) / rows_target;
+    if (g.split > GN_MAX_SPLIT) g.split = GN_MAX_SPLIT;
+    if (g.split < 1) g.split = 1;
+    g.rows_per_split = (HW + g.split - 1) / g.split;
+    g.split = (HW + g.rows_per_split - 1) / g.rows_per_split;
+    return g;
+}
+
+__device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
+__device__ __forceinline__ float dsilu_f(float z) {
+    float s = 1.f / (1.f + __expf(-z));
+    return s * (1.f + z * (1.f - s));
+}
+
+// --------------------------------------------------------------------------------------------
+// pass 1: per (sample, split, group) partial sums.  MODE 0: (sum x, sum x^2).
+// MODE 1 (backward): with z = a*x+b, dxh = dy*act'(z)*gamma, xh = (x-mean)*rstd:
+//                    (sum dxh, sum dxh*xh).
+// --------------------------------------------------------------------------------------------
+template <typename T, int MODE>
+__global__ void gn_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ gamma,
+                                  const float* __restrict__ beta, const float* __restrict__ stats,
+                                  float* __restrict__ part, int HW, int C, int G, int tpr, int rpi,
+                                  int rows_per_split, int act) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][rpi][C]
+    const int n = blockIdx.y, s = blockIdx.x, nsplit = gridDim.x;
+    const int tid = threadIdx.x;
+    const int cc = tid % tpr, rsub = tid / tpr;
+    const int c0 = cc * 8;
+    const int cpg = C / G;
+    const int row0 = s * rows_per_split;
+    int row1 = row0 + rows_per_split;
+    if (row1 > HW) row1 = HW;
+
+    float aco[8], bco[8], mu[8], rs[8], gm[8];
+    if (MODE == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int c = c0 + i, g = c / cpg;
+            mu[i] = stats[((size_t)n * G + g) * 2];
+            rs[i] = stats[((size_t)n * G + g) * 2 + 1];
+            gm[i] = gamma[c];
+            aco[i] = rs[i] * gm[i];
+            bco[i] = beta[c] - mu[i] * aco[i];
+        }
+    }
+    float s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
+    const T* xb = x + (size_t)n * HW * C + c0;
+    const T* dyb = (MODE == 1) ? dy + (size_t)n * HW * C + c0 : nullptr;
+    for (int r = row0 + rsub; r < row1; r += rpi) {
+        float v[8];
+        Vec8<T>::load(xb + (size_t)r * C, v);
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s1[i] += v[i]; s2[i] += v[i] * v[i]; }
+        } else {
+            float d[8];
+            Vec8<T>::load(dyb + (size_t)r * C, d);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float z = v[i] * aco[i] + bco[i];
+                float dz = act ? d[i] * dsilu_f(z) : d[i];
+                float dxh = dz * gm[i];
+                float xh = (v[i] - mu[i]) * rs[i];
+                s1[i] += dxh;
+                s2[i] += dxh * xh;
+            }
+        }
+    }
+    float* l1 = smem;
+    float* l2 = smem + (size_t)rpi * C;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        l1[rsub * C + c0 + i] = s1[i];
+        l2[rsub * C + c0 + i] = s2[i];
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += blockDim.x) {
+        float a = 0.f, b = 0.f;
+        for (int r = 0; r < rpi; ++r) { a += l1[r * C + c]; b += l2[r * C + c]; }
+        l1[c] = a;  // row 0 of each plane now holds the per-channel totals
+        l2[c] = b;
+    }
+    __syncthreads();
+    for (int g = tid; g < G; g += blockDim.x) {
+        float a = 0.f, b = 0.f;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += l1[c]; b += l2[c]; }
+        float* p = part + (((size_t)n * nsplit + s) * G + g) * 2;
+        p[0] = a;
+        p[1] = b;
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// pass 2 (forward): combine partials -> mean / rstd, then y = act(x * a_c + b_c)
+// --------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void gn_apply_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, const float* __restrict__ part,
+                                    float* __restrict__ stats, int HW, int C, int G, int tpr, int rpi,
+                                    int rows_per_split, float eps, int act) {
+    __shared__ float sh_mean[GN_MAX_G], sh_rstd[GN_MAX_G];
+    const int n = blockIdx.y, s = blockIdx.x, nsplit = gridDim.x;
+    const int tid = threadIdx.x;
+    const int cpg = C / G;
+    for (int g = tid; g < G; g += blockDim.x) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < nsplit; ++k) {
+            const float* p = part + (((size_t)n * nsplit + k) * G + g) * 2;
+            a += (double)p[0];
+            b += (double)p[1];
+        }
+        double cnt = (double)HW * cpg;
+        double mean = a / cnt;
+        double var = b / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        sh_mean[g] = (float)mean;
+        sh_rstd[g] = rstd;
+        if (s == 0) {
+            stats[((size_t)n * G + g) * 2] = (float)mean;
+            stats[((size_t)n * G + g) * 2 + 1] = rstd;
+        }
+    }
+    __syncthreads();
+    const int cc = tid % tpr, rsub = tid / tpr;
+    const int c0 = cc * 8;
+    float aco[8], bco[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int c = c0 + i, g = c / cpg;
+        aco[i] = sh_rstd[g] * gamma[c];
+        bco[i] = beta[c] - sh_mean[g] * aco[i];
+    }
+    const int row0 = s * rows_per_split;
+    int row1 = row0 + rows_per_split;
+    if (row1 > HW) row1 = HW;
+    const T* xb = x + (size_t)n * HW * C + c0;
+    T* yb = y + (size_t)n * HW * C + c0;
+    for (int r = row0 + rsub; r < row1; r += rpi) {
+        float v[8];
+        Vec8<T>::load(xb + (size_t)r * C, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float z = v[i] * aco[i] + bco[i];
+            v[i] = act ? silu_f(z) : z;
+        }
+        Vec8<T>::store(yb + (size_t)r * C, v);
+    }
+}
+
+// pass 2 (backward): dx = rstd * (dxh - S1/cnt - xh * S2/cnt)
+template <typename T>
+__global__ void gn_apply_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dx,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ stats, const float* __restrict__ part, int HW, int C,
+                                    int G, int tpr, int rpi, int rows_per_split, int act) {
+    __shared__ float sh_m1[GN_MAX_G], sh_m2[GN_MAX_G];
+    const int n = blockIdx.y, s = blockIdx.x, nsplit = gridDim.x;
+    const int tid = threadIdx.x;
+    const int cpg = C / G;
+    for (int g = tid; g < G; g += blockDim.x) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < nsplit; ++k) {
+            const float* p = part + (((size_t)n * nsplit + k) * G + g) * 2;
+            a += (double)p[0];
+            b += (double)p[1];
+        }
+        double cnt = (double)HW * cpg;
+        sh_m1[g] = (float)(a / cnt);
+        sh_m2[g] = (float)(b / cnt);
+    }
+    __syncthreads();
+    const int cc = tid % tpr, rsub = tid / tpr;
+    const int c0 = cc * 8;
+    float aco[8], bco[8], mu[8], rs[8], gm[8], m1[8], m2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int c = c0 + i, g = c / cpg;
+        mu[i] = stats[((size_t)n * G + g) * 2];
+        rs[i] = stats[((size_t)n * G + g) * 2 + 1];
+        gm[i] = gamma[c];
+        aco[i] = rs[i] * gm[i];
+        bco[i] = beta[c] - mu[i] * aco[i];
+        m1[i] = sh_m1[g];
+        m2[i] = sh_m2[g];
+    }
+    const int row0 = s * rows_per_split;
+    int row1 = row0 + rows_per_split;
+    if (row1 > HW) row1 = HW;
+    const size_t base = (size_t)n * HW * C + c0;
+    for (int r = row0 + rsub; r < row1; r += rpi) {
+        float v[8], d[8];
+        Vec8<T>::load(x + base + (size_t)r * C, v);
+        Vec8<T>::load(dy + base + (size_t)r * C, d);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float z = v[i] * aco[i] + bco[i];
+            float dz = act ? d[i] * dsilu_f(z) : d[i];
+            float dxh = dz * gm[i];
+            float xh = (v[i] - mu[i]) * rs[i];
+            v[i] = rs[i] * (dxh - m1[i] - xh * m2[i]);
+        }
+        Vec8<T>::store(dx + base + (size_t)r * C, v);
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// LayerNorm (+ positional-encoding add): one wave per token row, row kept in registers.
+// --------------------------------------------------------------------------------------------
+template <typename T, int NCH>  // NCH = ceil(C/8/64) chunks of 8 per lane
+__global__ void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, const float* __restrict__ pe, int64_t M, int C,
+                                 float eps, int pe_inner, int pe_frames) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wpb = blockDim.x >> 6;
+    const int nchunks = C / 8;
+    for (int64_t row = (int64_t)blockIdx.x * wpb + wave; row < M; row += (int64_t)gridDim.x * wpb) {
+        float v[NCH][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            int ch = lane + 64 * k;
+            if (ch < nchunks) {
+                Vec8<T>::load(x + row * C + ch * 8, v[k]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sum += v[k][i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[k][i] = 0.f;
+            }
+        }
+        const float mean = wave_sum(sum) / (float)C;
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            int ch = lane + 64 * k;
+            if (ch < nchunks) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { float d = v[k][i] - mean; sq += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+        const float* per = pe ? pe + (size_t)((row / pe_inner) % pe_frames) * C : nullptr;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            int ch = lane + 64 * k;
+            if (ch < nchunks) {
+                float o[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    int c = ch * 8 + i;
+                    o[i] = (v[k][i] - mean) * rstd * gamma[c] + beta[c];
+                    if (per) o[i] += per[c];
+                }
+                Vec8<T>::store(y + row * C + ch * 8, o);
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// GEGLU: y = a * gelu_erf(g)
+// --------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void geglu_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t M, int Cff) {
+    const int cpr = Cff / 8;
+    const int64_t total = M * cpr;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        int64_t m = idx / cpr;
+        int c = (int)(idx - m * cpr) * 8;
+        float a[8], g[8];
+        Vec8<T>::load(x + m * 2 * Cff + c, a);
+        Vec8<T>::load(x + m * 2 * Cff + Cff + c, g);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = a[i] * (0.5f * g[i] * (1.f + erff(g[i] * 0.70710678118654752f)));
+        Vec8<T>::store(y + m * Cff + c, a);
+    }
+}
+
+int gn_check(const void* x, const void* y, int N, int HW, int C, int G, int dtype) {
+    if (!x || !y) FMC_FAIL(FMC_E_NULL, "groupnorm: NULL tensor");
+    if (dtype != FMC_BF16 && dtype != FMC_F32) FMC_FAIL(FMC_E_DTYPE, "groupnorm: dtype %d", dtype);
+    if (N <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % 8 || C % G || G > GN_MAX_G || C > 8 * 512)
+        FMC_FAIL(FMC_E_SHAPE, "groupnorm: need C%%8==0, C%%G==0, G<=%d, C<=4096 (N=%d HW=%d C=%d G=%d)", GN_MAX_G, N,
+                 HW, C, G);
+    if (!fmc_aligned16(x) || !fmc_aligned16(y)) FMC_FAIL(FMC_E_ALIGN, "groupnorm: tensors must be 16-byte aligned");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t fmc_groupnorm_workspace_bytes(int N, int C, int G) {
+    (void)C;
+    return (int64_t)N * GN_MAX_SPLIT * G * 2 * (int64_t)sizeof(float);
+}
+
+extern "C" int fmc_groupnorm_silu_fwd(const void* x, void* y, const float* gamma, const float* beta, float* stats,
+                                      void* workspace, int N, int HW, int C, int G, float eps, int act, int dtype,
+                                      void* stream) {
+    if (int rc = gn_check(x, y, N, HW, C, G, dtype)) return rc;
+    if (!gamma || !beta || !stats || !workspace) FMC_FAIL(FMC_E_NULL, "groupnorm_fwd: NULL gamma/beta/stats/workspace");
+    GnGeom g = gn_geom(HW, C);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(g.split, N), block(g.block);
+    size_t lds = (size_t)2 * g.rpi * C * sizeof(float);
+    float* part = (float*)workspace;
+    if (dtype == FMC_BF16) {
+        hipLaunchKernelGGL((gn_partial_kernel<bf16_t, 0>), grid, block, lds, st, (const bf16_t*)x, nullptr, gamma, beta,
+                           nullptr, part, HW, C, G, g.tpr, g.rpi, g.rows_per_split, act);
+        hipLaunchKernelGGL((gn_apply_fwd_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)x, (bf16_t*)y, gamma, beta,
+                           part, stats, HW, C, G, g.tpr, g.rpi, g.rows_per_split, eps, act);
+    } else {
+        hipLaunchKernelGGL((gn_partial_kernel<float, 0>), grid, block, lds, st, (const float*)x, nullptr, gamma, beta,
+                           nullptr, part, HW, C, G, g.tpr, g.rpi, g.rows_per_split, act);
+        hipLaunchKernelGGL((gn_apply_fwd_kernel<float>), grid, block, 0, st, (const float*)x, (float*)y, gamma, beta,
+                           part, stats, HW, C, G, g.tpr, g.rpi, g.rows_per_split, eps, act);
+    }
+    FMC_CHECK_LAUNCH("fmc_groupnorm_silu_fwd");
+    return 0;
+}
+
+extern "C" int fmc_groupnorm_silu_bwd(const void* dy, const void* x, void* dx, const float* gamma, const float* beta,
+                                      const float* stats, void* workspace, int N, int HW, int C, int G, int act,
+                                      int dtype, void* stream) {
+    if (int rc = gn_check(x, dx, N, HW, C, G, dtype)) return rc;
+    if (!dy || !gamma || !beta || !stats || !workspace) FMC_FAIL(FMC_E_NULL, "groupnorm_bwd: NULL argument");
+    if (!fmc_aligned16(dy)) FMC_FAIL(FMC_E_ALIGN, "groupnorm_bwd: dy must be 16-byte aligned");
+    GnGeom g = gn_geom(HW, C);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(g.split, N), block(g.block);
+    size_t lds = (size_t)2 * g.rpi * C * sizeof(float);
+    float* part = (float*)workspace;
+    if (dtype == FMC_BF16) {
+        hipLaunchKernelGGL((gn_partial_kernel<bf16_t, 1>), grid, block, lds, st, (const bf16_t*)x, (const bf16_t*)dy,
+                           gamma, beta, stats, part, HW, C, G, g.tpr, g.rpi, g.rows_per_split, act);
+        hipLaunchKernelGGL((gn_apply_bwd_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)x,
+                           (bf16_t*)dx, gamma, beta, stats, part, HW, C, G, g.tpr, g.rpi, g.rows_per_split, act);
+    } else {
+        hipLaunchKernelGGL((gn_partial_kernel<float, 1>), grid, block, lds, st, (const float*)x, (const float*)dy, gamma,
+                           beta, stats, part, HW, C, G, g.tpr, g.rpi, g.rows_per_split, act);
+        hipLaunchKernelGGL((gn_apply_bwd_kernel<float>), grid, block, 0, st, (const float*)dy, (const float*)x,
+                           (float*)dx, gamma, beta, stats, part, HW, C, G, g.tpr, g.rpi, g.rows_per_split, act);
+    }
+    FMC_CHECK_LAUNCH("fmc_groupnorm_silu_bwd");
+    return 0;
+}
+
+template <typename T>
+static void launch_ln(const void* x, void* y, const float* gamma, const float* beta, const float* pe, int64_t M, int C,
+                      float eps, int pe_inner, int pe_frames, hipStream_t st) {
+    const int nch = (C / 8 + 63) / 64;
+    const int wpb = 4;
+    int64_t blocks = (M + wpb - 1) / wpb;
+    if (blocks > 8192) blocks = 8192;
+    dim3 grid((unsigned)blocks), block(64 * wpb);
+#define LN_CASE(K)                                                                                                  \
+    case K:                                                                                                         \
+        hipLaunchKernelGGL((layernorm_kernel<T, K>), grid, block, 0, st, (const T*)x, (T*)y, gamma, beta, pe, M, C, \
+                           eps, pe_inner, pe_frames);                                                               \
+        break;
+    switch (nch) {
+        LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5)
+        default: break;
+    }
+#undef LN_CASE
+}
+
+extern "C" int fmc_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, const float* pe,
+                                 int64_t M, int C, float eps, int pe_inner, int pe_frames, int dtype, void* stream) {
+    if (!x || !y || !gamma || !beta) FMC_FAIL(FMC_E_NULL, "layernorm: NULL argument");
+    if (M <= 0 || C <= 0 || C % 8 || C > 8 * 64 * 5) FMC_FAIL(FMC_E_SHAPE, "layernorm: need C%%8==0 and C<=2560 (C=%d)", C);
+    if (pe && (pe_inner <= 0 || pe_frames <= 0)) FMC_FAIL(FMC_E_SHAPE, "layernorm: pe_inner/pe_frames must be > 0");
+    if (!fmc_aligned16(x) || !fmc_aligned16(y)) FMC_FAIL(FMC_E_ALIGN, "layernorm: tensors must be 16-byte aligned");
+    if (!pe) { pe_inner = 1; pe_frames = 1; }
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == FMC_BF16) launch_ln<bf16_t>(x, y, gamma, beta, pe, M, C, eps, pe_inner, pe_frames, st);
+    else if (dtype == FMC_F32) launch_ln<float>(x, y, gamma, beta, pe, M, C, eps, pe_inner, pe_frames, st);
+    else FMC_FAIL(FMC_E_DTYPE, "layernorm: dtype %d", dtype);
+    FMC_CHECK_LAUNCH("fmc_layernorm_fwd");
+    return 0;
+}
+
+extern "C" int fmc_geglu_fwd(const void* x, void* y, int64_t M, int Cff, int dtype, void* stream) {
+    if (!x || !y) FMC_FAIL(FMC_E_NULL, "geglu: NULL argument");
+    if (M <= 0 || Cff <= 0 || Cff % 8) FMC_FAIL(FMC_E_SHAPE, "geglu: need Cff%%8==0 (Cff=%d)", Cff);
+    if (!fmc_aligned16(x) || !fmc_aligned16(y)) FMC_FAIL(FMC_E_ALIGN, "geglu: tensors must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    int64_t total = M * (Cff / 8);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    dim3 grid((unsigned)blocks), block(256);
+    if (dtype == FMC_BF16) hipLaunchKernelGGL((geglu_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)x, (bf16_t*)y, M, Cff);
+    else if (dtype == FMC_F32) hipLaunchKernelGGL((geglu_kernel<float>), grid, block, 0, st, (const float*)x, (float*)y, M, Cff);
+    else FMC_FAIL(FMC_E_DTYPE, "geglu: dtype %d", dtype);
+    FMC_CHECK_LAUNCH("fmc_geglu_fwd");
+    return 0;
+}

@@ -1,0 +1,348 @@
+// Spatial (per-frame) attention for gfx950: flash-style softmax(Q K^T * scale) V on the bf16 MFMA pipe.
+//
+// Replaces head_to_batch_dim + baddbmm + softmax + bmm + batch_to_head_dim of
+// fmc/models/attention_processor.py:61-67 / :148-154 (attn1: self, attn2: text cross, S_kv = 77).
+//
+// Design (CDNA4, wave = 64):
+//   * one workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 rows;
+//   * K/V tiles of 64 keys are staged in LDS: K row-major [64][D+pad] (read as MFMA A operand with
+//     ds_read_b128, pitch chosen bank-conflict free), V transposed [D][64+pad] (read as A operand of
+//     the PV product with two ds_read_b64);
+//   * "swapped" products:  S^T = K Q^T  and  O^T = V^T P^T  with v_mfma_f32_32x32x16_bf16, so a lane
+//     holds 16 scores of ONE query column -> the online softmax is lane-local plus one
+//     cross-half shuffle, and the rescale of O^T is a per-lane scalar;
+//   * the P^T B-operand is taken straight from the S^T accumulator registers: the key order inside
+//     a 16-wide K step is a fixed permutation, and the V^T fragment is read with the same permutation;
+//   * head dims 40 / 80 / 160 (any multiple of 8 up to 160): the QK^T reduction dim is padded to a
+//     multiple of 16 (48/80/160), the PV output dim to a multiple of 32 (64/96/160);
+//   * blockIdx -> (batch*head, q-block) is XCD aware: all q-blocks of one (batch, head) run on the
+//     same XCD so its K/V (<= 400 KB) is served from that XCD's L2;
+//   * FMC_F32 storage runs every product as split-bf16 x3 (hi*hi + hi*lo + lo*hi), fp32 accumulate:
+//     the parity mode (agrees with an fp32 reference to ~1e-5), 3x the MFMA work.
+//
+// Roofline: MFMA bound.  Algorithmic flops per launch = 4 * B*H * Sq*Skv * D.
+#include "common.h"
+
+namespace {
+
+constexpr int SA_WAVES = 4;
+constexpr int SA_BQ = 32 * SA_WAVES;  // query rows per workgroup
+constexpr int SA_BK = 64;             // keys per LDS tile
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct SAParams {
+    const void* q; const void* k; const void* v; void* o; float* lse;
+    int B, H, Sq, Skv, D;
+    int64_t qbs, qrs, kbs, krs, obs, ors;
+    int kv_batch_div;
+    float scale_log2;
+    int nqblk;
+    int xcd_remap;
+};
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { bf16x8 hi; };
+template <> struct Frag<float> { bf16x8 hi, lo; };
+
+__device__ __forceinline__ bf16x8 zero_frag() {
+    union { bf16x8 v; u32x4 u; } z;
+    z.u = u32x4{0u, 0u, 0u, 0u};
+    return z.v;
+}
+
+// 8 consecutive elements (global or LDS) -> MFMA fragment(s)
+template <typename T> __device__ __forceinline__ void make_frag(const T* p, Frag<T>& f);
+template <> __device__ __forceinline__ void make_frag<bf16_t>(const bf16_t* p, Frag<bf16_t>& f) {
+    union { bf16x8 v; u32x4 u; } r;
+    r.u = *reinterpret_cast<const u32x4*>(p);
+    f.hi = r.v;
+}
+template <> __device__ __forceinline__ void make_frag<float>(const float* p, Frag<float>& f) {
+    float v[8];
+    Vec8<float>::load(p, v);
+    split_bf16x8(v, f.hi, f.lo);
+}
+// two runs of 4 consecutive elements -> fragment
+template <typename T> __device__ __forceinline__ void make_frag_2x4(const T* p0, const T* p1, Frag<T>& f);
+template <> __device__ __forceinline__ void make_frag_2x4<bf16_t>(const bf16_t* p0, const bf16_t* p1, Frag<bf16_t>& f) {
+    union { bf16x8 v; u32x2 u[2]; } r;
+    r.u[0] = *reinterpret_cast<const u32x2*>(p0);
+    r.u[1] = *reinterpret_cast<const u32x2*>(p1);
+    f.hi = r.v;
+}
+template <> __device__ __forceinline__ void make_frag_2x4<float>(const float* p0, const float* p1, Frag<float>& f) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p0);
+    f32x4 b = *reinterpret_cast<const f32x4*>(p1);
+    float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    split_bf16x8(v, f.hi, f.lo);
+}
+template <typename T> __device__ __forceinline__ void zero(Frag<T>& f);
+template <> __device__ __forceinline__ void zero<bf16_t>(Frag<bf16_t>& f) { f.hi = zero_frag(); }
+template <> __device__ __forceinline__ void zero<float>(Frag<float>& f) { f.hi = zero_frag(); f.lo = zero_frag(); }
+
+// acc += A * B  (bf16: one MFMA; fp32 storage: hi*hi + hi*lo + lo*hi)
+__device__ __forceinline__ void mma32(const Frag<bf16_t>& a, const Frag<bf16_t>& b, f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma32(const Frag<float>& a, const Frag<float>& b, f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, acc, 0, 0, 0);
+}
+
+// 8 probabilities (fp32) -> P^T fragment(s)
+__device__ __forceinline__ void p_frag(const float (&p)[8], Frag<bf16_t>& f) {
+    union { bf16x8 v; unsigned u[4]; } r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.u[i] = pack_bf2(p[2 * i], p[2 * i + 1]);
+    f.hi = r.v;
+}
+__device__ __forceinline__ void p_frag(const float (&p)[8], Frag<float>& f) { split_bf16x8(p, f.hi, f.lo); }
+
+template <typename T> __device__ __forceinline__ void store4(T* p, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+    *reinterpret_cast<u32x2*>(p) = u32x2{pack_bf2(a, b), pack_bf2(c, d)};
+}
+template <> __device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{a, b, c, d};
+}
+
+// NKS: number of 16-wide k-steps of the QK^T reduction (D padded to 16*NKS); NDT = ceil(NKS/2)
+// SHORT_KV only separates the text cross-attention launches (S_kv = 77) from the self-attention ones in profiles
+// (same code path): the two differ by >10x in work per launch and would blur a per-kernel-name average.
+template <typename T, int NKS, bool SHORT_KV>
+__global__ __launch_bounds__(64 * SA_WAVES) void spatial_attn_kernel(const SAParams P) {
+    constexpr int NDT = (NKS + 1) / 2;
+    constexpr int DP16 = NKS * 16;
+    constexpr int KP = DP16 + 8;        // K tile pitch (elements)
+    constexpr int VP = SA_BK + 4;       // V^T tile pitch (elements)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* Ks = reinterpret_cast<T*>(smem_raw);              // [SA_BK][KP]
+    T* Vt = Ks + SA_BK * KP;                             // [NDT*32][VP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int D = P.D, CH = D / 8;
+
+    // ---- block -> (bh, q-block), XCD aware -----------------------------------------------------
+    int bh, qblk;
+    {
+        const int id = blockIdx.x;
+        if (P.xcd_remap) {
+            const int xcd = id & 7, within = id >> 3;
+            bh = (within / P.nqblk) * 8 + xcd;
+            qblk = within % P.nqblk;
+        } else {
+            bh = id / P.nqblk;
+            qblk = id % P.nqblk;
+        }
+    }
+    const int b = bh / P.H, h = bh - b * P.H;
+    const T* qg = (const T*)P.q + (int64_t)b * P.qbs + (int64_t)h * D;
+    const T* kg = (const T*)P.k + (int64_t)(b / P.kv_batch_div) * P.kbs + (int64_t)h * D;
+    const T* vg = (const T*)P.v + (int64_t)(b / P.kv_batch_div) * P.kbs + (int64_t)h * D;
+    T* og = (T*)P.o + (int64_t)b * P.obs + (int64_t)h * D;
+
+    // ---- Q^T fragments (B operand of S^T = K Q^T), kept in registers -----------------------------
+    const int qrow = qblk * SA_BQ + wave * 32 + l31;
+    Frag<T> qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int d0 = ks * 16 + half * 8;
+        if (qrow < P.Sq && d0 < D) make_frag<T>(qg + (int64_t)qrow * P.qrs + d0, qf[ks]);
+        else zero(qf[ks]);
+    }
+
+    // zero the K pad columns once (d in [D, DP16)): 0 * garbage must stay 0
+    if (DP16 > D) {
+        for (int r = tid; r < SA_BK; r += blockDim.x) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) Ks[r * KP + D + i] = T(0);
+        }
+    }
+
+    f32x16 oacc[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (P.Skv + SA_BK - 1) / SA_BK;
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int kv0 = tile * SA_BK;
+        __syncthreads();  // previous tile fully consumed
+        // ---- stage K (row-major) and V (transposed) --------------------------------------------
+        for (int c = tid; c < SA_BK * CH; c += blockDim.x) {
+            const int row = c / CH, ch = c - row * CH;
+            const int kv = kv0 + row;
+            float kvals[8], vvals[8];
+            if (kv < P.Skv) {
+                Vec8<T>::load(kg + (int64_t)kv * P.krs + ch * 8, kvals);
+                Vec8<T>::load(vg + (int64_t)kv * P.krs + ch * 8, vvals);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) kvals[i] = vvals[i] = 0.f;
+            }
+            Vec8<T>::store(Ks + row * KP + ch * 8, kvals);
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) Vt[(ch * 8 + i) * VP + row] = f2bf(vvals[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) Vt[(ch * 8 + i) * VP + row] = vvals[i];
+            }
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int sb = 0; sb < SA_BK / 32; ++sb) {
+            const int kvb = kv0 + sb * 32;
+            if (kvb >= P.Skv) break;  // block-uniform
+            // ---- S^T[32 keys x 32 queries] ---------------------------------------------------------
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                Frag<T> kf;
+                make_frag<T>(Ks + (sb * 32 + l31) * KP + ks * 16 + half * 8, kf);
+                mma32(kf, qf[ks], s);
+            }
+            // ---- online softmax over the key axis (lane-local + the other half-wave) ----------------
+            float mx = -INFINITY;
+            const bool tail = (kvb + 32 > P.Skv);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float x = s[r] * P.scale_log2;
+                if (tail) {
+                    const int kv = kvb + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (kv >= P.Skv) x = -INFINITY;
+                }
+                s[r] = x;
+                mx = fmaxf(mx, x);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);  // finite: the first block always holds key 0
+            const float alpha = exp2f(m_run - m_new);
+            float psum = 0.f;
+            float p[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                p[r] = exp2f(s[r] - m_new);
+                psum += p[r];
+            }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+            // ---- O^T += V^T P^T ------------------------------------------------------------------------
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float p8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) p8[i] = p[s2 * 8 + i];
+                Frag<T> pf;
+                p_frag(p8, pf);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    const T* vrow = Vt + (dt * 32 + l31) * VP + sb * 32 + s2 * 16 + half * 4;
+                    Frag<T> vf;
+                    make_frag_2x4<T>(vrow, vrow + 8, vf);
+                    mma32(vf, pf, oacc[dt]);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------------------
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+    if (qrow < P.Sq) {
+        T* orow = og + (int64_t)qrow * P.ors;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = dt * 32 + 8 * g + 4 * half;
+                if (d < D)
+                    store4<T>(orow + d, oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv, oacc[dt][4 * g + 2] * inv,
+                              oacc[dt][4 * g + 3] * inv);
+            }
+        }
+        if (P.lse && half == 0)
+            P.lse[((int64_t)b * P.H + h) * P.Sq + qrow] = m_run * 0.6931471805599453f + logf(l_tot);
+    }
+}
+
+template <typename T, int NKS, bool SHORT_KV>
+void launch_sa_v(const SAParams& P, hipStream_t st) {
+    constexpr int NDT = (NKS + 1) / 2;
+    const size_t lds = sizeof(T) * ((size_t)SA_BK * (NKS * 16 + 8) + (size_t)NDT * 32 * (SA_BK + 4));
+    dim3 grid((unsigned)(P.B * P.H * P.nqblk)), block(64 * SA_WAVES);
+    if (lds > 64 * 1024) {  // gfx950 has 160 KiB of LDS per CU; opting in is needed above 64 KiB
+        static bool raised = false;
+        if (!raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_attn_kernel<T, NKS, SHORT_KV>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL((spatial_attn_kernel<T, NKS, SHORT_KV>), grid, block, lds, st, P);
+}
+
+template <typename T, int NKS>
+void launch_sa(const SAParams& P, hipStream_t st) {
+    if (P.Skv <= 2 * SA_BK) launch_sa_v<T, NKS, true>(P, st);
+    else launch_sa_v<T, NKS, false>(P, st);
+}
+
+template <typename T>
+int dispatch_sa(const SAParams& P, hipStream_t st) {
+    switch ((P.D + 15) / 16) {
+        case 1: launch_sa<T, 1>(P, st); break;
+        case 2: launch_sa<T, 2>(P, st); break;
+        case 3: launch_sa<T, 3>(P, st); break;
+        case 4: launch_sa<T, 4>(P, st); break;
+        case 5: launch_sa<T, 5>(P, st); break;
+        case 6: launch_sa<T, 6>(P, st); break;
+        case 8: launch_sa<T, 8>(P, st); break;
+        case 10: launch_sa<T, 10>(P, st); break;
+        default: FMC_FAIL(FMC_E_SHAPE, "spatial_attn: head dim %d not built (supported: <=96, 113..128, 145..160)", P.D);
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int fmc_spatial_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H,
+                                    int Sq, int Skv, int D, int64_t q_batch_stride, int64_t q_row_stride,
+                                    int64_t kv_batch_stride, int64_t kv_row_stride, int64_t o_batch_stride,
+                                    int64_t o_row_stride, int kv_batch_div, float scale, int dtype, void* stream) {
+    if (!q || !k || !v || !o) FMC_FAIL(FMC_E_NULL, "spatial_attn: NULL tensor");
+    if (dtype != FMC_BF16 && dtype != FMC_F32) FMC_FAIL(FMC_E_DTYPE, "spatial_attn: dtype %d", dtype);
+    if (B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0 || D <= 0 || D % 8 || D > 160 || kv_batch_div <= 0)
+        FMC_FAIL(FMC_E_SHAPE, "spatial_attn: need D%%8==0, D<=160, positive sizes (B=%d H=%d Sq=%d Skv=%d D=%d)", B, H, Sq,
+                 Skv, D);
+    const int64_t strides[] = {q_batch_stride, q_row_stride, kv_batch_stride, kv_row_stride, o_batch_stride, o_row_stride};
+    for (int64_t s : strides)
+        if (s % 8) FMC_FAIL(FMC_E_ALIGN, "spatial_attn: strides must be multiples of 8 elements");
+    if (!fmc_aligned16(q) || !fmc_aligned16(k) || !fmc_aligned16(v) || !fmc_aligned16(o))
+        FMC_FAIL(FMC_E_ALIGN, "spatial_attn: tensors must be 16-byte aligned");
+    SAParams P;
+    P.q = q; P.k = k; P.v = v; P.o = o; P.lse = lse;
+    P.B = B; P.H = H; P.Sq = Sq; P.Skv = Skv; P.D = D;
+    P.qbs = q_batch_stride; P.qrs = q_row_stride; P.kbs = kv_batch_stride; P.krs = kv_row_stride;
+    P.obs = o_batch_stride; P.ors = o_row_stride;
+    P.kv_batch_div = kv_batch_div;
+    P.scale_log2 = scale * LOG2E;
+    P.nqblk = (Sq + SA_BQ - 1) / SA_BQ;
+    P.xcd_remap = ((B * H) % 8 == 0) ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = (dtype == FMC_BF16) ? dispatch_sa<bf16_t>(P, st) : dispatch_sa<float>(P, st);
+    if (rc) return rc;
+    FMC_CHECK_LAUNCH("fmc_spatial_attn_fwd");
+    return 0;
+}

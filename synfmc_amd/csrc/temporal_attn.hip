@@ -1,0 +1,282 @@
+// Temporal attention for gfx950: per (pixel, head) softmax(Q K^T * scale) V over F in {16, 32} frames.
+//
+// Replaces head_to_batch_dim + baddbmm + softmax + bmm + batch_to_head_dim of
+// fmc/models/attention_processor.py:271-281 (PoseAdaptorAttnProcessor) and :61-67 (AttnProcessor)
+// when reached from the motion modules / camera encoder (fmc/models/motion_module.py:365-389).
+//
+// This kernel is HBM bound (arithmetic intensity F/2 flop per byte): the design goal is to move
+// Q, K, V, O exactly once with full-line transactions and keep the MFMA work off the critical path.
+//   * work unit = (clip, pixel, head group); a head group is GH heads = CW <= 320 contiguous
+//     channels, so every frame row of a unit is one contiguous 640-byte run (bf16);
+//   * one wave (= one 64-thread workgroup) per unit: all 3*F rows are fetched with 16-byte loads,
+//     every one in flight before the first use, and staged in LDS [F][CW+8] (pitch is conflict free
+//     for the ds_read_b128 fragment reads);
+//   * strided addressing (clip / frame / pixel strides) lets the kernel read the channels-last
+//     activation `[(b f), hw, c]` in place: the reference's `b c f h w <-> (b h w) f c`
+//     transposes (fmc/models/motion_module.py:218,232) do not exist here;
+//   * per head: S^T = K Q^T with v_mfma_f32_16x16x32_bf16 (head dim padded to 32s), softmax over
+//     keys = 4 in-lane values + two cross-lane steps, P^T goes from the accumulator registers
+//     straight into v_mfma_f32_16x16x16_bf16 as the B operand of O^T = V^T P^T;
+//   * O is written back into the LDS slot of the Q rows it came from and leaves with the same
+//     coalesced 16-byte stores;
+//   * FMC_F32 storage = split-bf16 x3 products (parity mode), like the spatial kernel.
+//
+// Algorithmic bytes per launch = 4 * n_clips*n_pix*F*H*D * e; flops = 4 * n_clips*n_pix*H*F*F*D.
+#include "common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct TAParams {
+    const void* q; const void* k; const void* v; void* o;
+    int n_clips, n_pix, F, H, D, GH;
+    int64_t cs, fs, ps, ocs, ofs, ops;
+    float scale_log2;
+};
+
+template <typename T> struct F8;   // 8-wide fragment (QK^T operands)
+template <> struct F8<bf16_t> { bf16x8 hi; };
+template <> struct F8<float> { bf16x8 hi, lo; };
+template <typename T> struct F4;   // 4-wide fragment (PV operands)
+template <> struct F4<bf16_t> { s16x4 hi; };
+template <> struct F4<float> { s16x4 hi, lo; };
+
+__device__ __forceinline__ void load_f8(const bf16_t* p, bool valid, F8<bf16_t>& f) {
+    union { bf16x8 v; u32x4 u; } r;
+    r.u = valid ? *reinterpret_cast<const u32x4*>(p) : u32x4{0u, 0u, 0u, 0u};
+    f.hi = r.v;
+}
+__device__ __forceinline__ void load_f8(const float* p, bool valid, F8<float>& f) {
+    float v[8];
+    if (valid) Vec8<float>::load(p, v);
+    else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = 0.f;
+    }
+    split_bf16x8(v, f.hi, f.lo);
+}
+__device__ __forceinline__ void mma_qk(const F8<bf16_t>& a, const F8<bf16_t>& b, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.hi, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_qk(const F8<float>& a, const F8<float>& b, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, b.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.hi, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void make_f4(const float (&v)[4], F4<bf16_t>& f) {
+    f.hi = s16x4{(short)f2bf(v[0]), (short)f2bf(v[1]), (short)f2bf(v[2]), (short)f2bf(v[3])};
+}
+__device__ __forceinline__ void make_f4(const float (&v)[4], F4<float>& f) {
+    bf16_t h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { h[i] = f2bf(v[i]); l[i] = f2bf(v[i] - bf2f(h[i])); }
+    f.hi = s16x4{(short)h[0], (short)h[1], (short)h[2], (short)h[3]};
+    f.lo = s16x4{(short)l[0], (short)l[1], (short)l[2], (short)l[3]};
+}
+__device__ __forceinline__ void mma_pv(const F4<bf16_t>& a, const F4<bf16_t>& b, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.hi, b.hi, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_pv(const F4<float>& a, const F4<float>& b, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.lo, b.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.hi, b.lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.hi, b.hi, acc, 0, 0, 0);
+}
+__device__ __forceinline__ float ldsf(const bf16_t* p) { return bf2f(*p); }
+__device__ __forceinline__ float ldsf(const float* p) { return *p; }
+
+template <typename T> __device__ __forceinline__ void st4(T* p, const float (&v)[4]);
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float (&v)[4]) {
+    *reinterpret_cast<u32x2*>(p) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+}
+template <> __device__ __forceinline__ void st4<float>(float* p, const float (&v)[4]) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+}
+
+// FT = F/16 frame tiles; NK32 = ceil(D/32) k-steps of the QK^T reduction
+template <typename T, int FT, int NK32>
+__global__ __launch_bounds__(64) void temporal_attn_kernel(const TAParams P) {
+    constexpr int F = FT * 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int D = P.D, GH = P.GH, CW = GH * D, CPR = CW / 8, PITCH = CW + 8;
+    T* Qs = reinterpret_cast<T*>(smem_raw);  // [F][PITCH]; O overwrites it head by head
+    T* Ks = Qs + F * PITCH;
+    T* Vs = Ks + F * PITCH;
+    const int lane = threadIdx.x;
+    const int l15 = lane & 15, lg = lane >> 4;
+
+    // ---- unit decode ---------------------------------------------------------------------------
+    const int groups = P.H / GH;
+    int u = blockIdx.x;
+    const int hg = u % groups; u /= groups;
+    const int pix = u % P.n_pix;
+    const int clip = u / P.n_pix;
+    const int64_t in_off = (int64_t)clip * P.cs + (int64_t)pix * P.ps + (int64_t)hg * CW;
+    const int64_t out_off = (int64_t)clip * P.ocs + (int64_t)pix * P.ops + (int64_t)hg * CW;
+
+    // ---- stage Q, K, V: global -> LDS, 16 bytes per lane per load -------------------------------------
+    const int chunks = F * CPR;
+#pragma unroll 1
+    for (int which = 0; which < 3; ++which) {
+        const T* src = (const T*)(which == 0 ? P.q : (which == 1 ? P.k : P.v)) + in_off;
+        T* dst = which == 0 ? Qs : (which == 1 ? Ks : Vs);
+#pragma unroll 5
+        for (int c = lane; c < chunks; c += 64) {
+            const int f = c / CPR, ch = c - f * CPR;
+            float v[8];
+            Vec8<T>::load(src + (int64_t)f * P.fs + ch * 8, v);
+            Vec8<T>::store(dst + f * PITCH + ch * 8, v);
+        }
+    }
+    __syncthreads();
+
+    for (int hh = 0; hh < GH; ++hh) {
+        const int hc = hh * D;
+#pragma unroll
+        for (int qt = 0; qt < FT; ++qt) {
+            // ---- S^T = K Q^T for this query tile --------------------------------------------------------
+            F8<T> qf[NK32];
+#pragma unroll
+            for (int ks = 0; ks < NK32; ++ks) {
+                const int d0 = ks * 32 + lg * 8;
+                load_f8(Qs + (qt * 16 + l15) * PITCH + hc + d0, d0 < D, qf[ks]);
+            }
+            f32x4 s[FT];
+#pragma unroll
+            for (int kt = 0; kt < FT; ++kt) {
+                s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < NK32; ++ks) {
+                    const int d0 = ks * 32 + lg * 8;
+                    F8<T> kf;
+                    load_f8(Ks + (kt * 16 + l15) * PITCH + hc + d0, d0 < D, kf);
+                    mma_qk(kf, qf[ks], s[kt]);
+                }
+            }
+            // ---- softmax over keys: lane holds keys kt*16 + lg*4 + r of query qt*16 + l15 --------------------
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < FT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s[kt][r] *= P.scale_log2; mx = fmaxf(mx, s[kt][r]); }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < FT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s[kt][r] = exp2f(s[kt][r] - mx); sum += s[kt][r]; }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.f / sum;
+            F4<T> pf[FT];
+#pragma unroll
+            for (int kt = 0; kt < FT; ++kt) {
+                float p4[4] = {s[kt][0] * inv, s[kt][1] * inv, s[kt][2] * inv, s[kt][3] * inv};
+                make_f4(p4, pf[kt]);
+            }
+            // ---- O^T = V^T P^T, 16 output channels at a time; result replaces Q(qt, head) in LDS ---------
+            const int ndt = (D + 15) / 16;
+            for (int dt = 0; dt < ndt; ++dt) {
+                f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int dA = dt * 16 + l15;       // channel of this lane's V^T row
+#pragma unroll
+                for (int kt = 0; kt < FT; ++kt) {
+                    float v4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        v4[i] = dA < D ? ldsf(Vs + (kt * 16 + lg * 4 + i) * PITCH + hc + dA) : 0.f;
+                    F4<T> vf;
+                    make_f4(v4, vf);
+                    mma_pv(vf, pf[kt], o);
+                }
+                const int dO = dt * 16 + lg * 4;    // 4 consecutive output channels of query l15
+                if (dO < D) {
+                    float o4[4] = {o[0], o[1], o[2], o[3]};
+                    st4<T>(Qs + (qt * 16 + l15) * PITCH + hc + dO, o4);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- O: LDS -> global ------------------------------------------------------------------------------
+    T* og = (T*)P.o + out_off;
+#pragma unroll 5
+    for (int c = lane; c < chunks; c += 64) {
+        const int f = c / CPR, ch = c - f * CPR;
+        float v[8];
+        Vec8<T>::load(Qs + f * PITCH + ch * 8, v);
+        Vec8<T>::store(og + (int64_t)f * P.ofs + ch * 8, v);
+    }
+}
+
+template <typename T, int FT, int NK32>
+void launch_ta(const TAParams& P, hipStream_t st) {
+    const int CW = P.GH * P.D;
+    const size_t lds = sizeof(T) * 3 * (size_t)(FT * 16) * (CW + 8);
+    if (lds > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_attn_kernel<T, FT, NK32>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            raised = true;
+        }
+    }
+    dim3 grid((unsigned)((int64_t)P.n_clips * P.n_pix * (P.H / P.GH))), block(64);
+    hipLaunchKernelGGL((temporal_attn_kernel<T, FT, NK32>), grid, block, lds, st, P);
+}
+
+template <typename T, int FT>
+int dispatch_ta_k(const TAParams& P, hipStream_t st) {
+    switch ((P.D + 31) / 32) {
+        case 1: launch_ta<T, FT, 1>(P, st); break;
+        case 2: launch_ta<T, FT, 2>(P, st); break;
+        case 3: launch_ta<T, FT, 3>(P, st); break;
+        case 4: launch_ta<T, FT, 4>(P, st); break;
+        case 5: launch_ta<T, FT, 5>(P, st); break;
+        default: FMC_FAIL(FMC_E_SHAPE, "temporal_attn: head dim %d > 160", P.D);
+    }
+    return 0;
+}
+
+template <typename T>
+int dispatch_ta(const TAParams& P, hipStream_t st) {
+    if (P.F == 16) return dispatch_ta_k<T, 1>(P, st);
+    if (P.F == 32) return dispatch_ta_k<T, 2>(P, st);
+    FMC_FAIL(FMC_E_SHAPE, "temporal_attn: F must be 16 or 32 (got %d)", P.F);
+}
+
+}  // namespace
+
+extern "C" int fmc_temporal_attn_fwd(const void* q, const void* k, const void* v, void* o, int n_clips, int n_pix,
+                                     int F, int H, int D, int64_t clip_stride, int64_t frame_stride,
+                                     int64_t pix_stride, int64_t o_clip_stride, int64_t o_frame_stride,
+                                     int64_t o_pix_stride, float scale, int dtype, void* stream) {
+    if (!q || !k || !v || !o) FMC_FAIL(FMC_E_NULL, "temporal_attn: NULL tensor");
+    if (dtype != FMC_BF16 && dtype != FMC_F32) FMC_FAIL(FMC_E_DTYPE, "temporal_attn: dtype %d", dtype);
+    if (n_clips <= 0 || n_pix <= 0 || H <= 0 || D <= 0 || D % 8 || D > 160)
+        FMC_FAIL(FMC_E_SHAPE, "temporal_attn: need D%%8==0, D<=160, positive sizes (clips=%d pix=%d H=%d D=%d)", n_clips,
+                 n_pix, H, D);
+    const int64_t strides[] = {clip_stride, frame_stride, pix_stride, o_clip_stride, o_frame_stride, o_pix_stride};
+    for (int64_t s : strides)
+        if (s % 8) FMC_FAIL(FMC_E_ALIGN, "temporal_attn: strides must be multiples of 8 elements");
+    if (!fmc_aligned16(q) || !fmc_aligned16(k) || !fmc_aligned16(v) || !fmc_aligned16(o))
+        FMC_FAIL(FMC_E_ALIGN, "temporal_attn: tensors must be 16-byte aligned");
+    TAParams P;
+    P.q = q; P.k = k; P.v = v; P.o = o;
+    P.n_clips = n_clips; P.n_pix = n_pix; P.F = F; P.H = H; P.D = D;
+    // head group: the largest divisor GH of H with GH*D <= 320 channels (one 640-byte bf16 run per frame row)
+    int gh = 1;
+    for (int g = 1; g <= H; ++g)
+        if (H % g == 0 && g * D <= 320) gh = g;
+    P.GH = gh;
+    P.cs = clip_stride; P.fs = frame_stride; P.ps = pix_stride;
+    P.ocs = o_clip_stride; P.ofs = o_frame_stride; P.ops = o_pix_stride;
+    P.scale_log2 = scale * LOG2E;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = (dtype == FMC_BF16) ? dispatch_ta<bf16_t>(P, st) : dispatch_ta<float>(P, st);
+    if (rc) return rc;
+    FMC_CHECK_LAUNCH("fmc_temporal_attn_fwd");
+    return 0;
+}

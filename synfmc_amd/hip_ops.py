@@ -1,0 +1,311 @@
+"""Tensor-level entry points of the hand-written gfx950 kernels (through the C ABI).
+
+PyTorch is plumbing here: it owns device memory and the stream; every function below hands raw
+device pointers + sizes + the current `hipStream_t` to `libfmc_hip.so`.  No CPU / eager fallback:
+CPU tensors raise.
+
+Layout: activations are channels-last.  `[N, S, C]` "tokens" are what the kernels see; a
+`b c f h w` video in `torch.channels_last_3d` memory format *is* `[(b f), (h w), c]` tokens.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import FMC_BF16, FMC_F32
+
+_DT = {torch.bfloat16: FMC_BF16, torch.float32: FMC_F32}
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"fmc kernels take bf16 or fp32 activations, got {t.dtype}") from None
+
+
+def _dev(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("fmc HIP kernels need device (cuda/hip) tensors; there is no CPU fallback")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+_ws_cache = {}
+
+
+def _workspace(device, nbytes: int) -> torch.Tensor:
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(max(nbytes // 4 + 1, 1 << 16), dtype=torch.float32, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+# --------------------------------------------------------------------------------------------
+# GroupNorm (+SiLU)
+# --------------------------------------------------------------------------------------------
+def groupnorm_silu_raw(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,
+                       act: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+    """x `[N, S, C]` contiguous -> (y, stats `[N, G, 2]`)."""
+    _dev(x, gamma, beta)
+    assert x.ndim == 3 and x.is_contiguous(), "groupnorm: x must be contiguous [N, S, C] tokens"
+    N, S, C = x.shape
+    lib = _lib.load()
+    y = torch.empty_like(x)
+    stats = torch.empty(N, groups, 2, dtype=torch.float32, device=x.device)
+    ws = _workspace(x.device, lib.fmc_groupnorm_workspace_bytes(N, C, groups))
+    _lib.check(lib.fmc_groupnorm_silu_fwd(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                          stats.data_ptr(), ws.data_ptr(), N, S, C, groups, float(eps), int(act),
+                                          _dt(x), _stream()), "fmc_groupnorm_silu_fwd")
+    return y, stats
+
+
+class _GroupNormSiLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, act):
+        y, stats = groupnorm_silu_raw(x, gamma, beta, groups, eps, act)
+        ctx.save_for_backward(x, gamma, beta, stats)
+        ctx.groups, ctx.act = groups, act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, stats = ctx.saved_tensors
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise NotImplementedError("fmc_groupnorm_silu_bwd computes dX only (gamma/beta are frozen on the FMC path)")
+        dy = dy.contiguous()
+        N, S, C = x.shape
+        lib = _lib.load()
+        dx = torch.empty_like(x)
+        ws = _workspace(x.device, lib.fmc_groupnorm_workspace_bytes(N, C, ctx.groups))
+        _lib.check(lib.fmc_groupnorm_silu_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), gamma.data_ptr(),
+                                              beta.data_ptr(), stats.data_ptr(), ws.data_ptr(), N, S, C, ctx.groups,
+                                              int(ctx.act), _dt(x), _stream()), "fmc_groupnorm_silu_bwd")
+        return dx, None, None, None, None, None
+
+
+def groupnorm_silu(x, gamma, beta, groups: int, eps: float, act: bool) -> torch.Tensor:
+    """GroupNorm over `[N, S, C]` tokens (statistics per sample and group over S x C/G) + optional SiLU.
+    gamma/beta: fp32 `[C]`."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _GroupNormSiLU.apply(x, gamma, beta, groups, eps, act)
+    return groupnorm_silu_raw(x, gamma, beta, groups, eps, act)[0]
+
+
+# --------------------------------------------------------------------------------------------
+# LayerNorm (+ positional encoding), GEGLU
+# --------------------------------------------------------------------------------------------
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
+              pe: Optional[torch.Tensor] = None, pe_inner: int = 1, pe_frames: int = 1) -> torch.Tensor:
+    """LayerNorm over the last dim of contiguous tokens; optionally adds `pe[(row // pe_inner) % pe_frames]`
+    (fp32 `[>=pe_frames, C]`) after normalising."""
+    _dev(x, gamma, beta, pe)
+    assert x.is_contiguous()
+    C = x.shape[-1]
+    M = x.numel() // C
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().fmc_layernorm_fwd(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(pe), M,
+                                             C, float(eps), int(pe_inner), int(pe_frames), _dt(x), _stream()),
+               "fmc_layernorm_fwd")
+    return y
+
+
+def geglu(x: torch.Tensor) -> torch.Tensor:
+    """`a * gelu_erf(g)` with `a, g = x.chunk(2, -1)`; x contiguous `[..., 2*Cff]`."""
+    _dev(x)
+    assert x.is_contiguous()
+    cff = x.shape[-1] // 2
+    M = x.numel() // (2 * cff)
+    y = torch.empty(*x.shape[:-1], cff, dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().fmc_geglu_fwd(x.data_ptr(), y.data_ptr(), M, cff, _dt(x), _stream()), "fmc_geglu_fwd")
+    return y
+
+
+# --------------------------------------------------------------------------------------------
+# attention
+# --------------------------------------------------------------------------------------------
+def _rows(t: torch.Tensor) -> Tuple[int, int]:
+    """(batch stride, row stride) in elements of a `[B, S, C]` view whose last dim is dense."""
+    assert t.ndim == 3 and t.stride(2) == 1, "attention operands must be [B, S, C] with a dense channel dim"
+    return t.stride(0), t.stride(1)
+
+
+def spatial_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: Optional[float] = None,
+                      return_lse: bool = False):
+    """softmax(Q K^T * scale) V per (batch, head).  q `[B, Sq, H*D]`, k/v `[Bkv, Skv, H*D]` (strided views of a
+    fused projection are fine; B must be a multiple of Bkv: batch b reads kv batch b // (B // Bkv))."""
+    _dev(q, k, v)
+    B, Sq, C = q.shape
+    Bkv, Skv, _ = k.shape
+    assert C % heads == 0 and k.shape == v.shape and k.shape[2] == C and B % Bkv == 0
+    assert k.stride() == v.stride(), "k and v must share strides (slices of one fused projection)"
+    D = C // heads
+    scale = D ** -0.5 if scale is None else scale
+    o = torch.empty(B, Sq, C, dtype=q.dtype, device=q.device)
+    lse = torch.empty(B, heads, Sq, dtype=torch.float32, device=q.device) if return_lse else None
+    qb, qr = _rows(q)
+    kb, kr = _rows(k)
+    _lib.check(_lib.load().fmc_spatial_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), _p(lse), B,
+                                                heads, Sq, Skv, D, qb, qr, kb, kr, Sq * C, C, B // Bkv, float(scale),
+                                                _dt(q), _stream()), "fmc_spatial_attn_fwd")
+    return (o, lse) if return_lse else o
+
+
+def temporal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
+                       scale: Optional[float] = None) -> torch.Tensor:
+    """Attention over the frame axis.  Accepts the native layout `[B, F, P, C]` (frames outer, pixels inner: the
+    channels-last video) or the reference layout `[N, F, C]` (`(b h w) f c`).  q/k/v may be strided slices of a
+    fused QKV tensor (same strides for all three).  Returns a contiguous tensor of q's shape."""
+    _dev(q, k, v)
+    assert q.shape == k.shape == v.shape and q.stride() == k.stride() == v.stride() and q.stride(-1) == 1
+    C = q.shape[-1]
+    D = C // heads
+    scale = D ** -0.5 if scale is None else scale
+    o = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+    if q.ndim == 4:
+        B, F, P, _ = q.shape
+        cs, fs, ps = q.stride(0), q.stride(1), q.stride(2)
+        ocs, ofs, ops = o.stride(0), o.stride(1), o.stride(2)
+    elif q.ndim == 3:
+        P, F, _ = q.shape
+        B = 1
+        cs, fs, ps = 0, q.stride(1), q.stride(0)
+        ocs, ofs, ops = 0, o.stride(1), o.stride(0)
+    else:
+        raise ValueError("temporal_attention expects [B, F, P, C] or [N, F, C]")
+    _lib.check(_lib.load().fmc_temporal_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), B, P, F, heads,
+                                                 D, cs, fs, ps, ocs, ofs, ops, float(scale), _dt(q), _stream()),
+               "fmc_temporal_attn_fwd")
+    return o
+
+
+# --------------------------------------------------------------------------------------------
+# conditioning
+# --------------------------------------------------------------------------------------------
+def plucker(K: torch.Tensor, c2w: torch.Tensor, H: int, W: int, layout: str = "bfhwc",
+            dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """Pluecker embedding on device.  K `[B, F, 4]`, c2w `[B, F, 3|4, 4]` (fp32).
+    layout "bfhwc": `[B,F,H,W,6]` (= ray_condition); "bcfhw": `[B,6,F,H,W]`;
+    "unshuffle8": `[B*F, H/8, W/8, 384]` channels-last with PixelUnshuffle(8) applied."""
+    _dev(K, c2w)
+    B, F = K.shape[:2]
+    K = K.to(torch.float32).contiguous()
+    c2w = c2w.to(torch.float32).contiguous()
+    rows = c2w.shape[2]
+    code = {"bfhwc": 0, "bcfhw": 1, "unshuffle8": 2}[layout]
+    shape = {0: (B, F, H, W, 6), 1: (B, 6, F, H, W), 2: (B * F, H // 8, W // 8, 384)}[code]
+    out = torch.empty(shape, dtype=dtype, device=K.device)
+    _lib.check(_lib.load().fmc_plucker_fwd(K.data_ptr(), c2w.data_ptr(), out.data_ptr(), B, F, H, W, rows, code,
+                                           _dt(out), _stream()), "fmc_plucker_fwd")
+    return out
+
+
+def omc_rasterize(poses: torch.Tensor, masks: torch.Tensor, layout: str = "planar",
+                  dtype: torch.dtype = torch.float32) -> Tuple[torch.Tensor, torch.Tensor]:
+    """poses `[BF, n_obj, 12]`, masks `[BF, n_obj, H, W]` (fp32) -> (features, mask).
+    "planar": features `[BF,13,H,W]`, mask `[BF,1,H,W]`; "unshuffle8": features `[BF,H/8,W/8,832]`, mask `[BF,H,W]`."""
+    _dev(poses, masks)
+    BF, n_obj, H, W = masks.shape
+    poses = poses.to(torch.float32).contiguous()
+    masks = masks.to(torch.float32).contiguous()
+    code = {"planar": 0, "unshuffle8": 2}[layout]
+    feat = torch.empty((BF, 13, H, W) if code == 0 else (BF, H // 8, W // 8, 832), dtype=dtype, device=masks.device)
+    mout = torch.empty((BF, 1, H, W) if code == 0 else (BF, H, W), dtype=torch.float32, device=masks.device)
+    _lib.check(_lib.load().fmc_omc_rasterize_fwd(poses.data_ptr(), masks.data_ptr(), feat.data_ptr(), mout.data_ptr(),
+                                                 BF, n_obj, H, W, code, _dt(feat), _stream()), "fmc_omc_rasterize_fwd")
+    return feat, mout
+
+
+def _mask_modulate_raw(x, mask_in, h, w, want_mask):
+    N, S, C = x.shape
+    y = torch.empty_like(x)
+    mo = torch.empty(N, h, w, dtype=torch.float32, device=x.device) if want_mask else None
+    _lib.check(_lib.load().fmc_mask_modulate_fwd(x.data_ptr(), mask_in.data_ptr(), y.data_ptr(), _p(mo), N, h, w, C,
+                                                 mask_in.shape[1], mask_in.shape[2], _dt(x), _stream()),
+               "fmc_mask_modulate_fwd")
+    return y, mo
+
+
+class _MaskModulate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mask_in, h, w):
+        y, mo = _mask_modulate_raw(x, mask_in, h, w, True)
+        ctx.save_for_backward(mask_in)
+        ctx.hw = (h, w)
+        ctx.mark_non_differentiable(mo)
+        return y, mo
+
+    @staticmethod
+    def backward(ctx, dy, _dmo):
+        (mask_in,) = ctx.saved_tensors
+        dx, _ = _mask_modulate_raw(dy.contiguous(), mask_in, ctx.hw[0], ctx.hw[1], False)
+        return dx, None, None, None
+
+
+def mask_modulate(x: torch.Tensor, mask_in: torch.Tensor, h: int, w: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """`x * nearest(mask_in -> h x w)`; x `[N, h*w, C]` tokens, mask_in `[N, Hin, Win]` fp32.
+    Returns (y, resampled mask `[N, h, w]`)."""
+    _dev(x, mask_in)
+    assert x.is_contiguous() and mask_in.is_contiguous() and mask_in.dtype == torch.float32
+    assert x.shape[1] == h * w
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _MaskModulate.apply(x, mask_in, h, w)
+    return _mask_modulate_raw(x, mask_in, h, w, True)
+
+
+class _FeatureAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, t, skip):
+        ctx.skip, ctx.tshape = skip, t.shape
+        return _feature_add_raw(h, t, skip, False)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        return dy, dy.reshape(-1)[ctx.skip:].reshape(ctx.tshape), None
+
+
+def _feature_add_raw(h, t, skip, inplace):
+    out = h if inplace else torch.empty_like(h)
+    _lib.check(_lib.load().fmc_feature_add_fwd(h.data_ptr(), t.data_ptr(), out.data_ptr(), h.numel(), skip, _dt(h),
+                                               _stream()), "fmc_feature_add_fwd")
+    return out
+
+
+def feature_add(h: torch.Tensor, t: torch.Tensor, inplace: bool = False) -> torch.Tensor:
+    """`h + t` where `t` covers only the LAST `t.numel()` elements of `h` (the conditioned half under
+    classifier-free guidance; the leading elements get nothing added)."""
+    _dev(h, t)
+    assert h.is_contiguous() and t.is_contiguous() and h.dtype == t.dtype and t.numel() <= h.numel()
+    skip = h.numel() - t.numel()
+    if torch.is_grad_enabled() and (h.requires_grad or t.requires_grad):
+        out = _FeatureAdd.apply(h, t, skip)
+        return out
+    return _feature_add_raw(h, t, skip, inplace)
+
+
+def cfg_ddim_step(eps: torch.Tensor, x: torch.Tensor, guidance: float, alpha_t: float, alpha_prev: float,
+                  has_uncond: bool) -> torch.Tensor:
+    """Fused classifier-free-guidance combine + DDIM(eta=0) update.  eps `[2B, ...]` (uncond || cond) or `[B, ...]`;
+    x fp32 latents `[B, ...]`.  Returns the new fp32 latents."""
+    _dev(eps, x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and eps.is_contiguous()
+    n = x.numel()
+    assert eps.numel() == (2 * n if has_uncond else n)
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().fmc_cfg_ddim_step(eps.data_ptr(), x.data_ptr(), out.data_ptr(), n, int(has_uncond),
+                                             float(guidance), float(alpha_t), float(alpha_prev), _dt(eps), _stream()),
+               "fmc_cfg_ddim_step")
+    return out

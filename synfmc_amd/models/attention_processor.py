@@ -1,0 +1,204 @@
+"""Attention processors of FMC on the gfx950 kernels.
+
+Mirrors `fmc/models/attention_processor.py` (same four classes, constructor arguments, parameter names
+`qkv_merge` / `q_merge` / `kv_merge` / `to_{q,k,v,out}_lora.{down,up}` and call signatures, so they install
+through `set_attn_processor` / `set_mm_attn_processor` and load the reference's checkpoints), but the chain
+`head_to_batch_dim -> baddbmm -> softmax -> bmm -> batch_to_head_dim` (reference :61-67, :148-154, :271-281,
+:402-408) collapses into one `fmc_spatial_attn_fwd` / `fmc_temporal_attn_fwd` launch, Q/K/V come from ONE fused
+projection GEMM, and a frozen LoRA is merged into the projection weights (`W + s * up @ down`).
+
+Spatial vs temporal is decided by the shape of `hidden_states`:
+  * `[B, S, C]` tokens: attention over S (spatial self / text cross attention);
+  * with `temporal=True` (set by `TemporalSelfAttention`): `[B, F, P, C]` native channels-last video
+    tokens or `[N, F, C]` reference-layout tokens: attention over F.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import hip_ops as K
+from .layers import LoRALinearLayer
+
+
+def _tok(x: torch.Tensor) -> torch.Tensor:
+    """`b c h w -> b (h w) c` (free on channels-last storage); token tensors pass through."""
+    if x.ndim == 4:
+        n, c, h, w = x.shape
+        t = x.permute(0, 2, 3, 1)
+        return (t if t.is_contiguous() else t.contiguous()).view(n, h * w, c)
+    return x
+
+
+def _attention_core(attn, q_in: torch.Tensor, kv_in: Optional[torch.Tensor], temporal: bool, lora=None,
+                    lora_scale: float = 1.0) -> torch.Tensor:
+    """Fused projection -> attention kernel -> output projection (bias, dropout p=0)."""
+    heads = attn.heads
+    w_a, w_b, w_o = attn.fused_weights(lora, lora_scale)
+    c = attn.inner_dim
+    if kv_in is None:                                   # self attention: one [.., 3C] GEMM
+        qkv = F.linear(q_in, w_a)
+        q, k, v = qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
+        if temporal:
+            o = K.temporal_attention(q, k, v, heads, attn.scale)
+        else:
+            o = K.spatial_attention(q, k, v, heads, attn.scale)
+    else:                                               # cross attention: q GEMM + one [.., 2C] kv GEMM
+        assert not temporal
+        q = F.linear(q_in, w_a)
+        kv = F.linear(kv_in, w_b)
+        o = K.spatial_attention(q, kv[..., :c], kv[..., c:], heads, attn.scale)
+    return F.linear(o, w_o, attn.to_out[0].bias)
+
+
+def _finish(attn, out, residual, shape4):
+    if shape4 is not None:
+        n, c, h, w = shape4
+        out = out.view(n, h, w, c).permute(0, 3, 1, 2)
+    if attn.residual_connection:
+        out = out + residual
+    if attn.rescale_output_factor != 1.0:
+        out = out / attn.rescale_output_factor
+    return out
+
+
+class AttnProcessor:
+    """Reference: attention_processor.py:15-82 (`pose_feature` accepted and ignored, :28)."""
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
+                 scale: float = 1.0, pose_feature=None, temporal: bool = False):
+        attn.prepare_attention_mask(attention_mask, 0, 0)
+        shape4 = hidden_states.shape if (hidden_states.ndim == 4 and not temporal) else None
+        x = _tok(hidden_states) if not temporal else hidden_states
+        out = _attention_core(attn, x, encoder_hidden_states, temporal)
+        return _finish(attn, out, hidden_states, shape4)
+
+
+class LoRAAttnProcessor(nn.Module):
+    """Reference: attention_processor.py:85-169 (`W x + s * up(down(x))` on all four projections)."""
+
+    def __init__(self, hidden_size=None, cross_attention_dim=None, rank=4, network_alpha=None, lora_scale=1.0):
+        super().__init__()
+        self.rank, self.lora_scale = rank, lora_scale
+        kv_in = cross_attention_dim or hidden_size
+        self.to_q_lora = LoRALinearLayer(hidden_size, hidden_size, rank, network_alpha)
+        self.to_k_lora = LoRALinearLayer(kv_in, hidden_size, rank, network_alpha)
+        self.to_v_lora = LoRALinearLayer(kv_in, hidden_size, rank, network_alpha)
+        self.to_out_lora = LoRALinearLayer(hidden_size, hidden_size, rank, network_alpha)
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
+                 pose_feature=None, scale=None, temporal: bool = False):
+        _require_frozen(self)
+        attn.prepare_attention_mask(attention_mask, 0, 0)
+        s = self.lora_scale if scale is None else scale
+        shape4 = hidden_states.shape if (hidden_states.ndim == 4 and not temporal) else None
+        x = _tok(hidden_states) if not temporal else hidden_states
+        out = _attention_core(attn, x, encoder_hidden_states, temporal, lora=self, lora_scale=s)
+        return _finish(attn, out, hidden_states, shape4)
+
+
+def _require_frozen(proc: nn.Module) -> None:
+    if torch.is_grad_enabled() and any(p.requires_grad for n, p in proc.named_parameters() if "_lora" in n):
+        raise NotImplementedError(
+            "the gfx950 path merges LoRA into the projection weights; training the LoRA itself (FMC stage 1, a 2-D "
+            "U-Net, out of scope) is not supported -- call `.requires_grad_(False)` on the LoRA layers")
+
+
+class _PoseMerge:
+    def _build_merge(self, hidden_size, pose_feature_dim, query_condition, key_value_condition):
+        assert hidden_size == pose_feature_dim
+        self.query_condition, self.key_value_condition = query_condition, key_value_condition
+        name = "qkv_merge" if (query_condition and key_value_condition) else ("q_merge" if query_condition else "kv_merge")
+        layer = nn.Linear(hidden_size, hidden_size)
+        nn.init.zeros_(layer.weight)
+        nn.init.zeros_(layer.bias)
+        setattr(self, name, layer)
+
+    def _merge(self, hidden_states, encoder_hidden_states, pose_feature, s):
+        """`merge(h + pose) * s + h` (attention_processor.py:256-265)."""
+        if self.query_condition and self.key_value_condition:
+            m = torch.add(hidden_states, self.qkv_merge(hidden_states + pose_feature), alpha=s)
+            return m, None
+        if self.query_condition:
+            return torch.add(hidden_states, self.q_merge(hidden_states + pose_feature), alpha=s), encoder_hidden_states
+        return hidden_states, torch.add(encoder_hidden_states, self.kv_merge(encoder_hidden_states + pose_feature), alpha=s)
+
+
+def _pose_tokens(pose_feature, like):
+    """Bring the pose feature to the token layout of `like` (`[B,F,P,C]`, `[N,F,C]` or `[B,S,C]`)."""
+    if pose_feature.ndim == like.ndim and pose_feature.shape == like.shape:
+        return pose_feature
+    if pose_feature.ndim == 5:                     # b c f h w -> [B, F, (h w), C]; free on channels_last_3d storage
+        b, c, f, h, w = pose_feature.shape
+        t = pose_feature.permute(0, 2, 3, 4, 1)
+        t = (t if t.is_contiguous() else t.contiguous()).view(b, f, h * w, c)
+        if like.ndim == 3:                         # reference temporal layout (b h w) f c
+            t = t.permute(0, 2, 1, 3).reshape(b * h * w, f, c)
+        return t
+    if pose_feature.ndim == 4:
+        return _tok(pose_feature)
+    return pose_feature
+
+
+class PoseAdaptorAttnProcessor(nn.Module, _PoseMerge):
+    """Camera Adapter.  Reference: attention_processor.py:172-293 (zero-initialised merge layer, `pose_feature`
+    is the third positional argument of `forward`)."""
+
+    def __init__(self, hidden_size, pose_feature_dim=None, cross_attention_dim=None, query_condition=False,
+                 key_value_condition=False, scale=1.0):
+        super().__init__()
+        self.hidden_size, self.pose_feature_dim = hidden_size, pose_feature_dim
+        self.cross_attention_dim, self.scale = cross_attention_dim, scale
+        self._build_merge(hidden_size, pose_feature_dim, query_condition, key_value_condition)
+
+    def forward(self, attn, hidden_states, pose_feature, encoder_hidden_states=None, attention_mask=None, temb=None,
+                scale=None, temporal: bool = False):
+        assert pose_feature is not None
+        s = scale or self.scale
+        attn.prepare_attention_mask(attention_mask, 0, 0)
+        shape4 = hidden_states.shape if (hidden_states.ndim == 4 and not temporal) else None
+        x = hidden_states if temporal else _tok(hidden_states)
+        if self.query_condition and self.key_value_condition:
+            assert encoder_hidden_states is None
+        ctx = x if encoder_hidden_states is None else _tok(encoder_hidden_states)
+        q_in, kv_in = self._merge(x, ctx, _pose_tokens(pose_feature, x), s)
+        if not (self.query_condition and self.key_value_condition) and encoder_hidden_states is None:
+            raise NotImplementedError("q-only / kv-only pose merge on self attention needs un-fused projections; "
+                                      "the shipped FMC configs use query_condition = key_value_condition = True")
+        out = _attention_core(attn, q_in, kv_in, temporal)
+        return _finish(attn, out, hidden_states, shape4)
+
+
+class LORAPoseAdaptorAttnProcessor(nn.Module, _PoseMerge):
+    """Reference: attention_processor.py:296-420 (pose merge with `self.scale` + LoRA projections)."""
+
+    def __init__(self, hidden_size, pose_feature_dim=None, cross_attention_dim=None, query_condition=False,
+                 key_value_condition=False, scale=1.0, rank=4, network_alpha=None, lora_scale=1.0):
+        super().__init__()
+        self.hidden_size, self.pose_feature_dim = hidden_size, pose_feature_dim
+        self.cross_attention_dim, self.scale = cross_attention_dim, scale
+        self._build_merge(hidden_size, pose_feature_dim, query_condition, key_value_condition)
+        self.rank, self.lora_scale = rank, lora_scale
+        kv_in = cross_attention_dim or hidden_size
+        self.to_q_lora = LoRALinearLayer(hidden_size, hidden_size, rank, network_alpha)
+        self.to_k_lora = LoRALinearLayer(kv_in, hidden_size, rank, network_alpha)
+        self.to_v_lora = LoRALinearLayer(kv_in, hidden_size, rank, network_alpha)
+        self.to_out_lora = LoRALinearLayer(hidden_size, hidden_size, rank, network_alpha)
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
+                 pose_feature=None, temporal: bool = False):
+        assert pose_feature is not None
+        _require_frozen(self)
+        ls = self.lora_scale if scale is None else scale
+        attn.prepare_attention_mask(attention_mask, 0, 0)
+        shape4 = hidden_states.shape if (hidden_states.ndim == 4 and not temporal) else None
+        x = hidden_states if temporal else _tok(hidden_states)
+        if self.query_condition and self.key_value_condition:
+            assert encoder_hidden_states is None
+        ctx = x if encoder_hidden_states is None else _tok(encoder_hidden_states)
+        q_in, kv_in = self._merge(x, ctx, _pose_tokens(pose_feature, x), self.scale)
+        out = _attention_core(attn, q_in, kv_in, temporal, lora=self, lora_scale=ls)
+        return _finish(attn, out, hidden_states, shape4)

@@ -1,0 +1,395 @@
+"""Native building blocks of the FMC U-Net (the pieces the reference imports from `diffusers==0.24.0`).
+
+Same class names, constructor arguments, sub-module / parameter names (so reference checkpoints keep
+their state-dict keys) and logical tensor shapes as the reference call sites
+(`fmc/models/unet_blocks.py:6-7`, `fmc/models/unet.py:13-20`, `fmc/models/motion_module.py:8-10`), but:
+
+* activations are physically channels-last: a `(b f) c h w` tensor is a permuted view of `[(b f), h, w, c]`
+  storage, so the token view `[(b f), h*w, c]` is free and GroupNorm / attention kernels read whole rows;
+* GroupNorm(+SiLU), LayerNorm, GEGLU and attention run as hand-written gfx950 kernels through
+  `libfmc_hip.so` (`synfmc_amd.hip_ops`); convolutions and projections are MIOpen / hipBLASLt calls on
+  the same buffers.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import hip_ops as K
+
+
+# ----------------------------------------------------------------------------
+# layout helpers
+# ----------------------------------------------------------------------------
+def to_tokens(x: torch.Tensor) -> torch.Tensor:
+    """`[N, C, h, w]` (any strides) -> contiguous `[N, h*w, C]` tokens; free for channels-last storage."""
+    n, c, h, w = x.shape
+    t = x.permute(0, 2, 3, 1)
+    if not t.is_contiguous():
+        t = t.contiguous()
+    return t.view(n, h * w, c)
+
+
+def from_tokens(t: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """contiguous `[N, h*w, C]` tokens -> logical `[N, C, h, w]` view over channels-last storage."""
+    n, _, c = t.shape
+    return t.view(n, h, w, c).permute(0, 3, 1, 2)
+
+
+def f32_param(mod: nn.Module, name: str) -> torch.Tensor:
+    """fp32 copy of an affine parameter (the kernels take fp32 gamma / beta), cached per version."""
+    p = getattr(mod, name)
+    if p.dtype == torch.float32:
+        return p
+    cache = mod.__dict__.setdefault("_f32_cache", {})
+    key = (p.data_ptr(), p._version)
+    hit = cache.get(name)
+    if hit is None or hit[0] != key:
+        hit = (key, p.detach().float())
+        cache[name] = hit
+    return hit[1]
+
+
+class GroupNorm(nn.GroupNorm):
+    """nn.GroupNorm on a `[N, C, h, w]` tensor, optionally fused with SiLU (`fmc_groupnorm_silu_fwd`)."""
+
+    def forward(self, x: torch.Tensor, act: bool = False) -> torch.Tensor:
+        n, c, h, w = x.shape
+        y = K.groupnorm_silu(to_tokens(x), f32_param(self, "weight"), f32_param(self, "bias"), self.num_groups,
+                             self.eps, act)
+        return from_tokens(y, h, w)
+
+
+class LayerNorm(nn.LayerNorm):
+    def forward(self, x: torch.Tensor, pe: Optional[torch.Tensor] = None, pe_inner: int = 1,
+                pe_frames: int = 1) -> torch.Tensor:
+        if not x.is_contiguous():
+            x = x.contiguous()
+        return K.layernorm(x, f32_param(self, "weight"), f32_param(self, "bias"), self.eps, pe, pe_inner, pe_frames)
+
+
+class Conv2d(nn.Conv2d):
+    """MIOpen conv on channels-last storage; 1x1 stride-1 convs run as a token GEMM (hipBLASLt)."""
+
+    def forward(self, x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+        if self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0):
+            n, c, h, w = x.shape
+            y = F.linear(to_tokens(x), self.weight.view(self.out_channels, self.in_channels), self.bias)
+            return from_tokens(y, h, w)
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+
+
+class Linear(nn.Linear):
+    def forward(self, x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+        return F.linear(x, self.weight, self.bias)
+
+
+# ----------------------------------------------------------------------------
+# time embedding (fmc/models/unet.py:112,115)
+# ----------------------------------------------------------------------------
+class Timesteps(nn.Module):
+    def __init__(self, num_channels: int, flip_sin_to_cos: bool, downscale_freq_shift: float):
+        super().__init__()
+        self.num_channels, self.flip_sin_to_cos = num_channels, flip_sin_to_cos
+        self.downscale_freq_shift = downscale_freq_shift
+
+    def forward(self, timesteps: torch.Tensor) -> torch.Tensor:
+        half = self.num_channels // 2
+        k = torch.arange(half, dtype=torch.float32, device=timesteps.device)
+        freqs = torch.exp(-math.log(10000.0) * k / (half - self.downscale_freq_shift))
+        ang = timesteps[:, None].float() * freqs[None, :]
+        emb = torch.cat([torch.cos(ang), torch.sin(ang)] if self.flip_sin_to_cos
+                        else [torch.sin(ang), torch.cos(ang)], dim=-1)
+        return F.pad(emb, (0, 1)) if self.num_channels % 2 else emb
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, in_channels: int, time_embed_dim: int):
+        super().__init__()
+        self.linear_1 = nn.Linear(in_channels, time_embed_dim)
+        self.act = nn.SiLU()
+        self.linear_2 = nn.Linear(time_embed_dim, time_embed_dim)
+
+    def forward(self, sample):
+        return self.linear_2(self.act(self.linear_1(sample)))
+
+
+class LoRALinearLayer(nn.Module):
+    """`up(down(x))` (fmc/models/attention_processor.py:103-106); merged into the base weight by
+    `merge_lora_` when frozen, which is the case in FMC stages 2-3 and at inference."""
+
+    def __init__(self, in_features, out_features, rank=4, network_alpha=None, device=None, dtype=None):
+        super().__init__()
+        self.down = nn.Linear(in_features, rank, bias=False, device=device, dtype=dtype)
+        self.up = nn.Linear(rank, out_features, bias=False, device=device, dtype=dtype)
+        self.network_alpha, self.rank = network_alpha, rank
+        self.in_features, self.out_features = in_features, out_features
+        nn.init.normal_(self.down.weight, std=1 / rank)
+        nn.init.zeros_(self.up.weight)
+
+    def delta_weight(self) -> torch.Tensor:
+        w = self.up.weight.float() @ self.down.weight.float()
+        return w * (self.network_alpha / self.rank) if self.network_alpha is not None else w
+
+    def forward(self, hidden_states):
+        y = self.up(self.down(hidden_states))
+        return y * (self.network_alpha / self.rank) if self.network_alpha is not None else y
+
+
+# ----------------------------------------------------------------------------
+# ResNet / resampling (fmc/models/unet_blocks.py:175,306,350,625)
+# ----------------------------------------------------------------------------
+class ResnetBlock2D(nn.Module):
+    def __init__(self, *, in_channels, out_channels=None, conv_shortcut=False, dropout=0.0, temb_channels=512,
+                 groups=32, groups_out=None, pre_norm=True, eps=1e-6, non_linearity="swish",
+                 time_embedding_norm="default", output_scale_factor=1.0, use_in_shortcut=None):
+        super().__init__()
+        if time_embedding_norm != "default" or non_linearity not in ("swish", "silu"):
+            raise NotImplementedError("FMC builds default / SiLU resnets only")
+        out_channels = in_channels if out_channels is None else out_channels
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.output_scale_factor = output_scale_factor
+        self.norm1 = GroupNorm(num_groups=groups, num_channels=in_channels, eps=eps, affine=True)
+        self.conv1 = Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        self.time_emb_proj = Linear(temb_channels, out_channels) if temb_channels is not None else None
+        self.norm2 = GroupNorm(num_groups=groups if groups_out is None else groups_out, num_channels=out_channels,
+                               eps=eps, affine=True)
+        self.dropout = nn.Dropout(dropout)
+        self.conv2 = Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        self.nonlinearity = nn.SiLU()
+        self.use_in_shortcut = in_channels != out_channels if use_in_shortcut is None else use_in_shortcut
+        self.conv_shortcut = Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0) \
+            if self.use_in_shortcut else None
+
+    def forward(self, input_tensor, temb, scale: float = 1.0):
+        h = self.conv1(self.norm1(input_tensor, act=True))
+        if self.time_emb_proj is not None and temb is not None:
+            h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
+        h = self.conv2(self.norm2(h, act=True))
+        if self.conv_shortcut is not None:
+            input_tensor = self.conv_shortcut(input_tensor)
+        out = input_tensor + h
+        return out if self.output_scale_factor == 1.0 else out / self.output_scale_factor
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, channels, use_conv=False, out_channels=None, padding=1, name="conv"):
+        super().__init__()
+        assert use_conv, "FMC only builds conv downsamplers"
+        self.channels, self.out_channels = channels, out_channels or channels
+        self.use_conv, self.padding, self.name = use_conv, padding, name
+        conv = Conv2d(self.channels, self.out_channels, 3, stride=2, padding=padding)
+        if name == "conv":
+            self.Conv2d_0 = conv
+        self.conv = conv
+
+    def forward(self, hidden_states, scale: float = 1.0):
+        assert hidden_states.shape[1] == self.channels
+        if self.padding == 0:
+            hidden_states = F.pad(hidden_states, (0, 1, 0, 1), mode="constant", value=0)
+        return self.conv(hidden_states)
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, channels, use_conv=False, use_conv_transpose=False, out_channels=None, name="conv"):
+        super().__init__()
+        assert use_conv and not use_conv_transpose and name == "conv"
+        self.channels, self.out_channels = channels, out_channels or channels
+        self.use_conv, self.name = use_conv, name
+        self.conv = Conv2d(self.channels, self.out_channels, 3, padding=1)
+
+    def forward(self, hidden_states, output_size=None, scale: float = 1.0):
+        assert hidden_states.shape[1] == self.channels
+        if not hidden_states.is_contiguous(memory_format=torch.channels_last):
+            hidden_states = hidden_states.contiguous(memory_format=torch.channels_last)
+        if output_size is None:
+            hidden_states = F.interpolate(hidden_states, scale_factor=2.0, mode="nearest")
+        else:
+            hidden_states = F.interpolate(hidden_states, size=output_size, mode="nearest")
+        return self.conv(hidden_states)
+
+
+# ----------------------------------------------------------------------------
+# attention (base of TemporalSelfAttention, fmc/models/motion_module.py:324)
+# ----------------------------------------------------------------------------
+class Attention(nn.Module):
+    """Parameter container + helpers the processors use (SURVEY.md section 8b lists the members the reference
+    processors touch).  The arithmetic lives in the processors (`synfmc_amd.models.attention_processor`)."""
+
+    def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64, dropout=0.0, bias=False,
+                 upcast_attention=False, upcast_softmax=False, cross_attention_norm=None,
+                 cross_attention_norm_num_groups=32, added_kv_proj_dim=None, norm_num_groups=None,
+                 spatial_norm_dim=None, out_bias=True, scale_qk=True, only_cross_attention=False, eps=1e-5,
+                 rescale_output_factor=1.0, residual_connection=False, _from_deprecated_attn_block=False,
+                 processor=None):
+        super().__init__()
+        assert cross_attention_norm is None and added_kv_proj_dim is None and norm_num_groups is None
+        assert spatial_norm_dim is None and not only_cross_attention
+        self.inner_dim = dim_head * heads
+        self.query_dim = query_dim
+        self.is_cross = cross_attention_dim is not None
+        self.cross_attention_dim = cross_attention_dim if cross_attention_dim is not None else query_dim
+        self.upcast_attention, self.upcast_softmax = upcast_attention, upcast_softmax
+        self.rescale_output_factor, self.residual_connection = rescale_output_factor, residual_connection
+        self.scale = dim_head ** -0.5 if scale_qk else 1.0
+        self.heads = heads
+        self.sliceable_head_dim = heads
+        self.group_norm = self.spatial_norm = self.norm_cross = None
+        self.to_q = Linear(query_dim, self.inner_dim, bias=bias)
+        self.to_k = Linear(self.cross_attention_dim, self.inner_dim, bias=bias)
+        self.to_v = Linear(self.cross_attention_dim, self.inner_dim, bias=bias)
+        self.to_out = nn.ModuleList([Linear(self.inner_dim, query_dim, bias=out_bias), nn.Dropout(dropout)])
+        from .attention_processor import AttnProcessor
+        self.set_processor(processor if processor is not None else AttnProcessor())
+
+    def set_processor(self, processor, _remove_lora: bool = False):
+        if hasattr(self, "processor") and isinstance(self.processor, nn.Module) \
+                and not isinstance(processor, nn.Module):
+            self._modules.pop("processor")
+        self.processor = processor
+        self.__dict__.pop("_fused", None)
+
+    def set_use_memory_efficient_attention_xformers(self, *a, **k):
+        pass
+
+    def set_attention_slice(self, slice_size):
+        pass
+
+    def prepare_attention_mask(self, attention_mask, target_length, batch_size, out_dim=3):
+        if attention_mask is not None:
+            raise NotImplementedError("attention masks are never passed on the FMC path")
+        return None
+
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **cross_attention_kwargs):
+        return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states,
+                              attention_mask=attention_mask, **cross_attention_kwargs)
+
+    # ---- fused projection weights (cached; rebuilt when any source parameter changes) ----------------
+    def fused_weights(self, lora=None, lora_scale: float = 1.0):
+        """(W_qkv `[3C, Cin]` for self attention | (W_q, W_kv) for cross attention, W_out, b_out) with an
+        optional frozen LoRA (`W + s * up @ down`) merged in."""
+        srcs = [self.to_q.weight, self.to_k.weight, self.to_v.weight, self.to_out[0].weight]
+        if lora is not None:
+            for n in ("to_q_lora", "to_k_lora", "to_v_lora", "to_out_lora"):
+                srcs += [getattr(lora, n).down.weight, getattr(lora, n).up.weight]
+        key = tuple((p.data_ptr(), p._version) for p in srcs) + (lora_scale,)
+        hit = self.__dict__.get("_fused")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        with torch.no_grad():
+            def w(lin, name):
+                if lora is None:
+                    return lin.weight
+                return (lin.weight.float() + lora_scale * getattr(lora, name).delta_weight()).to(lin.weight.dtype)
+            wq, wk, wv = w(self.to_q, "to_q_lora"), w(self.to_k, "to_k_lora"), w(self.to_v, "to_v_lora")
+            wo = w(self.to_out[0], "to_out_lora")
+            if self.is_cross:
+                fused = (wq.contiguous(), torch.cat([wk, wv], dim=0).contiguous(), wo.contiguous())
+            else:
+                fused = (torch.cat([wq, wk, wv], dim=0).contiguous(), None, wo.contiguous())
+        self.__dict__["_fused"] = (key, fused)
+        return fused
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = Linear(dim_in, dim_out * 2)
+
+    def forward(self, hidden_states, scale: float = 1.0):
+        return K.geglu(self.proj(hidden_states))
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, dim_out=None, mult=4, dropout=0.0, activation_fn="geglu", final_dropout=False):
+        super().__init__()
+        if activation_fn != "geglu":
+            raise NotImplementedError("FMC only builds geglu feed-forwards")
+        inner = int(dim * mult)
+        self.net = nn.ModuleList([GEGLU(dim, inner), nn.Dropout(dropout),
+                                  Linear(inner, dim if dim_out is None else dim_out)])
+
+    def forward(self, hidden_states, scale: float = 1.0):
+        return self.net[2](self.net[0](hidden_states))
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, num_attention_heads, attention_head_dim, dropout=0.0, cross_attention_dim=None,
+                 activation_fn="geglu", attention_bias=False, only_cross_attention=False,
+                 double_self_attention=False, upcast_attention=False, norm_elementwise_affine=True,
+                 norm_type="layer_norm", norm_eps=1e-5, final_dropout=False):
+        super().__init__()
+        assert norm_type == "layer_norm" and not only_cross_attention and not double_self_attention
+        self.norm1 = LayerNorm(dim, elementwise_affine=norm_elementwise_affine, eps=norm_eps)
+        self.attn1 = Attention(query_dim=dim, heads=num_attention_heads, dim_head=attention_head_dim, dropout=dropout,
+                               bias=attention_bias, upcast_attention=upcast_attention)
+        if cross_attention_dim is not None:
+            self.norm2 = LayerNorm(dim, elementwise_affine=norm_elementwise_affine, eps=norm_eps)
+            self.attn2 = Attention(query_dim=dim, cross_attention_dim=cross_attention_dim, heads=num_attention_heads,
+                                   dim_head=attention_head_dim, dropout=dropout, bias=attention_bias,
+                                   upcast_attention=upcast_attention)
+        else:
+            self.norm2 = self.attn2 = None
+        self.norm3 = LayerNorm(dim, elementwise_affine=norm_elementwise_affine, eps=norm_eps)
+        self.ff = FeedForward(dim, dropout=dropout, activation_fn=activation_fn, final_dropout=final_dropout)
+
+    def forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None,
+                encoder_attention_mask=None, timestep=None, cross_attention_kwargs=None, class_labels=None):
+        kw = dict(cross_attention_kwargs) if cross_attention_kwargs is not None else {}
+        kw.pop("gligen", None)
+        hidden_states = self.attn1(self.norm1(hidden_states), encoder_hidden_states=None,
+                                   attention_mask=attention_mask, **kw) + hidden_states
+        if self.attn2 is not None:
+            hidden_states = self.attn2(self.norm2(hidden_states), encoder_hidden_states=encoder_hidden_states,
+                                       attention_mask=encoder_attention_mask, **kw) + hidden_states
+        return self.ff(self.norm3(hidden_states)) + hidden_states
+
+
+class Transformer2DModelOutput:
+    def __init__(self, sample):
+        self.sample = sample
+
+
+class Transformer2DModel(nn.Module):
+    """GN(eps 1e-6) -> 1x1 conv -> tokens -> BasicTransformerBlock -> 1x1 conv -> + residual
+    (ctor args at fmc/models/unet_blocks.py:323-333)."""
+
+    def __init__(self, num_attention_heads=16, attention_head_dim=88, in_channels=None, out_channels=None,
+                 num_layers=1, dropout=0.0, norm_num_groups=32, cross_attention_dim=None, attention_bias=False,
+                 activation_fn="geglu", use_linear_projection=False, only_cross_attention=False,
+                 double_self_attention=False, upcast_attention=False, norm_type="layer_norm",
+                 norm_elementwise_affine=True):
+        super().__init__()
+        assert not use_linear_projection, "SD-1.5 / FMC use conv projections"
+        inner = num_attention_heads * attention_head_dim
+        self.in_channels = in_channels
+        self.norm = GroupNorm(num_groups=norm_num_groups, num_channels=in_channels, eps=1e-6, affine=True)
+        self.proj_in = Conv2d(in_channels, inner, kernel_size=1, stride=1, padding=0)
+        self.transformer_blocks = nn.ModuleList([
+            BasicTransformerBlock(inner, num_attention_heads, attention_head_dim, dropout=dropout,
+                                  cross_attention_dim=cross_attention_dim, activation_fn=activation_fn,
+                                  attention_bias=attention_bias, upcast_attention=upcast_attention)
+            for _ in range(num_layers)])
+        self.proj_out = Conv2d(inner, in_channels, kernel_size=1, stride=1, padding=0)
+
+    def forward(self, hidden_states, encoder_hidden_states=None, timestep=None, class_labels=None,
+                cross_attention_kwargs=None, attention_mask=None, encoder_attention_mask=None,
+                return_dict: bool = True):
+        n, c, h, w = hidden_states.shape
+        residual = to_tokens(hidden_states)
+        x = K.groupnorm_silu(residual, f32_param(self.norm, "weight"), f32_param(self.norm, "bias"),
+                             self.norm.num_groups, self.norm.eps, False)
+        x = F.linear(x, self.proj_in.weight.view(self.proj_in.out_channels, c), self.proj_in.bias)
+        for blk in self.transformer_blocks:
+            x = blk(x, attention_mask=attention_mask, encoder_hidden_states=encoder_hidden_states,
+                    encoder_attention_mask=encoder_attention_mask, timestep=timestep,
+                    cross_attention_kwargs=cross_attention_kwargs, class_labels=class_labels)
+        x = F.linear(x, self.proj_out.weight.view(c, self.proj_out.in_channels), self.proj_out.bias)
+        out = from_tokens(x + residual, h, w)
+        return Transformer2DModelOutput(out) if return_dict else (out,)

@@ -1,0 +1,219 @@
+"""Temporal (motion) modules of FMC on the gfx950 kernels.
+
+Mirrors `fmc/models/motion_module.py` (class names, constructor arguments, parameter names), with the
+layout change that removes the reference's transposes: the reference moves `b c f h w` to `(b h w) f c`
+and back around every module (:218, :232); here the video stays channels-last `[B, F, (h w), C]`, every
+per-token op (LayerNorm, projections, GEGLU FF) runs on that buffer as is, and `fmc_temporal_attn_fwd`
+walks the frame axis with a stride.  The reference's 3-D `(b h w) f c` token layout is accepted as well
+(the camera encoder's public seam, `fmc/models/pose_adaptor.py:236-238`).
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Dict, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import hip_ops as K
+from .attention_processor import PoseAdaptorAttnProcessor
+from .layers import Attention, FeedForward, LayerNorm, f32_param
+from .resnet import InflatedGroupNorm
+
+
+def zero_module(module):
+    for p in module.parameters():
+        p.detach().zero_()
+    return module
+
+
+class TemporalTransformer3DModelOutput:
+    def __init__(self, sample):
+        self.sample = sample
+
+
+def get_motion_module(in_channels, motion_module_type: str, motion_module_kwargs: dict):
+    if motion_module_type == "Vanilla":
+        return VanillaTemporalModule(in_channels=in_channels, **motion_module_kwargs)
+    raise ValueError
+
+
+class PositionalEncoding(nn.Module):
+    """Sinusoidal table, buffer `pe` `[1, max_len, C]` (motion_module.py:303-321)."""
+
+    def __init__(self, d_model, dropout=0.0, max_len=32):
+        super().__init__()
+        self.dropout = nn.Dropout(p=dropout)
+        position = torch.arange(max_len).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model))
+        pe = torch.zeros(1, max_len, d_model)
+        pe[0, :, 0::2] = torch.sin(position * div_term)
+        pe[0, :, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pe", pe)
+
+    def table(self) -> torch.Tensor:
+        """fp32 `[max_len, C]` table for the fused LayerNorm+PE kernel."""
+        pe = self.pe
+        if pe.dtype != torch.float32:
+            hit = self.__dict__.get("_pe32")
+            if hit is None or hit[0] != (pe.data_ptr(), pe._version):
+                hit = ((pe.data_ptr(), pe._version), pe.float())
+                self.__dict__["_pe32"] = hit
+            pe = hit[1]
+        return pe[0]
+
+    def forward(self, x):
+        if x.ndim == 4:                      # [B, F, P, C]
+            return x + self.pe[0, : x.size(1)].to(x.dtype)[None, :, None, :]
+        return x + self.pe[:, : x.size(1)].to(x.dtype)
+
+
+class TemporalSelfAttention(Attention):
+    """motion_module.py:324-389.  `forward` adds the positional encoding (unless the caller already fused it
+    into the LayerNorm, `_pe_applied=True`), reshapes `pose_feature` and dispatches to the processor with
+    `encoder_hidden_states=None`."""
+
+    def __init__(self, attention_mode=None, temporal_position_encoding=False,
+                 temporal_position_encoding_max_len=32, rescale_output_factor=1.0, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        assert attention_mode == "Temporal_Self"
+        self.pos_encoder = PositionalEncoding(kwargs["query_dim"], max_len=temporal_position_encoding_max_len) \
+            if temporal_position_encoding else None
+        self.rescale_output_factor = rescale_output_factor
+
+    def set_use_memory_efficient_attention_xformers(self, *a, **k):
+        pass
+
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, _pe_applied: bool = False,
+                **cross_attention_kwargs):
+        if self.pos_encoder is not None and not _pe_applied:
+            hidden_states = self.pos_encoder(hidden_states)
+        kw = dict(cross_attention_kwargs)
+        if isinstance(self.processor, PoseAdaptorAttnProcessor):
+            pose_feature = kw.pop("pose_feature")
+            return self.processor(self, hidden_states, pose_feature, encoder_hidden_states=None,
+                                  attention_mask=attention_mask, temporal=True, **kw)
+        return self.processor(self, hidden_states, encoder_hidden_states=None, attention_mask=attention_mask,
+                              temporal=True, **kw)
+
+
+class TemporalTransformerBlock(nn.Module):
+    """motion_module.py:237-300: `x = attn_i(LN_i(x)) + x` for every attention block, then `x = FF(LN(x)) + x`.
+    Tokens: native `[B, F, P, C]` or reference `[N, F, C]`."""
+
+    def __init__(self, dim, num_attention_heads, attention_head_dim,
+                 attention_block_types=("Temporal_Self", "Temporal_Self"), dropout=0.0, norm_num_groups=32,
+                 cross_attention_dim=768, activation_fn="geglu", attention_bias=False, upcast_attention=False,
+                 temporal_position_encoding=False, temporal_position_encoding_max_len=32,
+                 encoder_hidden_states_query=(False, False), attention_activation_scale=1.0,
+                 attention_processor_kwargs: Dict = {}, rescale_output_factor=1.0):
+        super().__init__()
+        self.attention_block_types = attention_block_types
+        self.attention_blocks = nn.ModuleList([
+            TemporalSelfAttention(
+                attention_mode=name,
+                cross_attention_dim=cross_attention_dim if name in ("Temporal_Cross", "Temporal_Pose_Adaptor") else None,
+                query_dim=dim, heads=num_attention_heads, dim_head=attention_head_dim, dropout=dropout,
+                bias=attention_bias, upcast_attention=upcast_attention,
+                temporal_position_encoding=temporal_position_encoding,
+                temporal_position_encoding_max_len=temporal_position_encoding_max_len,
+                rescale_output_factor=rescale_output_factor)
+            for name in attention_block_types])
+        self.norms = nn.ModuleList([LayerNorm(dim) for _ in attention_block_types])
+        self.ff = FeedForward(dim, dropout=dropout, activation_fn=activation_fn)
+        self.ff_norm = LayerNorm(dim)
+
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None,
+                cross_attention_kwargs: Dict[str, Any] = {}):
+        if hidden_states.ndim == 4:
+            frames, inner = hidden_states.shape[1], hidden_states.shape[2]
+        else:
+            frames, inner = hidden_states.shape[1], 1
+        for attention_block, norm in zip(self.attention_blocks, self.norms):
+            pe = attention_block.pos_encoder
+            if pe is not None:       # LayerNorm and `pos_encoder(norm(x))` in one pass (motion_module.py:288,355)
+                n = norm(hidden_states, pe=pe.table(), pe_inner=inner, pe_frames=frames)
+            else:
+                n = norm(hidden_states)
+            hidden_states = attention_block(n, encoder_hidden_states=None, attention_mask=attention_mask,
+                                            _pe_applied=True, **cross_attention_kwargs) + hidden_states
+        return self.ff(self.ff_norm(hidden_states)) + hidden_states
+
+
+class TemporalTransformer3DModel(nn.Module):
+    """motion_module.py:93-234."""
+
+    def __init__(self, in_channels, num_attention_heads, attention_head_dim, num_layers,
+                 attention_block_types=("Temporal_Self", "Temporal_Self"), dropout=0.0, norm_num_groups=32,
+                 cross_attention_dim=320, activation_fn="geglu", attention_bias=False, upcast_attention=False,
+                 temporal_position_encoding=False, temporal_position_encoding_max_len=32,
+                 encoder_hidden_states_query=(False, False), attention_activation_scale=1.0,
+                 attention_processor_kwargs: Dict = {}, causal_temporal_attention=None,
+                 causal_temporal_attention_mask_type="", rescale_output_factor=1.0):
+        super().__init__()
+        assert causal_temporal_attention is not None
+        if causal_temporal_attention:
+            raise NotImplementedError("causal temporal masks (motion_module.py:151-208) are unused by the FMC configs")
+        self.causal_temporal_attention = causal_temporal_attention
+        inner_dim = num_attention_heads * attention_head_dim
+        self.norm = InflatedGroupNorm(num_groups=norm_num_groups, num_channels=in_channels, eps=1e-6, affine=True)
+        self.proj_in = nn.Linear(in_channels, inner_dim)
+        self.transformer_blocks = nn.ModuleList([
+            TemporalTransformerBlock(
+                dim=inner_dim, num_attention_heads=num_attention_heads, attention_head_dim=attention_head_dim,
+                attention_block_types=attention_block_types, dropout=dropout, norm_num_groups=norm_num_groups,
+                cross_attention_dim=cross_attention_dim, activation_fn=activation_fn, attention_bias=attention_bias,
+                upcast_attention=upcast_attention, temporal_position_encoding=temporal_position_encoding,
+                temporal_position_encoding_max_len=temporal_position_encoding_max_len,
+                rescale_output_factor=rescale_output_factor)
+            for _ in range(num_layers)])
+        self.proj_out = nn.Linear(inner_dim, in_channels)
+
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None,
+                cross_attention_kwargs: Dict[str, Any] = {}):
+        assert hidden_states.dim() == 5, f"Expected hidden_states to have ndim=5, but got ndim={hidden_states.dim()}."
+        b, c, f, h, w = hidden_states.shape
+        t = hidden_states.permute(0, 2, 3, 4, 1)                 # [B, F, h, w, C]; free on channels_last_3d storage
+        if not t.is_contiguous():
+            t = t.contiguous()
+        residual = t.view(b * f, h * w, c)
+        x = K.groupnorm_silu(residual, f32_param(self.norm, "weight"), f32_param(self.norm, "bias"),
+                             self.norm.num_groups, self.norm.eps, False)
+        x = self.proj_in(x).view(b, f, h * w, -1)
+        for block in self.transformer_blocks:
+            x = block(x, encoder_hidden_states=encoder_hidden_states, attention_mask=attention_mask,
+                      cross_attention_kwargs=cross_attention_kwargs)
+        x = self.proj_out(x).view(b * f, h * w, c) + residual
+        return x.view(b, f, h, w, c).permute(0, 4, 1, 2, 3)
+
+
+class VanillaTemporalModule(nn.Module):
+    """motion_module.py:44-90."""
+
+    def __init__(self, in_channels, num_attention_heads=8, num_transformer_block=2,
+                 attention_block_types=("Temporal_Self",), temporal_position_encoding=True,
+                 temporal_position_encoding_max_len=32, temporal_attention_dim_div=1, cross_attention_dim=320,
+                 zero_initialize=True, encoder_hidden_states_query=(False, False), attention_activation_scale=1.0,
+                 attention_processor_kwargs: Dict = {}, causal_temporal_attention=False,
+                 causal_temporal_attention_mask_type="", rescale_output_factor=1.0):
+        super().__init__()
+        self.temporal_transformer = TemporalTransformer3DModel(
+            in_channels=in_channels, num_attention_heads=num_attention_heads,
+            attention_head_dim=in_channels // num_attention_heads // temporal_attention_dim_div,
+            num_layers=num_transformer_block, attention_block_types=tuple(attention_block_types),
+            cross_attention_dim=cross_attention_dim, temporal_position_encoding=temporal_position_encoding,
+            temporal_position_encoding_max_len=temporal_position_encoding_max_len,
+            encoder_hidden_states_query=encoder_hidden_states_query,
+            attention_activation_scale=attention_activation_scale,
+            attention_processor_kwargs=attention_processor_kwargs,
+            causal_temporal_attention=causal_temporal_attention,
+            causal_temporal_attention_mask_type=causal_temporal_attention_mask_type,
+            rescale_output_factor=rescale_output_factor)
+        if zero_initialize:
+            self.temporal_transformer.proj_out = zero_module(self.temporal_transformer.proj_out)
+
+    def forward(self, hidden_states, temb=None, encoder_hidden_states=None, attention_mask=None,
+                cross_attention_kwargs: Dict[str, Any] = {}):
+        return self.temporal_transformer(hidden_states, encoder_hidden_states, attention_mask,
+                                         cross_attention_kwargs=cross_attention_kwargs)

@@ -1,0 +1,458 @@
+"""The FMC 3-D U-Net (`fmc/models/unet.py`, `fmc/models/unet_cam_obj.py`) on the gfx950 kernels.
+
+Classes and public methods keep the reference's names and signatures:
+
+* `UNet3DConditionModel`             -- SD-1.5 layout inflated to video (reference unet.py:49-826);
+* `UNet3DConditionModelPoseCond`     -- + Camera-Adapter conditioning (`pose_embedding_features`, unet.py:829-1300);
+* `UNet3DConditionModelCamObjCond`   -- + Object-Motion-Control features (`traj_features`, unet_cam_obj.py:829-1375);
+* `from_pretrained_2d`, `set_attn_processor` / `set_mm_attn_processor` (dict keyed by "<module path>.processor",
+  `ValueError` on a count mismatch), `set_all_attn_processor`, `attn_processors` / `mm_attn_processors`.
+
+Inputs / outputs are logically `b c f h w`; internally the video is channels-last (`torch.channels_last_3d`),
+so a reference-style contiguous input costs one transposing copy of the 4-channel latent on entry and exit and
+nothing in between.  Text embeddings are NOT repeated over frames (reference :1184): the cross-attention kernel
+maps frame batch `b*F+f` to text batch `b` (`kv_batch_div`).
+"""
+from __future__ import annotations
+
+import inspect
+import json
+import os
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import torch
+from torch import nn
+
+from .attention_processor import (AttnProcessor, LORAPoseAdaptorAttnProcessor, LoRAAttnProcessor,
+                                  PoseAdaptorAttnProcessor)
+from .layers import GroupNorm, TimestepEmbedding, Timesteps
+from .resnet import InflatedConv3d, _frames_back, _frames_first
+from .unet_blocks import (CrossAttnDownBlock3D, CrossAttnUpBlock3D, DownBlock3D, UNetMidBlock3DCrossAttn, UpBlock3D,
+                          get_down_block, get_up_block)
+
+CustomizedAttnProcessor = AttnProcessor
+CustomizedLoRAAttnProcessor = LoRAAttnProcessor
+WEIGHTS_NAME = "diffusion_pytorch_model.bin"
+
+
+class UNet3DConditionOutput:
+    def __init__(self, sample: torch.Tensor):
+        self.sample = sample
+
+    def __getitem__(self, i):
+        return (self.sample,)[i]
+
+
+class FrozenConfig(dict):
+    """attribute + item access, like diffusers' FrozenDict."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k) from None
+
+
+def _capture_config(obj, local_vars, cls):
+    sig = inspect.signature(cls.__init__)
+    cfg = {k: local_vars[k] for k in sig.parameters if k not in ("self", "kwargs") and k in local_vars}
+    prev = dict(getattr(obj, "config", {}))
+    prev.update(cfg)
+    obj.config = FrozenConfig(prev)
+
+
+class UNet3DConditionModel(nn.Module):
+    _supports_gradient_checkpointing = True
+
+    def __init__(self, sample_size: Optional[int] = None, in_channels: int = 4, out_channels: int = 4,
+                 center_input_sample: bool = False, flip_sin_to_cos: bool = True, freq_shift: int = 0,
+                 down_block_types: Tuple[str] = ("CrossAttnDownBlock3D", "CrossAttnDownBlock3D",
+                                                 "CrossAttnDownBlock3D", "DownBlock3D"),
+                 mid_block_type: str = "UNetMidBlock3DCrossAttn",
+                 up_block_types: Tuple[str] = ("UpBlock3D", "CrossAttnUpBlock3D", "CrossAttnUpBlock3D",
+                                               "CrossAttnUpBlock3D"),
+                 only_cross_attention: Union[bool, Tuple[bool]] = False,
+                 block_out_channels: Tuple[int] = (320, 640, 1280, 1280), layers_per_block: int = 2,
+                 downsample_padding: int = 1, mid_block_scale_factor: float = 1, act_fn: str = "silu",
+                 norm_num_groups: int = 32, norm_eps: float = 1e-5, cross_attention_dim: int = 1280,
+                 attention_head_dim: Union[int, Tuple[int]] = 8, dual_cross_attention: bool = False,
+                 use_linear_projection: bool = False, class_embed_type: Optional[str] = None,
+                 addition_embed_type: Optional[str] = None, num_class_embeds: Optional[int] = None,
+                 upcast_attention: bool = False, resnet_time_scale_shift: str = "default",
+                 use_motion_module=False, motion_module_resolutions=(1, 2, 4, 8), motion_module_mid_block=False,
+                 motion_module_type=None, motion_module_kwargs={}, fuse_first_frame: bool = False):
+        super().__init__()
+        _capture_config(self, locals(), UNet3DConditionModel)
+        if fuse_first_frame:
+            raise NotImplementedError("fuse_first_frame is broken in the reference (`emb_single` undefined, "
+                                      "unet.py:635 vs :621) and is not built")
+        if class_embed_type is not None or num_class_embeds is not None:
+            raise NotImplementedError("class embeddings are unused by FMC")
+        self.sample_size = sample_size
+        time_embed_dim = block_out_channels[0] * 4
+        self.conv_in = InflatedConv3d(in_channels, block_out_channels[0], kernel_size=3, padding=(1, 1))
+        self.time_proj = Timesteps(block_out_channels[0], flip_sin_to_cos, freq_shift)
+        self.time_embedding = TimestepEmbedding(block_out_channels[0], time_embed_dim)
+        self.class_embedding = None
+        self.down_blocks = nn.ModuleList([])
+        self.mid_block = None
+        self.up_blocks = nn.ModuleList([])
+        n = len(block_out_channels)
+        if isinstance(only_cross_attention, bool):
+            only_cross_attention = [only_cross_attention] * n
+        if isinstance(attention_head_dim, int):
+            attention_head_dim = (attention_head_dim,) * n
+
+        output_channel = block_out_channels[0]
+        for i, down_block_type in enumerate(down_block_types):
+            input_channel, output_channel = output_channel, block_out_channels[i]
+            self.down_blocks.append(get_down_block(
+                down_block_type, num_layers=layers_per_block, in_channels=input_channel,
+                out_channels=output_channel, temb_channels=time_embed_dim, add_downsample=i != n - 1,
+                resnet_eps=norm_eps, resnet_act_fn=act_fn, resnet_groups=norm_num_groups,
+                cross_attention_dim=cross_attention_dim, attn_num_head_channels=attention_head_dim[i],
+                downsample_padding=downsample_padding, dual_cross_attention=dual_cross_attention,
+                use_linear_projection=use_linear_projection, only_cross_attention=only_cross_attention[i],
+                upcast_attention=upcast_attention, resnet_time_scale_shift=resnet_time_scale_shift,
+                use_motion_module=use_motion_module and (2 ** i in motion_module_resolutions),
+                motion_module_type=motion_module_type, motion_module_kwargs=motion_module_kwargs))
+
+        if mid_block_type != "UNetMidBlock3DCrossAttn":
+            raise ValueError(f"unknown mid_block_type : {mid_block_type}")
+        self.mid_block = UNetMidBlock3DCrossAttn(
+            in_channels=block_out_channels[-1], temb_channels=time_embed_dim, resnet_eps=norm_eps,
+            resnet_act_fn=act_fn, output_scale_factor=mid_block_scale_factor,
+            resnet_time_scale_shift=resnet_time_scale_shift, cross_attention_dim=cross_attention_dim,
+            attn_num_head_channels=attention_head_dim[-1], resnet_groups=norm_num_groups,
+            dual_cross_attention=dual_cross_attention, use_linear_projection=use_linear_projection,
+            upcast_attention=upcast_attention, use_motion_module=use_motion_module and motion_module_mid_block,
+            motion_module_type=motion_module_type, motion_module_kwargs=motion_module_kwargs)
+
+        self.num_upsamplers = 0
+        rev_channels = list(reversed(block_out_channels))
+        rev_heads = list(reversed(attention_head_dim))
+        rev_only_cross = list(reversed(only_cross_attention))
+        output_channel = rev_channels[0]
+        for i, up_block_type in enumerate(up_block_types):
+            is_final_block = i == n - 1
+            prev_output_channel, output_channel = output_channel, rev_channels[i]
+            input_channel = rev_channels[min(i + 1, n - 1)]
+            if not is_final_block:
+                self.num_upsamplers += 1
+            self.up_blocks.append(get_up_block(
+                up_block_type, num_layers=layers_per_block + 1, in_channels=input_channel,
+                out_channels=output_channel, prev_output_channel=prev_output_channel,
+                temb_channels=time_embed_dim, add_upsample=not is_final_block, resnet_eps=norm_eps,
+                resnet_act_fn=act_fn, resnet_groups=norm_num_groups, cross_attention_dim=cross_attention_dim,
+                attn_num_head_channels=rev_heads[i], dual_cross_attention=dual_cross_attention,
+                use_linear_projection=use_linear_projection, only_cross_attention=rev_only_cross[i],
+                upcast_attention=upcast_attention, resnet_time_scale_shift=resnet_time_scale_shift,
+                use_motion_module=use_motion_module and (2 ** (3 - i) in motion_module_resolutions),
+                motion_module_type=motion_module_type, motion_module_kwargs=motion_module_kwargs))
+
+        self.conv_norm_out = GroupNorm(num_channels=block_out_channels[0], num_groups=norm_num_groups, eps=norm_eps)
+        self.conv_act = nn.SiLU()
+        self.conv_out = InflatedConv3d(block_out_channels[0], out_channels, kernel_size=3, padding=1)
+
+    # ---- ModelMixin-style helpers --------------------------------------------------------------------
+    @property
+    def dtype(self) -> torch.dtype:
+        return next(self.parameters()).dtype
+
+    @property
+    def device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    @property
+    def in_channels(self):                      # pipeline_animation_cm_om.py:630 reads `unet.in_channels`
+        return self.config.in_channels
+
+    @classmethod
+    def extract_init_dict(cls, config_dict, **kwargs):
+        keys = set()
+        for klass in cls.__mro__:
+            if klass in (nn.Module, object):
+                continue
+            if "__init__" in klass.__dict__:
+                keys |= {k for k in inspect.signature(klass.__init__).parameters if k not in ("self", "kwargs")}
+        config_dict = {k: v for k, v in config_dict.items() if not k.startswith("_")}
+        init_dict, unused = {}, {}
+        for k in keys:
+            if k in kwargs:
+                init_dict[k] = kwargs.pop(k)
+            elif k in config_dict:
+                init_dict[k] = config_dict[k]
+        unused = {k: v for k, v in {**config_dict, **kwargs}.items() if k not in init_dict}
+        return init_dict, unused
+
+    @classmethod
+    def from_config(cls, config, return_unused_kwargs=False, **kwargs):
+        init_dict, unused = cls.extract_init_dict(dict(config), **kwargs)
+        model = cls(**init_dict)
+        return (model, unused) if return_unused_kwargs else model
+
+    @classmethod
+    def from_pretrained_2d(cls, pretrained_model_path, subfolder=None, unet_additional_kwargs=None, logger=None):
+        """Build from an SD-1.5 `unet/config.json` + `diffusion_pytorch_model.bin` (unet.py:762-826): block types are
+        overridden to the 3-D ones, weights load with `strict=False` (motion-module keys come from a later ckpt)."""
+        if subfolder is not None:
+            pretrained_model_path = os.path.join(pretrained_model_path, subfolder)
+        config_file = os.path.join(pretrained_model_path, "config.json")
+        if not os.path.isfile(config_file):
+            raise RuntimeError(f"{config_file} does not exist")
+        with open(config_file, "r") as fh:
+            config = json.load(fh)
+        config["_class_name"] = cls.__name__
+        config["down_block_types"] = ["CrossAttnDownBlock3D"] * 3 + ["DownBlock3D"]
+        config["up_block_types"] = ["UpBlock3D"] + ["CrossAttnUpBlock3D"] * 3
+        if "mid_block_type" in config:
+            config["mid_block_type"] = "UNetMidBlock3DCrossAttn"
+        model, unused = cls.from_config(config, return_unused_kwargs=True, **(unet_additional_kwargs or {}))
+        if logger is not None:
+            for k, v in unused.items():
+                logger.info(f"{k:50s}: {repr(v)}")
+        model_file = os.path.join(pretrained_model_path, WEIGHTS_NAME)
+        if not os.path.isfile(model_file):
+            raise RuntimeError(f"{model_file} does not exist")
+        state_dict = torch.load(model_file, map_location="cpu")
+        m, u = model.load_state_dict(state_dict, strict=False)
+        print(f"### missing keys: {len(m)}; \n### unexpected keys: {len(u)};")
+        params = [p.numel() if "motion_modules." in n else 0 for n, p in model.named_parameters()]
+        print(f"### Motion Module Parameters: {sum(params) / 1e6} M")
+        return model
+
+    # ---- processor registries (unet.py:322-468) ------------------------------------------------------
+    def _attention_modules(self, temporal: bool) -> Dict[str, nn.Module]:
+        return {f"{name}.processor": mod for name, mod in self.named_modules()
+                if hasattr(mod, "set_processor") and (("motion_modules." in name) == temporal)}
+
+    @property
+    def attn_processors(self) -> Dict[str, Any]:
+        return {k: m.processor for k, m in self._attention_modules(False).items()}
+
+    @property
+    def mm_attn_processors(self) -> Dict[str, Any]:
+        return {k: m.processor for k, m in self._attention_modules(True).items()}
+
+    def _install(self, temporal: bool, processor):
+        mods = self._attention_modules(temporal)
+        if isinstance(processor, dict) and len(processor) != len(mods):
+            raise ValueError(
+                f"A dict of processors was passed, but the number of processors {len(processor)} does not match the"
+                f" number of attention layers: {len(mods)}. Please make sure to pass {len(mods)} processor classes.")
+        for key, mod in mods.items():
+            mod.set_processor(processor.pop(key) if isinstance(processor, dict) else processor)
+
+    def set_attn_processor(self, processor):
+        self._install(False, processor)
+
+    def set_mm_attn_processor(self, processor):
+        self._install(True, processor)
+
+    def _block_width(self, name: str):
+        boc = self.config.block_out_channels
+        if name.startswith("mid_block"):
+            return boc[-1], -1, False
+        idx = int(name.split(".")[1])
+        if name.startswith("up_blocks"):
+            return list(reversed(boc))[idx], idx, True
+        assert name.startswith("down_blocks")
+        return boc[idx], idx, False
+
+    def set_image_layer_lora(self, image_layer_lora_rank: int = 128):
+        procs = {}
+        for name in self.attn_processors.keys():
+            hidden, _, _ = self._block_width(name)
+            cross = None if name.endswith("attn1.processor") else self.config.cross_attention_dim
+            procs[name] = LoRAAttnProcessor(hidden_size=hidden, cross_attention_dim=cross,
+                                            rank=image_layer_lora_rank if image_layer_lora_rank > 16
+                                            else hidden // image_layer_lora_rank)
+        self.set_attn_processor(procs)
+
+    def set_image_layer_lora_scale(self, lora_scale: float = 1.0):
+        for block in list(self.down_blocks) + list(self.up_blocks) + [self.mid_block]:
+            setattr(block, "lora_scale", lora_scale)
+
+    def set_motion_module_lora_scale(self, lora_scale: float = 1.0):
+        for block in list(self.down_blocks) + list(self.up_blocks) + [self.mid_block]:
+            setattr(block, "motion_lora_scale", lora_scale)
+
+    def set_attention_slice(self, slice_size):
+        pass                                     # flash-style kernels never materialise S x S: nothing to slice
+
+    def _set_gradient_checkpointing(self, module, value=False):
+        if isinstance(module, (CrossAttnDownBlock3D, DownBlock3D, CrossAttnUpBlock3D, UpBlock3D)):
+            module.gradient_checkpointing = value
+
+    # ---- forward ---------------------------------------------------------------------------------------
+    def _time_embedding(self, sample, timestep):
+        timesteps = timestep
+        if not torch.is_tensor(timesteps):
+            dtype = torch.float64 if isinstance(timestep, float) else torch.int64
+            timesteps = torch.tensor([timesteps], dtype=dtype, device=sample.device)
+        elif len(timesteps.shape) == 0:
+            timesteps = timesteps[None].to(sample.device)
+        timesteps = timesteps.expand(sample.shape[0])
+        return self.time_embedding(self.time_proj(timesteps).to(dtype=self.dtype))
+
+    def _run(self, sample, timestep, encoder_hidden_states, attention_mask, cross_attention_kwargs,
+             pose_embedding_features, traj_features, use_pose, return_dict):
+        if attention_mask is not None:
+            raise NotImplementedError("attention masks are never passed on the FMC path")
+        if use_pose and cross_attention_kwargs is not None:
+            raise ValueError("pass cross_attention_kwargs=None: the reference's `cross_attention_kwargs.update(...)` "
+                             "evaluates to None (unet_cam_obj.py:1222)")
+        default_overall_up_factor = 2 ** self.num_upsamplers
+        forward_upsample_size = any(s % default_overall_up_factor != 0 for s in sample.shape[-2:])
+        upsample_size = None
+        if self.config.center_input_sample:
+            sample = 2 * sample - 1.0
+        emb = self._time_embedding(sample, timestep)
+        if sample.dtype != self.dtype:
+            sample = sample.to(self.dtype)
+        if encoder_hidden_states.dtype != self.dtype:
+            encoder_hidden_states = encoder_hidden_states.to(self.dtype)
+        # text stays [B, 77, C]: the cross-attention kernel shares it across the F frames of a clip
+        sample = self.conv_in(sample)
+        down_block_res_samples = (sample,)
+        for i, downsample_block in enumerate(self.down_blocks):
+            pf = pose_embedding_features[i] if use_pose else None
+            mkw = {"pose_feature": pf} if use_pose else {}
+            if getattr(downsample_block, "has_cross_attention", False):
+                ckw = cross_attention_kwargs
+                if use_pose:
+                    ckw = {"pose_feature": pf}
+                    if traj_features is not None or self._pass_traj_none:
+                        ckw["traj_features"] = traj_features
+                sample, res_samples = downsample_block(
+                    hidden_states=sample, temb=emb, encoder_hidden_states=encoder_hidden_states,
+                    attention_mask=attention_mask, cross_attention_kwargs=ckw if ckw is not None else {},
+                    motion_cross_attention_kwargs=mkw)
+            else:
+                sample, res_samples = downsample_block(hidden_states=sample, temb=emb,
+                                                       cross_attention_kwargs={"pose_feature": pf} if use_pose else None,
+                                                       motion_cross_attention_kwargs=mkw)
+            down_block_res_samples += res_samples
+        mid_kw = {"pose_feature": pose_embedding_features[-1]} if use_pose else cross_attention_kwargs
+        sample = self.mid_block(sample, emb, encoder_hidden_states=encoder_hidden_states,
+                                attention_mask=attention_mask, cross_attention_kwargs=mid_kw,
+                                motion_cross_attention_kwargs=mid_kw if use_pose else None)
+        dec_pose = use_pose and getattr(self, "decoder_add_posecond", True)
+        for i, upsample_block in enumerate(self.up_blocks):
+            is_final_block = i == len(self.up_blocks) - 1
+            n_res = len(upsample_block.resnets)
+            res_samples = down_block_res_samples[-n_res:]
+            down_block_res_samples = down_block_res_samples[:-n_res]
+            if not is_final_block and forward_upsample_size:
+                upsample_size = down_block_res_samples[-1].shape[-2:]
+            pf = pose_embedding_features[-(i + 1)] if dec_pose else None
+            mkw = {"pose_feature": pf} if dec_pose else {}
+            ckw = {"pose_feature": pf} if dec_pose else cross_attention_kwargs
+            if getattr(upsample_block, "has_cross_attention", False):
+                sample = upsample_block(hidden_states=sample, temb=emb, res_hidden_states_tuple=res_samples,
+                                        encoder_hidden_states=encoder_hidden_states, upsample_size=upsample_size,
+                                        attention_mask=attention_mask, cross_attention_kwargs=ckw,
+                                        motion_cross_attention_kwargs=mkw)
+            else:
+                sample = upsample_block(hidden_states=sample, temb=emb, res_hidden_states_tuple=res_samples,
+                                        upsample_size=upsample_size, cross_attention_kwargs=ckw,
+                                        motion_cross_attention_kwargs=mkw)
+        x4, b, f = _frames_first(sample)
+        x4 = self.conv_norm_out(x4, act=True)              # GroupNorm + SiLU (`conv_act`) in one pass
+        sample = self.conv_out(_frames_back(x4, b, f))
+        if not return_dict:
+            return (sample,)
+        return UNet3DConditionOutput(sample=sample)
+
+    _pass_traj_none = False
+
+    def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, attention_mask=None,
+                cross_attention_kwargs=None, return_dict: bool = True, down_block_additional_residuals=None,
+                mid_block_additional_residual=None, motion_module_alphas=1.0, debug: bool = False):
+        if down_block_additional_residuals is not None or mid_block_additional_residual is not None:
+            raise NotImplementedError("ControlNet residuals are unused by FMC")
+        return self._run(sample, timestep, encoder_hidden_states, attention_mask, cross_attention_kwargs, None, None,
+                         False, return_dict)
+
+
+class UNet3DConditionModelPoseCond(UNet3DConditionModel):
+    """+ Camera-Adapter conditioning (reference unet.py:829-1300)."""
+
+    def __init__(self, decoder_add_posecond=True, **kwargs):
+        super().__init__(**kwargs)
+        self.decoder_add_posecond = decoder_add_posecond
+        self.config = FrozenConfig({**self.config, "decoder_add_posecond": decoder_add_posecond})
+
+    def set_all_attn_processor(self, add_spatial=False, spatial_attn_names="attn1", add_temporal=False,
+                               add_spatial_lora=True, add_motion_lora=False, temporal_attn_names="0",
+                               pose_feature_dimensions=[320, 640, 1280, 1280], lora_kwargs={}, motion_lora_kwargs={},
+                               **attention_processor_kwargs):
+        """Which processor class goes on which attention layer (unet.py:897-1031)."""
+        lora_kwargs, motion_lora_kwargs = dict(lora_kwargs), dict(motion_lora_kwargs)
+        lora_rank = lora_kwargs.pop("lora_rank")
+        motion_lora_rank = motion_lora_kwargs.pop("lora_rank")
+        pfd = list(pose_feature_dimensions)
+
+        def build(names, temporal, add_pose, add_lora, rank_cfg, selected, extra):
+            chosen, procs = selected.split(","), {}
+            for name in names:
+                attn_name = name.split(".")[-2]
+                hidden, idx, is_up = self._block_width(name)
+                if temporal:
+                    cross = None
+                elif add_pose:
+                    cross = None if attn_name == "attn1" else self.config.cross_attention_dim
+                else:
+                    cross = None if name.endswith("attn1.processor") else self.config.cross_attention_dim
+                pose = add_pose and attn_name in chosen
+                if pose and temporal and is_up:
+                    pose = self.decoder_add_posecond
+                pdim = (list(reversed(pfd))[idx] if is_up else pfd[idx]) if pose else None
+                rank = (rank_cfg if rank_cfg > 16 else hidden // rank_cfg) if add_lora else None
+                if pose and add_lora:
+                    procs[name] = LORAPoseAdaptorAttnProcessor(hidden_size=hidden, pose_feature_dim=pdim,
+                                                               cross_attention_dim=cross, rank=rank,
+                                                               **attention_processor_kwargs, **extra)
+                elif pose:
+                    procs[name] = PoseAdaptorAttnProcessor(hidden_size=hidden, pose_feature_dim=pdim,
+                                                           cross_attention_dim=cross, **attention_processor_kwargs)
+                elif add_lora:
+                    procs[name] = CustomizedLoRAAttnProcessor(hidden_size=hidden, cross_attention_dim=cross, rank=rank)
+                else:
+                    procs[name] = CustomizedAttnProcessor()
+            return procs
+
+        self.set_attn_processor(build(list(self.attn_processors.keys()), False, add_spatial, add_spatial_lora,
+                                      lora_rank, spatial_attn_names, lora_kwargs))
+        self.set_mm_attn_processor(build(list(self.mm_attn_processors.keys()), True, add_temporal, add_motion_lora,
+                                         motion_lora_rank, temporal_attn_names, motion_lora_kwargs))
+
+    def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, attention_mask=None,
+                cross_attention_kwargs=None, pose_embedding_features: List[torch.Tensor] = None,
+                return_dict: bool = True, down_block_additional_residuals=None, mid_block_additional_residual=None,
+                motion_module_alphas=1.0, debug: bool = False):
+        if down_block_additional_residuals is not None or mid_block_additional_residual is not None:
+            raise NotImplementedError("ControlNet residuals are unused by FMC")
+        return self._run(sample, timestep, encoder_hidden_states, attention_mask, cross_attention_kwargs,
+                         pose_embedding_features, None, pose_embedding_features is not None, return_dict)
+
+
+class UNet3DConditionModelCamObjCond(UNet3DConditionModelPoseCond):
+    """+ Object-Motion-Control features (reference unet_cam_obj.py:829-1375).  `traj_features` is handed to the
+    CrossAttn down blocks inside `cross_attention_kwargs` (:1222-1223), exactly like the reference -- including
+    when it is `None` -- so the down blocks must carry the `Adapted_*_forward` patch
+    (`synfmc_amd.modified_modules.patch_unet_for_omc`) whenever this class is used."""
+
+    _pass_traj_none = True
+
+    def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, attention_mask=None,
+                cross_attention_kwargs=None, pose_embedding_features: List[torch.Tensor] = None,
+                traj_features: List[torch.Tensor] = None, return_dict: bool = True,
+                down_block_additional_residuals=None, mid_block_additional_residual=None, motion_module_alphas=1.0,
+                debug: bool = False):
+        if down_block_additional_residuals is not None or mid_block_additional_residual is not None:
+            raise NotImplementedError("ControlNet residuals are unused by FMC")
+        if pose_embedding_features is None:
+            raise TypeError("pose_embedding_features is required (the reference zips over it, unet_cam_obj.py:1211)")
+        return self._run(sample, timestep, encoder_hidden_states, attention_mask, cross_attention_kwargs,
+                         pose_embedding_features, traj_features, True, return_dict)

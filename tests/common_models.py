@@ -1,0 +1,123 @@
+"""Builders shared by the CPU and GPU tests: a reduced FMC stack (same topology as configs/obj.yaml, narrower)
+instantiated twice -- the CPU oracle and the gfx950 product -- with identical seeded weights."""
+import copy
+
+import numpy as np
+import torch
+
+from oracle import conditioning as OC
+from oracle import fmc_modules as OM
+
+MMK = dict(num_attention_heads=8, num_transformer_block=1, attention_block_types=["Temporal_Self", "Temporal_Self"],
+           temporal_position_encoding=True, temporal_position_encoding_max_len=32, temporal_attention_dim_div=1,
+           zero_initialize=False)
+
+
+def unet_kwargs(widths=(64, 128, 256, 256), cross_dim=64, motion=True):
+    cfg = dict(OM.SD15_UNET_CONFIG)
+    cfg.update(block_out_channels=tuple(widths), cross_attention_dim=cross_dim, sample_size=16)
+    cfg.update(use_motion_module=motion, motion_module_resolutions=[1, 2, 4, 8], motion_module_mid_block=False,
+               motion_module_type="Vanilla", motion_module_kwargs=copy.deepcopy(MMK))
+    return cfg
+
+
+def processor_kwargs(widths, lora=True):
+    return dict(add_spatial=False, spatial_attn_names="attn1", add_temporal=True, temporal_attn_names="0",
+                add_spatial_lora=lora, add_motion_lora=False,
+                lora_kwargs={"lora_rank": 2, "lora_scale": 1.0}, motion_lora_kwargs={"lora_rank": -1, "lora_scale": 1.0},
+                pose_feature_dimensions=list(widths), query_condition=True, key_value_condition=True, scale=1.0)
+
+
+def encoder_kwargs(widths, max_len=16):
+    return dict(downscale_factor=8, channels=list(widths), nums_rb=2, cin=384, ksize=1, sk=True, use_conv=False,
+                compression_factor=1, temporal_attention_nhead=8, attention_block_types=["Temporal_Self"],
+                temporal_position_encoding=True, temporal_position_encoding_max_len=max_len)
+
+
+def adapter_kwargs(widths):
+    return dict(channels=list(widths), nums_rb=2, cin=832, sk=True, use_conv=False, use_pre_zero_conv=True,
+                use_post_zero_conv=True)
+
+
+def reseed(module, seed, std=0.05):
+    """Seeded N(0, std) for every parameter: zero-initialised layers (qkv_merge, zero convs, LoRA up) would make the
+    conditioning paths invisible otherwise.  Norm gains are centred on 1."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            v = torch.randn(p.shape, generator=g) * std
+            if p.ndim == 1 and ("norm" in name and name.endswith("weight")):
+                v = v + 1.0
+            p.copy_(v)
+    return module
+
+
+def build_oracle(widths=(64, 128, 256, 256), cross_dim=64, conditioned=True, lora=True, seed=0):
+    unet = OM.UNet3DConditionModelCamObjCond(**unet_kwargs(widths, cross_dim))
+    if conditioned:
+        unet.set_all_attn_processor(**processor_kwargs(widths, lora))
+        OM.patch_down_blocks_for_omc(unet)
+    reseed(unet, seed)
+    enc = reseed(OM.CameraPoseEncoder(**encoder_kwargs(widths)), seed + 1) if conditioned else None
+    ada = reseed(OM.Adapter(**adapter_kwargs(widths)), seed + 2) if conditioned else None
+    return unet.eval(), (enc.eval() if enc else None), (ada.eval() if ada else None)
+
+
+def build_product(oracle_unet, oracle_enc, oracle_ada, widths=(64, 128, 256, 256), cross_dim=64, conditioned=True,
+                  lora=True, device="cuda", dtype=torch.float32):
+    from synfmc_amd.adapter import Adapter
+    from synfmc_amd.models.pose_adaptor import CameraPoseEncoder
+    from synfmc_amd.models.unet import UNet3DConditionModelCamObjCond
+    from synfmc_amd.modified_modules import patch_unet_for_omc
+    unet = UNet3DConditionModelCamObjCond(**unet_kwargs(widths, cross_dim))
+    if conditioned:
+        unet.set_all_attn_processor(**processor_kwargs(widths, lora))
+        patch_unet_for_omc(unet)
+    missing, unexpected = unet.load_state_dict(oracle_unet.state_dict(), strict=True)
+    unet = unet.to(device=device, dtype=dtype).eval().requires_grad_(False)
+    enc = ada = None
+    if conditioned:
+        enc = CameraPoseEncoder(**encoder_kwargs(widths))
+        enc.load_state_dict(oracle_enc.state_dict(), strict=True)
+        enc = enc.to(device=device, dtype=dtype).eval().requires_grad_(False)
+        ada = Adapter(**adapter_kwargs(widths))
+        ada.load_state_dict(oracle_ada.state_dict(), strict=True)
+        ada = ada.to(device=device, dtype=dtype).eval().requires_grad_(False)
+    return unet, enc, ada
+
+
+def synthetic_clip(B=1, Fr=16, H=128, W=128, n_obj=3, cross_dim=64, seed=100):
+    """SURVEY.md section 8d synthetic inputs: latents, text, smooth relative camera trajectory, intrinsics,
+    per-object relative poses and Gaussian circle masks."""
+    g = torch.Generator().manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    latents = torch.randn(B, 4, Fr, H // 8, W // 8, generator=g)
+    text = torch.randn(B, 77, cross_dim, generator=g)
+    c2w = np.zeros((B, Fr, 3, 4), dtype=np.float32)
+    for b in range(B):
+        ang, t = np.zeros(3), np.zeros(3)
+        for f in range(Fr):
+            if f:
+                ang += rng.normal(0, 0.02, 3)
+                t += rng.normal(0, 0.03, 3)
+            cx, cy, cz = np.cos(ang)
+            sx, sy, sz = np.sin(ang)
+            Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+            Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+            Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+            c2w[b, f, :, :3] = Rz @ Ry @ Rx
+            c2w[b, f, :, 3] = t
+    K = torch.tensor([float(W), float(W), W / 2.0, H / 2.0]).view(1, 1, 4).repeat(B, Fr, 1)
+    infos, masks = [], []
+    for b in range(B):
+        ctr = rng.uniform([W * 0.25, H * 0.25], [W * 0.75, H * 0.75], size=(n_obj, 2))
+        rad = rng.uniform(min(H, W) * 0.12, min(H, W) * 0.3, size=n_obj)
+        fi, fm = [], []
+        for f in range(Fr):
+            ctr = ctr + rng.normal(0, 1.5, size=ctr.shape)
+            fm.append(torch.from_numpy(np.stack(
+                [OC.gaussian_circle_mask(H, W, ctr[o], rad[o])[None] for o in range(n_obj)])).float())
+            fi.append(rng.normal(0, 0.5, size=(n_obj, 12)))
+        infos.append(fi)
+        masks.append(fm)
+    return dict(latents=latents, text=text, c2w=torch.from_numpy(c2w), K=K, infos=infos, masks=masks)

@@ -1,0 +1,110 @@
+"""End-to-end parity of the gfx950 product path against the CPU oracle on a reduced FMC stack
+(same topology as configs/obj.yaml, widths 64/128/256/256, 16 frames, 128x128 pixels).
+
+Tolerances (rel-inf): fp32 storage 1e-3 (the north-star's figure); bf16 storage 6e-2 end to end
+(8 mantissa bits through ~60 sequential layers; stated, not hidden).
+"""
+import pytest
+import torch
+from einops import rearrange
+
+from oracle import conditioning as OC
+from oracle import diffusers_restated as OD
+from oracle import pipeline as OP
+from tests import common_models as CM
+
+pytestmark = pytest.mark.gpu
+W4 = (64, 128, 256, 256)
+
+
+def rel_inf(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.fixture(scope="module")
+def stack():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    ou, oe, oa = CM.build_oracle(W4)
+    clip = CM.synthetic_clip(B=1, Fr=16, H=128, W=128)
+    with torch.no_grad():
+        plucker = OC.to_plucker_embedding(clip["c2w"], clip["K"], (128, 128))            # [B,F,6,H,W]
+        pose_emb = rearrange(plucker, "b f c h w -> b c f h w")
+        pose_feats = [rearrange(x, "(b f) c h w -> b c f h w", b=1) for x in oe(pose_emb)]
+        traj = OC.get_traj_features(clip["infos"], clip["masks"], oa)
+        t = torch.tensor([801])
+        ref = ou(clip["latents"], t, clip["text"], pose_embedding_features=pose_feats, traj_features=traj).sample
+        ref_notraj = ou(clip["latents"], t, clip["text"], pose_embedding_features=pose_feats, traj_features=None).sample
+    return dict(ou=ou, oe=oe, oa=oa, clip=clip, pose_emb=pose_emb, pose_feats=pose_feats, traj=traj, t=t, ref=ref,
+                ref_notraj=ref_notraj)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
+def test_conditioning_encoders(stack, dtype, tol):
+    from synfmc_amd.data.dataset import to_plucker_embedding
+    from synfmc_amd.util import get_traj_features_v2
+    pu, pe, pa = CM.build_product(stack["ou"], stack["oe"], stack["oa"], W4, dtype=dtype)
+    clip = stack["clip"]
+    emb = to_plucker_embedding(clip["c2w"], clip["K"], (128, 128))                       # [B,F,6,H,W] on device
+    assert rel_inf(emb, rearrange(stack["pose_emb"], "b c f h w -> b f c h w")) < 2e-6
+    feats = pe(rearrange(emb, "b f c h w -> b c f h w").to(dtype))
+    for got, want in zip(feats, stack["pose_feats"]):
+        assert rel_inf(rearrange(got.float(), "(b f) c h w -> b c f h w", b=1), want) < tol
+    traj = get_traj_features_v2(clip["infos"], clip["masks"], pa, False, 0.0, [False], 0, dtype)
+    for got, want in zip(traj, stack["traj"]):
+        assert got.shape == want.shape
+        assert rel_inf(got.float(), want) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
+def test_unet_forward_cmc_omc(stack, dtype, tol):
+    pu, pe, pa = CM.build_product(stack["ou"], stack["oe"], stack["oa"], W4, dtype=dtype)
+    clip = stack["clip"]
+    dev = lambda x: x.to("cuda", dtype)
+    pose = [dev(x) for x in stack["pose_feats"]]
+    traj = [dev(x) for x in stack["traj"]]
+    with torch.no_grad():
+        out = pu(dev(clip["latents"]), stack["t"].cuda(), dev(clip["text"]), pose_embedding_features=pose,
+                 traj_features=traj).sample
+        out0 = pu(dev(clip["latents"]), stack["t"].cuda(), dev(clip["text"]), pose_embedding_features=pose,
+                  traj_features=None).sample
+    assert out.shape == stack["ref"].shape
+    assert rel_inf(out.float(), stack["ref"]) < tol
+    assert rel_inf(out0.float(), stack["ref_notraj"]) < tol
+    # the OMC features must matter (guards against a silently skipped injection)
+    assert rel_inf(stack["ref"], stack["ref_notraj"]) > 10 * tol
+
+
+def test_unet_forward_unconditioned_base(stack):
+    """BASELINE config 1 topology: base U-Net, plain processors, no adapters."""
+    from synfmc_amd.models.unet import UNet3DConditionModel
+    ou, _, _ = CM.build_oracle(W4, conditioned=False, seed=7)
+    clip = stack["clip"]
+    base = UNet3DConditionModel(**CM.unet_kwargs(W4, 64))
+    base.load_state_dict(ou.state_dict(), strict=True)
+    base = base.cuda().eval()
+    with torch.no_grad():
+        ref = ou(clip["latents"], 500, clip["text"]).sample
+        out = base(clip["latents"].cuda(), 500, clip["text"].cuda()).sample
+    assert rel_inf(out, ref) < 1e-3
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_denoising_loop_cfg_omcm_gate(stack, use_graph):
+    """6 DDIM steps with CFG 2.0 (a larger scale amplifies fp32 round-off ~10x per step on random weights) and `omcm_min_step=700` (OMC active for t >= 700 only), fp32 parity mode."""
+    from synfmc_amd.pipelines.pipeline_animation_cm_om import CameraObjCtrlPipeline
+    from synfmc_amd.schedulers import DDIMScheduler
+    kw = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1,
+              clip_sample=False)
+    clip = stack["clip"]
+    g = torch.Generator().manual_seed(5)
+    text2 = torch.cat([torch.randn(1, 77, 64, generator=g), clip["text"]])
+    ref = OP.denoise(stack["ou"], OD.DDIMScheduler(**kw), stack["oe"], text2, stack["pose_emb"], clip["latents"],
+                     num_inference_steps=6, guidance_scale=2.0, traj_features=stack["traj"], omcm_min_step=700)
+    pu, pe, pa = CM.build_product(stack["ou"], stack["oe"], stack["oa"], W4)
+    pipe = CameraObjCtrlPipeline(None, None, None, pu, DDIMScheduler(**kw), pe)
+    out = pipe(None, stack["pose_emb"].cuda(), 16, traj_features=[t.cuda() for t in stack["traj"]], height=128,
+               width=128, num_inference_steps=6, guidance_scale=2.0, latents=clip["latents"].cuda(),
+               output_type="latent", prompt_embeds=text2.cuda(), omcm_min_step=700, use_graph=use_graph).videos
+    assert rel_inf(out, ref) < 1e-2      # CFG multiplies fp32 round-off by ~g*sqrt(2) per step

@@ -1,0 +1,147 @@
+"""Host-side logic of the product (module wiring, channels-last plumbing, processor installation, kwargs routing,
+pipeline loop) checked against the CPU oracle with the HIP kernels replaced by CPU stand-ins
+(`tests/fake_kernels.py`; test infrastructure, never a product fallback).  The same comparisons run for real on
+the GPU in tests/test_gpu_model.py."""
+import pytest
+import torch
+from einops import rearrange
+
+from oracle import conditioning as OC
+from oracle import diffusers_restated as OD
+from oracle import pipeline as OP
+from tests import common_models as CM
+from tests import fake_kernels
+
+W4 = (32, 64, 64, 64)          # head dims 4/8/8/8: fine for the stand-ins (the real kernels need D % 8 == 0)
+
+
+def rel_inf(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.fixture()
+def fake(monkeypatch):
+    fake_kernels.install(monkeypatch)
+
+
+@pytest.fixture(scope="module")
+def stack():
+    ou, oe, oa = CM.build_oracle(W4, cross_dim=32)
+    clip = CM.synthetic_clip(B=1, Fr=16, H=64, W=64, cross_dim=32)
+    with torch.no_grad():
+        pose_emb = rearrange(OC.to_plucker_embedding(clip["c2w"], clip["K"], (64, 64)), "b f c h w -> b c f h w")
+        pose_feats = [rearrange(x, "(b f) c h w -> b c f h w", b=1) for x in oe(pose_emb)]
+        traj = OC.get_traj_features(clip["infos"], clip["masks"], oa)
+        t = torch.tensor([801])
+        ref = ou(clip["latents"], t, clip["text"], pose_embedding_features=pose_feats, traj_features=traj).sample
+        ref0 = ou(clip["latents"], t, clip["text"], pose_embedding_features=pose_feats, traj_features=None).sample
+    return dict(ou=ou, oe=oe, oa=oa, clip=clip, pose_emb=pose_emb, pose_feats=pose_feats, traj=traj, t=t, ref=ref,
+                ref0=ref0)
+
+
+def test_product_fails_loudly_without_gpu():
+    from synfmc_amd import hip_ops as K
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        K.groupnorm_silu(torch.zeros(1, 4, 32), torch.ones(32), torch.zeros(32), 32, 1e-5, True)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        K.spatial_attention(torch.zeros(1, 4, 64), torch.zeros(1, 4, 64), torch.zeros(1, 4, 64), 8)
+
+
+def test_state_dict_keys_match_oracle(stack):
+    pu, pe, pa = CM.build_product(stack["ou"], stack["oe"], stack["oa"], W4, cross_dim=32, device="cpu")
+    assert set(pu.state_dict()) == set(stack["ou"].state_dict())
+    assert list(pe.state_dict()) == list(stack["oe"].state_dict())
+    assert list(pa.state_dict()) == list(stack["oa"].state_dict())
+    assert len(pu.attn_processors) == 32 and len(pu.mm_attn_processors) == 40
+    kinds = [type(p).__name__ for p in pu.mm_attn_processors.values()]
+    assert kinds.count("PoseAdaptorAttnProcessor") == 20 and kinds.count("AttnProcessor") == 20
+    with pytest.raises(ValueError, match="number of processors"):
+        pu.set_attn_processor({"x": None})
+
+
+def test_conditioning_encoders_plumbing(stack, fake):
+    from synfmc_amd.data.dataset import to_plucker_embedding
+    from synfmc_amd.models.pose_adaptor import features_to_video
+    from synfmc_amd.util import get_traj_features_v2
+    pu, pe, pa = CM.build_product(stack["ou"], stack["oe"], stack["oa"], W4, cross_dim=32, device="cpu")
+    clip = stack["clip"]
+    emb = to_plucker_embedding(clip["c2w"], clip["K"], (64, 64), device="cpu")
+    assert rel_inf(rearrange(emb, "b f c h w -> b c f h w"), stack["pose_emb"]) < 1e-6
+    feats = features_to_video(pe(rearrange(emb, "b f c h w -> b c f h w")), 1)
+    for got, want in zip(feats, stack["pose_feats"]):
+        assert got.shape == want.shape and rel_inf(got, want) < 1e-4
+    emb_u = to_plucker_embedding(clip["c2w"], clip["K"], (64, 64), device="cpu", layout="unshuffle8")
+    for got, want in zip(features_to_video(pe.forward_unshuffled(emb_u, 1), 1), stack["pose_feats"]):
+        assert rel_inf(got, want) < 1e-4
+    traj = get_traj_features_v2(clip["infos"], clip["masks"], pa, False, 0.0, [False], "cpu", torch.float32)
+    for got, want in zip(traj, stack["traj"]):
+        assert got.shape == want.shape and rel_inf(got, want) < 1e-4
+    planar = pa(*fake_kernels.omc_rasterize(*_stacked(clip), "planar"))
+    for got, want in zip(features_to_video(planar, 1), stack["traj"]):
+        assert rel_inf(got, want) < 1e-4
+
+
+def _stacked(clip):
+    from synfmc_amd.util import stack_object_inputs
+    return stack_object_inputs(clip["infos"], clip["masks"], "cpu")
+
+
+def test_unet_plumbing_cmc_omc(stack, fake):
+    pu, pe, pa = CM.build_product(stack["ou"], stack["oe"], stack["oa"], W4, cross_dim=32, device="cpu")
+    clip = stack["clip"]
+    with torch.no_grad():
+        out = pu(clip["latents"], stack["t"], clip["text"], pose_embedding_features=stack["pose_feats"],
+                 traj_features=stack["traj"]).sample
+        out0 = pu(clip["latents"], stack["t"], clip["text"], pose_embedding_features=stack["pose_feats"],
+                  traj_features=None).sample
+    assert out.shape == stack["ref"].shape
+    assert rel_inf(out, stack["ref"]) < 1e-3
+    assert rel_inf(out0, stack["ref0"]) < 1e-3
+    assert rel_inf(stack["ref"], stack["ref0"]) > 1e-3
+
+
+def test_unpatched_block_rejects_traj_features(stack, fake):
+    from synfmc_amd.models.unet import UNet3DConditionModelCamObjCond
+    unet = UNet3DConditionModelCamObjCond(**CM.unet_kwargs(W4, 32))
+    unet.set_all_attn_processor(**CM.processor_kwargs(W4))
+    clip = stack["clip"]
+    with pytest.raises(TypeError, match="traj_features"):
+        unet(clip["latents"], 1, clip["text"], pose_embedding_features=stack["pose_feats"], traj_features=None)
+
+
+def test_pose_adaptor_wrappers(stack, fake):
+    from synfmc_amd.models.pose_obj_adaptor import CamObjPoseAdaptor
+    pu, pe, pa = CM.build_product(stack["ou"], stack["oe"], stack["oa"], W4, cross_dim=32, device="cpu")
+    clip = stack["clip"]
+    with torch.no_grad():
+        out = CamObjPoseAdaptor(pu, pe)(clip["latents"], stack["t"], clip["text"], stack["pose_emb"], stack["traj"])
+    assert rel_inf(out, stack["ref"]) < 1e-3
+
+
+def test_unconditioned_base_unet(stack, fake):
+    from synfmc_amd.models.unet import UNet3DConditionModel
+    ou, _, _ = CM.build_oracle(W4, cross_dim=32, conditioned=False, seed=7)
+    base = UNet3DConditionModel(**CM.unet_kwargs(W4, 32))
+    base.load_state_dict(ou.state_dict(), strict=True)
+    clip = stack["clip"]
+    with torch.no_grad():
+        assert rel_inf(base.eval()(clip["latents"], 500, clip["text"]).sample,
+                       ou(clip["latents"], 500, clip["text"]).sample) < 1e-3
+
+
+def test_denoising_loop_plumbing(stack, fake):
+    from synfmc_amd.pipelines.pipeline_animation_cm_om import CameraObjCtrlPipeline
+    from synfmc_amd.schedulers import DDIMScheduler
+    kw = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1,
+              clip_sample=False)
+    clip = stack["clip"]
+    text2 = torch.cat([torch.randn(1, 77, 32, generator=torch.Generator().manual_seed(5)), clip["text"]])
+    ref = OP.denoise(stack["ou"], OD.DDIMScheduler(**kw), stack["oe"], text2, stack["pose_emb"], clip["latents"],
+                     num_inference_steps=4, guidance_scale=2.0, traj_features=stack["traj"], omcm_min_step=700)
+    pu, pe, pa = CM.build_product(stack["ou"], stack["oe"], stack["oa"], W4, cross_dim=32, device="cpu")
+    pipe = CameraObjCtrlPipeline(None, None, None, pu, DDIMScheduler(**kw), pe)
+    out = pipe(None, stack["pose_emb"], 16, traj_features=stack["traj"], height=64, width=64, num_inference_steps=4,
+               guidance_scale=2.0, latents=clip["latents"], output_type="latent", prompt_embeds=text2,
+               omcm_min_step=700, use_graph=False).videos
+    assert rel_inf(out, ref) < 5e-3      # CFG multiplies fp32 round-off by ~g*sqrt(2) per step
