@@ -132,7 +132,9 @@ def cpu_baseline(budget_s=25.0):
     batch 1 (no CFG); scaled to the metric's unit by analytic FLOPs (the oracle is the 'port')."""
     from oracle import fmc_modules as OM
     from tests import common_models as CM
-    cores = os.cpu_count() or 1
+    # oneDNN/OpenMP scaling collapses far below the 256 hardware threads of the GPU node (measured: 427 s with 256, 5.6 s with 64, 2.6 s with 32, 1.6 s with 16, 2.3 s with 8
+    # threads for the same sample), so the port is timed on a fixed, stated number of cores
+    cores = min(os.cpu_count() or 1, int(os.environ.get("FMC_CPU_BASELINE_THREADS", "16")))
     torch.set_num_threads(cores)
     sh, sw = 128 // 8, 192 // 8
     with torch.device("meta"):

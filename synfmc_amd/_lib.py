@@ -60,6 +60,9 @@ def load() -> ctypes.CDLL:
         raise FmcLibraryMissing(
             f"{LIB_PATH} not found: build it with `make -C synfmc_amd/csrc` (hipcc --offload-arch=gfx950). "
             "There is no fallback path.")
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; it must be the HIP runtime this library binds to (streams and
+    # device pointers are torch's), so make sure torch's copy is the one already mapped when we dlopen.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol

@@ -185,10 +185,10 @@ def test_plucker_against_golden_and_oracle(K, golden_dir):
     out = K.plucker(Kt.cuda(), c2w.cuda(), H, W, "bfhwc")
     assert rel_inf(out, torch.from_numpy(g["out"])) < 2e-6                     # the reference's own output
     out1 = K.plucker(Kt.cuda(), c2w[:, :, :3].contiguous().cuda(), H, W, "bcfhw")
-    assert torch.equal(out1.cpu(), out.permute(0, 4, 1, 2, 3).cpu())
+    assert rel_inf(out1, out.permute(0, 4, 1, 2, 3)) < 1e-6       # same math, separate template instance (fma contraction)
     out2 = K.plucker(Kt.cuda(), c2w.cuda(), H, W, "unshuffle8")
     ref2 = F.pixel_unshuffle(out.permute(0, 1, 4, 2, 3).reshape(-1, 6, H, W), 8).permute(0, 2, 3, 1)
-    assert torch.equal(out2.cpu(), ref2.cpu())
+    assert rel_inf(out2, ref2) < 1e-6
     Kb, cb = torch.from_numpy(g["K_b"]), torch.from_numpy(g["c2w_b"])
     outb = K.plucker(Kb.cuda(), cb.cuda(), int(g["H_b"]), int(g["W_b"]), "bfhwc")
     assert rel_inf(outb[:, :, :: int(g["row_step"])], torch.from_numpy(g["out_b"])) < 2e-6

@@ -73,7 +73,7 @@ def test_unet_forward_cmc_omc(stack, dtype, tol):
     assert rel_inf(out.float(), stack["ref"]) < tol
     assert rel_inf(out0.float(), stack["ref_notraj"]) < tol
     # the OMC features must matter (guards against a silently skipped injection)
-    assert rel_inf(stack["ref"], stack["ref_notraj"]) > 10 * tol
+    assert rel_inf(stack["ref"], stack["ref_notraj"]) > 0.1
 
 
 def test_unet_forward_unconditioned_base(stack):
