@@ -35,16 +35,17 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 typedef unsigned short bf16_t;  // raw storage
 
-// round-to-nearest-even float -> bf16 (inputs are finite on this path; NaN keeps a quiet pattern)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
-__device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((unsigned)b) << 16); }
+// float -> bf16, round-to-nearest-even, through the hardware converter (v_cvt_pk_bf16_f32 on gfx950: one VALU op
+// per PAIR of values; the integer add/shift sequence costs ~5 ops per value)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
-    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+    union { bf16x2_t v; unsigned u; } r;
+    r.v = __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t);
+    return r.u;
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
+__device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((unsigned)b) << 16); }
 
 // 8 consecutive activations <-> 8 floats, for both storage types
 template <typename T> struct Vec8;

@@ -241,9 +241,10 @@ __global__ void gn_apply_bwd_kernel(const T* __restrict__ dy, const T* __restric
 }
 
 // --------------------------------------------------------------------------------------------
-// LayerNorm (+ positional-encoding add): one wave per token row, row kept in registers.
+// LayerNorm (+ positional-encoding add): one wave normalises R token rows at a time; all R rows are
+// loaded (16 B per lane per chunk) before the first reduction so that R*NCH loads are in flight per lane.
 // --------------------------------------------------------------------------------------------
-template <typename T, int NCH>  // NCH = ceil(C/8/64) chunks of 8 per lane
+template <typename T, int NCH, int R>  // NCH = ceil(C/8/64) chunks of 8 per lane
 __global__ void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ gamma,
                                  const float* __restrict__ beta, const float* __restrict__ pe, int64_t M, int C,
                                  float eps, int pe_inner, int pe_frames) {
@@ -251,43 +252,71 @@ __global__ void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y, con
     const int wave = threadIdx.x >> 6;
     const int wpb = blockDim.x >> 6;
     const int nchunks = C / 8;
-    for (int64_t row = (int64_t)blockIdx.x * wpb + wave; row < M; row += (int64_t)gridDim.x * wpb) {
-        float v[NCH][8];
-        float sum = 0.f;
+    const float inv_c = 1.f / (float)C;
+    for (int64_t row0 = ((int64_t)blockIdx.x * wpb + wave) * R; row0 < M; row0 += (int64_t)gridDim.x * wpb * R) {
+        float v[R][NCH][8];
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            int ch = lane + 64 * k;
-            if (ch < nchunks) {
-                Vec8<T>::load(x + row * C + ch * 8, v[k]);
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = row0 + r;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) sum += v[k][i];
-            } else {
+            for (int k = 0; k < NCH; ++k) {
+                const int ch = lane + 64 * k;
+                if (row < M && ch < nchunks) Vec8<T>::load(x + row * C + ch * 8, v[r][k]);
+                else {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[k][i] = 0.f;
+                    for (int i = 0; i < 8; ++i) v[r][k][i] = 0.f;
+                }
             }
         }
-        const float mean = wave_sum(sum) / (float)C;
-        float sq = 0.f;
+        float mean[R], rstd[R];
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            int ch = lane + 64 * k;
-            if (ch < nchunks) {
+        for (int r = 0; r < R; ++r) {
+            float s = 0.f;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { float d = v[k][i] - mean; sq += d * d; }
-            }
+            for (int k = 0; k < NCH; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s += v[r][k][i];
+            mean[r] = s;
         }
-        const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
-        const float* per = pe ? pe + (size_t)((row / pe_inner) % pe_frames) * C : nullptr;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int r = 0; r < R; ++r) mean[r] += __shfl_xor(mean[r], o, 64);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            mean[r] *= inv_c;
+            float q = 0.f;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                if (lane + 64 * k < nchunks) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { float d = v[r][k][i] - mean[r]; q += d * d; }
+                }
+            }
+            rstd[r] = q;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int r = 0; r < R; ++r) rstd[r] += __shfl_xor(rstd[r], o, 64);
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
-            int ch = lane + 64 * k;
-            if (ch < nchunks) {
+            const int ch = lane + 64 * k;
+            if (ch >= nchunks) continue;
+            float gm[8], bt[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { gm[i] = gamma[ch * 8 + i]; bt[i] = beta[ch * 8 + i]; }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int64_t row = row0 + r;
+                if (row >= M) continue;
+                const float rs = rsqrtf(rstd[r] * inv_c + eps);
+                const float* per = pe ? pe + (size_t)((row / pe_inner) % pe_frames) * C + ch * 8 : nullptr;
                 float o[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    int c = ch * 8 + i;
-                    o[i] = (v[k][i] - mean) * rstd * gamma[c] + beta[c];
-                    if (per) o[i] += per[c];
+                    o[i] = (v[r][k][i] - mean[r]) * rs * gm[i] + bt[i];
+                    if (per) o[i] += per[i];
                 }
                 Vec8<T>::store(y + row * C + ch * 8, o);
             }
@@ -388,19 +417,21 @@ static void launch_ln(const void* x, void* y, const float* gamma, const float* b
                       float eps, int pe_inner, int pe_frames, hipStream_t st) {
     const int nch = (C / 8 + 63) / 64;
     const int wpb = 4;
-    int64_t blocks = (M + wpb - 1) / wpb;
-    if (blocks > 8192) blocks = 8192;
+    const int R = nch <= 3 ? 4 : 2;
+    int64_t blocks = (M + wpb * R - 1) / (wpb * R);
+    if (blocks > 65536) blocks = 65536;
     dim3 grid((unsigned)blocks), block(64 * wpb);
-#define LN_CASE(K)                                                                                                  \
-    case K:                                                                                                         \
-        hipLaunchKernelGGL((layernorm_kernel<T, K>), grid, block, 0, st, (const T*)x, (T*)y, gamma, beta, pe, M, C, \
-                           eps, pe_inner, pe_frames);                                                               \
+#define LN_CASE(K, RR)                                                                                                  \
+    case K:                                                                                                             \
+        hipLaunchKernelGGL((layernorm_kernel<T, K, RR>), grid, block, 0, st, (const T*)x, (T*)y, gamma, beta, pe, M, C, \
+                           eps, pe_inner, pe_frames);                                                                   \
         break;
     switch (nch) {
-        LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5)
+        LN_CASE(1, 4) LN_CASE(2, 4) LN_CASE(3, 4) LN_CASE(4, 2) LN_CASE(5, 2)
         default: break;
     }
 #undef LN_CASE
+    (void)R;
 }
 
 extern "C" int fmc_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, const float* pe,

@@ -108,10 +108,79 @@ template <> __device__ __forceinline__ void store4<float>(float* p, float a, flo
 }
 
 // NKS: number of 16-wide k-steps of the QK^T reduction (D padded to 16*NKS); NDT = ceil(NKS/2)
+// One 32-key x 32-query block for one wave: S^T = K Q^T, online softmax, O^T += V^T P^T.
+//
+// Online softmax with a deferred rescale: scores are exponentiated against the running reference m_run, which is
+// only raised (and O^T / l rescaled) when some query's block maximum exceeds it by more than RESCALE_THR (log2
+// units), a wave-uniform and -- after the first block -- rare branch.  Until then p = 2^(s - m_run) <= 2^THR, which
+// fp32 accumulation absorbs; the final O / l is independent of the reference.  This removes the per-block
+// accumulator rescale (32-80 multiplies + AGPR round trips) from the common path.
+constexpr float RESCALE_THR = 8.f;
+
+template <typename T, int NKS, bool TAIL>
+__device__ __forceinline__ void attn_block(const T* __restrict__ Ks, const T* __restrict__ Vt, const Frag<T> (&qf)[NKS],
+                                           f32x16 (&oacc)[(NKS + 1) / 2], float& m_run, float& l_run, int sb, int kvb,
+                                           int Skv, float scale_log2, int l31, int half) {
+    constexpr int NDT = (NKS + 1) / 2;
+    constexpr int KP = NKS * 16 + 8;
+    constexpr int VP = SA_BK + 4;
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        Frag<T> kf;
+        make_frag<T>(Ks + (sb * 32 + l31) * KP + ks * 16 + half * 8, kf);
+        mma32(kf, qf[ks], s);
+    }
+    if (TAIL) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (kvb + (r & 3) + 8 * (r >> 2) + 4 * half >= Skv) s[r] = -INFINITY;
+    }
+    float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+#pragma unroll
+    for (int r = 4; r < 16; r += 4) mx = fmaxf(mx, fmaxf(fmaxf(s[r], s[r + 1]), fmaxf(s[r + 2], s[r + 3])));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2;      // scale > 0
+    if (__any(mx > m_run + RESCALE_THR)) {
+        const float m_new = fmaxf(m_run, mx);                  // finite: the first block always holds key 0
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+        m_run = m_new;
+    }
+    float p[16];
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        p[r] = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2, -m_run));
+        psum += p[r];
+    }
+    l_run += psum;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        float p8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p8[i] = p[s2 * 8 + i];
+        Frag<T> pf;
+        p_frag(p8, pf);
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            const T* vrow = Vt + (dt * 32 + l31) * VP + sb * 32 + s2 * 16 + half * 4;
+            Frag<T> vf;
+            make_frag_2x4<T>(vrow, vrow + 8, vf);
+            mma32(vf, pf, oacc[dt]);
+        }
+    }
+}
+
 // SHORT_KV only separates the text cross-attention launches (S_kv = 77) from the self-attention ones in profiles
 // (same code path): the two differ by >10x in work per launch and would blur a per-kernel-name average.
 template <typename T, int NKS, bool SHORT_KV>
-__global__ __launch_bounds__(64 * SA_WAVES) void spatial_attn_kernel(const SAParams P) {
+__global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 ? 3 : 2) : 1) void spatial_attn_kernel(const SAParams P) {
     constexpr int NDT = (NKS + 1) / 2;
     constexpr int DP16 = NKS * 16;
     constexpr int KP = DP16 + 8;        // K tile pitch (elements)
@@ -195,65 +264,15 @@ __global__ __launch_bounds__(64 * SA_WAVES) void spatial_attn_kernel(const SAPar
         }
         __syncthreads();
 
+        if (kv0 + SA_BK <= P.Skv) {                       // full tile: no key masking anywhere
 #pragma unroll
-        for (int sb = 0; sb < SA_BK / 32; ++sb) {
-            const int kvb = kv0 + sb * 32;
-            if (kvb >= P.Skv) break;  // block-uniform
-            // ---- S^T[32 keys x 32 queries] ---------------------------------------------------------
-            f32x16 s;
+            for (int sb = 0; sb < SA_BK / 32; ++sb)
+                attn_block<T, NKS, false>(Ks, Vt, qf, oacc, m_run, l_run, sb, kv0 + sb * 32, P.Skv, P.scale_log2, l31, half);
+        } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                Frag<T> kf;
-                make_frag<T>(Ks + (sb * 32 + l31) * KP + ks * 16 + half * 8, kf);
-                mma32(kf, qf[ks], s);
-            }
-            // ---- online softmax over the key axis (lane-local + the other half-wave) ----------------
-            float mx = -INFINITY;
-            const bool tail = (kvb + 32 > P.Skv);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float x = s[r] * P.scale_log2;
-                if (tail) {
-                    const int kv = kvb + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (kv >= P.Skv) x = -INFINITY;
-                }
-                s[r] = x;
-                mx = fmaxf(mx, x);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);  // finite: the first block always holds key 0
-            const float alpha = exp2f(m_run - m_new);
-            float psum = 0.f;
-            float p[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                p[r] = exp2f(s[r] - m_new);
-                psum += p[r];
-            }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
-            // ---- O^T += V^T P^T ------------------------------------------------------------------------
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                float p8[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) p8[i] = p[s2 * 8 + i];
-                Frag<T> pf;
-                p_frag(p8, pf);
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) {
-                    const T* vrow = Vt + (dt * 32 + l31) * VP + sb * 32 + s2 * 16 + half * 4;
-                    Frag<T> vf;
-                    make_frag_2x4<T>(vrow, vrow + 8, vf);
-                    mma32(vf, pf, oacc[dt]);
-                }
-            }
+            for (int sb = 0; sb < SA_BK / 32; ++sb)
+                if (kv0 + sb * 32 < P.Skv)                 // block-uniform
+                    attn_block<T, NKS, true>(Ks, Vt, qf, oacc, m_run, l_run, sb, kv0 + sb * 32, P.Skv, P.scale_log2, l31, half);
         }
     }
 

@@ -82,7 +82,20 @@ class Conv2d(nn.Conv2d):
             return from_tokens(y, h, w)
         if not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)
-        return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        return F.conv2d(x, self._weight_cl(), self.bias, self.stride, self.padding, self.dilation, self.groups)
+
+    def _weight_cl(self) -> torch.Tensor:
+        """The filter in channels-last memory format.  ATen's MIOpen path otherwise re-lays-out the (up to 29 MB)
+        filter on EVERY call when the input is channels-last; frozen weights are converted once and cached."""
+        w = self.weight
+        if w.is_contiguous(memory_format=torch.channels_last) or (torch.is_grad_enabled() and w.requires_grad):
+            return w
+        key = (w.data_ptr(), w._version)
+        hit = self.__dict__.get("_w_cl")
+        if hit is None or hit[0] != key:
+            hit = (key, w.detach().contiguous(memory_format=torch.channels_last))
+            self.__dict__["_w_cl"] = hit
+        return hit[1]
 
 
 class Linear(nn.Linear):

@@ -51,7 +51,8 @@ def gemm_case(M, Kd, N, bias=True):
 
 def main():
     print(torch.__version__, torch.cuda.get_device_name(0), "NHWC env", os.environ.get("PYTORCH_MIOPEN_SUGGEST_NHWC"))
-    for bm in (False, True):
+    only_kernels = os.environ.get("PROBE", "") == "kernels"
+    for bm in (() if only_kernels else (False, True)):
         torch.backends.cudnn.benchmark = bm
         print(f"--- cudnn.benchmark={bm}")
         for case in [(32, 320, 320, 40, 64), (32, 640, 640, 20, 32), (32, 1280, 1280, 10, 16), (32, 2560, 1280, 10, 16),
@@ -59,7 +60,7 @@ def main():
             conv_case(*case)
         conv_case(32, 320, 320, 40, 64, 3, 2)
     print("--- GEMM")
-    for M, Kd, N in [(81920, 320, 960), (81920, 320, 320), (81920, 320, 2560), (81920, 1280, 320), (20480, 640, 1920),
+    for M, Kd, N in [] if only_kernels else [(81920, 320, 960), (81920, 320, 320), (81920, 320, 2560), (81920, 1280, 320), (20480, 640, 1920),
                      (20480, 640, 5120), (20480, 2560, 640), (5120, 1280, 3840), (5120, 1280, 10240), (5120, 5120, 1280),
                      (154, 768, 640)]:
         gemm_case(M, Kd, N)
