@@ -159,6 +159,32 @@ int fmc_feature_add_fwd(const void* h, const void* t, void* out, int64_t n_elems
 int fmc_cfg_ddim_step(const void* eps_uc, const float* x, float* x_out, int64_t n, int has_uncond,
                       float guidance, float alpha_t, float alpha_prev, int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * bf16 MFMA GEMM with fused epilogue:  out = alpha * (x @ w^T + bias) + residual      (epilogue 0)
+ *                                      out = (x @ wa^T + ba) * gelu_erf(x @ wg^T + bg)  (epilogue 1, GEGLU)
+ * Replaces nn.Linear of diffusers' Attention / FeedForward / Transformer2D 1x1 proj (call sites
+ * fmc/models/attention_processor.py:50-69,255-283, fmc/models/motion_module.py:219,228,284) together with the
+ * `+ hidden_states` residual that follows (motion_module.py:289-297) and the Camera-Adapter axpy
+ * `qkv_merge(h + pose) * scale + h` (attention_processor.py:257).
+ *   x [M, K] rows `ldx` apart, w [N, K] contiguous, bias [N] or NULL, residual [M, N] rows `ldres` apart or NULL,
+ *   out [M, N] (epilogue 0) or [M, N/2] (epilogue 1), rows `ldo` apart.  All bf16, fp32 accumulate.
+ *   epilogue 1 expects w / bias pre-interleaved per 128-row tile: rows [128t, 128t+64) = value rows
+ *   [64t, 64t+64) of the GEGLU projection, rows [128t+64, 128t+128) = the matching gate rows.
+ *   Requires K % 64 == 0, N % 8 == 0 (N % 128 == 0 for epilogue 1), strides % 8 == 0.
+ * ------------------------------------------------------------------------------------------- */
+int fmc_linear_bf16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int N,
+                    int K, int64_t ldx, int64_t ldres, int64_t ldo, float alpha, int epilogue, void* stream);
+
+/* Implicit-GEMM 3x3 convolution (stride 1, pad 1) on channels-last bf16 images with the ResNet-block epilogue:
+ *   out[i,y,x,:] = conv(x)[i,y,x,:] + bias + temb[i,:] + residual[i,y,x,:]
+ * Replaces conv1 / conv2 of diffusers' ResnetBlock2D (ctor args fmc/models/unet_blocks.py:306-317), including
+ * `+ time_emb_proj(silu(temb))[:, :, None, None]` and the `input_tensor + hidden_states` residual, and the conv of
+ * Upsample2D (unet_blocks.py:625).
+ *   x [n_img, H, W, Cin], w [Cout, 3, 3, Cin] (= the filter in torch.channels_last memory format),
+ *   bias [Cout] | NULL, temb [n_img, Cout] | NULL, residual / out [n_img, H, W, Cout].  Cin % 64 == 0, Cout % 8 == 0. */
+int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, const void* temb, const void* residual, void* out,
+                     int n_img, int H, int W, int Cin, int Cout, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

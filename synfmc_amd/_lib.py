@@ -41,6 +41,10 @@ SIGNATURES = {
     "fmc_feature_add_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "fmc_cfg_ddim_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_int,
                                   c_void_p]),
+    "fmc_linear_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64,
+                                c_int64, c_int64, c_float, c_int, c_void_p]),
+    "fmc_conv3x3_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                 c_int, c_int, c_void_p]),
 }
 
 _lib = None

@@ -309,3 +309,156 @@ def cfg_ddim_step(eps: torch.Tensor, x: torch.Tensor, guidance: float, alpha_t: 
                                              float(guidance), float(alpha_t), float(alpha_prev), _dt(eps), _stream()),
                "fmc_cfg_ddim_step")
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# bf16 MFMA GEMM / implicit 3x3 conv with fused epilogues
+# --------------------------------------------------------------------------------------------
+def linear_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.stride(-1) == 1
+            and weight.shape[1] % 64 == 0 and weight.shape[0] % 8 == 0 and weight.is_contiguous())
+
+
+def _rows2d(t: torch.Tensor):
+    """(M, row stride) of a tensor whose leading dims collapse to uniformly strided rows with a dense last dim."""
+    C = t.shape[-1]
+    if t.is_contiguous():
+        return t.numel() // C, C
+    assert t.ndim == 2 and t.stride(1) == 1, "strided operands must be 2-D [M, C] views"
+    return t.shape[0], t.stride(0)
+
+
+def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                residual: Optional[torch.Tensor] = None, alpha: float = 1.0, geglu: bool = False) -> torch.Tensor:
+    """`alpha * (x @ weight^T + bias) + residual` (or the GEGLU gate, see fmc_linear_bf16) on the bf16 MFMA kernel.
+    x `[..., K]`, weight `[N, K]`; residual has the output's shape."""
+    _dev(x, weight, bias, residual)
+    N, Kd = weight.shape
+    M, ldx = _rows2d(x)
+    n_out = N // 2 if geglu else N
+    out = torch.empty(*x.shape[:-1], n_out, dtype=x.dtype, device=x.device)
+    ldres = 0
+    if residual is not None:
+        assert residual.shape == out.shape
+        _, ldres = _rows2d(residual)
+    _lib.check(_lib.load().fmc_linear_bf16(x.data_ptr(), weight.data_ptr(), _p(bias), _p(residual), out.data_ptr(), M, N,
+                                           Kd, ldx, ldres, n_out, float(alpha), int(geglu), _stream()),
+               "fmc_linear_bf16")
+    return out
+
+
+def conv3x3_supported(x: torch.Tensor, weight: torch.Tensor, stride, padding) -> bool:
+    return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
+            and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1)
+            and weight.shape[1] % 64 == 0 and weight.shape[0] % 8 == 0)
+
+
+def conv3x3_bf16(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                 temb: Optional[torch.Tensor] = None, residual_nhwc: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x `[N, H, W, Cin]` contiguous, weight `[Cout, Cin, 3, 3]` in channels_last memory format (physically
+    `[Cout, 3, 3, Cin]`), temb `[N, Cout]`, residual `[N, H, W, Cout]` -> `[N, H, W, Cout]`."""
+    _dev(x_nhwc, weight_cl, bias, temb, residual_nhwc)
+    n, h, w, cin = x_nhwc.shape
+    cout = weight_cl.shape[0]
+    assert x_nhwc.is_contiguous() and weight_cl.is_contiguous(memory_format=torch.channels_last)
+    assert temb is None or (temb.is_contiguous() and temb.shape == (n, cout))
+    assert residual_nhwc is None or (residual_nhwc.is_contiguous() and residual_nhwc.shape == (n, h, w, cout))
+    out = torch.empty(n, h, w, cout, dtype=x_nhwc.dtype, device=x_nhwc.device)
+    _lib.check(_lib.load().fmc_conv3x3_bf16(x_nhwc.data_ptr(), weight_cl.data_ptr(), _p(bias), _p(temb),
+                                            _p(residual_nhwc), out.data_ptr(), n, h, w, cin, cout, _stream()),
+               "fmc_conv3x3_bf16")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# projection / convolution front-ends: pick, per problem shape, between the fused gfx950 kernel and the vendor
+# library call (+ separate epilogue passes).  The choice is measured once per shape on the first eager call (the
+# pipelines run eager warm-up steps before capturing a HIP graph) and cached; while a graph is being captured an
+# unseen shape falls back to a static rule.  Both arms compute the same function.
+# --------------------------------------------------------------------------------------------
+_choice = {}
+AUTOTUNE = True
+
+
+def _time_ms(fn, iters=4):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def _pick(key, hip_fn, lib_fn, static_hip: bool) -> bool:
+    use = _choice.get(key)
+    if use is None:
+        if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
+            return static_hip
+        use = _time_ms(hip_fn) <= _time_ms(lib_fn)
+        _choice[key] = use
+    return use
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+           residual: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
+    """`alpha * (x @ weight^T + bias) + residual` for bf16 device tensors (see `linear_bf16`)."""
+    import torch.nn.functional as F
+
+    def lib():
+        y = F.linear(x, weight, bias)
+        if residual is not None:
+            return torch.add(residual, y, alpha=alpha)
+        return y if alpha == 1.0 else y * alpha
+
+    if not linear_supported(x, weight) or (x.ndim > 2 and not x.is_contiguous()):
+        return lib()
+    N, Kd = weight.shape
+    M = x.numel() // Kd
+    key = ("lin", M, N, Kd, bias is not None, residual is not None)
+    hip = lambda: linear_bf16(x, weight, bias, residual, alpha)
+    static = Kd <= 640 and N <= 1024 and M >= 16384
+    return hip() if _pick(key, hip, lib, static) else lib()
+
+
+def geglu_linear(x: torch.Tensor, weight: torch.Tensor, bias, weight_il: torch.Tensor, bias_il) -> torch.Tensor:
+    """GEGLU feed-forward input projection: `a * gelu(g)`, `a, g = (x @ weight^T + bias).chunk(2)`.  `weight_il` /
+    `bias_il` are the tile-interleaved copies the fused kernel wants (`models.layers.interleave_geglu`)."""
+    import torch.nn.functional as F
+    lib = lambda: geglu(F.linear(x, weight, bias))
+    if not linear_supported(x, weight_il) or weight_il.shape[0] % 128 or (x.ndim > 2 and not x.is_contiguous()):
+        return lib()
+    N, Kd = weight.shape
+    M = x.numel() // Kd
+    hip = lambda: linear_bf16(x, weight_il, bias_il, geglu=True)
+    return hip() if _pick(("geglu", M, N, Kd), hip, lib, M >= 65536) else lib()
+
+
+def conv3x3(x_nchw: torch.Tensor, weight_cl: torch.Tensor, bias, temb=None, residual_nchw=None, stride=(1, 1),
+            padding=(1, 1)) -> torch.Tensor:
+    """3x3 conv on a logical NCHW / physical channels-last tensor with `+ temb[:, :, None, None]` and `+ residual`.
+    Returns a logical NCHW view over channels-last storage."""
+    import torch.nn.functional as F
+
+    def lib():
+        y = F.conv2d(x_nchw, weight_cl, bias, stride, padding)
+        if temb is not None:
+            y = y + temb[:, :, None, None]
+        if residual_nchw is not None:
+            y = y + residual_nchw
+        return y
+
+    if not conv3x3_supported(x_nchw, weight_cl, stride, padding):
+        return lib()
+    n, cin, h, w = x_nchw.shape
+    cout = weight_cl.shape[0]
+    x = x_nchw.permute(0, 2, 3, 1)
+    r = None if residual_nchw is None else residual_nchw.permute(0, 2, 3, 1)
+    if not x.is_contiguous() or (r is not None and not r.is_contiguous()):
+        return lib()
+    key = ("conv", n, h, w, cin, cout, temb is not None, r is not None)
+    hip = lambda: conv3x3_bf16(x, weight_cl, bias, temb, r).permute(0, 3, 1, 2)
+    tiles = ((n * h * w + 127) // 128) * ((cout + 127) // 128)
+    return hip() if _pick(key, hip, lib, tiles >= 256) else lib()

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import hip_ops as K
-from .layers import LoRALinearLayer
+from .layers import LoRALinearLayer, linear_op
 
 
 def _tok(x: torch.Tensor) -> torch.Tensor:
@@ -34,13 +34,13 @@ def _tok(x: torch.Tensor) -> torch.Tensor:
 
 
 def _attention_core(attn, q_in: torch.Tensor, kv_in: Optional[torch.Tensor], temporal: bool, lora=None,
-                    lora_scale: float = 1.0) -> torch.Tensor:
-    """Fused projection -> attention kernel -> output projection (bias, dropout p=0)."""
+                    lora_scale: float = 1.0, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Fused projection -> attention kernel -> output projection (bias, dropout p=0) [+ residual]."""
     heads = attn.heads
     w_a, w_b, w_o = attn.fused_weights(lora, lora_scale)
     c = attn.inner_dim
     if kv_in is None:                                   # self attention: one [.., 3C] GEMM
-        qkv = F.linear(q_in, w_a)
+        qkv = linear_op(q_in, w_a)
         q, k, v = qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
         if temporal:
             o = K.temporal_attention(q, k, v, heads, attn.scale)
@@ -48,10 +48,20 @@ def _attention_core(attn, q_in: torch.Tensor, kv_in: Optional[torch.Tensor], tem
             o = K.spatial_attention(q, k, v, heads, attn.scale)
     else:                                               # cross attention: q GEMM + one [.., 2C] kv GEMM
         assert not temporal
-        q = F.linear(q_in, w_a)
-        kv = F.linear(kv_in, w_b)
+        q = linear_op(q_in, w_a)
+        kv = linear_op(kv_in, w_b)
         o = K.spatial_attention(q, kv[..., :c], kv[..., c:], heads, attn.scale)
-    return F.linear(o, w_o, attn.to_out[0].bias)
+    return linear_op(o, w_o, attn.to_out[0].bias, residual)
+
+
+def _fusable(attn, residual, shape4):
+    """The block-level `attn(x) + hidden_states` may ride in the output projection only when the processor applies
+    nothing after it (`residual_connection` off, `rescale_output_factor` 1) and the tokens are not re-shaped."""
+    if residual is None:
+        return None
+    assert shape4 is None and not attn.residual_connection and attn.rescale_output_factor == 1.0, \
+        "internal: fused block residual needs a plain attention module"
+    return residual
 
 
 def _finish(attn, out, residual, shape4):
@@ -69,11 +79,11 @@ class AttnProcessor:
     """Reference: attention_processor.py:15-82 (`pose_feature` accepted and ignored, :28)."""
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
-                 scale: float = 1.0, pose_feature=None, temporal: bool = False):
+                 scale: float = 1.0, pose_feature=None, temporal: bool = False, _residual=None):
         attn.prepare_attention_mask(attention_mask, 0, 0)
         shape4 = hidden_states.shape if (hidden_states.ndim == 4 and not temporal) else None
         x = _tok(hidden_states) if not temporal else hidden_states
-        out = _attention_core(attn, x, encoder_hidden_states, temporal)
+        out = _attention_core(attn, x, encoder_hidden_states, temporal, residual=_fusable(attn, _residual, shape4))
         return _finish(attn, out, hidden_states, shape4)
 
 
@@ -90,13 +100,14 @@ class LoRAAttnProcessor(nn.Module):
         self.to_out_lora = LoRALinearLayer(hidden_size, hidden_size, rank, network_alpha)
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
-                 pose_feature=None, scale=None, temporal: bool = False):
+                 pose_feature=None, scale=None, temporal: bool = False, _residual=None):
         _require_frozen(self)
         attn.prepare_attention_mask(attention_mask, 0, 0)
         s = self.lora_scale if scale is None else scale
         shape4 = hidden_states.shape if (hidden_states.ndim == 4 and not temporal) else None
         x = _tok(hidden_states) if not temporal else hidden_states
-        out = _attention_core(attn, x, encoder_hidden_states, temporal, lora=self, lora_scale=s)
+        out = _attention_core(attn, x, encoder_hidden_states, temporal, lora=self, lora_scale=s,
+                              residual=_fusable(attn, _residual, shape4))
         return _finish(attn, out, hidden_states, shape4)
 
 
@@ -120,7 +131,7 @@ class _PoseMerge:
     def _merge(self, hidden_states, encoder_hidden_states, pose_feature, s):
         """`merge(h + pose) * s + h` (attention_processor.py:256-265)."""
         if self.query_condition and self.key_value_condition:
-            m = torch.add(hidden_states, self.qkv_merge(hidden_states + pose_feature), alpha=s)
+            m = linear_op(hidden_states + pose_feature, self.qkv_merge.weight, self.qkv_merge.bias, hidden_states, s)
             return m, None
         if self.query_condition:
             return torch.add(hidden_states, self.q_merge(hidden_states + pose_feature), alpha=s), encoder_hidden_states
@@ -155,7 +166,7 @@ class PoseAdaptorAttnProcessor(nn.Module, _PoseMerge):
         self._build_merge(hidden_size, pose_feature_dim, query_condition, key_value_condition)
 
     def forward(self, attn, hidden_states, pose_feature, encoder_hidden_states=None, attention_mask=None, temb=None,
-                scale=None, temporal: bool = False):
+                scale=None, temporal: bool = False, _residual=None):
         assert pose_feature is not None
         s = scale or self.scale
         attn.prepare_attention_mask(attention_mask, 0, 0)
@@ -168,7 +179,7 @@ class PoseAdaptorAttnProcessor(nn.Module, _PoseMerge):
         if not (self.query_condition and self.key_value_condition) and encoder_hidden_states is None:
             raise NotImplementedError("q-only / kv-only pose merge on self attention needs un-fused projections; "
                                       "the shipped FMC configs use query_condition = key_value_condition = True")
-        out = _attention_core(attn, q_in, kv_in, temporal)
+        out = _attention_core(attn, q_in, kv_in, temporal, residual=_fusable(attn, _residual, shape4))
         return _finish(attn, out, hidden_states, shape4)
 
 
@@ -189,7 +200,7 @@ class LORAPoseAdaptorAttnProcessor(nn.Module, _PoseMerge):
         self.to_out_lora = LoRALinearLayer(hidden_size, hidden_size, rank, network_alpha)
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
-                 pose_feature=None, temporal: bool = False):
+                 pose_feature=None, temporal: bool = False, _residual=None):
         assert pose_feature is not None
         _require_frozen(self)
         ls = self.lora_scale if scale is None else scale
@@ -200,5 +211,6 @@ class LORAPoseAdaptorAttnProcessor(nn.Module, _PoseMerge):
             assert encoder_hidden_states is None
         ctx = x if encoder_hidden_states is None else _tok(encoder_hidden_states)
         q_in, kv_in = self._merge(x, ctx, _pose_tokens(pose_feature, x), self.scale)
-        out = _attention_core(attn, q_in, kv_in, temporal, lora=self, lora_scale=ls)
+        out = _attention_core(attn, q_in, kv_in, temporal, lora=self, lora_scale=ls,
+                              residual=_fusable(attn, _residual, shape4))
         return _finish(attn, out, hidden_states, shape4)

@@ -75,14 +75,26 @@ class LayerNorm(nn.LayerNorm):
 class Conv2d(nn.Conv2d):
     """MIOpen conv on channels-last storage; 1x1 stride-1 convs run as a token GEMM (hipBLASLt)."""
 
-    def forward(self, x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, scale: float = 1.0, temb: Optional[torch.Tensor] = None,
+                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """conv(x) [+ temb[:, :, None, None]] [+ residual]; the two extras ride in the kernel epilogue when the
+        gfx950 implicit-GEMM conv / GEMM is used."""
         if self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0):
             n, c, h, w = x.shape
-            y = F.linear(to_tokens(x), self.weight.view(self.out_channels, self.in_channels), self.bias)
+            assert temb is None
+            y = linear_op(to_tokens(x), self.weight.view(self.out_channels, self.in_channels), self.bias,
+                          None if residual is None else to_tokens(residual))
             return from_tokens(y, h, w)
         if not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)
-        return F.conv2d(x, self._weight_cl(), self.bias, self.stride, self.padding, self.dilation, self.groups)
+        if self.kernel_size == (3, 3) and self.dilation == (1, 1) and self.groups == 1 and x.is_cuda:
+            return K.conv3x3(x, self._weight_cl(), self.bias, temb, residual, self.stride, self.padding)
+        y = F.conv2d(x, self._weight_cl(), self.bias, self.stride, self.padding, self.dilation, self.groups)
+        if temb is not None:
+            y = y + temb[:, :, None, None]
+        if residual is not None:
+            y = y + residual
+        return y
 
     def _weight_cl(self) -> torch.Tensor:
         """The filter in channels-last memory format.  ATen's MIOpen path otherwise re-lays-out the (up to 29 MB)
@@ -98,9 +110,20 @@ class Conv2d(nn.Conv2d):
         return hit[1]
 
 
+def linear_op(x, weight, bias=None, residual=None, alpha: float = 1.0):
+    """`alpha * (x @ W^T + b) + residual`: fused gfx950 GEMM or hipBLASLt + epilogue passes (`hip_ops.linear`) for
+    frozen bf16 weights on the GPU, plain autograd ops otherwise."""
+    if x.is_cuda and x.dtype == torch.bfloat16 and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)):
+        return K.linear(x, weight, bias, residual, alpha)
+    y = F.linear(x, weight, bias)
+    if alpha != 1.0:
+        y = y * alpha
+    return y if residual is None else y + residual
+
+
 class Linear(nn.Linear):
-    def forward(self, x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
-        return F.linear(x, self.weight, self.bias)
+    def forward(self, x: torch.Tensor, scale: float = 1.0, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return linear_op(x, self.weight, self.bias, residual)
 
 
 # ----------------------------------------------------------------------------
@@ -181,13 +204,13 @@ class ResnetBlock2D(nn.Module):
             if self.use_in_shortcut else None
 
     def forward(self, input_tensor, temb, scale: float = 1.0):
-        h = self.conv1(self.norm1(input_tensor, act=True))
+        t = None
         if self.time_emb_proj is not None and temb is not None:
-            h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
-        h = self.conv2(self.norm2(h, act=True))
+            t = self.time_emb_proj(F.silu(temb))                       # [N, Cout], rides in conv1's epilogue
+        h = self.conv1(self.norm1(input_tensor, act=True), temb=t)
         if self.conv_shortcut is not None:
             input_tensor = self.conv_shortcut(input_tensor)
-        out = input_tensor + h
+        out = self.conv2(self.norm2(h, act=True), residual=input_tensor)   # `input + h` rides in conv2's epilogue
         return out if self.output_scale_factor == 1.0 else out / self.output_scale_factor
 
 
@@ -310,12 +333,32 @@ class Attention(nn.Module):
         return fused
 
 
+def interleave_geglu(weight: torch.Tensor, bias: Optional[torch.Tensor]):
+    """Row order `fmc_linear_bf16(epilogue=GEGLU)` expects: per 128-row tile, 64 value rows then their 64 gate rows."""
+    two_cff, k = weight.shape
+    cff = two_cff // 2
+    assert cff % 64 == 0
+    w = weight.view(2, cff // 64, 64, k).permute(1, 0, 2, 3).reshape(two_cff, k).contiguous()
+    b = None if bias is None else bias.view(2, cff // 64, 64).permute(1, 0, 2).reshape(two_cff).contiguous()
+    return w, b
+
+
 class GEGLU(nn.Module):
     def __init__(self, dim_in, dim_out):
         super().__init__()
         self.proj = Linear(dim_in, dim_out * 2)
 
     def forward(self, hidden_states, scale: float = 1.0):
+        w = self.proj.weight
+        if hidden_states.is_cuda and hidden_states.dtype == torch.bfloat16 and w.shape[0] % 256 == 0 \
+                and not (torch.is_grad_enabled() and w.requires_grad):
+            key = (w.data_ptr(), w._version)
+            hit = self.__dict__.get("_il")
+            if hit is None or hit[0] != key:
+                with torch.no_grad():
+                    hit = (key, interleave_geglu(w.detach(), None if self.proj.bias is None else self.proj.bias.detach()))
+                self.__dict__["_il"] = hit
+            return K.geglu_linear(hidden_states, w, self.proj.bias, hit[1][0], hit[1][1])
         return K.geglu(self.proj(hidden_states))
 
 
@@ -328,8 +371,8 @@ class FeedForward(nn.Module):
         self.net = nn.ModuleList([GEGLU(dim, inner), nn.Dropout(dropout),
                                   Linear(inner, dim if dim_out is None else dim_out)])
 
-    def forward(self, hidden_states, scale: float = 1.0):
-        return self.net[2](self.net[0](hidden_states))
+    def forward(self, hidden_states, scale: float = 1.0, residual: Optional[torch.Tensor] = None):
+        return self.net[2](self.net[0](hidden_states), residual=residual)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -356,12 +399,13 @@ class BasicTransformerBlock(nn.Module):
                 encoder_attention_mask=None, timestep=None, cross_attention_kwargs=None, class_labels=None):
         kw = dict(cross_attention_kwargs) if cross_attention_kwargs is not None else {}
         kw.pop("gligen", None)
+        # `attn(...) + hidden_states` / `ff(...) + hidden_states`: the residual rides in the output projection's epilogue
         hidden_states = self.attn1(self.norm1(hidden_states), encoder_hidden_states=None,
-                                   attention_mask=attention_mask, **kw) + hidden_states
+                                   attention_mask=attention_mask, _residual=hidden_states, **kw)
         if self.attn2 is not None:
             hidden_states = self.attn2(self.norm2(hidden_states), encoder_hidden_states=encoder_hidden_states,
-                                       attention_mask=encoder_attention_mask, **kw) + hidden_states
-        return self.ff(self.norm3(hidden_states)) + hidden_states
+                                       attention_mask=encoder_attention_mask, _residual=hidden_states, **kw)
+        return self.ff(self.norm3(hidden_states), residual=hidden_states)
 
 
 class Transformer2DModelOutput:
@@ -398,11 +442,11 @@ class Transformer2DModel(nn.Module):
         residual = to_tokens(hidden_states)
         x = K.groupnorm_silu(residual, f32_param(self.norm, "weight"), f32_param(self.norm, "bias"),
                              self.norm.num_groups, self.norm.eps, False)
-        x = F.linear(x, self.proj_in.weight.view(self.proj_in.out_channels, c), self.proj_in.bias)
+        x = linear_op(x, self.proj_in.weight.view(self.proj_in.out_channels, c), self.proj_in.bias)
         for blk in self.transformer_blocks:
             x = blk(x, attention_mask=attention_mask, encoder_hidden_states=encoder_hidden_states,
                     encoder_attention_mask=encoder_attention_mask, timestep=timestep,
                     cross_attention_kwargs=cross_attention_kwargs, class_labels=class_labels)
-        x = F.linear(x, self.proj_out.weight.view(c, self.proj_out.in_channels), self.proj_out.bias)
-        out = from_tokens(x + residual, h, w)
+        x = linear_op(x, self.proj_out.weight.view(c, self.proj_out.in_channels), self.proj_out.bias, residual)
+        out = from_tokens(x, h, w)
         return Transformer2DModelOutput(out) if return_dict else (out,)

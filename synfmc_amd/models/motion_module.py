@@ -18,7 +18,7 @@ from torch import nn
 
 from .. import hip_ops as K
 from .attention_processor import PoseAdaptorAttnProcessor
-from .layers import Attention, FeedForward, LayerNorm, f32_param
+from .layers import Attention, FeedForward, LayerNorm, f32_param, linear_op
 from .resnet import InflatedGroupNorm
 
 
@@ -137,8 +137,8 @@ class TemporalTransformerBlock(nn.Module):
             else:
                 n = norm(hidden_states)
             hidden_states = attention_block(n, encoder_hidden_states=None, attention_mask=attention_mask,
-                                            _pe_applied=True, **cross_attention_kwargs) + hidden_states
-        return self.ff(self.ff_norm(hidden_states)) + hidden_states
+                                            _pe_applied=True, _residual=hidden_states, **cross_attention_kwargs)
+        return self.ff(self.ff_norm(hidden_states), residual=hidden_states)
 
 
 class TemporalTransformer3DModel(nn.Module):
@@ -180,11 +180,11 @@ class TemporalTransformer3DModel(nn.Module):
         residual = t.view(b * f, h * w, c)
         x = K.groupnorm_silu(residual, f32_param(self.norm, "weight"), f32_param(self.norm, "bias"),
                              self.norm.num_groups, self.norm.eps, False)
-        x = self.proj_in(x).view(b, f, h * w, -1)
+        x = linear_op(x, self.proj_in.weight, self.proj_in.bias).view(b, f, h * w, -1)
         for block in self.transformer_blocks:
             x = block(x, encoder_hidden_states=encoder_hidden_states, attention_mask=attention_mask,
                       cross_attention_kwargs=cross_attention_kwargs)
-        x = self.proj_out(x).view(b * f, h * w, c) + residual
+        x = linear_op(x.view(b * f, h * w, -1), self.proj_out.weight, self.proj_out.bias, residual)
         return x.view(b, f, h, w, c).permute(0, 4, 1, 2, 3)
 
 

@@ -267,3 +267,57 @@ def test_cfg_ddim_step(K, dtype):
         ref = sch.step(eps, t, x).prev_sample
         got = mine.step_cfg(ed, t, x.cuda(), 8.0, True)
         assert rel_inf(got, ref) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,Kd,bias,res,alpha", [(300, 320, 320, True, True, 1.0), (1000, 960, 320, False, False, 1.0),
+                                                    (129, 640, 2560, True, True, 0.5), (77 * 2, 640, 768, False, False, 1.0),
+                                                    (4096, 1280, 1280, True, False, 1.0), (64, 8, 64, True, True, 1.0)])
+def test_linear_bf16_fused_epilogue(K, M, N, Kd, bias, res, alpha):
+    dtype = torch.bfloat16
+    xo, xd = rnd((M, Kd), 60, dtype)
+    wo, wd = rnd((N, Kd), 61, dtype, scale=Kd ** -0.5)
+    bo, bd = rnd((N,), 62, dtype)
+    ro, rd = rnd((M, N), 63, dtype)
+    ref = F.linear(xo, wo, bo if bias else None) * alpha + (ro if res else 0)
+    out = K.linear_bf16(xd, wd, bd if bias else None, rd if res else None, alpha)
+    assert rel_inf(out.float(), ref) < 1e-2
+    # strided input rows (a slice of a wider matrix)
+    wide = torch.cat([xd, xd], dim=1)
+    out2 = K.linear_bf16(wide[:, Kd:], wd, bd if bias else None, rd if res else None, alpha)
+    assert torch.equal(out2, out)
+
+
+def test_linear_bf16_geglu(K):
+    dtype = torch.bfloat16
+    M, C, Cff = 513, 320, 1280
+    xo, xd = rnd((M, C), 64, dtype)
+    wo, wd = rnd((2 * Cff, C), 65, dtype, scale=C ** -0.5)
+    bo, bd = rnd((2 * Cff,), 66, dtype)
+    a, g = F.linear(xo, wo, bo).chunk(2, dim=-1)
+    ref = a * F.gelu(g)
+    from synfmc_amd.models.layers import interleave_geglu
+    wi, bi = interleave_geglu(wd, bd)
+    out = K.linear_bf16(xd, wi, bi, geglu=True)
+    assert out.shape == (M, Cff)
+    assert rel_inf(out.float(), ref) < 1e-2
+
+
+@pytest.mark.parametrize("n,H,W,cin,cout,temb,res", [(2, 10, 16, 320, 320, True, True), (3, 9, 7, 640, 320, False, False),
+                                                     (1, 40, 64, 320, 320, True, False), (2, 5, 8, 1280, 1280, True, True),
+                                                     (2, 12, 12, 64, 136, False, True)])
+def test_conv3x3_bf16_fused_epilogue(K, n, H, W, cin, cout, temb, res):
+    dtype = torch.bfloat16
+    xo, xd = rnd((n, cin, H, W), 70, dtype)
+    wo, wd = rnd((cout, cin, 3, 3), 71, dtype, scale=(9 * cin) ** -0.5)
+    bo, bd = rnd((cout,), 72, dtype)
+    to, td = rnd((n, cout), 73, dtype)
+    ro, rd = rnd((n, cout, H, W), 74, dtype)
+    ref = F.conv2d(xo, wo, bo, 1, 1)
+    if temb:
+        ref = ref + to[:, :, None, None]
+    if res:
+        ref = ref + ro
+    out = K.conv3x3_bf16(xd.permute(0, 2, 3, 1).contiguous(), wd.contiguous(memory_format=torch.channels_last), bd,
+                         td if temb else None, rd.permute(0, 2, 3, 1).contiguous() if res else None)
+    assert rel_inf(out.permute(0, 3, 1, 2).float(), ref) < 1e-2
