@@ -170,10 +170,12 @@ int fmc_cfg_ddim_step(const void* eps_uc, const float* x, float* x_out, int64_t 
  *   out [M, N] (epilogue 0) or [M, N/2] (epilogue 1), rows `ldo` apart.  All bf16, fp32 accumulate.
  *   epilogue 1 expects w / bias pre-interleaved per 128-row tile: rows [128t, 128t+64) = value rows
  *   [64t, 64t+64) of the GEGLU projection, rows [128t+64, 128t+128) = the matching gate rows.
- *   Requires K % 64 == 0, N % 8 == 0 (N % 128 == 0 for epilogue 1), strides % 8 == 0.
+ *   Requires K % 64 == 0, N % 8 == 0 (N % 256 == 0 for epilogue 1), strides % 8 == 0.
+ *   tile: workgroup tile geometry, 0 = pick by shape, 1 = 128x128 (4 waves), 2 = 256x128 (8), 3 = 256x256 (16);
+ *   every geometry computes the same function (callers may time them and keep the fastest).
  * ------------------------------------------------------------------------------------------- */
 int fmc_linear_bf16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int N,
-                    int K, int64_t ldx, int64_t ldres, int64_t ldo, float alpha, int epilogue, void* stream);
+                    int K, int64_t ldx, int64_t ldres, int64_t ldo, float alpha, int epilogue, int tile, void* stream);
 
 /* Implicit-GEMM 3x3 convolution (stride 1, pad 1) on channels-last bf16 images with the ResNet-block epilogue:
  *   out[i,y,x,:] = conv(x)[i,y,x,:] + bias + temb[i,:] + residual[i,y,x,:]
@@ -183,7 +185,7 @@ int fmc_linear_bf16(const void* x, const void* w, const void* bias, const void* 
  *   x [n_img, H, W, Cin], w [Cout, 3, 3, Cin] (= the filter in torch.channels_last memory format),
  *   bias [Cout] | NULL, temb [n_img, Cout] | NULL, residual / out [n_img, H, W, Cout].  Cin % 64 == 0, Cout % 8 == 0. */
 int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, const void* temb, const void* residual, void* out,
-                     int n_img, int H, int W, int Cin, int Cout, void* stream);
+                     int n_img, int H, int W, int Cin, int Cout, int tile, void* stream);
 
 #ifdef __cplusplus
 }

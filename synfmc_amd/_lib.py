@@ -42,9 +42,9 @@ SIGNATURES = {
     "fmc_cfg_ddim_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_int,
                                   c_void_p]),
     "fmc_linear_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64,
-                                c_int64, c_int64, c_float, c_int, c_void_p]),
+                                c_int64, c_int64, c_float, c_int, c_int, c_void_p]),
     "fmc_conv3x3_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                 c_int, c_int, c_void_p]),
+                                 c_int, c_int, c_int, c_void_p]),
 }
 
 _lib = None

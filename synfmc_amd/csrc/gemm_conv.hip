@@ -2,32 +2,40 @@
 // fused epilogues.  Replaces, on the FMC path,
 //   * nn.Linear of diffusers' Attention / FeedForward / Transformer2D proj_in|out (call sites
 //     fmc/models/attention_processor.py:50-69,255-283; fmc/models/motion_module.py:219,228,284) including the
-//     `+ residual` that follows them (motion_module.py:289-297, diffusers BasicTransformerBlock) and the GEGLU gate;
-//   * the 3x3 convolutions of diffusers' ResnetBlock2D / Downsample2D(stride 1 only here) / Upsample2D
-//     (ctor args fmc/models/unet_blocks.py:306-317) with `+ time_emb_proj(silu(temb))[:, :, None, None]` and the
-//     `input + h` residual fused into the epilogue.
+//     `+ residual` that follows them (motion_module.py:289-297, diffusers BasicTransformerBlock), the Camera-Adapter
+//     axpy `qkv_merge(h + pose) * scale + h` (attention_processor.py:257) and the GEGLU gate;
+//   * the 3x3 convolutions of diffusers' ResnetBlock2D / Upsample2D (ctor args fmc/models/unet_blocks.py:306-317,
+//     :625) with `+ time_emb_proj(silu(temb))[:, :, None, None]` and the `input + h` residual fused into the epilogue.
 //
 // out[m, n] = epi( sum_k A[m, k] * W[n, k] )      A: [M, K] bf16 (K contiguous), W: [N, K] bf16 (K contiguous)
 //   conv mode: m = (img, y, x) pixel of an NHWC image, k = (tap, ci): A[m, k] = X[img, y+dy-1, x+dx-1, ci] (zero
 //   outside), W = the filter in channels-last memory format [Cout][3][3][Cin] -- exactly K-contiguous.
 //
-// Structure (CDNA4, wave = 64): 128x128 output tile per 256-thread workgroup (2x2 waves, 64x64 per wave as 2x2
-// v_mfma_f32_32x32x16_bf16 tiles), BK = 64, operands staged global -> registers -> LDS with the loads of tile k+1 in
-// flight under the MFMAs of tile k, two LDS stages (one barrier per k-tile), XOR-swizzled 16-byte chunks so that
-// both the ds_write_b128 of the staging pass and the ds_read_b128 fragment reads are bank-conflict free, products
-// computed "swapped" (MFMA A operand = W rows) so a lane ends up with 4 consecutive output columns, C tile staged
-// through LDS and written with full-row 16-byte stores with bias / temb / residual / GEGLU applied on the way out.
-// XCD-aware tile order: the N-tiles of one M-tile run on one XCD (A rows come from that L2).
+// Structure (CDNA4, wave = 64):
+//   * a workgroup of WM x WN waves computes a (64*WM) x (64*WN) output tile, every wave a 64x64 sub-tile as 2x2
+//     v_mfma_f32_32x32x16_bf16 accumulators; three geometries are built: 128x128 (4 waves, 2 workgroups per CU),
+//     256x128 (8 waves) and 256x256 (16 waves, one workgroup per CU).  The first version (128x128 only) ran at
+//     ~64 flop per byte moved L2->LDS and measured 10.6 TB/s of that traffic = 680 TFLOP/s on every shape: it was
+//     L2-bandwidth bound, so the larger tiles (85 / 128 flop per byte) are the lever, not the inner loop;
+//   * operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction): no staging
+//     registers, no ds_write pass; the 16-byte chunks of a 128-byte tile row are XOR-swizzled through the SOURCE
+//     address so that the ds_read_b128 fragment reads are bank-conflict free; out-of-range rows / padding taps read
+//     a 16-byte zero page; two LDS stages, the DMA of k-tile t+1 runs under the MFMAs of k-tile t, one raw
+//     s_barrier per k-tile (a __syncthreads() would drain the DMA);
+//   * products are computed "swapped" (MFMA A operand = W rows) so a lane ends up with 4 consecutive output
+//     columns; the C tile leaves through LDS in fp32 (64-row slabs) with full-row 16-byte stores, bias / alpha /
+//     temb / residual / GEGLU applied on the way out;
+//   * XCD-aware tile order: the N-tiles of one M-tile run back to back on one XCD (A rows come from that L2).
 //
 // Roofline: MFMA bound for K >= ~640, HBM bound (output write) for the K = 320 level-0 projections.
 // Algorithmic flops per launch = 2*M*N*K.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int STAGE_ELEMS = (BM + BN) * BK;          // bf16 elements per LDS stage (32 KiB)
-constexpr int CP = BN + 8;                           // C tile pitch (elements)
+constexpr int BK = 64;
 
 struct GemmParams {
     const bf16_t* a; const bf16_t* w; const bf16_t* bias; const bf16_t* temb; const bf16_t* res; bf16_t* out;
@@ -43,87 +51,99 @@ __device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.f + er
 // physical 16-byte chunk of logical chunk c in tile row r (8 chunks per 128-byte row)
 __device__ __forceinline__ int swz(int r, int c) { return c ^ ((r >> 1) & 7); }
 
-// MODE 0: token GEMM, 1: implicit 3x3 conv.  EPI 0: (+bias)(+temb)(+residual); 1: GEGLU (weights pre-interleaved so
-// that tile columns [0,64) are the value half and [64,128) the matching gate half; out is [M, N/2]).
-template <int MODE, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams P) {
+// 16 zero bytes in global memory: the LDS-DMA source of out-of-range rows / padding taps
+__device__ u32x4 g_zero16 = {0u, 0u, 0u, 0u};
+
+// one 1-KiB LDS-DMA piece: lane i's 16 bytes land at lds_base + 16*i (global_load_lds_dwordx4)
+__device__ __forceinline__ void dma16(const bf16_t* gsrc, bf16_t* lds_base_wave_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_base_wave_uniform, 16, 0, 0);
+}
+
+// MODE 0: token GEMM, 1: implicit 3x3 conv.  EPI 0: alpha*(acc+bias) (+temb)(+residual); 1: GEGLU (weights
+// pre-interleaved per 128 rows: 64 value rows then their 64 gate rows; out is [M, N/2]).
+template <int MODE, int EPI, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) == 4 ? 2 : (WM * WN) / 4)
+void gemm_kernel(const GemmParams P) {
+    constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN, NT = 64 * NW;
+    constexpr int STAGE_ELEMS = (BM + BN) * BK;
+    constexpr int PIECES = (BM + BN) / 8;            // 1-KiB pieces (8 rows x 128 B) per k-tile
+    constexpr int PPW = PIECES / NW;                 // pieces per wave
+    constexpr int CP = BN + 8;                       // fp32 C slab pitch
+    static_assert(PIECES % NW == 0, "pieces must divide evenly over the waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, half = lane >> 5;
 
     // ---- tile order: XCD aware (blockIdx % 8 = XCD): n-tiles of one m-tile stay on one XCD --------------------
     int tile_m, tile_n;
     {
         const int id = blockIdx.x, total = P.tiles_m * P.tiles_n;
-        const int per_xcd = (total + 7) / 8;
-        const int xcd = id & 7, j = id >> 3;
-        int lin = xcd * per_xcd + j;                 // contiguous range of the linear (m-major) order per XCD
-        if ((total & 7) != 0) lin = id;              // keep it bijective when 8 does not divide the grid
+        int lin = id;
+        if ((total & 7) == 0) lin = (id & 7) * (total >> 3) + (id >> 3);
         tile_m = lin / P.tiles_n;
         tile_n = lin - tile_m * P.tiles_n;
-        if (tile_m >= P.tiles_m) return;
     }
     const int64_t m0 = (int64_t)tile_m * BM;
     const int n0 = tile_n * BN;
 
-    // ---- per-thread staging slots: 4 A chunks + 4 W chunks of 16 bytes per k-tile ----------------------------------
-    const int srow = tid >> 3, sc = tid & 7;        // rows srow + 32*j, chunk sc
-    const bf16_t* aptr[4];
-    bool aval[4];
-    int ay[4], ax[4];
-    const bf16_t* wptr[4];
-    bool wval[4];
+    // ---- my LDS-DMA pieces: piece p = wave + NW*j; p < BM/8 -> rows 8p.. of A, else rows of W --------------------
+    const bf16_t* src[PPW];
+    bool val[PPW];
+    int py[PPW], px[PPW];
+    const int prow = lane >> 3, pphys = lane & 7;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int64_t m = m0 + srow + 32 * j;
-        aval[j] = m < P.M;
-        if (MODE == 0) {
-            aptr[j] = P.a + (aval[j] ? m : 0) * P.lda + sc * 8;
-            ay[j] = ax[j] = 0;
-        } else {
-            const int64_t mm = aval[j] ? m : 0;
-            const int pix = (int)(mm % P.hw);
-            ay[j] = pix / P.img_w;
-            ax[j] = pix - ay[j] * P.img_w;
-            aptr[j] = P.a + mm * P.cin + sc * 8;
-        }
-        const int n = n0 + srow + 32 * j;
-        wval[j] = n < P.N;
-        wptr[j] = P.w + (int64_t)(wval[j] ? n : 0) * P.K + sc * 8;
-    }
-
-    u32x4 ra[4], rb[4];
-    auto gload = [&](int kt) {
-        const int k0 = kt * BK;
-        if (MODE == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                ra[j] = aval[j] ? *reinterpret_cast<const u32x4*>(aptr[j] + k0) : u32x4{0u, 0u, 0u, 0u};
-        } else {
-            const int tap = k0 / P.cin, ci0 = k0 - tap * P.cin;
-            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-            const int64_t shift = ((int64_t)dy * P.img_w + dx) * P.cin + ci0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool ok = aval[j] && (unsigned)(ay[j] + dy) < (unsigned)P.img_h &&
-                                (unsigned)(ax[j] + dx) < (unsigned)P.img_w;
-                ra[j] = ok ? *reinterpret_cast<const u32x4*>(aptr[j] + shift) : u32x4{0u, 0u, 0u, 0u};
+    for (int j = 0; j < PPW; ++j) {
+        const int p = wave + NW * j;
+        if (p < BM / 8) {
+            const int rloc = 8 * p + prow;
+            const int sc = swz(rloc, pphys);
+            const int64_t m = m0 + rloc;
+            val[j] = m < P.M;
+            const int64_t mm = val[j] ? m : 0;
+            if (MODE == 0) {
+                src[j] = P.a + mm * P.lda + sc * 8;
+                py[j] = px[j] = 0;
+            } else {
+                const int pix = (int)(mm % P.hw);
+                py[j] = pix / P.img_w;
+                px[j] = pix - py[j] * P.img_w;
+                src[j] = P.a + mm * P.cin + sc * 8;
             }
+        } else {
+            const int rloc = 8 * (p - BM / 8) + prow;
+            const int sc = swz(rloc, pphys);
+            const int n = n0 + rloc;
+            val[j] = n < P.N;
+            src[j] = P.w + (int64_t)(val[j] ? n : 0) * P.K + sc * 8;
+            py[j] = px[j] = 0;
+        }
+    }
+    auto dma_issue = [&](int kt, int buf) {
+        const int k0 = kt * BK;
+        bf16_t* stage = smem + buf * STAGE_ELEMS;
+        const bf16_t* zero = reinterpret_cast<const bf16_t*>(&g_zero16);
+        int64_t shift = k0;
+        int dy = 0, dx = 0;
+        if (MODE == 1) {
+            const int tap = k0 / P.cin, ci0 = k0 - tap * P.cin;
+            dy = tap / 3 - 1;
+            dx = tap - (tap / 3) * 3 - 1;
+            shift = ((int64_t)dy * P.img_w + dx) * P.cin + ci0;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            rb[j] = wval[j] ? *reinterpret_cast<const u32x4*>(wptr[j] + k0) : u32x4{0u, 0u, 0u, 0u};
-    };
-    auto lstore = [&](int buf) {
-        bf16_t* As = smem + buf * STAGE_ELEMS;
-        bf16_t* Ws = As + BM * BK;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = srow + 32 * j;
-            *reinterpret_cast<u32x4*>(As + r * BK + swz(r, sc) * 8) = ra[j];
-            *reinterpret_cast<u32x4*>(Ws + r * BK + swz(r, sc) * 8) = rb[j];
+        for (int j = 0; j < PPW; ++j) {
+            const int p = wave + NW * j;             // wave-uniform
+            if (p < BM / 8) {
+                bool ok = val[j];
+                if (MODE == 1)
+                    ok = ok && (unsigned)(py[j] + dy) < (unsigned)P.img_h && (unsigned)(px[j] + dx) < (unsigned)P.img_w;
+                dma16(ok ? src[j] + shift : zero, stage + p * 8 * BK);
+            } else {
+                dma16(val[j] ? src[j] + k0 : zero, stage + p * 8 * BK);   // W rows follow the A rows in the stage
+            }
         }
     };
 
@@ -136,11 +156,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams P) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int nk = P.K / BK;
-    gload(0);
-    lstore(0);
-    __syncthreads();
+    dma_issue(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) gload(kt + 1);
+        // my pieces of tile kt have landed; after the barrier everybody's have, and everybody has finished reading
+        // the other stage (compute kt-1), so tile kt+1 may start streaming into it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk) dma_issue(kt + 1, (kt + 1) & 1);
         const bf16_t* As = smem + (kt & 1) * STAGE_ELEMS;
         const bf16_t* Ws = As + BM * BK;
 #pragma unroll
@@ -162,17 +184,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams P) {
                 for (int mi = 0; mi < 2; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
         }
-        if (kt + 1 < nk) lstore((kt + 1) & 1);
-        __syncthreads();
     }
 
-    // ---- epilogue: C tile -> LDS (bf16 would lose the fp32 sum before bias/residual: keep fp32 pairs packed later)
-    // The tile is staged as fp32-accurate bf16 AFTER adding nothing; bias / temb / residual are added in fp32 on the
-    // way out from a second fp32 staging would cost 64 KiB, so the sum is rounded once here and once at the store:
-    // instead we stage fp32 in two halves of 64 rows to keep full precision until the final rounding.
-    float* Cs = reinterpret_cast<float*>(smem_raw);             // [64][CP] fp32 = 34 KiB per half
-#pragma unroll
-    for (int hm = 0; hm < 2; ++hm) {
+    // ---- epilogue: fp32 C slabs of 64 rows through LDS, bias / alpha / temb / residual / GEGLU on the way out ----------
+    float* Cs = reinterpret_cast<float*>(smem_raw);             // [64][CP] fp32
+#pragma unroll 1
+    for (int hm = 0; hm < WM; ++hm) {
         __syncthreads();
         if (wm == hm) {
 #pragma unroll
@@ -189,15 +206,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams P) {
         }
         __syncthreads();
         if (EPI == 0) {
-            // 64 rows x 16 chunks of 8 columns; thread: chunk = tid & 15, rows tid>>4 + 16*i
-            const int ch = tid & 15, n = n0 + ch * 8;
+            constexpr int CPR = BN / 8;                  // 8-column chunks per slab row
+            constexpr int RSTEP = NT / CPR;              // rows covered per pass
+            const int ch = tid % CPR, n = n0 + ch * 8;
             if (n < P.N) {
                 float bv[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) bv[i] = P.bias ? bf2f(P.bias[n + i]) : 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = (tid >> 4) + 16 * i;
+                for (int r = tid / CPR; r < 64; r += RSTEP) {
                     const int64_t m = m0 + hm * 64 + r;
                     if (m >= P.M) continue;
                     float v[8];
@@ -220,23 +236,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams P) {
                 }
             }
         } else {
-            // GEGLU: value columns [0,64), gate columns [64,128) of the tile -> 64 output columns
-            const int ch = tid & 7, no = tile_n * 64 + ch * 8;      // output column
+            // GEGLU: within every 128 tile columns, [0,64) = value, [64,128) = gate -> 64 output columns
+            constexpr int CPR = BN / 16;                 // 8-column output chunks per slab row
+            constexpr int RSTEP = NT / CPR;
+            const int ch = tid % CPR;
+            const int grp = ch / 8, cc = ch % 8;         // 128-column group inside the tile, chunk inside the group
+            const int ncol = grp * 128 + cc * 8;         // tile column of the value chunk
+            const int no = (n0 / 2) + grp * 64 + cc * 8; // output column
             if (no < P.N / 2) {
                 float ba[8], bg[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    ba[i] = P.bias ? bf2f(P.bias[n0 + ch * 8 + i]) : 0.f;
-                    bg[i] = P.bias ? bf2f(P.bias[n0 + 64 + ch * 8 + i]) : 0.f;
+                    ba[i] = P.bias ? bf2f(P.bias[n0 + ncol + i]) : 0.f;
+                    bg[i] = P.bias ? bf2f(P.bias[n0 + ncol + 64 + i]) : 0.f;
                 }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int r = (tid >> 3) + 32 * i;
+                for (int r = tid / CPR; r < 64; r += RSTEP) {
                     const int64_t m = m0 + hm * 64 + r;
                     if (m >= P.M) continue;
                     float a[8], g[8];
-                    Vec8<float>::load(Cs + r * CP + ch * 8, a);
-                    Vec8<float>::load(Cs + r * CP + 64 + ch * 8, g);
+                    Vec8<float>::load(Cs + r * CP + ncol, a);
+                    Vec8<float>::load(Cs + r * CP + ncol + 64, g);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) a[k] = (a[k] + ba[k]) * gelu_erf(g[k] + bg[k]);
                     Vec8<bf16_t>::store(P.out + m * P.ldo + no, a);
@@ -246,32 +265,59 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams P) {
     }
 }
 
-template <int MODE, int EPI>
-int launch_gemm(GemmParams& P, hipStream_t st) {
+int gemm_geometry_override() {           // FMC_GEMM_TILE = 0 (caller's choice) | 1: 128x128 | 2: 256x128 | 3: 256x256
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("FMC_GEMM_TILE");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
+template <int MODE, int EPI, int WM, int WN>
+void launch_gemm_g(GemmParams& P, hipStream_t st) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
     P.tiles_m = (int)((P.M + BM - 1) / BM);
     P.tiles_n = (P.N + BN - 1) / BN;
-    const int total = P.tiles_m * P.tiles_n;
-    const int grid = (total % 8 == 0) ? total : total;      // non-multiples of 8 use the identity map in-kernel
-    const size_t lds = (size_t)2 * STAGE_ELEMS * sizeof(bf16_t);   // 64 KiB; also covers the 34 KiB fp32 C staging
+    size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16_t);
+    const size_t slab = (size_t)64 * (BN + 8) * sizeof(float);
+    if (slab > lds) lds = slab;
     static bool raised = false;
     if (!raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, EPI>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, EPI, WM, WN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         raised = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<MODE, EPI>), dim3(grid), dim3(256), lds, st, P);
-    return 0;
+    hipLaunchKernelGGL((gemm_kernel<MODE, EPI, WM, WN>), dim3(P.tiles_m * P.tiles_n), dim3(64 * WM * WN), lds, st, P);
+}
+
+// geometry: the largest tile that still gives every CU work and does not waste more than ~20 % of N
+template <int MODE, int EPI>
+void launch_gemm(GemmParams& P, int tile, hipStream_t st) {
+    int g = gemm_geometry_override();
+    if (g == 0) g = tile;
+    if (g == 0) {
+        auto tiles = [&](int bm, int bn) { return ((P.M + bm - 1) / bm) * ((P.N + bn - 1) / bn); };
+        auto waste = [&](int bn) { return (double)(((P.N + bn - 1) / bn) * bn) / P.N; };
+        if (tiles(256, 256) >= 256 && waste(256) <= 1.2) g = 3;
+        else if (tiles(256, 128) >= 256 && waste(128) <= 1.25) g = 2;
+        else g = 1;
+    }
+    if (g == 3) launch_gemm_g<MODE, EPI, 4, 4>(P, st);
+    else if (g == 2) launch_gemm_g<MODE, EPI, 4, 2>(P, st);
+    else launch_gemm_g<MODE, EPI, 2, 2>(P, st);
 }
 
 }  // namespace
 
 extern "C" int fmc_linear_bf16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,
-                               int N, int K, int64_t ldx, int64_t ldres, int64_t ldo, float alpha, int epilogue, void* stream) {
+                               int N, int K, int64_t ldx, int64_t ldres, int64_t ldo, float alpha, int epilogue, int tile,
+                               void* stream) {
     if (!x || !w || !out) FMC_FAIL(FMC_E_NULL, "linear_bf16: NULL tensor");
     if (M <= 0 || N <= 0 || K <= 0 || K % BK || N % 8 || ldx % 8 || ldo % 8 || (residual && ldres % 8))
         FMC_FAIL(FMC_E_SHAPE, "linear_bf16: need K%%64==0, N%%8==0 and strides %%8==0 (M=%lld N=%d K=%d)", (long long)M, N, K);
     if (epilogue != 0 && epilogue != 1) FMC_FAIL(FMC_E_SHAPE, "linear_bf16: epilogue %d", epilogue);
-    if (epilogue == 1 && (N % BN || residual)) FMC_FAIL(FMC_E_SHAPE, "linear_bf16: GEGLU needs N%%128==0 and no residual");
+    if (epilogue == 1 && (N % 256 || residual)) FMC_FAIL(FMC_E_SHAPE, "linear_bf16: GEGLU needs N%%256==0 and no residual");
     if (!fmc_aligned16(x) || !fmc_aligned16(w) || !fmc_aligned16(out) || (residual && !fmc_aligned16(residual)) ||
         (bias && !fmc_aligned16(bias)))
         FMC_FAIL(FMC_E_ALIGN, "linear_bf16: tensors must be 16-byte aligned");
@@ -281,13 +327,14 @@ extern "C" int fmc_linear_bf16(const void* x, const void* w, const void* bias, c
     P.M = M; P.N = N; P.K = K; P.lda = ldx; P.ldres = ldres; P.ldo = ldo;
     P.img_h = P.img_w = P.cin = 0; P.hw = 1; P.alpha = alpha;
     hipStream_t st = (hipStream_t)stream;
-    if (epilogue == 0) launch_gemm<0, 0>(P, st); else launch_gemm<0, 1>(P, st);
+    if (tile < 0 || tile > 3) FMC_FAIL(FMC_E_SHAPE, "linear_bf16: tile %d", tile);
+    if (epilogue == 0) launch_gemm<0, 0>(P, tile, st); else launch_gemm<0, 1>(P, tile, st);
     FMC_CHECK_LAUNCH("fmc_linear_bf16");
     return 0;
 }
 
 extern "C" int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, const void* temb, const void* residual,
-                                void* out, int n_img, int H, int W, int Cin, int Cout, void* stream) {
+                                void* out, int n_img, int H, int W, int Cin, int Cout, int tile, void* stream) {
     if (!x || !w || !out) FMC_FAIL(FMC_E_NULL, "conv3x3_bf16: NULL tensor");
     if (n_img <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % BK || Cout % 8)
         FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: need Cin%%64==0 and Cout%%8==0 (Cin=%d Cout=%d)", Cin, Cout);
@@ -299,7 +346,8 @@ extern "C" int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, 
     P.res = (const bf16_t*)residual; P.out = (bf16_t*)out;
     P.M = (int64_t)n_img * H * W; P.N = Cout; P.K = 9 * Cin; P.lda = Cin; P.ldres = Cout; P.ldo = Cout;
     P.img_h = H; P.img_w = W; P.cin = Cin; P.hw = H * W; P.alpha = 1.f;
-    launch_gemm<1, 0>(P, (hipStream_t)stream);
+    if (tile < 0 || tile > 3) FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: tile %d", tile);
+    launch_gemm<1, 0>(P, tile, (hipStream_t)stream);
     FMC_CHECK_LAUNCH("fmc_conv3x3_bf16");
     return 0;
 }

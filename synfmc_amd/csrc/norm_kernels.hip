@@ -304,19 +304,20 @@ __global__ void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y, con
             const int ch = lane + 64 * k;
             if (ch >= nchunks) continue;
             float gm[8], bt[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { gm[i] = gamma[ch * 8 + i]; bt[i] = beta[ch * 8 + i]; }
+            Vec8<float>::load(gamma + ch * 8, gm);
+            Vec8<float>::load(beta + ch * 8, bt);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int64_t row = row0 + r;
                 if (row >= M) continue;
                 const float rs = rsqrtf(rstd[r] * inv_c + eps);
                 const float* per = pe ? pe + (size_t)((row / pe_inner) % pe_frames) * C + ch * 8 : nullptr;
-                float o[8];
+                float o[8], pv[8];
+                if (per) Vec8<float>::load(per, pv);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     o[i] = (v[r][k][i] - mean[r]) * rs * gm[i] + bt[i];
-                    if (per) o[i] += per[i];
+                    if (per) o[i] += pv[i];
                 }
                 Vec8<T>::store(y + row * C + ch * 8, o);
             }
@@ -412,26 +413,37 @@ extern "C" int fmc_groupnorm_silu_bwd(const void* dy, const void* x, void* dx, c
     return 0;
 }
 
+template <typename T, int NCH, int R>
+static void launch_ln_r(const void* x, void* y, const float* gamma, const float* beta, const float* pe, int64_t M, int C,
+                        float eps, int pe_inner, int pe_frames, hipStream_t st) {
+    const int wpb = 4;
+    int64_t blocks = (M + wpb * R - 1) / (wpb * R);
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL((layernorm_kernel<T, NCH, R>), dim3((unsigned)blocks), dim3(64 * wpb), 0, st, (const T*)x, (T*)y,
+                       gamma, beta, pe, M, C, eps, pe_inner, pe_frames);
+}
+
+// rows per wave: 4 when there are plenty of rows (loads in flight per lane), fewer when the row count alone cannot
+// fill 256 CUs x 8 waves (level 2/3 token matrices have only 1280-5120 rows)
+template <typename T, int NCH>
+static void launch_ln_n(const void* x, void* y, const float* gamma, const float* beta, const float* pe, int64_t M, int C,
+                        float eps, int pe_inner, int pe_frames, hipStream_t st) {
+    if (NCH <= 3 && M >= 32768) launch_ln_r<T, NCH, 4>(x, y, gamma, beta, pe, M, C, eps, pe_inner, pe_frames, st);
+    else if (M >= 16384) launch_ln_r<T, NCH, 2>(x, y, gamma, beta, pe, M, C, eps, pe_inner, pe_frames, st);
+    else launch_ln_r<T, NCH, 1>(x, y, gamma, beta, pe, M, C, eps, pe_inner, pe_frames, st);
+}
+
 template <typename T>
 static void launch_ln(const void* x, void* y, const float* gamma, const float* beta, const float* pe, int64_t M, int C,
                       float eps, int pe_inner, int pe_frames, hipStream_t st) {
-    const int nch = (C / 8 + 63) / 64;
-    const int wpb = 4;
-    const int R = nch <= 3 ? 4 : 2;
-    int64_t blocks = (M + wpb * R - 1) / (wpb * R);
-    if (blocks > 65536) blocks = 65536;
-    dim3 grid((unsigned)blocks), block(64 * wpb);
-#define LN_CASE(K, RR)                                                                                                  \
-    case K:                                                                                                             \
-        hipLaunchKernelGGL((layernorm_kernel<T, K, RR>), grid, block, 0, st, (const T*)x, (T*)y, gamma, beta, pe, M, C, \
-                           eps, pe_inner, pe_frames);                                                                   \
-        break;
-    switch (nch) {
-        LN_CASE(1, 4) LN_CASE(2, 4) LN_CASE(3, 4) LN_CASE(4, 2) LN_CASE(5, 2)
+    switch ((C / 8 + 63) / 64) {
+        case 1: launch_ln_n<T, 1>(x, y, gamma, beta, pe, M, C, eps, pe_inner, pe_frames, st); break;
+        case 2: launch_ln_n<T, 2>(x, y, gamma, beta, pe, M, C, eps, pe_inner, pe_frames, st); break;
+        case 3: launch_ln_n<T, 3>(x, y, gamma, beta, pe, M, C, eps, pe_inner, pe_frames, st); break;
+        case 4: launch_ln_n<T, 4>(x, y, gamma, beta, pe, M, C, eps, pe_inner, pe_frames, st); break;
+        case 5: launch_ln_n<T, 5>(x, y, gamma, beta, pe, M, C, eps, pe_inner, pe_frames, st); break;
         default: break;
     }
-#undef LN_CASE
-    (void)R;
 }
 
 extern "C" int fmc_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, const float* pe,

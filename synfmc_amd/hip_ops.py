@@ -329,7 +329,8 @@ def _rows2d(t: torch.Tensor):
 
 
 def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
-                residual: Optional[torch.Tensor] = None, alpha: float = 1.0, geglu: bool = False) -> torch.Tensor:
+                residual: Optional[torch.Tensor] = None, alpha: float = 1.0, geglu: bool = False,
+                tile: int = 0) -> torch.Tensor:
     """`alpha * (x @ weight^T + bias) + residual` (or the GEGLU gate, see fmc_linear_bf16) on the bf16 MFMA kernel.
     x `[..., K]`, weight `[N, K]`; residual has the output's shape."""
     _dev(x, weight, bias, residual)
@@ -342,7 +343,7 @@ def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
         assert residual.shape == out.shape
         _, ldres = _rows2d(residual)
     _lib.check(_lib.load().fmc_linear_bf16(x.data_ptr(), weight.data_ptr(), _p(bias), _p(residual), out.data_ptr(), M, N,
-                                           Kd, ldx, ldres, n_out, float(alpha), int(geglu), _stream()),
+                                           Kd, ldx, ldres, n_out, float(alpha), int(geglu), int(tile), _stream()),
                "fmc_linear_bf16")
     return out
 
@@ -354,7 +355,8 @@ def conv3x3_supported(x: torch.Tensor, weight: torch.Tensor, stride, padding) ->
 
 
 def conv3x3_bf16(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias: Optional[torch.Tensor] = None,
-                 temb: Optional[torch.Tensor] = None, residual_nhwc: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 temb: Optional[torch.Tensor] = None, residual_nhwc: Optional[torch.Tensor] = None,
+                 tile: int = 0) -> torch.Tensor:
     """x `[N, H, W, Cin]` contiguous, weight `[Cout, Cin, 3, 3]` in channels_last memory format (physically
     `[Cout, 3, 3, Cin]`), temb `[N, Cout]`, residual `[N, H, W, Cout]` -> `[N, H, W, Cout]`."""
     _dev(x_nhwc, weight_cl, bias, temb, residual_nhwc)
@@ -365,7 +367,7 @@ def conv3x3_bf16(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias: Optional[t
     assert residual_nhwc is None or (residual_nhwc.is_contiguous() and residual_nhwc.shape == (n, h, w, cout))
     out = torch.empty(n, h, w, cout, dtype=x_nhwc.dtype, device=x_nhwc.device)
     _lib.check(_lib.load().fmc_conv3x3_bf16(x_nhwc.data_ptr(), weight_cl.data_ptr(), _p(bias), _p(temb),
-                                            _p(residual_nhwc), out.data_ptr(), n, h, w, cin, cout, _stream()),
+                                            _p(residual_nhwc), out.data_ptr(), n, h, w, cin, cout, int(tile), _stream()),
                "fmc_conv3x3_bf16")
     return out
 
@@ -392,12 +394,14 @@ def _time_ms(fn, iters=4):
     return e0.elapsed_time(e1) / iters
 
 
-def _pick(key, hip_fn, lib_fn, static_hip: bool) -> bool:
+def _pick(key, hip_fn, lib_fn, static_hip: bool) -> int:
+    """0 = vendor library arm, 1..3 = fused gfx950 kernel with that tile geometry (`hip_fn(tile)`)."""
     use = _choice.get(key)
     if use is None:
         if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
-            return static_hip
-        use = _time_ms(hip_fn) <= _time_ms(lib_fn)
+            return 0 if not static_hip else -1          # -1: kernel's own geometry heuristic
+        times = [(_time_ms(lib_fn), 0)] + [(_time_ms(lambda t=t: hip_fn(t)), t) for t in (1, 2, 3)]
+        use = min(times)[1]
         _choice[key] = use
     return use
 
@@ -418,9 +422,9 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     N, Kd = weight.shape
     M = x.numel() // Kd
     key = ("lin", M, N, Kd, bias is not None, residual is not None)
-    hip = lambda: linear_bf16(x, weight, bias, residual, alpha)
-    static = Kd <= 640 and N <= 1024 and M >= 16384
-    return hip() if _pick(key, hip, lib, static) else lib()
+    hip = lambda tile: linear_bf16(x, weight, bias, residual, alpha, tile=tile)
+    use = _pick(key, hip, lib, Kd <= 640 and N <= 1024 and M >= 16384)
+    return lib() if use == 0 else hip(max(use, 0))
 
 
 def geglu_linear(x: torch.Tensor, weight: torch.Tensor, bias, weight_il: torch.Tensor, bias_il) -> torch.Tensor:
@@ -428,12 +432,13 @@ def geglu_linear(x: torch.Tensor, weight: torch.Tensor, bias, weight_il: torch.T
     `bias_il` are the tile-interleaved copies the fused kernel wants (`models.layers.interleave_geglu`)."""
     import torch.nn.functional as F
     lib = lambda: geglu(F.linear(x, weight, bias))
-    if not linear_supported(x, weight_il) or weight_il.shape[0] % 128 or (x.ndim > 2 and not x.is_contiguous()):
+    if not linear_supported(x, weight_il) or weight_il.shape[0] % 256 or (x.ndim > 2 and not x.is_contiguous()):
         return lib()
     N, Kd = weight.shape
     M = x.numel() // Kd
-    hip = lambda: linear_bf16(x, weight_il, bias_il, geglu=True)
-    return hip() if _pick(("geglu", M, N, Kd), hip, lib, M >= 65536) else lib()
+    hip = lambda tile: linear_bf16(x, weight_il, bias_il, geglu=True, tile=tile)
+    use = _pick(("geglu", M, N, Kd), hip, lib, M >= 65536)
+    return lib() if use == 0 else hip(max(use, 0))
 
 
 def conv3x3(x_nchw: torch.Tensor, weight_cl: torch.Tensor, bias, temb=None, residual_nchw=None, stride=(1, 1),
@@ -459,6 +464,7 @@ def conv3x3(x_nchw: torch.Tensor, weight_cl: torch.Tensor, bias, temb=None, resi
     if not x.is_contiguous() or (r is not None and not r.is_contiguous()):
         return lib()
     key = ("conv", n, h, w, cin, cout, temb is not None, r is not None)
-    hip = lambda: conv3x3_bf16(x, weight_cl, bias, temb, r).permute(0, 3, 1, 2)
+    hip = lambda tile: conv3x3_bf16(x, weight_cl, bias, temb, r, tile=tile).permute(0, 3, 1, 2)
     tiles = ((n * h * w + 127) // 128) * ((cout + 127) // 128)
-    return hip() if _pick(key, hip, lib, tiles >= 256) else lib()
+    use = _pick(key, hip, lib, tiles >= 256)
+    return lib() if use == 0 else hip(max(use, 0))
