@@ -187,6 +187,33 @@ int fmc_linear_bf16(const void* x, const void* w, const void* bias, const void* 
 int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, const void* temb, const void* residual, void* out,
                      int n_img, int H, int W, int Cin, int Cout, int tile, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Backward entry points (training stages 2/3 of the reference: the U-Net is frozen but the activation gradient
+ * flows through every layer back to the OMC / CMC injection points, train_cam_obj_ctrl.py:917-929,
+ * train_cam_ctrl.py:626-650; in the reference this is PyTorch autograd through the same call sites as the forwards).
+ * ------------------------------------------------------------------------------------------- */
+/* dX (and optionally dgamma / dbeta, fp32 [C], ACCUMULATED into: zero them first) of fmc_layernorm_fwd. */
+int fmc_layernorm_bwd(const void* dy, const void* x, const float* gamma, void* dx, float* dgamma, float* dbeta,
+                      int64_t M, int C, float eps, int dtype, void* stream);
+/* dX [M, 2*Cff] of fmc_geglu_fwd from dy [M, Cff] and the forward input x. */
+int fmc_geglu_bwd(const void* dy, const void* x, void* dx, int64_t M, int Cff, int dtype, void* stream);
+/* dQ, dK, dV of fmc_spatial_attn_fwd.  o / lse are the forward's outputs, d_o has o's strides, dvec is a
+ * [B, H, Sq] fp32 scratch (receives rowsum(dO .* O)).  dk / dv are [B / kv_batch_div, Skv, H*D]: frames sharing one
+ * text K/V are summed inside the kernel. */
+int fmc_spatial_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                         float* dvec, void* dq, void* dk, void* dv, int B, int H, int Sq, int Skv, int D,
+                         int64_t q_batch_stride, int64_t q_row_stride, int64_t kv_batch_stride, int64_t kv_row_stride,
+                         int64_t o_batch_stride, int64_t o_row_stride, int64_t dq_batch_stride, int64_t dq_row_stride,
+                         int64_t dkv_batch_stride, int64_t dkv_row_stride, int kv_batch_div, float scale, int dtype,
+                         void* stream);
+/* dQ, dK, dV of fmc_temporal_attn_fwd (probabilities are recomputed; nothing saved by the forward).
+ * q/k/v share (clip, frame, pix) strides, d_o has its own, dq/dk/dv share a third triple. */
+int fmc_temporal_attn_bwd(const void* q, const void* k, const void* v, const void* d_o, void* dq, void* dk, void* dv,
+                          int n_clips, int n_pix, int F, int H, int D, int64_t clip_stride, int64_t frame_stride,
+                          int64_t pix_stride, int64_t do_clip_stride, int64_t do_frame_stride, int64_t do_pix_stride,
+                          int64_t dq_clip_stride, int64_t dq_frame_stride, int64_t dq_pix_stride, float scale,
+                          int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -345,6 +345,120 @@ __global__ void geglu_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t
     }
 }
 
+// --------------------------------------------------------------------------------------------
+// LayerNorm backward: dx = rstd * (dyh - mean(dyh) - xh * mean(dyh * xh)), dyh = dy * gamma, per row; mean / rstd are
+// recomputed from x (nothing saved by the forward).  Optional dgamma / dbeta: per-wave register partials over its
+// rows, then one fp32 atomicAdd per channel per wave (buffers zeroed by the caller).
+// --------------------------------------------------------------------------------------------
+template <typename T, int NCH>
+__global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
+                                     T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                     int64_t M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wpb = blockDim.x >> 6;
+    const int nchunks = C / 8;
+    const float inv_c = 1.f / (float)C;
+    float gm[NCH][8], ag[NCH][8], ab[NCH][8];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + 64 * k;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { gm[k][i] = ch < nchunks ? gamma[ch * 8 + i] : 0.f; ag[k][i] = ab[k][i] = 0.f; }
+    }
+    for (int64_t row = (int64_t)blockIdx.x * wpb + wave; row < M; row += (int64_t)gridDim.x * wpb) {
+        float v[NCH][8], d[NCH][8];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = lane + 64 * k;
+            if (ch < nchunks) {
+                Vec8<T>::load(x + row * C + ch * 8, v[k]);
+                Vec8<T>::load(dy + row * C + ch * 8, d[k]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s += v[k][i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[k][i] = d[k][i] = 0.f;
+            }
+        }
+        const float mean = wave_sum(s) * inv_c;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+            if (lane + 64 * k < nchunks) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float t = v[k][i] - mean; q += t * t; }
+            }
+        const float rstd = rsqrtf(wave_sum(q) * inv_c + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+            if (lane + 64 * k < nchunks) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float xh = (v[k][i] - mean) * rstd;
+                    const float dyh = d[k][i] * gm[k][i];
+                    s1 += dyh;
+                    s2 += dyh * xh;
+                    ag[k][i] += d[k][i] * xh;
+                    ab[k][i] += d[k][i];
+                    v[k][i] = xh;
+                    d[k][i] = dyh;
+                }
+            }
+        const float m1 = wave_sum(s1) * inv_c, m2 = wave_sum(s2) * inv_c;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = lane + 64 * k;
+            if (ch < nchunks) {
+                float o[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = rstd * (d[k][i] - m1 - v[k][i] * m2);
+                Vec8<T>::store(dx + row * C + ch * 8, o);
+            }
+        }
+    }
+    if (dgamma) {
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = lane + 64 * k;
+            if (ch < nchunks) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    atomicAdd(dgamma + ch * 8 + i, ag[k][i]);
+                    atomicAdd(dbeta + ch * 8 + i, ab[k][i]);
+                }
+            }
+        }
+    }
+}
+
+// GEGLU backward: y = a * gelu(g):  da = dy * gelu(g),  dg = dy * a * (Phi(g) + g * phi(g))
+template <typename T>
+__global__ void geglu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dx, int64_t M, int Cff) {
+    const int cpr = Cff / 8;
+    const int64_t total = M * cpr;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = idx / cpr;
+        const int c = (int)(idx - m * cpr) * 8;
+        float a[8], g[8], d[8], da[8], dg[8];
+        Vec8<T>::load(x + m * 2 * Cff + c, a);
+        Vec8<T>::load(x + m * 2 * Cff + Cff + c, g);
+        Vec8<T>::load(dy + m * Cff + c, d);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float cdf = 0.5f * (1.f + erff(g[i] * 0.70710678118654752f));
+            const float pdf = 0.3989422804014327f * __expf(-0.5f * g[i] * g[i]);
+            da[i] = d[i] * g[i] * cdf;
+            dg[i] = d[i] * a[i] * (cdf + g[i] * pdf);
+        }
+        Vec8<T>::store(dx + m * 2 * Cff + c, da);
+        Vec8<T>::store(dx + m * 2 * Cff + Cff + c, dg);
+    }
+}
+
 int gn_check(const void* x, const void* y, int N, int HW, int C, int G, int dtype) {
     if (!x || !y) FMC_FAIL(FMC_E_NULL, "groupnorm: NULL tensor");
     if (dtype != FMC_BF16 && dtype != FMC_F32) FMC_FAIL(FMC_E_DTYPE, "groupnorm: dtype %d", dtype);
@@ -474,5 +588,54 @@ extern "C" int fmc_geglu_fwd(const void* x, void* y, int64_t M, int Cff, int dty
     else if (dtype == FMC_F32) hipLaunchKernelGGL((geglu_kernel<float>), grid, block, 0, st, (const float*)x, (float*)y, M, Cff);
     else FMC_FAIL(FMC_E_DTYPE, "geglu: dtype %d", dtype);
     FMC_CHECK_LAUNCH("fmc_geglu_fwd");
+    return 0;
+}
+
+template <typename T>
+static void launch_ln_bwd(const void* dy, const void* x, const float* gamma, void* dx, float* dgamma, float* dbeta,
+                          int64_t M, int C, float eps, hipStream_t st) {
+    const int wpb = 4;
+    int64_t blocks = (M + wpb - 1) / wpb;
+    if (blocks > 2048) blocks = 2048;            // grid-stride: every wave owns many rows -> few dgamma/dbeta atomics
+    dim3 grid((unsigned)blocks), block(64 * wpb);
+#define LNB_CASE(K)                                                                                                   \
+    case K:                                                                                                           \
+        hipLaunchKernelGGL((layernorm_bwd_kernel<T, K>), grid, block, 0, st, (const T*)dy, (const T*)x, gamma, (T*)dx, \
+                           dgamma, dbeta, M, C, eps);                                                                 \
+        break;
+    switch ((C / 8 + 63) / 64) {
+        LNB_CASE(1) LNB_CASE(2) LNB_CASE(3) LNB_CASE(4) LNB_CASE(5)
+        default: break;
+    }
+#undef LNB_CASE
+}
+
+extern "C" int fmc_layernorm_bwd(const void* dy, const void* x, const float* gamma, void* dx, float* dgamma,
+                                 float* dbeta, int64_t M, int C, float eps, int dtype, void* stream) {
+    if (!dy || !x || !gamma || !dx) FMC_FAIL(FMC_E_NULL, "layernorm_bwd: NULL argument");
+    if ((dgamma == nullptr) != (dbeta == nullptr)) FMC_FAIL(FMC_E_NULL, "layernorm_bwd: pass both dgamma and dbeta or neither");
+    if (M <= 0 || C <= 0 || C % 8 || C > 8 * 64 * 5) FMC_FAIL(FMC_E_SHAPE, "layernorm_bwd: need C%%8==0 and C<=2560 (C=%d)", C);
+    if (!fmc_aligned16(dy) || !fmc_aligned16(x) || !fmc_aligned16(dx)) FMC_FAIL(FMC_E_ALIGN, "layernorm_bwd: tensors must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == FMC_BF16) launch_ln_bwd<bf16_t>(dy, x, gamma, dx, dgamma, dbeta, M, C, eps, st);
+    else if (dtype == FMC_F32) launch_ln_bwd<float>(dy, x, gamma, dx, dgamma, dbeta, M, C, eps, st);
+    else FMC_FAIL(FMC_E_DTYPE, "layernorm_bwd: dtype %d", dtype);
+    FMC_CHECK_LAUNCH("fmc_layernorm_bwd");
+    return 0;
+}
+
+extern "C" int fmc_geglu_bwd(const void* dy, const void* x, void* dx, int64_t M, int Cff, int dtype, void* stream) {
+    if (!dy || !x || !dx) FMC_FAIL(FMC_E_NULL, "geglu_bwd: NULL argument");
+    if (M <= 0 || Cff <= 0 || Cff % 8) FMC_FAIL(FMC_E_SHAPE, "geglu_bwd: need Cff%%8==0 (Cff=%d)", Cff);
+    if (!fmc_aligned16(dy) || !fmc_aligned16(x) || !fmc_aligned16(dx)) FMC_FAIL(FMC_E_ALIGN, "geglu_bwd: tensors must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    int64_t total = M * (Cff / 8);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    dim3 grid((unsigned)blocks), block(256);
+    if (dtype == FMC_BF16) hipLaunchKernelGGL((geglu_bwd_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, M, Cff);
+    else if (dtype == FMC_F32) hipLaunchKernelGGL((geglu_bwd_kernel<float>), grid, block, 0, st, (const float*)dy, (const float*)x, (float*)dx, M, Cff);
+    else FMC_FAIL(FMC_E_DTYPE, "geglu_bwd: dtype %d", dtype);
+    FMC_CHECK_LAUNCH("fmc_geglu_bwd");
     return 0;
 }

@@ -211,6 +211,249 @@ __global__ __launch_bounds__(64) void temporal_attn_kernel(const TAParams P) {
     }
 }
 
+// --------------------------------------------------------------------------------------------
+// Backward.  Same unit decomposition and staging as the forward; Q, K, V, dO in, dQ, dK, dV out (7 LDS tiles).
+// With P = softmax(S), S = scale * Q K^T:   dV = P^T dO,  dP = dO V^T,  dS = P .* (dP - rowsum(P .* dP)),
+// dQ = scale * dS K,  dK = scale * dS^T Q.  The 16x16 score tiles are computed twice, once per register layout:
+//   L1 (lane = query column, registers = keys): softmax statistics are lane-local; dS^T is the B operand of
+//       dQ^T = K^T dS^T (contraction over keys);
+//   L2 (lane = key column, registers = queries): P and dS are the B operands of dV^T = dO^T P and dK^T = Q^T dS
+//       (contraction over queries); the per-query statistics come from L1 by lane shuffles.
+// All of it is noise next to the 7 HBM passes (the kernel is HBM bound like the forward).
+// --------------------------------------------------------------------------------------------
+struct TABwdParams {
+    const void* q; const void* k; const void* v; const void* d_o; void* dq; void* dk; void* dv;
+    int n_clips, n_pix, F, H, D, GH;
+    int64_t cs, fs, ps, ocs, ofs, ops, dcs, dfs, dps;
+    float scale, scale_log2;
+};
+
+template <typename T> __device__ __forceinline__ void col_f4(const T* base, int pitch, bool valid, F4<T>& f) {
+    float v4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v4[i] = valid ? ldsf(base + i * pitch) : 0.f;
+    make_f4(v4, f);
+}
+
+template <typename T, int FT, int NK32>
+__global__ __launch_bounds__(64) void temporal_attn_bwd_kernel(const TABwdParams P) {
+    constexpr int F = FT * 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int D = P.D, GH = P.GH, CW = GH * D, CPR = CW / 8, PITCH = CW + 8;
+    T* Qs = reinterpret_cast<T*>(smem_raw);
+    T* Ks = Qs + F * PITCH;
+    T* Vs = Ks + F * PITCH;
+    T* Gs = Vs + F * PITCH;      // dO
+    T* dQs = Gs + F * PITCH;
+    T* dKs = dQs + F * PITCH;
+    T* dVs = dKs + F * PITCH;
+    const int lane = threadIdx.x;
+    const int l15 = lane & 15, lg = lane >> 4;
+
+    const int groups = P.H / GH;
+    int u = blockIdx.x;
+    const int hg = u % groups; u /= groups;
+    const int pix = u % P.n_pix;
+    const int clip = u / P.n_pix;
+    const int64_t in_off = (int64_t)clip * P.cs + (int64_t)pix * P.ps + (int64_t)hg * CW;
+    const int64_t go_off = (int64_t)clip * P.ocs + (int64_t)pix * P.ops + (int64_t)hg * CW;
+    const int64_t dq_off = (int64_t)clip * P.dcs + (int64_t)pix * P.dps + (int64_t)hg * CW;
+
+    const int chunks = F * CPR;
+#pragma unroll 1
+    for (int which = 0; which < 4; ++which) {
+        const T* src = which == 0 ? (const T*)P.q + in_off : which == 1 ? (const T*)P.k + in_off
+                     : which == 2 ? (const T*)P.v + in_off : (const T*)P.d_o + go_off;
+        const int64_t fstride = which == 3 ? P.ofs : P.fs;
+        T* dst = which == 0 ? Qs : which == 1 ? Ks : which == 2 ? Vs : Gs;
+#pragma unroll 5
+        for (int c = lane; c < chunks; c += 64) {
+            const int f = c / CPR, ch = c - f * CPR;
+            float v[8];
+            Vec8<T>::load(src + (int64_t)f * fstride + ch * 8, v);
+            Vec8<T>::store(dst + f * PITCH + ch * 8, v);
+        }
+    }
+    __syncthreads();
+
+    const int ndt = (D + 15) / 16;
+    for (int hh = 0; hh < GH; ++hh) {
+        const int hc = hh * D;
+        float st_m[FT], st_inv[FT], st_d[FT];          // per query (lane l15 of tile qt), from layout L1
+        // ================= L1: lane = query, registers = keys =================
+#pragma unroll
+        for (int qt = 0; qt < FT; ++qt) {
+            F8<T> qf[NK32], gf[NK32];
+#pragma unroll
+            for (int ks = 0; ks < NK32; ++ks) {
+                const int d0 = ks * 32 + lg * 8;
+                load_f8(Qs + (qt * 16 + l15) * PITCH + hc + d0, d0 < D, qf[ks]);
+                load_f8(Gs + (qt * 16 + l15) * PITCH + hc + d0, d0 < D, gf[ks]);
+            }
+            f32x4 s[FT], dp[FT];
+#pragma unroll
+            for (int kt = 0; kt < FT; ++kt) {
+                s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dp[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < NK32; ++ks) {
+                    const int d0 = ks * 32 + lg * 8;
+                    F8<T> kf, vf;
+                    load_f8(Ks + (kt * 16 + l15) * PITCH + hc + d0, d0 < D, kf);
+                    load_f8(Vs + (kt * 16 + l15) * PITCH + hc + d0, d0 < D, vf);
+                    mma_qk(kf, qf[ks], s[kt]);
+                    mma_qk(vf, gf[ks], dp[kt]);
+                }
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < FT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s[kt][r] *= P.scale_log2; mx = fmaxf(mx, s[kt][r]); }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < FT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s[kt][r] = exp2f(s[kt][r] - mx); sum += s[kt][r]; }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.f / sum;
+            float dsum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < FT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s[kt][r] *= inv; dsum += s[kt][r] * dp[kt][r]; }
+            dsum += __shfl_xor(dsum, 16, 64);
+            dsum += __shfl_xor(dsum, 32, 64);
+            st_m[qt] = mx; st_inv[qt] = inv; st_d[qt] = dsum;
+            F4<T> dsf[FT];
+#pragma unroll
+            for (int kt = 0; kt < FT; ++kt) {
+                float d4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d4[r] = s[kt][r] * (dp[kt][r] - dsum) * P.scale;
+                make_f4(d4, dsf[kt]);
+            }
+            // dQ^T[d, q] = sum_kv K^T[d, kv] dS^T[kv, q]
+            for (int dt = 0; dt < ndt; ++dt) {
+                f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int dA = dt * 16 + l15;
+#pragma unroll
+                for (int kt = 0; kt < FT; ++kt) {
+                    F4<T> kf4;
+                    col_f4(Ks + (kt * 16 + lg * 4) * PITCH + hc + dA, PITCH, dA < D, kf4);
+                    mma_pv(kf4, dsf[kt], o);
+                }
+                const int dO_ = dt * 16 + lg * 4;
+                if (dO_ < D) {
+                    float o4[4] = {o[0], o[1], o[2], o[3]};
+                    st4<T>(dQs + (qt * 16 + l15) * PITCH + hc + dO_, o4);
+                }
+            }
+        }
+        // ================= L2: lane = key, registers = queries =================
+#pragma unroll
+        for (int kt = 0; kt < FT; ++kt) {
+            F8<T> kf[NK32], vf[NK32];
+#pragma unroll
+            for (int ks = 0; ks < NK32; ++ks) {
+                const int d0 = ks * 32 + lg * 8;
+                load_f8(Ks + (kt * 16 + l15) * PITCH + hc + d0, d0 < D, kf[ks]);
+                load_f8(Vs + (kt * 16 + l15) * PITCH + hc + d0, d0 < D, vf[ks]);
+            }
+            F4<T> pf[FT], dsf[FT];
+#pragma unroll
+            for (int qt = 0; qt < FT; ++qt) {
+                f32x4 s2 = f32x4{0.f, 0.f, 0.f, 0.f}, dp2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < NK32; ++ks) {
+                    const int d0 = ks * 32 + lg * 8;
+                    F8<T> qf, gf;
+                    load_f8(Qs + (qt * 16 + l15) * PITCH + hc + d0, d0 < D, qf);
+                    load_f8(Gs + (qt * 16 + l15) * PITCH + hc + d0, d0 < D, gf);
+                    mma_qk(qf, kf[ks], s2);          // rows q = qt*16 + lg*4 + r, col kv = kt*16 + l15
+                    mma_qk(gf, vf[ks], dp2);
+                }
+                float p4[4], d4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ql = lg * 4 + r;       // lane that owns this query's statistics in L1
+                    const float m = __shfl(st_m[qt], ql, 64), inv = __shfl(st_inv[qt], ql, 64);
+                    const float dsum = __shfl(st_d[qt], ql, 64);
+                    p4[r] = exp2f(s2[r] * P.scale_log2 - m) * inv;
+                    d4[r] = p4[r] * (dp2[r] - dsum) * P.scale;
+                }
+                make_f4(p4, pf[qt]);
+                make_f4(d4, dsf[qt]);
+            }
+            // dV^T[d, kv] = sum_q dO^T[d, q] P[q, kv];  dK^T[d, kv] = sum_q Q^T[d, q] dS[q, kv]
+            for (int dt = 0; dt < ndt; ++dt) {
+                f32x4 ov = f32x4{0.f, 0.f, 0.f, 0.f}, ok = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int dA = dt * 16 + l15;
+#pragma unroll
+                for (int qt = 0; qt < FT; ++qt) {
+                    F4<T> gf4, qf4;
+                    col_f4(Gs + (qt * 16 + lg * 4) * PITCH + hc + dA, PITCH, dA < D, gf4);
+                    col_f4(Qs + (qt * 16 + lg * 4) * PITCH + hc + dA, PITCH, dA < D, qf4);
+                    mma_pv(gf4, pf[qt], ov);
+                    mma_pv(qf4, dsf[qt], ok);
+                }
+                const int dO_ = dt * 16 + lg * 4;
+                if (dO_ < D) {
+                    float v4[4] = {ov[0], ov[1], ov[2], ov[3]}, k4[4] = {ok[0], ok[1], ok[2], ok[3]};
+                    st4<T>(dVs + (kt * 16 + l15) * PITCH + hc + dO_, v4);
+                    st4<T>(dKs + (kt * 16 + l15) * PITCH + hc + dO_, k4);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int which = 0; which < 3; ++which) {
+        T* dst = (T*)(which == 0 ? P.dq : which == 1 ? P.dk : P.dv) + dq_off;
+        const T* srcl = which == 0 ? dQs : which == 1 ? dKs : dVs;
+#pragma unroll 5
+        for (int c = lane; c < chunks; c += 64) {
+            const int f = c / CPR, ch = c - f * CPR;
+            float v[8];
+            Vec8<T>::load(srcl + f * PITCH + ch * 8, v);
+            Vec8<T>::store(dst + (int64_t)f * P.dfs + ch * 8, v);
+        }
+    }
+}
+
+template <typename T, int FT, int NK32>
+void launch_ta_bwd(const TABwdParams& P, hipStream_t st) {
+    const int CW = P.GH * P.D;
+    const size_t lds = sizeof(T) * 7 * (size_t)(FT * 16) * (CW + 8);
+    if (lds > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_attn_bwd_kernel<T, FT, NK32>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            raised = true;
+        }
+    }
+    dim3 grid((unsigned)((int64_t)P.n_clips * P.n_pix * (P.H / P.GH))), block(64);
+    hipLaunchKernelGGL((temporal_attn_bwd_kernel<T, FT, NK32>), grid, block, lds, st, P);
+}
+
+template <typename T, int FT>
+int dispatch_ta_bwd_k(const TABwdParams& P, hipStream_t st) {
+    switch ((P.D + 31) / 32) {
+        case 1: launch_ta_bwd<T, FT, 1>(P, st); break;
+        case 2: launch_ta_bwd<T, FT, 2>(P, st); break;
+        case 3: launch_ta_bwd<T, FT, 3>(P, st); break;
+        case 4: launch_ta_bwd<T, FT, 4>(P, st); break;
+        case 5: launch_ta_bwd<T, FT, 5>(P, st); break;
+        default: FMC_FAIL(FMC_E_SHAPE, "temporal_attn_bwd: head dim %d > 160", P.D);
+    }
+    return 0;
+}
+
 template <typename T, int FT, int NK32>
 void launch_ta(const TAParams& P, hipStream_t st) {
     const int CW = P.GH * P.D;
@@ -278,5 +521,45 @@ extern "C" int fmc_temporal_attn_fwd(const void* q, const void* k, const void* v
     int rc = (dtype == FMC_BF16) ? dispatch_ta<bf16_t>(P, st) : dispatch_ta<float>(P, st);
     if (rc) return rc;
     FMC_CHECK_LAUNCH("fmc_temporal_attn_fwd");
+    return 0;
+}
+
+extern "C" int fmc_temporal_attn_bwd(const void* q, const void* k, const void* v, const void* d_o, void* dq, void* dk,
+                                     void* dv, int n_clips, int n_pix, int F, int H, int D, int64_t clip_stride,
+                                     int64_t frame_stride, int64_t pix_stride, int64_t do_clip_stride,
+                                     int64_t do_frame_stride, int64_t do_pix_stride, int64_t dq_clip_stride,
+                                     int64_t dq_frame_stride, int64_t dq_pix_stride, float scale, int dtype,
+                                     void* stream) {
+    if (!q || !k || !v || !d_o || !dq || !dk || !dv) FMC_FAIL(FMC_E_NULL, "temporal_attn_bwd: NULL tensor");
+    if (dtype != FMC_BF16 && dtype != FMC_F32) FMC_FAIL(FMC_E_DTYPE, "temporal_attn_bwd: dtype %d", dtype);
+    if (n_clips <= 0 || n_pix <= 0 || H <= 0 || D <= 0 || D % 8 || D > 160 || (F != 16 && F != 32))
+        FMC_FAIL(FMC_E_SHAPE, "temporal_attn_bwd: need F in {16,32}, D%%8==0, D<=160 (F=%d H=%d D=%d)", F, H, D);
+    const int64_t strides[] = {clip_stride, frame_stride, pix_stride, do_clip_stride, do_frame_stride, do_pix_stride,
+                               dq_clip_stride, dq_frame_stride, dq_pix_stride};
+    for (int64_t s : strides)
+        if (s % 8) FMC_FAIL(FMC_E_ALIGN, "temporal_attn_bwd: strides must be multiples of 8 elements");
+    const void* ptrs[] = {q, k, v, d_o, dq, dk, dv};
+    for (const void* p : ptrs)
+        if (!fmc_aligned16(p)) FMC_FAIL(FMC_E_ALIGN, "temporal_attn_bwd: tensors must be 16-byte aligned");
+    TABwdParams P;
+    P.q = q; P.k = k; P.v = v; P.d_o = d_o; P.dq = dq; P.dk = dk; P.dv = dv;
+    P.n_clips = n_clips; P.n_pix = n_pix; P.F = F; P.H = H; P.D = D;
+    // head group: largest divisor of H whose 7 LDS tiles fit in ~150 KiB and whose rows are <= 320 channels
+    const size_t esz = dtype == FMC_BF16 ? 2 : 4;
+    int gh = 1;
+    for (int g = 1; g <= H; ++g)
+        if (H % g == 0 && g * D <= 320 && 7 * (size_t)F * (g * D + 8) * esz <= 150 * 1024) gh = g;
+    if (7 * (size_t)F * (gh * D + 8) * esz > 160 * 1024) FMC_FAIL(FMC_E_SHAPE, "temporal_attn_bwd: F=%d D=%d does not fit LDS in this dtype", F, D);
+    P.GH = gh;
+    P.cs = clip_stride; P.fs = frame_stride; P.ps = pix_stride;
+    P.ocs = do_clip_stride; P.ofs = do_frame_stride; P.ops = do_pix_stride;
+    P.dcs = dq_clip_stride; P.dfs = dq_frame_stride; P.dps = dq_pix_stride;
+    P.scale = scale; P.scale_log2 = scale * LOG2E;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (dtype == FMC_BF16) rc = F == 16 ? dispatch_ta_bwd_k<bf16_t, 1>(P, st) : dispatch_ta_bwd_k<bf16_t, 2>(P, st);
+    else rc = F == 16 ? dispatch_ta_bwd_k<float, 1>(P, st) : dispatch_ta_bwd_k<float, 2>(P, st);
+    if (rc) return rc;
+    FMC_CHECK_LAUNCH("fmc_temporal_attn_bwd");
     return 0;
 }

@@ -107,10 +107,40 @@ def groupnorm_silu(x, gamma, beta, groups: int, eps: float, act: bool) -> torch.
 # --------------------------------------------------------------------------------------------
 # LayerNorm (+ positional encoding), GEGLU
 # --------------------------------------------------------------------------------------------
+class _LayerNorm(torch.autograd.Function):
+    """gamma / beta here are the fp32 views the kernel reads; their grads come back in fp32."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, pe, pe_inner, pe_frames):
+        ctx.save_for_backward(x, gamma)
+        ctx.eps = eps
+        return _layernorm_raw(x, gamma, beta, eps, pe, pe_inner, pe_frames)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma = ctx.saved_tensors
+        dy = dy.contiguous()
+        C = x.shape[-1]
+        M = x.numel() // C
+        dx = torch.empty_like(x)
+        want_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dg = torch.zeros(C, dtype=torch.float32, device=x.device) if want_p else None
+        db = torch.zeros(C, dtype=torch.float32, device=x.device) if want_p else None
+        _lib.check(_lib.load().fmc_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), dx.data_ptr(), _p(dg),
+                                                 _p(db), M, C, float(ctx.eps), _dt(x), _stream()), "fmc_layernorm_bwd")
+        return dx, dg, db, None, None, None, None
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
               pe: Optional[torch.Tensor] = None, pe_inner: int = 1, pe_frames: int = 1) -> torch.Tensor:
     """LayerNorm over the last dim of contiguous tokens; optionally adds `pe[(row // pe_inner) % pe_frames]`
     (fp32 `[>=pe_frames, C]`) after normalising."""
+    if torch.is_grad_enabled() and (x.requires_grad or gamma.requires_grad or beta.requires_grad):
+        return _LayerNorm.apply(x, gamma, beta, eps, pe, pe_inner, pe_frames)
+    return _layernorm_raw(x, gamma, beta, eps, pe, pe_inner, pe_frames)
+
+
+def _layernorm_raw(x, gamma, beta, eps, pe, pe_inner, pe_frames):
     _dev(x, gamma, beta, pe)
     assert x.is_contiguous()
     C = x.shape[-1]
@@ -122,8 +152,31 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     return y
 
 
+class _Geglu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return _geglu_raw(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        cff = x.shape[-1] // 2
+        dx = torch.empty_like(x)
+        _lib.check(_lib.load().fmc_geglu_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), x.numel() // (2 * cff), cff,
+                                             _dt(x), _stream()), "fmc_geglu_bwd")
+        return dx
+
+
 def geglu(x: torch.Tensor) -> torch.Tensor:
     """`a * gelu_erf(g)` with `a, g = x.chunk(2, -1)`; x contiguous `[..., 2*Cff]`."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _Geglu.apply(x)
+    return _geglu_raw(x)
+
+
+def _geglu_raw(x: torch.Tensor) -> torch.Tensor:
     _dev(x)
     assert x.is_contiguous()
     cff = x.shape[-1] // 2
@@ -142,8 +195,47 @@ def _rows(t: torch.Tensor) -> Tuple[int, int]:
     return t.stride(0), t.stride(1)
 
 
+class _SpatialAttention(torch.autograd.Function):
+    """q `[B,S,C]`, kv-side tensors `[Bkv,Skv,C]` (strided slices allowed).  Grads come back as dense tensors."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, scale):
+        o, lse = _spatial_attention_raw(q, k, v, heads, scale, True)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.heads, ctx.scale = heads, scale
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        q, k, v, o, lse = ctx.saved_tensors
+        B, Sq, C = q.shape
+        Bkv, Skv, _ = k.shape
+        heads = ctx.heads
+        D = C // heads
+        d_o = d_o.contiguous()
+        dq = torch.empty(B, Sq, C, dtype=q.dtype, device=q.device)
+        dk = torch.empty(Bkv, Skv, C, dtype=q.dtype, device=q.device)
+        dv = torch.empty(Bkv, Skv, C, dtype=q.dtype, device=q.device)
+        dvec = torch.empty(B, heads, Sq, dtype=torch.float32, device=q.device)
+        _lib.check(_lib.load().fmc_spatial_attn_bwd(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), dvec.data_ptr(),
+            dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, heads, Sq, Skv, D, q.stride(0), q.stride(1), k.stride(0),
+            k.stride(1), Sq * C, C, Sq * C, C, Skv * C, C, B // Bkv, float(ctx.scale), _dt(q), _stream()),
+            "fmc_spatial_attn_bwd")
+        return dq, dk, dv, None, None
+
+
 def spatial_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: Optional[float] = None,
                       return_lse: bool = False):
+    """softmax(Q K^T * scale) V per (batch, head); differentiable (fmc_spatial_attn_bwd)."""
+    if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad) and not return_lse:
+        sc = (q.shape[-1] // heads) ** -0.5 if scale is None else scale
+        return _SpatialAttention.apply(q, k, v, heads, sc)
+    return _spatial_attention_raw(q, k, v, heads, scale, return_lse)
+
+
+def _spatial_attention_raw(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: Optional[float] = None,
+                           return_lse: bool = False):
     """softmax(Q K^T * scale) V per (batch, head).  q `[B, Sq, H*D]`, k/v `[Bkv, Skv, H*D]` (strided views of a
     fused projection are fine; B must be a multiple of Bkv: batch b reads kv batch b // (B // Bkv))."""
     _dev(q, k, v)
@@ -163,8 +255,47 @@ def spatial_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: 
     return (o, lse) if return_lse else o
 
 
+def _tstrides(t):
+    if t.ndim == 4:
+        return t.shape[0], t.shape[2], t.shape[1], t.stride(0), t.stride(1), t.stride(2)
+    return 1, t.shape[0], t.shape[1], 0, t.stride(1), t.stride(0)
+
+
+class _TemporalAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, heads, scale):
+        ctx.save_for_backward(q, k, v)
+        ctx.heads, ctx.scale = heads, scale
+        return _temporal_attention_raw(q, k, v, heads, scale)
+
+    @staticmethod
+    def backward(ctx, d_o):
+        q, k, v = ctx.saved_tensors
+        d_o = d_o.contiguous()
+        C = q.shape[-1]
+        dqkv = torch.empty(*q.shape[:-1], 3 * C, dtype=q.dtype, device=q.device)   # fused [.., 3C] gradient
+        dq, dk, dv = dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:]
+        B, P, F, cs, fs, ps = _tstrides(q)
+        _, _, _, ocs, ofs, ops = _tstrides(d_o)
+        _, _, _, dcs, dfs, dps = _tstrides(dq)
+        _lib.check(_lib.load().fmc_temporal_attn_bwd(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), d_o.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, P,
+            F, ctx.heads, C // ctx.heads, cs, fs, ps, ocs, ofs, ops, dcs, dfs, dps, float(ctx.scale), _dt(q), _stream()),
+            "fmc_temporal_attn_bwd")
+        return dq, dk, dv, None, None
+
+
 def temporal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
                        scale: Optional[float] = None) -> torch.Tensor:
+    """Attention over the frame axis (see `_temporal_attention_raw`); differentiable (fmc_temporal_attn_bwd)."""
+    if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
+        sc = (q.shape[-1] // heads) ** -0.5 if scale is None else scale
+        return _TemporalAttention.apply(q, k, v, heads, sc)
+    return _temporal_attention_raw(q, k, v, heads, scale)
+
+
+def _temporal_attention_raw(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
+                            scale: Optional[float] = None) -> torch.Tensor:
     """Attention over the frame axis.  Accepts the native layout `[B, F, P, C]` (frames outer, pixels inner: the
     channels-last video) or the reference layout `[N, F, C]` (`(b h w) f c`).  q/k/v may be strided slices of a
     fused QKV tensor (same strides for all three).  Returns a contiguous tensor of q's shape."""

@@ -45,6 +45,8 @@ def f32_param(mod: nn.Module, name: str) -> torch.Tensor:
     p = getattr(mod, name)
     if p.dtype == torch.float32:
         return p
+    if torch.is_grad_enabled() and p.requires_grad:
+        return p.float()                      # differentiable cast: trainable bf16 norm parameters still get a grad
     cache = mod.__dict__.setdefault("_f32_cache", {})
     key = (p.data_ptr(), p._version)
     hit = cache.get(name)
@@ -87,7 +89,8 @@ class Conv2d(nn.Conv2d):
             return from_tokens(y, h, w)
         if not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)
-        if self.kernel_size == (3, 3) and self.dilation == (1, 1) and self.groups == 1 and x.is_cuda:
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)
+        if self.kernel_size == (3, 3) and self.dilation == (1, 1) and self.groups == 1 and x.is_cuda and not needs_grad:
             return K.conv3x3(x, self._weight_cl(), self.bias, temb, residual, self.stride, self.padding)
         y = F.conv2d(x, self._weight_cl(), self.bias, self.stride, self.padding, self.dilation, self.groups)
         if temb is not None:
@@ -311,6 +314,12 @@ class Attention(nn.Module):
         """(W_qkv `[3C, Cin]` for self attention | (W_q, W_kv) for cross attention, W_out, b_out) with an
         optional frozen LoRA (`W + s * up @ down`) merged in."""
         srcs = [self.to_q.weight, self.to_k.weight, self.to_v.weight, self.to_out[0].weight]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in srcs):
+            # trainable projections (camera encoder, CMC stage): build the fused weight inside autograd, uncached
+            assert lora is None, "a LoRA on trainable base weights is not a configuration the reference uses"
+            if self.is_cross:
+                return self.to_q.weight, torch.cat([self.to_k.weight, self.to_v.weight], dim=0), self.to_out[0].weight
+            return torch.cat([self.to_q.weight, self.to_k.weight, self.to_v.weight], dim=0), None, self.to_out[0].weight
         if lora is not None:
             for n in ("to_q_lora", "to_k_lora", "to_v_lora", "to_out_lora"):
                 srcs += [getattr(lora, n).down.weight, getattr(lora, n).up.weight]
@@ -351,7 +360,7 @@ class GEGLU(nn.Module):
     def forward(self, hidden_states, scale: float = 1.0):
         w = self.proj.weight
         if hidden_states.is_cuda and hidden_states.dtype == torch.bfloat16 and w.shape[0] % 256 == 0 \
-                and not (torch.is_grad_enabled() and w.requires_grad):
+                and not (torch.is_grad_enabled() and (w.requires_grad or hidden_states.requires_grad)):
             key = (w.data_ptr(), w._version)
             hit = self.__dict__.get("_il")
             if hit is None or hit[0] != key:

@@ -39,27 +39,32 @@ def adapter_kwargs(widths):
                 use_post_zero_conv=True)
 
 
-def reseed(module, seed, std=0.05):
+def reseed(module, seed, std=0.05, fan_in_gain=None):
     """Seeded N(0, std) for every parameter: zero-initialised layers (qkv_merge, zero convs, LoRA up) would make the
-    conditioning paths invisible otherwise.  Norm gains are centred on 1."""
+    conditioning paths invisible otherwise.  Norm gains are centred on 1.  With `fan_in_gain` matrices / filters get
+    std = gain / sqrt(fan_in): a contractive net whose GRADIENTS are well conditioned (the fixed-std net is chaotic:
+    its directional derivatives differ by orders of magnitude between fp-equivalent implementations)."""
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for name, p in module.named_parameters():
-            v = torch.randn(p.shape, generator=g) * std
+            s = std
+            if fan_in_gain is not None and p.ndim >= 2:
+                s = fan_in_gain / (p[0].numel() ** 0.5)
+            v = torch.randn(p.shape, generator=g) * s
             if p.ndim == 1 and ("norm" in name and name.endswith("weight")):
                 v = v + 1.0
             p.copy_(v)
     return module
 
 
-def build_oracle(widths=(64, 128, 256, 256), cross_dim=64, conditioned=True, lora=True, seed=0):
+def build_oracle(widths=(64, 128, 256, 256), cross_dim=64, conditioned=True, lora=True, seed=0, fan_in_gain=None):
     unet = OM.UNet3DConditionModelCamObjCond(**unet_kwargs(widths, cross_dim))
     if conditioned:
         unet.set_all_attn_processor(**processor_kwargs(widths, lora))
         OM.patch_down_blocks_for_omc(unet)
-    reseed(unet, seed)
-    enc = reseed(OM.CameraPoseEncoder(**encoder_kwargs(widths)), seed + 1) if conditioned else None
-    ada = reseed(OM.Adapter(**adapter_kwargs(widths)), seed + 2) if conditioned else None
+    reseed(unet, seed, fan_in_gain=fan_in_gain)
+    enc = reseed(OM.CameraPoseEncoder(**encoder_kwargs(widths)), seed + 1, fan_in_gain=fan_in_gain) if conditioned else None
+    ada = reseed(OM.Adapter(**adapter_kwargs(widths)), seed + 2, fan_in_gain=fan_in_gain) if conditioned else None
     return unet.eval(), (enc.eval() if enc else None), (ada.eval() if ada else None)
 
 

@@ -58,10 +58,12 @@ def mask_modulate(x, mask_in, h, w):
 
 
 def feature_add(h, t, inplace=False):
-    out = h if inplace else h.clone()
-    flat = out.reshape(-1)
-    flat[h.numel() - t.numel():] += t.reshape(-1)
-    return out
+    skip = h.numel() - t.numel()
+    if inplace:
+        h.reshape(-1)[skip:] += t.reshape(-1)
+        return h
+    pad = torch.cat([torch.zeros(skip, dtype=t.dtype), t.reshape(-1)]) if skip else t.reshape(-1)
+    return h + pad.view_as(h)
 
 
 def cfg_ddim_step(eps, x, guidance, alpha_t, alpha_prev, has_uncond):

@@ -149,3 +149,68 @@ def test_two_rank_gloo_sharding(tmp_path):
     assert res["world"] == 2 and res["tmax"] == 2.0 and res["tsum"] == 10.0
     flat = sorted(res["shards"][0] + res["shards"][1])
     assert set(flat) == set(range(9)) and len(flat) == 10           # 9 clips padded to 10 by wrapping
+
+
+_GLOO_REDUCER = r'''
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from synfmc_amd.training import GradAllReducer, broadcast_parameters
+dist.init_process_group("gloo", init_method="env://")
+r, w = dist.get_rank(), dist.get_world_size()
+torch.manual_seed(100 + r)                       # different init per rank: broadcast must fix it
+net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 32), torch.nn.ReLU(),
+                          torch.nn.Linear(32, 4))
+unused = torch.nn.Linear(8, 8)                   # never reached by the loss (like the Adapter's level 3)
+broadcast_parameters(net); broadcast_parameters(unused)
+params = list(net.parameters()) + list(unused.parameters())
+red = GradAllReducer(params, bucket_bytes=3000)  # several small buckets
+assert len(red.buckets) > 2
+x = torch.randn(5, 16, generator=torch.Generator().manual_seed(r))
+for step in range(2):
+    loss = net(x).pow(2).mean() * (step + 1)
+    loss.backward()
+    red.finish()
+    got = torch.cat([p.grad.reshape(-1) for p in params]).clone()
+    # local reference: average of every rank's own gradient
+    ref_net = [p.detach().clone().requires_grad_(True) for p in net.parameters()]
+    def fwd(ps, xx):
+        h = torch.relu(xx @ ps[0].t() + ps[1]); h = torch.relu(h @ ps[2].t() + ps[3]); return h @ ps[4].t() + ps[5]
+    total = [torch.zeros_like(p) for p in ref_net]
+    for rr in range(w):
+        xr = torch.randn(5, 16, generator=torch.Generator().manual_seed(rr))
+        gs = torch.autograd.grad(fwd(ref_net, xr).pow(2).mean() * (step + 1), ref_net)
+        total = [t + g / w for t, g in zip(total, gs)]
+    want = torch.cat([t.reshape(-1) for t in total] + [torch.zeros(8 * 8 + 8)])
+    err = (got - want).abs().max().item()
+    red.zero_grad()
+    assert all(float(p.grad.abs().max()) == 0.0 for p in params)
+    if r == 0:
+        print(json.dumps({"step": step, "err": err, "buckets": len(red.buckets)}))
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_grad_allreduce(tmp_path):
+    script = tmp_path / "reducer.py"
+    script.write_text(_GLOO_REDUCER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29732", str(script), ROOT],
+                         capture_output=True, text=True, env=env, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 2 and all(l["err"] < 1e-6 for l in lines)
+
+
+def test_loss_and_timestep_sampling_match_oracle():
+    from oracle import pipeline as OP
+    from synfmc_amd.training import biased_timesteps, masked_mse_loss
+    g = torch.Generator().manual_seed(0)
+    pred, tgt = torch.randn(2, 4, 16, 8, 12, generator=g), torch.randn(2, 4, 16, 8, 12, generator=g)
+    masks = torch.rand(2, 16, 64, 96, generator=g) > 0.7
+    assert torch.allclose(masked_mse_loss(pred, tgt, masks, 0.3, 1.0), OP.stage3_loss(pred, tgt, masks, 0.3, 1.0), atol=1e-6)
+    t = biased_timesteps(20000, 1000, 700, 0.8, "cpu", torch.Generator().manual_seed(1))
+    frac_hi = (t >= 700).float().mean().item()
+    assert abs(frac_hi - 0.8) < 0.02 and int(t.min()) >= 0 and int(t.max()) < 1000

@@ -321,3 +321,81 @@ def test_conv3x3_bf16_fused_epilogue(K, n, H, W, cin, cout, temb, res):
     out = K.conv3x3_bf16(xd.permute(0, 2, 3, 1).contiguous(), wd.contiguous(memory_format=torch.channels_last), bd,
                          td if temb else None, rd.permute(0, 2, 3, 1).contiguous() if res else None)
     assert rel_inf(out.permute(0, 3, 1, 2).float(), ref) < 1e-2
+
+
+# ---------------------------------------------------------------------------------------------
+# backward kernels vs autograd through the oracle's forward (fp32 CPU)
+# ---------------------------------------------------------------------------------------------
+GTOL = {torch.float32: 1e-4, torch.bfloat16: 3e-2}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [64, 320, 1280])
+def test_layernorm_backward(K, dtype, C):
+    xo, xd = rnd((3, 16, 7, C), 80, dtype, scale=1.5, shift=0.3)
+    do, dd = rnd((3, 16, 7, C), 81, dtype)
+    g = torch.Generator().manual_seed(82)
+    gamma, beta = torch.randn(C, generator=g).requires_grad_(True), torch.randn(C, generator=g).requires_grad_(True)
+    xr = xo.clone().requires_grad_(True)
+    F.layer_norm(xr, (C,), gamma, beta, 1e-5).backward(do)
+    gd, bd_ = gamma.detach().cuda().requires_grad_(True), beta.detach().cuda().requires_grad_(True)
+    xg = xd.clone().requires_grad_(True)
+    K.layernorm(xg, gd, bd_, 1e-5).backward(dd)
+    assert rel_inf(xg.grad.float(), xr.grad) < GTOL[dtype]
+    assert rel_inf(gd.grad, gamma.grad) < GTOL[dtype] and rel_inf(bd_.grad, beta.grad) < GTOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_geglu_backward(K, dtype):
+    xo, xd = rnd((5, 33, 2 * 640), 83, dtype, scale=1.5)
+    do, dd = rnd((5, 33, 640), 84, dtype)
+    xr = xo.clone().requires_grad_(True)
+    a, g = xr.chunk(2, dim=-1)
+    (a * F.gelu(g)).backward(do)
+    xg = xd.clone().requires_grad_(True)
+    K.geglu(xg).backward(dd)
+    assert rel_inf(xg.grad.float(), xr.grad) < GTOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,S,H,D", [(2, 160, 8, 40), (1, 200, 8, 80), (2, 70, 8, 160), (1, 300, 4, 8)])
+def test_spatial_attention_backward_self(K, dtype, B, S, H, D):
+    C = H * D
+    qkvo, qkvd = rnd((B, S, 3 * C), 85, dtype)
+    do, dd = rnd((B, S, C), 86, dtype)
+    xr = qkvo.clone().requires_grad_(True)
+    oracle_attention(xr[..., :C], xr[..., C:2 * C], xr[..., 2 * C:], H).backward(do)
+    xg = qkvd.clone().requires_grad_(True)
+    K.spatial_attention(xg[..., :C], xg[..., C:2 * C], xg[..., 2 * C:], H).backward(dd)
+    assert rel_inf(xg.grad.float(), xr.grad) < GTOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_spatial_attention_backward_cross_shared_text(K, dtype):
+    B, Fr, S, H, D = 2, 3, 100, 8, 40
+    C = H * D
+    qo, qd = rnd((B * Fr, S, C), 87, dtype)
+    kvo, kvd = rnd((B, 77, 2 * C), 88, dtype)
+    do, dd = rnd((B * Fr, S, C), 89, dtype)
+    qr, kvr = qo.clone().requires_grad_(True), kvo.clone().requires_grad_(True)
+    rep = kvr.repeat_interleave(Fr, dim=0)
+    oracle_attention(qr, rep[..., :C], rep[..., C:], H).backward(do)
+    qg, kvg = qd.clone().requires_grad_(True), kvd.clone().requires_grad_(True)
+    K.spatial_attention(qg, kvg[..., :C], kvg[..., C:], H).backward(dd)
+    assert rel_inf(qg.grad.float(), qr.grad) < GTOL[dtype]
+    assert rel_inf(kvg.grad.float(), kvr.grad) < GTOL[dtype]          # summed over the F frames of each clip
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,Fr,P,H,D", [(2, 16, 6, 8, 40), (1, 16, 5, 8, 160), (1, 32, 3, 8, 80), (2, 16, 4, 4, 8)])
+def test_temporal_attention_backward(K, dtype, B, Fr, P, H, D):
+    C = H * D
+    qkvo, qkvd = rnd((B, Fr, P, 3 * C), 90, dtype)
+    do, dd = rnd((B, Fr, P, C), 91, dtype)
+    xr = qkvo.clone().requires_grad_(True)
+    ref_in = xr.permute(0, 2, 1, 3).reshape(B * P, Fr, 3 * C)
+    out = oracle_attention(ref_in[..., :C], ref_in[..., C:2 * C], ref_in[..., 2 * C:], H)
+    out.backward(do.permute(0, 2, 1, 3).reshape(B * P, Fr, C))
+    xg = qkvd.clone().requires_grad_(True)
+    K.temporal_attention(xg[..., :C], xg[..., C:2 * C], xg[..., 2 * C:], H).backward(dd)
+    assert rel_inf(xg.grad.float(), xr.grad) < GTOL[dtype]

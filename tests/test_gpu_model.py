@@ -108,3 +108,25 @@ def test_denoising_loop_cfg_omcm_gate(stack, use_graph):
                width=128, num_inference_steps=6, guidance_scale=2.0, latents=clip["latents"].cuda(),
                output_type="latent", prompt_embeds=text2.cuda(), omcm_min_step=700, use_graph=use_graph).videos
     assert rel_inf(out, ref) < 1e-2      # CFG multiplies fp32 round-off by ~g*sqrt(2) per step
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-3), (torch.bfloat16, 1.5e-1)])
+def test_stage3_training_gradients(stack, dtype, tol):
+    """OMC-stage training step: Adapter gradients through the frozen U-Net.  Exercises every backward kernel
+    (GroupNorm+SiLU, LayerNorm, GEGLU, spatial self/cross attention, temporal attention, mask modulate, feature add)
+    end to end against autograd through the CPU oracle.  Well-conditioned (fan-in scaled) weights: see
+    tests/common_models.reseed.  bf16: 8 mantissa bits through ~120 sequential fwd+bwd layers, stated tolerance."""
+    from tests import training_common as TC
+    ou, oe, oa = CM.build_oracle(W4, seed=20, fan_in_gain=0.7)
+    pu, pe, pa = CM.build_product(ou, oe, oa, W4, dtype=dtype)
+    if dtype == torch.bfloat16:
+        pa = pa.float()                              # fp32 master weights for the trainable part, bf16 autocast compute
+    clip = stack["clip"]
+    noise = torch.randn(clip["latents"].shape, generator=torch.Generator().manual_seed(9))
+    t = torch.tensor([801])
+    l_ref, g_ref = TC.oracle_grads(ou, oe, oa, clip, stack["pose_emb"], t, noise)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+        l_got, g_got = TC.product_grads(pu, pe, pa, clip, stack["pose_emb"], t, noise, "cuda", dtype)
+    assert abs(float(l_ref) - float(l_got)) < (1e-4 if dtype == torch.float32 else 2e-2) * abs(float(l_ref))
+    err, scale = TC.compare(g_ref, g_got)
+    assert scale > 0 and err < tol

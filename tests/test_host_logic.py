@@ -28,9 +28,9 @@ def fake(monkeypatch):
 @pytest.fixture(scope="module")
 def stack():
     ou, oe, oa = CM.build_oracle(W4, cross_dim=32)
-    clip = CM.synthetic_clip(B=1, Fr=16, H=64, W=64, cross_dim=32)
+    clip = CM.synthetic_clip(B=1, Fr=16, H=128, W=128, cross_dim=32)
     with torch.no_grad():
-        pose_emb = rearrange(OC.to_plucker_embedding(clip["c2w"], clip["K"], (64, 64)), "b f c h w -> b c f h w")
+        pose_emb = rearrange(OC.to_plucker_embedding(clip["c2w"], clip["K"], (128, 128)), "b f c h w -> b c f h w")
         pose_feats = [rearrange(x, "(b f) c h w -> b c f h w", b=1) for x in oe(pose_emb)]
         traj = OC.get_traj_features(clip["infos"], clip["masks"], oa)
         t = torch.tensor([801])
@@ -66,12 +66,12 @@ def test_conditioning_encoders_plumbing(stack, fake):
     from synfmc_amd.util import get_traj_features_v2
     pu, pe, pa = CM.build_product(stack["ou"], stack["oe"], stack["oa"], W4, cross_dim=32, device="cpu")
     clip = stack["clip"]
-    emb = to_plucker_embedding(clip["c2w"], clip["K"], (64, 64), device="cpu")
+    emb = to_plucker_embedding(clip["c2w"], clip["K"], (128, 128), device="cpu")
     assert rel_inf(rearrange(emb, "b f c h w -> b c f h w"), stack["pose_emb"]) < 1e-6
     feats = features_to_video(pe(rearrange(emb, "b f c h w -> b c f h w")), 1)
     for got, want in zip(feats, stack["pose_feats"]):
         assert got.shape == want.shape and rel_inf(got, want) < 1e-4
-    emb_u = to_plucker_embedding(clip["c2w"], clip["K"], (64, 64), device="cpu", layout="unshuffle8")
+    emb_u = to_plucker_embedding(clip["c2w"], clip["K"], (128, 128), device="cpu", layout="unshuffle8")
     for got, want in zip(features_to_video(pe.forward_unshuffled(emb_u, 1), 1), stack["pose_feats"]):
         assert rel_inf(got, want) < 1e-4
     traj = get_traj_features_v2(clip["infos"], clip["masks"], pa, False, 0.0, [False], "cpu", torch.float32)
@@ -141,7 +141,25 @@ def test_denoising_loop_plumbing(stack, fake):
                      num_inference_steps=4, guidance_scale=2.0, traj_features=stack["traj"], omcm_min_step=700)
     pu, pe, pa = CM.build_product(stack["ou"], stack["oe"], stack["oa"], W4, cross_dim=32, device="cpu")
     pipe = CameraObjCtrlPipeline(None, None, None, pu, DDIMScheduler(**kw), pe)
-    out = pipe(None, stack["pose_emb"], 16, traj_features=stack["traj"], height=64, width=64, num_inference_steps=4,
+    out = pipe(None, stack["pose_emb"], 16, traj_features=stack["traj"], height=128, width=128, num_inference_steps=4,
                guidance_scale=2.0, latents=clip["latents"], output_type="latent", prompt_embeds=text2,
                omcm_min_step=700, use_graph=False).videos
     assert rel_inf(out, ref) < 5e-3      # CFG multiplies fp32 round-off by ~g*sqrt(2) per step
+
+
+def test_stage3_training_gradients_plumbing(stack, fake):
+    """Adapter gradients through the frozen product U-Net (CPU stand-in kernels are differentiable torch ops)."""
+    from tests import training_common as TC
+    ou, oe, oa = CM.build_oracle(W4, cross_dim=32, seed=20, fan_in_gain=0.7)     # well-conditioned gradients
+    pu, pe, pa = CM.build_product(ou, oe, oa, W4, cross_dim=32, device="cpu")
+    clip = stack["clip"]
+    noise = torch.randn(clip["latents"].shape, generator=torch.Generator().manual_seed(9))
+    t = torch.tensor([801])
+    l_ref, g_ref = TC.oracle_grads(ou, oe, oa, clip, stack["pose_emb"], t, noise)
+    l_got, g_got = TC.product_grads(pu, pe, pa, clip, stack["pose_emb"], t, noise, "cpu")
+    assert abs(float(l_ref) - float(l_got)) < 1e-4 * abs(float(l_ref))
+    err, scale = TC.compare(g_ref, g_got)
+    assert scale > 0 and err < 2e-3
+    # level-3 Adapter blocks receive no gradient (DownBlock3D never consumes traj_features, unet_cam_obj.py:1227-1234)
+    assert all(float(g_got[k].abs().max()) == 0.0 for k in g_got if k.startswith("body.6") or k.startswith("body.7")
+               or k.startswith("zero_conv_out_list.3"))

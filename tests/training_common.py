@@ -1,0 +1,58 @@
+"""Stage-3 (OMC) training step on the reduced stack: gradients of the Adapter through the frozen U-Net, oracle vs product."""
+import torch
+from einops import rearrange
+
+from oracle import conditioning as OC
+from oracle import diffusers_restated as OD
+from oracle import pipeline as OP
+
+SCHED = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1,
+             clip_sample=False)
+
+
+def union_masks(clip, thr=0.5):
+    return torch.stack([torch.stack([(m[:, 0] > thr).any(dim=0) for m in clip["masks"][b]]) for b in range(len(clip["masks"]))])
+
+
+def oracle_grads(ou, oe, oa, clip, pose_emb, t, noise):
+    for m in (ou, oe):
+        m.requires_grad_(False)
+    oa.requires_grad_(True)
+    oa.zero_grad(set_to_none=True)
+    sched = OD.DDIMScheduler(**SCHED)
+    noisy = sched.add_noise(clip["latents"], noise, t)
+    pose_feats = [rearrange(x, "(b f) c h w -> b c f h w", b=1) for x in oe(pose_emb)]
+    traj = OC.get_traj_features(clip["infos"], clip["masks"], oa)
+    pred = ou(noisy, t, clip["text"], pose_embedding_features=pose_feats, traj_features=traj).sample
+    loss = OP.stage3_loss(pred, noise, union_masks(clip), 0.3, 1.0)
+    loss.backward()
+    grads = {k: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for k, p in oa.named_parameters()}
+    oa.requires_grad_(False)
+    return loss.detach(), grads
+
+
+def product_grads(pu, pe, pa, clip, pose_emb, t, noise, device, dtype=torch.float32):
+    from synfmc_amd.models.pose_obj_adaptor import CamObjPoseAdaptor
+    from synfmc_amd.schedulers import DDIMScheduler
+    from synfmc_amd.training import masked_mse_loss
+    from synfmc_amd.util import get_traj_features_v2
+    pu.requires_grad_(False)
+    pe.requires_grad_(False)
+    pa.requires_grad_(True)
+    pa.zero_grad(set_to_none=True)
+    sched = DDIMScheduler(**SCHED)
+    dev = lambda x: x.to(device)
+    noisy = sched.add_noise(dev(clip["latents"]), dev(noise), dev(t))
+    traj = get_traj_features_v2(clip["infos"], clip["masks"], pa, False, 0.0, [False], device, dtype)
+    pred = CamObjPoseAdaptor(pu, pe)(noisy.to(dtype), dev(t), dev(clip["text"]).to(dtype), dev(pose_emb).to(dtype), traj)
+    loss = masked_mse_loss(pred, dev(noise), dev(union_masks(clip)), 0.3, 1.0)
+    loss.backward()
+    grads = {k: (p.grad.detach().float().cpu() if p.grad is not None else torch.zeros(p.shape)) for k, p in pa.named_parameters()}
+    pa.requires_grad_(False)
+    return loss.detach().cpu(), grads
+
+
+def compare(g_ref, g_got):
+    ref = torch.cat([g_ref[k].reshape(-1) for k in g_ref]).double()
+    got = torch.cat([g_got[k].reshape(-1).double() for k in g_ref])
+    return ((ref - got).abs().max() / ref.abs().max()).item(), float(ref.abs().max())
