@@ -173,6 +173,86 @@ def cpu_baseline(budget_s=25.0):
                       f"({f_step / 1e12:.2f} TFLOP)"}
 
 
+def train_main(args):
+    """Secondary measurement: stage-3 (OMC) training steps/s, one clip per GPU, weak scaling, gradients averaged
+    over ranks by `synfmc_amd.training.GradAllReducer` (RCCL).  Reference loop: train_cam_obj_ctrl.py:782-943."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    global HEIGHT, WIDTH
+    HEIGHT, WIDTH = 256, 384
+    dtype = torch.bfloat16
+    from synfmc_amd.models.pose_obj_adaptor import CamObjPoseAdaptor
+    from synfmc_amd.schedulers import DDIMScheduler
+    from synfmc_amd.training import GradAllReducer, biased_timesteps, broadcast_parameters, stage3_training_step
+    from synfmc_amd.util import stack_object_inputs
+    from synfmc_amd import hip_ops as K
+    from synfmc_amd.models.pose_adaptor import features_to_video
+    from tests import training_common as TC
+    unet, enc, ada = build_models(device, dtype)
+    ada = ada.float().requires_grad_(True)                  # fp32 master weights for the trainable Adapter
+    broadcast_parameters(ada)
+    clip, _ = synthetic_inputs(rank, device)
+    sched = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="linear",
+                          steps_offset=1, clip_sample=False)
+    opt = torch.optim.AdamW([p for p in ada.parameters()], lr=1e-6, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+    reducer = GradAllReducer(ada.parameters())
+    wrapper = CamObjPoseAdaptor(unet, enc)
+    poses, masks = stack_object_inputs(clip["infos"], clip["masks"], device)
+    c2w, Kin = clip["c2w"].to(device), clip["K"].to(device)
+    latents, text = clip["latents"].to(device).to(dtype), clip["text"].to(device).to(dtype)
+    obj_masks = TC.union_masks(clip).to(device)
+    gen = torch.Generator(device=device).manual_seed(77 + rank)
+
+    def step():
+        noise = torch.randn(latents.shape, device=device, dtype=dtype, generator=gen)
+        t = biased_timesteps(1, 1000, 700, 0.8, device, gen)
+        emb = K.plucker(Kin, c2w, HEIGHT, WIDTH, "bcfhw", dtype)      # on device, every step (reference: CPU + H2D)
+
+        def traj_fn():
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                feats, m = K.omc_rasterize(poses, masks, "unshuffle8", dtype)
+                return features_to_video(ada(feats, m), 1)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return stage3_training_step(wrapper, ada, sched, opt, reducer, latents, noise, t, text, emb, traj_fn, obj_masks)
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    assert torch.isfinite(loss).all()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "OMC-stage training steps/sec (secondary), 16x256x384 bf16, frozen U-Net + trainable Adapter",
+            "value": round(world * args.steps / elapsed, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "stage-3 (configs/obj.yaml) training step, 1 clip per GPU, AdamW, clip-norm 1.0, "
+                                   "bucketed RCCL all-reduce of 152.5M fp32 Adapter gradients",
+                       "parallelism": f"dp{world}", "allreduce_bytes": sum(b["flat"].numel() * 4 for b in reducer.buckets)},
+            "last_loss": float(loss)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,7 +262,13 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--guidance", type=float, default=8.0)
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+                    help="infer = the headline metric (denoising steps/s); train = OMC-stage optimisation steps/s "
+                         "(secondary: forward + activation backward through the frozen U-Net + Adapter backward + RCCL "
+                         "gradient all-reduce + AdamW), 16x256x384 like configs/obj.yaml")
     args = ap.parse_args()
+    if args.mode == "train":
+        return train_main(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
