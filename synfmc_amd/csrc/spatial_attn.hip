@@ -22,11 +22,13 @@
 //
 // Roofline: MFMA bound.  Algorithmic flops per launch = 4 * B*H * Sq*Skv * D.
 #include "attn_common.h"
+#include <cstdlib>
 
 namespace {
 
 constexpr int SA_WAVES = 4;
 constexpr int SA_BQ = 32 * SA_WAVES;  // query rows per workgroup
+constexpr bool SA_PREFETCH_DEFAULT = true;
 constexpr int SA_BK = 64;             // keys per LDS tile
 constexpr float LOG2E = 1.4426950408889634f;
 
@@ -40,25 +42,33 @@ struct SAParams {
     int xcd_remap;
 };
 
-// One 32-key x 32-query block for one wave: S^T = K Q^T, online softmax, O^T += V^T P^T.
+// One 32-key x 32-query block for one wave: S^T = K Q^T, softmax numerators, O^T += V^T P^T.
 //
-// Online softmax with a deferred rescale: scores are exponentiated against the running reference m_run, which is
-// only raised (and O^T / l rescaled) when some query's block maximum exceeds it by more than RESCALE_THR (log2
-// units), a wave-uniform and -- after the first block -- rare branch.  Until then p = 2^(s - m_run) <= 2^THR, which
-// fp32 accumulation absorbs; the final O / l is independent of the reference.  This removes the per-block
-// accumulator rescale (32-80 multiplies + AGPR round trips) from the common path.
-constexpr float RESCALE_THR = 8.f;
+// The softmax is arranged so that a block costs ~2 VALU per score (exp2 + its share of cvt_pk / max3) and has no
+// branch and no conditionally updated state (a conditional rescale of the O^T tuples makes the register allocator
+// copy them on every block):
+//  * Q is pre-multiplied by scale*log2(e) when its fragments are built: scores leave the MFMA in log2 units;
+//  * FIXED reference: m_ref is the row maximum over the first K tile (a prologue).  -m_ref lives in a 16-register
+//    tuple that is the C operand of the first QK^T MFMA, so the accumulators already hold s - m_ref and
+//    p = exp2(acc).  p, l and O are all relative to m_ref and O / l does not depend on it; bf16 and fp32 share an
+//    8-bit exponent, so nothing overflows while max(s) - m_ref <= REF_LIMIT (log2 units).  Every block folds its
+//    maximum into `worst`; if some row exceeded the limit the workgroup redoes the K/V sweep once with the now
+//    exactly known row maxima (never seen on real activations; tested with adversarial inputs);
+//  * when the padded V^T tile has a spare row (odd NKS: D = 40, 80, ...) that row holds ones, so the PV MFMAs
+//    accumulate l = sum(p) in O^T row NDT*32-1 for free (and from the same rounded p as the numerator).
+constexpr float REF_LIMIT = 64.f;
 
+// max of three; this file is built with -fno-honor-nans so that the fmaxf chain selects v_max3_f32 without the NaN
+// canonicalisation (v_max x,x) of every MFMA output.  (Not inline asm: the compiler must see these reads to insert the
+// MFMA -> VALU wait states itself.)
+__device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+
+// scores of one block relative to the reference in `cinit` (= -m_ref, or 0 in the prologue)
 template <typename T, int NKS, bool TAIL>
-__device__ __forceinline__ void attn_block(const T* __restrict__ Ks, const T* __restrict__ Vt, const Frag<T> (&qf)[NKS],
-                                           f32x16 (&oacc)[(NKS + 1) / 2], float& m_run, float& l_run, int sb, int kvb,
-                                           int Skv, float scale_log2, int l31, int half) {
-    constexpr int NDT = (NKS + 1) / 2;
+__device__ __forceinline__ f32x16 qk_block(const T* __restrict__ Ks, const Frag<T> (&qf)[NKS], const f32x16& cinit, int sb,
+                                           int kvb, int Skv, int l31, int half) {
     constexpr int KP = NKS * 16 + 8;
-    constexpr int VP = SA_BK + 4;
-    f32x16 s;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    f32x16 s = cinit;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         Frag<T> kf;
@@ -70,28 +80,37 @@ __device__ __forceinline__ void attn_block(const T* __restrict__ Ks, const T* __
         for (int r = 0; r < 16; ++r)
             if (kvb + (r & 3) + 8 * (r >> 2) + 4 * half >= Skv) s[r] = -INFINITY;
     }
-    float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
-#pragma unroll
-    for (int r = 4; r < 16; r += 4) mx = fmaxf(mx, fmaxf(fmaxf(s[r], s[r + 1]), fmaxf(s[r + 2], s[r + 3])));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2;      // scale > 0
-    if (__any(mx > m_run + RESCALE_THR)) {
-        const float m_new = fmaxf(m_run, mx);                  // finite: the first block always holds key 0
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        l_run *= alpha;
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
-        m_run = m_new;
-    }
+    return s;
+}
+
+// max(w, s[0..15]) in 8 v_max3
+__device__ __forceinline__ float fold_max(const f32x16& s, float w) {
+    float ma = max3(s[0], s[1], s[2]), mb = max3(s[8], s[9], s[10]);
+    ma = max3(ma, s[3], s[4]);
+    mb = max3(mb, s[11], s[12]);
+    ma = max3(ma, s[5], s[6]);
+    mb = max3(mb, s[13], s[14]);
+    return max3(max3(ma, mb, s[7]), s[15], w);
+}
+
+template <typename T, int NKS, bool TAIL>
+__device__ __forceinline__ void attn_block(const T* __restrict__ Ks, const T* __restrict__ Vt, const Frag<T> (&qf)[NKS],
+                                           f32x16 (&oacc)[(NKS + 1) / 2], const f32x16& negm, float& worst, float& l_run,
+                                           int sb, int kvb, int Skv, int l31, int half) {
+    constexpr int NDT = (NKS + 1) / 2;
+    constexpr int VP = SA_BK + 4;
+    constexpr bool LROW = (NKS & 1) != 0;
+    const f32x16 s = qk_block<T, NKS, TAIL>(Ks, qf, negm, sb, kvb, Skv, l31, half);
+    worst = fold_max(s, worst);
     float p[16];
-    float psum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        p[r] = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2, -m_run));
-        psum += p[r];
+    for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(s[r]);
+    if (!LROW) {
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) psum += p[r];
+        l_run += psum;
     }
-    l_run += psum;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
         float p8[8];
@@ -111,7 +130,12 @@ __device__ __forceinline__ void attn_block(const T* __restrict__ Ks, const T* __
 
 // SHORT_KV only separates the text cross-attention launches (S_kv = 77) from the self-attention ones in profiles
 // (same code path): the two differ by >10x in work per launch and would blur a per-kernel-name average.
-template <typename T, int NKS, bool SHORT_KV>
+template <typename T> __device__ __forceinline__ T to_elem(float v);
+template <> __device__ __forceinline__ bf16_t to_elem<bf16_t>(float v) { return f2bf(v); }
+template <> __device__ __forceinline__ float to_elem<float>(float v) { return v; }
+
+// PREFETCH keeps the next K/V tile in registers under the current tile's MFMAs (costs ~40 VGPRs).
+template <typename T, int NKS, bool SHORT_KV, bool PREFETCH>
 __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 ? 3 : 2) : 1) void spatial_attn_kernel(const SAParams P) {
     constexpr int NDT = (NKS + 1) / 2;
     constexpr int DP16 = NKS * 16;
@@ -150,8 +174,15 @@ __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 ? 3 : 2
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         const int d0 = ks * 16 + half * 8;
-        if (qrow < P.Sq && d0 < D) make_frag<T>(qg + (int64_t)qrow * P.qrs + d0, qf[ks]);
-        else zero(qf[ks]);
+        if (qrow < P.Sq && d0 < D) {
+            float qv[8];
+            Vec8<T>::load(qg + (int64_t)qrow * P.qrs + d0, qv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) qv[i] *= P.scale_log2;
+            p_frag(qv, qf[ks]);       // fp32 values -> fragment(s): bf16 rounding / hi+lo split
+        } else {
+            zero(qf[ks]);
+        }
     }
 
     // zero the K pad columns once (d in [D, DP16)): 0 * garbage must stay 0
@@ -162,19 +193,54 @@ __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 ? 3 : 2
         }
     }
 
-    f32x16 oacc[NDT];
-#pragma unroll
-    for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    constexpr bool LROW = (NKS & 1) != 0;
+    if (LROW) {   // ones in the last (spare) V^T row: O^T row NDT*32-1 accumulates l = sum(p)
+        for (int c = tid; c < SA_BK; c += 64 * SA_WAVES) Vt[(NDT * 32 - 1) * VP + c] = to_elem<T>(1.f);
+    }
 
-    const int ntiles = (P.Skv + SA_BK - 1) / SA_BK;
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const int kv0 = tile * SA_BK;
-        __syncthreads();  // previous tile fully consumed
-        // ---- stage K (row-major) and V (transposed) --------------------------------------------
-        for (int c = tid; c < SA_BK * CH; c += blockDim.x) {
+    // K/V staging is split (T14-style): the 16-byte global loads of tile t+1 are issued right after tile t has been
+    // written to LDS and stay in flight under tile t's MFMAs; they are written to LDS after the next barrier.
+    constexpr int NSLOT = (SA_BK * NKS * 2 + 64 * SA_WAVES - 1) / (64 * SA_WAVES);   // 8-element chunks per thread
+    constexpr int RW = sizeof(T) * 2;                                                  // dwords per chunk
+    typedef uint32_t __attribute__((ext_vector_type(RW))) raw_t;
+    raw_t kreg[NSLOT], vreg[NSLOT];
+    auto gload = [&](int kv0) {
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) {
+            const int c = tid + j * 64 * SA_WAVES;
+            const int row = c / CH, ch = c - row * CH;
+            const int kv = kv0 + row;
+            if (c < SA_BK * CH && kv < P.Skv) {
+                kreg[j] = *reinterpret_cast<const raw_t*>(kg + (int64_t)kv * P.krs + ch * 8);
+                vreg[j] = *reinterpret_cast<const raw_t*>(vg + (int64_t)kv * P.krs + ch * 8);
+            } else {
+                kreg[j] = raw_t(0);
+                vreg[j] = raw_t(0);
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) {
+            const int c = tid + j * 64 * SA_WAVES;
+            if (c < SA_BK * CH) {
+                const int row = c / CH, ch = c - row * CH;
+                *reinterpret_cast<raw_t*>(Ks + row * KP + ch * 8) = kreg[j];
+                if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        Vt[(ch * 8 + 2 * i) * VP + row] = (T)(vreg[j][i] & 0xffffu);
+                        Vt[(ch * 8 + 2 * i + 1) * VP + row] = (T)(vreg[j][i] >> 16);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) Vt[(ch * 8 + i) * VP + row] = __uint_as_float(vreg[j][i]);
+                }
+            }
+        }
+    };
+    auto stage_rolled = [&](int kv0) {   // one chunk live at a time (register-starved variants)
+        for (int c = tid; c < SA_BK * CH; c += 64 * SA_WAVES) {
             const int row = c / CH, ch = c - row * CH;
             const int kv = kv0 + row;
             float kvals[8], vvals[8];
@@ -186,30 +252,76 @@ __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 ? 3 : 2
                 for (int i = 0; i < 8; ++i) kvals[i] = vvals[i] = 0.f;
             }
             Vec8<T>::store(Ks + row * KP + ch * 8, kvals);
-            if constexpr (sizeof(T) == 2) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) Vt[(ch * 8 + i) * VP + row] = f2bf(vvals[i]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) Vt[(ch * 8 + i) * VP + row] = vvals[i];
-            }
+            for (int i = 0; i < 8; ++i) Vt[(ch * 8 + i) * VP + row] = to_elem<T>(vvals[i]);
         }
-        __syncthreads();
+    };
 
-        if (kv0 + SA_BK <= P.Skv) {                       // full tile: no key masking anywhere
+    const int ntiles = (P.Skv + SA_BK - 1) / SA_BK, nfull = P.Skv / SA_BK;
+
+    // ---- prologue: tile 0 -> LDS, reference m_ref = row maximum over its keys -----------------------
+    if (PREFETCH) { gload(0); lstore(); } else { stage_rolled(0); }
+    __syncthreads();
+    if (PREFETCH && ntiles > 1) gload(SA_BK);
+    float m_ref;
+    f32x16 negm;
+    {
+        f32x16 zero16;
 #pragma unroll
-            for (int sb = 0; sb < SA_BK / 32; ++sb)
-                attn_block<T, NKS, false>(Ks, Vt, qf, oacc, m_run, l_run, sb, kv0 + sb * 32, P.Skv, P.scale_log2, l31, half);
-        } else {
+        for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+        float mx = fold_max(qk_block<T, NKS, true>(Ks, qf, zero16, 0, 0, P.Skv, l31, half), -INFINITY);
+        if (P.Skv > 32) mx = fold_max(qk_block<T, NKS, true>(Ks, qf, zero16, 1, 32, P.Skv, l31, half), mx);
+        m_ref = fmaxf(mx, __shfl_xor(mx, 32, 64));   // finite: key 0 always exists
 #pragma unroll
-            for (int sb = 0; sb < SA_BK / 32; ++sb)
-                if (kv0 + sb * 32 < P.Skv)                 // block-uniform
-                    attn_block<T, NKS, true>(Ks, Vt, qf, oacc, m_run, l_run, sb, kv0 + sb * 32, P.Skv, P.scale_log2, l31, half);
-        }
+        for (int r = 0; r < 16; ++r) negm[r] = -m_ref;
     }
 
+    f32x16 oacc[NDT];
+    float l_run;
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+        l_run = 0.f;
+        float worst = -INFINITY;   // max over all keys of s - m_ref (this lane's half of the keys)
+
+        auto stage = [&](int tile) {
+            if (tile > 0 || pass > 0) {             // tile 0 is already resident after the prologue
+                if (pass > 0 && tile == 0 && PREFETCH) gload(0);
+                __syncthreads();  // previous tile fully consumed
+                if (PREFETCH) lstore(); else stage_rolled(tile * SA_BK);
+                __syncthreads();
+                if (PREFETCH && tile + 1 < ntiles) gload((tile + 1) * SA_BK);
+            }
+        };
+        // full tiles: no key masking anywhere, no branch in the body (a second path merging into the loop makes the
+        // register allocator copy the O^T tuples every iteration); the ragged last tile is peeled.
+        for (int tile = 0; tile < nfull; ++tile) {
+            stage(tile);
+#pragma unroll
+            for (int sb = 0; sb < SA_BK / 32; ++sb)
+                attn_block<T, NKS, false>(Ks, Vt, qf, oacc, negm, worst, l_run, sb, tile * SA_BK + sb * 32, P.Skv, l31, half);
+        }
+        if (nfull < ntiles) {
+            stage(nfull);
+#pragma unroll
+            for (int sb = 0; sb < SA_BK / 32; ++sb)
+                if (nfull * SA_BK + sb * 32 < P.Skv)           // block-uniform
+                    attn_block<T, NKS, true>(Ks, Vt, qf, oacc, negm, worst, l_run, sb, nfull * SA_BK + sb * 32, P.Skv, l31, half);
+        }
+        // did any row of this workgroup leave the safe range of the fixed reference?  (block-uniform decision)
+        if (!__syncthreads_or(worst > REF_LIMIT)) break;
+        m_ref += fmaxf(worst, __shfl_xor(worst, 32, 64));     // now the exact row maximum
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[r] = -m_ref;
+    }
+    const float m_run = m_ref;
+
     // ---- epilogue ----------------------------------------------------------------------------------
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float l_tot;
+    if (LROW) l_tot = __shfl(oacc[NDT - 1][15], l31 + 32, 64);   // row NDT*32-1 lives in the upper half's register 15
+    else l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.f / l_tot;
     if (qrow < P.Sq) {
         T* orow = og + (int64_t)qrow * P.ors;
@@ -228,7 +340,7 @@ __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 ? 3 : 2
     }
 }
 
-template <typename T, int NKS, bool SHORT_KV>
+template <typename T, int NKS, bool SHORT_KV, bool PF>
 void launch_sa_v(const SAParams& P, hipStream_t st) {
     constexpr int NDT = (NKS + 1) / 2;
     const size_t lds = sizeof(T) * ((size_t)SA_BK * (NKS * 16 + 8) + (size_t)NDT * 32 * (SA_BK + 4));
@@ -236,18 +348,34 @@ void launch_sa_v(const SAParams& P, hipStream_t st) {
     if (lds > 64 * 1024) {  // gfx950 has 160 KiB of LDS per CU; opting in is needed above 64 KiB
         static bool raised = false;
         if (!raised) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_attn_kernel<T, NKS, SHORT_KV>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_attn_kernel<T, NKS, SHORT_KV, PF>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             raised = true;
         }
     }
-    hipLaunchKernelGGL((spatial_attn_kernel<T, NKS, SHORT_KV>), grid, block, lds, st, P);
+    hipLaunchKernelGGL((spatial_attn_kernel<T, NKS, SHORT_KV, PF>), grid, block, lds, st, P);
+}
+
+// FMC_SA_PREFETCH=0/1 overrides the default policy (experiments only)
+inline int sa_prefetch_env() {
+    static const int v = [] {
+        const char* e = getenv("FMC_SA_PREFETCH");
+        return e ? atoi(e) : -1;
+    }();
+    return v;
 }
 
 template <typename T, int NKS>
 void launch_sa(const SAParams& P, hipStream_t st) {
-    if (P.Skv <= 2 * SA_BK) launch_sa_v<T, NKS, true>(P, st);
-    else launch_sa_v<T, NKS, false>(P, st);
+    if (P.Skv <= 2 * SA_BK) {
+        launch_sa_v<T, NKS, true, false>(P, st);
+    } else {
+        if constexpr (sizeof(T) == 2 && NKS <= 6) {
+            const int e = sa_prefetch_env();
+            if (e < 0 ? SA_PREFETCH_DEFAULT : e != 0) return launch_sa_v<T, NKS, false, true>(P, st);
+        }
+        launch_sa_v<T, NKS, false, false>(P, st);
+    }
 }
 
 template <typename T>
