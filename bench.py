@@ -262,6 +262,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--guidance", type=float, default=8.0)
+    ap.add_argument("--autotune-log", default=None, help="write the per-shape GEMM/conv arm timings to this file")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer = the headline metric (denoising steps/s); train = OMC-stage optimisation steps/s "
                          "(secondary: forward + activation backward through the frozen U-Net + Adapter backward + RCCL "
@@ -386,6 +387,10 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
+        if args.autotune_log:
+            with open(args.autotune_log, "w") as f:
+                for key, use, times, calls in sorted(K.autotune_report(), key=lambda r: -r[3] * min(r[2].values() or [0])):
+                    f.write(f"{key} -> arm {use}  calls {calls}  ms {times}\n")
     if world > 1:
         dist.destroy_process_group()
 

@@ -171,7 +171,8 @@ int fmc_cfg_ddim_step(const void* eps_uc, const float* x, float* x_out, int64_t 
  *   epilogue 1 expects w / bias pre-interleaved per 128-row tile: rows [128t, 128t+64) = value rows
  *   [64t, 64t+64) of the GEGLU projection, rows [128t+64, 128t+128) = the matching gate rows.
  *   Requires K % 64 == 0, N % 8 == 0 (N % 256 == 0 for epilogue 1), strides % 8 == 0.
- *   tile: workgroup tile geometry, 0 = pick by shape, 1 = 128x128 (4 waves), 2 = 256x128 (8), 3 = 256x256 (16);
+ *   tile: workgroup tile geometry, 0 = pick by shape, 1 = 128x128 (4 waves), 2 = 256x128 (8), 3 = 256x256 (16) with
+ *   64-deep k-tiles; 4..6 = the same three with 32-deep k-tiles (half the LDS, twice the workgroups per CU);
  *   every geometry computes the same function (callers may time them and keep the fastest).
  * ------------------------------------------------------------------------------------------- */
 int fmc_linear_bf16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int N,

@@ -35,7 +35,7 @@
 
 namespace {
 
-constexpr int BK = 64;
+constexpr int BK_MAX = 64;   // K must be a multiple of this (every FMC projection / conv is)
 
 struct GemmParams {
     const bf16_t* a; const bf16_t* w; const bf16_t* bias; const bf16_t* temb; const bf16_t* res; bf16_t* out;
@@ -48,8 +48,11 @@ struct GemmParams {
 
 __device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.f + erff(g * 0.70710678118654752f)); }
 
-// physical 16-byte chunk of logical chunk c in tile row r (8 chunks per 128-byte row)
-__device__ __forceinline__ int swz(int r, int c) { return c ^ ((r >> 1) & 7); }
+// physical 16-byte chunk of logical chunk c in tile row r: 8 chunks per 128-byte row (BK = 64) or 4 per 64-byte row
+// (BK = 32); both make the ds_read_b128 lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} bank-conflict free
+template <int BK> __device__ __forceinline__ int swz(int r, int c) {
+    return BK == 64 ? (c ^ ((r >> 1) & 7)) : (c ^ ((r >> 2) & 3));
+}
 
 // 16 zero bytes in global memory: the LDS-DMA source of out-of-range rows / padding taps
 __device__ u32x4 g_zero16 = {0u, 0u, 0u, 0u};
@@ -62,12 +65,18 @@ __device__ __forceinline__ void dma16(const bf16_t* gsrc, bf16_t* lds_base_wave_
 
 // MODE 0: token GEMM, 1: implicit 3x3 conv.  EPI 0: alpha*(acc+bias) (+temb)(+residual); 1: GEGLU (weights
 // pre-interleaved per 128 rows: 64 value rows then their 64 gate rows; out is [M, N/2]).
-template <int MODE, int EPI, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN) == 4 ? 2 : (WM * WN) / 4)
+//
+// BK = 64: two 128-byte-row stages; BK = 32: half the LDS per workgroup, i.e. twice the workgroups per CU -- the arm
+// for the K = 320 / 640 projections, whose 5-10 k-tiles cannot hide the DMA latency behind their own MFMAs and need
+// other workgroups on the CU to do it.
+template <int MODE, int EPI, int WM, int WN, int BK>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) == 16 ? 4 : (BK == 32 ? 4 : 2))
 void gemm_kernel(const GemmParams P) {
     constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN, NT = 64 * NW;
     constexpr int STAGE_ELEMS = (BM + BN) * BK;
-    constexpr int PIECES = (BM + BN) / 8;            // 1-KiB pieces (8 rows x 128 B) per k-tile
+    constexpr int RPP = 512 / BK;                    // tile rows per 1-KiB DMA piece (8 x 128 B or 16 x 64 B)
+    constexpr int CPRW = BK / 8;                     // 16-byte chunks per tile row
+    constexpr int PIECES = (BM + BN) / RPP;          // pieces per k-tile
     constexpr int PPW = PIECES / NW;                 // pieces per wave
     constexpr int CP = BN + 8;                       // fp32 C slab pitch
     static_assert(PIECES % NW == 0, "pieces must divide evenly over the waves");
@@ -93,13 +102,13 @@ void gemm_kernel(const GemmParams P) {
     const bf16_t* src[PPW];
     bool val[PPW];
     int py[PPW], px[PPW];
-    const int prow = lane >> 3, pphys = lane & 7;
+    const int prow = lane / CPRW, pphys = lane % CPRW;
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
         const int p = wave + NW * j;
-        if (p < BM / 8) {
-            const int rloc = 8 * p + prow;
-            const int sc = swz(rloc, pphys);
+        if (p < BM / RPP) {
+            const int rloc = RPP * p + prow;
+            const int sc = swz<BK>(rloc, pphys);
             const int64_t m = m0 + rloc;
             val[j] = m < P.M;
             const int64_t mm = val[j] ? m : 0;
@@ -113,8 +122,8 @@ void gemm_kernel(const GemmParams P) {
                 src[j] = P.a + mm * P.cin + sc * 8;
             }
         } else {
-            const int rloc = 8 * (p - BM / 8) + prow;
-            const int sc = swz(rloc, pphys);
+            const int rloc = RPP * (p - BM / RPP) + prow;
+            const int sc = swz<BK>(rloc, pphys);
             const int n = n0 + rloc;
             val[j] = n < P.N;
             src[j] = P.w + (int64_t)(val[j] ? n : 0) * P.K + sc * 8;
@@ -136,13 +145,13 @@ void gemm_kernel(const GemmParams P) {
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
             const int p = wave + NW * j;             // wave-uniform
-            if (p < BM / 8) {
+            if (p < BM / RPP) {
                 bool ok = val[j];
                 if (MODE == 1)
                     ok = ok && (unsigned)(py[j] + dy) < (unsigned)P.img_h && (unsigned)(px[j] + dx) < (unsigned)P.img_w;
-                dma16(ok ? src[j] + shift : zero, stage + p * 8 * BK);
+                dma16(ok ? src[j] + shift : zero, stage + p * 512);
             } else {
-                dma16(val[j] ? src[j] + k0 : zero, stage + p * 8 * BK);   // W rows follow the A rows in the stage
+                dma16(val[j] ? src[j] + k0 : zero, stage + p * 512);       // W rows follow the A rows in the stage
             }
         }
     };
@@ -173,8 +182,8 @@ void gemm_kernel(const GemmParams P) {
                 const int rw = wn * 64 + i * 32 + l31;
                 const int rm = wm * 64 + i * 32 + l31;
                 union { bf16x8 v; u32x4 u; } tw, ta;
-                tw.u = *reinterpret_cast<const u32x4*>(Ws + rw * BK + swz(rw, 2 * ks + half) * 8);
-                ta.u = *reinterpret_cast<const u32x4*>(As + rm * BK + swz(rm, 2 * ks + half) * 8);
+                tw.u = *reinterpret_cast<const u32x4*>(Ws + rw * BK + swz<BK>(rw, 2 * ks + half) * 8);
+                ta.u = *reinterpret_cast<const u32x4*>(As + rm * BK + swz<BK>(rm, 2 * ks + half) * 8);
                 wf[i] = tw.v;
                 af[i] = ta.v;
             }
@@ -265,7 +274,7 @@ void gemm_kernel(const GemmParams P) {
     }
 }
 
-int gemm_geometry_override() {           // FMC_GEMM_TILE = 0 (caller's choice) | 1: 128x128 | 2: 256x128 | 3: 256x256
+int gemm_geometry_override() {   // FMC_GEMM_TILE = 0 (caller's choice) | 1..3: 128x128, 256x128, 256x256 at BK 64 | 4..6: same at BK 32
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("FMC_GEMM_TILE");
@@ -274,7 +283,7 @@ int gemm_geometry_override() {           // FMC_GEMM_TILE = 0 (caller's choice) 
     return v;
 }
 
-template <int MODE, int EPI, int WM, int WN>
+template <int MODE, int EPI, int WM, int WN, int BK>
 void launch_gemm_g(GemmParams& P, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     P.tiles_m = (int)((P.M + BM - 1) / BM);
@@ -284,11 +293,11 @@ void launch_gemm_g(GemmParams& P, hipStream_t st) {
     if (slab > lds) lds = slab;
     static bool raised = false;
     if (!raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, EPI, WM, WN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, EPI, WM, WN, BK>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         raised = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<MODE, EPI, WM, WN>), dim3(P.tiles_m * P.tiles_n), dim3(64 * WM * WN), lds, st, P);
+    hipLaunchKernelGGL((gemm_kernel<MODE, EPI, WM, WN, BK>), dim3(P.tiles_m * P.tiles_n), dim3(64 * WM * WN), lds, st, P);
 }
 
 // geometry: the largest tile that still gives every CU work and does not waste more than ~20 % of N
@@ -303,9 +312,14 @@ void launch_gemm(GemmParams& P, int tile, hipStream_t st) {
         else if (tiles(256, 128) >= 256 && waste(128) <= 1.25) g = 2;
         else g = 1;
     }
-    if (g == 3) launch_gemm_g<MODE, EPI, 4, 4>(P, st);
-    else if (g == 2) launch_gemm_g<MODE, EPI, 4, 2>(P, st);
-    else launch_gemm_g<MODE, EPI, 2, 2>(P, st);
+    switch (g) {
+        case 6: launch_gemm_g<MODE, EPI, 4, 4, 32>(P, st); break;
+        case 5: launch_gemm_g<MODE, EPI, 4, 2, 32>(P, st); break;
+        case 4: launch_gemm_g<MODE, EPI, 2, 2, 32>(P, st); break;
+        case 3: launch_gemm_g<MODE, EPI, 4, 4, 64>(P, st); break;
+        case 2: launch_gemm_g<MODE, EPI, 4, 2, 64>(P, st); break;
+        default: launch_gemm_g<MODE, EPI, 2, 2, 64>(P, st); break;
+    }
 }
 
 }  // namespace
@@ -314,7 +328,7 @@ extern "C" int fmc_linear_bf16(const void* x, const void* w, const void* bias, c
                                int N, int K, int64_t ldx, int64_t ldres, int64_t ldo, float alpha, int epilogue, int tile,
                                void* stream) {
     if (!x || !w || !out) FMC_FAIL(FMC_E_NULL, "linear_bf16: NULL tensor");
-    if (M <= 0 || N <= 0 || K <= 0 || K % BK || N % 8 || ldx % 8 || ldo % 8 || (residual && ldres % 8))
+    if (M <= 0 || N <= 0 || K <= 0 || K % BK_MAX || N % 8 || ldx % 8 || ldo % 8 || (residual && ldres % 8))
         FMC_FAIL(FMC_E_SHAPE, "linear_bf16: need K%%64==0, N%%8==0 and strides %%8==0 (M=%lld N=%d K=%d)", (long long)M, N, K);
     if (epilogue != 0 && epilogue != 1) FMC_FAIL(FMC_E_SHAPE, "linear_bf16: epilogue %d", epilogue);
     if (epilogue == 1 && (N % 256 || residual)) FMC_FAIL(FMC_E_SHAPE, "linear_bf16: GEGLU needs N%%256==0 and no residual");
@@ -327,7 +341,7 @@ extern "C" int fmc_linear_bf16(const void* x, const void* w, const void* bias, c
     P.M = M; P.N = N; P.K = K; P.lda = ldx; P.ldres = ldres; P.ldo = ldo;
     P.img_h = P.img_w = P.cin = 0; P.hw = 1; P.alpha = alpha;
     hipStream_t st = (hipStream_t)stream;
-    if (tile < 0 || tile > 3) FMC_FAIL(FMC_E_SHAPE, "linear_bf16: tile %d", tile);
+    if (tile < 0 || tile > 6) FMC_FAIL(FMC_E_SHAPE, "linear_bf16: tile %d", tile);
     if (epilogue == 0) launch_gemm<0, 0>(P, tile, st); else launch_gemm<0, 1>(P, tile, st);
     FMC_CHECK_LAUNCH("fmc_linear_bf16");
     return 0;
@@ -336,7 +350,7 @@ extern "C" int fmc_linear_bf16(const void* x, const void* w, const void* bias, c
 extern "C" int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, const void* temb, const void* residual,
                                 void* out, int n_img, int H, int W, int Cin, int Cout, int tile, void* stream) {
     if (!x || !w || !out) FMC_FAIL(FMC_E_NULL, "conv3x3_bf16: NULL tensor");
-    if (n_img <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % BK || Cout % 8)
+    if (n_img <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % BK_MAX || Cout % 8)
         FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: need Cin%%64==0 and Cout%%8==0 (Cin=%d Cout=%d)", Cin, Cout);
     if (!fmc_aligned16(x) || !fmc_aligned16(w) || !fmc_aligned16(out) || (residual && !fmc_aligned16(residual)) ||
         (temb && !fmc_aligned16(temb)) || (bias && !fmc_aligned16(bias)))
@@ -346,7 +360,7 @@ extern "C" int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, 
     P.res = (const bf16_t*)residual; P.out = (bf16_t*)out;
     P.M = (int64_t)n_img * H * W; P.N = Cout; P.K = 9 * Cin; P.lda = Cin; P.ldres = Cout; P.ldo = Cout;
     P.img_h = H; P.img_w = W; P.cin = Cin; P.hw = H * W; P.alpha = 1.f;
-    if (tile < 0 || tile > 3) FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: tile %d", tile);
+    if (tile < 0 || tile > 6) FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: tile %d", tile);
     launch_gemm<1, 0>(P, tile, (hipStream_t)stream);
     FMC_CHECK_LAUNCH("fmc_conv3x3_bf16");
     return 0;

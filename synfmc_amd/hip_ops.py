@@ -510,7 +510,15 @@ def conv3x3_bf16(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias: Optional[t
 # unseen shape falls back to a static rule.  Both arms compute the same function.
 # --------------------------------------------------------------------------------------------
 _choice = {}
+_tune_log = {}      # key -> {arm: ms} measured when the choice was made
+_calls = {}         # key -> eager calls seen (graph replays do not pass through Python)
 AUTOTUNE = True
+GEMM_TILES = (1, 2, 3, 4, 5, 6)     # fmc_linear_bf16 / fmc_conv3x3_bf16 `tile` arms tried per shape
+
+
+def autotune_report():
+    """[(key, chosen arm, {arm: ms}, eager calls)] for every shape tuned so far (arm 0 = vendor library)."""
+    return [(k, _choice[k], _tune_log.get(k, {}), _calls.get(k, 0)) for k in _choice]
 
 
 def _time_ms(fn, iters=4):
@@ -526,14 +534,16 @@ def _time_ms(fn, iters=4):
 
 
 def _pick(key, hip_fn, lib_fn, static_hip: bool) -> int:
-    """0 = vendor library arm, 1..3 = fused gfx950 kernel with that tile geometry (`hip_fn(tile)`)."""
+    """0 = vendor library arm, 1..6 = fused gfx950 kernel with that tile geometry (`hip_fn(tile)`)."""
     use = _choice.get(key)
+    _calls[key] = _calls.get(key, 0) + 1
     if use is None:
         if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
             return 0 if not static_hip else -1          # -1: kernel's own geometry heuristic
-        times = [(_time_ms(lib_fn), 0)] + [(_time_ms(lambda t=t: hip_fn(t)), t) for t in (1, 2, 3)]
+        times = [(_time_ms(lib_fn), 0)] + [(_time_ms(lambda t=t: hip_fn(t)), t) for t in GEMM_TILES]
         use = min(times)[1]
         _choice[key] = use
+        _tune_log[key] = {arm: round(ms, 4) for ms, arm in times}
     return use
 
 

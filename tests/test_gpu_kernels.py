@@ -318,6 +318,32 @@ def test_linear_bf16_fused_epilogue(K, M, N, Kd, bias, res, alpha):
     assert torch.equal(out2, out)
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+def test_gemm_tile_geometries_agree(K, tile):
+    """every `tile` arm (3 geometries x k-tile depth 64 / 32) must compute the same function, ragged edges included"""
+    dtype = torch.bfloat16
+    xo, xd = rnd((777, 320), 67, dtype)
+    wo, wd = rnd((328, 320), 68, dtype, scale=320 ** -0.5)
+    bo, bd = rnd((328,), 69, dtype)
+    ro, rd = rnd((777, 328), 59, dtype)
+    ref = F.linear(xo, wo, bo) + ro
+    out = K.linear_bf16(xd, wd, bd, rd, 1.0, tile=tile)
+    assert rel_inf(out.float(), ref) < 1e-2
+    assert torch.equal(out, K.linear_bf16(xd, wd, bd, rd, 1.0, tile=1))         # same accumulation order in every arm
+    co, cd = rnd((2, 128, 11, 13), 58, dtype)
+    fo, fd = rnd((72, 128, 3, 3), 57, dtype, scale=(9 * 128) ** -0.5)
+    refc = F.conv2d(co, fo, None, 1, 1)
+    outc = K.conv3x3_bf16(cd.permute(0, 2, 3, 1).contiguous(), fd.contiguous(memory_format=torch.channels_last), None,
+                          None, None, tile=tile)
+    assert rel_inf(outc.permute(0, 3, 1, 2).float(), refc) < 1e-2
+    from synfmc_amd.models.layers import interleave_geglu
+    go, gd = rnd((512, 320), 56, dtype, scale=320 ** -0.5)
+    wi, bi = interleave_geglu(gd, None)
+    a, g = F.linear(xo, go).chunk(2, dim=-1)
+    outg = K.linear_bf16(xd, wi, bi, geglu=True, tile=tile)
+    assert rel_inf(outg.float(), a * F.gelu(g)) < 1e-2
+
+
 def test_linear_bf16_geglu(K):
     dtype = torch.bfloat16
     M, C, Cff = 513, 320, 1280
