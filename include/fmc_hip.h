@@ -174,9 +174,13 @@ int fmc_cfg_ddim_step(const void* eps_uc, const float* x, float* x_out, int64_t 
  *   tile: workgroup tile geometry, 0 = pick by shape, 1 = 128x128 (4 waves), 2 = 256x128 (8), 3 = 256x256 (16) with
  *   64-deep k-tiles; 4..6 = the same three with 32-deep k-tiles (half the LDS, twice the workgroups per CU);
  *   every geometry computes the same function (callers may time them and keep the fastest).
+ *   split_k > 1 (epilogue 0 only): the k-tiles of every output tile are dealt to split_k workgroups that write fp32
+ *   partial sums to `workspace` (>= split_k * M * N * 4 bytes, 16-byte aligned, caller-owned scratch); a second kernel
+ *   sums them in a fixed order and applies the epilogue.  For M*N too small to fill 256 CUs (the 5x8 level).
  * ------------------------------------------------------------------------------------------- */
 int fmc_linear_bf16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int N,
-                    int K, int64_t ldx, int64_t ldres, int64_t ldo, float alpha, int epilogue, int tile, void* stream);
+                    int K, int64_t ldx, int64_t ldres, int64_t ldo, float alpha, int epilogue, int tile, int split_k,
+                    void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Implicit-GEMM 3x3 convolution (stride 1, pad 1) on channels-last bf16 images with the ResNet-block epilogue:
  *   out[i,y,x,:] = conv(x)[i,y,x,:] + bias + temb[i,:] + residual[i,y,x,:]
@@ -184,9 +188,11 @@ int fmc_linear_bf16(const void* x, const void* w, const void* bias, const void* 
  * `+ time_emb_proj(silu(temb))[:, :, None, None]` and the `input_tensor + hidden_states` residual, and the conv of
  * Upsample2D (unet_blocks.py:625).
  *   x [n_img, H, W, Cin], w [Cout, 3, 3, Cin] (= the filter in torch.channels_last memory format),
- *   bias [Cout] | NULL, temb [n_img, Cout] | NULL, residual / out [n_img, H, W, Cout].  Cin % 64 == 0, Cout % 8 == 0. */
+ *   bias [Cout] | NULL, temb [n_img, Cout] | NULL, residual / out [n_img, H, W, Cout].  Cin % 64 == 0, Cout % 8 == 0.
+ *   tile / split_k / workspace: as for fmc_linear_bf16 (M = n_img*H*W, N = Cout, K = 9*Cin). */
 int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, const void* temb, const void* residual, void* out,
-                     int n_img, int H, int W, int Cin, int Cout, int tile, void* stream);
+                     int n_img, int H, int W, int Cin, int Cout, int tile, int split_k, void* workspace,
+                     int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Backward entry points (training stages 2/3 of the reference: the U-Net is frozen but the activation gradient

@@ -44,6 +44,8 @@ struct GemmParams {
     int img_h, img_w, cin, hw;        // conv mode
     float alpha;
     int tiles_m, tiles_n;
+    int split_k;                      // > 1: k-tiles are dealt to split_k workgroups per output tile, which write fp32
+    float* ws;                        //      partial sums to ws[split][M][N]; splitk_reduce_kernel applies the epilogue
 };
 
 __device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.f + erff(g * 0.70710678118654752f)); }
@@ -89,9 +91,11 @@ void gemm_kernel(const GemmParams P) {
     // ---- tile order: XCD aware (blockIdx % 8 = XCD): n-tiles of one m-tile stay on one XCD --------------------
     int tile_m, tile_n;
     {
-        const int id = blockIdx.x, total = P.tiles_m * P.tiles_n;
+        const int total = P.tiles_m * P.tiles_n;
+        int id = blockIdx.x;
+        if (P.split_k > 1) id /= P.split_k;              // the splits of one tile are neighbours in launch order
         int lin = id;
-        if ((total & 7) == 0) lin = (id & 7) * (total >> 3) + (id >> 3);
+        if (P.split_k == 1 && (total & 7) == 0) lin = (id & 7) * (total >> 3) + (id >> 3);
         tile_m = lin / P.tiles_n;
         tile_n = lin - tile_m * P.tiles_n;
     }
@@ -164,9 +168,15 @@ void gemm_kernel(const GemmParams P) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int nk = P.K / BK;
-    dma_issue(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
+    int kt0 = 0, nk = P.K / BK;
+    const int split = P.split_k > 1 ? (int)(blockIdx.x % P.split_k) : 0;
+    if (P.split_k > 1) {
+        const int per = (nk + P.split_k - 1) / P.split_k;
+        kt0 = split * per;
+        nk = min(nk, kt0 + per);
+    }
+    if (kt0 < nk) dma_issue(kt0, kt0 & 1);
+    for (int kt = kt0; kt < nk; ++kt) {
         // my pieces of tile kt have landed; after the barrier everybody's have, and everybody has finished reading
         // the other stage (compute kt-1), so tile kt+1 may start streaming into it
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -214,7 +224,20 @@ void gemm_kernel(const GemmParams P) {
                     }
         }
         __syncthreads();
-        if (EPI == 0) {
+        if (EPI == 0 && P.split_k > 1) {                 // raw fp32 partial sums; epilogue in splitk_reduce_kernel
+            constexpr int CPR = BN / 8;
+            constexpr int RSTEP = NT / CPR;
+            const int ch = tid % CPR, n = n0 + ch * 8;
+            if (n < P.N) {
+                for (int r = tid / CPR; r < 64; r += RSTEP) {
+                    const int64_t m = m0 + hm * 64 + r;
+                    if (m >= P.M) continue;
+                    float* dst = P.ws + ((int64_t)split * P.M + m) * P.N + n;
+                    *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(Cs + r * CP + ch * 8);
+                    *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(Cs + r * CP + ch * 8 + 4);
+                }
+            }
+        } else if (EPI == 0) {
             constexpr int CPR = BN / 8;                  // 8-column chunks per slab row
             constexpr int RSTEP = NT / CPR;              // rows covered per pass
             const int ch = tid % CPR, n = n0 + ch * 8;
@@ -283,6 +306,38 @@ int gemm_geometry_override() {   // FMC_GEMM_TILE = 0 (caller's choice) | 1..3: 
     return v;
 }
 
+// second pass of a split-K launch: out = alpha * (sum_s ws[s] + bias) (+ temb) (+ residual), fixed summation order
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams P) {
+    const int cpr = P.N / 8;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P.M * cpr) return;
+    const int64_t m = idx / cpr;
+    const int n = (int)(idx - m * cpr) * 8;
+    float v[8];
+    Vec8<float>::load(P.ws + m * P.N + n, v);
+    for (int sp = 1; sp < P.split_k; ++sp) {
+        float t[8];
+        Vec8<float>::load(P.ws + ((int64_t)sp * P.M + m) * P.N + n, t);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += t[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (v[k] + (P.bias ? bf2f(P.bias[n + k]) : 0.f)) * P.alpha;
+    if (P.temb) {
+        float t[8];
+        Vec8<bf16_t>::load(P.temb + (m / P.hw) * P.N + n, t);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += t[k];
+    }
+    if (P.res) {
+        float t[8];
+        Vec8<bf16_t>::load(P.res + m * P.ldres + n, t);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += t[k];
+    }
+    Vec8<bf16_t>::store(P.out + m * P.ldo + n, v);
+}
+
 template <int MODE, int EPI, int WM, int WN, int BK>
 void launch_gemm_g(GemmParams& P, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
@@ -297,7 +352,12 @@ void launch_gemm_g(GemmParams& P, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         raised = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<MODE, EPI, WM, WN, BK>), dim3(P.tiles_m * P.tiles_n), dim3(64 * WM * WN), lds, st, P);
+    hipLaunchKernelGGL((gemm_kernel<MODE, EPI, WM, WN, BK>), dim3(P.tiles_m * P.tiles_n * P.split_k), dim3(64 * WM * WN),
+                       lds, st, P);
+    if (P.split_k > 1) {
+        const int64_t chunks = P.M * (P.N / 8);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, P);
+    }
 }
 
 // geometry: the largest tile that still gives every CU work and does not waste more than ~20 % of N
@@ -322,11 +382,24 @@ void launch_gemm(GemmParams& P, int tile, hipStream_t st) {
     }
 }
 
+int set_split_k(GemmParams& P, int split_k, void* workspace, int64_t workspace_bytes, bool plain_epilogue, const char* who) {
+    P.split_k = 1;
+    P.ws = nullptr;
+    if (split_k <= 1) return 0;
+    if (split_k > 16 || !plain_epilogue) FMC_FAIL(FMC_E_SHAPE, "%s: split_k %d (1..16, not with the GEGLU epilogue)", who, split_k);
+    if (!workspace || !fmc_aligned16(workspace)) FMC_FAIL(FMC_E_NULL, "%s: split_k needs a 16-byte aligned workspace", who);
+    if (workspace_bytes < (int64_t)split_k * P.M * P.N * (int64_t)sizeof(float))
+        FMC_FAIL(FMC_E_SHAPE, "%s: workspace of %lld bytes < split_k*M*N*4", who, (long long)workspace_bytes);
+    P.split_k = split_k;
+    P.ws = (float*)workspace;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int fmc_linear_bf16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,
                                int N, int K, int64_t ldx, int64_t ldres, int64_t ldo, float alpha, int epilogue, int tile,
-                               void* stream) {
+                               int split_k, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!x || !w || !out) FMC_FAIL(FMC_E_NULL, "linear_bf16: NULL tensor");
     if (M <= 0 || N <= 0 || K <= 0 || K % BK_MAX || N % 8 || ldx % 8 || ldo % 8 || (residual && ldres % 8))
         FMC_FAIL(FMC_E_SHAPE, "linear_bf16: need K%%64==0, N%%8==0 and strides %%8==0 (M=%lld N=%d K=%d)", (long long)M, N, K);
@@ -342,13 +415,15 @@ extern "C" int fmc_linear_bf16(const void* x, const void* w, const void* bias, c
     P.img_h = P.img_w = P.cin = 0; P.hw = 1; P.alpha = alpha;
     hipStream_t st = (hipStream_t)stream;
     if (tile < 0 || tile > 6) FMC_FAIL(FMC_E_SHAPE, "linear_bf16: tile %d", tile);
+    if (int rc = set_split_k(P, split_k, workspace, workspace_bytes, epilogue == 0, "linear_bf16")) return rc;
     if (epilogue == 0) launch_gemm<0, 0>(P, tile, st); else launch_gemm<0, 1>(P, tile, st);
     FMC_CHECK_LAUNCH("fmc_linear_bf16");
     return 0;
 }
 
 extern "C" int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, const void* temb, const void* residual,
-                                void* out, int n_img, int H, int W, int Cin, int Cout, int tile, void* stream) {
+                                void* out, int n_img, int H, int W, int Cin, int Cout, int tile, int split_k,
+                                void* workspace, int64_t workspace_bytes, void* stream) {
     if (!x || !w || !out) FMC_FAIL(FMC_E_NULL, "conv3x3_bf16: NULL tensor");
     if (n_img <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % BK_MAX || Cout % 8)
         FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: need Cin%%64==0 and Cout%%8==0 (Cin=%d Cout=%d)", Cin, Cout);
@@ -361,6 +436,7 @@ extern "C" int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, 
     P.M = (int64_t)n_img * H * W; P.N = Cout; P.K = 9 * Cin; P.lda = Cin; P.ldres = Cout; P.ldo = Cout;
     P.img_h = H; P.img_w = W; P.cin = Cin; P.hw = H * W; P.alpha = 1.f;
     if (tile < 0 || tile > 6) FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: tile %d", tile);
+    if (int rc = set_split_k(P, split_k, workspace, workspace_bytes, true, "conv3x3_bf16")) return rc;
     launch_gemm<1, 0>(P, tile, (hipStream_t)stream);
     FMC_CHECK_LAUNCH("fmc_conv3x3_bf16");
     return 0;

@@ -42,12 +42,15 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 _ws_cache = {}
+_ws_retired = []
 
 
 def _workspace(device, nbytes: int) -> torch.Tensor:
     key = (device.index, torch.cuda.current_stream().cuda_stream)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
+        if ws is not None:
+            _ws_retired.append(ws)      # a captured HIP graph may have baked its address: never hand it back
         ws = torch.empty(max(nbytes // 4 + 1, 1 << 16), dtype=torch.float32, device=device)
         _ws_cache[key] = ws
     return ws
@@ -445,6 +448,31 @@ def cfg_ddim_step(eps: torch.Tensor, x: torch.Tensor, guidance: float, alpha_t: 
 # --------------------------------------------------------------------------------------------
 # bf16 MFMA GEMM / implicit 3x3 conv with fused epilogues
 # --------------------------------------------------------------------------------------------
+def _decode_arm(tile: int, split_k: int):
+    """autotune arm id -> (tile geometry 0..6, split_k)"""
+    if tile >= 8:
+        return tile & 7, 1 << (tile >> 3)
+    return tile, split_k
+
+
+def _splitk_workspace(device, split_k: int, M: int, N: int):
+    if split_k <= 1:
+        return None, 0
+    nbytes = split_k * M * N * 4
+    return _workspace(device, nbytes).data_ptr(), nbytes
+
+
+def split_arms(M: int, N: int, Kd: int):
+    """extra autotune arms for problems whose 128x128 output tiles cannot fill the 256 CUs: split-K 2 / 4 (/ 8)"""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles > 320 or Kd < 1024:
+        return ()
+    arms = [t + 8 * si for si in (1, 2) for t in (1, 2, 4)]
+    if tiles <= 128 and Kd >= 4096:
+        arms += [1 + 8 * 3, 4 + 8 * 3]
+    return tuple(arms)
+
+
 def linear_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
     return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.stride(-1) == 1
             and weight.shape[1] % 64 == 0 and weight.shape[0] % 8 == 0 and weight.is_contiguous())
@@ -461,9 +489,11 @@ def _rows2d(t: torch.Tensor):
 
 def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
                 residual: Optional[torch.Tensor] = None, alpha: float = 1.0, geglu: bool = False,
-                tile: int = 0) -> torch.Tensor:
+                tile: int = 0, split_k: int = 1) -> torch.Tensor:
     """`alpha * (x @ weight^T + bias) + residual` (or the GEGLU gate, see fmc_linear_bf16) on the bf16 MFMA kernel.
-    x `[..., K]`, weight `[N, K]`; residual has the output's shape."""
+    x `[..., K]`, weight `[N, K]`; residual has the output's shape.  `tile` may also be an autotune arm id
+    (`tile + 8 * log2(split_k)`)."""
+    tile, split_k = _decode_arm(tile, split_k)
     _dev(x, weight, bias, residual)
     N, Kd = weight.shape
     M, ldx = _rows2d(x)
@@ -473,8 +503,10 @@ def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     if residual is not None:
         assert residual.shape == out.shape
         _, ldres = _rows2d(residual)
+    ws, ws_bytes = _splitk_workspace(x.device, split_k, M, N)
     _lib.check(_lib.load().fmc_linear_bf16(x.data_ptr(), weight.data_ptr(), _p(bias), _p(residual), out.data_ptr(), M, N,
-                                           Kd, ldx, ldres, n_out, float(alpha), int(geglu), int(tile), _stream()),
+                                           Kd, ldx, ldres, n_out, float(alpha), int(geglu), int(tile), int(split_k),
+                                           ws, ws_bytes, _stream()),
                "fmc_linear_bf16")
     return out
 
@@ -487,7 +519,7 @@ def conv3x3_supported(x: torch.Tensor, weight: torch.Tensor, stride, padding) ->
 
 def conv3x3_bf16(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias: Optional[torch.Tensor] = None,
                  temb: Optional[torch.Tensor] = None, residual_nhwc: Optional[torch.Tensor] = None,
-                 tile: int = 0) -> torch.Tensor:
+                 tile: int = 0, split_k: int = 1) -> torch.Tensor:
     """x `[N, H, W, Cin]` contiguous, weight `[Cout, Cin, 3, 3]` in channels_last memory format (physically
     `[Cout, 3, 3, Cin]`), temb `[N, Cout]`, residual `[N, H, W, Cout]` -> `[N, H, W, Cout]`."""
     _dev(x_nhwc, weight_cl, bias, temb, residual_nhwc)
@@ -497,8 +529,11 @@ def conv3x3_bf16(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias: Optional[t
     assert temb is None or (temb.is_contiguous() and temb.shape == (n, cout))
     assert residual_nhwc is None or (residual_nhwc.is_contiguous() and residual_nhwc.shape == (n, h, w, cout))
     out = torch.empty(n, h, w, cout, dtype=x_nhwc.dtype, device=x_nhwc.device)
+    tile, split_k = _decode_arm(tile, split_k)
+    ws, ws_bytes = _splitk_workspace(x_nhwc.device, split_k, n * h * w, cout)
     _lib.check(_lib.load().fmc_conv3x3_bf16(x_nhwc.data_ptr(), weight_cl.data_ptr(), _p(bias), _p(temb),
-                                            _p(residual_nhwc), out.data_ptr(), n, h, w, cin, cout, int(tile), _stream()),
+                                            _p(residual_nhwc), out.data_ptr(), n, h, w, cin, cout, int(tile),
+                                            int(split_k), ws, ws_bytes, _stream()),
                "fmc_conv3x3_bf16")
     return out
 
@@ -521,26 +556,45 @@ def autotune_report():
     return [(k, _choice[k], _tune_log.get(k, {}), _calls.get(k, 0)) for k in _choice]
 
 
-def _time_ms(fn, iters=4):
-    fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
+_tune_stream = None
 
 
-def _pick(key, hip_fn, lib_fn, static_hip: bool) -> int:
+def _time_ms(fn, reps=8):
+    """GPU time of one `fn()` call, measured on a captured HIP graph of `reps` calls so that the Python / launch
+    overhead of the 10-30 us kernels does not decide the arm (in the pipelines they replay from a graph as well)."""
+    global _tune_stream
+    if _tune_stream is None:
+        _tune_stream = torch.cuda.Stream()
+    cur = torch.cuda.current_stream()
+    _tune_stream.wait_stream(cur)
+    with torch.cuda.stream(_tune_stream):
+        fn()                                            # lazy initialisation (workspaces, library heuristics) outside capture
+        _tune_stream.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=_tune_stream):
+            for _ in range(reps):
+                fn()
+        g.replay()
+        _tune_stream.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        _tune_stream.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        del g
+    cur.wait_stream(_tune_stream)
+    return ms
+
+
+def _pick(key, hip_fn, lib_fn, static_hip: bool, extra_arms=()) -> int:
     """0 = vendor library arm, 1..6 = fused gfx950 kernel with that tile geometry (`hip_fn(tile)`)."""
     use = _choice.get(key)
     _calls[key] = _calls.get(key, 0) + 1
     if use is None:
         if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
             return 0 if not static_hip else -1          # -1: kernel's own geometry heuristic
-        times = [(_time_ms(lib_fn), 0)] + [(_time_ms(lambda t=t: hip_fn(t)), t) for t in GEMM_TILES]
+        times = [(_time_ms(lib_fn), 0)] + [(_time_ms(lambda t=t: hip_fn(t)), t) for t in GEMM_TILES + tuple(extra_arms)]
         use = min(times)[1]
         _choice[key] = use
         _tune_log[key] = {arm: round(ms, 4) for ms, arm in times}
@@ -564,7 +618,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     M = x.numel() // Kd
     key = ("lin", M, N, Kd, bias is not None, residual is not None)
     hip = lambda tile: linear_bf16(x, weight, bias, residual, alpha, tile=tile)
-    use = _pick(key, hip, lib, Kd <= 640 and N <= 1024 and M >= 16384)
+    use = _pick(key, hip, lib, Kd <= 640 and N <= 1024 and M >= 16384, split_arms(M, N, Kd))
     return lib() if use == 0 else hip(max(use, 0))
 
 
@@ -607,5 +661,5 @@ def conv3x3(x_nchw: torch.Tensor, weight_cl: torch.Tensor, bias, temb=None, resi
     key = ("conv", n, h, w, cin, cout, temb is not None, r is not None)
     hip = lambda tile: conv3x3_bf16(x, weight_cl, bias, temb, r, tile=tile).permute(0, 3, 1, 2)
     tiles = ((n * h * w + 127) // 128) * ((cout + 127) // 128)
-    use = _pick(key, hip, lib, tiles >= 256)
+    use = _pick(key, hip, lib, tiles >= 256, split_arms(n * h * w, cout, 9 * cin))
     return lib() if use == 0 else hip(max(use, 0))

@@ -344,6 +344,30 @@ def test_gemm_tile_geometries_agree(K, tile):
     assert rel_inf(outg.float(), a * F.gelu(g)) < 1e-2
 
 
+@pytest.mark.parametrize("split_k", [2, 4, 8])
+@pytest.mark.parametrize("tile", [1, 2, 4])
+def test_gemm_split_k(K, tile, split_k):
+    """split-K arms: fp32 partial sums in a workspace + a fixed-order reduce; ragged k-tile division included"""
+    dtype = torch.bfloat16
+    xo, xd = rnd((333, 1280 + 64), 50, dtype)                                   # 21 k-tiles: not divisible by 2/4/8
+    wo, wd = rnd((200, 1280 + 64), 51, dtype, scale=1344 ** -0.5)
+    bo, bd = rnd((200,), 52, dtype)
+    ro, rd = rnd((333, 200), 53, dtype)
+    ref = (F.linear(xo, wo, bo)) * 0.5 + ro
+    out = K.linear_bf16(xd, wd, bd, rd, 0.5, tile=tile, split_k=split_k)
+    assert rel_inf(out.float(), ref) < 1e-2
+    assert torch.equal(out, K.linear_bf16(xd, wd, bd, rd, 0.5, tile=tile, split_k=split_k))   # deterministic
+    assert torch.equal(out, K.linear_bf16(xd, wd, bd, rd, 0.5, tile=tile + 8 * {2: 1, 4: 2, 8: 3}[split_k]))  # arm id
+    co, cd = rnd((2, 256, 5, 8), 54, dtype)
+    fo, fd = rnd((136, 256, 3, 3), 55, dtype, scale=(9 * 256) ** -0.5)
+    to, td = rnd((2, 136), 49, dtype)
+    so, sd = rnd((2, 136, 5, 8), 48, dtype)
+    refc = F.conv2d(co, fo, None, 1, 1) + to[:, :, None, None] + so
+    outc = K.conv3x3_bf16(cd.permute(0, 2, 3, 1).contiguous(), fd.contiguous(memory_format=torch.channels_last), None,
+                          td, sd.permute(0, 2, 3, 1).contiguous(), tile=tile, split_k=split_k)
+    assert rel_inf(outc.permute(0, 3, 1, 2).float(), refc) < 1e-2
+
+
 def test_linear_bf16_geglu(K):
     dtype = torch.bfloat16
     M, C, Cff = 513, 320, 1280
