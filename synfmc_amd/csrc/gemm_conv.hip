@@ -71,8 +71,19 @@ __device__ __forceinline__ void dma16(const bf16_t* gsrc, bf16_t* lds_base_wave_
 // BK = 64: two 128-byte-row stages; BK = 32: half the LDS per workgroup, i.e. twice the workgroups per CU -- the arm
 // for the K = 320 / 640 projections, whose 5-10 k-tiles cannot hide the DMA latency behind their own MFMAs and need
 // other workgroups on the CU to do it.
-template <int MODE, int EPI, int WM, int WN, int BK>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN) == 16 ? 4 : (BK == 32 ? 4 : 2))
+//
+// STAGES: depth of the LDS ring.  STAGES-1 k-tiles are in flight under the MFMAs of the current one (counted
+// s_waitcnt vmcnt(N), never a drain): what bounds these kernels is bytes in flight per CU (L2/HBM latency x
+// bandwidth), so the ring is as deep as the 160 KiB of LDS allow for the geometry.
+template <int WM, int WN, int BK, int STAGES> constexpr int gemm_min_waves() {
+    const size_t lds = (size_t)STAGES * 64 * (WM + WN) * BK * 2;
+    const int wgs = (int)(160 * 1024 / lds) > 0 ? (int)(160 * 1024 / lds) : 1;     // workgroups per CU the LDS allows
+    const int w = wgs * WM * WN / 4;                                                 // waves per SIMD
+    return w > 4 ? 4 : (w < 1 ? 1 : w);
+}
+
+template <int MODE, int EPI, int WM, int WN, int BK, int STAGES>
+__global__ __launch_bounds__(64 * WM * WN, (gemm_min_waves<WM, WN, BK, STAGES>()))
 void gemm_kernel(const GemmParams P) {
     constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN, NT = 64 * NW;
     constexpr int STAGE_ELEMS = (BM + BN) * BK;
@@ -175,14 +186,26 @@ void gemm_kernel(const GemmParams P) {
         kt0 = split * per;
         nk = min(nk, kt0 + per);
     }
-    if (kt0 < nk) dma_issue(kt0, kt0 & 1);
+    // ring: tile kt lives in stage (kt - kt0) % STAGES; tiles kt+1 .. kt+STAGES-1 stream in under compute(kt)
+#pragma unroll
+    for (int s0 = 0; s0 < STAGES - 1; ++s0)
+        if (kt0 + s0 < nk) dma_issue(kt0 + s0, s0);
+    int st_cur = 0, st_free = STAGES - 1;            // stage of tile kt, stage that tile kt+STAGES-1 will use
     for (int kt = kt0; kt < nk; ++kt) {
-        // my pieces of tile kt have landed; after the barrier everybody's have, and everybody has finished reading
-        // the other stage (compute kt-1), so tile kt+1 may start streaming into it
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // my pieces of tile kt have landed (the younger STAGES-2 tiles may still be in flight); after the barrier
+        // everybody's have, and everybody has finished reading the stage of tile kt-1, which is the one tile
+        // kt+STAGES-1 streams into
+        {
+            const int younger = min(STAGES - 2, nk - 1 - kt);
+            if (STAGES >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+            else if (STAGES >= 3 && younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
-        if (kt + 1 < nk) dma_issue(kt + 1, (kt + 1) & 1);
-        const bf16_t* As = smem + (kt & 1) * STAGE_ELEMS;
+        if (kt + STAGES - 1 < nk) dma_issue(kt + STAGES - 1, st_free);
+        const bf16_t* As = smem + st_cur * STAGE_ELEMS;
+        st_free = st_cur;
+        st_cur = st_cur + 1 == STAGES ? 0 : st_cur + 1;
         const bf16_t* Ws = As + BM * BK;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
@@ -297,7 +320,7 @@ void gemm_kernel(const GemmParams P) {
     }
 }
 
-int gemm_geometry_override() {   // FMC_GEMM_TILE = 0 (caller's choice) | 1..3: 128x128, 256x128, 256x256 at BK 64 | 4..6: same at BK 32
+int gemm_geometry_override() {   // FMC_GEMM_TILE = 0 (caller's choice) | 1..10: see fmc_hip.h
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("FMC_GEMM_TILE");
@@ -338,27 +361,30 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams P) 
     Vec8<bf16_t>::store(P.out + m * P.ldo + n, v);
 }
 
-template <int MODE, int EPI, int WM, int WN, int BK>
+template <int MODE, int EPI, int WM, int WN, int BK, int STAGES>
 void launch_gemm_g(GemmParams& P, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     P.tiles_m = (int)((P.M + BM - 1) / BM);
     P.tiles_n = (P.N + BN - 1) / BN;
-    size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16_t);
+    size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(bf16_t);
     const size_t slab = (size_t)64 * (BN + 8) * sizeof(float);
     if (slab > lds) lds = slab;
     static bool raised = false;
     if (!raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, EPI, WM, WN, BK>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, EPI, WM, WN, BK, STAGES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         raised = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<MODE, EPI, WM, WN, BK>), dim3(P.tiles_m * P.tiles_n * P.split_k), dim3(64 * WM * WN),
-                       lds, st, P);
+    hipLaunchKernelGGL((gemm_kernel<MODE, EPI, WM, WN, BK, STAGES>), dim3(P.tiles_m * P.tiles_n * P.split_k),
+                       dim3(64 * WM * WN), lds, st, P);
     if (P.split_k > 1) {
         const int64_t chunks = P.M * (P.N / 8);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, P);
     }
 }
+
+// tile arms (fmc_hip.h): geometry x k-tile depth x ring depth
+constexpr int GEMM_TILE_MAX = 10;
 
 // geometry: the largest tile that still gives every CU work and does not waste more than ~20 % of N
 template <int MODE, int EPI>
@@ -373,12 +399,16 @@ void launch_gemm(GemmParams& P, int tile, hipStream_t st) {
         else g = 1;
     }
     switch (g) {
-        case 6: launch_gemm_g<MODE, EPI, 4, 4, 32>(P, st); break;
-        case 5: launch_gemm_g<MODE, EPI, 4, 2, 32>(P, st); break;
-        case 4: launch_gemm_g<MODE, EPI, 2, 2, 32>(P, st); break;
-        case 3: launch_gemm_g<MODE, EPI, 4, 4, 64>(P, st); break;
-        case 2: launch_gemm_g<MODE, EPI, 4, 2, 64>(P, st); break;
-        default: launch_gemm_g<MODE, EPI, 2, 2, 64>(P, st); break;
+        case 10: launch_gemm_g<MODE, EPI, 4, 2, 32, 4>(P, st); break;
+        case 9: launch_gemm_g<MODE, EPI, 2, 2, 32, 4>(P, st); break;
+        case 8: launch_gemm_g<MODE, EPI, 4, 4, 32, 4>(P, st); break;
+        case 7: launch_gemm_g<MODE, EPI, 4, 2, 64, 3>(P, st); break;
+        case 6: launch_gemm_g<MODE, EPI, 4, 4, 32, 2>(P, st); break;
+        case 5: launch_gemm_g<MODE, EPI, 4, 2, 32, 2>(P, st); break;
+        case 4: launch_gemm_g<MODE, EPI, 2, 2, 32, 2>(P, st); break;
+        case 3: launch_gemm_g<MODE, EPI, 4, 4, 64, 2>(P, st); break;
+        case 2: launch_gemm_g<MODE, EPI, 4, 2, 64, 2>(P, st); break;
+        default: launch_gemm_g<MODE, EPI, 2, 2, 64, 2>(P, st); break;
     }
 }
 
@@ -414,7 +444,7 @@ extern "C" int fmc_linear_bf16(const void* x, const void* w, const void* bias, c
     P.M = M; P.N = N; P.K = K; P.lda = ldx; P.ldres = ldres; P.ldo = ldo;
     P.img_h = P.img_w = P.cin = 0; P.hw = 1; P.alpha = alpha;
     hipStream_t st = (hipStream_t)stream;
-    if (tile < 0 || tile > 6) FMC_FAIL(FMC_E_SHAPE, "linear_bf16: tile %d", tile);
+    if (tile < 0 || tile > GEMM_TILE_MAX) FMC_FAIL(FMC_E_SHAPE, "linear_bf16: tile %d", tile);
     if (int rc = set_split_k(P, split_k, workspace, workspace_bytes, epilogue == 0, "linear_bf16")) return rc;
     if (epilogue == 0) launch_gemm<0, 0>(P, tile, st); else launch_gemm<0, 1>(P, tile, st);
     FMC_CHECK_LAUNCH("fmc_linear_bf16");
@@ -435,7 +465,7 @@ extern "C" int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, 
     P.res = (const bf16_t*)residual; P.out = (bf16_t*)out;
     P.M = (int64_t)n_img * H * W; P.N = Cout; P.K = 9 * Cin; P.lda = Cin; P.ldres = Cout; P.ldo = Cout;
     P.img_h = H; P.img_w = W; P.cin = Cin; P.hw = H * W; P.alpha = 1.f;
-    if (tile < 0 || tile > 6) FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: tile %d", tile);
+    if (tile < 0 || tile > GEMM_TILE_MAX) FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: tile %d", tile);
     if (int rc = set_split_k(P, split_k, workspace, workspace_bytes, true, "conv3x3_bf16")) return rc;
     launch_gemm<1, 0>(P, tile, (hipStream_t)stream);
     FMC_CHECK_LAUNCH("fmc_conv3x3_bf16");

@@ -450,8 +450,8 @@ def cfg_ddim_step(eps: torch.Tensor, x: torch.Tensor, guidance: float, alpha_t: 
 # --------------------------------------------------------------------------------------------
 def _decode_arm(tile: int, split_k: int):
     """autotune arm id -> (tile geometry 0..6, split_k)"""
-    if tile >= 8:
-        return tile & 7, 1 << (tile >> 3)
+    if tile >= 16:
+        return tile & 15, 1 << (tile >> 4)
     return tile, split_k
 
 
@@ -467,9 +467,9 @@ def split_arms(M: int, N: int, Kd: int):
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if tiles > 320 or Kd < 1024:
         return ()
-    arms = [t + 8 * si for si in (1, 2) for t in (1, 2, 4)]
+    arms = [t + 16 * si for si in (1, 2) for t in (1, 2, 9)]
     if tiles <= 128 and Kd >= 4096:
-        arms += [1 + 8 * 3, 4 + 8 * 3]
+        arms += [1 + 16 * 3, 9 + 16 * 3]
     return tuple(arms)
 
 
@@ -492,7 +492,7 @@ def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
                 tile: int = 0, split_k: int = 1) -> torch.Tensor:
     """`alpha * (x @ weight^T + bias) + residual` (or the GEGLU gate, see fmc_linear_bf16) on the bf16 MFMA kernel.
     x `[..., K]`, weight `[N, K]`; residual has the output's shape.  `tile` may also be an autotune arm id
-    (`tile + 8 * log2(split_k)`)."""
+    (`tile + 16 * log2(split_k)`)."""
     tile, split_k = _decode_arm(tile, split_k)
     _dev(x, weight, bias, residual)
     N, Kd = weight.shape
@@ -548,7 +548,7 @@ _choice = {}
 _tune_log = {}      # key -> {arm: ms} measured when the choice was made
 _calls = {}         # key -> eager calls seen (graph replays do not pass through Python)
 AUTOTUNE = True
-GEMM_TILES = (1, 2, 3, 4, 5, 6)     # fmc_linear_bf16 / fmc_conv3x3_bf16 `tile` arms tried per shape
+GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10)     # fmc_linear_bf16 / fmc_conv3x3_bf16 `tile` arms tried per shape
 
 
 def autotune_report():

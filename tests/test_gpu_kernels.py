@@ -318,9 +318,9 @@ def test_linear_bf16_fused_epilogue(K, M, N, Kd, bias, res, alpha):
     assert torch.equal(out2, out)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_gemm_tile_geometries_agree(K, tile):
-    """every `tile` arm (3 geometries x k-tile depth 64 / 32) must compute the same function, ragged edges included"""
+    """every `tile` arm (3 geometries x k-tile depth 64 / 32 x ring depth 2..4) must compute the same function, ragged edges included"""
     dtype = torch.bfloat16
     xo, xd = rnd((777, 320), 67, dtype)
     wo, wd = rnd((328, 320), 68, dtype, scale=320 ** -0.5)
@@ -345,7 +345,7 @@ def test_gemm_tile_geometries_agree(K, tile):
 
 
 @pytest.mark.parametrize("split_k", [2, 4, 8])
-@pytest.mark.parametrize("tile", [1, 2, 4])
+@pytest.mark.parametrize("tile", [1, 2, 9])
 def test_gemm_split_k(K, tile, split_k):
     """split-K arms: fp32 partial sums in a workspace + a fixed-order reduce; ragged k-tile division included"""
     dtype = torch.bfloat16
@@ -357,7 +357,7 @@ def test_gemm_split_k(K, tile, split_k):
     out = K.linear_bf16(xd, wd, bd, rd, 0.5, tile=tile, split_k=split_k)
     assert rel_inf(out.float(), ref) < 1e-2
     assert torch.equal(out, K.linear_bf16(xd, wd, bd, rd, 0.5, tile=tile, split_k=split_k))   # deterministic
-    assert torch.equal(out, K.linear_bf16(xd, wd, bd, rd, 0.5, tile=tile + 8 * {2: 1, 4: 2, 8: 3}[split_k]))  # arm id
+    assert torch.equal(out, K.linear_bf16(xd, wd, bd, rd, 0.5, tile=tile + 16 * {2: 1, 4: 2, 8: 3}[split_k]))  # arm id
     co, cd = rnd((2, 256, 5, 8), 54, dtype)
     fo, fd = rnd((136, 256, 3, 3), 55, dtype, scale=(9 * 256) ** -0.5)
     to, td = rnd((2, 136), 49, dtype)

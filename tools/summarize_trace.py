@@ -24,7 +24,13 @@ def main(path, nsteps=4):
     print(f"window: {nsteps} steps, {(t1 - t0) / 1e6 / nsteps:.3f} ms/step wall, {busy / 1e6 / nsteps:.3f} ms/step kernel-busy\n")
     cat = collections.defaultdict(float)
     for k, (d, c) in agg.items():
-        if "igemm" in k or "conv" in k.lower():
+        if "gemm_kernel<1" in k:
+            cat["conv3x3 (fmc gemm_kernel)"] += d
+        elif "gemm_kernel<0" in k:
+            cat["linear (fmc gemm_kernel)"] += d
+        elif "splitk_reduce" in k:
+            cat["split-K reduce (fmc)"] += d
+        elif "igemm" in k or "conv" in k.lower():
             cat["conv (MIOpen)"] += d
         elif k.startswith("Cijk") or "Custom_Cijk" in k:
             cat["gemm (hipBLASLt)"] += d
