@@ -207,9 +207,10 @@ void gemm_kernel(const GemmParams P) {
         st_free = st_cur;
         st_cur = st_cur + 1 == STAGES ? 0 : st_cur + 1;
         const bf16_t* Ws = As + BM * BK;
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 wf[2], af[2];
+        // fragments are double-buffered in registers: the ds_read_b128s of k-step ks+1 are issued before the MFMAs
+        // of k-step ks (sched_barrier pins that order; left alone the compiler re-uses one register set and every
+        // k-step eats its own LDS latency)
+        auto load_frags = [&](int ks, bf16x8 (&wf)[2], bf16x8 (&af)[2]) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int rw = wn * 64 + i * 32 + l31;
@@ -220,11 +221,19 @@ void gemm_kernel(const GemmParams P) {
                 wf[i] = tw.v;
                 af[i] = ta.v;
             }
+        };
+        bf16x8 wf[2][2], af[2][2];
+        load_frags(0, wf[0], af[0]);
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            if (ks + 1 < BK / 16) load_frags(ks + 1, wf[(ks + 1) & 1], af[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][ni], af[ks & 1][mi], acc[ni][mi], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
