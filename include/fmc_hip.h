@@ -179,6 +179,12 @@ int fmc_cfg_ddim_step(const void* eps_uc, const float* x, float* x_out, int64_t 
  *   split_k > 1 (epilogue 0 only): the k-tiles of every output tile are dealt to split_k workgroups that write fp32
  *   partial sums to `workspace` (>= split_k * M * N * 4 bytes, 16-byte aligned, caller-owned scratch); a second kernel
  *   sums them in a fixed order and applies the epilogue.  For M*N too small to fill 256 CUs (the 5x8 level).
+ *   split_k == -1: stream-K.  One persistent workgroup per CU slot; the (tile, k-tile) iteration space is cut into equal
+ *   contiguous ranges so every CU does the same number of k-tiles whatever tiles / CUs is; a tile cut by a range
+ *   boundary is finished by the workgroup holding its first k-tiles, the others hand over fp32 partials through the
+ *   workspace (sc1 accesses + flags, no fences; deterministic summation order).  `workspace` = [4096 bytes of flags,
+ *   ZERO on entry and handed back zero | >= workgroups * tile_rows * tile_cols * 4 bytes]; too small a problem or
+ *   workspace silently runs the plain grid.  Both epilogues.
  * ------------------------------------------------------------------------------------------- */
 int fmc_linear_bf16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int N,
                     int K, int64_t ldx, int64_t ldres, int64_t ldo, float alpha, int epilogue, int tile, int split_k,

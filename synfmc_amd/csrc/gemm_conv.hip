@@ -31,6 +31,8 @@
 // Algorithmic flops per launch = 2*M*N*K.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -46,6 +48,9 @@ struct GemmParams {
     int tiles_m, tiles_n;
     int split_k;                      // > 1: k-tiles are dealt to split_k workgroups per output tile, which write fp32
     float* ws;                        //      partial sums to ws[split][M][N]; splitk_reduce_kernel applies the epilogue
+    int sk;                           // stream-K: grid = sk persistent workgroups (a multiple of 8), each owning a
+    int* sk_flags;                    //   contiguous range of (tile, k-tile) iterations; ws[block][BM][BN] partials
+    int64_t sk_ws_bytes;
 };
 
 __device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.f + erff(g * 0.70710678118654752f)); }
@@ -65,6 +70,14 @@ __device__ __forceinline__ void dma16(const bf16_t* gsrc, bf16_t* lds_base_wave_
                                      (__attribute__((address_space(3))) void*)lds_base_wave_uniform, 16, 0, 0);
 }
 
+// stream-K hand-off payload: 16-byte buffer accesses with sc0 sc1 (write-through / cache-bypassing, coherent across the
+// 8 XCD L2s) -- no release / acquire fence, which on gfx950 means a whole-L2 write-back / invalidate per workgroup
+// (measured: the fenced version ran 2-3x slower than the plain grid)
+constexpr int SK_SC = 17;                                // cache-policy bits: sc0 | sc1
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sk_rsrc(float* ws) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)ws, 0, 0x7fffffff, 0x00020000);
+}
+
 // MODE 0: token GEMM, 1: implicit 3x3 conv.  EPI 0: alpha*(acc+bias) (+temb)(+residual); 1: GEGLU (weights
 // pre-interleaved per 128 rows: 64 value rows then their 64 gate rows; out is [M, N/2]).
 //
@@ -82,7 +95,7 @@ template <int WM, int WN, int BK, int STAGES> constexpr int gemm_min_waves() {
     return w > 4 ? 4 : (w < 1 ? 1 : w);
 }
 
-template <int MODE, int EPI, int WM, int WN, int BK, int STAGES>
+template <int MODE, int EPI, int WM, int WN, int BK, int STAGES, bool SK>
 __global__ __launch_bounds__(64 * WM * WN, (gemm_min_waves<WM, WN, BK, STAGES>()))
 void gemm_kernel(const GemmParams P) {
     constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN, NT = 64 * NW;
@@ -99,9 +112,50 @@ void gemm_kernel(const GemmParams P) {
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, half = lane >> 5;
 
-    // ---- tile order: XCD aware (blockIdx % 8 = XCD): n-tiles of one m-tile stay on one XCD --------------------
-    int tile_m, tile_n;
-    {
+    // ---- work assignment ---------------------------------------------------------------------------------------
+    // plain / split-K: one output tile per workgroup, XCD aware (blockIdx % 8 = XCD): the n-tiles of one m-tile stay on
+    // one XCD.  stream-K (P.sk persistent workgroups, one per CU slot): the tiles are dealt to the 8 XCD groups at tile
+    // granularity; inside a group the (tile, k-tile) iteration space is cut into equal contiguous ranges, one per
+    // workgroup, so every CU does the same number of k-tiles whatever tiles/256 is.  A tile cut by a range boundary is
+    // finished by the workgroup that holds its FIRST k-tiles (it reaches them at the END of its range, when the others
+    // -- who meet their share of that tile at the START of theirs -- are long done): they leave fp32 partials in
+    // ws[block] and raise sk_flags[block]; ranges are handed out in reverse block order, so a workgroup only ever
+    // waits for lower block ids.
+    const int nkt = P.K / BK;
+    int64_t sk_it = 0, sk_end = 0, sk_gbase = 0, sk_I = 0;
+    int sk_r = 0, sk_per = 1;
+    if (SK) {
+        const int T = P.tiles_m * P.tiles_n, x = blockIdx.x & 7, q = blockIdx.x >> 3;
+        sk_per = P.sk >> 3;
+        const int tg0 = (int)((int64_t)T * x / 8), tg1 = (int)((int64_t)T * (x + 1) / 8);
+        sk_gbase = (int64_t)tg0 * nkt;
+        sk_I = (int64_t)(tg1 - tg0) * nkt;
+        sk_r = sk_per - 1 - q;
+        sk_it = sk_gbase + sk_I * sk_r / sk_per;
+        sk_end = sk_gbase + sk_I * (sk_r + 1) / sk_per;
+    }
+    for (;;) {                                           // one pass per segment (exactly one without stream-K)
+    int tile_m, tile_n, kt0 = 0, nk = nkt;
+    int sk_np = 0;                                       // stream-K owner: partials to add (from blocks id - 8, - 16, ..)
+    bool sk_partial = false;                             // stream-K: this segment leaves a partial instead of output
+    if (SK) {
+        if (sk_it >= sk_end) break;
+        const int lin = (int)(sk_it / nkt);
+        kt0 = (int)(sk_it - (int64_t)lin * nkt);
+        nk = (int)min((int64_t)nkt, kt0 + (sk_end - sk_it));
+        sk_it += nk - kt0;
+        tile_m = lin / P.tiles_n;
+        tile_n = lin - tile_m * P.tiles_n;
+        sk_partial = kt0 > 0;
+        if (kt0 == 0 && nk < nkt) {                      // I hold the head of a cut tile: who holds the rest?
+            const int64_t tile_end = (int64_t)(lin + 1) * nkt;
+            int64_t e = sk_end;
+            while (e < tile_end) {
+                ++sk_np;
+                e = sk_gbase + sk_I * (sk_r + 1 + sk_np) / sk_per;
+            }
+        }
+    } else {
         const int total = P.tiles_m * P.tiles_n;
         int id = blockIdx.x;
         if (P.split_k > 1) id /= P.split_k;              // the splits of one tile are neighbours in launch order
@@ -179,7 +233,6 @@ void gemm_kernel(const GemmParams P) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    int kt0 = 0, nk = P.K / BK;
     const int split = P.split_k > 1 ? (int)(blockIdx.x % P.split_k) : 0;
     if (P.split_k > 1) {
         const int per = (nk + P.split_k - 1) / P.split_k;
@@ -237,6 +290,19 @@ void gemm_kernel(const GemmParams P) {
         }
     }
 
+    if (SK && sk_np > 0 && tid == 0) {
+        // stream-K owner: the other shares of this tile were produced at the START of their workgroups' ranges.  Flag and
+        // payload are sc1 (agent-scope) accesses, so no cache-wide acquire is needed; the __syncthreads() at the top of
+        // the slab loop orders the payload reads of the workgroup after this wait.  The spin is bounded: a bug must not
+        // hang the GPU.
+        for (int j = 1; j <= sk_np; ++j) {
+            const int* f = P.sk_flags + (blockIdx.x - 8 * j);
+            int spins = 0;
+            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 22))
+                __builtin_amdgcn_s_sleep(8);
+        }
+    }
+
     // ---- epilogue: fp32 C slabs of 64 rows through LDS, bias / alpha / temb / residual / GEGLU on the way out ----------
     float* Cs = reinterpret_cast<float*>(smem_raw);             // [64][CP] fp32
 #pragma unroll 1
@@ -256,7 +322,33 @@ void gemm_kernel(const GemmParams P) {
                     }
         }
         __syncthreads();
-        if (EPI == 0 && P.split_k > 1) {                 // raw fp32 partial sums; epilogue in splitk_reduce_kernel
+        if (SK && sk_np > 0) {                           // stream-K owner: fold the other shares of this tile into the slab
+            constexpr int C4 = BN / 4;
+            const __amdgpu_buffer_rsrc_t rs = sk_rsrc(P.ws);
+#pragma unroll
+            for (int c = tid; c < 64 * C4; c += NT) {
+                const int r = c / C4, c4 = c - r * C4;
+                f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CP + c4 * 4);
+                for (int j = 1; j <= sk_np; ++j) {
+                    union { u32x4 u; f32x4 f; } t;
+                    t.u = __builtin_amdgcn_raw_buffer_load_b128(
+                        rs, (int)((((int64_t)(blockIdx.x - 8 * j) * BM + hm * 64 + r) * BN + c4 * 4) * 4), 0, SK_SC);
+                    v += t.f;
+                }
+                *reinterpret_cast<f32x4*>(Cs + r * CP + c4 * 4) = v;
+            }
+            __syncthreads();
+        }
+        if (SK && sk_partial) {                          // stream-K: tile-local fp32 partial in my slot
+            constexpr int C4 = BN / 4;                   // 16-byte chunks per row; consecutive lanes = consecutive chunks
+            const __amdgpu_buffer_rsrc_t rs = sk_rsrc(P.ws);
+#pragma unroll
+            for (int c = tid; c < 64 * C4; c += NT) {
+                const int r = c / C4, c4 = c - r * C4;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(Cs + r * CP + c4 * 4);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)((((int64_t)blockIdx.x * BM + hm * 64 + r) * BN + c4 * 4) * 4), 0, SK_SC);
+            }
+        } else if (EPI == 0 && P.split_k > 1) {          // raw fp32 partial sums; epilogue in splitk_reduce_kernel
             constexpr int CPR = BN / 8;
             constexpr int RSTEP = NT / CPR;
             const int ch = tid % CPR, n = n0 + ch * 8;
@@ -327,6 +419,31 @@ void gemm_kernel(const GemmParams P) {
             }
         }
     }
+    if (!SK) break;
+    if (sk_partial) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my sc1 payload stores have completed ...
+        __syncthreads();
+        if (tid == 0)                                    // ... everybody's have: raise the flag
+            __hip_atomic_store(P.sk_flags + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (sk_np > 0) {
+        __syncthreads();                                 // everybody has read the partials: hand the flags back as zeros
+        if (tid == 0)
+            for (int j = 1; j <= sk_np; ++j)
+                __hip_atomic_store(P.sk_flags + (blockIdx.x - 8 * j), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                                     // the C slab aliases the operand stages of the next segment
+    }  // segment loop
+}
+
+int fmc_cu_count() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
 }
 
 int gemm_geometry_override() {   // FMC_GEMM_TILE = 0 (caller's choice) | 1..10: see fmc_hip.h
@@ -370,6 +487,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams P) 
     Vec8<bf16_t>::store(P.out + m * P.ldo + n, v);
 }
 
+template <int MODE, int EPI, int WM, int WN, int BK, int STAGES, bool SK>
+void launch_gemm_k(GemmParams& P, unsigned grid, size_t lds, hipStream_t st) {
+    static bool raised = false;
+    if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, EPI, WM, WN, BK, STAGES, SK>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        raised = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel<MODE, EPI, WM, WN, BK, STAGES, SK>), dim3(grid), dim3(64 * WM * WN), lds, st, P);
+}
+
 template <int MODE, int EPI, int WM, int WN, int BK, int STAGES>
 void launch_gemm_g(GemmParams& P, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
@@ -378,14 +506,29 @@ void launch_gemm_g(GemmParams& P, hipStream_t st) {
     size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(bf16_t);
     const size_t slab = (size_t)64 * (BN + 8) * sizeof(float);
     if (slab > lds) lds = slab;
-    static bool raised = false;
-    if (!raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, EPI, WM, WN, BK, STAGES>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        raised = true;
+    unsigned grid = (unsigned)(P.tiles_m * P.tiles_n * P.split_k);
+    if (P.sk) {
+        // persistent grid: exactly the workgroups that are co-resident (LDS / wave-slot limited), a multiple of 8
+        constexpr int by_waves = 16 / (WM * WN) > 0 ? 16 / (WM * WN) : 1;
+        const int by_lds = (int)(160 * 1024 / lds);
+        const int per_cu = by_lds < by_waves ? (by_lds < 1 ? 1 : by_lds) : by_waves;
+        const int64_t iters = (int64_t)P.tiles_m * P.tiles_n * (P.K / BK);
+        const int g = (fmc_cu_count() * per_cu) & ~7;
+        const int64_t need = (int64_t)g * BM * BN * (int64_t)sizeof(float) + 4096;
+        if (STAGES != 2 || g < 8 || iters < 4 * (int64_t)g || P.sk_ws_bytes < need || g * (int)sizeof(int) > 4096) {
+            P.sk = 0;                                    // too little work (or workspace): the plain grid
+        } else {
+            P.sk = g;
+            grid = (unsigned)g;
+        }
     }
-    hipLaunchKernelGGL((gemm_kernel<MODE, EPI, WM, WN, BK, STAGES>), dim3(P.tiles_m * P.tiles_n * P.split_k),
-                       dim3(64 * WM * WN), lds, st, P);
+    if constexpr (STAGES == 2) {
+        if (P.sk) {
+            launch_gemm_k<MODE, EPI, WM, WN, BK, STAGES, true>(P, grid, lds, st);
+            return;
+        }
+    }
+    launch_gemm_k<MODE, EPI, WM, WN, BK, STAGES, false>(P, grid, lds, st);
     if (P.split_k > 1) {
         const int64_t chunks = P.M * (P.N / 8);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, P);
@@ -424,6 +567,18 @@ void launch_gemm(GemmParams& P, int tile, hipStream_t st) {
 int set_split_k(GemmParams& P, int split_k, void* workspace, int64_t workspace_bytes, bool plain_epilogue, const char* who) {
     P.split_k = 1;
     P.ws = nullptr;
+    P.sk = 0;
+    P.sk_flags = nullptr;
+    P.sk_ws_bytes = 0;
+    if (split_k == -1) {                                 // stream-K: [4096 B of flags (zero on entry and on return) | partials]
+        if (!workspace || !fmc_aligned16(workspace) || workspace_bytes < 8192)
+            FMC_FAIL(FMC_E_NULL, "%s: stream-K needs a 16-byte aligned, zero-initialised workspace", who);
+        P.sk = 1;
+        P.sk_flags = (int*)workspace;
+        P.ws = (float*)((char*)workspace + 4096);
+        P.sk_ws_bytes = workspace_bytes;
+        return 0;
+    }
     if (split_k <= 1) return 0;
     if (split_k > 16 || !plain_epilogue) FMC_FAIL(FMC_E_SHAPE, "%s: split_k %d (1..16, not with the GEGLU epilogue)", who, split_k);
     if (!workspace || !fmc_aligned16(workspace)) FMC_FAIL(FMC_E_NULL, "%s: split_k needs a 16-byte aligned workspace", who);

@@ -450,12 +450,28 @@ def cfg_ddim_step(eps: torch.Tensor, x: torch.Tensor, guidance: float, alpha_t: 
 # --------------------------------------------------------------------------------------------
 def _decode_arm(tile: int, split_k: int):
     """autotune arm id -> (tile geometry 0..6, split_k)"""
+    if tile >= 128:
+        return tile - 128, -1                           # stream-K
     if tile >= 16:
         return tile & 15, 1 << (tile >> 4)
     return tile, split_k
 
 
+_sk_ws = {}
+
+
+def _streamk_workspace(device):
+    """[4 KiB of flags | fp32 partial tiles] for the stream-K arms: zero on first use, handed back zeroed by the kernel"""
+    ws = _sk_ws.get(device.index)
+    if ws is None:
+        ws = torch.zeros((4096 + 1024 * 256 * 256 * 4) // 4, dtype=torch.float32, device=device)
+        _sk_ws[device.index] = ws
+    return ws.data_ptr(), ws.numel() * 4
+
+
 def _splitk_workspace(device, split_k: int, M: int, N: int):
+    if split_k == -1:
+        return _streamk_workspace(device)
     if split_k <= 1:
         return None, 0
     nbytes = split_k * M * N * 4
@@ -548,7 +564,8 @@ _choice = {}
 _tune_log = {}      # key -> {arm: ms} measured when the choice was made
 _calls = {}         # key -> eager calls seen (graph replays do not pass through Python)
 AUTOTUNE = True
-GEMM_TILES = (1, 2, 3, 4, 5, 6, 7)      # 8..10 (4-stage rings) exist but never won on the FMC shapes     # fmc_linear_bf16 / fmc_conv3x3_bf16 `tile` arms tried per shape
+GEMM_TILES = (1, 2, 3, 4, 5, 6, 7,     # 8..10 (4-stage rings) exist but never won on the FMC shapes
+              128 + 2, 128 + 3)                 # stream-K (persistent workgroups) on the two 1-per-CU geometries     # fmc_linear_bf16 / fmc_conv3x3_bf16 `tile` arms tried per shape
 
 
 def autotune_report():

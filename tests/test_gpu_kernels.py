@@ -368,6 +368,42 @@ def test_gemm_split_k(K, tile, split_k):
     assert rel_inf(outc.permute(0, 3, 1, 2).float(), refc) < 1e-2
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+def test_gemm_stream_k(K, tile):
+    """stream-K arms (persistent workgroups, tiles cut at range boundaries, fp32 partials handed over through flags):
+    ragged M / N, conv and GEGLU epilogues, and -- because the partial slots and flags are reused by every launch and
+    per-XCD L2s are not coherent -- many back-to-back launches on fresh data"""
+    dtype = torch.bfloat16
+    M, N, Kd = 4100, 1032, 1280
+    wo, wd = rnd((N, Kd), 45, dtype, scale=Kd ** -0.5)
+    bo, bd = rnd((N,), 46, dtype)
+    for it in range(12):
+        xo, xd = rnd((M, Kd), 200 + it, dtype)
+        ro, rd = rnd((M, N), 300 + it, dtype)
+        want = K.linear_bf16(xd, wd, bd, rd, 1.0, tile=tile)
+        got = K.linear_bf16(xd, wd, bd, rd, 1.0, tile=128 + tile)
+        assert rel_inf(got.float(), want.float()) < 4e-3, it                     # same products, other summation order
+        if it == 0:
+            assert rel_inf(got.float(), F.linear(xo, wo, bo) + ro) < 1e-2
+            assert torch.equal(got, K.linear_bf16(xd, wd, bd, rd, 1.0, tile=128 + tile))   # deterministic
+    co, cd = rnd((4, 320, 36, 30), 47, dtype)
+    fo, fd = rnd((328, 320, 3, 3), 44, dtype, scale=(9 * 320) ** -0.5)
+    to, td = rnd((4, 328), 43, dtype)
+    refc = F.conv2d(co, fo, None, 1, 1) + to[:, :, None, None]
+    outc = K.conv3x3_bf16(cd.permute(0, 2, 3, 1).contiguous(), fd.contiguous(memory_format=torch.channels_last), None,
+                          td, None, tile=128 + tile)
+    assert rel_inf(outc.permute(0, 3, 1, 2).float(), refc) < 1e-2
+    from synfmc_amd.models.layers import interleave_geglu
+    go, gd = rnd((2048, Kd), 42, dtype, scale=Kd ** -0.5)
+    xo, xd = rnd((M, Kd), 41, dtype)
+    wi, bi = interleave_geglu(gd, None)
+    a, g = F.linear(xo, go).chunk(2, dim=-1)
+    outg = K.linear_bf16(xd, wi, bi, geglu=True, tile=128 + tile)
+    assert rel_inf(outg.float(), a * F.gelu(g)) < 1e-2
+    ws = K._sk_ws[torch.cuda.current_device()]
+    assert int(ws[:1024].view(torch.int32).abs().sum()) == 0                      # flags handed back as zeros
+
+
 def test_linear_bf16_geglu(K):
     dtype = torch.bfloat16
     M, C, Cff = 513, 320, 1280
