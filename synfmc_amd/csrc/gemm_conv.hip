@@ -44,6 +44,7 @@ struct GemmParams {
     int64_t M; int N, K;
     int64_t lda, ldres, ldo;
     int img_h, img_w, cin, hw;        // conv mode
+    int64_t temb_ld; int temb_div;    // temb row of image i = temb + (i / temb_div) * temb_ld
     float alpha;
     int tiles_m, tiles_n;
     int split_k;                      // > 1: k-tiles are dealt to split_k workgroups per output tile, which write fp32
@@ -53,7 +54,19 @@ struct GemmParams {
     int64_t sk_ws_bytes;
 };
 
-__device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.f + erff(g * 0.70710678118654752f)); }
+// exact-erf GELU for a bf16 result: erf by Abramowitz & Stegun 7.1.26 (|error| < 1.5e-7, far below bf16's 2^-9) with the
+// hardware reciprocal and exp2 -- libdevice's erff costs ~3x as many VALU slots, and the level-0 GEGLU projection
+// evaluates 105 M of them per launch
+__device__ __forceinline__ float gelu_erf(float g) {
+    const float x = fabsf(g) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = 1.f - p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);   // erf(|g|/sqrt 2)
+    return 0.5f * g + 0.5f * fabsf(g) * e;                                                 // g/2 (1 + sign(g) erf)
+}
 
 // physical 16-byte chunk of logical chunk c in tile row r: 8 chunks per 128-byte row (BK = 64) or 4 per 64-byte row
 // (BK = 32); both make the ds_read_b128 lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} bank-conflict free
@@ -378,7 +391,7 @@ void gemm_kernel(const GemmParams P) {
                     for (int k = 0; k < 8; ++k) v[k] = (v[k] + bv[k]) * P.alpha;
                     if (MODE == 1 && P.temb) {
                         float t[8];
-                        Vec8<bf16_t>::load(P.temb + (m / P.hw) * P.N + n, t);
+                        Vec8<bf16_t>::load(P.temb + ((m / P.hw) / P.temb_div) * P.temb_ld + n, t);
 #pragma unroll
                         for (int k = 0; k < 8; ++k) v[k] += t[k];
                     }
@@ -474,7 +487,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams P) 
     for (int k = 0; k < 8; ++k) v[k] = (v[k] + (P.bias ? bf2f(P.bias[n + k]) : 0.f)) * P.alpha;
     if (P.temb) {
         float t[8];
-        Vec8<bf16_t>::load(P.temb + (m / P.hw) * P.N + n, t);
+        Vec8<bf16_t>::load(P.temb + ((m / P.hw) / P.temb_div) * P.temb_ld + n, t);
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] += t[k];
     }
@@ -606,7 +619,7 @@ extern "C" int fmc_linear_bf16(const void* x, const void* w, const void* bias, c
     P.a = (const bf16_t*)x; P.w = (const bf16_t*)w; P.bias = (const bf16_t*)bias; P.temb = nullptr;
     P.res = (const bf16_t*)residual; P.out = (bf16_t*)out;
     P.M = M; P.N = N; P.K = K; P.lda = ldx; P.ldres = ldres; P.ldo = ldo;
-    P.img_h = P.img_w = P.cin = 0; P.hw = 1; P.alpha = alpha;
+    P.img_h = P.img_w = P.cin = 0; P.hw = 1; P.alpha = alpha; P.temb_ld = 0; P.temb_div = 1;
     hipStream_t st = (hipStream_t)stream;
     if (tile < 0 || tile > GEMM_TILE_MAX) FMC_FAIL(FMC_E_SHAPE, "linear_bf16: tile %d", tile);
     if (int rc = set_split_k(P, split_k, workspace, workspace_bytes, epilogue == 0, "linear_bf16")) return rc;
@@ -616,7 +629,8 @@ extern "C" int fmc_linear_bf16(const void* x, const void* w, const void* bias, c
 }
 
 extern "C" int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, const void* temb, const void* residual,
-                                void* out, int n_img, int H, int W, int Cin, int Cout, int tile, int split_k,
+                                void* out, int n_img, int H, int W, int Cin, int Cout, int64_t temb_row_stride,
+                                int temb_img_div, int tile, int split_k,
                                 void* workspace, int64_t workspace_bytes, void* stream) {
     if (!x || !w || !out) FMC_FAIL(FMC_E_NULL, "conv3x3_bf16: NULL tensor");
     if (n_img <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % BK_MAX || Cout % 8)
@@ -629,6 +643,8 @@ extern "C" int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, 
     P.res = (const bf16_t*)residual; P.out = (bf16_t*)out;
     P.M = (int64_t)n_img * H * W; P.N = Cout; P.K = 9 * Cin; P.lda = Cin; P.ldres = Cout; P.ldo = Cout;
     P.img_h = H; P.img_w = W; P.cin = Cin; P.hw = H * W; P.alpha = 1.f;
+    if (temb && (temb_img_div < 1 || temb_row_stride % 8)) FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: temb_img_div >= 1, temb_row_stride %% 8 == 0");
+    P.temb_ld = temb_row_stride; P.temb_div = temb_img_div < 1 ? 1 : temb_img_div;
     if (tile < 0 || tile > GEMM_TILE_MAX) FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: tile %d", tile);
     if (int rc = set_split_k(P, split_k, workspace, workspace_bytes, true, "conv3x3_bf16")) return rc;
     launch_gemm<1, 0>(P, tile, (hipStream_t)stream);

@@ -535,20 +535,22 @@ def conv3x3_supported(x: torch.Tensor, weight: torch.Tensor, stride, padding) ->
 
 def conv3x3_bf16(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias: Optional[torch.Tensor] = None,
                  temb: Optional[torch.Tensor] = None, residual_nhwc: Optional[torch.Tensor] = None,
-                 tile: int = 0, split_k: int = 1) -> torch.Tensor:
+                 tile: int = 0, split_k: int = 1, temb_div: int = 1) -> torch.Tensor:
     """x `[N, H, W, Cin]` contiguous, weight `[Cout, Cin, 3, 3]` in channels_last memory format (physically
-    `[Cout, 3, 3, Cin]`), temb `[N, Cout]`, residual `[N, H, W, Cout]` -> `[N, H, W, Cout]`."""
+    `[Cout, 3, 3, Cin]`), temb `[N // temb_div, Cout]` (rows may be strided: a column slice of a wider matrix),
+    residual `[N, H, W, Cout]` -> `[N, H, W, Cout]`."""
     _dev(x_nhwc, weight_cl, bias, temb, residual_nhwc)
     n, h, w, cin = x_nhwc.shape
     cout = weight_cl.shape[0]
     assert x_nhwc.is_contiguous() and weight_cl.is_contiguous(memory_format=torch.channels_last)
-    assert temb is None or (temb.is_contiguous() and temb.shape == (n, cout))
+    assert temb is None or (temb.stride(1) == 1 and temb.shape == (n // temb_div, cout) and n % temb_div == 0)
     assert residual_nhwc is None or (residual_nhwc.is_contiguous() and residual_nhwc.shape == (n, h, w, cout))
     out = torch.empty(n, h, w, cout, dtype=x_nhwc.dtype, device=x_nhwc.device)
     tile, split_k = _decode_arm(tile, split_k)
     ws, ws_bytes = _splitk_workspace(x_nhwc.device, split_k, n * h * w, cout)
     _lib.check(_lib.load().fmc_conv3x3_bf16(x_nhwc.data_ptr(), weight_cl.data_ptr(), _p(bias), _p(temb),
-                                            _p(residual_nhwc), out.data_ptr(), n, h, w, cin, cout, int(tile),
+                                            _p(residual_nhwc), out.data_ptr(), n, h, w, cin, cout,
+                                            0 if temb is None else temb.stride(0), int(temb_div), int(tile),
                                             int(split_k), ws, ws_bytes, _stream()),
                "fmc_conv3x3_bf16")
     return out
@@ -593,12 +595,14 @@ def _time_ms(fn, reps=8):
                 fn()
         g.replay()
         _tune_stream.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        g.replay()
-        e1.record()
-        _tune_stream.synchronize()
-        ms = e0.elapsed_time(e1) / reps
+        ms = float("inf")
+        for _ in range(3):                              # min of 3: one noisy sample must not pick the arm
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            _tune_stream.synchronize()
+            ms = min(ms, e0.elapsed_time(e1) / reps)
         del g
     cur.wait_stream(_tune_stream)
     return ms
@@ -654,7 +658,7 @@ def geglu_linear(x: torch.Tensor, weight: torch.Tensor, bias, weight_il: torch.T
 
 
 def conv3x3(x_nchw: torch.Tensor, weight_cl: torch.Tensor, bias, temb=None, residual_nchw=None, stride=(1, 1),
-            padding=(1, 1)) -> torch.Tensor:
+            padding=(1, 1), temb_div: int = 1) -> torch.Tensor:
     """3x3 conv on a logical NCHW / physical channels-last tensor with `+ temb[:, :, None, None]` and `+ residual`.
     Returns a logical NCHW view over channels-last storage."""
     import torch.nn.functional as F
@@ -662,7 +666,7 @@ def conv3x3(x_nchw: torch.Tensor, weight_cl: torch.Tensor, bias, temb=None, resi
     def lib():
         y = F.conv2d(x_nchw, weight_cl, bias, stride, padding)
         if temb is not None:
-            y = y + temb[:, :, None, None]
+            y = y + (temb if temb_div == 1 else temb.repeat_interleave(temb_div, dim=0))[:, :, None, None]
         if residual_nchw is not None:
             y = y + residual_nchw
         return y
@@ -676,7 +680,7 @@ def conv3x3(x_nchw: torch.Tensor, weight_cl: torch.Tensor, bias, temb=None, resi
     if not x.is_contiguous() or (r is not None and not r.is_contiguous()):
         return lib()
     key = ("conv", n, h, w, cin, cout, temb is not None, r is not None)
-    hip = lambda tile: conv3x3_bf16(x, weight_cl, bias, temb, r, tile=tile).permute(0, 3, 1, 2)
+    hip = lambda tile: conv3x3_bf16(x, weight_cl, bias, temb, r, tile=tile, temb_div=temb_div).permute(0, 3, 1, 2)
     tiles = ((n * h * w + 127) // 128) * ((cout + 127) // 128)
     use = _pick(key, hip, lib, tiles >= 256, split_arms(n * h * w, cout, 9 * cin))
     return lib() if use == 0 else hip(max(use, 0))

@@ -78,9 +78,9 @@ class Conv2d(nn.Conv2d):
     """MIOpen conv on channels-last storage; 1x1 stride-1 convs run as a token GEMM (hipBLASLt)."""
 
     def forward(self, x: torch.Tensor, scale: float = 1.0, temb: Optional[torch.Tensor] = None,
-                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+                residual: Optional[torch.Tensor] = None, temb_div: int = 1) -> torch.Tensor:
         """conv(x) [+ temb[:, :, None, None]] [+ residual]; the two extras ride in the kernel epilogue when the
-        gfx950 implicit-GEMM conv / GEMM is used."""
+        gfx950 implicit-GEMM conv / GEMM is used.  `temb_div` > 1: image i uses temb row i // temb_div."""
         if self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0):
             n, c, h, w = x.shape
             assert temb is None
@@ -91,10 +91,10 @@ class Conv2d(nn.Conv2d):
             x = x.contiguous(memory_format=torch.channels_last)
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)
         if self.kernel_size == (3, 3) and self.dilation == (1, 1) and self.groups == 1 and x.is_cuda and not needs_grad:
-            return K.conv3x3(x, self._weight_cl(), self.bias, temb, residual, self.stride, self.padding)
+            return K.conv3x3(x, self._weight_cl(), self.bias, temb, residual, self.stride, self.padding, temb_div)
         y = F.conv2d(x, self._weight_cl(), self.bias, self.stride, self.padding, self.dilation, self.groups)
         if temb is not None:
-            y = y + temb[:, :, None, None]
+            y = y + (temb if temb_div == 1 else temb.repeat_interleave(temb_div, dim=0))[:, :, None, None]
         if residual is not None:
             y = y + residual
         return y
@@ -206,11 +206,16 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0) \
             if self.use_in_shortcut else None
 
+    # set by the U-Net for one forward (inference): (`[clips, Cout]` slice of the batched projection, frames per clip)
+    _t_pre = None
+
     def forward(self, input_tensor, temb, scale: float = 1.0):
-        t = None
-        if self.time_emb_proj is not None and temb is not None:
+        t, div = None, 1
+        if self._t_pre is not None:
+            t, div = self._t_pre
+        elif self.time_emb_proj is not None and temb is not None:
             t = self.time_emb_proj(F.silu(temb))                       # [N, Cout], rides in conv1's epilogue
-        h = self.conv1(self.norm1(input_tensor, act=True), temb=t)
+        h = self.conv1(self.norm1(input_tensor, act=True), temb=t, temb_div=div)
         if self.conv_shortcut is not None:
             input_tensor = self.conv_shortcut(input_tensor)
         out = self.conv2(self.norm2(h, act=True), residual=input_tensor)   # `input + h` rides in conv2's epilogue

@@ -22,6 +22,7 @@ from typing import Any, Dict, List, Optional, Tuple, Union
 
 import torch
 from torch import nn
+import torch.nn.functional as F
 
 from .attention_processor import (AttnProcessor, LORAPoseAdaptorAttnProcessor, LoRAAttnProcessor,
                                   PoseAdaptorAttnProcessor)
@@ -308,6 +309,48 @@ class UNet3DConditionModel(nn.Module):
         if self.config.center_input_sample:
             sample = 2 * sample - 1.0
         emb = self._time_embedding(sample, timestep)
+        self._project_time_embedding(emb, sample.shape[2])
+        try:
+            return self._run_blocks(sample, emb, encoder_hidden_states, attention_mask, cross_attention_kwargs,
+                                    pose_embedding_features, traj_features, use_pose, return_dict, upsample_size,
+                                    forward_upsample_size)
+        finally:
+            for r in self._resnets_with_temb():
+                r._t_pre = None
+
+    def _resnets_with_temb(self):
+        rs = getattr(self, "_temb_resnets", None)
+        if rs is None:
+            from .layers import ResnetBlock2D
+            rs = [m for m in self.modules() if isinstance(m, ResnetBlock2D) and m.time_emb_proj is not None]
+            object.__setattr__(self, "_temb_resnets", rs)
+        return rs
+
+    def _project_time_embedding(self, emb, frames):
+        """Inference only: `time_emb_proj(silu(emb))` of all 22 ResNet blocks (diffusers ResnetBlock2D.forward) as ONE
+        GEMM on the [clips, 1280] embedding; every block's conv1 epilogue then reads its column slice with
+        image -> clip indexing, so neither the per-block projections nor the per-frame repeats run."""
+        rs = self._resnets_with_temb()
+        if torch.is_grad_enabled() or not rs or not emb.is_cuda or emb.dtype != torch.bfloat16 \
+                or os.environ.get("FMC_NO_TEMB_BATCH"):
+            return
+        key = tuple((r.time_emb_proj.weight.data_ptr(), r.time_emb_proj.weight._version) for r in rs)
+        cache = getattr(self, "_temb_cat", None)
+        if cache is None or cache[0] != key:
+            w = torch.cat([r.time_emb_proj.weight.detach() for r in rs], 0).to(emb.dtype)
+            b = torch.cat([r.time_emb_proj.bias.detach() for r in rs], 0).to(emb.dtype)
+            cache = (key, w, b)
+            object.__setattr__(self, "_temb_cat", cache)
+        t_all = F.linear(F.silu(emb), cache[1], cache[2])               # [clips, sum Cout]
+        off = 0
+        for r in rs:
+            co = r.time_emb_proj.weight.shape[0]
+            r._t_pre = (t_all[:, off:off + co], frames)
+            off += co
+
+    def _run_blocks(self, sample, emb, encoder_hidden_states, attention_mask, cross_attention_kwargs,
+                    pose_embedding_features, traj_features, use_pose, return_dict, upsample_size,
+                    forward_upsample_size):
         if sample.dtype != self.dtype:
             sample = sample.to(self.dtype)
         if encoder_hidden_states.dtype != self.dtype:

@@ -142,7 +142,7 @@ class _DownBlock(_Block3D):
     def _down(self, hidden_states, temb, text, cross_kw, motion_kw, traj_features):
         self._check_ckpt()
         x4, b, f = _frames_first(hidden_states)
-        temb_rep = temb.repeat_interleave(f, dim=0)
+        temb_rep = None if self.resnets[0]._t_pre is not None else temb.repeat_interleave(f, dim=0)
         outs = ()
         for i in range(len(self.resnets)):
             x4 = self._layer(i, x4, b, f, temb_rep, text, cross_kw, motion_kw)
@@ -251,7 +251,7 @@ class UNetMidBlock3DCrossAttn(_Block3D):
     def forward(self, hidden_states, temb=None, encoder_hidden_states=None, attention_mask=None,
                 motion_module_alpha=1., cross_attention_kwargs=None, motion_cross_attention_kwargs=None):
         x4, b, f = _frames_first(hidden_states)
-        temb_rep = temb.repeat_interleave(f, dim=0)
+        temb_rep = None if self.resnets[0]._t_pre is not None else temb.repeat_interleave(f, dim=0)
         ls = getattr(self, "lora_scale", None)
         cross_kw = {"scale": ls} if ls is not None else cross_attention_kwargs
         motion_kw = self._motion_kwargs(motion_cross_attention_kwargs)
@@ -292,7 +292,7 @@ class _UpBlock(_Block3D):
     def _up(self, hidden_states, res_hidden_states_tuple, temb, text, upsample_size, cross_kw, motion_kw):
         self._check_ckpt()
         x4, b, f = _frames_first(hidden_states)
-        temb_rep = temb.repeat_interleave(f, dim=0)
+        temb_rep = None if self.resnets[0]._t_pre is not None else temb.repeat_interleave(f, dim=0)
         for i in range(len(self.resnets)):
             skip4 = _frames_first(res_hidden_states_tuple[-1])[0]
             res_hidden_states_tuple = res_hidden_states_tuple[:-1]
