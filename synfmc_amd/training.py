@@ -159,3 +159,32 @@ def stage3_training_step(pose_adaptor, omcm, noise_scheduler, optimizer, reducer
     else:
         optimizer.zero_grad(set_to_none=True)
     return loss.detach()
+
+
+def stage2_trainable_parameters(unet, pose_encoder) -> List[torch.nn.Parameter]:
+    """The CMC stage trains the camera encoder and the Camera-Adapter merge layers of the temporal attention
+    processors (`qkv_merge` / `q_merge` / `kv_merge`), everything else is frozen (train_cam_ctrl.py:262-283)."""
+    params = list(pose_encoder.parameters())
+    params += [p for n, p in unet.named_parameters() if "_merge." in n]
+    return params
+
+
+def stage2_training_step(pose_adaptor, trainable: Iterable[torch.nn.Parameter], noise_scheduler, optimizer,
+                         reducer: Optional[GradAllReducer], latents, noise, timesteps, encoder_hidden_states,
+                         plucker_embedding, obj_masks=None, sd_loss_weight=0.3, mask_loss_weight=1.0, max_grad_norm=1.0):
+    """One CMC-stage optimisation step (train_cam_ctrl.py:540-665 minus data loading, VAE and CLIP): the camera
+    encoder runs inside `pose_adaptor` with gradients, the loss weights the background (`1 - object mask`, :624)."""
+    noisy_latents = noise_scheduler.add_noise(latents, noise, timesteps)
+    model_pred = pose_adaptor(noisy_latents, timesteps, encoder_hidden_states=encoder_hidden_states,
+                              pose_embedding=plucker_embedding)
+    loss = masked_mse_loss(model_pred, noise, obj_masks, sd_loss_weight, mask_loss_weight, invert=True)
+    loss.backward()
+    if reducer is not None:
+        reducer.finish()
+    torch.nn.utils.clip_grad_norm_([p for p in trainable if p.requires_grad], max_grad_norm)
+    optimizer.step()
+    if reducer is not None:
+        reducer.zero_grad()
+    else:
+        optimizer.zero_grad(set_to_none=True)
+    return loss.detach()

@@ -130,3 +130,28 @@ def test_stage3_training_gradients(stack, dtype, tol):
     assert abs(float(l_ref) - float(l_got)) < (1e-4 if dtype == torch.float32 else 2e-2) * abs(float(l_ref))
     err, scale = TC.compare(g_ref, g_got)
     assert scale > 0 and err < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-3), (torch.bfloat16, 1.5e-1)])
+def test_stage2_training_gradients(stack, dtype, tol):
+    """CMC-stage training step (train_cam_ctrl.py:540-665): gradients of the camera encoder (through its own temporal
+    transformer blocks and 3x3 convs) and of the `qkv_merge` layers inside the frozen U-Net, background-weighted loss,
+    against autograd through the CPU oracle."""
+    from tests import training_common as TC
+    ou, oe, oa = CM.build_oracle(W4, seed=21, fan_in_gain=0.7)
+    pu, pe, pa = CM.build_product(ou, oe, oa, W4, dtype=dtype)
+    if dtype == torch.bfloat16:
+        pe = pe.float()                              # fp32 master weights for the trainable encoder, bf16 autocast compute
+    clip = stack["clip"]
+    noise = torch.randn(clip["latents"].shape, generator=torch.Generator().manual_seed(11))
+    t = torch.tensor([423])
+    l_ref, g_ref = TC.oracle_grads_stage2(ou, oe, clip, stack["pose_emb"], t, noise)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+        l_got, g_got = TC.product_grads_stage2(pu, pe, clip, stack["pose_emb"], t, noise, "cuda", dtype)
+    assert abs(float(l_ref) - float(l_got)) < (1e-4 if dtype == torch.float32 else 2e-2) * abs(float(l_ref))
+    enc = {k: v for k, v in g_ref.items() if k.startswith("enc.")}
+    mrg = {k: v for k, v in g_ref.items() if k.startswith("unet.")}
+    assert enc and mrg
+    for part in (enc, mrg):
+        err, scale = TC.compare(part, g_got)
+        assert scale > 0 and err < tol

@@ -56,3 +56,56 @@ def compare(g_ref, g_got):
     ref = torch.cat([g_ref[k].reshape(-1) for k in g_ref]).double()
     got = torch.cat([g_got[k].reshape(-1).double() for k in g_ref])
     return ((ref - got).abs().max() / ref.abs().max()).item(), float(ref.abs().max())
+
+
+# ---- stage 2 (CMC): camera encoder + the processors' merge layers are trainable, loss on the background --------------
+def _stage2_loss(pred, noise, masks):
+    return OP.stage3_loss(pred, noise, ~masks, 0.3, 1.0)         # `1 - mask` (train_cam_ctrl.py:624) on a bool mask
+
+
+def _merge_params(unet):
+    return {n: p for n, p in unet.named_parameters() if "_merge." in n}
+
+
+def oracle_grads_stage2(ou, oe, clip, pose_emb, t, noise):
+    ou.requires_grad_(False)
+    oe.requires_grad_(True)
+    tr = dict({"enc." + k: p for k, p in oe.named_parameters()}, **{"unet." + k: p for k, p in _merge_params(ou).items()})
+    for p in tr.values():
+        p.requires_grad_(True)
+        p.grad = None
+    sched = OD.DDIMScheduler(**SCHED)
+    noisy = sched.add_noise(clip["latents"], noise, t)
+    pose_feats = [rearrange(x, "(b f) c h w -> b c f h w", b=1) for x in oe(pose_emb)]
+    pred = ou(noisy, t, clip["text"], pose_embedding_features=pose_feats).sample
+    loss = _stage2_loss(pred, noise, union_masks(clip))
+    loss.backward()
+    grads = {k: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for k, p in tr.items()}
+    for p in tr.values():
+        p.requires_grad_(False)
+        p.grad = None
+    return loss.detach(), grads
+
+
+def product_grads_stage2(pu, pe, clip, pose_emb, t, noise, device, dtype=torch.float32):
+    from synfmc_amd.models.pose_adaptor import PoseAdaptor
+    from synfmc_amd.schedulers import DDIMScheduler
+    from synfmc_amd.training import masked_mse_loss, stage2_trainable_parameters
+    pu.requires_grad_(False)
+    pe.requires_grad_(False)
+    tr = dict({"enc." + k: p for k, p in pe.named_parameters()}, **{"unet." + k: p for k, p in _merge_params(pu).items()})
+    assert {id(p) for p in tr.values()} == {id(p) for p in stage2_trainable_parameters(pu, pe)}
+    for p in tr.values():
+        p.requires_grad_(True)
+        p.grad = None
+    sched = DDIMScheduler(**SCHED)
+    dev = lambda x: x.to(device)
+    noisy = sched.add_noise(dev(clip["latents"]), dev(noise), dev(t))
+    pred = PoseAdaptor(pu, pe)(noisy.to(dtype), dev(t), dev(clip["text"]).to(dtype), dev(pose_emb).to(dtype))
+    loss = masked_mse_loss(pred, dev(noise), dev(union_masks(clip)), 0.3, 1.0, invert=True)
+    loss.backward()
+    grads = {k: (p.grad.detach().float().cpu() if p.grad is not None else torch.zeros(p.shape)) for k, p in tr.items()}
+    for p in tr.values():
+        p.requires_grad_(False)
+        p.grad = None
+    return loss.detach().cpu(), grads
