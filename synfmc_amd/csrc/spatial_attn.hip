@@ -368,6 +368,9 @@ inline int sa_prefetch_env() {
 template <typename T, int NKS>
 void launch_sa(const SAParams& P, hipStream_t st) {
     if (P.Skv <= 2 * SA_BK) {
+        if constexpr (sizeof(T) == 2 && NKS <= 6) {
+            if (sa_prefetch_env() != 0 && P.Skv > SA_BK) return launch_sa_v<T, NKS, true, true>(P, st);
+        }
         launch_sa_v<T, NKS, true, false>(P, st);
     } else {
         if constexpr (sizeof(T) == 2 && NKS <= 6) {

@@ -95,14 +95,18 @@ template <> __device__ __forceinline__ void st4<float>(float* p, const float (&v
 
 // FT = F/16 frame tiles; NK32 = ceil(D/32) k-steps of the QK^T reduction
 template <typename T, int FT, int NK32>
-__global__ __launch_bounds__(64) void temporal_attn_kernel(const TAParams P) {
+__global__ __launch_bounds__(256) void temporal_attn_kernel(const TAParams P) {
     constexpr int F = FT * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int D = P.D, GH = P.GH, CW = GH * D, CPR = CW / 8, PITCH = CW + 8;
     T* Qs = reinterpret_cast<T*>(smem_raw);  // [F][PITCH]; O overwrites it head by head
     T* Ks = Qs + F * PITCH;
     T* Vs = Ks + F * PITCH;
-    const int lane = threadIdx.x;
+    // up to 4 waves per unit: they stage the rows together and split the unit's heads, so that the short dependent
+    // chains of one head (LDS read -> MFMA -> softmax -> MFMA -> LDS write) overlap with other heads' (one wave per
+    // unit ran at ~1 wave per SIMD -- the LDS footprint caps a CU at 5 units -- and every latency was exposed)
+    const int tid = threadIdx.x, NTH = blockDim.x, wave = tid >> 6, NWV = NTH >> 6;
+    const int lane = tid & 63;
     const int l15 = lane & 15, lg = lane >> 4;
 
     // ---- unit decode ---------------------------------------------------------------------------
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(64) void temporal_attn_kernel(const TAParams P) {
         const T* src = (const T*)(which == 0 ? P.q : (which == 1 ? P.k : P.v)) + in_off;
         T* dst = which == 0 ? Qs : (which == 1 ? Ks : Vs);
 #pragma unroll 5
-        for (int c = lane; c < chunks; c += 64) {
+        for (int c = tid; c < chunks; c += NTH) {
             const int f = c / CPR, ch = c - f * CPR;
             float v[8];
             Vec8<T>::load(src + (int64_t)f * P.fs + ch * 8, v);
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(64) void temporal_attn_kernel(const TAParams P) {
     }
     __syncthreads();
 
-    for (int hh = 0; hh < GH; ++hh) {
+    for (int hh = wave; hh < GH; hh += NWV) {
         const int hc = hh * D;
 #pragma unroll
         for (int qt = 0; qt < FT; ++qt) {
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(64) void temporal_attn_kernel(const TAParams P) {
     // ---- O: LDS -> global ------------------------------------------------------------------------------
     T* og = (T*)P.o + out_off;
 #pragma unroll 5
-    for (int c = lane; c < chunks; c += 64) {
+    for (int c = tid; c < chunks; c += NTH) {
         const int f = c / CPR, ch = c - f * CPR;
         float v[8];
         Vec8<T>::load(Qs + f * PITCH + ch * 8, v);
@@ -466,7 +470,8 @@ void launch_ta(const TAParams& P, hipStream_t st) {
             raised = true;
         }
     }
-    dim3 grid((unsigned)((int64_t)P.n_clips * P.n_pix * (P.H / P.GH))), block(64);
+    const int waves = P.GH >= 4 ? 4 : (P.GH >= 2 ? 2 : 1);           // the waves of a workgroup split the unit's heads
+    dim3 grid((unsigned)((int64_t)P.n_clips * P.n_pix * (P.H / P.GH))), block(64 * waves);
     hipLaunchKernelGGL((temporal_attn_kernel<T, FT, NK32>), grid, block, lds, st, P);
 }
 
