@@ -326,6 +326,104 @@ __global__ void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y, con
 }
 
 // --------------------------------------------------------------------------------------------
+// LayerNorm, LPR = C/40 lanes per row (C = 320 / 640 / 1280: every FMC width; 5 chunks of 8 elements per lane).
+// The kernel above leaves 24 of 64 lanes idle at C = 320 and reduces over the whole wave through the LDS crossbar; here
+// a wave works on (64/LPR) x U rows at once with every lane active, a row's lanes read LPR*16 contiguous bytes per
+// load, and the two row reductions are 3-4 DPP steps (+ one cross-row shuffle at LPR = 32).
+// --------------------------------------------------------------------------------------------
+template <int LPR> __device__ __forceinline__ float group_sum(float v) {   // sum over LPR consecutive lanes, in every lane
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    if (LPR >= 16) v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    if (LPR >= 32) v += __shfl_xor(v, 16, 64);
+    return v;
+}
+
+template <typename T, int LPR, int U>   // 5 eight-element chunks per lane, U rows per lane group
+__global__ __launch_bounds__(256) void layernorm_g_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ pe, int64_t M, float eps, int pe_inner,
+                                                          int pe_frames) {
+    constexpr int NCH = 5, C = LPR * NCH * 8, RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, t = lane % LPR, g = lane / LPR;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t row0 = wave * (RPW * U) + g;               // this group's rows: row0 + RPW*u
+    float v[U][NCH][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t row = row0 + RPW * u;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            if (row < M) Vec8<T>::load(x + row * C + (j * LPR + t) * 8, v[u][j]);
+            else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[u][j][i] = 0.f;
+            }
+        }
+    }
+    float mean[U], rs[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += v[u][j][i];
+        mean[u] = group_sum<LPR>(s) * (1.f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float d = v[u][j][i] - mean[u]; q += d * d; }
+        rs[u] = rsqrtf(group_sum<LPR>(q) * (1.f / C) + eps);
+    }
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        float gm[8], bt[8];
+        Vec8<float>::load(gamma + (j * LPR + t) * 8, gm);
+        Vec8<float>::load(beta + (j * LPR + t) * 8, bt);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = row0 + RPW * u;
+            if (row >= M) continue;
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (v[u][j][i] - mean[u]) * rs[u] * gm[i] + bt[i];
+            if (pe) {
+                float pv[8];
+                Vec8<float>::load(pe + (size_t)((row / pe_inner) % pe_frames) * C + (j * LPR + t) * 8, pv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] += pv[i];
+            }
+            Vec8<T>::store(y + row * C + (j * LPR + t) * 8, o);
+        }
+    }
+}
+
+template <typename T, int LPR, int U>
+static void launch_ln_g(const void* x, void* y, const float* gamma, const float* beta, const float* pe, int64_t M, float eps,
+                        int pe_inner, int pe_frames, hipStream_t st) {
+    const int64_t rpw = (64 / LPR) * U, waves = (M + rpw - 1) / rpw;
+    hipLaunchKernelGGL((layernorm_g_kernel<T, LPR, U>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, (const T*)x,
+                       (T*)y, gamma, beta, pe, M, eps, pe_inner, pe_frames);
+}
+
+template <typename T>
+static bool try_launch_ln16(const void* x, void* y, const float* gamma, const float* beta, const float* pe, int64_t M, int C,
+                            float eps, int pe_inner, int pe_frames, hipStream_t st) {
+    const bool many = M >= 32768;                            // two rows per lane group when there are plenty of rows
+    switch (C) {
+        case 320: many ? launch_ln_g<T, 8, 2>(x, y, gamma, beta, pe, M, eps, pe_inner, pe_frames, st)
+                       : launch_ln_g<T, 8, 1>(x, y, gamma, beta, pe, M, eps, pe_inner, pe_frames, st); return true;
+        case 640: many ? launch_ln_g<T, 16, 2>(x, y, gamma, beta, pe, M, eps, pe_inner, pe_frames, st)
+                       : launch_ln_g<T, 16, 1>(x, y, gamma, beta, pe, M, eps, pe_inner, pe_frames, st); return true;
+        case 1280: launch_ln_g<T, 32, 1>(x, y, gamma, beta, pe, M, eps, pe_inner, pe_frames, st); return true;
+        default: return false;
+    }
+}
+
+// --------------------------------------------------------------------------------------------
 // GEGLU: y = a * gelu_erf(g)
 // --------------------------------------------------------------------------------------------
 template <typename T>
@@ -550,6 +648,7 @@ static void launch_ln_n(const void* x, void* y, const float* gamma, const float*
 template <typename T>
 static void launch_ln(const void* x, void* y, const float* gamma, const float* beta, const float* pe, int64_t M, int C,
                       float eps, int pe_inner, int pe_frames, hipStream_t st) {
+    if (try_launch_ln16<T>(x, y, gamma, beta, pe, M, C, eps, pe_inner, pe_frames, st)) return;
     switch ((C / 8 + 63) / 64) {
         case 1: launch_ln_n<T, 1>(x, y, gamma, beta, pe, M, C, eps, pe_inner, pe_frames, st); break;
         case 2: launch_ln_n<T, 2>(x, y, gamma, beta, pe, M, C, eps, pe_inner, pe_frames, st); break;
