@@ -184,6 +184,139 @@ __global__ void gn_apply_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, 
     }
 }
 
+// --------------------------------------------------------------------------------------------
+// single-pass forward for the small levels: one workgroup owns ALL pixels of (image n, a slab of GPB whole groups =
+// CS channels), keeps them in registers (<= GN1_MAXCH 8-element chunks per thread), reduces, normalises, writes.  x is
+// read once and there is one launch instead of two -- at [32, 160, 1280] the two-pass pair costs 20 us against a 6 us
+// copy.  Thread (pl, ch) always handles the same 8 channels (chunk ch of the slab) of pixels pl, pl+PL, ...
+// --------------------------------------------------------------------------------------------
+constexpr int GN1_MAXCH = 16;
+
+template <typename T, int MAXCH>
+__global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ stats, int HW, int C, int G, int CS, int PL,
+                                                           float eps, int act) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][PL][CS] partial sums, then [2][CS] totals
+    __shared__ float sh_mean[GN_MAX_G], sh_rstd[GN_MAX_G];
+    const int n = blockIdx.y, slab = blockIdx.x, tid = threadIdx.x;
+    const int CPS = CS / 8, cpg = C / G, GPB = CS / cpg;
+    const int ch = tid % CPS, pl = tid / CPS;
+    const int c0 = slab * CS + ch * 8;                             // my 8 channels (global index)
+    const T* xb = x + (size_t)n * HW * C + c0;
+    float v[MAXCH][8];
+    float s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
+    // branch-free loads (clamped row) so that all of them are in flight together: a load inside `if (p < HW)` is
+    // waited for inside its own branch region, i.e. one memory round trip per chunk
+#pragma unroll
+    for (int j = 0; j < MAXCH; ++j) {
+        const int p = pl + PL * j;
+        Vec8<T>::load(xb + (size_t)(p < HW ? p : HW - 1) * C, v[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < MAXCH; ++j) {
+        const float m = (pl + PL * j) < HW ? 1.f : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float t = v[j][i] * m; s1[i] += t; s2[i] += t * v[j][i]; }
+    }
+    float* l1 = smem;
+    float* l2 = smem + (size_t)PL * CS;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        l1[pl * CS + ch * 8 + i] = s1[i];
+        l2[pl * CS + ch * 8 + i] = s2[i];
+    }
+    __syncthreads();
+    for (int c = tid; c < CS; c += blockDim.x) {
+        float a = 0.f, b = 0.f;
+        for (int r = 0; r < PL; ++r) { a += l1[r * CS + c]; b += l2[r * CS + c]; }
+        l1[c] = a;
+        l2[c] = b;
+    }
+    __syncthreads();
+    if (tid < GPB) {
+        double a = 0.0, b = 0.0;
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += (double)l1[c]; b += (double)l2[c]; }
+        const double cnt = (double)HW * cpg, mean = a / cnt;
+        double var = b / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        sh_mean[tid] = (float)mean;
+        sh_rstd[tid] = rstd;
+        const int g = slab * GPB + tid;
+        stats[((size_t)n * G + g) * 2] = (float)mean;
+        stats[((size_t)n * G + g) * 2 + 1] = rstd;
+    }
+    __syncthreads();
+    float aco[8], bco[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = c0 + i, gl = (ch * 8 + i) / cpg;
+        aco[i] = sh_rstd[gl] * gamma[c];
+        bco[i] = beta[c] - sh_mean[gl] * aco[i];
+    }
+    T* yb = y + (size_t)n * HW * C + c0;
+#pragma unroll
+    for (int j = 0; j < MAXCH; ++j) {
+        const int p = pl + PL * j;
+        if (p < HW) {
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float z = v[j][i] * aco[i] + bco[i];
+                o[i] = act ? silu_f(z) : z;
+            }
+            Vec8<T>::store(yb + (size_t)p * C, o);
+        }
+    }
+}
+
+// slab choice for the single-pass kernel: GPB whole groups per workgroup such that the slab is a whole number of
+// 16-byte chunks and all HW pixels of it fit the register budget; longest contiguous runs first, then most workgroups
+struct Gn1Geom { int CS, PL, block, chunks; };
+static bool gn1_geom(int HW, int C, int G, Gn1Geom& out) {
+    const int cpg = C / G;
+    int best = 0, best_score = -1;
+    for (int gpb = 1; gpb <= G; ++gpb) {
+        if (G % gpb || gpb > GN_MAX_G) continue;
+        const int cs = gpb * cpg;
+        if (cs % 8) continue;
+        const int cps = cs / 8;
+        if (cps > 256) break;
+        const int pl = 256 / cps < HW ? 256 / cps : HW;
+        const int chunks = (HW + pl - 1) / pl;
+        if (chunks > GN1_MAXCH) continue;
+        if ((size_t)2 * pl * cs * sizeof(float) > 60 * 1024) continue;
+        // contiguous bytes per pixel (as bf16) up to 160 count; beyond that prefer small slabs: more workgroups than CUs
+        // (so one's load burst overlaps another's arithmetic) and few chunks per thread (registers -> occupancy)
+        const int run = cs * 2 < 160 ? cs * 2 : 160;
+        const int score = run * 1024 - chunks * 8 - gpb;
+        if (score > best_score) { best_score = score; best = gpb; }
+    }
+    if (!best) return false;
+    out.CS = best * cpg;
+    const int cps = out.CS / 8;
+    out.PL = 256 / cps < HW ? 256 / cps : HW;
+    out.block = cps * out.PL;
+    out.chunks = (HW + out.PL - 1) / out.PL;
+    return true;
+}
+
+template <typename T>
+static void launch_gn1(const Gn1Geom& g1, const void* x, void* y, const float* gamma, const float* beta, float* stats, int N,
+                       int HW, int C, int G, float eps, int act, hipStream_t st) {
+    dim3 grid1(C / g1.CS, N), block1(g1.block);
+    const size_t lds1 = (size_t)2 * g1.PL * g1.CS * sizeof(float);
+    if (g1.chunks <= 8)
+        hipLaunchKernelGGL((gn_fused_fwd_kernel<T, 8>), grid1, block1, lds1, st, (const T*)x, (T*)y, gamma, beta, stats, HW, C,
+                           G, g1.CS, g1.PL, eps, act);
+    else
+        hipLaunchKernelGGL((gn_fused_fwd_kernel<T, GN1_MAXCH>), grid1, block1, lds1, st, (const T*)x, (T*)y, gamma, beta,
+                           stats, HW, C, G, g1.CS, g1.PL, eps, act);
+}
+
 // pass 2 (backward): dx = rstd * (dxh - S1/cnt - xh * S2/cnt)
 template <typename T>
 __global__ void gn_apply_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dx,
@@ -579,8 +712,15 @@ extern "C" int fmc_groupnorm_silu_fwd(const void* x, void* y, const float* gamma
                                       void* stream) {
     if (int rc = gn_check(x, y, N, HW, C, G, dtype)) return rc;
     if (!gamma || !beta || !stats || !workspace) FMC_FAIL(FMC_E_NULL, "groupnorm_fwd: NULL gamma/beta/stats/workspace");
-    GnGeom g = gn_geom(HW, C);
     hipStream_t st = (hipStream_t)stream;
+    Gn1Geom g1;
+    if (gn1_geom(HW, C, G, g1)) {                        // small levels: one launch, x read once
+        if (dtype == FMC_BF16) launch_gn1<bf16_t>(g1, x, y, gamma, beta, stats, N, HW, C, G, eps, act, st);
+        else launch_gn1<float>(g1, x, y, gamma, beta, stats, N, HW, C, G, eps, act, st);
+        FMC_CHECK_LAUNCH("fmc_groupnorm_silu_fwd");
+        return 0;
+    }
+    GnGeom g = gn_geom(HW, C);
     dim3 grid(g.split, N), block(g.block);
     size_t lds = (size_t)2 * g.rpi * C * sizeof(float);
     float* part = (float*)workspace;
