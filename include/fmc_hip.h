@@ -174,8 +174,9 @@ int fmc_cfg_ddim_step(const void* eps_uc, const float* x, float* x_out, int64_t 
  *   tile: workgroup tile geometry, 0 = pick by shape, 1 = 128x128 (4 waves), 2 = 256x128 (8), 3 = 256x256 (16) with
  *   64-deep k-tiles in a 2-stage LDS ring; 4..6 = the same three with 32-deep k-tiles (half the LDS, twice the
  *   workgroups per CU); 7 = 256x128, 64-deep, 3 stages; 8 / 9 / 10 = 256x256 / 128x128 / 256x128, 32-deep, 4 stages
- *   (deeper rings keep more bytes in flight per CU).  Every arm computes the same function, bit for bit (callers may
- *   time them and keep the fastest).
+ *   (deeper rings keep more bytes in flight per CU); 11 = 128x320 (10 waves; spans N = 320 / 640 / 960 without padded
+ *   columns; plain epilogue only).  Every arm computes the same function, bit for bit (callers may time them and keep
+ *   the fastest).
  *   split_k > 1 (epilogue 0 only): the k-tiles of every output tile are dealt to split_k workgroups that write fp32
  *   partial sums to `workspace` (>= split_k * M * N * 4 bytes, 16-byte aligned, caller-owned scratch); a second kernel
  *   sums them in a fixed order and applies the epilogue.  For M*N too small to fill 256 CUs (the 5x8 level).

@@ -101,24 +101,29 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sk_rsrc(float* ws) {
 // STAGES: depth of the LDS ring.  STAGES-1 k-tiles are in flight under the MFMAs of the current one (counted
 // s_waitcnt vmcnt(N), never a drain): what bounds these kernels is bytes in flight per CU (L2/HBM latency x
 // bandwidth), so the ring is as deep as the 160 KiB of LDS allow for the geometry.
-template <int WM, int WN, int BK, int STAGES> constexpr int gemm_min_waves() {
+template <int WM, int WN, int MI, int BK, int STAGES> constexpr int gemm_min_waves() {
+    if (MI == 4) return (WM * WN + 3) / 4;              // 128 accumulator registers per wave: one workgroup per CU
     const size_t lds = (size_t)STAGES * 64 * (WM + WN) * BK * 2;
     const int wgs = (int)(160 * 1024 / lds) > 0 ? (int)(160 * 1024 / lds) : 1;     // workgroups per CU the LDS allows
     const int w = wgs * WM * WN / 4;                                                 // waves per SIMD
     return w > 4 ? 4 : (w < 1 ? 1 : w);
 }
 
-template <int MODE, int EPI, int WM, int WN, int BK, int STAGES, bool SK>
-__global__ __launch_bounds__(64 * WM * WN, (gemm_min_waves<WM, WN, BK, STAGES>()))
+//
+// MI: 32-row A blocks per wave (2 = every wave a 64x64 sub-tile; 4 = 128 (m) x 64 (n), kept for experiments).
+// WN = 5 gives tiles that span N = 320 / 640 / 960 exactly: no padded columns and A read once per 320 columns -- the
+// K = 320 projections are bound by L2 -> LDS operand traffic (64 flop/B with 128x128 tiles, 91 with 128x320).
+template <int MODE, int EPI, int WM, int WN, int MI, int BK, int STAGES, bool SK>
+__global__ __launch_bounds__(64 * WM * WN, (gemm_min_waves<WM, WN, MI, BK, STAGES>()))
 void gemm_kernel(const GemmParams P) {
-    constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN, NT = 64 * NW;
+    constexpr int BM = 32 * MI * WM, BN = 64 * WN, NW = WM * WN, NT = 64 * NW;
     constexpr int STAGE_ELEMS = (BM + BN) * BK;
     constexpr int RPP = 512 / BK;                    // tile rows per 1-KiB DMA piece (8 x 128 B or 16 x 64 B)
     constexpr int CPRW = BK / 8;                     // 16-byte chunks per tile row
     constexpr int PIECES = (BM + BN) / RPP;          // pieces per k-tile
-    constexpr int PPW = PIECES / NW;                 // pieces per wave
+    constexpr int PPW = (PIECES + NW - 1) / NW;      // pieces per wave (the last round may be ragged)
     constexpr int CP = BN + 8;                       // fp32 C slab pitch
-    static_assert(PIECES % NW == 0, "pieces must divide evenly over the waves");
+    static_assert(PIECES % NW == 0 || STAGES == 2, "counted vmcnt needs the same number of pieces in every wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -188,7 +193,9 @@ void gemm_kernel(const GemmParams P) {
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
         const int p = wave + NW * j;
-        if (p < BM / RPP) {
+        if (p >= PIECES) {
+            src[j] = nullptr; val[j] = false; py[j] = px[j] = 0;
+        } else if (p < BM / RPP) {
             const int rloc = RPP * p + prow;
             const int sc = swz<BK>(rloc, pphys);
             const int64_t m = m0 + rloc;
@@ -227,6 +234,7 @@ void gemm_kernel(const GemmParams P) {
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
             const int p = wave + NW * j;             // wave-uniform
+            if (p >= PIECES) continue;
             if (p < BM / RPP) {
                 bool ok = val[j];
                 if (MODE == 1)
@@ -238,11 +246,11 @@ void gemm_kernel(const GemmParams P) {
         }
     };
 
-    f32x16 acc[2][2];                                // [ni][mi]: rows = n (registers), cols = m (lanes)
+    f32x16 acc[2][MI];                               // [ni][mi]: rows = n (registers), cols = m (lanes)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < MI; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
@@ -276,19 +284,23 @@ void gemm_kernel(const GemmParams P) {
         // fragments are double-buffered in registers: the ds_read_b128s of k-step ks+1 are issued before the MFMAs
         // of k-step ks (sched_barrier pins that order; left alone the compiler re-uses one register set and every
         // k-step eats its own LDS latency)
-        auto load_frags = [&](int ks, bf16x8 (&wf)[2], bf16x8 (&af)[2]) {
+        auto load_frags = [&](int ks, bf16x8 (&wf)[2], bf16x8 (&af)[MI]) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int rw = wn * 64 + i * 32 + l31;
-                const int rm = wm * 64 + i * 32 + l31;
-                union { bf16x8 v; u32x4 u; } tw, ta;
+                union { bf16x8 v; u32x4 u; } tw;
                 tw.u = *reinterpret_cast<const u32x4*>(Ws + rw * BK + swz<BK>(rw, 2 * ks + half) * 8);
-                ta.u = *reinterpret_cast<const u32x4*>(As + rm * BK + swz<BK>(rm, 2 * ks + half) * 8);
                 wf[i] = tw.v;
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int rm = wm * (32 * MI) + i * 32 + l31;
+                union { bf16x8 v; u32x4 u; } ta;
+                ta.u = *reinterpret_cast<const u32x4*>(As + rm * BK + swz<BK>(rm, 2 * ks + half) * 8);
                 af[i] = ta.v;
             }
         };
-        bf16x8 wf[2][2], af[2][2];
+        bf16x8 wf[2][2], af[2][MI];
         load_frags(0, wf[0], af[0]);
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
@@ -297,7 +309,7 @@ void gemm_kernel(const GemmParams P) {
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][ni], af[ks & 1][mi], acc[ni][mi], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -319,9 +331,12 @@ void gemm_kernel(const GemmParams P) {
     // ---- epilogue: fp32 C slabs of 64 rows through LDS, bias / alpha / temb / residual / GEGLU on the way out ----------
     float* Cs = reinterpret_cast<float*>(smem_raw);             // [64][CP] fp32
 #pragma unroll 1
-    for (int hm = 0; hm < WM; ++hm) {
+    for (int hw = 0; hw < WM; ++hw)
+#pragma unroll
+    for (int part = 0; part < MI / 2; ++part) {      // 64-row slab hm: rows [64*part, 64*part+64) of wave row hw
+        const int hm = hw * (MI / 2) + part;
         __syncthreads();
-        if (wm == hm) {
+        if (wm == hw) {
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -330,8 +345,8 @@ void gemm_kernel(const GemmParams P) {
                     for (int g = 0; g < 4; ++g) {
                         const int m = mi * 32 + l31;
                         const int n = wn * 64 + ni * 32 + 8 * g + 4 * half;
-                        *reinterpret_cast<f32x4*>(Cs + m * CP + n) =
-                            f32x4{acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]};
+                        const f32x16& a = acc[ni][part * 2 + mi];
+                        *reinterpret_cast<f32x4*>(Cs + m * CP + n) = f32x4{a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
                     }
         }
         __syncthreads();
@@ -500,20 +515,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams P) 
     Vec8<bf16_t>::store(P.out + m * P.ldo + n, v);
 }
 
-template <int MODE, int EPI, int WM, int WN, int BK, int STAGES, bool SK>
+template <int MODE, int EPI, int WM, int WN, int MI, int BK, int STAGES, bool SK>
 void launch_gemm_k(GemmParams& P, unsigned grid, size_t lds, hipStream_t st) {
     static bool raised = false;
     if (!raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, EPI, WM, WN, BK, STAGES, SK>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, EPI, WM, WN, MI, BK, STAGES, SK>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         raised = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<MODE, EPI, WM, WN, BK, STAGES, SK>), dim3(grid), dim3(64 * WM * WN), lds, st, P);
+    hipLaunchKernelGGL((gemm_kernel<MODE, EPI, WM, WN, MI, BK, STAGES, SK>), dim3(grid), dim3(64 * WM * WN), lds, st, P);
 }
 
-template <int MODE, int EPI, int WM, int WN, int BK, int STAGES>
+template <int MODE, int EPI, int WM, int WN, int BK, int STAGES, int MI = 2>
 void launch_gemm_g(GemmParams& P, hipStream_t st) {
-    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int BM = 32 * MI * WM, BN = 64 * WN;
     P.tiles_m = (int)((P.M + BM - 1) / BM);
     P.tiles_n = (P.N + BN - 1) / BN;
     size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(bf16_t);
@@ -528,20 +543,20 @@ void launch_gemm_g(GemmParams& P, hipStream_t st) {
         const int64_t iters = (int64_t)P.tiles_m * P.tiles_n * (P.K / BK);
         const int g = (fmc_cu_count() * per_cu) & ~7;
         const int64_t need = (int64_t)g * BM * BN * (int64_t)sizeof(float) + 4096;
-        if (STAGES != 2 || g < 8 || iters < 4 * (int64_t)g || P.sk_ws_bytes < need || g * (int)sizeof(int) > 4096) {
+        if (STAGES != 2 || MI != 2 || g < 8 || iters < 4 * (int64_t)g || P.sk_ws_bytes < need || g * (int)sizeof(int) > 4096) {
             P.sk = 0;                                    // too little work (or workspace): the plain grid
         } else {
             P.sk = g;
             grid = (unsigned)g;
         }
     }
-    if constexpr (STAGES == 2) {
+    if constexpr (STAGES == 2 && MI == 2) {
         if (P.sk) {
-            launch_gemm_k<MODE, EPI, WM, WN, BK, STAGES, true>(P, grid, lds, st);
+            launch_gemm_k<MODE, EPI, WM, WN, MI, BK, STAGES, true>(P, grid, lds, st);
             return;
         }
     }
-    launch_gemm_k<MODE, EPI, WM, WN, BK, STAGES, false>(P, grid, lds, st);
+    launch_gemm_k<MODE, EPI, WM, WN, MI, BK, STAGES, false>(P, grid, lds, st);
     if (P.split_k > 1) {
         const int64_t chunks = P.M * (P.N / 8);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, P);
@@ -549,7 +564,7 @@ void launch_gemm_g(GemmParams& P, hipStream_t st) {
 }
 
 // tile arms (fmc_hip.h): geometry x k-tile depth x ring depth
-constexpr int GEMM_TILE_MAX = 10;
+constexpr int GEMM_TILE_MAX = 11;
 
 // geometry: the largest tile that still gives every CU work and does not waste more than ~20 % of N
 template <int MODE, int EPI>
@@ -564,6 +579,10 @@ void launch_gemm(GemmParams& P, int tile, hipStream_t st) {
         else g = 1;
     }
     switch (g) {
+        case 11:                                         // 128x320: 2 x 5 waves (plain epilogue only)
+            if constexpr (EPI == 0) launch_gemm_g<MODE, EPI, 2, 5, 64, 2>(P, st);
+            else launch_gemm_g<MODE, EPI, 4, 4, 64, 2>(P, st);
+            break;
         case 10: launch_gemm_g<MODE, EPI, 4, 2, 32, 4>(P, st); break;
         case 9: launch_gemm_g<MODE, EPI, 2, 2, 32, 4>(P, st); break;
         case 8: launch_gemm_g<MODE, EPI, 4, 4, 32, 4>(P, st); break;

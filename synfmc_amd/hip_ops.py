@@ -566,7 +566,7 @@ _choice = {}
 _tune_log = {}      # key -> {arm: ms} measured when the choice was made
 _calls = {}         # key -> eager calls seen (graph replays do not pass through Python)
 AUTOTUNE = True
-GEMM_TILES = (1, 2, 3, 4, 5, 6, 7,     # 8..10 (4-stage rings) exist but never won on the FMC shapes
+GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 11,     # 8..10 (4-stage rings) exist but never won on the FMC shapes
               128 + 2, 128 + 3)                 # stream-K (persistent workgroups) on the two 1-per-CU geometries     # fmc_linear_bf16 / fmc_conv3x3_bf16 `tile` arms tried per shape
 
 
