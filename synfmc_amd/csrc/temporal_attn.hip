@@ -240,7 +240,7 @@ template <typename T> __device__ __forceinline__ void col_f4(const T* base, int 
 }
 
 template <typename T, int FT, int NK32>
-__global__ __launch_bounds__(64) void temporal_attn_bwd_kernel(const TABwdParams P) {
+__global__ __launch_bounds__(256) void temporal_attn_bwd_kernel(const TABwdParams P) {
     constexpr int F = FT * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int D = P.D, GH = P.GH, CW = GH * D, CPR = CW / 8, PITCH = CW + 8;
@@ -251,7 +251,10 @@ __global__ __launch_bounds__(64) void temporal_attn_bwd_kernel(const TABwdParams
     T* dQs = Gs + F * PITCH;
     T* dKs = dQs + F * PITCH;
     T* dVs = dKs + F * PITCH;
-    const int lane = threadIdx.x;
+    // up to 4 waves per unit split its heads (see the forward kernel); every head works on its own channel columns of
+    // the seven tiles, so the waves never touch the same LDS words
+    const int tid = threadIdx.x, NTH = blockDim.x, wave = tid >> 6, NWV = NTH >> 6;
+    const int lane = tid & 63;
     const int l15 = lane & 15, lg = lane >> 4;
 
     const int groups = P.H / GH;
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(64) void temporal_attn_bwd_kernel(const TABwdParams
         const int64_t fstride = which == 3 ? P.ofs : P.fs;
         T* dst = which == 0 ? Qs : which == 1 ? Ks : which == 2 ? Vs : Gs;
 #pragma unroll 5
-        for (int c = lane; c < chunks; c += 64) {
+        for (int c = tid; c < chunks; c += NTH) {
             const int f = c / CPR, ch = c - f * CPR;
             float v[8];
             Vec8<T>::load(src + (int64_t)f * fstride + ch * 8, v);
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(64) void temporal_attn_bwd_kernel(const TABwdParams
     __syncthreads();
 
     const int ndt = (D + 15) / 16;
-    for (int hh = 0; hh < GH; ++hh) {
+    for (int hh = wave; hh < GH; hh += NWV) {
         const int hc = hh * D;
         float st_m[FT], st_inv[FT], st_d[FT];          // per query (lane l15 of tile qt), from layout L1
         // ================= L1: lane = query, registers = keys =================
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(64) void temporal_attn_bwd_kernel(const TABwdParams
         T* dst = (T*)(which == 0 ? P.dq : which == 1 ? P.dk : P.dv) + dq_off;
         const T* srcl = which == 0 ? dQs : which == 1 ? dKs : dVs;
 #pragma unroll 5
-        for (int c = lane; c < chunks; c += 64) {
+        for (int c = tid; c < chunks; c += NTH) {
             const int f = c / CPR, ch = c - f * CPR;
             float v[8];
             Vec8<T>::load(srcl + f * PITCH + ch * 8, v);
@@ -441,7 +444,8 @@ void launch_ta_bwd(const TABwdParams& P, hipStream_t st) {
             raised = true;
         }
     }
-    dim3 grid((unsigned)((int64_t)P.n_clips * P.n_pix * (P.H / P.GH))), block(64);
+    const int waves = P.GH >= 4 ? 4 : (P.GH >= 2 ? 2 : 1);
+    dim3 grid((unsigned)((int64_t)P.n_clips * P.n_pix * (P.H / P.GH))), block(64 * waves);
     hipLaunchKernelGGL((temporal_attn_bwd_kernel<T, FT, NK32>), grid, block, lds, st, P);
 }
 
