@@ -199,7 +199,9 @@ def train_main(args):
     clip, _ = synthetic_inputs(rank, device)
     sched = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="linear",
                           steps_offset=1, clip_sample=False)
-    opt = torch.optim.AdamW([p for p in ada.parameters()], lr=1e-6, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+    use_graph = world == 1 and not args.no_graph           # one rank: the whole step (fwd, bwd, clip, AdamW) is one HIP graph
+    opt = torch.optim.AdamW([p for p in ada.parameters()], lr=1e-6, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8,
+                            capturable=use_graph)
     reducer = GradAllReducer(ada.parameters())
     wrapper = CamObjPoseAdaptor(unet, enc)
     poses, masks = stack_object_inputs(clip["infos"], clip["masks"], device)
@@ -208,9 +210,14 @@ def train_main(args):
     obj_masks = TC.union_masks(clip).to(device)
     gen = torch.Generator(device=device).manual_seed(77 + rank)
 
-    def step():
-        noise = torch.randn(latents.shape, device=device, dtype=dtype, generator=gen)
-        t = biased_timesteps(1, 1000, 700, 0.8, device, gen)
+    noise = torch.empty(latents.shape, device=device, dtype=dtype)    # static inputs of the (graphed) step
+    t = torch.zeros(1, device=device, dtype=torch.long)
+
+    def draw():
+        noise.copy_(torch.randn(latents.shape, device=device, dtype=dtype, generator=gen))
+        t.copy_(biased_timesteps(1, 1000, 700, 0.8, device, gen))
+
+    def body():
         emb = K.plucker(Kin, c2w, HEIGHT, WIDTH, "bcfhw", dtype)      # on device, every step (reference: CPU + H2D)
 
         def traj_fn():
@@ -219,6 +226,31 @@ def train_main(args):
                 return features_to_video(ada(feats, m), 1)
         with torch.autocast("cuda", dtype=torch.bfloat16):
             return stage3_training_step(wrapper, ada, sched, opt, reducer, latents, noise, t, text, emb, traj_fn, obj_masks)
+
+    if use_graph:
+        # eager warm-up on a side stream (autotune, MIOpen find, optimizer state), then capture the step once: eagerly the
+        # step is launch-bound (34 ms of kernels in 77 ms of wall clock on one GPU)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                draw()
+                body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        draw()
+        with torch.cuda.graph(graph):
+            static_loss = body()
+
+        def step():
+            draw()
+            graph.replay()
+            return static_loss
+    else:
+        def step():
+            draw()
+            return body()
 
     for _ in range(args.warmup):
         loss = step()
@@ -247,7 +279,7 @@ def train_main(args):
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "stage-3 (configs/obj.yaml) training step, 1 clip per GPU, AdamW, clip-norm 1.0, "
                                    "bucketed RCCL all-reduce of 152.5M fp32 Adapter gradients",
-                       "parallelism": f"dp{world}", "allreduce_bytes": sum(b["flat"].numel() * 4 for b in reducer.buckets)},
+                       "hip_graph": use_graph, "parallelism": f"dp{world}", "allreduce_bytes": sum(b["flat"].numel() * 4 for b in reducer.buckets)},
             "last_loss": float(loss)}), flush=True)
     if world > 1:
         dist.destroy_process_group()

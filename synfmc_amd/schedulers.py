@@ -65,7 +65,11 @@ class DDIMScheduler:
         return a_t, a_prev
 
     def add_noise(self, original_samples, noise, timesteps):
-        ac = self.alphas_cumprod.to(device=original_samples.device, dtype=original_samples.dtype)
+        key = (original_samples.device, original_samples.dtype)
+        cache = self.__dict__.setdefault("_ac_dev", {})
+        ac = cache.get(key)
+        if ac is None:                 # one host-to-device copy per (device, dtype): capturable in a HIP graph afterwards
+            ac = cache[key] = self.alphas_cumprod.to(device=original_samples.device, dtype=original_samples.dtype)
         timesteps = timesteps.to(original_samples.device)
         a = ac[timesteps] ** 0.5
         s = (1 - ac[timesteps]) ** 0.5
