@@ -201,10 +201,13 @@ int fmc_linear_bf16(const void* x, const void* w, const void* bias, const void* 
  *   temb | NULL: image i adds row (i / temb_img_div) of temb, rows `temb_row_stride` elements apart -- [n_img, Cout]
  *   contiguous is (Cout, 1); the U-Net passes a column slice of ONE projection of all 22 ResNet blocks' time embeddings,
  *   [clips, sum Cout], with temb_img_div = frames, so the reference's per-frame repeat never materialises.
+ *   upsample2x != 0: x is [n_img, H/2, W/2, Cin] and the convolution reads it through a nearest-neighbour 2x upsample
+ *   (diffusers Upsample2D, unet_blocks.py:625: `F.interpolate(scale_factor=2)` then conv) -- the 4x larger tensor is
+ *   never written; H, W stay the OUTPUT size.
  *   tile / split_k / workspace: as for fmc_linear_bf16 (M = n_img*H*W, N = Cout, K = 9*Cin). */
 int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, const void* temb, const void* residual, void* out,
-                     int n_img, int H, int W, int Cin, int Cout, int64_t temb_row_stride, int temb_img_div, int tile,
-                     int split_k, void* workspace, int64_t workspace_bytes, void* stream);
+                     int n_img, int H, int W, int Cin, int Cout, int64_t temb_row_stride, int temb_img_div,
+                     int upsample2x, int tile, int split_k, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Backward entry points (training stages 2/3 of the reference: the U-Net is frozen but the activation gradient

@@ -49,7 +49,7 @@ SIGNATURES = {
     "fmc_spatial_attn_bwd": (c_int, [c_void_p] * 10 + [c_int] * 5 + [c_int64] * 10 + [c_int, c_float, c_int, c_void_p]),
     "fmc_temporal_attn_bwd": (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_int64] * 9 + [c_float, c_int, c_void_p]),
     "fmc_conv3x3_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                 c_int, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
+                                 c_int, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
 }
 
 _lib = None

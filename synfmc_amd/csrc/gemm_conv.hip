@@ -45,6 +45,7 @@ struct GemmParams {
     int64_t lda, ldres, ldo;
     int img_h, img_w, cin, hw;        // conv mode
     int64_t temb_ld; int temb_div;    // temb row of image i = temb + (i / temb_div) * temb_ld
+    int ups;                          // conv mode: x is [n, H/2, W/2, Cin] and is read through a nearest 2x upsample
     float alpha;
     int tiles_m, tiles_n;
     int split_k;                      // > 1: k-tiles are dealt to split_k workgroups per output tile, which write fp32
@@ -208,7 +209,8 @@ void gemm_kernel(const GemmParams P) {
                 const int pix = (int)(mm % P.hw);
                 py[j] = pix / P.img_w;
                 px[j] = pix - py[j] * P.img_w;
-                src[j] = P.a + mm * P.cin + sc * 8;
+                if (P.ups) src[j] = P.a + (mm / P.hw) * (int64_t)(P.hw >> 2) * P.cin + sc * 8;   // image base (half-res)
+                else src[j] = P.a + mm * P.cin + sc * 8;
             }
         } else {
             const int rloc = RPP * (p - BM / RPP) + prow;
@@ -224,9 +226,10 @@ void gemm_kernel(const GemmParams P) {
         bf16_t* stage = smem + buf * STAGE_ELEMS;
         const bf16_t* zero = reinterpret_cast<const bf16_t*>(&g_zero16);
         int64_t shift = k0;
-        int dy = 0, dx = 0;
+        int dy = 0, dx = 0, ci0 = 0;
         if (MODE == 1) {
-            const int tap = k0 / P.cin, ci0 = k0 - tap * P.cin;
+            const int tap = k0 / P.cin;
+            ci0 = k0 - tap * P.cin;
             dy = tap / 3 - 1;
             dx = tap - (tap / 3) * 3 - 1;
             shift = ((int64_t)dy * P.img_w + dx) * P.cin + ci0;
@@ -239,7 +242,12 @@ void gemm_kernel(const GemmParams P) {
                 bool ok = val[j];
                 if (MODE == 1)
                     ok = ok && (unsigned)(py[j] + dy) < (unsigned)P.img_h && (unsigned)(px[j] + dx) < (unsigned)P.img_w;
-                dma16(ok ? src[j] + shift : zero, stage + p * 512);
+                if (MODE == 1 && P.ups) {            // tap (y+dy, x+dx) of the upsampled image = source pixel (.. >> 1)
+                    const int64_t so = ((int64_t)((py[j] + dy) >> 1) * (P.img_w >> 1) + ((px[j] + dx) >> 1)) * P.cin + ci0;
+                    dma16(ok ? src[j] + so : zero, stage + p * 512);
+                } else {
+                    dma16(ok ? src[j] + shift : zero, stage + p * 512);
+                }
             } else {
                 dma16(val[j] ? src[j] + k0 : zero, stage + p * 512);       // W rows follow the A rows in the stage
             }
@@ -638,7 +646,7 @@ extern "C" int fmc_linear_bf16(const void* x, const void* w, const void* bias, c
     P.a = (const bf16_t*)x; P.w = (const bf16_t*)w; P.bias = (const bf16_t*)bias; P.temb = nullptr;
     P.res = (const bf16_t*)residual; P.out = (bf16_t*)out;
     P.M = M; P.N = N; P.K = K; P.lda = ldx; P.ldres = ldres; P.ldo = ldo;
-    P.img_h = P.img_w = P.cin = 0; P.hw = 1; P.alpha = alpha; P.temb_ld = 0; P.temb_div = 1;
+    P.img_h = P.img_w = P.cin = 0; P.hw = 1; P.alpha = alpha; P.temb_ld = 0; P.temb_div = 1; P.ups = 0;
     hipStream_t st = (hipStream_t)stream;
     if (tile < 0 || tile > GEMM_TILE_MAX) FMC_FAIL(FMC_E_SHAPE, "linear_bf16: tile %d", tile);
     if (int rc = set_split_k(P, split_k, workspace, workspace_bytes, epilogue == 0, "linear_bf16")) return rc;
@@ -649,7 +657,7 @@ extern "C" int fmc_linear_bf16(const void* x, const void* w, const void* bias, c
 
 extern "C" int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, const void* temb, const void* residual,
                                 void* out, int n_img, int H, int W, int Cin, int Cout, int64_t temb_row_stride,
-                                int temb_img_div, int tile, int split_k,
+                                int temb_img_div, int upsample2x, int tile, int split_k,
                                 void* workspace, int64_t workspace_bytes, void* stream) {
     if (!x || !w || !out) FMC_FAIL(FMC_E_NULL, "conv3x3_bf16: NULL tensor");
     if (n_img <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % BK_MAX || Cout % 8)
@@ -664,6 +672,8 @@ extern "C" int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, 
     P.img_h = H; P.img_w = W; P.cin = Cin; P.hw = H * W; P.alpha = 1.f;
     if (temb && (temb_img_div < 1 || temb_row_stride % 8)) FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: temb_img_div >= 1, temb_row_stride %% 8 == 0");
     P.temb_ld = temb_row_stride; P.temb_div = temb_img_div < 1 ? 1 : temb_img_div;
+    if (upsample2x && ((H | W) & 1)) FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: upsample2x needs even H, W (the OUTPUT size)");
+    P.ups = upsample2x ? 1 : 0;
     if (tile < 0 || tile > GEMM_TILE_MAX) FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: tile %d", tile);
     if (int rc = set_split_k(P, split_k, workspace, workspace_bytes, true, "conv3x3_bf16")) return rc;
     launch_gemm<1, 0>(P, tile, (hipStream_t)stream);

@@ -535,12 +535,14 @@ def conv3x3_supported(x: torch.Tensor, weight: torch.Tensor, stride, padding) ->
 
 def conv3x3_bf16(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias: Optional[torch.Tensor] = None,
                  temb: Optional[torch.Tensor] = None, residual_nhwc: Optional[torch.Tensor] = None,
-                 tile: int = 0, split_k: int = 1, temb_div: int = 1) -> torch.Tensor:
+                 tile: int = 0, split_k: int = 1, temb_div: int = 1, upsample: bool = False) -> torch.Tensor:
     """x `[N, H, W, Cin]` contiguous, weight `[Cout, Cin, 3, 3]` in channels_last memory format (physically
     `[Cout, 3, 3, Cin]`), temb `[N // temb_div, Cout]` (rows may be strided: a column slice of a wider matrix),
     residual `[N, H, W, Cout]` -> `[N, H, W, Cout]`."""
     _dev(x_nhwc, weight_cl, bias, temb, residual_nhwc)
     n, h, w, cin = x_nhwc.shape
+    if upsample:                                        # x is the half-resolution source of a nearest 2x upsample
+        h, w = 2 * h, 2 * w
     cout = weight_cl.shape[0]
     assert x_nhwc.is_contiguous() and weight_cl.is_contiguous(memory_format=torch.channels_last)
     assert temb is None or (temb.stride(1) == 1 and temb.shape == (n // temb_div, cout) and n % temb_div == 0)
@@ -550,7 +552,8 @@ def conv3x3_bf16(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias: Optional[t
     ws, ws_bytes = _splitk_workspace(x_nhwc.device, split_k, n * h * w, cout)
     _lib.check(_lib.load().fmc_conv3x3_bf16(x_nhwc.data_ptr(), weight_cl.data_ptr(), _p(bias), _p(temb),
                                             _p(residual_nhwc), out.data_ptr(), n, h, w, cin, cout,
-                                            0 if temb is None else temb.stride(0), int(temb_div), int(tile),
+                                            0 if temb is None else temb.stride(0), int(temb_div), int(upsample),
+                                            int(tile),
                                             int(split_k), ws, ws_bytes, _stream()),
                "fmc_conv3x3_bf16")
     return out
@@ -658,13 +661,14 @@ def geglu_linear(x: torch.Tensor, weight: torch.Tensor, bias, weight_il: torch.T
 
 
 def conv3x3(x_nchw: torch.Tensor, weight_cl: torch.Tensor, bias, temb=None, residual_nchw=None, stride=(1, 1),
-            padding=(1, 1), temb_div: int = 1) -> torch.Tensor:
+            padding=(1, 1), temb_div: int = 1, upsample: bool = False) -> torch.Tensor:
     """3x3 conv on a logical NCHW / physical channels-last tensor with `+ temb[:, :, None, None]` and `+ residual`.
     Returns a logical NCHW view over channels-last storage."""
     import torch.nn.functional as F
 
     def lib():
-        y = F.conv2d(x_nchw, weight_cl, bias, stride, padding)
+        xin = F.interpolate(x_nchw, scale_factor=2.0, mode="nearest") if upsample else x_nchw
+        y = F.conv2d(xin, weight_cl, bias, stride, padding)
         if temb is not None:
             y = y + (temb if temb_div == 1 else temb.repeat_interleave(temb_div, dim=0))[:, :, None, None]
         if residual_nchw is not None:
@@ -679,8 +683,11 @@ def conv3x3(x_nchw: torch.Tensor, weight_cl: torch.Tensor, bias, temb=None, resi
     r = None if residual_nchw is None else residual_nchw.permute(0, 2, 3, 1)
     if not x.is_contiguous() or (r is not None and not r.is_contiguous()):
         return lib()
-    key = ("conv", n, h, w, cin, cout, temb is not None, r is not None)
-    hip = lambda tile: conv3x3_bf16(x, weight_cl, bias, temb, r, tile=tile, temb_div=temb_div).permute(0, 3, 1, 2)
+    if upsample:
+        h, w = 2 * h, 2 * w
+    key = ("conv", n, h, w, cin, cout, temb is not None, r is not None, upsample)
+    hip = lambda tile: conv3x3_bf16(x, weight_cl, bias, temb, r, tile=tile, temb_div=temb_div,
+                                    upsample=upsample).permute(0, 3, 1, 2)
     tiles = ((n * h * w + 127) // 128) * ((cout + 127) // 128)
     use = _pick(key, hip, lib, tiles >= 256, split_arms(n * h * w, cout, 9 * cin))
     return lib() if use == 0 else hip(max(use, 0))

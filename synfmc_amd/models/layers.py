@@ -78,9 +78,10 @@ class Conv2d(nn.Conv2d):
     """MIOpen conv on channels-last storage; 1x1 stride-1 convs run as a token GEMM (hipBLASLt)."""
 
     def forward(self, x: torch.Tensor, scale: float = 1.0, temb: Optional[torch.Tensor] = None,
-                residual: Optional[torch.Tensor] = None, temb_div: int = 1) -> torch.Tensor:
+                residual: Optional[torch.Tensor] = None, temb_div: int = 1, upsample: bool = False) -> torch.Tensor:
         """conv(x) [+ temb[:, :, None, None]] [+ residual]; the two extras ride in the kernel epilogue when the
-        gfx950 implicit-GEMM conv / GEMM is used.  `temb_div` > 1: image i uses temb row i // temb_div."""
+        gfx950 implicit-GEMM conv / GEMM is used.  `temb_div` > 1: image i uses temb row i // temb_div.
+        `upsample`: conv(nearest-2x(x)) with the upsample folded into the kernel's operand addressing."""
         if self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0):
             n, c, h, w = x.shape
             assert temb is None
@@ -91,7 +92,10 @@ class Conv2d(nn.Conv2d):
             x = x.contiguous(memory_format=torch.channels_last)
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)
         if self.kernel_size == (3, 3) and self.dilation == (1, 1) and self.groups == 1 and x.is_cuda and not needs_grad:
-            return K.conv3x3(x, self._weight_cl(), self.bias, temb, residual, self.stride, self.padding, temb_div)
+            return K.conv3x3(x, self._weight_cl(), self.bias, temb, residual, self.stride, self.padding, temb_div,
+                             upsample)
+        if upsample:
+            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
         y = F.conv2d(x, self._weight_cl(), self.bias, self.stride, self.padding, self.dilation, self.groups)
         if temb is not None:
             y = y + (temb if temb_div == 1 else temb.repeat_interleave(temb_div, dim=0))[:, :, None, None]
@@ -252,8 +256,8 @@ class Upsample2D(nn.Module):
         assert hidden_states.shape[1] == self.channels
         if not hidden_states.is_contiguous(memory_format=torch.channels_last):
             hidden_states = hidden_states.contiguous(memory_format=torch.channels_last)
-        if output_size is None:
-            hidden_states = F.interpolate(hidden_states, scale_factor=2.0, mode="nearest")
+        if output_size is None or tuple(output_size) == (2 * hidden_states.shape[-2], 2 * hidden_states.shape[-1]):
+            return self.conv(hidden_states, upsample=True)           # the 4x larger tensor is never materialised
         else:
             hidden_states = F.interpolate(hidden_states, size=output_size, mode="nearest")
         return self.conv(hidden_states)

@@ -439,6 +439,21 @@ def test_conv3x3_bf16_fused_epilogue(K, n, H, W, cin, cout, temb, res):
     assert rel_inf(out.permute(0, 3, 1, 2).float(), ref) < 1e-2
 
 
+@pytest.mark.parametrize("tile", [0, 1, 3, 11, 128 + 2])
+def test_conv3x3_bf16_fused_upsample(K, tile):
+    """diffusers Upsample2D: nearest 2x then 3x3 conv; the kernel reads the half-resolution source directly"""
+    dtype = torch.bfloat16
+    n, cin, cout, h, w = 3, 128, 320, 10, 14
+    xo, xd = rnd((n, cin, h, w), 75, dtype)
+    wo, wd = rnd((cout, cin, 3, 3), 76, dtype, scale=(9 * cin) ** -0.5)
+    bo, bd = rnd((cout,), 77, dtype)
+    ref = F.conv2d(F.interpolate(xo, scale_factor=2.0, mode="nearest"), wo, bo, 1, 1)
+    out = K.conv3x3_bf16(xd.permute(0, 2, 3, 1).contiguous(), wd.contiguous(memory_format=torch.channels_last), bd,
+                         None, None, tile=tile, upsample=True)
+    assert out.shape == (n, 2 * h, 2 * w, cout)
+    assert rel_inf(out.permute(0, 3, 1, 2).float(), ref) < 1e-2
+
+
 # ---------------------------------------------------------------------------------------------
 # backward kernels vs autograd through the oracle's forward (fp32 CPU)
 # ---------------------------------------------------------------------------------------------
