@@ -124,7 +124,6 @@ void gemm_kernel(const GemmParams P) {
     constexpr int PIECES = (BM + BN) / RPP;          // pieces per k-tile
     constexpr int PPW = (PIECES + NW - 1) / NW;      // pieces per wave (the last round may be ragged)
     constexpr int CP = BN + 8;                       // fp32 C slab pitch
-    static_assert(PIECES % NW == 0 || STAGES == 2, "counted vmcnt needs the same number of pieces in every wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -237,7 +236,10 @@ void gemm_kernel(const GemmParams P) {
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
             const int p = wave + NW * j;             // wave-uniform
-            if (p >= PIECES) continue;
+            if (p >= PIECES) {                       // ragged last round: with a counted vmcnt every wave must issue the
+                if (STAGES > 2) dma16(zero, smem + STAGES * STAGE_ELEMS);   // same number of DMAs -> dummy into a scratch KiB
+                continue;
+            }
             if (p < BM / RPP) {
                 bool ok = val[j];
                 if (MODE == 1)
@@ -343,6 +345,21 @@ void gemm_kernel(const GemmParams P) {
 #pragma unroll
     for (int part = 0; part < MI / 2; ++part) {      // 64-row slab hm: rows [64*part, 64*part+64) of wave row hw
         const int hm = hw * (MI / 2) + part;
+        // the residual rows of this slab are requested NOW, all at once and branch-free, so that their latency runs under
+        // the slab staging below (one load per row inside the output loop is one exposed memory round trip per row:
+        // 8 of them were ~12 us of a 26 us workgroup on the K = 320 projections)
+        constexpr int E_CPR = BN / 8, E_RSTEP = NT / E_CPR, E_IT = 64 / E_RSTEP;
+        static_assert(64 % E_RSTEP == 0, "slab rows must divide over the threads");
+        u32x4 resv[E_IT];
+        if (EPI == 0 && P.res && !(SK && sk_partial) && P.split_k == 1) {
+            const int ch = tid % E_CPR;
+            const int nn = min(n0 + ch * 8, P.N - 8);
+#pragma unroll
+            for (int it = 0; it < E_IT; ++it) {
+                const int64_t m = min(m0 + hm * 64 + tid / E_CPR + it * E_RSTEP, P.M - 1);
+                resv[it] = *reinterpret_cast<const u32x4*>(P.res + m * P.ldres + nn);
+            }
+        }
         __syncthreads();
         if (wm == hw) {
 #pragma unroll
@@ -405,7 +422,9 @@ void gemm_kernel(const GemmParams P) {
                 float bv[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) bv[i] = P.bias ? bf2f(P.bias[n + i]) : 0.f;
-                for (int r = tid / CPR; r < 64; r += RSTEP) {
+#pragma unroll
+                for (int it = 0; it < E_IT; ++it) {
+                    const int r = tid / CPR + it * RSTEP;
                     const int64_t m = m0 + hm * 64 + r;
                     if (m >= P.M) continue;
                     float v[8];
@@ -419,10 +438,11 @@ void gemm_kernel(const GemmParams P) {
                         for (int k = 0; k < 8; ++k) v[k] += t[k];
                     }
                     if (P.res) {
-                        float t[8];
-                        Vec8<bf16_t>::load(P.res + m * P.ldres + n, t);
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) v[k] += t[k];
+                        for (int k = 0; k < 4; ++k) {
+                            v[2 * k] += __uint_as_float(resv[it][k] << 16);
+                            v[2 * k + 1] += __uint_as_float(resv[it][k] & 0xffff0000u);
+                        }
                     }
                     Vec8<bf16_t>::store(P.out + m * P.ldo + n, v);
                 }
@@ -539,7 +559,7 @@ void launch_gemm_g(GemmParams& P, hipStream_t st) {
     constexpr int BM = 32 * MI * WM, BN = 64 * WN;
     P.tiles_m = (int)((P.M + BM - 1) / BM);
     P.tiles_n = (P.N + BN - 1) / BN;
-    size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(bf16_t);
+    size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(bf16_t) + 1024;
     const size_t slab = (size_t)64 * (BN + 8) * sizeof(float);
     if (slab > lds) lds = slab;
     unsigned grid = (unsigned)(P.tiles_m * P.tiles_n * P.split_k);
@@ -572,7 +592,7 @@ void launch_gemm_g(GemmParams& P, hipStream_t st) {
 }
 
 // tile arms (fmc_hip.h): geometry x k-tile depth x ring depth
-constexpr int GEMM_TILE_MAX = 11;
+constexpr int GEMM_TILE_MAX = 12;
 
 // geometry: the largest tile that still gives every CU work and does not waste more than ~20 % of N
 template <int MODE, int EPI>
@@ -587,6 +607,10 @@ void launch_gemm(GemmParams& P, int tile, hipStream_t st) {
         else g = 1;
     }
     switch (g) {
+        case 12:                                         // 128x320, 32-deep k-tiles, 4-stage ring
+            if constexpr (EPI == 0) launch_gemm_g<MODE, EPI, 2, 5, 32, 4>(P, st);
+            else launch_gemm_g<MODE, EPI, 4, 4, 64, 2>(P, st);
+            break;
         case 11:                                         // 128x320: 2 x 5 waves (plain epilogue only)
             if constexpr (EPI == 0) launch_gemm_g<MODE, EPI, 2, 5, 64, 2>(P, st);
             else launch_gemm_g<MODE, EPI, 4, 4, 64, 2>(P, st);

@@ -318,7 +318,7 @@ def test_linear_bf16_fused_epilogue(K, M, N, Kd, bias, res, alpha):
     assert torch.equal(out2, out)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 def test_gemm_tile_geometries_agree(K, tile):
     """every `tile` arm (3 geometries x k-tile depth 64 / 32 x ring depth 2..4) must compute the same function, ragged edges included"""
     dtype = torch.bfloat16

@@ -31,3 +31,17 @@ for M, C in [(81920, 320), (20480, 640)]:
     wi, _ = interleave_geglu(w, None)
     row(f"geglu M={M} C={C}", 2.0 * M * C * 8 * C,
         [("lib", lambda: K.geglu(F.linear(a, w)))] + [(t, lambda t=t: K.linear_bf16(a, wi, None, geglu=True, tile=t)) for t in tiles])
+print("--- with residual epilogue (us per call)")
+for M, Kd, N in [(81920, 320, 320), (20480, 640, 640), (5120, 1280, 1280), (81920, 1280, 320)]:
+    a = torch.randn(M, Kd, device=dev, dtype=dt)
+    w2 = torch.randn(N, Kd, device=dev, dtype=dt) * 0.02
+    b2 = torch.zeros(N, device=dev, dtype=dt)
+    r2 = torch.randn(M, N, device=dev, dtype=dt)
+    print(f"lin+res M={M} K={Kd} N={N}: lib {K._time_ms(lambda: F.linear(a, w2, b2) + r2) * 1e3:6.1f} | " +
+          " ".join(f"{t}:{K._time_ms(lambda t=t: K.linear_bf16(a, w2, b2, r2, tile=t)) * 1e3:6.1f}" for t in tiles), flush=True)
+for n, ci, co, h, w_ in [(32, 320, 320, 40, 64), (32, 1280, 1280, 10, 16)]:
+    x = torch.randn(n, h, w_, ci, device=dev, dtype=dt)
+    wt = (torch.randn(co, ci, 3, 3, device=dev, dtype=dt) * 0.02).contiguous(memory_format=torch.channels_last)
+    r = torch.randn(n, h, w_, co, device=dev, dtype=dt)
+    print(f"conv+res {n}x{h}x{w_} {ci}->{co}: " +
+          " ".join(f"{t}:{K._time_ms(lambda t=t: K.conv3x3_bf16(x, wt, None, None, r, tile=t)) * 1e3:6.1f}" for t in tiles), flush=True)
