@@ -82,7 +82,23 @@ __global__ void gn_partial_kernel(const T* __restrict__ x, const T* __restrict__
     for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
     const T* xb = x + (size_t)n * HW * C + c0;
     const T* dyb = (MODE == 1) ? dy + (size_t)n * HW * C + c0 : nullptr;
-    for (int r = row0 + rsub; r < row1; r += rpi) {
+    if (MODE == 0) {
+        for (int r = row0 + rsub; r < row1; r += 4 * rpi) {       // four rows per trip, all loads first
+            float v4[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rr = r + u * rpi;
+                Vec8<T>::load(xb + (size_t)(rr < row1 ? rr : row1 - 1) * C, v4[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float m = (r + u * rpi) < row1 ? 1.f : 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float t = v4[u][i] * m; s1[i] += t; s2[i] += t * v4[u][i]; }
+            }
+        }
+    }
+    for (int r = row0 + rsub; MODE == 1 && r < row1; r += rpi) {
         float v[8];
         Vec8<T>::load(xb + (size_t)r * C, v);
         if (MODE == 0) {
@@ -172,15 +188,24 @@ __global__ void gn_apply_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, 
     if (row1 > HW) row1 = HW;
     const T* xb = x + (size_t)n * HW * C + c0;
     T* yb = y + (size_t)n * HW * C + c0;
-    for (int r = row0 + rsub; r < row1; r += rpi) {
-        float v[8];
-        Vec8<T>::load(xb + (size_t)r * C, v);
+    // four rows per trip, loads first (branch-free, clamped): a row per trip leaves one 16-byte load in flight per thread
+    for (int r = row0 + rsub; r < row1; r += 4 * rpi) {
+        float v[4][8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float z = v[i] * aco[i] + bco[i];
-            v[i] = act ? silu_f(z) : z;
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + u * rpi;
+            Vec8<T>::load(xb + (size_t)(rr < row1 ? rr : row1 - 1) * C, v[u]);
         }
-        Vec8<T>::store(yb + (size_t)r * C, v);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + u * rpi;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float z = v[u][i] * aco[i] + bco[i];
+                v[u][i] = act ? silu_f(z) : z;
+            }
+            if (rr < row1) Vec8<T>::store(yb + (size_t)rr * C, v[u]);
+        }
     }
 }
 
