@@ -93,37 +93,61 @@ __device__ __forceinline__ float fold_max(const f32x16& s, float w) {
     return max3(max3(ma, mb, s[7]), s[15], w);
 }
 
-template <typename T, int NKS, bool TAIL>
-__device__ __forceinline__ void attn_block(const T* __restrict__ Ks, const T* __restrict__ Vt, const Frag<T> (&qf)[NKS],
-                                           f32x16 (&oacc)[(NKS + 1) / 2], const f32x16& negm, float& worst, float& l_run,
-                                           int sb, int kvb, int Skv, int l31, int half) {
+// NQ 32-query blocks per wave share every K / V^T fragment read: per 32 keys 3 + 4 LDS fragment loads feed 7*NQ MFMAs
+// (at NQ = 1 the LDS port is ~80 % busy at d = 40: 12 waves per CU x 44 LDS cycles per 224 MFMA cycles)
+template <typename T, int NKS, int NQ, bool TAIL>
+__device__ __forceinline__ void attn_block(const T* __restrict__ Ks, const T* __restrict__ Vt, const Frag<T> (&qf)[NQ][NKS],
+                                           f32x16 (&oacc)[NQ][(NKS + 1) / 2], const f32x16 (&negm)[NQ], float (&worst)[NQ],
+                                           float (&l_run)[NQ], int sb, int kvb, int Skv, int l31, int half) {
     constexpr int NDT = (NKS + 1) / 2;
+    constexpr int KP = NKS * 16 + 8;
     constexpr int VP = SA_BK + 4;
     constexpr bool LROW = (NKS & 1) != 0;
-    const f32x16 s = qk_block<T, NKS, TAIL>(Ks, qf, negm, sb, kvb, Skv, l31, half);
-    worst = fold_max(s, worst);
-    float p[16];
+    f32x16 s[NQ];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(s[r]);
-    if (!LROW) {
-        float psum = 0.f;
+    for (int nq = 0; nq < NQ; ++nq) s[nq] = negm[nq];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) psum += p[r];
-        l_run += psum;
+    for (int ks = 0; ks < NKS; ++ks) {
+        Frag<T> kf;
+        make_frag<T>(Ks + (sb * 32 + l31) * KP + ks * 16 + half * 8, kf);
+#pragma unroll
+        for (int nq = 0; nq < NQ; ++nq) mma32(kf, qf[nq][ks], s[nq]);
+    }
+    Frag<T> pf[NQ][2];
+#pragma unroll
+    for (int nq = 0; nq < NQ; ++nq) {
+        if (TAIL) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kvb + (r & 3) + 8 * (r >> 2) + 4 * half >= Skv) s[nq][r] = -INFINITY;
+        }
+        worst[nq] = fold_max(s[nq], worst[nq]);
+        float p[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(s[nq][r]);
+        if (!LROW) {
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) psum += p[r];
+            l_run[nq] += psum;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float p8[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) p8[i] = p[s2 * 8 + i];
+            p_frag(p8, pf[nq][s2]);
+        }
     }
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-        float p8[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) p8[i] = p[s2 * 8 + i];
-        Frag<T> pf;
-        p_frag(p8, pf);
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
             const T* vrow = Vt + (dt * 32 + l31) * VP + sb * 32 + s2 * 16 + half * 4;
             Frag<T> vf;
             make_frag_2x4<T>(vrow, vrow + 8, vf);
-            mma32(vf, pf, oacc[dt]);
+#pragma unroll
+            for (int nq = 0; nq < NQ; ++nq) mma32(vf, pf[nq][s2], oacc[nq][dt]);
         }
     }
 }
@@ -135,8 +159,8 @@ template <> __device__ __forceinline__ bf16_t to_elem<bf16_t>(float v) { return 
 template <> __device__ __forceinline__ float to_elem<float>(float v) { return v; }
 
 // PREFETCH keeps the next K/V tile in registers under the current tile's MFMAs (costs ~40 VGPRs).
-template <typename T, int NKS, bool SHORT_KV, bool PREFETCH>
-__global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 ? 3 : 2) : 1) void spatial_attn_kernel(const SAParams P) {
+template <typename T, int NKS, bool SHORT_KV, bool PREFETCH, int NQ>
+__global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 && NQ == 1 ? 3 : 2) : 1) void spatial_attn_kernel(const SAParams P) {
     constexpr int NDT = (NKS + 1) / 2;
     constexpr int DP16 = NKS * 16;
     constexpr int KP = DP16 + 8;        // K tile pitch (elements)
@@ -169,19 +193,23 @@ __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 ? 3 : 2
     T* og = (T*)P.o + (int64_t)b * P.obs + (int64_t)h * D;
 
     // ---- Q^T fragments (B operand of S^T = K Q^T), kept in registers -----------------------------
-    const int qrow = qblk * SA_BQ + wave * 32 + l31;
-    Frag<T> qf[NKS];
+    int qrow[NQ];
+    Frag<T> qf[NQ][NKS];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        const int d0 = ks * 16 + half * 8;
-        if (qrow < P.Sq && d0 < D) {
-            float qv[8];
-            Vec8<T>::load(qg + (int64_t)qrow * P.qrs + d0, qv);
+    for (int nq = 0; nq < NQ; ++nq) {
+        qrow[nq] = (qblk * SA_WAVES + wave) * (32 * NQ) + nq * 32 + l31;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) qv[i] *= P.scale_log2;
-            p_frag(qv, qf[ks]);       // fp32 values -> fragment(s): bf16 rounding / hi+lo split
-        } else {
-            zero(qf[ks]);
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int d0 = ks * 16 + half * 8;
+            if (qrow[nq] < P.Sq && d0 < D) {
+                float qv[8];
+                Vec8<T>::load(qg + (int64_t)qrow[nq] * P.qrs + d0, qv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) qv[i] *= P.scale_log2;
+                p_frag(qv, qf[nq][ks]);   // fp32 values -> fragment(s): bf16 rounding / hi+lo split
+            } else {
+                zero(qf[nq][ks]);
+            }
         }
     }
 
@@ -263,28 +291,35 @@ __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 ? 3 : 2
     if (PREFETCH) { gload(0); lstore(); } else { stage_rolled(0); }
     __syncthreads();
     if (PREFETCH && ntiles > 1) gload(SA_BK);
-    float m_ref;
-    f32x16 negm;
+    float m_ref[NQ];
+    f32x16 negm[NQ];
     {
         f32x16 zero16;
 #pragma unroll
         for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
-        float mx = fold_max(qk_block<T, NKS, true>(Ks, qf, zero16, 0, 0, P.Skv, l31, half), -INFINITY);
-        if (P.Skv > 32) mx = fold_max(qk_block<T, NKS, true>(Ks, qf, zero16, 1, 32, P.Skv, l31, half), mx);
-        m_ref = fmaxf(mx, __shfl_xor(mx, 32, 64));   // finite: key 0 always exists
 #pragma unroll
-        for (int r = 0; r < 16; ++r) negm[r] = -m_ref;
+        for (int nq = 0; nq < NQ; ++nq) {
+            float mx = fold_max(qk_block<T, NKS, true>(Ks, qf[nq], zero16, 0, 0, P.Skv, l31, half), -INFINITY);
+            if (P.Skv > 32) mx = fold_max(qk_block<T, NKS, true>(Ks, qf[nq], zero16, 1, 32, P.Skv, l31, half), mx);
+            m_ref[nq] = fmaxf(mx, __shfl_xor(mx, 32, 64));   // finite: key 0 always exists
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[nq][r] = -m_ref[nq];
+        }
     }
 
-    f32x16 oacc[NDT];
-    float l_run;
+    f32x16 oacc[NQ][NDT];
+    float l_run[NQ];
     for (int pass = 0; pass < 2; ++pass) {
+        float worst[NQ];           // max over all keys of s - m_ref (this lane's half of the keys)
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt)
+        for (int nq = 0; nq < NQ; ++nq) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-        l_run = 0.f;
-        float worst = -INFINITY;   // max over all keys of s - m_ref (this lane's half of the keys)
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[nq][dt][r] = 0.f;
+            l_run[nq] = 0.f;
+            worst[nq] = -INFINITY;
+        }
 
         auto stage = [&](int tile) {
             if (tile > 0 || pass > 0) {             // tile 0 is already resident after the prologue
@@ -301,59 +336,69 @@ __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 ? 3 : 2
             stage(tile);
 #pragma unroll
             for (int sb = 0; sb < SA_BK / 32; ++sb)
-                attn_block<T, NKS, false>(Ks, Vt, qf, oacc, negm, worst, l_run, sb, tile * SA_BK + sb * 32, P.Skv, l31, half);
+                attn_block<T, NKS, NQ, false>(Ks, Vt, qf, oacc, negm, worst, l_run, sb, tile * SA_BK + sb * 32, P.Skv, l31, half);
         }
         if (nfull < ntiles) {
             stage(nfull);
 #pragma unroll
             for (int sb = 0; sb < SA_BK / 32; ++sb)
                 if (nfull * SA_BK + sb * 32 < P.Skv)           // block-uniform
-                    attn_block<T, NKS, true>(Ks, Vt, qf, oacc, negm, worst, l_run, sb, nfull * SA_BK + sb * 32, P.Skv, l31, half);
+                    attn_block<T, NKS, NQ, true>(Ks, Vt, qf, oacc, negm, worst, l_run, sb, nfull * SA_BK + sb * 32, P.Skv, l31, half);
         }
         // did any row of this workgroup leave the safe range of the fixed reference?  (block-uniform decision)
-        if (!__syncthreads_or(worst > REF_LIMIT)) break;
-        m_ref += fmaxf(worst, __shfl_xor(worst, 32, 64));     // now the exact row maximum
+        bool bad = false;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) negm[r] = -m_ref;
+        for (int nq = 0; nq < NQ; ++nq) bad = bad || worst[nq] > REF_LIMIT;
+        if (!__syncthreads_or(bad)) break;
+#pragma unroll
+        for (int nq = 0; nq < NQ; ++nq) {
+            m_ref[nq] += fmaxf(worst[nq], __shfl_xor(worst[nq], 32, 64));     // now the exact row maximum
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[nq][r] = -m_ref[nq];
+        }
     }
-    const float m_run = m_ref;
 
     // ---- epilogue ----------------------------------------------------------------------------------
-    float l_tot;
-    if (LROW) l_tot = __shfl(oacc[NDT - 1][15], l31 + 32, 64);   // row NDT*32-1 lives in the upper half's register 15
-    else l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.f / l_tot;
-    if (qrow < P.Sq) {
-        T* orow = og + (int64_t)qrow * P.ors;
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
+    for (int nq = 0; nq < NQ; ++nq) {
+        float l_tot;
+        if (LROW) l_tot = __shfl(oacc[nq][NDT - 1][15], l31 + 32, 64);   // row NDT*32-1 lives in the upper half's register 15
+        else l_tot = l_run[nq] + __shfl_xor(l_run[nq], 32, 64);
+        const float inv = 1.f / l_tot;
+        if (qrow[nq] < P.Sq) {
+            T* orow = og + (int64_t)qrow[nq] * P.ors;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d = dt * 32 + 8 * g + 4 * half;
-                if (d < D)
-                    store4<T>(orow + d, oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv, oacc[dt][4 * g + 2] * inv,
-                              oacc[dt][4 * g + 3] * inv);
+            for (int dt = 0; dt < NDT; ++dt) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = dt * 32 + 8 * g + 4 * half;
+                    if (d < D)
+                        store4<T>(orow + d, oacc[nq][dt][4 * g] * inv, oacc[nq][dt][4 * g + 1] * inv,
+                                  oacc[nq][dt][4 * g + 2] * inv, oacc[nq][dt][4 * g + 3] * inv);
+                }
             }
+            if (P.lse && half == 0)
+                P.lse[((int64_t)b * P.H + h) * P.Sq + qrow[nq]] = m_ref[nq] * 0.6931471805599453f + logf(l_tot);
         }
-        if (P.lse && half == 0)
-            P.lse[((int64_t)b * P.H + h) * P.Sq + qrow] = m_run * 0.6931471805599453f + logf(l_tot);
     }
 }
 
-template <typename T, int NKS, bool SHORT_KV, bool PF>
-void launch_sa_v(const SAParams& P, hipStream_t st) {
+template <typename T, int NKS, bool SHORT_KV, bool PF, int NQ = 1>
+void launch_sa_v(const SAParams& Pin, hipStream_t st) {
+    SAParams P = Pin;
+    P.nqblk = (P.Sq + SA_BQ * NQ - 1) / (SA_BQ * NQ);
     constexpr int NDT = (NKS + 1) / 2;
     const size_t lds = sizeof(T) * ((size_t)SA_BK * (NKS * 16 + 8) + (size_t)NDT * 32 * (SA_BK + 4));
     dim3 grid((unsigned)(P.B * P.H * P.nqblk)), block(64 * SA_WAVES);
     if (lds > 64 * 1024) {  // gfx950 has 160 KiB of LDS per CU; opting in is needed above 64 KiB
         static bool raised = false;
         if (!raised) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_attn_kernel<T, NKS, SHORT_KV, PF>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_attn_kernel<T, NKS, SHORT_KV, PF, NQ>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             raised = true;
         }
     }
-    hipLaunchKernelGGL((spatial_attn_kernel<T, NKS, SHORT_KV, PF>), grid, block, lds, st, P);
+    hipLaunchKernelGGL((spatial_attn_kernel<T, NKS, SHORT_KV, PF, NQ>), grid, block, lds, st, P);
 }
 
 // FMC_SA_PREFETCH=0/1 overrides the default policy (experiments only)
@@ -361,6 +406,14 @@ inline int sa_prefetch_env() {
     static const int v = [] {
         const char* e = getenv("FMC_SA_PREFETCH");
         return e ? atoi(e) : -1;
+    }();
+    return v;
+}
+
+inline int sa_nq_env() {              // FMC_SA_NQ = 1 | 2 query blocks per wave for d <= 48 (default 2)
+    static const int v = [] {
+        const char* e = getenv("FMC_SA_NQ");
+        return e ? atoi(e) : 2;
     }();
     return v;
 }
@@ -375,7 +428,12 @@ void launch_sa(const SAParams& P, hipStream_t st) {
     } else {
         if constexpr (sizeof(T) == 2 && NKS <= 6) {
             const int e = sa_prefetch_env();
-            if (e < 0 ? SA_PREFETCH_DEFAULT : e != 0) return launch_sa_v<T, NKS, false, true>(P, st);
+            if (e < 0 ? SA_PREFETCH_DEFAULT : e != 0) {
+                if constexpr (NKS <= 3) {
+                    if (sa_nq_env() == 2 && P.Sq >= 2 * SA_BQ) return launch_sa_v<T, NKS, false, true, 2>(P, st);
+                }
+                return launch_sa_v<T, NKS, false, true>(P, st);
+            }
         }
         launch_sa_v<T, NKS, false, false>(P, st);
     }
