@@ -422,7 +422,12 @@ template <typename T, int NKS>
 void launch_sa(const SAParams& P, hipStream_t st) {
     if (P.Skv <= 2 * SA_BK) {
         if constexpr (sizeof(T) == 2 && NKS <= 6) {
-            if (sa_prefetch_env() != 0 && P.Skv > SA_BK) return launch_sa_v<T, NKS, true, true>(P, st);
+            if (sa_prefetch_env() != 0 && P.Skv > SA_BK) {
+                if constexpr (NKS <= 3) {
+                    if (sa_nq_env() == 2 && P.Sq >= 2 * SA_BQ) return launch_sa_v<T, NKS, true, true, 2>(P, st);
+                }
+                return launch_sa_v<T, NKS, true, true>(P, st);
+            }
         }
         launch_sa_v<T, NKS, true, false>(P, st);
     } else {
