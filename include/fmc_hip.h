@@ -203,7 +203,8 @@ int fmc_linear_bf16(const void* x, const void* w, const void* bias, const void* 
  *   [clips, sum Cout], with temb_img_div = frames, so the reference's per-frame repeat never materialises.
  *   upsample2x != 0: x is [n_img, H/2, W/2, Cin] and the convolution reads it through a nearest-neighbour 2x upsample
  *   (diffusers Upsample2D, unet_blocks.py:625: `F.interpolate(scale_factor=2)` then conv) -- the 4x larger tensor is
- *   never written; H, W stay the OUTPUT size.
+ *   never written; H, W stay the OUTPUT size.  upsample2x == 2: stride-2 convolution (diffusers Downsample2D,
+ *   unet_blocks.py:350: 3x3, stride 2, pad 1): x is [n_img, 2H, 2W, Cin], H, W the OUTPUT size.
  *   tile / split_k / workspace: as for fmc_linear_bf16 (M = n_img*H*W, N = Cout, K = 9*Cin). */
 int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, const void* temb, const void* residual, void* out,
                      int n_img, int H, int W, int Cin, int Cout, int64_t temb_row_stride, int temb_img_div,

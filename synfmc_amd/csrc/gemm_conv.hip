@@ -45,7 +45,8 @@ struct GemmParams {
     int64_t lda, ldres, ldo;
     int img_h, img_w, cin, hw;        // conv mode
     int64_t temb_ld; int temb_div;    // temb row of image i = temb + (i / temb_div) * temb_ld
-    int ups;                          // conv mode: x is [n, H/2, W/2, Cin] and is read through a nearest 2x upsample
+    int ups;                          // conv mode: 1 = x is [n, H/2, W/2, Cin], read through a nearest 2x upsample;
+                                      //            2 = stride-2 convolution, x is [n, 2H, 2W, Cin]  (H, W = output size)
     float alpha;
     int tiles_m, tiles_n;
     int split_k;                      // > 1: k-tiles are dealt to split_k workgroups per output tile, which write fp32
@@ -208,7 +209,8 @@ void gemm_kernel(const GemmParams P) {
                 const int pix = (int)(mm % P.hw);
                 py[j] = pix / P.img_w;
                 px[j] = pix - py[j] * P.img_w;
-                if (P.ups) src[j] = P.a + (mm / P.hw) * (int64_t)(P.hw >> 2) * P.cin + sc * 8;   // image base (half-res)
+                if (P.ups == 1) src[j] = P.a + (mm / P.hw) * (int64_t)(P.hw >> 2) * P.cin + sc * 8;   // image base (half-res)
+                else if (P.ups == 2) src[j] = P.a + (mm / P.hw) * (int64_t)(P.hw << 2) * P.cin + sc * 8;   // image base (2x res)
                 else src[j] = P.a + mm * P.cin + sc * 8;
             }
         } else {
@@ -244,9 +246,13 @@ void gemm_kernel(const GemmParams P) {
                 bool ok = val[j];
                 if (MODE == 1)
                     ok = ok && (unsigned)(py[j] + dy) < (unsigned)P.img_h && (unsigned)(px[j] + dx) < (unsigned)P.img_w;
-                if (MODE == 1 && P.ups) {            // tap (y+dy, x+dx) of the upsampled image = source pixel (.. >> 1)
+                if (MODE == 1 && P.ups == 1) {       // tap (y+dy, x+dx) of the upsampled image = source pixel (.. >> 1)
                     const int64_t so = ((int64_t)((py[j] + dy) >> 1) * (P.img_w >> 1) + ((px[j] + dx) >> 1)) * P.cin + ci0;
                     dma16(ok ? src[j] + so : zero, stage + p * 512);
+                } else if (MODE == 1 && P.ups == 2) {   // stride 2, pad 1: input pixel (2y+dy, 2x+dx) of the 2H x 2W image
+                    const int iy = 2 * py[j] + dy, ix = 2 * px[j] + dx;
+                    const bool ok2 = val[j] && iy >= 0 && ix >= 0;                // (the high side is always inside)
+                    dma16(ok2 ? src[j] + ((int64_t)iy * (2 * P.img_w) + ix) * P.cin + ci0 : zero, stage + p * 512);
                 } else {
                     dma16(ok ? src[j] + shift : zero, stage + p * 512);
                 }
@@ -696,8 +702,9 @@ extern "C" int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, 
     P.img_h = H; P.img_w = W; P.cin = Cin; P.hw = H * W; P.alpha = 1.f;
     if (temb && (temb_img_div < 1 || temb_row_stride % 8)) FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: temb_img_div >= 1, temb_row_stride %% 8 == 0");
     P.temb_ld = temb_row_stride; P.temb_div = temb_img_div < 1 ? 1 : temb_img_div;
-    if (upsample2x && ((H | W) & 1)) FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: upsample2x needs even H, W (the OUTPUT size)");
-    P.ups = upsample2x ? 1 : 0;
+    if (upsample2x < 0 || upsample2x > 2) FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: resample mode %d", upsample2x);
+    if (upsample2x == 1 && ((H | W) & 1)) FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: upsample2x needs even H, W (the OUTPUT size)");
+    P.ups = upsample2x;
     if (tile < 0 || tile > GEMM_TILE_MAX) FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: tile %d", tile);
     if (int rc = set_split_k(P, split_k, workspace, workspace_bytes, true, "conv3x3_bf16")) return rc;
     launch_gemm<1, 0>(P, tile, (hipStream_t)stream);

@@ -528,14 +528,16 @@ def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
 
 
 def conv3x3_supported(x: torch.Tensor, weight: torch.Tensor, stride, padding) -> bool:
+    s2 = tuple(stride) == (2, 2) and x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0
     return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
-            and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1)
+            and tuple(weight.shape[2:]) == (3, 3) and (tuple(stride) == (1, 1) or s2) and tuple(padding) == (1, 1)
             and weight.shape[1] % 64 == 0 and weight.shape[0] % 8 == 0)
 
 
 def conv3x3_bf16(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias: Optional[torch.Tensor] = None,
                  temb: Optional[torch.Tensor] = None, residual_nhwc: Optional[torch.Tensor] = None,
-                 tile: int = 0, split_k: int = 1, temb_div: int = 1, upsample: bool = False) -> torch.Tensor:
+                 tile: int = 0, split_k: int = 1, temb_div: int = 1, upsample: bool = False,
+                 stride2: bool = False) -> torch.Tensor:
     """x `[N, H, W, Cin]` contiguous, weight `[Cout, Cin, 3, 3]` in channels_last memory format (physically
     `[Cout, 3, 3, Cin]`), temb `[N // temb_div, Cout]` (rows may be strided: a column slice of a wider matrix),
     residual `[N, H, W, Cout]` -> `[N, H, W, Cout]`."""
@@ -543,6 +545,9 @@ def conv3x3_bf16(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias: Optional[t
     n, h, w, cin = x_nhwc.shape
     if upsample:                                        # x is the half-resolution source of a nearest 2x upsample
         h, w = 2 * h, 2 * w
+    if stride2:                                         # 3x3 / stride 2 / pad 1 (even input size): output is half-size
+        assert not upsample and h % 2 == 0 and w % 2 == 0
+        h, w = h // 2, w // 2
     cout = weight_cl.shape[0]
     assert x_nhwc.is_contiguous() and weight_cl.is_contiguous(memory_format=torch.channels_last)
     assert temb is None or (temb.stride(1) == 1 and temb.shape == (n // temb_div, cout) and n % temb_div == 0)
@@ -552,7 +557,7 @@ def conv3x3_bf16(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias: Optional[t
     ws, ws_bytes = _splitk_workspace(x_nhwc.device, split_k, n * h * w, cout)
     _lib.check(_lib.load().fmc_conv3x3_bf16(x_nhwc.data_ptr(), weight_cl.data_ptr(), _p(bias), _p(temb),
                                             _p(residual_nhwc), out.data_ptr(), n, h, w, cin, cout,
-                                            0 if temb is None else temb.stride(0), int(temb_div), int(upsample),
+                                            0 if temb is None else temb.stride(0), int(temb_div), 2 if stride2 else int(upsample),
                                             int(tile),
                                             int(split_k), ws, ws_bytes, _stream()),
                "fmc_conv3x3_bf16")
@@ -685,9 +690,12 @@ def conv3x3(x_nchw: torch.Tensor, weight_cl: torch.Tensor, bias, temb=None, resi
         return lib()
     if upsample:
         h, w = 2 * h, 2 * w
-    key = ("conv", n, h, w, cin, cout, temb is not None, r is not None, upsample)
+    stride2 = tuple(stride) == (2, 2)
+    if stride2:
+        h, w = h // 2, w // 2
+    key = ("conv", n, h, w, cin, cout, temb is not None, r is not None, upsample, stride2)
     hip = lambda tile: conv3x3_bf16(x, weight_cl, bias, temb, r, tile=tile, temb_div=temb_div,
-                                    upsample=upsample).permute(0, 3, 1, 2)
+                                    upsample=upsample, stride2=stride2).permute(0, 3, 1, 2)
     tiles = ((n * h * w + 127) // 128) * ((cout + 127) // 128)
     use = _pick(key, hip, lib, tiles >= 256, split_arms(n * h * w, cout, 9 * cin))
     return lib() if use == 0 else hip(max(use, 0))

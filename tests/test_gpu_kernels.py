@@ -454,6 +454,21 @@ def test_conv3x3_bf16_fused_upsample(K, tile):
     assert rel_inf(out.permute(0, 3, 1, 2).float(), ref) < 1e-2
 
 
+@pytest.mark.parametrize("tile", [0, 2, 5, 11])
+def test_conv3x3_bf16_stride2(K, tile):
+    """diffusers Downsample2D: 3x3, stride 2, pad 1"""
+    dtype = torch.bfloat16
+    n, cin, cout, h, w = 3, 128, 320, 20, 28
+    xo, xd = rnd((n, cin, h, w), 78, dtype)
+    wo, wd = rnd((cout, cin, 3, 3), 79, dtype, scale=(9 * cin) ** -0.5)
+    bo, bd = rnd((cout,), 80, dtype)
+    ref = F.conv2d(xo, wo, bo, 2, 1)
+    out = K.conv3x3_bf16(xd.permute(0, 2, 3, 1).contiguous(), wd.contiguous(memory_format=torch.channels_last), bd,
+                         None, None, tile=tile, stride2=True)
+    assert out.shape == (n, h // 2, w // 2, cout)
+    assert rel_inf(out.permute(0, 3, 1, 2).float(), ref) < 1e-2
+
+
 # ---------------------------------------------------------------------------------------------
 # backward kernels vs autograd through the oracle's forward (fp32 CPU)
 # ---------------------------------------------------------------------------------------------
