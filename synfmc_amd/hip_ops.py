@@ -699,3 +699,71 @@ def conv3x3(x_nchw: torch.Tensor, weight_cl: torch.Tensor, bias, temb=None, resi
     tiles = ((n * h * w + 127) // 128) * ((cout + 127) // 128)
     use = _pick(key, hip, lib, tiles >= 256, split_arms(n * h * w, cout, 9 * cin))
     return lib() if use == 0 else hip(max(use, 0))
+
+
+# --------------------------------------------------------------------------------------------
+# frozen-weight autograd wrappers (training stages 2-3: the U-Net is frozen, only the activation gradient flows through
+# it, train_cam_obj_ctrl.py:242).  Forward = the fused front-ends above; backward-data = the same kernels:
+#   conv3x3:  dX = conv3x3(dY, W') with W'[ci, ky, kx, co] = W[co, 2-ky, 2-kx, ci]   (pad 1, stride 1)
+#   linear:   dX = alpha * dY @ W,  d(residual) = dY
+# --------------------------------------------------------------------------------------------
+_flip_cache = {}
+
+
+def _flipped_filter(weight_cl: torch.Tensor) -> torch.Tensor:
+    """`[Cin, Cout, 3, 3]` filter of the backward-data convolution, channels-last memory format, cached per weight."""
+    key = (weight_cl.data_ptr(), weight_cl._version)
+    hit = _flip_cache.get(key)
+    if hit is None:
+        hit = weight_cl.detach().flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
+        _flip_cache[key] = hit
+    return hit
+
+
+class _Conv3x3Frozen(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight_cl, bias, temb, residual, temb_div):
+        ctx.save_for_backward(weight_cl)
+        ctx.has_res = residual is not None and residual.requires_grad
+        with torch.no_grad():
+            return conv3x3(x, weight_cl, bias, temb, residual, (1, 1), (1, 1), temb_div)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (weight_cl,) = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            with torch.no_grad():
+                dx = conv3x3(dy, _flipped_filter(weight_cl), None)
+        return dx, None, None, None, (dy if ctx.has_res else None), None
+
+
+def conv3x3_frozen(x, weight_cl, bias, temb=None, residual=None, temb_div: int = 1):
+    """3x3 / stride 1 / pad 1 conv with frozen filter, differentiable w.r.t. x (and the residual)."""
+    return _Conv3x3Frozen.apply(x, weight_cl, bias, temb, residual, temb_div)
+
+
+class _LinearFrozen(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, alpha):
+        ctx.save_for_backward(weight)
+        ctx.alpha = alpha
+        ctx.has_res = residual is not None and residual.requires_grad
+        with torch.no_grad():
+            return linear(x, weight, bias, residual, alpha)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (weight,) = ctx.saved_tensors
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.matmul(dy, weight)                 # [.., N] @ [N, K]
+            if ctx.alpha != 1.0:
+                dx = dx * ctx.alpha
+        return dx, None, None, (dy if ctx.has_res else None), None
+
+
+def linear_frozen(x, weight, bias=None, residual=None, alpha: float = 1.0):
+    """`alpha * (x @ W^T + b) + residual` with frozen W, b; differentiable w.r.t. x and the residual."""
+    return _LinearFrozen.apply(x, weight, bias, residual, alpha)

@@ -90,7 +90,15 @@ class Conv2d(nn.Conv2d):
             return from_tokens(y, h, w)
         if not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)
-        needs_grad = torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad or
+                                                  (residual is not None and residual.requires_grad))
+        if (needs_grad and not upsample and self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1)
+                and self.dilation == (1, 1) and self.groups == 1 and x.is_cuda and x.dtype == torch.bfloat16
+                and self.weight.dtype == torch.bfloat16 and not self.weight.requires_grad
+                and (self.bias is None or not self.bias.requires_grad) and (temb is None or not temb.requires_grad)
+                and self.in_channels % 64 == 0 and self.out_channels % 64 == 0):
+            # frozen filter, activation gradient only (training stages 2-3): forward and backward-data on the gfx950 kernel
+            return K.conv3x3_frozen(x, self._weight_cl(), self.bias, temb, residual, temb_div)
         if self.kernel_size == (3, 3) and self.dilation == (1, 1) and self.groups == 1 and x.is_cuda and not needs_grad:
             return K.conv3x3(x, self._weight_cl(), self.bias, temb, residual, self.stride, self.padding, temb_div,
                              upsample)
@@ -120,8 +128,12 @@ class Conv2d(nn.Conv2d):
 def linear_op(x, weight, bias=None, residual=None, alpha: float = 1.0):
     """`alpha * (x @ W^T + b) + residual`: fused gfx950 GEMM or hipBLASLt + epilogue passes (`hip_ops.linear`) for
     frozen bf16 weights on the GPU, plain autograd ops otherwise."""
-    if x.is_cuda and x.dtype == torch.bfloat16 and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)):
-        return K.linear(x, weight, bias, residual, alpha)
+    if x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16:
+        grad = torch.is_grad_enabled()
+        if not (grad and (x.requires_grad or weight.requires_grad or (residual is not None and residual.requires_grad))):
+            return K.linear(x, weight, bias, residual, alpha)
+        if not weight.requires_grad and (bias is None or not bias.requires_grad):   # frozen layer, activation gradient only
+            return K.linear_frozen(x, weight, bias, residual, alpha)
     y = F.linear(x, weight, bias)
     if alpha != 1.0:
         y = y * alpha
