@@ -57,19 +57,21 @@ def reseed(module, seed, std=0.05, fan_in_gain=None):
     return module
 
 
-def build_oracle(widths=(64, 128, 256, 256), cross_dim=64, conditioned=True, lora=True, seed=0, fan_in_gain=None):
+def build_oracle(widths=(64, 128, 256, 256), cross_dim=64, conditioned=True, lora=True, seed=0, fan_in_gain=None,
+                 enc_max_len=16):
     unet = OM.UNet3DConditionModelCamObjCond(**unet_kwargs(widths, cross_dim))
     if conditioned:
         unet.set_all_attn_processor(**processor_kwargs(widths, lora))
         OM.patch_down_blocks_for_omc(unet)
     reseed(unet, seed, fan_in_gain=fan_in_gain)
-    enc = reseed(OM.CameraPoseEncoder(**encoder_kwargs(widths)), seed + 1, fan_in_gain=fan_in_gain) if conditioned else None
+    enc = reseed(OM.CameraPoseEncoder(**encoder_kwargs(widths, enc_max_len)), seed + 1, fan_in_gain=fan_in_gain) \
+        if conditioned else None
     ada = reseed(OM.Adapter(**adapter_kwargs(widths)), seed + 2, fan_in_gain=fan_in_gain) if conditioned else None
     return unet.eval(), (enc.eval() if enc else None), (ada.eval() if ada else None)
 
 
 def build_product(oracle_unet, oracle_enc, oracle_ada, widths=(64, 128, 256, 256), cross_dim=64, conditioned=True,
-                  lora=True, device="cuda", dtype=torch.float32):
+                  lora=True, device="cuda", dtype=torch.float32, enc_max_len=16):
     from synfmc_amd.adapter import Adapter
     from synfmc_amd.models.pose_adaptor import CameraPoseEncoder
     from synfmc_amd.models.unet import UNet3DConditionModelCamObjCond
@@ -82,7 +84,7 @@ def build_product(oracle_unet, oracle_enc, oracle_ada, widths=(64, 128, 256, 256
     unet = unet.to(device=device, dtype=dtype).eval().requires_grad_(False)
     enc = ada = None
     if conditioned:
-        enc = CameraPoseEncoder(**encoder_kwargs(widths))
+        enc = CameraPoseEncoder(**encoder_kwargs(widths, enc_max_len))
         enc.load_state_dict(oracle_enc.state_dict(), strict=True)
         enc = enc.to(device=device, dtype=dtype).eval().requires_grad_(False)
         ada = Adapter(**adapter_kwargs(widths))

@@ -155,3 +155,38 @@ def test_stage2_training_gradients(stack, dtype, tol):
     for part in (enc, mrg):
         err, scale = TC.compare(part, g_got)
         assert scale > 0 and err < tol
+
+
+@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 1e-3, 3e-3), (torch.bfloat16, 6e-2, 1.5e-1)])
+def test_frames32_forward_and_training(dtype, tol, gtol):
+    """BASELINE.json config 5 shape class: 32-frame clips (temporal attention over F = 32, positional-encoding length 32)
+    through the CMC + OMC U-Net -- forward parity and stage-3 gradients against the oracle on the reduced stack."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tests import training_common as TC
+    ou, oe, oa = CM.build_oracle(W4, seed=30, fan_in_gain=0.7, enc_max_len=32)
+    clip = CM.synthetic_clip(B=1, Fr=32, H=128, W=128, seed=130)
+    with torch.no_grad():
+        plucker = OC.to_plucker_embedding(clip["c2w"], clip["K"], (128, 128))
+        pose_emb = rearrange(plucker, "b f c h w -> b c f h w")
+        pose_feats = [rearrange(x, "(b f) c h w -> b c f h w", b=1) for x in oe(pose_emb)]
+        traj = OC.get_traj_features(clip["infos"], clip["masks"], oa)
+        t = torch.tensor([801])
+        ref = ou(clip["latents"], t, clip["text"], pose_embedding_features=pose_feats, traj_features=traj).sample
+    pu, pe, pa = CM.build_product(ou, oe, oa, W4, dtype=dtype, enc_max_len=32)
+    from synfmc_amd.models.pose_obj_adaptor import CamObjPoseAdaptor
+    from synfmc_amd.util import get_traj_features_v2
+    with torch.no_grad():
+        tf = get_traj_features_v2(clip["infos"], clip["masks"], pa, False, 0.0, [False], "cuda", dtype)
+        out = CamObjPoseAdaptor(pu, pe)(clip["latents"].cuda().to(dtype), t.cuda(), clip["text"].cuda().to(dtype),
+                                        pose_emb.cuda().to(dtype), tf)
+    assert out.shape == ref.shape and rel_inf(out.float(), ref) < tol
+    noise = torch.randn(clip["latents"].shape, generator=torch.Generator().manual_seed(12))
+    l_ref, g_ref = TC.oracle_grads(ou, oe, oa, clip, pose_emb, t, noise)
+    if dtype == torch.bfloat16:
+        pa = pa.float()
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+        l_got, g_got = TC.product_grads(pu, pe, pa, clip, pose_emb, t, noise, "cuda", dtype)
+    assert abs(float(l_ref) - float(l_got)) < (1e-4 if dtype == torch.float32 else 2e-2) * abs(float(l_ref))
+    err, scale = TC.compare(g_ref, g_got)
+    assert scale > 0 and err < gtol
