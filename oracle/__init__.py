@@ -23,6 +23,6 @@ Pinning status:
 * The reference-owned orchestration that *uses* those primitives
   (`fmc/models/*.py`, `fmc/modified_modules.py`) is additionally pinned by
   running the reference's own source over `oracle.diffusers_restated` exposed
-  as a stand-in `diffusers` namespace (`tests/golden/make_golden_shim.py`);
+  as a stand-in `diffusers` namespace (`tests/golden/make_golden_g5.py`, vectors `g5_*`);
   that pins the reference-owned arithmetic only, never diffusers' own.
 """

@@ -86,3 +86,36 @@ def test_g4_relative_pose(golden_dir):
     g = np.load(os.path.join(golden_dir, "g4_relpose.npz"))
     rel = C.relative_cam_poses(g["abs_rt"], scale_T=float(g["scale_T"]))
     assert np.abs(rel - g["rel"]).max() < 1e-12
+
+
+def test_g5_reference_unet_over_restated_diffusers(golden_dir):
+    """G5: the reference's own `UNet3DConditionModelCamObjCond` (+ processors, motion modules, blocks, the
+    `Adapted_*_forward` patch, `CameraPoseEncoder`), run by `tests/golden/make_golden_g5.py` over the restated diffusers
+    primitives with the oracle's seeded weights (strict state-dict load).  The oracle must reproduce its outputs and
+    its state-dict key set."""
+    import numpy as np
+    from einops import rearrange
+    from oracle import conditioning as OC
+    from tests import common_models as CM
+    g = np.load(os.path.join(golden_dir, "g5_unet_cmc_omc.npz"))
+    W4 = tuple(int(x) for x in g["widths"])
+    ou, oe, oa = CM.build_oracle(W4, seed=int(g["seed"]))
+    keys = open(os.path.join(golden_dir, "g5_unet_keys.txt")).read().split()
+    assert sorted(ou.state_dict().keys()) == keys and len(keys) == int(g["n_keys"])
+    clip = CM.synthetic_clip(B=1, Fr=16, H=128, W=128, seed=int(g["clip_seed"]))
+    with torch.no_grad():
+        plucker = OC.to_plucker_embedding(clip["c2w"], clip["K"], (128, 128))
+        pose_emb = rearrange(plucker, "b f c h w -> b c f h w")
+        pf = oe(pose_emb)
+        assert np.allclose([float(x.double().sum()) for x in pf], g["enc_feat_sums"], rtol=1e-5, atol=1e-4)
+        assert torch.allclose(pf[0][:2, :8], torch.from_numpy(g["enc_feat0"]), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(pf[3][:2, :8], torch.from_numpy(g["enc_feat3"]), rtol=1e-5, atol=1e-6)
+        pose_feats = [rearrange(x, "(b f) c h w -> b c f h w", b=1) for x in pf]
+        traj = OC.get_traj_features(clip["infos"], clip["masks"], oa)
+        for t, traj_in, key in ((801, traj, "out"), (801, None, "out_notraj"), (17, traj, "out_t17")):
+            out = ou(clip["latents"], torch.tensor([t]), clip["text"], pose_embedding_features=pose_feats,
+                     traj_features=traj_in).sample
+            ref = torch.from_numpy(g[key])
+            assert out.shape == ref.shape
+            assert ((out - ref).abs().max() / ref.abs().max()).item() < 1e-5, key
+    assert not np.allclose(g["out"], g["out_notraj"])             # the OMC features matter in the reference too
