@@ -184,6 +184,23 @@ def main():
         out_notraj = ru(clip["latents"], t, clip["text"], pose_embedding_features=pose_feats, traj_features=None).sample
         t2 = torch.tensor([17])
         out_t2 = ru(clip["latents"], t2, clip["text"], pose_embedding_features=pose_feats, traj_features=traj).sample
+    # CMC-only model of fmc/models/unet.py (CameraCtrlPipeline, configs/cam.yaml), un-patched blocks, same weights
+    from fmc.models.unet import UNet3DConditionModelPoseCond, UNet3DConditionModel as BaseUNet
+    rp = UNet3DConditionModelPoseCond(**CM.unet_kwargs(W4, 64))
+    rp.set_all_attn_processor(**CM.processor_kwargs(W4, True))
+    rp.load_state_dict(ou.state_dict(), strict=True)
+    rp.eval()
+    # plain AnimateDiff-style base model (no processors installed): weights of an un-conditioned oracle
+    ob, _, _ = CM.build_oracle(W4, conditioned=False, seed=41)
+    rb = BaseUNet(**CM.unet_kwargs(W4, 64))
+    assert sorted(rb.state_dict().keys()) == sorted(ob.state_dict().keys())
+    rb.load_state_dict(ob.state_dict(), strict=True)
+    rb.eval()
+    with torch.no_grad():
+        out_posecond = rp(clip["latents"], t, clip["text"], pose_embedding_features=pose_feats).sample
+        out_base = rb(clip["latents"], t, clip["text"]).sample
+    np.savez_compressed(os.path.join(HERE, "g5_unet_variants.npz"), out_posecond=out_posecond.numpy(),
+                        out_base=out_base.numpy(), base_seed=np.array(41))
     np.savez_compressed(os.path.join(HERE, "g5_unet_cmc_omc.npz"),
                         widths=np.array(W4), seed=np.array(40), clip_seed=np.array(140),
                         out=out.numpy(), out_notraj=out_notraj.numpy(), out_t17=out_t2.numpy(),

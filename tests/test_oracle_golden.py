@@ -119,3 +119,23 @@ def test_g5_reference_unet_over_restated_diffusers(golden_dir):
             assert out.shape == ref.shape
             assert ((out - ref).abs().max() / ref.abs().max()).item() < 1e-5, key
     assert not np.allclose(g["out"], g["out_notraj"])             # the OMC features matter in the reference too
+
+
+def test_g5_reference_unet_variants(golden_dir):
+    """G5: `fmc.models.unet.UNet3DConditionModelPoseCond` (CMC only, un-patched blocks: CameraCtrlPipeline) on the same
+    weights equals the CMC+OMC model called without `traj_features`; the processor-less base `UNet3DConditionModel`
+    equals an un-conditioned oracle.  Both reference outputs come from make_golden_g5.py."""
+    import numpy as np
+    from einops import rearrange
+    from oracle import conditioning as OC
+    from tests import common_models as CM
+    g = np.load(os.path.join(golden_dir, "g5_unet_cmc_omc.npz"))
+    v = np.load(os.path.join(golden_dir, "g5_unet_variants.npz"))
+    W4 = tuple(int(x) for x in g["widths"])
+    clip = CM.synthetic_clip(B=1, Fr=16, H=128, W=128, seed=int(g["clip_seed"]))
+    assert np.allclose(v["out_posecond"], g["out_notraj"], rtol=1e-6, atol=1e-6)          # reference vs reference
+    ob, _, _ = CM.build_oracle(W4, conditioned=False, seed=int(v["base_seed"]))
+    with torch.no_grad():
+        out = ob(clip["latents"], torch.tensor([801]), clip["text"]).sample
+    ref = torch.from_numpy(v["out_base"])
+    assert ((out - ref).abs().max() / ref.abs().max()).item() < 1e-5
