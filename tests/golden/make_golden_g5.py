@@ -52,7 +52,11 @@ def _mod(name, **attrs):
 
 
 class _Config(dict):
-    __getattr__ = dict.__getitem__
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k) from None
 
 
 def register_to_config(init):
@@ -130,7 +134,33 @@ def install_diffusers_shim():
     _mod("diffusers.models.normalization", AdaGroupNorm=_Unused)
     _mod("diffusers.loaders", AttnProcsLayers=AttnProcsLayers, UNet2DConditionLoadersMixin=type("UNet2DConditionLoadersMixin", (), {}),
          LoraLoaderMixin=type("LoraLoaderMixin", (), {}))
-    _mod("diffusers.schedulers", DDIMScheduler=OD.DDIMScheduler)
+    other = type("_OtherScheduler", (), {})
+    _mod("diffusers.schedulers", DDIMScheduler=OD.DDIMScheduler, PNDMScheduler=other, LMSDiscreteScheduler=other,
+         EulerDiscreteScheduler=other, EulerAncestralDiscreteScheduler=other, DPMSolverMultistepScheduler=other)
+    sys.modules["diffusers.models"].AutoencoderKL = type("AutoencoderKL", (), {})
+
+    class DiffusionPipeline:
+        _optional_components = []
+
+        def register_modules(self, **kw):
+            for k, v in kw.items():
+                setattr(self, k, v)
+
+        def progress_bar(self, iterable=None, total=None):
+            import contextlib
+
+            class _Bar:
+                def update(self, n=1):
+                    pass
+
+            @contextlib.contextmanager
+            def cm():
+                yield _Bar()
+            return cm() if iterable is None else iterable
+
+    _mod("transformers", CLIPTextModel=type("CLIPTextModel", (), {}), CLIPTokenizer=type("CLIPTokenizer", (), {}))   # type hints only
+    _mod("diffusers.pipelines")
+    _mod("diffusers.pipelines.pipeline_utils", DiffusionPipeline=DiffusionPipeline)
 
 
 def main():
@@ -199,6 +229,48 @@ def main():
     with torch.no_grad():
         out_posecond = rp(clip["latents"], t, clip["text"], pose_embedding_features=pose_feats).sample
         out_base = rb(clip["latents"], t, clip["text"]).sample
+    # ---- the reference's own denoising loop (CameraObjCtrlPipeline.__call__, pipeline_animation_cm_om.py:570-738):
+    # CFG concatenation order, zero traj features for the unconditional half, omcm_min_step gating, scheduler.step.
+    # VAE / CLIP are outside the path: stub tokenizer + text encoder map a prompt to fixed embeddings, the stub VAE decodes
+    # linearly so the final latents can be read back from the returned "video".
+    from fmc.pipelines.pipeline_animation_cm_om import CameraObjCtrlPipeline
+    emb_text, emb_uncond = clip["text"], torch.randn(1, 77, 64, generator=torch.Generator().manual_seed(7))
+
+    class _Tok:
+        model_max_length = 77
+
+        def __call__(self, prompt, **kw):
+            ids = torch.tensor([[1 if p else 0] * 77 for p in (prompt if isinstance(prompt, list) else [prompt])])
+            return types.SimpleNamespace(input_ids=ids, attention_mask=None)
+
+        def batch_decode(self, ids):
+            return [""]
+
+    class _TextEnc(nn.Module):
+        config = types.SimpleNamespace()
+        dtype = torch.float32
+
+        def forward(self, ids, attention_mask=None):
+            return (torch.cat([emb_text if int(r[0]) else emb_uncond for r in ids], 0),)
+
+    class _Vae:
+        config = types.SimpleNamespace(block_out_channels=[1, 1, 1, 1])
+
+        def decode(self, z):
+            return types.SimpleNamespace(sample=z * 0.18215 * 0.01)   # keeps |latent| < 100 inside the clamp
+
+    sched = OD.DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="linear",
+                             steps_offset=1, clip_sample=False)
+    sched.config = types.SimpleNamespace(steps_offset=1, clip_sample=False)
+    object.__setattr__(ru, "in_channels", 4)
+    pipe = CameraObjCtrlPipeline(_Vae(), _TextEnc(), _Tok(), ru, sched, re_)
+    pipe_out = {}
+    for name, gs, min_step in (("cfg2_gate700", 2.0, 700), ("cfg2_nogate", 2.0, 0), ("nocfg", 1.0, 0)):
+        video = pipe("a prompt", pose_emb, video_length=16, traj_features=[x.clone() for x in traj], height=128, width=128,
+                     num_inference_steps=6, guidance_scale=gs, negative_prompt=None, latents=clip["latents"].clone(),
+                     output_type="tensor", omcm_min_step=min_step, multidiff_overlaps=0).videos
+        pipe_out[name] = ((video.double() - 0.5) * 200.0).float().numpy()   # undo the stub VAE: final latents
+    np.savez_compressed(os.path.join(HERE, "g5_pipeline.npz"), emb_uncond=emb_uncond.numpy(), **pipe_out)
     np.savez_compressed(os.path.join(HERE, "g5_unet_variants.npz"), out_posecond=out_posecond.numpy(),
                         out_base=out_base.numpy(), base_seed=np.array(41))
     np.savez_compressed(os.path.join(HERE, "g5_unet_cmc_omc.npz"),

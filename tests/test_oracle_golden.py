@@ -139,3 +139,35 @@ def test_g5_reference_unet_variants(golden_dir):
         out = ob(clip["latents"], torch.tensor([801]), clip["text"]).sample
     ref = torch.from_numpy(v["out_base"])
     assert ((out - ref).abs().max() / ref.abs().max()).item() < 1e-5
+
+
+def test_g5_reference_pipeline_loop(golden_dir):
+    """G5: the reference's own `CameraObjCtrlPipeline.__call__` (6 DDIM steps; CFG 2.0 with and without the
+    `omcm_min_step` gate, and no CFG) on stub VAE / CLIP, run by make_golden_g5.py.  `oracle.pipeline.denoise` must
+    return the same final latents."""
+    import numpy as np
+    from einops import rearrange
+    from oracle import conditioning as OC
+    from oracle import diffusers_restated as OD
+    from oracle import pipeline as OP
+    from tests import common_models as CM
+    g = np.load(os.path.join(golden_dir, "g5_unet_cmc_omc.npz"))
+    gp = np.load(os.path.join(golden_dir, "g5_pipeline.npz"))
+    W4 = tuple(int(x) for x in g["widths"])
+    ou, oe, oa = CM.build_oracle(W4, seed=int(g["seed"]))
+    clip = CM.synthetic_clip(B=1, Fr=16, H=128, W=128, seed=int(g["clip_seed"]))
+    emb_uncond = torch.from_numpy(gp["emb_uncond"])
+    with torch.no_grad():
+        plucker = OC.to_plucker_embedding(clip["c2w"], clip["K"], (128, 128))
+        pose_emb = rearrange(plucker, "b f c h w -> b c f h w")
+        traj = OC.get_traj_features(clip["infos"], clip["masks"], oa)
+        for key, gs, min_step in (("cfg2_gate700", 2.0, 700), ("cfg2_nogate", 2.0, 0), ("nocfg", 1.0, 0)):
+            sched = OD.DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="linear",
+                                     steps_offset=1, clip_sample=False)
+            text = torch.cat([emb_uncond, clip["text"]], 0) if gs > 1.0 else clip["text"]
+            out = OP.denoise(ou, sched, oe, text, pose_emb, clip["latents"].clone(), num_inference_steps=6,
+                             guidance_scale=gs, traj_features=[x.clone() for x in traj], omcm_min_step=min_step)
+            ref = torch.from_numpy(gp[key])
+            # the stub VAE round trip ((x*0.01/2+0.5) in fp32, then back) costs ~6e-8 * 200 absolute
+            assert ((out - ref).abs().max() / ref.abs().max()).item() < 2e-5, key
+    assert not np.allclose(gp["cfg2_gate700"], gp["cfg2_nogate"], atol=1e-4)
