@@ -279,6 +279,30 @@ def main():
                         enc_feat_sums=np.array([float(x.double().sum()) for x in pf_ref]),
                         enc_feat0=pf_ref[0][:2, :8].numpy(), enc_feat3=pf_ref[3][:2, :8].numpy(),
                         n_keys=np.array(len(ref_keys)))
+    # ---- the same reference forward at the widths of the GPU parity tests (head dims the HIP kernels accept), so that
+    # tests/test_gpu_model.py can compare the product with the reference's output directly
+    WG = (64, 128, 256, 256)
+    og, oeg, oag = CM.build_oracle(WG, seed=42)
+    rg = UNet3DConditionModelCamObjCond(**CM.unet_kwargs(WG, 64))
+    rg.set_all_attn_processor(**CM.processor_kwargs(WG, True))
+    idx = 0
+    for name, module in rg.down_blocks.named_modules():
+        cls = module.__class__.__name__
+        if cls in ("CrossAttnDownBlock3D", "DownBlock3D"):
+            fwd = Adapted_CrossAttnDownBlock3D_forward if cls == "CrossAttnDownBlock3D" else Adapted_DownBlock3D_forward
+            setattr(module, "forward", fwd.__get__(module, module.__class__))
+            setattr(module, "traj_fea_idx", idx)
+            idx += 1
+    rg.load_state_dict(og.state_dict(), strict=True)
+    reg = CameraPoseEncoder(**CM.encoder_kwargs(WG))
+    reg.load_state_dict(oeg.state_dict(), strict=True)
+    rg.eval(); reg.eval()
+    with torch.no_grad():
+        pfg = [rearrange(x, "(b f) c h w -> b c f h w", b=1) for x in reg(pose_emb)]
+        trajg = OC.get_traj_features(clip["infos"], clip["masks"], oag)
+        outg = rg(clip["latents"], t, clip["text"], pose_embedding_features=pfg, traj_features=trajg).sample
+    np.savez_compressed(os.path.join(HERE, "g5_unet_gpu_widths.npz"), widths=np.array(WG), seed=np.array(42),
+                        clip_seed=np.array(140), out=outg.numpy())
     with open(os.path.join(HERE, "g5_unet_keys.txt"), "w") as f:
         f.write("\n".join(ref_keys) + "\n")
     print("G5 written:", out.shape, float(out.abs().max()), "keys", len(ref_keys))
