@@ -55,12 +55,15 @@ const char* fmc_last_error(void);
  *   stats       : [N, G, 2] fp32 out (mean, rstd) -- kept for the backward; must not be NULL
  *   workspace   : fp32 scratch of fmc_groupnorm_workspace_bytes(N, C, G) bytes
  *   act         : 0 = none, 1 = SiLU
+ *   x2, C1      : two-source input, or NULL / 0.  With x2 the normalised tensor is the channel concat of x [N, HW, C1]
+ *                 and x2 [N, HW, C - C1] (C1 % 8 == 0); y is the contiguous [N, HW, C].  The up blocks' `torch.cat([
+ *                 hidden, skip], dim=1)` (unet_blocks.py:683,798) is then never materialised.
  * Requires C % 8 == 0 and C % G == 0.
  * ------------------------------------------------------------------------------------------- */
 int64_t fmc_groupnorm_workspace_bytes(int N, int C, int G);
 int fmc_groupnorm_silu_fwd(const void* x, void* y, const float* gamma, const float* beta, float* stats,
                            void* workspace, int N, int HW, int C, int G, float eps, int act, int dtype,
-                           void* stream);
+                           const void* x2, int C1, void* stream);
 /* dX of the above (frozen gamma/beta: the only case on the FMC training path).
  *   dy, x, dx : [N, HW, C]; stats from the forward; act as in the forward. */
 int fmc_groupnorm_silu_bwd(const void* dy, const void* x, void* dx, const float* gamma, const float* beta,
@@ -171,6 +174,8 @@ int fmc_cfg_ddim_step(const void* eps_uc, const float* x, float* x_out, int64_t 
  *   epilogue 1 expects w / bias pre-interleaved per 128-row tile: rows [128t, 128t+64) = value rows
  *   [64t, 64t+64) of the GEGLU projection, rows [128t+64, 128t+128) = the matching gate rows.
  *   Requires K % 64 == 0, N % 8 == 0 (N % 256 == 0 for epilogue 1), strides % 8 == 0.
+ *   x2 != NULL: two-source A operand -- columns [0, k_split) of every row come from x, [k_split, K) from x2 (rows
+ *   `ldx2` apart, k_split % 64 == 0): the 1x1 shortcut conv of an up-block ResNet reads (hidden, skip) without a concat.
  *   tile: workgroup tile geometry, 0 = pick by shape, 1 = 128x128 (4 waves), 2 = 256x128 (8), 3 = 256x256 (16) with
  *   64-deep k-tiles in a 2-stage LDS ring; 4..6 = the same three with 32-deep k-tiles (half the LDS, twice the
  *   workgroups per CU); 7 = 256x128, 64-deep, 3 stages; 8 / 9 / 10 = 256x256 / 128x128 / 256x128, 32-deep, 4 stages
@@ -189,7 +194,7 @@ int fmc_cfg_ddim_step(const void* eps_uc, const float* x, float* x_out, int64_t 
  * ------------------------------------------------------------------------------------------- */
 int fmc_linear_bf16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int N,
                     int K, int64_t ldx, int64_t ldres, int64_t ldo, float alpha, int epilogue, int tile, int split_k,
-                    void* workspace, int64_t workspace_bytes, void* stream);
+                    void* workspace, int64_t workspace_bytes, const void* x2, int64_t ldx2, int k_split, void* stream);
 
 /* Implicit-GEMM 3x3 convolution (stride 1, pad 1) on channels-last bf16 images with the ResNet-block epilogue:
  *   out[i,y,x,:] = conv(x)[i,y,x,:] + bias + temb[i,:] + residual[i,y,x,:]

@@ -22,7 +22,7 @@ SIGNATURES = {
     "fmc_last_error": (c_char_p, []),
     "fmc_groupnorm_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "fmc_groupnorm_silu_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                       c_int, c_float, c_int, c_int, c_void_p]),
+                                       c_int, c_float, c_int, c_int, c_void_p, c_int, c_void_p]),
     "fmc_groupnorm_silu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                        c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fmc_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int,
@@ -42,7 +42,8 @@ SIGNATURES = {
     "fmc_cfg_ddim_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_int,
                                   c_void_p]),
     "fmc_linear_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64,
-                                c_int64, c_int64, c_float, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
+                                c_int64, c_int64, c_float, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int,
+                                c_void_p]),
     "fmc_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float,
                                   c_int, c_void_p]),
     "fmc_geglu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),

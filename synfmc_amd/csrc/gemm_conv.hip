@@ -45,6 +45,7 @@ struct GemmParams {
     int64_t lda, ldres, ldo;
     int img_h, img_w, cin, hw;        // conv mode
     int64_t temb_ld; int temb_div;    // temb row of image i = temb + (i / temb_div) * temb_ld
+    const bf16_t* a2; int64_t lda2; int ksplit;   // token mode: columns [ksplit, K) of A come from a2 (rows lda2 apart)
     int ups;                          // conv mode: 1 = x is [n, H/2, W/2, Cin], read through a nearest 2x upsample;
                                       //            2 = stride-2 convolution, x is [n, 2H, 2W, Cin]  (H, W = output size)
     float alpha;
@@ -188,6 +189,7 @@ void gemm_kernel(const GemmParams P) {
 
     // ---- my LDS-DMA pieces: piece p = wave + NW*j; p < BM/8 -> rows 8p.. of A, else rows of W --------------------
     const bf16_t* src[PPW];
+    const bf16_t* src2[PPW];                         // second A source (token mode, two-source operand)
     bool val[PPW];
     int py[PPW], px[PPW];
     const int prow = lane / CPRW, pphys = lane % CPRW;
@@ -195,7 +197,7 @@ void gemm_kernel(const GemmParams P) {
     for (int j = 0; j < PPW; ++j) {
         const int p = wave + NW * j;
         if (p >= PIECES) {
-            src[j] = nullptr; val[j] = false; py[j] = px[j] = 0;
+            src[j] = src2[j] = nullptr; val[j] = false; py[j] = px[j] = 0;
         } else if (p < BM / RPP) {
             const int rloc = RPP * p + prow;
             const int sc = swz<BK>(rloc, pphys);
@@ -204,9 +206,11 @@ void gemm_kernel(const GemmParams P) {
             const int64_t mm = val[j] ? m : 0;
             if (MODE == 0) {
                 src[j] = P.a + mm * P.lda + sc * 8;
+                src2[j] = P.a2 ? P.a2 + mm * P.lda2 + sc * 8 : nullptr;
                 py[j] = px[j] = 0;
             } else {
                 const int pix = (int)(mm % P.hw);
+                src2[j] = nullptr;
                 py[j] = pix / P.img_w;
                 px[j] = pix - py[j] * P.img_w;
                 if (P.ups == 1) src[j] = P.a + (mm / P.hw) * (int64_t)(P.hw >> 2) * P.cin + sc * 8;   // image base (half-res)
@@ -219,6 +223,7 @@ void gemm_kernel(const GemmParams P) {
             const int n = n0 + rloc;
             val[j] = n < P.N;
             src[j] = P.w + (int64_t)(val[j] ? n : 0) * P.K + sc * 8;
+            src2[j] = nullptr;
             py[j] = px[j] = 0;
         }
     }
@@ -253,6 +258,8 @@ void gemm_kernel(const GemmParams P) {
                     const int iy = 2 * py[j] + dy, ix = 2 * px[j] + dx;
                     const bool ok2 = val[j] && iy >= 0 && ix >= 0;                // (the high side is always inside)
                     dma16(ok2 ? src[j] + ((int64_t)iy * (2 * P.img_w) + ix) * P.cin + ci0 : zero, stage + p * 512);
+                } else if (MODE == 0 && P.a2 && k0 >= P.ksplit) {
+                    dma16(ok ? src2[j] + (k0 - P.ksplit) : zero, stage + p * 512);
                 } else {
                     dma16(ok ? src[j] + shift : zero, stage + p * 512);
                 }
@@ -663,7 +670,8 @@ int set_split_k(GemmParams& P, int split_k, void* workspace, int64_t workspace_b
 
 extern "C" int fmc_linear_bf16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,
                                int N, int K, int64_t ldx, int64_t ldres, int64_t ldo, float alpha, int epilogue, int tile,
-                               int split_k, void* workspace, int64_t workspace_bytes, void* stream) {
+                               int split_k, void* workspace, int64_t workspace_bytes, const void* x2, int64_t ldx2,
+                               int k_split, void* stream) {
     if (!x || !w || !out) FMC_FAIL(FMC_E_NULL, "linear_bf16: NULL tensor");
     if (M <= 0 || N <= 0 || K <= 0 || K % BK_MAX || N % 8 || ldx % 8 || ldo % 8 || (residual && ldres % 8))
         FMC_FAIL(FMC_E_SHAPE, "linear_bf16: need K%%64==0, N%%8==0 and strides %%8==0 (M=%lld N=%d K=%d)", (long long)M, N, K);
@@ -677,6 +685,9 @@ extern "C" int fmc_linear_bf16(const void* x, const void* w, const void* bias, c
     P.res = (const bf16_t*)residual; P.out = (bf16_t*)out;
     P.M = M; P.N = N; P.K = K; P.lda = ldx; P.ldres = ldres; P.ldo = ldo;
     P.img_h = P.img_w = P.cin = 0; P.hw = 1; P.alpha = alpha; P.temb_ld = 0; P.temb_div = 1; P.ups = 0;
+    if (x2 && (k_split <= 0 || k_split >= K || k_split % BK_MAX || ldx2 % 8 || !fmc_aligned16(x2)))
+        FMC_FAIL(FMC_E_SHAPE, "linear_bf16: two-source input needs 0 < k_split < K, k_split %% 64 == 0 (k_split=%d K=%d)", k_split, K);
+    P.a2 = (const bf16_t*)x2; P.lda2 = ldx2; P.ksplit = x2 ? k_split : 0;
     hipStream_t st = (hipStream_t)stream;
     if (tile < 0 || tile > GEMM_TILE_MAX) FMC_FAIL(FMC_E_SHAPE, "linear_bf16: tile %d", tile);
     if (int rc = set_split_k(P, split_k, workspace, workspace_bytes, epilogue == 0, "linear_bf16")) return rc;
@@ -699,6 +710,7 @@ extern "C" int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, 
     P.a = (const bf16_t*)x; P.w = (const bf16_t*)w; P.bias = (const bf16_t*)bias; P.temb = (const bf16_t*)temb;
     P.res = (const bf16_t*)residual; P.out = (bf16_t*)out;
     P.M = (int64_t)n_img * H * W; P.N = Cout; P.K = 9 * Cin; P.lda = Cin; P.ldres = Cout; P.ldo = Cout;
+    P.a2 = nullptr; P.lda2 = 0; P.ksplit = 0;
     P.img_h = H; P.img_w = W; P.cin = Cin; P.hw = H * W; P.alpha = 1.f;
     if (temb && (temb_img_div < 1 || temb_row_stride % 8)) FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: temb_img_div >= 1, temb_row_stride %% 8 == 0");
     P.temb_ld = temb_row_stride; P.temb_div = temb_img_div < 1 ? 1 : temb_img_div;

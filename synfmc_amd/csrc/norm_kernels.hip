@@ -54,7 +54,7 @@ template <typename T, int MODE>
 __global__ void gn_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ gamma,
                                   const float* __restrict__ beta, const float* __restrict__ stats,
                                   float* __restrict__ part, int HW, int C, int G, int tpr, int rpi,
-                                  int rows_per_split, int act) {
+                                  int rows_per_split, int act, const T* __restrict__ x2 = nullptr, int C1 = 0) {
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][rpi][C]
     const int n = blockIdx.y, s = blockIdx.x, nsplit = gridDim.x;
     const int tid = threadIdx.x;
@@ -80,7 +80,13 @@ __global__ void gn_partial_kernel(const T* __restrict__ x, const T* __restrict__
     float s1[8], s2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
+    // two-source input (channels [0, C1) from x, [C1, C) from x2): the channel concat of the up blocks is never written
+    int xs = C;
     const T* xb = x + (size_t)n * HW * C + c0;
+    if (x2) {
+        xs = c0 < C1 ? C1 : C - C1;
+        xb = c0 < C1 ? x + (size_t)n * HW * C1 + c0 : x2 + (size_t)n * HW * (C - C1) + (c0 - C1);
+    }
     const T* dyb = (MODE == 1) ? dy + (size_t)n * HW * C + c0 : nullptr;
     if (MODE == 0) {
         for (int r = row0 + rsub; r < row1; r += 4 * rpi) {       // four rows per trip, all loads first
@@ -88,7 +94,7 @@ __global__ void gn_partial_kernel(const T* __restrict__ x, const T* __restrict__
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int rr = r + u * rpi;
-                Vec8<T>::load(xb + (size_t)(rr < row1 ? rr : row1 - 1) * C, v4[u]);
+                Vec8<T>::load(xb + (size_t)(rr < row1 ? rr : row1 - 1) * xs, v4[u]);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -149,7 +155,8 @@ template <typename T>
 __global__ void gn_apply_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, const float* __restrict__ part,
                                     float* __restrict__ stats, int HW, int C, int G, int tpr, int rpi,
-                                    int rows_per_split, float eps, int act) {
+                                    int rows_per_split, float eps, int act, const T* __restrict__ x2 = nullptr,
+                                    int C1 = 0) {
     __shared__ float sh_mean[GN_MAX_G], sh_rstd[GN_MAX_G];
     const int n = blockIdx.y, s = blockIdx.x, nsplit = gridDim.x;
     const int tid = threadIdx.x;
@@ -186,7 +193,12 @@ __global__ void gn_apply_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, 
     const int row0 = s * rows_per_split;
     int row1 = row0 + rows_per_split;
     if (row1 > HW) row1 = HW;
+    int xs = C;
     const T* xb = x + (size_t)n * HW * C + c0;
+    if (x2) {
+        xs = c0 < C1 ? C1 : C - C1;
+        xb = c0 < C1 ? x + (size_t)n * HW * C1 + c0 : x2 + (size_t)n * HW * (C - C1) + (c0 - C1);
+    }
     T* yb = y + (size_t)n * HW * C + c0;
     // four rows per trip, loads first (branch-free, clamped): a row per trip leaves one 16-byte load in flight per thread
     for (int r = row0 + rsub; r < row1; r += 4 * rpi) {
@@ -194,7 +206,7 @@ __global__ void gn_apply_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, 
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int rr = r + u * rpi;
-            Vec8<T>::load(xb + (size_t)(rr < row1 ? rr : row1 - 1) * C, v[u]);
+            Vec8<T>::load(xb + (size_t)(rr < row1 ? rr : row1 - 1) * xs, v[u]);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -221,14 +233,19 @@ template <typename T, int MAXCH>
 __global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ stats, int HW, int C, int G, int CS, int PL,
-                                                           float eps, int act) {
+                                                           float eps, int act, const T* __restrict__ x2, int C1) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][PL][CS] partial sums, then [2][CS] totals
     __shared__ float sh_mean[GN_MAX_G], sh_rstd[GN_MAX_G];
     const int n = blockIdx.y, slab = blockIdx.x, tid = threadIdx.x;
     const int CPS = CS / 8, cpg = C / G, GPB = CS / cpg;
     const int ch = tid % CPS, pl = tid / CPS;
     const int c0 = slab * CS + ch * 8;                             // my 8 channels (global index)
+    int xs = C;
     const T* xb = x + (size_t)n * HW * C + c0;
+    if (x2) {
+        xs = c0 < C1 ? C1 : C - C1;
+        xb = c0 < C1 ? x + (size_t)n * HW * C1 + c0 : x2 + (size_t)n * HW * (C - C1) + (c0 - C1);
+    }
     float v[MAXCH][8];
     float s1[8], s2[8];
 #pragma unroll
@@ -238,7 +255,7 @@ __global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const T* __restrict__
 #pragma unroll
     for (int j = 0; j < MAXCH; ++j) {
         const int p = pl + PL * j;
-        Vec8<T>::load(xb + (size_t)(p < HW ? p : HW - 1) * C, v[j]);
+        Vec8<T>::load(xb + (size_t)(p < HW ? p : HW - 1) * xs, v[j]);
     }
 #pragma unroll
     for (int j = 0; j < MAXCH; ++j) {
@@ -331,15 +348,15 @@ static bool gn1_geom(int HW, int C, int G, Gn1Geom& out) {
 
 template <typename T>
 static void launch_gn1(const Gn1Geom& g1, const void* x, void* y, const float* gamma, const float* beta, float* stats, int N,
-                       int HW, int C, int G, float eps, int act, hipStream_t st) {
+                       int HW, int C, int G, float eps, int act, hipStream_t st, const void* x2, int C1) {
     dim3 grid1(C / g1.CS, N), block1(g1.block);
     const size_t lds1 = (size_t)2 * g1.PL * g1.CS * sizeof(float);
     if (g1.chunks <= 8)
         hipLaunchKernelGGL((gn_fused_fwd_kernel<T, 8>), grid1, block1, lds1, st, (const T*)x, (T*)y, gamma, beta, stats, HW, C,
-                           G, g1.CS, g1.PL, eps, act);
+                           G, g1.CS, g1.PL, eps, act, (const T*)x2, C1);
     else
         hipLaunchKernelGGL((gn_fused_fwd_kernel<T, GN1_MAXCH>), grid1, block1, lds1, st, (const T*)x, (T*)y, gamma, beta,
-                           stats, HW, C, G, g1.CS, g1.PL, eps, act);
+                           stats, HW, C, G, g1.CS, g1.PL, eps, act, (const T*)x2, C1);
 }
 
 // pass 2 (backward): dx = rstd * (dxh - S1/cnt - xh * S2/cnt)
@@ -734,14 +751,17 @@ extern "C" int64_t fmc_groupnorm_workspace_bytes(int N, int C, int G) {
 
 extern "C" int fmc_groupnorm_silu_fwd(const void* x, void* y, const float* gamma, const float* beta, float* stats,
                                       void* workspace, int N, int HW, int C, int G, float eps, int act, int dtype,
-                                      void* stream) {
+                                      const void* x2, int C1, void* stream) {
     if (int rc = gn_check(x, y, N, HW, C, G, dtype)) return rc;
+    if (x2 && (C1 <= 0 || C1 >= C || C1 % 8 || !fmc_aligned16(x2)))
+        FMC_FAIL(FMC_E_SHAPE, "groupnorm_fwd: two-source input needs 0 < C1 < C, C1 %% 8 == 0 (C1=%d C=%d)", C1, C);
+    if (!x2) C1 = 0;
     if (!gamma || !beta || !stats || !workspace) FMC_FAIL(FMC_E_NULL, "groupnorm_fwd: NULL gamma/beta/stats/workspace");
     hipStream_t st = (hipStream_t)stream;
     Gn1Geom g1;
     if (gn1_geom(HW, C, G, g1)) {                        // small levels: one launch, x read once
-        if (dtype == FMC_BF16) launch_gn1<bf16_t>(g1, x, y, gamma, beta, stats, N, HW, C, G, eps, act, st);
-        else launch_gn1<float>(g1, x, y, gamma, beta, stats, N, HW, C, G, eps, act, st);
+        if (dtype == FMC_BF16) launch_gn1<bf16_t>(g1, x, y, gamma, beta, stats, N, HW, C, G, eps, act, st, x2, C1);
+        else launch_gn1<float>(g1, x, y, gamma, beta, stats, N, HW, C, G, eps, act, st, x2, C1);
         FMC_CHECK_LAUNCH("fmc_groupnorm_silu_fwd");
         return 0;
     }
@@ -751,14 +771,14 @@ extern "C" int fmc_groupnorm_silu_fwd(const void* x, void* y, const float* gamma
     float* part = (float*)workspace;
     if (dtype == FMC_BF16) {
         hipLaunchKernelGGL((gn_partial_kernel<bf16_t, 0>), grid, block, lds, st, (const bf16_t*)x, nullptr, gamma, beta,
-                           nullptr, part, HW, C, G, g.tpr, g.rpi, g.rows_per_split, act);
+                           nullptr, part, HW, C, G, g.tpr, g.rpi, g.rows_per_split, act, (const bf16_t*)x2, C1);
         hipLaunchKernelGGL((gn_apply_fwd_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)x, (bf16_t*)y, gamma, beta,
-                           part, stats, HW, C, G, g.tpr, g.rpi, g.rows_per_split, eps, act);
+                           part, stats, HW, C, G, g.tpr, g.rpi, g.rows_per_split, eps, act, (const bf16_t*)x2, C1);
     } else {
         hipLaunchKernelGGL((gn_partial_kernel<float, 0>), grid, block, lds, st, (const float*)x, nullptr, gamma, beta,
-                           nullptr, part, HW, C, G, g.tpr, g.rpi, g.rows_per_split, act);
+                           nullptr, part, HW, C, G, g.tpr, g.rpi, g.rows_per_split, act, (const float*)x2, C1);
         hipLaunchKernelGGL((gn_apply_fwd_kernel<float>), grid, block, 0, st, (const float*)x, (float*)y, gamma, beta,
-                           part, stats, HW, C, G, g.tpr, g.rpi, g.rows_per_split, eps, act);
+                           part, stats, HW, C, G, g.tpr, g.rpi, g.rows_per_split, eps, act, (const float*)x2, C1);
     }
     FMC_CHECK_LAUNCH("fmc_groupnorm_silu_fwd");
     return 0;

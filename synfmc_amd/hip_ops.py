@@ -60,18 +60,24 @@ def _workspace(device, nbytes: int) -> torch.Tensor:
 # GroupNorm (+SiLU)
 # --------------------------------------------------------------------------------------------
 def groupnorm_silu_raw(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,
-                       act: bool) -> Tuple[torch.Tensor, torch.Tensor]:
-    """x `[N, S, C]` contiguous -> (y, stats `[N, G, 2]`)."""
-    _dev(x, gamma, beta)
+                       act: bool, x2: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """x `[N, S, C]` contiguous -> (y, stats `[N, G, 2]`).  With `x2 [N, S, C2]` the normalised tensor is the channel
+    concat `[x, x2]` (never materialised); y is `[N, S, C + C2]`."""
+    _dev(x, gamma, beta, x2)
     assert x.ndim == 3 and x.is_contiguous(), "groupnorm: x must be contiguous [N, S, C] tokens"
-    N, S, C = x.shape
+    N, S, C1 = x.shape
+    C = C1
+    if x2 is not None:
+        assert x2.is_contiguous() and x2.shape[:2] == x.shape[:2] and x2.dtype == x.dtype
+        C = C1 + x2.shape[2]
     lib = _lib.load()
-    y = torch.empty_like(x)
+    y = torch.empty(N, S, C, dtype=x.dtype, device=x.device)
     stats = torch.empty(N, groups, 2, dtype=torch.float32, device=x.device)
     ws = _workspace(x.device, lib.fmc_groupnorm_workspace_bytes(N, C, groups))
     _lib.check(lib.fmc_groupnorm_silu_fwd(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                           stats.data_ptr(), ws.data_ptr(), N, S, C, groups, float(eps), int(act),
-                                          _dt(x), _stream()), "fmc_groupnorm_silu_fwd")
+                                          _dt(x), _p(x2), C1 if x2 is not None else 0, _stream()),
+               "fmc_groupnorm_silu_fwd")
     return y, stats
 
 
@@ -99,12 +105,14 @@ class _GroupNormSiLU(torch.autograd.Function):
         return dx, None, None, None, None, None
 
 
-def groupnorm_silu(x, gamma, beta, groups: int, eps: float, act: bool) -> torch.Tensor:
+def groupnorm_silu(x, gamma, beta, groups: int, eps: float, act: bool, x2=None) -> torch.Tensor:
     """GroupNorm over `[N, S, C]` tokens (statistics per sample and group over S x C/G) + optional SiLU.
-    gamma/beta: fp32 `[C]`."""
-    if torch.is_grad_enabled() and x.requires_grad:
+    gamma/beta: fp32 `[C]`.  `x2`: second channel block (the result normalises `cat([x, x2], -1)` without building it)."""
+    if torch.is_grad_enabled() and (x.requires_grad or (x2 is not None and x2.requires_grad)):
+        if x2 is not None:
+            x = torch.cat([x, x2], dim=-1)
         return _GroupNormSiLU.apply(x, gamma, beta, groups, eps, act)
-    return groupnorm_silu_raw(x, gamma, beta, groups, eps, act)[0]
+    return groupnorm_silu_raw(x, gamma, beta, groups, eps, act, x2)[0]
 
 
 # --------------------------------------------------------------------------------------------
@@ -505,14 +513,20 @@ def _rows2d(t: torch.Tensor):
 
 def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
                 residual: Optional[torch.Tensor] = None, alpha: float = 1.0, geglu: bool = False,
-                tile: int = 0, split_k: int = 1) -> torch.Tensor:
+                tile: int = 0, split_k: int = 1, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
     """`alpha * (x @ weight^T + bias) + residual` (or the GEGLU gate, see fmc_linear_bf16) on the bf16 MFMA kernel.
     x `[..., K]`, weight `[N, K]`; residual has the output's shape.  `tile` may also be an autotune arm id
-    (`tile + 16 * log2(split_k)`)."""
+    (`tile + 16 * log2(split_k)`).  `x2 [..., K2]`: the A operand is the concat `[x, x2]` (weight `[N, K + K2]`),
+    never materialised."""
     tile, split_k = _decode_arm(tile, split_k)
-    _dev(x, weight, bias, residual)
+    _dev(x, weight, bias, residual, x2)
     N, Kd = weight.shape
     M, ldx = _rows2d(x)
+    ldx2, k_split = 0, 0
+    if x2 is not None:
+        M2, ldx2 = _rows2d(x2)
+        k_split = x.shape[-1]
+        assert M2 == M and k_split + x2.shape[-1] == Kd
     n_out = N // 2 if geglu else N
     out = torch.empty(*x.shape[:-1], n_out, dtype=x.dtype, device=x.device)
     ldres = 0
@@ -522,7 +536,7 @@ def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     ws, ws_bytes = _splitk_workspace(x.device, split_k, M, N)
     _lib.check(_lib.load().fmc_linear_bf16(x.data_ptr(), weight.data_ptr(), _p(bias), _p(residual), out.data_ptr(), M, N,
                                            Kd, ldx, ldres, n_out, float(alpha), int(geglu), int(tile), int(split_k),
-                                           ws, ws_bytes, _stream()),
+                                           ws, ws_bytes, _p(x2), ldx2, k_split, _stream()),
                "fmc_linear_bf16")
     return out
 
@@ -631,22 +645,29 @@ def _pick(key, hip_fn, lib_fn, static_hip: bool, extra_arms=()) -> int:
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
-           residual: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
-    """`alpha * (x @ weight^T + bias) + residual` for bf16 device tensors (see `linear_bf16`)."""
+           residual: Optional[torch.Tensor] = None, alpha: float = 1.0, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`alpha * (x @ weight^T + bias) + residual` for bf16 device tensors (see `linear_bf16`).  With `x2` the input is
+    the concat `[x, x2]` along the last dim; the fused kernel reads the two tensors in place."""
     import torch.nn.functional as F
 
     def lib():
-        y = F.linear(x, weight, bias)
+        xin = x if x2 is None else torch.cat([x, x2], dim=-1)
+        y = F.linear(xin, weight, bias)
         if residual is not None:
             return torch.add(residual, y, alpha=alpha)
         return y if alpha == 1.0 else y * alpha
 
-    if not linear_supported(x, weight) or (x.ndim > 2 and not x.is_contiguous()):
-        return lib()
     N, Kd = weight.shape
-    M = x.numel() // Kd
-    key = ("lin", M, N, Kd, bias is not None, residual is not None)
-    hip = lambda tile: linear_bf16(x, weight, bias, residual, alpha, tile=tile)
+    ok = x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and Kd % 64 == 0 and N % 8 == 0
+    if x2 is None:
+        ok = ok and linear_supported(x, weight)
+    else:
+        ok = ok and x.shape[-1] % 64 == 0 and x2.dtype == x.dtype and x2.is_contiguous()
+    if not ok or (x.ndim > 2 and not x.is_contiguous()):
+        return lib()
+    M = x.numel() // x.shape[-1]
+    key = ("lin", M, N, Kd, bias is not None, residual is not None, 0 if x2 is None else x.shape[-1])
+    hip = lambda tile: linear_bf16(x, weight, bias, residual, alpha, tile=tile, x2=x2)
     use = _pick(key, hip, lib, Kd <= 640 and N <= 1024 and M >= 16384, split_arms(M, N, Kd))
     return lib() if use == 0 else hip(max(use, 0))
 

@@ -59,10 +59,11 @@ def f32_param(mod: nn.Module, name: str) -> torch.Tensor:
 class GroupNorm(nn.GroupNorm):
     """nn.GroupNorm on a `[N, C, h, w]` tensor, optionally fused with SiLU (`fmc_groupnorm_silu_fwd`)."""
 
-    def forward(self, x: torch.Tensor, act: bool = False) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, act: bool = False, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`x2`: second channel block -- normalises `cat([x, x2], 1)` without building it."""
         n, c, h, w = x.shape
         y = K.groupnorm_silu(to_tokens(x), f32_param(self, "weight"), f32_param(self, "bias"), self.num_groups,
-                             self.eps, act)
+                             self.eps, act, None if x2 is None else to_tokens(x2))
         return from_tokens(y, h, w)
 
 
@@ -78,7 +79,8 @@ class Conv2d(nn.Conv2d):
     """MIOpen conv on channels-last storage; 1x1 stride-1 convs run as a token GEMM (hipBLASLt)."""
 
     def forward(self, x: torch.Tensor, scale: float = 1.0, temb: Optional[torch.Tensor] = None,
-                residual: Optional[torch.Tensor] = None, temb_div: int = 1, upsample: bool = False) -> torch.Tensor:
+                residual: Optional[torch.Tensor] = None, temb_div: int = 1, upsample: bool = False,
+                x2: Optional[torch.Tensor] = None) -> torch.Tensor:
         """conv(x) [+ temb[:, :, None, None]] [+ residual]; the two extras ride in the kernel epilogue when the
         gfx950 implicit-GEMM conv / GEMM is used.  `temb_div` > 1: image i uses temb row i // temb_div.
         `upsample`: conv(nearest-2x(x)) with the upsample folded into the kernel's operand addressing."""
@@ -86,8 +88,9 @@ class Conv2d(nn.Conv2d):
             n, c, h, w = x.shape
             assert temb is None
             y = linear_op(to_tokens(x), self.weight.view(self.out_channels, self.in_channels), self.bias,
-                          None if residual is None else to_tokens(residual))
+                          None if residual is None else to_tokens(residual), 1.0, None if x2 is None else to_tokens(x2))
             return from_tokens(y, h, w)
+        assert x2 is None, "two-source input: 1x1 convs only"
         if not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad or
@@ -125,15 +128,20 @@ class Conv2d(nn.Conv2d):
         return hit[1]
 
 
-def linear_op(x, weight, bias=None, residual=None, alpha: float = 1.0):
+def linear_op(x, weight, bias=None, residual=None, alpha: float = 1.0, x2=None):
     """`alpha * (x @ W^T + b) + residual`: fused gfx950 GEMM or hipBLASLt + epilogue passes (`hip_ops.linear`) for
     frozen bf16 weights on the GPU, plain autograd ops otherwise."""
     if x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16:
         grad = torch.is_grad_enabled()
-        if not (grad and (x.requires_grad or weight.requires_grad or (residual is not None and residual.requires_grad))):
-            return K.linear(x, weight, bias, residual, alpha)
+        if not (grad and (x.requires_grad or weight.requires_grad or (residual is not None and residual.requires_grad)
+                          or (x2 is not None and x2.requires_grad))):
+            return K.linear(x, weight, bias, residual, alpha, x2)
+        if x2 is not None:
+            x, x2 = torch.cat([x, x2], dim=-1), None
         if not weight.requires_grad and (bias is None or not bias.requires_grad):   # frozen layer, activation gradient only
             return K.linear_frozen(x, weight, bias, residual, alpha)
+    if x2 is not None:
+        x = torch.cat([x, x2], dim=-1)
     y = F.linear(x, weight, bias)
     if alpha != 1.0:
         y = y * alpha
@@ -225,15 +233,19 @@ class ResnetBlock2D(nn.Module):
     # set by the U-Net for one forward (inference): (`[clips, Cout]` slice of the batched projection, frames per clip)
     _t_pre = None
 
-    def forward(self, input_tensor, temb, scale: float = 1.0):
+    def forward(self, input_tensor, temb, scale: float = 1.0, skip: Optional[torch.Tensor] = None):
+        """`skip`: the up blocks' skip connection -- the block input is `cat([input_tensor, skip], 1)`
+        (unet_blocks.py:683,798), read in place by the two consumers (norm1, the 1x1 shortcut) instead of being built."""
         t, div = None, 1
         if self._t_pre is not None:
             t, div = self._t_pre
         elif self.time_emb_proj is not None and temb is not None:
             t = self.time_emb_proj(F.silu(temb))                       # [N, Cout], rides in conv1's epilogue
-        h = self.conv1(self.norm1(input_tensor, act=True), temb=t, temb_div=div)
+        if skip is not None and self.conv_shortcut is None:
+            input_tensor, skip = torch.cat([input_tensor, skip], dim=1), None
+        h = self.conv1(self.norm1(input_tensor, act=True, x2=skip), temb=t, temb_div=div)
         if self.conv_shortcut is not None:
-            input_tensor = self.conv_shortcut(input_tensor)
+            input_tensor = self.conv_shortcut(input_tensor, x2=skip)
         out = self.conv2(self.norm2(h, act=True), residual=input_tensor)   # `input + h` rides in conv2's epilogue
         return out if self.output_scale_factor == 1.0 else out / self.output_scale_factor
 

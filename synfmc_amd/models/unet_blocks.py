@@ -104,9 +104,10 @@ class _Block3D(nn.Module):
             kw = {"scale": ms} if kw is None else {**kw, "scale": ms}
         return {} if kw is None else kw
 
-    def _layer(self, i, x4, b, f, temb_rep, text, cross_kw, motion_kw):
-        """x4: `(b f) c h w`.  resnet -> [transformer] -> [motion module]."""
-        x4 = self.resnets[i](x4, temb_rep)
+    def _layer(self, i, x4, b, f, temb_rep, text, cross_kw, motion_kw, skip4=None):
+        """x4: `(b f) c h w`.  resnet -> [transformer] -> [motion module].  `skip4`: up-block skip connection, the
+        resnet input is `cat([x4, skip4], 1)`."""
+        x4 = self.resnets[i](x4, temb_rep, skip=skip4)
         if self.has_cross_attention:
             x4 = self.attentions[i](x4, encoder_hidden_states=text, cross_attention_kwargs=cross_kw).sample
         mm = self.motion_modules[i] if len(self.motion_modules) else None
@@ -296,8 +297,7 @@ class _UpBlock(_Block3D):
         for i in range(len(self.resnets)):
             skip4 = _frames_first(res_hidden_states_tuple[-1])[0]
             res_hidden_states_tuple = res_hidden_states_tuple[:-1]
-            x4 = torch.cat([x4, skip4], dim=1)
-            x4 = self._layer(i, x4, b, f, temb_rep, text, cross_kw, motion_kw)
+            x4 = self._layer(i, x4, b, f, temb_rep, text, cross_kw, motion_kw, skip4)   # cat([x4, skip4]) read in place
         if self.upsamplers is not None:
             for up in self.upsamplers:
                 x4 = up(x4, upsample_size)

@@ -469,6 +469,38 @@ def test_conv3x3_bf16_stride2(K, tile):
     assert rel_inf(out.permute(0, 3, 1, 2).float(), ref) < 1e-2
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,HW,C1,C2", [(2, 2560, 320, 320), (3, 160, 1280, 640), (2, 40, 1280, 1280), (2, 640, 640, 320)])
+def test_groupnorm_two_source_concat(K, dtype, N, HW, C1, C2):
+    """up-block ResNet input: GroupNorm(+SiLU) of cat([hidden, skip], channels) with the concat never materialised
+    (two-pass kernels at 40x64, single-pass kernel at the smaller levels)"""
+    xo, xd = rnd((N, HW, C1), 90, dtype, scale=1.3, shift=0.2)
+    so, sd = rnd((N, HW, C2), 91, dtype, scale=0.7, shift=-0.4)
+    go, gd = rnd((C1 + C2,), 92, torch.float32)
+    bo, bd = rnd((C1 + C2,), 93, torch.float32)
+    cat = torch.cat([xo, so], dim=-1)
+    ref = F.silu(F.group_norm(cat.permute(0, 2, 1), 32, go, bo, 1e-5)).permute(0, 2, 1)
+    out = K.groupnorm_silu(xd, gd, bd, 32, 1e-5, True, x2=sd)
+    assert out.shape == (N, HW, C1 + C2) and rel_inf(out.float(), ref) < TOL[dtype] * (5 if dtype == torch.float32 else 1)
+    assert torch.equal(out, K.groupnorm_silu(torch.cat([xd, sd], dim=-1), gd, bd, 32, 1e-5, True))
+
+
+@pytest.mark.parametrize("tile", [0, 1, 3, 5, 11, 128 + 2])
+def test_linear_two_source_concat(K, tile):
+    """1x1 shortcut conv of an up-block ResNet: x @ W^T with x = cat([hidden, skip]) read from the two tensors"""
+    dtype = torch.bfloat16
+    M, K1, K2, N = 1000, 640, 320, 328
+    xo, xd = rnd((M, K1), 94, dtype)
+    so, sd = rnd((M, K2), 95, dtype)
+    wo, wd = rnd((N, K1 + K2), 96, dtype, scale=(K1 + K2) ** -0.5)
+    bo, bd = rnd((N,), 97, dtype)
+    ref = F.linear(torch.cat([xo, so], -1), wo, bo)
+    out = K.linear_bf16(xd, wd, bd, None, 1.0, tile=tile, x2=sd)
+    assert rel_inf(out.float(), ref) < 1e-2
+    if tile < 128:
+        assert torch.equal(out, K.linear_bf16(torch.cat([xd, sd], -1), wd, bd, None, 1.0, tile=tile))
+
+
 # ---------------------------------------------------------------------------------------------
 # backward kernels vs autograd through the oracle's forward (fp32 CPU)
 # ---------------------------------------------------------------------------------------------
