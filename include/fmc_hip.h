@@ -171,16 +171,16 @@ int fmc_cfg_ddim_step(const void* eps_uc, const float* x, float* x_out, int64_t 
  * `qkv_merge(h + pose) * scale + h` (attention_processor.py:257).
  *   x [M, K] rows `ldx` apart, w [N, K] contiguous, bias [N] or NULL, residual [M, N] rows `ldres` apart or NULL,
  *   out [M, N] (epilogue 0) or [M, N/2] (epilogue 1), rows `ldo` apart.  All bf16, fp32 accumulate.
- *   epilogue 1 expects w / bias pre-interleaved per 128-row tile: rows [128t, 128t+64) = value rows
- *   [64t, 64t+64) of the GEGLU projection, rows [128t+64, 128t+128) = the matching gate rows.
- *   Requires K % 64 == 0, N % 8 == 0 (N % 256 == 0 for epilogue 1), strides % 8 == 0.
+ *   epilogue 1 expects w / bias pre-interleaved per 64 rows: rows [64t, 64t+32) = value rows [32t, 32t+32) of the
+ *   GEGLU projection, rows [64t+32, 64t+64) = the matching gate rows.
+ *   Requires K % 64 == 0, N % 8 == 0 (N % 64 == 0 for epilogue 1), strides % 8 == 0.
  *   x2 != NULL: two-source A operand -- columns [0, k_split) of every row come from x, [k_split, K) from x2 (rows
  *   `ldx2` apart, k_split % 64 == 0): the 1x1 shortcut conv of an up-block ResNet reads (hidden, skip) without a concat.
  *   tile: workgroup tile geometry, 0 = pick by shape, 1 = 128x128 (4 waves), 2 = 256x128 (8), 3 = 256x256 (16) with
  *   64-deep k-tiles in a 2-stage LDS ring; 4..6 = the same three with 32-deep k-tiles (half the LDS, twice the
  *   workgroups per CU); 7 = 256x128, 64-deep, 3 stages; 8 / 9 / 10 = 256x256 / 128x128 / 256x128, 32-deep, 4 stages
  *   (deeper rings keep more bytes in flight per CU); 11 = 128x320 (10 waves; spans N = 320 / 640 / 960 without padded
- *   columns; plain epilogue only).  Every arm computes the same function, bit for bit (callers may time them and keep
+ *   columns).  Every arm computes the same function, bit for bit (callers may time them and keep
  *   the fastest).
  *   split_k > 1 (epilogue 0 only): the k-tiles of every output tile are dealt to split_k workgroups that write fp32
  *   partial sums to `workspace` (>= split_k * M * N * 4 bytes, 16-byte aligned, caller-owned scratch); a second kernel

@@ -95,7 +95,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sk_rsrc(float* ws) {
 }
 
 // MODE 0: token GEMM, 1: implicit 3x3 conv.  EPI 0: alpha*(acc+bias) (+temb)(+residual); 1: GEGLU (weights
-// pre-interleaved per 128 rows: 64 value rows then their 64 gate rows; out is [M, N/2]).
+// pre-interleaved per 64 rows: 32 value rows then their 32 gate rows; out is [M, N/2]).
 //
 // BK = 64: two 128-byte-row stages; BK = 32: half the LDS per workgroup, i.e. twice the workgroups per CU -- the arm
 // for the K = 320 / 640 projections, whose 5-10 k-tiles cannot hide the DMA latency behind their own MFMAs and need
@@ -461,26 +461,26 @@ void gemm_kernel(const GemmParams P) {
                 }
             }
         } else {
-            // GEGLU: within every 128 tile columns, [0,64) = value, [64,128) = gate -> 64 output columns
+            // GEGLU: within every 64 tile columns, [0,32) = value, [32,64) = gate -> 32 output columns
             constexpr int CPR = BN / 16;                 // 8-column output chunks per slab row
             constexpr int RSTEP = NT / CPR;
             const int ch = tid % CPR;
-            const int grp = ch / 8, cc = ch % 8;         // 128-column group inside the tile, chunk inside the group
-            const int ncol = grp * 128 + cc * 8;         // tile column of the value chunk
-            const int no = (n0 / 2) + grp * 64 + cc * 8; // output column
+            const int grp = ch / 4, cc = ch % 4;         // 64-column group inside the tile, chunk inside the group
+            const int ncol = grp * 64 + cc * 8;          // tile column of the value chunk
+            const int no = (n0 / 2) + grp * 32 + cc * 8; // output column
             if (no < P.N / 2) {
                 float ba[8], bg[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     ba[i] = P.bias ? bf2f(P.bias[n0 + ncol + i]) : 0.f;
-                    bg[i] = P.bias ? bf2f(P.bias[n0 + ncol + 64 + i]) : 0.f;
+                    bg[i] = P.bias ? bf2f(P.bias[n0 + ncol + 32 + i]) : 0.f;
                 }
                 for (int r = tid / CPR; r < 64; r += RSTEP) {
                     const int64_t m = m0 + hm * 64 + r;
                     if (m >= P.M) continue;
                     float a[8], g[8];
                     Vec8<float>::load(Cs + r * CP + ncol, a);
-                    Vec8<float>::load(Cs + r * CP + ncol + 64, g);
+                    Vec8<float>::load(Cs + r * CP + ncol + 32, g);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) a[k] = (a[k] + ba[k]) * gelu_erf(g[k] + bg[k]);
                     Vec8<bf16_t>::store(P.out + m * P.ldo + no, a);
@@ -620,14 +620,8 @@ void launch_gemm(GemmParams& P, int tile, hipStream_t st) {
         else g = 1;
     }
     switch (g) {
-        case 12:                                         // 128x320, 32-deep k-tiles, 4-stage ring
-            if constexpr (EPI == 0) launch_gemm_g<MODE, EPI, 2, 5, 32, 4>(P, st);
-            else launch_gemm_g<MODE, EPI, 4, 4, 64, 2>(P, st);
-            break;
-        case 11:                                         // 128x320: 2 x 5 waves (plain epilogue only)
-            if constexpr (EPI == 0) launch_gemm_g<MODE, EPI, 2, 5, 64, 2>(P, st);
-            else launch_gemm_g<MODE, EPI, 4, 4, 64, 2>(P, st);
-            break;
+        case 12: launch_gemm_g<MODE, EPI, 2, 5, 32, 4>(P, st); break;   // 128x320, 32-deep k-tiles, 4-stage ring
+        case 11: launch_gemm_g<MODE, EPI, 2, 5, 64, 2>(P, st); break;   // 128x320: 2 x 5 waves
         case 10: launch_gemm_g<MODE, EPI, 4, 2, 32, 4>(P, st); break;
         case 9: launch_gemm_g<MODE, EPI, 2, 2, 32, 4>(P, st); break;
         case 8: launch_gemm_g<MODE, EPI, 4, 4, 32, 4>(P, st); break;
@@ -676,7 +670,7 @@ extern "C" int fmc_linear_bf16(const void* x, const void* w, const void* bias, c
     if (M <= 0 || N <= 0 || K <= 0 || K % BK_MAX || N % 8 || ldx % 8 || ldo % 8 || (residual && ldres % 8))
         FMC_FAIL(FMC_E_SHAPE, "linear_bf16: need K%%64==0, N%%8==0 and strides %%8==0 (M=%lld N=%d K=%d)", (long long)M, N, K);
     if (epilogue != 0 && epilogue != 1) FMC_FAIL(FMC_E_SHAPE, "linear_bf16: epilogue %d", epilogue);
-    if (epilogue == 1 && (N % 256 || residual)) FMC_FAIL(FMC_E_SHAPE, "linear_bf16: GEGLU needs N%%256==0 and no residual");
+    if (epilogue == 1 && (N % 64 || residual)) FMC_FAIL(FMC_E_SHAPE, "linear_bf16: GEGLU needs N%%64==0 and no residual");
     if (!fmc_aligned16(x) || !fmc_aligned16(w) || !fmc_aligned16(out) || (residual && !fmc_aligned16(residual)) ||
         (bias && !fmc_aligned16(bias)))
         FMC_FAIL(FMC_E_ALIGN, "linear_bf16: tensors must be 16-byte aligned");

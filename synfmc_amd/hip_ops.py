@@ -677,7 +677,7 @@ def geglu_linear(x: torch.Tensor, weight: torch.Tensor, bias, weight_il: torch.T
     `bias_il` are the tile-interleaved copies the fused kernel wants (`models.layers.interleave_geglu`)."""
     import torch.nn.functional as F
     lib = lambda: geglu(F.linear(x, weight, bias))
-    if not linear_supported(x, weight_il) or weight_il.shape[0] % 256 or (x.ndim > 2 and not x.is_contiguous()):
+    if not linear_supported(x, weight_il) or weight_il.shape[0] % 64 or (x.ndim > 2 and not x.is_contiguous()):
         return lib()
     N, Kd = weight.shape
     M = x.numel() // Kd

@@ -376,12 +376,13 @@ class Attention(nn.Module):
 
 
 def interleave_geglu(weight: torch.Tensor, bias: Optional[torch.Tensor]):
-    """Row order `fmc_linear_bf16(epilogue=GEGLU)` expects: per 128-row tile, 64 value rows then their 64 gate rows."""
+    """Row order `fmc_linear_bf16(epilogue=GEGLU)` expects: per 64 rows, 32 value rows then their 32 gate rows (so any
+    tile width that is a multiple of 64 holds matching value / gate columns)."""
     two_cff, k = weight.shape
     cff = two_cff // 2
-    assert cff % 64 == 0
-    w = weight.view(2, cff // 64, 64, k).permute(1, 0, 2, 3).reshape(two_cff, k).contiguous()
-    b = None if bias is None else bias.view(2, cff // 64, 64).permute(1, 0, 2).reshape(two_cff).contiguous()
+    assert cff % 32 == 0
+    w = weight.view(2, cff // 32, 32, k).permute(1, 0, 2, 3).reshape(two_cff, k).contiguous()
+    b = None if bias is None else bias.view(2, cff // 32, 32).permute(1, 0, 2).reshape(two_cff).contiguous()
     return w, b
 
 
