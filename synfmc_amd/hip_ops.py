@@ -728,17 +728,16 @@ def conv3x3(x_nchw: torch.Tensor, weight_cl: torch.Tensor, bias, temb=None, resi
 #   conv3x3:  dX = conv3x3(dY, W') with W'[ci, ky, kx, co] = W[co, 2-ky, 2-kx, ci]   (pad 1, stride 1)
 #   linear:   dX = alpha * dY @ W,  d(residual) = dY
 # --------------------------------------------------------------------------------------------
-_flip_cache = {}
-
-
 def _flipped_filter(weight_cl: torch.Tensor) -> torch.Tensor:
-    """`[Cin, Cout, 3, 3]` filter of the backward-data convolution, channels-last memory format, cached per weight."""
-    key = (weight_cl.data_ptr(), weight_cl._version)
-    hit = _flip_cache.get(key)
-    if hit is None:
-        hit = weight_cl.detach().flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
-        _flip_cache[key] = hit
-    return hit
+    """`[Cin, Cout, 3, 3]` filter of the backward-data convolution, channels-last memory format.  Cached ON the weight
+    tensor (an attribute, keyed by its version counter): a global dict keyed by `data_ptr()` hands out stale filters
+    when a freed weight's address is reused by another model."""
+    hit = getattr(weight_cl, "_fmc_flipped", None)
+    if hit is None or hit[0] != weight_cl._version:
+        hit = (weight_cl._version,
+               weight_cl.detach().flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last))
+        weight_cl._fmc_flipped = hit
+    return hit[1]
 
 
 class _Conv3x3Frozen(torch.autograd.Function):
