@@ -296,6 +296,100 @@ class _TemporalAttention(torch.autograd.Function):
         return dq, dk, dv, None, None
 
 
+class _SelfAttentionQKV(torch.autograd.Function):
+    """Self attention on the fused projection output `qkv [.., 3C]`; the backward kernels write dQ | dK | dV straight
+    into ONE `[.., 3C]` gradient through their stride arguments.  (Passing the three slices through autograd instead
+    costs, per attention, three zero-fills of the fused shape, three slice copies and two adds.)"""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, scale, temporal):
+        C = qkv.shape[-1] // 3
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        ctx.heads, ctx.scale, ctx.temporal = heads, scale, temporal
+        if temporal:
+            ctx.save_for_backward(qkv)
+            return _temporal_attention_raw(q, k, v, heads, scale)
+        o, lse = _spatial_attention_raw(q, k, v, heads, scale, True)
+        ctx.save_for_backward(qkv, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        qkv = ctx.saved_tensors[0]
+        C = qkv.shape[-1] // 3
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        d_o = d_o.contiguous()
+        dqkv = torch.empty(qkv.shape, dtype=qkv.dtype, device=qkv.device)
+        dq, dk, dv = dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:]
+        heads = ctx.heads
+        if ctx.temporal:
+            B, P, F, cs, fs, ps = _tstrides(q)
+            _, _, _, ocs, ofs, ops = _tstrides(d_o)
+            _, _, _, dcs, dfs, dps = _tstrides(dq)
+            _lib.check(_lib.load().fmc_temporal_attn_bwd(
+                q.data_ptr(), k.data_ptr(), v.data_ptr(), d_o.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B,
+                P, F, heads, C // heads, cs, fs, ps, ocs, ofs, ops, dcs, dfs, dps, float(ctx.scale), _dt(q), _stream()),
+                "fmc_temporal_attn_bwd")
+        else:
+            _, o, lse = ctx.saved_tensors
+            B, S, _ = q.shape
+            dvec = torch.empty(B, heads, S, dtype=torch.float32, device=q.device)
+            _lib.check(_lib.load().fmc_spatial_attn_bwd(
+                q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), dvec.data_ptr(),
+                dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, heads, S, S, C // heads, q.stride(0), q.stride(1),
+                k.stride(0), k.stride(1), S * C, C, dq.stride(0), dq.stride(1), dk.stride(0), dk.stride(1), 1,
+                float(ctx.scale), _dt(q), _stream()), "fmc_spatial_attn_bwd")
+        return dqkv, None, None, None
+
+
+class _CrossAttentionQKV(torch.autograd.Function):
+    """Cross attention with the fused `kv [Bkv, Skv, 2C]` projection; one fused dK | dV gradient."""
+
+    @staticmethod
+    def forward(ctx, q, kv, heads, scale):
+        C = q.shape[-1]
+        o, lse = _spatial_attention_raw(q, kv[..., :C], kv[..., C:], heads, scale, True)
+        ctx.save_for_backward(q, kv, o, lse)
+        ctx.heads, ctx.scale = heads, scale
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        q, kv, o, lse = ctx.saved_tensors
+        B, Sq, C = q.shape
+        Bkv, Skv, _ = kv.shape
+        k, v = kv[..., :C], kv[..., C:]
+        heads = ctx.heads
+        d_o = d_o.contiguous()
+        dq = torch.empty(B, Sq, C, dtype=q.dtype, device=q.device)
+        dkv = torch.empty(kv.shape, dtype=q.dtype, device=q.device)
+        dk, dv = dkv[..., :C], dkv[..., C:]
+        dvec = torch.empty(B, heads, Sq, dtype=torch.float32, device=q.device)
+        _lib.check(_lib.load().fmc_spatial_attn_bwd(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), dvec.data_ptr(),
+            dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, heads, Sq, Skv, C // heads, q.stride(0), q.stride(1),
+            k.stride(0), k.stride(1), Sq * C, C, Sq * C, C, dk.stride(0), dk.stride(1), B // Bkv, float(ctx.scale),
+            _dt(q), _stream()), "fmc_spatial_attn_bwd")
+        return dq, dkv, None, None
+
+
+def self_attention_qkv(qkv: torch.Tensor, heads: int, scale: float, temporal: bool) -> torch.Tensor:
+    """Attention on a fused `[.., 3C]` projection (q | k | v); differentiable with a single fused gradient."""
+    C = qkv.shape[-1] // 3
+    if torch.is_grad_enabled() and qkv.requires_grad:
+        return _SelfAttentionQKV.apply(qkv, heads, scale, temporal)
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    return _temporal_attention_raw(q, k, v, heads, scale) if temporal else _spatial_attention_raw(q, k, v, heads, scale)
+
+
+def cross_attention_q_kv(q: torch.Tensor, kv: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
+    """Cross attention with a fused `[.., 2C]` (k | v) projection; differentiable with a fused dK | dV gradient."""
+    C = q.shape[-1]
+    if torch.is_grad_enabled() and (q.requires_grad or kv.requires_grad):
+        return _CrossAttentionQKV.apply(q, kv, heads, scale)
+    return _spatial_attention_raw(q, kv[..., :C], kv[..., C:], heads, scale)
+
+
 def temporal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
                        scale: Optional[float] = None) -> torch.Tensor:
     """Attention over the frame axis (see `_temporal_attention_raw`); differentiable (fmc_temporal_attn_bwd)."""

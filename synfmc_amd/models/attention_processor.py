@@ -41,16 +41,12 @@ def _attention_core(attn, q_in: torch.Tensor, kv_in: Optional[torch.Tensor], tem
     c = attn.inner_dim
     if kv_in is None:                                   # self attention: one [.., 3C] GEMM
         qkv = linear_op(q_in, w_a)
-        q, k, v = qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
-        if temporal:
-            o = K.temporal_attention(q, k, v, heads, attn.scale)
-        else:
-            o = K.spatial_attention(q, k, v, heads, attn.scale)
+        o = K.self_attention_qkv(qkv, heads, attn.scale, temporal)      # q | k | v stay slices of the fused output
     else:                                               # cross attention: q GEMM + one [.., 2C] kv GEMM
         assert not temporal
         q = linear_op(q_in, w_a)
         kv = linear_op(kv_in, w_b)
-        o = K.spatial_attention(q, kv[..., :c], kv[..., c:], heads, attn.scale)
+        o = K.cross_attention_q_kv(q, kv, heads, attn.scale)
     return linear_op(o, w_o, attn.to_out[0].bias, residual)
 
 

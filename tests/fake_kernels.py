@@ -54,6 +54,17 @@ def temporal_attention(q, k, v, heads, scale=None):
     return _attn(q, k, v, heads, scale).to(q.dtype)
 
 
+def self_attention_qkv(qkv, heads, scale, temporal):
+    c = qkv.shape[-1] // 3
+    q, k, v = qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
+    return temporal_attention(q, k, v, heads, scale) if temporal else spatial_attention(q, k, v, heads, scale)
+
+
+def cross_attention_q_kv(q, kv, heads, scale):
+    c = q.shape[-1]
+    return spatial_attention(q, kv[..., :c], kv[..., c:], heads, scale)
+
+
 def mask_modulate(x, mask_in, h, w):
     m = F.interpolate(mask_in[:, None], size=(h, w), mode="nearest")
     return (x.float() * m.reshape(x.shape[0], h * w, 1)).to(x.dtype), m[:, 0].contiguous()
@@ -107,7 +118,8 @@ def omc_rasterize(poses, masks, layout="planar", dtype=torch.float32):
     return F.pixel_unshuffle(feat, 8).permute(0, 2, 3, 1).contiguous().to(dtype), mo[:, 0].contiguous()
 
 
-ALL = ["groupnorm_silu", "layernorm", "geglu", "spatial_attention", "temporal_attention", "mask_modulate",
+ALL = ["groupnorm_silu", "layernorm", "geglu", "spatial_attention", "temporal_attention", "self_attention_qkv",
+       "cross_attention_q_kv", "mask_modulate",
        "feature_add", "cfg_ddim_step", "plucker", "omc_rasterize"]
 
 
