@@ -227,7 +227,8 @@ int fmc_layernorm_bwd(const void* dy, const void* x, const float* gamma, void* d
 int fmc_geglu_bwd(const void* dy, const void* x, void* dx, int64_t M, int Cff, int dtype, void* stream);
 /* dQ, dK, dV of fmc_spatial_attn_fwd.  o / lse are the forward's outputs, d_o has o's strides, dvec is a
  * [B, H, Sq] fp32 scratch (receives rowsum(dO .* O)).  dk / dv are [B / kv_batch_div, Skv, H*D]: frames sharing one
- * text K/V are summed inside the kernel. */
+ * text K/V are summed inside the kernel.  dk and dv may be NULL together (frozen text projections: the key/value
+ * side needs no gradient); the dK/dV kernel is then not launched. */
 int fmc_spatial_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
                          float* dvec, void* dq, void* dk, void* dv, int B, int H, int Sq, int Skv, int D,
                          int64_t q_batch_stride, int64_t q_row_stride, int64_t kv_batch_stride, int64_t kv_row_stride,

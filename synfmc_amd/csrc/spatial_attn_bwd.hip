@@ -330,7 +330,7 @@ void launch_bwd(SABwdParams P, hipStream_t st) {
         P.nblk = (P.Sq + 127) / 128;
         hipLaunchKernelGGL((attn_dq_kernel<T, NKS>), dim3((unsigned)(P.B * P.H * P.nblk)), dim3(256), lds, st, P);
     }
-    {
+    if (P.dk) {                                       // dk == dv == NULL: the key/value side needs no gradient
         constexpr int BKV = 32 * WAVES;
         const size_t lds = sizeof(T) * ((size_t)2 * BKV * KP + (size_t)2 * BQ * KP + (size_t)2 * NDT * 32 * (BQ + 4)) +
                            2 * BQ * sizeof(float);
@@ -367,7 +367,8 @@ extern "C" int fmc_spatial_attn_bwd(const void* q, const void* k, const void* v,
                                     int64_t o_row_stride, int64_t dq_batch_stride, int64_t dq_row_stride,
                                     int64_t dkv_batch_stride, int64_t dkv_row_stride, int kv_batch_div, float scale,
                                     int dtype, void* stream) {
-    if (!q || !k || !v || !o || !d_o || !lse || !dvec || !dq || !dk || !dv) FMC_FAIL(FMC_E_NULL, "spatial_attn_bwd: NULL tensor");
+    if (!q || !k || !v || !o || !d_o || !lse || !dvec || !dq || (!dk != !dv))
+        FMC_FAIL(FMC_E_NULL, "spatial_attn_bwd: NULL tensor (dk and dv may be NULL together)");
     if (dtype != FMC_BF16 && dtype != FMC_F32) FMC_FAIL(FMC_E_DTYPE, "spatial_attn_bwd: dtype %d", dtype);
     if (B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0 || D <= 0 || D % 8 || D > 160 || kv_batch_div <= 0 || B % kv_batch_div)
         FMC_FAIL(FMC_E_SHAPE, "spatial_attn_bwd: bad shape (B=%d H=%d Sq=%d Skv=%d D=%d div=%d)", B, H, Sq, Skv, D, kv_batch_div);
@@ -377,7 +378,7 @@ extern "C" int fmc_spatial_attn_bwd(const void* q, const void* k, const void* v,
         if (s % 8) FMC_FAIL(FMC_E_ALIGN, "spatial_attn_bwd: strides must be multiples of 8 elements");
     const void* ptrs[] = {q, k, v, o, d_o, dq, dk, dv};
     for (const void* p : ptrs)
-        if (!fmc_aligned16(p)) FMC_FAIL(FMC_E_ALIGN, "spatial_attn_bwd: tensors must be 16-byte aligned");
+        if (p && !fmc_aligned16(p)) FMC_FAIL(FMC_E_ALIGN, "spatial_attn_bwd: tensors must be 16-byte aligned");
     SABwdParams P;
     P.q = q; P.k = k; P.v = v; P.o = o; P.d_o = d_o; P.lse = lse; P.dvec = dvec; P.dq = dq; P.dk = dk; P.dv = dv;
     P.B = B; P.H = H; P.Sq = Sq; P.Skv = Skv; P.D = D;

@@ -225,12 +225,13 @@ class _SpatialAttention(torch.autograd.Function):
         D = C // heads
         d_o = d_o.contiguous()
         dq = torch.empty(B, Sq, C, dtype=q.dtype, device=q.device)
-        dk = torch.empty(Bkv, Skv, C, dtype=q.dtype, device=q.device)
-        dv = torch.empty(Bkv, Skv, C, dtype=q.dtype, device=q.device)
+        need_kv = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dk = torch.empty(Bkv, Skv, C, dtype=q.dtype, device=q.device) if need_kv else None
+        dv = torch.empty(Bkv, Skv, C, dtype=q.dtype, device=q.device) if need_kv else None
         dvec = torch.empty(B, heads, Sq, dtype=torch.float32, device=q.device)
         _lib.check(_lib.load().fmc_spatial_attn_bwd(
             q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), dvec.data_ptr(),
-            dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, heads, Sq, Skv, D, q.stride(0), q.stride(1), k.stride(0),
+            dq.data_ptr(), _p(dk), _p(dv), B, heads, Sq, Skv, D, q.stride(0), q.stride(1), k.stride(0),
             k.stride(1), Sq * C, C, Sq * C, C, Skv * C, C, B // Bkv, float(ctx.scale), _dt(q), _stream()),
             "fmc_spatial_attn_bwd")
         return dq, dk, dv, None, None
@@ -362,14 +363,26 @@ class _CrossAttentionQKV(torch.autograd.Function):
         heads = ctx.heads
         d_o = d_o.contiguous()
         dq = torch.empty(B, Sq, C, dtype=q.dtype, device=q.device)
-        dkv = torch.empty(kv.shape, dtype=q.dtype, device=q.device)
-        dk, dv = dkv[..., :C], dkv[..., C:]
         dvec = torch.empty(B, heads, Sq, dtype=torch.float32, device=q.device)
+        div, kbs = B // Bkv, k.stride(0)
+        if not ctx.needs_input_grad[1]:
+            # frozen to_k / to_v on a constant text embedding (every FMC training stage): no dK / dV kernel at all
+            dkv = dk = dv = None
+        elif Bkv == 1 and div > 1:
+            # one text for all frames: per-frame partial dK | dV (batch stride 0 on K / V keeps B x heads workgroups
+            # busy instead of `heads`), summed over the frames afterwards
+            part = torch.empty(B, Skv, 2 * C, dtype=q.dtype, device=q.device)
+            dk, dv, div, kbs, dkv = part[..., :C], part[..., C:], 1, 0, part
+        else:
+            dkv = torch.empty(kv.shape, dtype=q.dtype, device=q.device)
+            dk, dv = dkv[..., :C], dkv[..., C:]
         _lib.check(_lib.load().fmc_spatial_attn_bwd(
             q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), dvec.data_ptr(),
-            dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, heads, Sq, Skv, C // heads, q.stride(0), q.stride(1),
-            k.stride(0), k.stride(1), Sq * C, C, Sq * C, C, dk.stride(0), dk.stride(1), B // Bkv, float(ctx.scale),
-            _dt(q), _stream()), "fmc_spatial_attn_bwd")
+            dq.data_ptr(), _p(dk), _p(dv), B, heads, Sq, Skv, C // heads, q.stride(0), q.stride(1), kbs, k.stride(1),
+            Sq * C, C, Sq * C, C, dk.stride(0) if dk is not None else 0, dk.stride(1) if dk is not None else 2 * C, div,
+            float(ctx.scale), _dt(q), _stream()), "fmc_spatial_attn_bwd")
+        if dkv is not None and dkv.shape[0] != Bkv:
+            dkv = dkv.sum(0, keepdim=True, dtype=torch.float32).to(q.dtype)
         return dq, dkv, None, None
 
 

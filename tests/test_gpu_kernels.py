@@ -565,6 +565,28 @@ def test_spatial_attention_backward_cross_shared_text(K, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("clips,kv_grad", [(1, True), (2, True), (1, False)])
+def test_cross_attention_fused_kv_backward(K, dtype, clips, kv_grad):
+    """Fused K|V projection: one clip = per-frame partial dK|dV summed afterwards, several clips = summed inside the
+    kernel, frozen K/V (the FMC training stages) = no dK/dV kernel; dQ identical in all three."""
+    Fr, S, H, D = 4, 130, 8, 40
+    C = H * D
+    qo, qd = rnd((clips * Fr, S, C), 187, dtype)
+    kvo, kvd = rnd((clips, 77, 2 * C), 188, dtype)
+    do, dd = rnd((clips * Fr, S, C), 189, dtype)
+    qr, kvr = qo.clone().requires_grad_(True), kvo.clone().requires_grad_(True)
+    rep = kvr.repeat_interleave(Fr, dim=0)
+    oracle_attention(qr, rep[..., :C], rep[..., C:], H).backward(do)
+    qg, kvg = qd.clone().requires_grad_(True), kvd.clone().requires_grad_(kv_grad)
+    K.cross_attention_q_kv(qg, kvg, H, D ** -0.5).backward(dd)
+    assert rel_inf(qg.grad.float(), qr.grad) < GTOL[dtype]
+    if kv_grad:
+        assert rel_inf(kvg.grad.float(), kvr.grad) < GTOL[dtype]
+    else:
+        assert kvg.grad is None
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,Fr,P,H,D", [(2, 16, 6, 8, 40), (1, 16, 5, 8, 160), (1, 32, 3, 8, 80), (2, 16, 4, 4, 8)])
 def test_temporal_attention_backward(K, dtype, B, Fr, P, H, D):
     C = H * D
