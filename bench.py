@@ -69,7 +69,7 @@ def build_models(device, dtype):
     with torch.device(device):
         unet = UNet3DConditionModelCamObjCond(**CM.unet_kwargs(WIDTHS, CROSS_DIM))
         unet.set_all_attn_processor(**CM.processor_kwargs(WIDTHS))
-        enc = CameraPoseEncoder(**CM.encoder_kwargs(WIDTHS))
+        enc = CameraPoseEncoder(**CM.encoder_kwargs(WIDTHS, max(16, FRAMES)))
         ada = Adapter(**CM.adapter_kwargs(WIDTHS))
     patch_unet_for_omc(unet)
     for i, m in enumerate((unet, enc, ada)):
@@ -186,8 +186,8 @@ def train_main(args):
     device = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
-    global HEIGHT, WIDTH
-    HEIGHT, WIDTH = 256, 384
+    global FRAMES, HEIGHT, WIDTH
+    FRAMES, HEIGHT, WIDTH = (int(v) for v in args.clip.lower().split("x"))
     dtype = torch.bfloat16
     from synfmc_amd.models.pose_obj_adaptor import CamObjPoseAdaptor
     from synfmc_amd.schedulers import DDIMScheduler
@@ -276,7 +276,7 @@ def train_main(args):
     assert torch.isfinite(loss).all()
     if rank == 0:
         print(json.dumps({
-            "metric": "OMC-stage training steps/sec (secondary), 16x256x384 bf16, frozen U-Net + trainable Adapter",
+            "metric": f"OMC-stage training steps/sec (secondary), {FRAMES}x{HEIGHT}x{WIDTH} bf16, frozen U-Net + trainable Adapter",
             "value": round(world * args.steps / elapsed, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -302,6 +302,8 @@ def main():
                     help="infer = the headline metric (denoising steps/s); train = OMC-stage optimisation steps/s "
                          "(secondary: forward + activation backward through the frozen U-Net + Adapter backward + RCCL "
                          "gradient all-reduce + AdamW), 16x256x384 like configs/obj.yaml")
+    ap.add_argument("--clip", default="16x256x384", help="train mode: frames x height x width of the clip "
+                    "(16x256x384 = configs/obj.yaml; 32x512x512 = BASELINE configs[4] in bf16)")
     args = ap.parse_args()
     if args.mode == "train":
         return train_main(args)

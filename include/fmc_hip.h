@@ -141,6 +141,12 @@ int fmc_plucker_fwd(const float* K, const float* c2w, void* out, int B, int F, i
 int fmc_omc_rasterize_fwd(const float* poses, const float* masks, void* feat, float* mask_out, int BF,
                           int n_obj, int H, int W, int layout, int dtype, void* stream);
 
+/* Gaussian circle masks: the analytic part of the reference's sphere-mask synthesis (fmc/data/dataset.py:5365-5380;
+ * cv2.minEnclosingCircle stays on the host and supplies the circles).  circles [N,3] fp32 = (cx, cy, radius) in
+ * pixels, radius > 0; out [N,H,W] fp32 = [(x-int(cx))^2 + (y-int(cy))^2 <= int(r)^2] * g / max(g),
+ * g = exp(-0.5 (d / (r/2))^2) with d the distance to the float centre.  Feeds fmc_omc_rasterize_fwd. */
+int fmc_gaussian_circle_mask_fwd(const float* circles, float* out, int N, int H, int W, void* stream);
+
 /* y[n,i,j,:] = x[n,i,j,:] * mask_in[n, si(i), sj(j)] with PyTorch's nearest rule
  * si(i) = min(floor(i * (float)Hin/h), Hin-1); also emits the resampled mask for the next level
  * (the reference cascades: fmc/adapter.py:175-177).  Used for the backward too (dX = mask * dY).

@@ -36,6 +36,7 @@ SIGNATURES = {
     "fmc_plucker_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fmc_omc_rasterize_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_void_p]),
+    "fmc_gaussian_circle_mask_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "fmc_mask_modulate_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_int, c_void_p]),
     "fmc_feature_add_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),

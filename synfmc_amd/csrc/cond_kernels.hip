@@ -267,6 +267,30 @@ extern "C" int fmc_plucker_fwd(const float* K, const float* c2w, void* out, int 
     return 0;
 }
 
+
+namespace {
+// ---- Gaussian circle masks (fmc/data/dataset.py:5365-5380, the analytic part: cv2.minEnclosingCircle stays on the host)
+// circles [N,3] = (cx, cy, radius) in pixels.  mask = [ (x-int(cx))^2 + (y-int(cy))^2 <= int(r)^2 ] * g / max(g) with
+// g = exp(-d^2 / (2 (r/2)^2)), d the distance to the float centre; max(g) is attained at the pixel nearest the centre,
+// so g / max(g) = exp(-(d^2 - dmin^2) * 2 / r^2) without a reduction.  HBM bound: one 4-byte store per pixel.
+__global__ void gaussian_circle_mask_kernel(const float* __restrict__ circles, float* __restrict__ out, int H, int W) {
+    const int n = blockIdx.y;
+    const float cx = circles[n * 3], cy = circles[n * 3 + 1], r = circles[n * 3 + 2];
+    const float nx = fminf(fmaxf(rintf(cx), 0.f), (float)(W - 1)), ny = fminf(fmaxf(rintf(cy), 0.f), (float)(H - 1));
+    const float dmin2 = (nx - cx) * (nx - cx) + (ny - cy) * (ny - cy);
+    const float k = -2.f / (r * r) * 1.4426950408889634f;
+    const int icx = (int)cx, icy = (int)cy, ir = (int)r;
+    float* o = out + (int64_t)n * H * W;
+    const int total = H * W;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int y = i / W, x = i - y * W;
+        const float dx = (float)x - cx, dy = (float)y - cy;
+        const bool inside = (x - icx) * (x - icx) + (y - icy) * (y - icy) <= ir * ir;
+        o[i] = inside ? exp2f((dx * dx + dy * dy - dmin2) * k) : 0.f;
+    }
+}
+}  // namespace
+
 extern "C" int fmc_omc_rasterize_fwd(const float* poses, const float* masks, void* feat, float* mask_out, int BF,
                                      int n_obj, int H, int W, int layout, int dtype, void* stream) {
     if (!poses || !masks || !feat || !mask_out) FMC_FAIL(FMC_E_NULL, "omc_rasterize: NULL argument");
@@ -291,6 +315,15 @@ extern "C" int fmc_omc_rasterize_fwd(const float* poses, const float* masks, voi
             hipLaunchKernelGGL((raster_planar_kernel<float>), grid, block, 0, st, poses, masks, (float*)feat, mask_out, n_obj, H, W);
     }
     FMC_CHECK_LAUNCH("fmc_omc_rasterize_fwd");
+    return 0;
+}
+
+extern "C" int fmc_gaussian_circle_mask_fwd(const float* circles, float* out, int N, int H, int W, void* stream) {
+    if (!circles || !out) FMC_FAIL(FMC_E_NULL, "gaussian_circle_mask: NULL argument");
+    if (N <= 0 || H <= 0 || W <= 0 || N > 65535) FMC_FAIL(FMC_E_SHAPE, "gaussian_circle_mask: bad shape N=%d H=%d W=%d", N, H, W);
+    dim3 grid(grid_for((int64_t)H * W, 256, 256), N), block(256);
+    hipLaunchKernelGGL(gaussian_circle_mask_kernel, grid, block, 0, (hipStream_t)stream, circles, out, H, W);
+    FMC_CHECK_LAUNCH("fmc_gaussian_circle_mask_fwd");
     return 0;
 }
 

@@ -1,6 +1,7 @@
-"""Pluecker-ray conditioning on device (`fmc/data/dataset.py:930-972`, `train_cam_obj_ctrl.py:80-91`).
+"""Pluecker-ray conditioning and Gaussian circle masks on device (`fmc/data/dataset.py:930-972,5365-5380`,
+`train_cam_obj_ctrl.py:80-91`).
 
-Only the two functions the hot path calls are provided; the SynFMC dataset classes (folder / CSV parsing,
+Only the functions the hot path consumes are provided; the SynFMC dataset classes (folder / CSV parsing,
 captions, mask loading) are CPU data preparation and out of scope.  The reference
 computes the embedding on the CPU every training step and copies 63 MB per clip to the GPU; here one
 `fmc_plucker_fwd` launch writes it in HBM.
@@ -32,3 +33,10 @@ def to_plucker_embedding(c2w_rel_poses, intrinsics, sample_size, ori_h=None, ori
     if layout == "bfchw":
         return K.plucker(intr, c2w, H, W, "bcfhw", dtype).permute(0, 2, 1, 3, 4)
     return K.plucker(intr, c2w, H, W, layout, dtype)
+
+
+def gaussian_circle_masks(circles, H, W, device="cuda"):
+    """Analytic half of the reference's sphere masks (`dataset.py:5365-5380`): `circles [..., 3]` = (cx, cy, radius)
+    from `cv2.minEnclosingCircle` (host side, out of scope) -> `[..., H, W]` fp32 masks written in HBM by
+    `fmc_gaussian_circle_mask_fwd`, ready for `util.get_traj_features_v2` / `fmc_omc_rasterize_fwd`."""
+    return K.gaussian_circle_masks(torch.as_tensor(circles, dtype=torch.float32).to(device), H, W)

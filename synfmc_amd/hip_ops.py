@@ -461,6 +461,16 @@ def plucker(K: torch.Tensor, c2w: torch.Tensor, H: int, W: int, layout: str = "b
     return out
 
 
+def gaussian_circle_masks(circles: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """circles `[..., 3]` = (cx, cy, radius) pixels -> Gaussian circle masks `[..., H, W]` fp32 (dataset.py:5365-5380)."""
+    _dev(circles)
+    c = circles.to(torch.float32).contiguous()
+    out = torch.empty(*c.shape[:-1], H, W, dtype=torch.float32, device=c.device)
+    _lib.check(_lib.load().fmc_gaussian_circle_mask_fwd(c.data_ptr(), out.data_ptr(), c.numel() // 3, H, W, _stream()),
+               "fmc_gaussian_circle_mask_fwd")
+    return out
+
+
 def omc_rasterize(poses: torch.Tensor, masks: torch.Tensor, layout: str = "planar",
                   dtype: torch.dtype = torch.float32) -> Tuple[torch.Tensor, torch.Tensor]:
     """poses `[BF, n_obj, 12]`, masks `[BF, n_obj, H, W]` (fp32) -> (features, mask).

@@ -599,3 +599,18 @@ def test_temporal_attention_backward(K, dtype, B, Fr, P, H, D):
     xg = qkvd.clone().requires_grad_(True)
     K.temporal_attention(xg[..., :C], xg[..., C:2 * C], xg[..., 2 * C:], H).backward(dd)
     assert rel_inf(xg.grad.float(), xr.grad) < GTOL[dtype]
+
+
+def test_gaussian_circle_masks_match_oracle(K):
+    """dataset.py:5365-5380 analytic mask: float centres (incl. off-image and x.5 ties), truncated disc radius."""
+    from oracle import conditioning as OC
+    from synfmc_amd.data.dataset import gaussian_circle_masks
+    H, W = 96, 136
+    rng = np.random.default_rng(7)
+    circ = np.concatenate([rng.uniform([0, 0, 4], [W, H, 50], size=(20, 3)),
+                           [[10.5, 20.5, 7.9], [-3.2, 5.0, 12.0], [W + 4.0, H - 1.0, 30.0], [50.0, 40.0, 1.0]]])
+    out = gaussian_circle_masks(circ.reshape(4, 6, 3), H, W)
+    assert out.shape == (4, 6, H, W) and out.dtype == torch.float32
+    ref = np.stack([OC.gaussian_circle_mask(H, W, c[:2], c[2]) for c in circ]).reshape(4, 6, H, W)
+    assert np.abs(out.cpu().numpy() - ref).max() < 2e-6
+    assert ((out.cpu().numpy() > 0) == (ref > 0)).all()
