@@ -111,7 +111,7 @@ def measure_attention_roofline(device, dtype, iters=20):
             "avg_launch_ms": round(ms, 4), "flops_per_launch": flops,
             # HBM-side bytes per launch of this exact shape, from rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, the
             # gfx950 correction of MI355X_MICROARCH.md); recorded, not re-measured here: profiles/r01_attn_pmc.md
-            "traffic": 564.8e6, "traffic_algorithmic": 4.0 * B * S * H * D * 2}
+            "traffic": 259.6e6, "traffic_algorithmic": 4.0 * B * S * H * D * 2}
 
 
 def unet_flops(batch, h, w):

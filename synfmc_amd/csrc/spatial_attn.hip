@@ -16,7 +16,10 @@
 //   * head dims 40 / 80 / 160 (any multiple of 8 up to 160): the QK^T reduction dim is padded to a
 //     multiple of 16 (48/80/160), the PV output dim to a multiple of 32 (64/96/160);
 //   * blockIdx -> (batch*head, q-block) is XCD aware: all q-blocks of one (batch, head) run on the
-//     same XCD so its K/V (<= 400 KB) is served from that XCD's L2;
+//     same XCD so its K/V (<= 400 KB) is served from that XCD's L2 -- and, when the batch count allows, all HEADS
+//     of a batch entry too: a head's 80-byte row slice of the fused [.., 3C] projection shares its 128-byte lines
+//     with the neighbouring heads, so spreading the heads over the XCDs made every L2 fetch those lines again
+//     (measured 2.7x the algorithmic read bytes);
 //   * FMC_F32 storage runs every product as split-bf16 x3 (hi*hi + hi*lo + lo*hi), fp32 accumulate:
 //     the parity mode (agrees with an fp32 reference to ~1e-5), 3x the MFMA work.
 //
@@ -177,7 +180,12 @@ __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 && NQ =
     int bh, qblk;
     {
         const int id = blockIdx.x;
-        if (P.xcd_remap) {
+        if (P.xcd_remap == 2) {                         // all heads of a batch entry on one XCD (see the header)
+            const int xcd = id & 7, within = id >> 3, per_b = P.H * P.nqblk;
+            const int rem = within % per_b;
+            bh = ((within / per_b) * 8 + xcd) * P.H + rem / P.nqblk;
+            qblk = rem % P.nqblk;
+        } else if (P.xcd_remap) {
             const int xcd = id & 7, within = id >> 3;
             bh = (within / P.nqblk) * 8 + xcd;
             qblk = within % P.nqblk;
@@ -484,7 +492,11 @@ extern "C" int fmc_spatial_attn_fwd(const void* q, const void* k, const void* v,
     P.kv_batch_div = kv_batch_div;
     P.scale_log2 = scale * LOG2E;
     P.nqblk = (Sq + SA_BQ - 1) / SA_BQ;
-    P.xcd_remap = ((B * H) % 8 == 0) ? 1 : 0;
+    P.xcd_remap = (B % 8 == 0) ? 2 : ((B * H) % 8 == 0) ? 1 : 0;
+    if (const char* e = getenv("FMC_SA_XCD")) {          // A/B switch: 0 = plain order, 1 = (batch, head) per XCD
+        const int want = atoi(e);
+        if (want == 0 || (want == 1 && (B * H) % 8 == 0)) P.xcd_remap = want;
+    }
     hipStream_t st = (hipStream_t)stream;
     int rc = (dtype == FMC_BF16) ? dispatch_sa<bf16_t>(P, st) : dispatch_sa<float>(P, st);
     if (rc) return rc;
