@@ -50,12 +50,27 @@ struct GemmParams {
                                       //            2 = stride-2 convolution, x is [n, 2H, 2W, Cin]  (H, W = output size)
     float alpha;
     int tiles_m, tiles_n;
+    int tap_outer;                    // conv mode A/B switch (FMC_CONV_TAP_OUTER=1): the old (tap, channel) k order
+    int group_m;                      // tile order: m runs fastest inside groups of group_m m-tiles (see lin_to_tile)
     int split_k;                      // > 1: k-tiles are dealt to split_k workgroups per output tile, which write fp32
     float* ws;                        //      partial sums to ws[split][M][N]; splitk_reduce_kernel applies the epilogue
     int sk;                           // stream-K: grid = sk persistent workgroups (a multiple of 8), each owning a
     int* sk_flags;                    //   contiguous range of (tile, k-tile) iterations; ws[block][BM][BN] partials
     int64_t sk_ws_bytes;
 };
+
+// Launch-order index -> output tile.  Inside a group of `group_m` m-tiles the order is n-outer / m-inner, so the C
+// workgroups an XCD runs at any moment cover ~group_m m-tiles x C/group_m n-tiles: each k-step they pull group_m
+// A sub-tiles and C/group_m W sub-tiles through that XCD's L2 instead of 1 and C (row-major order re-streamed the whole
+// weight matrix from the Infinity Cache once per m-tile row as soon as it outgrew the 4 MB L2: PMC showed 9 TB/s of
+// L2-miss traffic on the GEGLU projections, 12x their algorithmic bytes).
+__device__ __forceinline__ void lin_to_tile(int lin, const GemmParams& P, int& tile_m, int& tile_n) {
+    const int gsz = P.group_m * P.tiles_n;
+    const int g = lin / gsz, r = lin - g * gsz, first = g * P.group_m;
+    const int gm = min(P.group_m, P.tiles_m - first);
+    tile_n = r / gm;
+    tile_m = first + (r - tile_n * gm);
+}
 
 // exact-erf GELU for a bf16 result: erf by Abramowitz & Stegun 7.1.26 (|error| < 1.5e-7, far below bf16's 2^-9) with the
 // hardware reciprocal and exp2 -- libdevice's erff costs ~3x as many VALU slots, and the level-0 GEGLU projection
@@ -164,8 +179,7 @@ void gemm_kernel(const GemmParams P) {
         kt0 = (int)(sk_it - (int64_t)lin * nkt);
         nk = (int)min((int64_t)nkt, kt0 + (sk_end - sk_it));
         sk_it += nk - kt0;
-        tile_m = lin / P.tiles_n;
-        tile_n = lin - tile_m * P.tiles_n;
+        lin_to_tile(lin, P, tile_m, tile_n);
         sk_partial = kt0 > 0;
         if (kt0 == 0 && nk < nkt) {                      // I hold the head of a cut tile: who holds the rest?
             const int64_t tile_end = (int64_t)(lin + 1) * nkt;
@@ -180,9 +194,11 @@ void gemm_kernel(const GemmParams P) {
         int id = blockIdx.x;
         if (P.split_k > 1) id /= P.split_k;              // the splits of one tile are neighbours in launch order
         int lin = id;
-        if (P.split_k == 1 && (total & 7) == 0) lin = (id & 7) * (total >> 3) + (id >> 3);
-        tile_m = lin / P.tiles_n;
-        tile_n = lin - tile_m * P.tiles_n;
+        if (P.split_k == 1) {                            // XCD x = id % 8 owns a contiguous range of the tile order
+            const int q = total >> 3, r = total & 7, x = id & 7;
+            lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+        }
+        lin_to_tile(lin, P, tile_m, tile_n);
     }
     const int64_t m0 = (int64_t)tile_m * BM;
     const int n0 = tile_n * BN;
@@ -228,18 +244,29 @@ void gemm_kernel(const GemmParams P) {
         }
     }
     auto dma_issue = [&](int kt, int buf) {
-        const int k0 = kt * BK;
+        int k0 = kt * BK;
         bf16_t* stage = smem + buf * STAGE_ELEMS;
         const bf16_t* zero = reinterpret_cast<const bf16_t*>(&g_zero16);
-        int64_t shift = k0;
         int dy = 0, dx = 0, ci0 = 0;
+        int tap = 0;
         if (MODE == 1) {
-            const int tap = k0 / P.cin;
-            ci0 = k0 - tap * P.cin;
+            // k-tile order = (channel chunk outer, tap inner): the 9 taps of a chunk re-read the same input lines (shifted by
+            // a pixel) in 9 consecutive k-steps, so they hit the L2.  With (tap outer, channel inner) the re-use distance was
+            // the whole channel depth of every co-resident tile -- the input came back from the Infinity Cache once per tap
+            // (PMC: 565 MB of L2 misses per 1280->640 launch whose input is 65 MB).
+            if (P.tap_outer) {
+                tap = k0 / P.cin;
+                ci0 = k0 - tap * P.cin;
+            } else {
+                const int chunk = kt / 9;
+                tap = kt - chunk * 9;
+                ci0 = chunk * BK;
+                k0 = tap * P.cin + ci0;
+            }
             dy = tap / 3 - 1;
             dx = tap - (tap / 3) * 3 - 1;
-            shift = ((int64_t)dy * P.img_w + dx) * P.cin + ci0;
         }
+        const int64_t shift = MODE == 1 ? ((int64_t)dy * P.img_w + dx) * P.cin + ci0 : (int64_t)k0;
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
             const int p = wave + NW * j;             // wave-uniform
@@ -524,6 +551,15 @@ int gemm_geometry_override() {   // FMC_GEMM_TILE = 0 (caller's choice) | 1..10:
     return v;
 }
 
+int gemm_group_m_override() {   // FMC_GEMM_GM: m-tiles per group of the tile order (1 = row-major); unset = per launch
+    static int v = -2;
+    if (v == -2) {
+        const char* e = getenv("FMC_GEMM_GM");
+        v = e ? atoi(e) : -1;
+    }
+    return v;
+}
+
 // second pass of a split-K launch: out = alpha * (sum_s ws[s] + bias) (+ temb) (+ residual), fixed summation order
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams P) {
     const int cpr = P.N / 8;
@@ -572,15 +608,33 @@ void launch_gemm_g(GemmParams& P, hipStream_t st) {
     constexpr int BM = 32 * MI * WM, BN = 64 * WN;
     P.tiles_m = (int)((P.M + BM - 1) / BM);
     P.tiles_n = (P.N + BN - 1) / BN;
+    P.group_m = 1;
+    {
+        static const int tap_outer = getenv("FMC_CONV_TAP_OUTER") ? atoi(getenv("FMC_CONV_TAP_OUTER")) : 0;
+        P.tap_outer = tap_outer;
+    }
     size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(bf16_t) + 1024;
     const size_t slab = (size_t)64 * (BN + 8) * sizeof(float);
     if (slab > lds) lds = slab;
     unsigned grid = (unsigned)(P.tiles_m * P.tiles_n * P.split_k);
+    // co-resident workgroups per CU (LDS / wave-slot limited)
+    constexpr int by_waves = 16 / (WM * WN) > 0 ? 16 / (WM * WN) : 1;
+    const int by_lds = (int)(160 * 1024 / lds);
+    const int per_cu = by_lds < by_waves ? (by_lds < 1 ? 1 : by_lds) : by_waves;
+    // Tile order (lin_to_tile).  Row-major is optimal while the weight matrix fits an XCD's L2 or the c workgroups an
+    // XCD runs at once already span all n-tiles; otherwise make their footprint square in bytes: gm x c/gm tiles with
+    // gm * BM = (c / gm) * BN.  Measured (tools/pmc_tile_order.sh): L2-miss bytes of the level-1 / level-2 GEGLU
+    // projections 810 -> 172 MB and 1015 -> 221 MB per launch, launch time -4 .. -8 %; convs (3-5 n-tiles, k-lockstep
+    // already shares W) only lost L2 hits to grouping, so they keep row-major.
+    if (gemm_group_m_override() > 0) {
+        P.group_m = gemm_group_m_override();
+    } else if (MODE == 0 && (int64_t)P.N * P.K * 2 > (int64_t)5 << 19) {
+        const double c = fmin(32.0 * per_cu, (double)P.tiles_m * P.tiles_n / 8.0);
+        const int gm = (int)lround(sqrt(c * BN / BM));
+        if (gm > 1 && P.tiles_n * 2 > 3 * (c / gm)) P.group_m = gm;
+    }
     if (P.sk) {
-        // persistent grid: exactly the workgroups that are co-resident (LDS / wave-slot limited), a multiple of 8
-        constexpr int by_waves = 16 / (WM * WN) > 0 ? 16 / (WM * WN) : 1;
-        const int by_lds = (int)(160 * 1024 / lds);
-        const int per_cu = by_lds < by_waves ? (by_lds < 1 ? 1 : by_lds) : by_waves;
+        // persistent grid: exactly the co-resident workgroups, a multiple of 8
         const int64_t iters = (int64_t)P.tiles_m * P.tiles_n * (P.K / BK);
         const int g = (fmc_cu_count() * per_cu) & ~7;
         const int64_t need = (int64_t)g * BM * BN * (int64_t)sizeof(float) + 4096;
