@@ -182,6 +182,10 @@ int fmc_cfg_ddim_step(const void* eps_uc, const float* x, float* x_out, int64_t 
  *   Requires K % 64 == 0, N % 8 == 0 (N % 64 == 0 for epilogue 1), strides % 8 == 0.
  *   x2 != NULL: two-source A operand -- columns [0, k_split) of every row come from x, [k_split, K) from x2 (rows
  *   `ldx2` apart, k_split % 64 == 0): the 1x1 shortcut conv of an up-block ResNet reads (hidden, skip) without a concat.
+ *   residual2 != NULL (needs residual; same row stride; epilogue 0): a second tensor added like residual.  The Camera
+ *   Adapter's `qkv_merge(h + pose) * s + h` is linear in pose, and pose is constant over the denoising steps of a clip:
+ *   with residual2 = s * (pose @ w^T + bias) computed once per clip the per-step call is alpha = s, no bias,
+ *   residual = h, and the `h + pose` pass of attention_processor.py:257 disappears.
  *   tile: workgroup tile geometry, 0 = pick by shape, 1 = 128x128 (4 waves), 2 = 256x128 (8), 3 = 256x256 (16) with
  *   64-deep k-tiles in a 2-stage LDS ring; 4..6 = the same three with 32-deep k-tiles (half the LDS, twice the
  *   workgroups per CU); 7 = 256x128, 64-deep, 3 stages; 8 / 9 / 10 = 256x256 / 128x128 / 256x128, 32-deep, 4 stages
@@ -200,7 +204,8 @@ int fmc_cfg_ddim_step(const void* eps_uc, const float* x, float* x_out, int64_t 
  * ------------------------------------------------------------------------------------------- */
 int fmc_linear_bf16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int N,
                     int K, int64_t ldx, int64_t ldres, int64_t ldo, float alpha, int epilogue, int tile, int split_k,
-                    void* workspace, int64_t workspace_bytes, const void* x2, int64_t ldx2, int k_split, void* stream);
+                    void* workspace, int64_t workspace_bytes, const void* x2, int64_t ldx2, int k_split,
+                    const void* residual2, void* stream);
 
 /* Implicit-GEMM 3x3 convolution (stride 1, pad 1) on channels-last bf16 images with the ResNet-block epilogue:
  *   out[i,y,x,:] = conv(x)[i,y,x,:] + bias + temb[i,:] + residual[i,y,x,:]

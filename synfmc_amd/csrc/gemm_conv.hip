@@ -41,6 +41,7 @@ constexpr int BK_MAX = 64;   // K must be a multiple of this (every FMC projecti
 
 struct GemmParams {
     const bf16_t* a; const bf16_t* w; const bf16_t* bias; const bf16_t* temb; const bf16_t* res; bf16_t* out;
+    const bf16_t* res2;               // optional second residual (rows ldres apart, like res)
     int64_t M; int N, K;
     int64_t lda, ldres, ldo;
     int img_h, img_w, cin, hw;        // conv mode
@@ -390,7 +391,7 @@ void gemm_kernel(const GemmParams P) {
         // 8 of them were ~12 us of a 26 us workgroup on the K = 320 projections)
         constexpr int E_CPR = BN / 8, E_RSTEP = NT / E_CPR, E_IT = 64 / E_RSTEP;
         static_assert(64 % E_RSTEP == 0, "slab rows must divide over the threads");
-        u32x4 resv[E_IT];
+        u32x4 resv[E_IT], resv2[E_IT];
         if (EPI == 0 && P.res && !(SK && sk_partial) && P.split_k == 1) {
             const int ch = tid % E_CPR;
             const int nn = min(n0 + ch * 8, P.N - 8);
@@ -398,6 +399,7 @@ void gemm_kernel(const GemmParams P) {
             for (int it = 0; it < E_IT; ++it) {
                 const int64_t m = min(m0 + hm * 64 + tid / E_CPR + it * E_RSTEP, P.M - 1);
                 resv[it] = *reinterpret_cast<const u32x4*>(P.res + m * P.ldres + nn);
+                if (P.res2) resv2[it] = *reinterpret_cast<const u32x4*>(P.res2 + m * P.ldres + nn);
             }
         }
         __syncthreads();
@@ -482,6 +484,13 @@ void gemm_kernel(const GemmParams P) {
                         for (int k = 0; k < 4; ++k) {
                             v[2 * k] += __uint_as_float(resv[it][k] << 16);
                             v[2 * k + 1] += __uint_as_float(resv[it][k] & 0xffff0000u);
+                        }
+                        if (P.res2) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                v[2 * k] += __uint_as_float(resv2[it][k] << 16);
+                                v[2 * k + 1] += __uint_as_float(resv2[it][k] & 0xffff0000u);
+                            }
                         }
                     }
                     Vec8<bf16_t>::store(P.out + m * P.ldo + n, v);
@@ -588,6 +597,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams P) 
         Vec8<bf16_t>::load(P.res + m * P.ldres + n, t);
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] += t[k];
+        if (P.res2) {
+            Vec8<bf16_t>::load(P.res2 + m * P.ldres + n, t);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += t[k];
+        }
     }
     Vec8<bf16_t>::store(P.out + m * P.ldo + n, v);
 }
@@ -719,7 +733,7 @@ int set_split_k(GemmParams& P, int split_k, void* workspace, int64_t workspace_b
 extern "C" int fmc_linear_bf16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,
                                int N, int K, int64_t ldx, int64_t ldres, int64_t ldo, float alpha, int epilogue, int tile,
                                int split_k, void* workspace, int64_t workspace_bytes, const void* x2, int64_t ldx2,
-                               int k_split, void* stream) {
+                               int k_split, const void* residual2, void* stream) {
     if (!x || !w || !out) FMC_FAIL(FMC_E_NULL, "linear_bf16: NULL tensor");
     if (M <= 0 || N <= 0 || K <= 0 || K % BK_MAX || N % 8 || ldx % 8 || ldo % 8 || (residual && ldres % 8))
         FMC_FAIL(FMC_E_SHAPE, "linear_bf16: need K%%64==0, N%%8==0 and strides %%8==0 (M=%lld N=%d K=%d)", (long long)M, N, K);
@@ -730,7 +744,9 @@ extern "C" int fmc_linear_bf16(const void* x, const void* w, const void* bias, c
         FMC_FAIL(FMC_E_ALIGN, "linear_bf16: tensors must be 16-byte aligned");
     GemmParams P{};
     P.a = (const bf16_t*)x; P.w = (const bf16_t*)w; P.bias = (const bf16_t*)bias; P.temb = nullptr;
-    P.res = (const bf16_t*)residual; P.out = (bf16_t*)out;
+    if (residual2 && (!residual || !fmc_aligned16(residual2)))
+        FMC_FAIL(FMC_E_NULL, "linear_bf16: residual2 needs residual (same row stride) and 16-byte alignment");
+    P.res = (const bf16_t*)residual; P.res2 = (const bf16_t*)residual2; P.out = (bf16_t*)out;
     P.M = M; P.N = N; P.K = K; P.lda = ldx; P.ldres = ldres; P.ldo = ldo;
     P.img_h = P.img_w = P.cin = 0; P.hw = 1; P.alpha = alpha; P.temb_ld = 0; P.temb_div = 1; P.ups = 0;
     if (x2 && (k_split <= 0 || k_split >= K || k_split % BK_MAX || ldx2 % 8 || !fmc_aligned16(x2)))
@@ -756,7 +772,7 @@ extern "C" int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, 
         FMC_FAIL(FMC_E_ALIGN, "conv3x3_bf16: tensors must be 16-byte aligned");
     GemmParams P{};
     P.a = (const bf16_t*)x; P.w = (const bf16_t*)w; P.bias = (const bf16_t*)bias; P.temb = (const bf16_t*)temb;
-    P.res = (const bf16_t*)residual; P.out = (bf16_t*)out;
+    P.res = (const bf16_t*)residual; P.res2 = nullptr; P.out = (bf16_t*)out;
     P.M = (int64_t)n_img * H * W; P.N = Cout; P.K = 9 * Cin; P.lda = Cin; P.ldres = Cout; P.ldo = Cout;
     P.a2 = nullptr; P.lda2 = 0; P.ksplit = 0;
     P.img_h = H; P.img_w = W; P.cin = Cin; P.hw = H * W; P.alpha = 1.f;

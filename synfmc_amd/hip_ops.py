@@ -630,8 +630,9 @@ def _rows2d(t: torch.Tensor):
 
 def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
                 residual: Optional[torch.Tensor] = None, alpha: float = 1.0, geglu: bool = False,
-                tile: int = 0, split_k: int = 1, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """`alpha * (x @ weight^T + bias) + residual` (or the GEGLU gate, see fmc_linear_bf16) on the bf16 MFMA kernel.
+                tile: int = 0, split_k: int = 1, x2: Optional[torch.Tensor] = None,
+                residual2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`alpha * (x @ weight^T + bias) + residual [+ residual2]` (or the GEGLU gate, see fmc_linear_bf16) on the bf16 MFMA kernel.
     x `[..., K]`, weight `[N, K]`; residual has the output's shape.  `tile` may also be an autotune arm id
     (`tile + 16 * log2(split_k)`).  `x2 [..., K2]`: the A operand is the concat `[x, x2]` (weight `[N, K + K2]`),
     never materialised."""
@@ -650,10 +651,12 @@ def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     if residual is not None:
         assert residual.shape == out.shape
         _, ldres = _rows2d(residual)
+    if residual2 is not None:
+        assert residual is not None and residual2.shape == out.shape and _rows2d(residual2)[1] == ldres
     ws, ws_bytes = _splitk_workspace(x.device, split_k, M, N)
     _lib.check(_lib.load().fmc_linear_bf16(x.data_ptr(), weight.data_ptr(), _p(bias), _p(residual), out.data_ptr(), M, N,
                                            Kd, ldx, ldres, n_out, float(alpha), int(geglu), int(tile), int(split_k),
-                                           ws, ws_bytes, _p(x2), ldx2, k_split, _stream()),
+                                           ws, ws_bytes, _p(x2), ldx2, k_split, _p(residual2), _stream()),
                "fmc_linear_bf16")
     return out
 
@@ -762,16 +765,18 @@ def _pick(key, hip_fn, lib_fn, static_hip: bool, extra_arms=()) -> int:
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
-           residual: Optional[torch.Tensor] = None, alpha: float = 1.0, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """`alpha * (x @ weight^T + bias) + residual` for bf16 device tensors (see `linear_bf16`).  With `x2` the input is
-    the concat `[x, x2]` along the last dim; the fused kernel reads the two tensors in place."""
+           residual: Optional[torch.Tensor] = None, alpha: float = 1.0, x2: Optional[torch.Tensor] = None,
+           residual2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`alpha * (x @ weight^T + bias) + residual [+ residual2]` for bf16 device tensors (see `linear_bf16`).  With `x2`
+    the input is the concat `[x, x2]` along the last dim; the fused kernel reads the two tensors in place."""
     import torch.nn.functional as F
 
     def lib():
         xin = x if x2 is None else torch.cat([x, x2], dim=-1)
         y = F.linear(xin, weight, bias)
         if residual is not None:
-            return torch.add(residual, y, alpha=alpha)
+            y = torch.add(residual, y, alpha=alpha)
+            return y if residual2 is None else y + residual2
         return y if alpha == 1.0 else y * alpha
 
     N, Kd = weight.shape
@@ -783,8 +788,9 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     if not ok or (x.ndim > 2 and not x.is_contiguous()):
         return lib()
     M = x.numel() // x.shape[-1]
-    key = ("lin", M, N, Kd, bias is not None, residual is not None, 0 if x2 is None else x.shape[-1])
-    hip = lambda tile: linear_bf16(x, weight, bias, residual, alpha, tile=tile, x2=x2)
+    key = ("lin", M, N, Kd, bias is not None, (residual is not None) + (residual2 is not None),
+           0 if x2 is None else x.shape[-1])
+    hip = lambda tile: linear_bf16(x, weight, bias, residual, alpha, tile=tile, x2=x2, residual2=residual2)
     use = _pick(key, hip, lib, Kd <= 640 and N <= 1024 and M >= 16384, split_arms(M, N, Kd))
     return lib() if use == 0 else hip(max(use, 0))
 

@@ -14,6 +14,7 @@ Spatial vs temporal is decided by the shape of `hidden_states`:
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -22,6 +23,9 @@ from torch import nn
 
 from .. import hip_ops as K
 from .layers import LoRALinearLayer, linear_op
+
+
+_POSE_TERM = os.environ.get("FMC_NO_POSE_TERM", "0") != "1"      # A/B switch for the pre-computed Camera-Adapter term
 
 
 def _tok(x: torch.Tensor) -> torch.Tensor:
@@ -127,11 +131,35 @@ class _PoseMerge:
     def _merge(self, hidden_states, encoder_hidden_states, pose_feature, s):
         """`merge(h + pose) * s + h` (attention_processor.py:256-265)."""
         if self.query_condition and self.key_value_condition:
-            m = linear_op(hidden_states + pose_feature, self.qkv_merge.weight, self.qkv_merge.bias, hidden_states, s)
+            w, b = self.qkv_merge.weight, self.qkv_merge.bias
+            if (_POSE_TERM and not torch.is_grad_enabled() and hidden_states.is_cuda and hidden_states.dtype == torch.bfloat16
+                    and w.dtype == torch.bfloat16 and pose_feature.shape == hidden_states.shape
+                    and pose_feature.dtype == torch.bfloat16 and hidden_states.is_contiguous()):
+                # merge is linear in pose and pose is constant over the denoising steps of a clip: its term
+                # s * (W pose + b) is computed once and rides in the GEMM epilogue as a second residual, so the per-step
+                # `h + pose` pass (one read of h and pose, one write, per motion module) is gone
+                return K.linear(hidden_states, w, None, hidden_states, s, residual2=self._pose_term(pose_feature, w, b, s)), None
+            m = linear_op(hidden_states + pose_feature, w, b, hidden_states, s)
             return m, None
         if self.query_condition:
             return torch.add(hidden_states, self.q_merge(hidden_states + pose_feature), alpha=s), encoder_hidden_states
         return hidden_states, torch.add(encoder_hidden_states, self.kv_merge(encoder_hidden_states + pose_feature), alpha=s)
+
+
+def _pose_term_impl(self, pose_feature, w, b, s):
+    """`s * (pose @ W^T + b)`, cached per processor.  The entry keeps `pose_feature` alive, so an equal data pointer
+    means the same storage, and in-place writes to it bump the version counter it is keyed on."""
+    key = (pose_feature.data_ptr(), pose_feature._version, tuple(pose_feature.shape), w.data_ptr(), w._version,
+           None if b is None else b._version, float(s))
+    hit = self.__dict__.get("_pose_term_cache")
+    if hit is None or hit[0] != key:
+        pf = pose_feature if pose_feature.is_contiguous() else pose_feature.contiguous()
+        hit = (key, K.linear(pf, w, b, None, s), pose_feature)
+        self.__dict__["_pose_term_cache"] = hit
+    return hit[1]
+
+
+_PoseMerge._pose_term = _pose_term_impl
 
 
 def _pose_tokens(pose_feature, like):

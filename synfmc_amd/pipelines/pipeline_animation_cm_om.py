@@ -55,6 +55,9 @@ class _GraphedUNet:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = self._call()
+        # per-clip constants the processors computed during the warm-up (Camera-Adapter pose terms): the graph reads
+        # them, so they must live as long as it does even if another clip replaces the processors' cache entries
+        self._keep = [m.__dict__.get("_pose_term_cache") for m in self.unet.modules()]
 
     def __call__(self, x, t):
         self.x.copy_(x)

@@ -344,6 +344,28 @@ def test_gemm_tile_geometries_agree(K, tile):
     assert rel_inf(outg.float(), a * F.gelu(g)) < 1e-2
 
 
+@pytest.mark.parametrize("tile", [0, 1, 3, 4, 11, 1 + 16, 128 + 2])
+def test_linear_second_residual(K, tile):
+    """`alpha * (x W^T + b) + residual + residual2` (plain, split-K and stream-K arms) -- the Camera-Adapter merge with the
+    per-clip pose term pre-computed: s*(W(h+pose)+b)+h == s*(W h) + h + s*(W pose + b)."""
+    dtype = torch.bfloat16
+    M, C, s_ = 2100, 1280, 0.7
+    ho, hd = rnd((M, C), 70, dtype)
+    po, pd = rnd((M, C), 71, dtype)
+    wo, wd = rnd((C, C), 72, dtype, scale=C ** -0.5)
+    bo, bd = rnd((C,), 73, dtype)
+    ref = F.linear(ho + po, wo, bo) * s_ + ho                                   # attention_processor.py:257
+    term = K.linear_bf16(pd, wd, bd, None, s_)
+    out = K.linear_bf16(hd, wd, None, hd, s_, tile=tile, residual2=term)
+    assert rel_inf(out.float(), ref) < 1e-2
+    r2o, r2d = rnd((M, C), 74, dtype)
+    want = F.linear(ho, wo, bo) * s_ + po + r2o
+    got = K.linear_bf16(hd, wd, bd, pd, s_, tile=tile, residual2=r2d)
+    assert rel_inf(got.float(), want) < 1e-2
+    with pytest.raises((ValueError, AssertionError)):
+        K.linear_bf16(hd, wd, bd, None, s_, residual2=r2d)                      # a second residual needs the first
+
+
 @pytest.mark.parametrize("split_k", [2, 4, 8])
 @pytest.mark.parametrize("tile", [1, 2, 9])
 def test_gemm_split_k(K, tile, split_k):

@@ -76,6 +76,37 @@ def test_unet_forward_cmc_omc(stack, dtype, tol):
     assert rel_inf(stack["ref"], stack["ref_notraj"]) > 0.1
 
 
+def test_pose_term_cache_follows_the_pose_features(stack):
+    """bf16 inference pre-computes the Camera-Adapter term `s * (W pose + b)` once per pose tensor: new pose features
+    (fresh tensors that may reuse the freed addresses, and an in-place update) must be picked up."""
+    pu, pe, pa = CM.build_product(stack["ou"], stack["oe"], stack["oa"], W4, dtype=torch.bfloat16)
+    clip = stack["clip"]
+    dev = lambda x: x.to("cuda", torch.bfloat16)
+    ou = stack["ou"]
+    x, text, t = clip["latents"], clip["text"], stack["t"]
+
+    def both(pose_cpu, pose_dev=None):
+        with torch.no_grad():
+            ref = ou(x, t, text, pose_embedding_features=pose_cpu, traj_features=None).sample
+            pose_dev = [dev(p) for p in pose_cpu] if pose_dev is None else pose_dev
+            out = pu(dev(x), t.cuda(), dev(text), pose_embedding_features=pose_dev, traj_features=None).sample
+        return ref, out, pose_dev
+
+    ref_a, out_a, pose_dev = both(stack["pose_feats"])
+    assert rel_inf(out_a.float(), ref_a) < 6e-2
+    assert any("_pose_term_cache" in m.__dict__ for m in pu.modules())         # the fast path is the one running
+    del pose_dev
+    pose_b = [p.flip(2) * 1.5 for p in stack["pose_feats"]]                       # same shapes, other values
+    ref_b, out_b, pose_dev = both(pose_b)
+    assert rel_inf(ref_b, ref_a) > 0.05
+    assert rel_inf(out_b.float(), ref_b) < 6e-2
+    for p in pose_dev:                                                            # in place: same storage, new version
+        p.mul_(-1.0)
+    ref_c, out_c, _ = both([-p for p in pose_b], pose_dev)
+    assert rel_inf(ref_c, ref_b) > 0.05
+    assert rel_inf(out_c.float(), ref_c) < 6e-2
+
+
 def test_unet_forward_unconditioned_base(stack):
     """BASELINE config 1 topology: base U-Net, plain processors, no adapters."""
     from synfmc_amd.models.unet import UNet3DConditionModel
