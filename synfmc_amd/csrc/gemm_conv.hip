@@ -51,6 +51,7 @@ struct GemmParams {
                                       //            2 = stride-2 convolution, x is [n, 2H, 2W, Cin]  (H, W = output size)
     float alpha;
     int tiles_m, tiles_n;
+    int regepi;                       // A/B switch (FMC_GEMM_REGEPI=0): in-register epilogues off, everything through the fp32 slab
     int tap_outer;                    // conv mode A/B switch (FMC_CONV_TAP_OUTER=1): the old (tap, channel) k order
     int group_m;                      // tile order: m runs fastest inside groups of group_m m-tiles (see lin_to_tile)
     int split_k;                      // > 1: k-tiles are dealt to split_k workgroups per output tile, which write fp32
@@ -379,6 +380,103 @@ void gemm_kernel(const GemmParams P) {
         }
     }
 
+    // ---- GEGLU epilogue of the plain grid: in registers.  The weight rows are interleaved per 64 so that acc[0] holds the
+    // value and acc[1] the gate of the SAME 32 output columns, register for register: every wave gates its own 64 x 32
+    // outputs at once, stages them as bf16 (one LDS round for the whole tile instead of one fp32 slab round per wave
+    // row, a quarter of the LDS bytes) and the tile leaves with whole-row 16-byte stores.
+    if (EPI == 1 && !SK && P.regepi) {
+        constexpr int OP = BN / 2 + 8;                   // bf16 pitch of the staged output tile (16-byte aligned rows)
+        bf16_t* Os = smem;                               // [BM][OP]
+        float ba[16], bg[16];
+        const bool cols_ok = n0 + wn * 64 < P.N;        // N % 64 == 0: a 64-column group is inside or outside as a whole
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int nb = n0 + wn * 64 + 8 * g + 4 * half + j;
+                ba[4 * g + j] = (P.bias && cols_ok) ? bf2f(P.bias[nb]) : 0.f;
+                bg[4 * g + j] = (P.bias && cols_ok) ? bf2f(P.bias[nb + 32]) : 0.f;
+            }
+        __syncthreads();                                 // every wave is done with the operand ring
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    o[j] = (acc[0][mi][4 * g + j] + ba[4 * g + j]) * gelu_erf(acc[1][mi][4 * g + j] + bg[4 * g + j]);
+                const int row = wm * (32 * MI) + mi * 32 + l31, col = wn * 32 + 8 * g + 4 * half;
+                *reinterpret_cast<u32x2*>(Os + row * OP + col) = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+            }
+        __syncthreads();
+        constexpr int OCPR = BN / 16;                    // 16-byte chunks per output row
+#pragma unroll 4
+        for (int c = tid; c < BM * OCPR; c += NT) {
+            const int r = c / OCPR, ch = c - r * OCPR;
+            const int64_t m = m0 + r;
+            const int no = n0 / 2 + ch * 8;
+            if (m < P.M && no < P.N / 2)
+                *reinterpret_cast<u32x4*>(P.out + m * P.ldo + no) = *reinterpret_cast<const u32x4*>(Os + r * OP + ch * 8);
+        }
+        break;
+    }
+
+    // ---- the same for the plain epilogue when there is no residual to add (QKV / proj_in projections, the first conv of a
+    // ResNet block with its time-embedding row): bias, alpha and temb are applied in the accumulator registers, the
+    // tile is staged once as bf16.  With a residual the fp32 slab path below stays.  Measured alternatives: the residual
+    // read in accumulator layout (8 bytes per lane and row) was 20 % slower than the slab path's whole-row 16-byte
+    // loads; adding it at the read-out of the bf16 tile (two roundings, like the un-fused ops) was no faster.
+    if (EPI == 0 && !SK && P.split_k == 1 && !P.res && P.regepi) {
+        constexpr int OP = BN + 8;
+        bf16_t* Os = smem;                               // [BM][OP]
+        __syncthreads();                                 // every wave is done with the operand ring
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            float bv[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int nb = n0 + wn * 64 + ni * 32 + 8 * g + 4 * half + j;
+                    bv[4 * g + j] = (P.bias && nb < P.N) ? bf2f(P.bias[nb]) : 0.f;
+                }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int row = wm * (32 * MI) + mi * 32 + l31;
+                const bf16_t* trow = nullptr;
+                if (MODE == 1 && P.temb) {
+                    const int64_t m = min(m0 + row, P.M - 1);
+                    trow = P.temb + ((m / P.hw) / P.temb_div) * P.temb_ld;
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = wn * 64 + ni * 32 + 8 * g + 4 * half;
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (acc[ni][mi][4 * g + j] + bv[4 * g + j]) * P.alpha;
+                    if (MODE == 1 && P.temb) {
+                        const u32x2 t = *reinterpret_cast<const u32x2*>(trow + min(n0 + col, P.N - 4));
+                        o[0] += __uint_as_float(t[0] << 16); o[1] += __uint_as_float(t[0] & 0xffff0000u);
+                        o[2] += __uint_as_float(t[1] << 16); o[3] += __uint_as_float(t[1] & 0xffff0000u);
+                    }
+                    *reinterpret_cast<u32x2*>(Os + row * OP + col) = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+                }
+            }
+        }
+        __syncthreads();
+        constexpr int OCPR = BN / 8;                     // 16-byte chunks per output row
+#pragma unroll 4
+        for (int c = tid; c < BM * OCPR; c += NT) {
+            const int r = c / OCPR, ch = c - r * OCPR;
+            const int64_t m = m0 + r;
+            const int n = n0 + ch * 8;
+            if (m < P.M && n < P.N)
+                *reinterpret_cast<u32x4*>(P.out + m * P.ldo + n) = *reinterpret_cast<const u32x4*>(Os + r * OP + ch * 8);
+        }
+        break;
+    }
+
     // ---- epilogue: fp32 C slabs of 64 rows through LDS, bias / alpha / temb / residual / GEGLU on the way out ----------
     float* Cs = reinterpret_cast<float*>(smem_raw);             // [64][CP] fp32
 #pragma unroll 1
@@ -608,11 +706,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams P) 
 
 template <int MODE, int EPI, int WM, int WN, int MI, int BK, int STAGES, bool SK>
 void launch_gemm_k(GemmParams& P, unsigned grid, size_t lds, hipStream_t st) {
-    static bool raised = false;
-    if (!raised) {
+    static size_t raised = 0;                            // (the LDS size of one instantiation depends on the epilogue variant)
+    if (lds > raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, EPI, WM, WN, MI, BK, STAGES, SK>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        raised = true;
+        raised = lds;
     }
     hipLaunchKernelGGL((gemm_kernel<MODE, EPI, WM, WN, MI, BK, STAGES, SK>), dim3(grid), dim3(64 * WM * WN), lds, st, P);
 }
@@ -626,14 +724,19 @@ void launch_gemm_g(GemmParams& P, hipStream_t st) {
     {
         static const int tap_outer = getenv("FMC_CONV_TAP_OUTER") ? atoi(getenv("FMC_CONV_TAP_OUTER")) : 0;
         P.tap_outer = tap_outer;
+        static const int regepi = getenv("FMC_GEMM_REGEPI") ? atoi(getenv("FMC_GEMM_REGEPI")) : 1;
+        P.regepi = regepi;
     }
     size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(bf16_t) + 1024;
     const size_t slab = (size_t)64 * (BN + 8) * sizeof(float);
     if (slab > lds) lds = slab;
+    // the plain grid stages the whole output tile as bf16 (in-register epilogues); stream-K and split-K keep the fp32 slab
+    const size_t staged = (size_t)BM * ((EPI == 1 ? BN / 2 : BN) + 8) * sizeof(bf16_t);
+    const size_t lds_plain = (P.split_k == 1 && (EPI == 1 || !P.res) && staged > lds) ? staged : lds;
     unsigned grid = (unsigned)(P.tiles_m * P.tiles_n * P.split_k);
     // co-resident workgroups per CU (LDS / wave-slot limited)
     constexpr int by_waves = 16 / (WM * WN) > 0 ? 16 / (WM * WN) : 1;
-    const int by_lds = (int)(160 * 1024 / lds);
+    const int by_lds = (int)(160 * 1024 / (P.sk ? lds : lds_plain));
     const int per_cu = by_lds < by_waves ? (by_lds < 1 ? 1 : by_lds) : by_waves;
     // Tile order (lin_to_tile).  Row-major is optimal while the weight matrix fits an XCD's L2 or the c workgroups an
     // XCD runs at once already span all n-tiles; otherwise make their footprint square in bytes: gm x c/gm tiles with
@@ -665,7 +768,7 @@ void launch_gemm_g(GemmParams& P, hipStream_t st) {
             return;
         }
     }
-    launch_gemm_k<MODE, EPI, WM, WN, MI, BK, STAGES, false>(P, grid, lds, st);
+    launch_gemm_k<MODE, EPI, WM, WN, MI, BK, STAGES, false>(P, grid, lds_plain, st);
     if (P.split_k > 1) {
         const int64_t chunks = P.M * (P.N / 8);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, P);
