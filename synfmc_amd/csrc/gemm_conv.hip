@@ -51,7 +51,7 @@ struct GemmParams {
                                       //            2 = stride-2 convolution, x is [n, 2H, 2W, Cin]  (H, W = output size)
     float alpha;
     int tiles_m, tiles_n;
-    int regepi;                       // A/B switch (FMC_GEMM_REGEPI=0): in-register epilogues off, everything through the fp32 slab
+    int regepi;                       // A/B switch FMC_GEMM_REGEPI: 0 = everything through the fp32 slab, 2 = residual calls only, 1 = none
     int tap_outer;                    // conv mode A/B switch (FMC_CONV_TAP_OUTER=1): the old (tap, channel) k order
     int group_m;                      // tile order: m runs fastest inside groups of group_m m-tiles (see lin_to_tile)
     int split_k;                      // > 1: k-tiles are dealt to split_k workgroups per output tile, which write fp32
@@ -424,13 +424,35 @@ void gemm_kernel(const GemmParams P) {
 
     // ---- the same for the plain epilogue when there is no residual to add (QKV / proj_in projections, the first conv of a
     // ResNet block with its time-embedding row): bias, alpha and temb are applied in the accumulator registers, the
-    // tile is staged once as bf16.  With a residual the fp32 slab path below stays.  Measured alternatives: the residual
-    // read in accumulator layout (8 bytes per lane and row) was 20 % slower than the slab path's whole-row 16-byte
-    // loads; adding it at the read-out of the bf16 tile (two roundings, like the un-fused ops) was no faster.
-    if (EPI == 0 && !SK && P.split_k == 1 && !P.res && P.regepi) {
+    // tile is staged once as bf16.  A residual goes through the same tile first (see below), so it is still added in fp32
+    // before the one rounding.  Measured alternatives: the residual read from global memory in accumulator layout (8
+    // bytes per lane and row) was 20 % slower than whole-row 16-byte loads; adding it at the read-out of the bf16
+    // tile (two roundings, like the un-fused ops) was no faster.  Two residuals keep the fp32 slab path below.
+    if (EPI == 0 && !SK && P.split_k == 1 && !P.res2 && P.regepi && (P.regepi == 1 || !P.res)) {
         constexpr int OP = BN + 8;
         bf16_t* Os = smem;                               // [BM][OP]
+        // residual: whole-row 16-byte loads into registers now, into the staging tile behind the barrier; every lane then
+        // picks its own (row, 4 columns) words out of LDS, adds them in fp32 and overwrites them with the result
+        constexpr int R_CPR = BN / 8, R_IT = BM * R_CPR / NT;
+        static_assert(BM * R_CPR % NT == 0, "tile chunks must divide over the threads");
+        const bool has_res = P.res != nullptr;
+        u32x4 rchunk[R_IT];
+        if (has_res) {
+#pragma unroll
+            for (int it = 0; it < R_IT; ++it) {
+                const int c = tid + it * NT, r = c / R_CPR, ch = c - r * R_CPR;
+                rchunk[it] = *reinterpret_cast<const u32x4*>(P.res + min(m0 + r, P.M - 1) * P.ldres + min(n0 + ch * 8, P.N - 8));
+            }
+        }
         __syncthreads();                                 // every wave is done with the operand ring
+        if (has_res) {
+#pragma unroll
+            for (int it = 0; it < R_IT; ++it) {
+                const int c = tid + it * NT, r = c / R_CPR, ch = c - r * R_CPR;
+                *reinterpret_cast<u32x4*>(Os + r * OP + ch * 8) = rchunk[it];
+            }
+            __syncthreads();
+        }
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             float bv[16];
@@ -457,6 +479,11 @@ void gemm_kernel(const GemmParams P) {
                     for (int j = 0; j < 4; ++j) o[j] = (acc[ni][mi][4 * g + j] + bv[4 * g + j]) * P.alpha;
                     if (MODE == 1 && P.temb) {
                         const u32x2 t = *reinterpret_cast<const u32x2*>(trow + min(n0 + col, P.N - 4));
+                        o[0] += __uint_as_float(t[0] << 16); o[1] += __uint_as_float(t[0] & 0xffff0000u);
+                        o[2] += __uint_as_float(t[1] << 16); o[3] += __uint_as_float(t[1] & 0xffff0000u);
+                    }
+                    if (has_res) {
+                        const u32x2 t = *reinterpret_cast<const u32x2*>(Os + row * OP + col);
                         o[0] += __uint_as_float(t[0] << 16); o[1] += __uint_as_float(t[0] & 0xffff0000u);
                         o[2] += __uint_as_float(t[1] << 16); o[3] += __uint_as_float(t[1] & 0xffff0000u);
                     }
@@ -732,7 +759,7 @@ void launch_gemm_g(GemmParams& P, hipStream_t st) {
     if (slab > lds) lds = slab;
     // the plain grid stages the whole output tile as bf16 (in-register epilogues); stream-K and split-K keep the fp32 slab
     const size_t staged = (size_t)BM * ((EPI == 1 ? BN / 2 : BN) + 8) * sizeof(bf16_t);
-    const size_t lds_plain = (P.split_k == 1 && (EPI == 1 || !P.res) && staged > lds) ? staged : lds;
+    const size_t lds_plain = (P.split_k == 1 && (EPI == 1 || !P.res2) && staged > lds) ? staged : lds;
     unsigned grid = (unsigned)(P.tiles_m * P.tiles_n * P.split_k);
     // co-resident workgroups per CU (LDS / wave-slot limited)
     constexpr int by_waves = 16 / (WM * WN) > 0 ? 16 / (WM * WN) : 1;
