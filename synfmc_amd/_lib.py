@@ -10,7 +10,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfmc_hip.so")
+LIB_PATH = os.environ.get("FMC_HIP_LIB") or os.path.join(_HERE, "lib", "libfmc_hip.so")   # env: another BUILD of the same library (A/B timing)
 
 FMC_BF16, FMC_F32 = 0, 1
 

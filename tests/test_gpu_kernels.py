@@ -44,7 +44,9 @@ def rnd(shape, seed, dtype, scale=1.0, shift=0.0):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("N,HW,C,act", [(2, 40, 320, True), (3, 160, 640, False), (2, 9, 1280, True),
-                                        (1, 640, 960, True), (2, 7, 2560, True), (2, 33, 64, False)])
+                                        (1, 640, 960, True), (2, 7, 2560, True), (2, 33, 64, False),
+                                        (2, 2560, 320, True), (1, 2560, 640, False), (2, 2499, 320, True),
+                                        (1, 2560, 960, True), (1, 4096, 320, True)])
 def test_groupnorm_silu(K, dtype, N, HW, C, act):
     xo, xd = rnd((N, HW, C), 1, dtype, scale=1.5, shift=0.7)
     g = torch.Generator().manual_seed(2)
