@@ -96,9 +96,20 @@ __device__ __forceinline__ float fold_max(const f32x16& s, float w) {
     return max3(max3(ma, mb, s[7]), s[15], w);
 }
 
+// VR (bf16): V stays ROW-major in LDS ([key][d], one ds_write_b128 per staged chunk instead of eight ds_write_b16 plus
+// the unpacking) and the V^T fragments of the PV products come out of ds_read_b64_tr_b16: inside a 16-lane group lane i
+// supplies the address of row i/4, columns 4(i%4)..+3 of a [4 keys][16 d] block and receives column i of it -- 4
+// consecutive keys of one d, exactly one half of a fragment.  The pitch makes the 8 x 32-byte pieces a 32-lane half
+// touches tile the 64 LDS banks exactly (pitch * 2 = 64 or 192 mod 256 bytes).
+template <int NDT> constexpr int sa_vr_pitch() { return NDT == 1 ? 32 : (NDT == 2 ? 96 : 160); }
+typedef short __attribute__((ext_vector_type(4))) sa_s4;
+__device__ __forceinline__ sa_s4 lds_tr16(const bf16_t* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) sa_s4*)(p));
+}
+
 // NQ 32-query blocks per wave share every K / V^T fragment read: per 32 keys 3 + 4 LDS fragment loads feed 7*NQ MFMAs
 // (at NQ = 1 the LDS port is ~80 % busy at d = 40: 12 waves per CU x 44 LDS cycles per 224 MFMA cycles)
-template <typename T, int NKS, int NQ, bool TAIL>
+template <typename T, int NKS, int NQ, bool TAIL, bool MK = false, bool VR = false>
 __device__ __forceinline__ void attn_block(const T* __restrict__ Ks, const T* __restrict__ Vt, const Frag<T> (&qf)[NQ][NKS],
                                            f32x16 (&oacc)[NQ][(NKS + 1) / 2], const f32x16 (&negm)[NQ], float (&worst)[NQ],
                                            float (&l_run)[NQ], int sb, int kvb, int Skv, int l31, int half) {
@@ -108,7 +119,14 @@ __device__ __forceinline__ void attn_block(const T* __restrict__ Ks, const T* __
     constexpr bool LROW = (NKS & 1) != 0;
     f32x16 s[NQ];
 #pragma unroll
-    for (int nq = 0; nq < NQ; ++nq) s[nq] = negm[nq];
+    for (int nq = 0; nq < NQ; ++nq) {
+        if (MK) {                                    // the reference rides in the reduction (see the kernel): C = 0, no
+#pragma unroll                                       // 16-register splat of -m_ref per block
+            for (int r = 0; r < 16; ++r) s[nq][r] = 0.f;
+        } else {
+            s[nq] = negm[nq];
+        }
+    }
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         Frag<T> kf;
@@ -146,9 +164,19 @@ __device__ __forceinline__ void attn_block(const T* __restrict__ Ks, const T* __
     for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
-            const T* vrow = Vt + (dt * 32 + l31) * VP + sb * 32 + s2 * 16 + half * 4;
             Frag<T> vf;
-            make_frag_2x4<T>(vrow, vrow + 8, vf);
+            if constexpr (VR && sizeof(T) == 2) {
+                constexpr int VPR = sa_vr_pitch<NDT>();
+                const bf16_t* vp = reinterpret_cast<const bf16_t*>(Vt) +
+                                   (sb * 32 + s2 * 16 + half * 4 + ((l31 & 15) >> 2)) * VPR + dt * 32 + (l31 >> 4) * 16 + (l31 & 3) * 4;
+                union { bf16x8 v; sa_s4 h[2]; } r;
+                r.h[0] = lds_tr16(vp);                   // keys +0..3 of this lane's d
+                r.h[1] = lds_tr16(vp + 8 * VPR);         // keys +8..11 (the P^T fragment's key permutation)
+                vf.hi = r.v;
+            } else {
+                const T* vrow = Vt + (dt * 32 + l31) * VP + sb * 32 + s2 * 16 + half * 4;
+                make_frag_2x4<T>(vrow, vrow + 8, vf);
+            }
 #pragma unroll
             for (int nq = 0; nq < NQ; ++nq) mma32(vf, pf[nq][s2], oacc[nq][dt]);
         }
@@ -162,7 +190,7 @@ template <> __device__ __forceinline__ bf16_t to_elem<bf16_t>(float v) { return 
 template <> __device__ __forceinline__ float to_elem<float>(float v) { return v; }
 
 // PREFETCH keeps the next K/V tile in registers under the current tile's MFMAs (costs ~40 VGPRs).
-template <typename T, int NKS, bool SHORT_KV, bool PREFETCH, int NQ>
+template <typename T, int NKS, bool SHORT_KV, bool PREFETCH, int NQ, bool MK, bool VR>
 __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 && NQ == 1 ? 3 : 2) : 1) void spatial_attn_kernel(const SAParams P) {
     constexpr int NDT = (NKS + 1) / 2;
     constexpr int DP16 = NKS * 16;
@@ -170,7 +198,9 @@ __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 && NQ =
     constexpr int VP = SA_BK + 4;       // V^T tile pitch (elements)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* Ks = reinterpret_cast<T*>(smem_raw);              // [SA_BK][KP]
-    T* Vt = Ks + SA_BK * KP;                             // [NDT*32][VP]
+    T* Vt = Ks + SA_BK * KP;                             // [NDT*32][VP]  (VR: V row-major, [SA_BK][VPR])
+    constexpr int VPR = sa_vr_pitch<NDT>();
+    static_assert(!VR || (PREFETCH && sizeof(T) == 2), "VR: bf16 prefetch variants only");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -225,13 +255,13 @@ __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 && NQ =
     if (DP16 > D) {
         for (int r = tid; r < SA_BK; r += blockDim.x) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) Ks[r * KP + D + i] = T(0);
+            for (int i = 0; i < 8; ++i) Ks[r * KP + D + i] = (MK && i == 0) ? to_elem<T>(1.f) : T(0);
         }
     }
 
     constexpr bool LROW = (NKS & 1) != 0;
     if (LROW) {   // ones in the last (spare) V^T row: O^T row NDT*32-1 accumulates l = sum(p)
-        for (int c = tid; c < SA_BK; c += 64 * SA_WAVES) Vt[(NDT * 32 - 1) * VP + c] = to_elem<T>(1.f);
+        for (int c = tid; c < SA_BK; c += 64 * SA_WAVES) Vt[VR ? c * VPR + NDT * 32 - 1 : (NDT * 32 - 1) * VP + c] = to_elem<T>(1.f);
     }
 
     // K/V staging is split (T14-style): the 16-byte global loads of tile t+1 are issued right after tile t has been
@@ -262,7 +292,9 @@ __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 && NQ =
             if (c < SA_BK * CH) {
                 const int row = c / CH, ch = c - row * CH;
                 *reinterpret_cast<raw_t*>(Ks + row * KP + ch * 8) = kreg[j];
-                if constexpr (sizeof(T) == 2) {
+                if constexpr (VR) {
+                    *reinterpret_cast<raw_t*>(Vt + row * VPR + ch * 8) = vreg[j];
+                } else if constexpr (sizeof(T) == 2) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         Vt[(ch * 8 + 2 * i) * VP + row] = (T)(vreg[j][i] & 0xffffu);
@@ -301,6 +333,23 @@ __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 && NQ =
     if (PREFETCH && ntiles > 1) gload(SA_BK);
     float m_ref[NQ];
     f32x16 negm[NQ];
+    // MK (bf16, D % 16 == 8): the reference is subtracted by the QK^T MFMAs themselves -- K's first pad column holds 1, the
+    // matching (otherwise zero) element of the Q^T fragment holds -m_ref -- so the score accumulator starts from the
+    // inline constant 0 instead of a 16-register splat of -m_ref that the compiler re-materialised for every block
+    // (60 v_mov per 64-key tile).  The reference is rounded to bf16 for that; it only has to be the SAME for all keys
+    // of a row (softmax is shift invariant), and the rounded value is what the LSE and the redo test use.
+    auto set_ref = [&](int nq) {
+        if (MK) {
+            const bf16_t mb = f2bf(-m_ref[nq]);
+            m_ref[nq] = -bf2f(mb);
+            union { bf16x8 v; bf16_t e[8]; } u;
+            u.v = qf[nq][NKS - 1].hi;
+            if (half == 1) u.e[0] = mb;                  // d = D of k-step NKS-1 (D % 16 == 8: upper half, element 0)
+            qf[nq][NKS - 1].hi = u.v;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[nq][r] = -m_ref[nq];
+    };
     {
         f32x16 zero16;
 #pragma unroll
@@ -310,8 +359,7 @@ __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 && NQ =
             float mx = fold_max(qk_block<T, NKS, true>(Ks, qf[nq], zero16, 0, 0, P.Skv, l31, half), -INFINITY);
             if (P.Skv > 32) mx = fold_max(qk_block<T, NKS, true>(Ks, qf[nq], zero16, 1, 32, P.Skv, l31, half), mx);
             m_ref[nq] = fmaxf(mx, __shfl_xor(mx, 32, 64));   // finite: key 0 always exists
-#pragma unroll
-            for (int r = 0; r < 16; ++r) negm[nq][r] = -m_ref[nq];
+            set_ref(nq);
         }
     }
 
@@ -344,14 +392,14 @@ __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 && NQ =
             stage(tile);
 #pragma unroll
             for (int sb = 0; sb < SA_BK / 32; ++sb)
-                attn_block<T, NKS, NQ, false>(Ks, Vt, qf, oacc, negm, worst, l_run, sb, tile * SA_BK + sb * 32, P.Skv, l31, half);
+                attn_block<T, NKS, NQ, false, MK, VR>(Ks, Vt, qf, oacc, negm, worst, l_run, sb, tile * SA_BK + sb * 32, P.Skv, l31, half);
         }
         if (nfull < ntiles) {
             stage(nfull);
 #pragma unroll
             for (int sb = 0; sb < SA_BK / 32; ++sb)
                 if (nfull * SA_BK + sb * 32 < P.Skv)           // block-uniform
-                    attn_block<T, NKS, NQ, true>(Ks, Vt, qf, oacc, negm, worst, l_run, sb, nfull * SA_BK + sb * 32, P.Skv, l31, half);
+                    attn_block<T, NKS, NQ, true, MK, VR>(Ks, Vt, qf, oacc, negm, worst, l_run, sb, nfull * SA_BK + sb * 32, P.Skv, l31, half);
         }
         // did any row of this workgroup leave the safe range of the fixed reference?  (block-uniform decision)
         bool bad = false;
@@ -361,8 +409,7 @@ __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 && NQ =
 #pragma unroll
         for (int nq = 0; nq < NQ; ++nq) {
             m_ref[nq] += fmaxf(worst[nq], __shfl_xor(worst[nq], 32, 64));     // now the exact row maximum
-#pragma unroll
-            for (int r = 0; r < 16; ++r) negm[nq][r] = -m_ref[nq];
+            set_ref(nq);
         }
     }
 
@@ -391,22 +438,22 @@ __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 && NQ =
     }
 }
 
-template <typename T, int NKS, bool SHORT_KV, bool PF, int NQ = 1>
+template <typename T, int NKS, bool SHORT_KV, bool PF, int NQ = 1, bool MK = false, bool VR = false>
 void launch_sa_v(const SAParams& Pin, hipStream_t st) {
     SAParams P = Pin;
     P.nqblk = (P.Sq + SA_BQ * NQ - 1) / (SA_BQ * NQ);
     constexpr int NDT = (NKS + 1) / 2;
-    const size_t lds = sizeof(T) * ((size_t)SA_BK * (NKS * 16 + 8) + (size_t)NDT * 32 * (SA_BK + 4));
+    const size_t lds = sizeof(T) * ((size_t)SA_BK * (NKS * 16 + 8) + (VR ? (size_t)SA_BK * sa_vr_pitch<NDT>() : (size_t)NDT * 32 * (SA_BK + 4)));
     dim3 grid((unsigned)(P.B * P.H * P.nqblk)), block(64 * SA_WAVES);
     if (lds > 64 * 1024) {  // gfx950 has 160 KiB of LDS per CU; opting in is needed above 64 KiB
         static bool raised = false;
         if (!raised) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_attn_kernel<T, NKS, SHORT_KV, PF, NQ>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_attn_kernel<T, NKS, SHORT_KV, PF, NQ, MK, VR>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             raised = true;
         }
     }
-    hipLaunchKernelGGL((spatial_attn_kernel<T, NKS, SHORT_KV, PF, NQ>), grid, block, lds, st, P);
+    hipLaunchKernelGGL((spatial_attn_kernel<T, NKS, SHORT_KV, PF, NQ, MK, VR>), grid, block, lds, st, P);
 }
 
 // FMC_SA_PREFETCH=0/1 overrides the default policy (experiments only)
@@ -426,13 +473,35 @@ inline int sa_nq_env() {              // FMC_SA_NQ = 1 | 2 query blocks per wave
     return v;
 }
 
+inline int sa_vr_env() {              // FMC_SA_VR=0: V transposed while staging instead of by the transpose read (A/B)
+    static const int v = [] {
+        const char* e = getenv("FMC_SA_VR");
+        return e ? atoi(e) : 1;
+    }();
+    return v;
+}
+
+inline int sa_mk_env() {              // FMC_SA_MK=0: softmax reference through the accumulator instead of the QK^T reduction
+    static const int v = [] {               // (the reduction form frees 33 VGPRs: -2 % on top of the transpose-read V path)
+        const char* e = getenv("FMC_SA_MK");
+        return e ? atoi(e) : 1;
+    }();
+    return v;
+}
+
 template <typename T, int NKS>
 void launch_sa(const SAParams& P, hipStream_t st) {
     if (P.Skv <= 2 * SA_BK) {
         if constexpr (sizeof(T) == 2 && NKS <= 6) {
             if (sa_prefetch_env() != 0 && P.Skv > SA_BK) {
                 if constexpr (NKS <= 3) {
-                    if (sa_nq_env() == 2 && P.Sq >= 2 * SA_BQ) return launch_sa_v<T, NKS, true, true, 2>(P, st);
+                    if (sa_nq_env() == 2 && P.Sq >= 2 * SA_BQ) {
+                        if (sa_vr_env()) {
+                            if (P.D % 16 == 8 && sa_mk_env()) return launch_sa_v<T, NKS, true, true, 2, true, true>(P, st);
+                            return launch_sa_v<T, NKS, true, true, 2, false, true>(P, st);
+                        }
+                        return launch_sa_v<T, NKS, true, true, 2>(P, st);
+                    }
                 }
                 return launch_sa_v<T, NKS, true, true>(P, st);
             }
@@ -443,7 +512,13 @@ void launch_sa(const SAParams& P, hipStream_t st) {
             const int e = sa_prefetch_env();
             if (e < 0 ? SA_PREFETCH_DEFAULT : e != 0) {
                 if constexpr (NKS <= 3) {
-                    if (sa_nq_env() == 2 && P.Sq >= 2 * SA_BQ) return launch_sa_v<T, NKS, false, true, 2>(P, st);
+                    if (sa_nq_env() == 2 && P.Sq >= 2 * SA_BQ) {
+                        if (sa_vr_env()) {
+                            if (P.D % 16 == 8 && sa_mk_env()) return launch_sa_v<T, NKS, false, true, 2, true, true>(P, st);
+                            return launch_sa_v<T, NKS, false, true, 2, false, true>(P, st);
+                        }
+                        return launch_sa_v<T, NKS, false, true, 2>(P, st);
+                    }
                 }
                 return launch_sa_v<T, NKS, false, true>(P, st);
             }

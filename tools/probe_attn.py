@@ -20,6 +20,7 @@ def bench(fn, iters=20, warm=3):
 
 def main():
     dev = "cuda"
+    torch.manual_seed(0)
     print("FMC_SA_PREFETCH =", os.environ.get("FMC_SA_PREFETCH"))
     for (B, S, H, D) in [(32, 2560, 8, 40), (32, 640, 8, 80), (32, 160, 8, 160), (32, 40, 8, 160)]:
         C = H * D
