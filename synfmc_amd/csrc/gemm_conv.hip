@@ -143,6 +143,7 @@ void gemm_kernel(const GemmParams P) {
     constexpr int PIECES = (BM + BN) / RPP;          // pieces per k-tile
     constexpr int PPW = (PIECES + NW - 1) / NW;      // pieces per wave (the last round may be ragged)
     constexpr int CP = BN + 8;                       // fp32 C slab pitch
+    constexpr bool FRAG_ALL = NW <= 8 && BK == 64 && MI == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -352,18 +353,36 @@ void gemm_kernel(const GemmParams P) {
                 af[i] = ta.v;
             }
         };
-        bf16x8 wf[2][2], af[2][MI];
-        load_frags(0, wf[0], af[0]);
+        if constexpr (FRAG_ALL) {
+            // every fragment of the k-tile requested up front: with the double-buffered form below a ds_read_b128 has the 4 MFMAs
+            // of one k-step (128 cycles) to land, which it does not under load -- +8..13 % on the deep-K shapes.  Needs 32 more
+            // VGPRs: the geometries below 16 waves per workgroup have them
+            bf16x8 wfa[BK / 16][2], afa[BK / 16][MI];
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            if (ks + 1 < BK / 16) load_frags(ks + 1, wf[(ks + 1) & 1], af[(ks + 1) & 1]);
+            for (int ks = 0; ks < BK / 16; ++ks) load_frags(ks, wfa[ks], afa[ks]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ks = 0; ks < BK / 16; ++ks)
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][ni], af[ks & 1][mi], acc[ni][mi], 0, 0, 0);
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfa[ks][ni], afa[ks][mi], acc[ni][mi], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+        } else {
+            bf16x8 wf[2][2], af[2][MI];
+            load_frags(0, wf[0], af[0]);
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                if (ks + 1 < BK / 16) load_frags(ks + 1, wf[(ks + 1) & 1], af[(ks + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][ni], af[ks & 1][mi], acc[ni][mi], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 
