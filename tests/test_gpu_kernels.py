@@ -368,6 +368,31 @@ def test_linear_second_residual(K, tile):
         K.linear_bf16(hd, wd, bd, None, s_, residual2=r2d)                      # a second residual needs the first
 
 
+@pytest.mark.parametrize("tile", [0, 1, 3, 5, 7, 11])
+def test_conv_epilogue_variants_plain_grid(K, tile):
+    """plain-grid epilogues of the conv kernel (one bf16 staging round): bias only, temb only (per-image and per-clip
+    rows), residual only, temb + residual; ragged Cout (tile columns beyond N) and ragged pixel count."""
+    dtype = torch.bfloat16
+    n, ci, co, h, w = 6, 128, 136, 13, 11
+    xo, xd = rnd((n, ci, h, w), 150, dtype)
+    fo, fd = rnd((co, ci, 3, 3), 151, dtype, scale=(9 * ci) ** -0.5)
+    bo, bd = rnd((co,), 152, dtype)
+    to, td = rnd((n, co), 153, dtype)
+    t2o, t2d = rnd((n // 3, co), 154, dtype)
+    ro, rd = rnd((n, co, h, w), 155, dtype)
+    x_cl, f_cl, r_cl = xd.permute(0, 2, 3, 1).contiguous(), fd.contiguous(memory_format=torch.channels_last), \
+        rd.permute(0, 2, 3, 1).contiguous()
+    base = F.conv2d(xo, fo, None, 1, 1)
+    cases = [(bd, None, None, 1, base + bo[None, :, None, None]),
+             (None, td, None, 1, base + to[:, :, None, None]),
+             (None, t2d, None, 3, base + t2o.repeat_interleave(3, 0)[:, :, None, None]),
+             (None, None, r_cl, 1, base + ro),
+             (bd, td, r_cl, 1, base + bo[None, :, None, None] + to[:, :, None, None] + ro)]
+    for bias, temb, res, div, ref in cases:
+        out = K.conv3x3_bf16(x_cl, f_cl, bias, temb, res, tile=tile, temb_div=div)
+        assert rel_inf(out.permute(0, 3, 1, 2).float(), ref) < 1e-2
+
+
 @pytest.mark.parametrize("split_k", [2, 4, 8])
 @pytest.mark.parametrize("tile", [1, 2, 9])
 def test_gemm_split_k(K, tile, split_k):
