@@ -109,15 +109,12 @@ __device__ __forceinline__ sa_s4 lds_tr16(const bf16_t* p) {
 
 // NQ 32-query blocks per wave share every K / V^T fragment read: per 32 keys 3 + 4 LDS fragment loads feed 7*NQ MFMAs
 // (at NQ = 1 the LDS port is ~80 % busy at d = 40: 12 waves per CU x 44 LDS cycles per 224 MFMA cycles)
-template <typename T, int NKS, int NQ, bool TAIL, bool MK = false, bool VR = false>
-__device__ __forceinline__ void attn_block(const T* __restrict__ Ks, const T* __restrict__ Vt, const Frag<T> (&qf)[NQ][NKS],
-                                           f32x16 (&oacc)[NQ][(NKS + 1) / 2], const f32x16 (&negm)[NQ], float (&worst)[NQ],
-                                           float (&l_run)[NQ], int sb, int kvb, int Skv, int l31, int half) {
-    constexpr int NDT = (NKS + 1) / 2;
+// One 32-key block in two phases, so that the caller can issue the QK^T MFMAs of the NEXT block before the softmax of this
+// one (the matrix pipe then works under the exp / max / convert VALU work instead of waiting for it).
+template <typename T, int NKS, int NQ, bool MK>
+__device__ __forceinline__ void qk_scores(const T* __restrict__ Ks, const Frag<T> (&qf)[NQ][NKS], const f32x16 (&negm)[NQ],
+                                          f32x16 (&s)[NQ], int sb, int l31, int half) {
     constexpr int KP = NKS * 16 + 8;
-    constexpr int VP = SA_BK + 4;
-    constexpr bool LROW = (NKS & 1) != 0;
-    f32x16 s[NQ];
 #pragma unroll
     for (int nq = 0; nq < NQ; ++nq) {
         if (MK) {                                    // the reference rides in the reduction (see the kernel): C = 0, no
@@ -134,6 +131,14 @@ __device__ __forceinline__ void attn_block(const T* __restrict__ Ks, const T* __
 #pragma unroll
         for (int nq = 0; nq < NQ; ++nq) mma32(kf, qf[nq][ks], s[nq]);
     }
+}
+
+template <typename T, int NKS, int NQ, bool TAIL, bool VR>
+__device__ __forceinline__ void softmax_pv(const T* __restrict__ Vt, f32x16 (&s)[NQ], f32x16 (&oacc)[NQ][(NKS + 1) / 2],
+                                           float (&worst)[NQ], float (&l_run)[NQ], int sb, int kvb, int Skv, int l31, int half) {
+    constexpr int NDT = (NKS + 1) / 2;
+    constexpr int VP = SA_BK + 4;
+    constexpr bool LROW = (NKS & 1) != 0;
     Frag<T> pf[NQ][2];
 #pragma unroll
     for (int nq = 0; nq < NQ; ++nq) {
@@ -183,6 +188,15 @@ __device__ __forceinline__ void attn_block(const T* __restrict__ Ks, const T* __
     }
 }
 
+template <typename T, int NKS, int NQ, bool TAIL, bool MK = false, bool VR = false>
+__device__ __forceinline__ void attn_block(const T* __restrict__ Ks, const T* __restrict__ Vt, const Frag<T> (&qf)[NQ][NKS],
+                                           f32x16 (&oacc)[NQ][(NKS + 1) / 2], const f32x16 (&negm)[NQ], float (&worst)[NQ],
+                                           float (&l_run)[NQ], int sb, int kvb, int Skv, int l31, int half) {
+    f32x16 s[NQ];
+    qk_scores<T, NKS, NQ, MK>(Ks, qf, negm, s, sb, l31, half);
+    softmax_pv<T, NKS, NQ, TAIL, VR>(Vt, s, oacc, worst, l_run, sb, kvb, Skv, l31, half);
+}
+
 // SHORT_KV only separates the text cross-attention launches (S_kv = 77) from the self-attention ones in profiles
 // (same code path): the two differ by >10x in work per launch and would blur a per-kernel-name average.
 template <typename T> __device__ __forceinline__ T to_elem(float v);
@@ -190,7 +204,7 @@ template <> __device__ __forceinline__ bf16_t to_elem<bf16_t>(float v) { return 
 template <> __device__ __forceinline__ float to_elem<float>(float v) { return v; }
 
 // PREFETCH keeps the next K/V tile in registers under the current tile's MFMAs (costs ~40 VGPRs).
-template <typename T, int NKS, bool SHORT_KV, bool PREFETCH, int NQ, bool MK, bool VR>
+template <typename T, int NKS, bool SHORT_KV, bool PREFETCH, int NQ, bool MK, bool VR, bool PIPE = VR>
 __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 && NQ == 1 ? 3 : 2) : 1) void spatial_attn_kernel(const SAParams P) {
     constexpr int NDT = (NKS + 1) / 2;
     constexpr int DP16 = NKS * 16;
@@ -390,9 +404,20 @@ __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 && NQ =
         // register allocator copy the O^T tuples every iteration); the ragged last tile is peeled.
         for (int tile = 0; tile < nfull; ++tile) {
             stage(tile);
+            if constexpr (SA_BK == 64 && sizeof(T) == 2 && PIPE) {
+                // QK^T of both 32-key blocks first: the second one's MFMAs run under the softmax VALU work of the first, the
+                // first one's PV MFMAs under the softmax of the second (PMC: matrix pipe 34 % + other VALU ~40 % of the SIMD
+                // cycles, one after the other, in the block-by-block order)
+                f32x16 s0[NQ], s1[NQ];
+                qk_scores<T, NKS, NQ, MK>(Ks, qf, negm, s0, 0, l31, half);
+                qk_scores<T, NKS, NQ, MK>(Ks, qf, negm, s1, 1, l31, half);
+                softmax_pv<T, NKS, NQ, false, VR>(Vt, s0, oacc, worst, l_run, 0, tile * SA_BK, P.Skv, l31, half);
+                softmax_pv<T, NKS, NQ, false, VR>(Vt, s1, oacc, worst, l_run, 1, tile * SA_BK + 32, P.Skv, l31, half);
+            } else {
 #pragma unroll
-            for (int sb = 0; sb < SA_BK / 32; ++sb)
-                attn_block<T, NKS, NQ, false, MK, VR>(Ks, Vt, qf, oacc, negm, worst, l_run, sb, tile * SA_BK + sb * 32, P.Skv, l31, half);
+                for (int sb = 0; sb < SA_BK / 32; ++sb)
+                    attn_block<T, NKS, NQ, false, MK, VR>(Ks, Vt, qf, oacc, negm, worst, l_run, sb, tile * SA_BK + sb * 32, P.Skv, l31, half);
+            }
         }
         if (nfull < ntiles) {
             stage(nfull);
