@@ -188,6 +188,57 @@ __device__ __forceinline__ void softmax_pv(const T* __restrict__ Vt, f32x16 (&s)
     }
 }
 
+// The same, query block by query block with the V^T fragments of the 32-key block loaded once up front: the PV MFMAs of
+// query block 0 are in flight while the VALU does the softmax of query block 1.
+template <typename T, int NKS, int NQ, bool VR>
+__device__ __forceinline__ void softmax_pv_perq(const T* __restrict__ Vt, f32x16 (&s)[NQ], f32x16 (&oacc)[NQ][(NKS + 1) / 2],
+                                                float (&worst)[NQ], float (&l_run)[NQ], int sb, int l31, int half) {
+    constexpr int NDT = (NKS + 1) / 2;
+    constexpr int VP = SA_BK + 4;
+    constexpr bool LROW = (NKS & 1) != 0;
+    Frag<T> vf[2][NDT];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            if constexpr (VR && sizeof(T) == 2) {
+                constexpr int VPR = sa_vr_pitch<NDT>();
+                const bf16_t* vp = reinterpret_cast<const bf16_t*>(Vt) +
+                                   (sb * 32 + s2 * 16 + half * 4 + ((l31 & 15) >> 2)) * VPR + dt * 32 + (l31 >> 4) * 16 + (l31 & 3) * 4;
+                union { bf16x8 v; sa_s4 h[2]; } r;
+                r.h[0] = lds_tr16(vp);
+                r.h[1] = lds_tr16(vp + 8 * VPR);
+                vf[s2][dt].hi = r.v;
+            } else {
+                const T* vrow = Vt + (dt * 32 + l31) * VP + sb * 32 + s2 * 16 + half * 4;
+                make_frag_2x4<T>(vrow, vrow + 8, vf[s2][dt]);
+            }
+        }
+#pragma unroll
+    for (int nq = 0; nq < NQ; ++nq) {
+        worst[nq] = fold_max(s[nq], worst[nq]);
+        float p[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(s[nq][r]);
+        if (!LROW) {
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) psum += p[r];
+            l_run[nq] += psum;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float p8[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) p8[i] = p[s2 * 8 + i];
+            Frag<T> pf;
+            p_frag(p8, pf);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) mma32(vf[s2][dt], pf, oacc[nq][dt]);
+        }
+    }
+}
+
 template <typename T, int NKS, int NQ, bool TAIL, bool MK = false, bool VR = false>
 __device__ __forceinline__ void attn_block(const T* __restrict__ Ks, const T* __restrict__ Vt, const Frag<T> (&qf)[NQ][NKS],
                                            f32x16 (&oacc)[NQ][(NKS + 1) / 2], const f32x16 (&negm)[NQ], float (&worst)[NQ],
@@ -411,8 +462,8 @@ __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 && NQ =
                 f32x16 s0[NQ], s1[NQ];
                 qk_scores<T, NKS, NQ, MK>(Ks, qf, negm, s0, 0, l31, half);
                 qk_scores<T, NKS, NQ, MK>(Ks, qf, negm, s1, 1, l31, half);
-                softmax_pv<T, NKS, NQ, false, VR>(Vt, s0, oacc, worst, l_run, 0, tile * SA_BK, P.Skv, l31, half);
-                softmax_pv<T, NKS, NQ, false, VR>(Vt, s1, oacc, worst, l_run, 1, tile * SA_BK + 32, P.Skv, l31, half);
+                softmax_pv_perq<T, NKS, NQ, VR>(Vt, s0, oacc, worst, l_run, 0, l31, half);
+                softmax_pv_perq<T, NKS, NQ, VR>(Vt, s1, oacc, worst, l_run, 1, l31, half);
             } else {
 #pragma unroll
                 for (int sb = 0; sb < SA_BK / 32; ++sb)
