@@ -114,6 +114,30 @@ def measure_attention_roofline(device, dtype, iters=20):
             "traffic": 259.6e6, "traffic_algorithmic": 4.0 * B * S * H * D * 2}
 
 
+def measure_conv_roofline(device, dtype, iters=20):
+    """The GEMM / conv kernel is where most of the step goes (63 %): one of its launches exactly as the U-Net issues it
+    (level-1 ResNet conv, CFG batch 2 x 16 frames of 20x32, 640 -> 640, 256x256 tile), for the record next to the
+    attention roofline the north-star asks for."""
+    from synfmc_amd import hip_ops as K
+    n, h, w, ci, co = 2 * FRAMES, HEIGHT // 16, WIDTH // 16, WIDTHS[1], WIDTHS[1]
+    x = torch.randn(n, h, w, ci, device=device, dtype=dtype)
+    wt = (torch.randn(co, ci, 3, 3, device=device, dtype=dtype) * 0.02).contiguous(memory_format=torch.channels_last)
+    for _ in range(3):
+        K.conv3x3_bf16(x, wt, None, None, None, tile=3)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        K.conv3x3_bf16(x, wt, None, None, None, tile=3)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * n * h * w * 9 * ci * co
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": f"gemm_kernel<conv3x3,256x256> [{n}x{h}x{w}, {ci}->{co}]", "achieved": round(achieved, 2),
+            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+            "avg_launch_ms": round(ms, 4), "flops_per_launch": flops}
+
+
 def unet_flops(batch, h, w):
     """Analytic forward FLOPs of the reference graph (un-merged LoRA) from a meta-device trace of the oracle."""
     from torch.utils.flop_counter import FlopCounterMode
@@ -400,6 +424,7 @@ def main():
 
     if rank == 0:
         roof = measure_attention_roofline(device, dtype) if dtype == torch.bfloat16 else None
+        roof_conv = measure_conv_roofline(device, dtype) if dtype == torch.bfloat16 else None
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -421,7 +446,7 @@ def main():
             "unet_tflop_per_step_reference_graph": round(f_step / 1e12, 3),
             "effective_tflops_per_gpu": round(f_step / 1e12 / (ms * 1e-3), 1),
             "conditioning_once_per_clip_ms": round(cond_ms, 2),
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_conv": roof_conv, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
         if args.autotune_log:
