@@ -255,7 +255,7 @@ template <> __device__ __forceinline__ bf16_t to_elem<bf16_t>(float v) { return 
 template <> __device__ __forceinline__ float to_elem<float>(float v) { return v; }
 
 // PREFETCH keeps the next K/V tile in registers under the current tile's MFMAs (costs ~40 VGPRs).
-template <typename T, int NKS, bool SHORT_KV, bool PREFETCH, int NQ, bool MK, bool VR, bool PIPE = VR>
+template <typename T, int NKS, bool SHORT_KV, bool PREFETCH, int NQ, bool MK, bool VR, bool PIPE = (PREFETCH && sizeof(T) == 2)>
 __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 && NQ == 1 ? 3 : 2) : 1) void spatial_attn_kernel(const SAParams P) {
     constexpr int NDT = (NKS + 1) / 2;
     constexpr int DP16 = NKS * 16;
