@@ -54,3 +54,38 @@ def stage3_loss(model_pred, target, obj_masks, sd_loss_weight=0.3, mask_loss_wei
     m = rearrange(m, "(b f) c h w -> b c f h w", b=B)
     ml = F.mse_loss((m * model_pred).float(), (m * target).float(), reduction="mean")
     return mask_loss_weight * ml + sd_loss_weight * sd
+
+
+@torch.no_grad()
+def denoise_plain(unet, scheduler, text_embeddings, latents, video_length, num_inference_steps=50, guidance_scale=7.5,
+                  multidiff_total_steps: int = 1, multidiff_overlaps: int = 12, callback=None):
+    """The plain text-to-video loop of `AnimationPipeline.__call__` (pipeline_animation_cm_om.py:315-440): no camera /
+    OMC conditioning, sliding windows of `video_length` frames overlapping by `multidiff_overlaps` whose guided noise
+    predictions are averaged where they overlap (:392-421).  `latents` `[B,4,F_total,h,w]` with
+    `F_total = multidiff_total_steps * (video_length - multidiff_overlaps) + multidiff_overlaps` (:369)."""
+    cfg = guidance_scale > 1.0
+    scheduler.set_timesteps(num_inference_steps)
+    single = video_length
+    assert latents.shape[2] == multidiff_total_steps * (single - multidiff_overlaps) + multidiff_overlaps
+    for i, t in enumerate(scheduler.timesteps):
+        full = torch.zeros_like(latents)
+        mask = torch.zeros_like(latents)
+        preds = []
+        for step in range(multidiff_total_steps):                                                        # :399-412
+            s0 = step * (single - multidiff_overlaps)
+            part = latents[:, :, s0:s0 + single].contiguous()
+            mask[:, :, s0:s0 + single] += 1
+            x = torch.cat([part] * 2) if cfg else part
+            x = scheduler.scale_model_input(x, t)
+            eps = unet(x, t, encoder_hidden_states=text_embeddings).sample.to(latents.dtype)
+            if cfg:
+                eps_u, eps_c = eps.chunk(2)
+                eps = eps_u + guidance_scale * (eps_c - eps_u)
+            preds.append(eps)
+        for j, eps in enumerate(preds):                                                                  # :414-416
+            s0 = j * (single - multidiff_overlaps)
+            full[:, :, s0:s0 + single] += eps / mask[:, :, s0:s0 + single]
+        latents = scheduler.step(full, t, latents).prev_sample                                           # :419
+        if callback is not None:
+            callback(i, t, latents)
+    return latents

@@ -12,7 +12,13 @@ What changes under the hood (one denoising step = one U-Net forward at CFG batch
   * OMC features are NOT zero-padded for the unconditional half (reference :671-676): `fmc_feature_add_fwd` simply
     skips that half;
   * `omcm_min_step` gating (:682-685) picks between two captured HIP graphs (with / without OMC features);
-  * CFG combine + DDIM update are one fused kernel on fp32 latents (:711-720).
+  * CFG combine + DDIM update are one fused kernel on fp32 latents (:711-720);
+  * the captured graphs are kept on the pipeline between calls: text, camera and OMC features are copied into the
+    graph's static buffers per clip (and the per-clip Camera-Adapter pose terms recomputed in place), so a second clip
+    of the same shape costs no warm-up and no capture.
+
+`AnimationPipeline` (:40-440) is the plain text-to-video loop of the LoRA-only configuration (BASELINE configs[1]):
+base U-Net, no pose encoder, sliding-window "multidiff" blending included.
 """
 from __future__ import annotations
 
@@ -30,20 +36,27 @@ class AnimationPipelineOutput:
 
 
 class _GraphedUNet:
-    """Captures `unet(x, t, text, pose_feats, traj)` into a HIP graph; replays with new latents / timestep."""
+    """Captures `unet(x, t, text[, pose_feats, traj])` into a HIP graph whose inputs are static buffers owned here;
+    `set_conditioning` refills them for a new clip, `__call__` replays with new latents / timestep."""
 
     def __init__(self, unet, latents_shape, text, pose_feats, traj_feats, dtype):
         self.unet = unet
         dev = text.device
         self.x = torch.zeros(latents_shape, dtype=dtype, device=dev)
         self.t = torch.zeros((), dtype=torch.int64, device=dev)
-        self.text, self.pose, self.traj = text, pose_feats, traj_feats
+        own = lambda v: v.detach().clone(memory_format=torch.preserve_format)
+        self.text = own(text)
+        self.pose = None if pose_feats is None else [own(p) for p in pose_feats]
+        self.traj = None if traj_feats is None else [own(p) for p in traj_feats]
         self.graph = None
         self.out = None
+        self._pose_terms = []
 
     def _call(self):
-        return self.unet(self.x, self.t, encoder_hidden_states=self.text, pose_embedding_features=self.pose,
-                         traj_features=self.traj).sample
+        kw = {}
+        if self.pose is not None:
+            kw = dict(pose_embedding_features=self.pose, traj_features=self.traj)
+        return self.unet(self.x, self.t, encoder_hidden_states=self.text, **kw).sample
 
     def capture(self):
         side = torch.cuda.Stream()
@@ -55,9 +68,22 @@ class _GraphedUNet:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = self._call()
-        # per-clip constants the processors computed during the warm-up (Camera-Adapter pose terms): the graph reads
-        # them, so they must live as long as it does even if another clip replaces the processors' cache entries
-        self._keep = [m.__dict__.get("_pose_term_cache") for m in self.unet.modules()]
+        # per-clip constants the processors computed during the warm-up (Camera-Adapter pose terms `s (W pose + b)`): the
+        # graph reads them by address, so this runner keeps them alive and refreshes them in place for a new clip
+        self._pose_terms = [(m, m.__dict__["_pose_term_cache"]) for m in self.unet.modules()
+                            if m.__dict__.get("_pose_term_cache") is not None]
+
+    def set_conditioning(self, text, pose_feats, traj_feats):
+        """New clip, same shapes: refill the static buffers, recompute the pose terms into the tensors the graph reads."""
+        from .. import hip_ops as K
+        self.text.copy_(text)
+        for dst, src in zip(self.pose or [], pose_feats or []):
+            dst.copy_(src)
+        for dst, src in zip(self.traj or [], traj_feats or []):
+            dst.copy_(src)
+        for mod, (key, term, pose_view) in self._pose_terms:
+            pf = pose_view if pose_view.is_contiguous() else pose_view.contiguous()
+            term.copy_(K.linear(pf, mod.qkv_merge.weight, mod.qkv_merge.bias, None, key[-1]))
 
     def __call__(self, x, t):
         self.x.copy_(x)
@@ -66,12 +92,22 @@ class _GraphedUNet:
         return self.out
 
 
-class CameraObjCtrlPipeline:
+def _weights_version(module) -> int:
+    return sum(p._version for p in module.parameters())
+
+
+class AnimationPipeline:
+    """Plain text-to-video loop.  Reference: pipeline_animation_cm_om.py:40-440 --
+    `AnimationPipeline(vae, text_encoder, tokenizer, unet, scheduler)(prompt, video_length, height, width,
+    num_inference_steps, guidance_scale, ...)`.  One denoising step = the base U-Net at CFG batch 2 on every sliding
+    window (`multidiff_total_steps` windows of `video_length` frames overlapping by `multidiff_overlaps`, noise predictions
+    averaged where windows overlap, :399-421) + the DDIM update."""
     vae_scale_factor = 8
 
-    def __init__(self, vae, text_encoder, tokenizer, unet, scheduler, pose_encoder):
+    def __init__(self, vae, text_encoder, tokenizer, unet, scheduler):
         self.vae, self.text_encoder, self.tokenizer = vae, text_encoder, tokenizer
-        self.unet, self.scheduler, self.pose_encoder = unet, scheduler, pose_encoder
+        self.unet, self.scheduler = unet, scheduler
+        self._runners = {}
 
     # ---- pieces outside the metric ------------------------------------------------------------------
     def _encode_prompt(self, prompt, device, num_videos_per_prompt, do_classifier_free_guidance, negative_prompt):
@@ -99,18 +135,143 @@ class CameraObjCtrlPipeline:
         video = video.reshape(b, video_length, *video.shape[1:]).permute(0, 2, 1, 3, 4)
         return ((video / 2 + 0.5).clamp(0, 1)).cpu().float().numpy()
 
+    def check_inputs(self, prompt, height, width, callback_steps):
+        if prompt is not None and not isinstance(prompt, (str, list)):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if callback_steps is None or not isinstance(callback_steps, int) or callback_steps <= 0:
+            raise ValueError(f"`callback_steps` has to be a positive integer but is {callback_steps} of type"
+                             f" {type(callback_steps)}.")
+
     def prepare_latents(self, batch_size, num_channels_latents, video_length, height, width, dtype, device, generator,
                         latents=None):
         shape = (batch_size, num_channels_latents, video_length, height // self.vae_scale_factor,
                  width // self.vae_scale_factor)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective"
+                             f" batch size of {batch_size}.")
         if latents is None:
-            gen_dev = generator.device if isinstance(generator, torch.Generator) else torch.device(device)
-            latents = torch.randn(shape, generator=generator, device=gen_dev, dtype=torch.float32).to(device)
+            if isinstance(generator, list):
+                latents = torch.cat([torch.randn((1,) + shape[1:], generator=g, device=g.device, dtype=torch.float32)
+                                     .to(device) for g in generator])
+            else:
+                gen_dev = generator.device if isinstance(generator, torch.Generator) else torch.device(device)
+                latents = torch.randn(shape, generator=generator, device=gen_dev, dtype=torch.float32).to(device)
         else:
             if latents.shape != shape:
                 raise ValueError(f"Unexpected latents shape, got {latents.shape}, expected {shape}")
             latents = latents.to(device)
         return latents.float() * self.scheduler.init_noise_sigma
+
+    # ---- shared machinery of the two loops -----------------------------------------------------------
+    def _prologue(self, prompt, height, width, callback_steps, latents, num_videos_per_prompt, guidance_scale,
+                  negative_prompt, prompt_embeds, device, eta):
+        if eta != 0.0:
+            raise NotImplementedError("eta > 0 is never used by FMC")
+        unet = self.unet
+        height = height or unet.config.sample_size * self.vae_scale_factor
+        width = width or unet.config.sample_size * self.vae_scale_factor
+        self.check_inputs(prompt, height, width, callback_steps)
+        do_cfg = guidance_scale > 1.0
+        batch_size = 1
+        if latents is not None:
+            batch_size = latents.shape[0]
+        if isinstance(prompt, list):
+            batch_size = len(prompt)
+        if prompt_embeds is None:
+            prompt = prompt if isinstance(prompt, list) else [prompt] * batch_size
+            if negative_prompt is not None and not isinstance(negative_prompt, list):
+                negative_prompt = [negative_prompt] * batch_size
+            prompt_embeds = self._encode_prompt(prompt, device, num_videos_per_prompt, do_cfg, negative_prompt)
+        text = prompt_embeds.to(device=device, dtype=unet.dtype)
+        return height, width, do_cfg, batch_size, text
+
+    def _runner(self, x_shape, text, pose_feats, traj, use_graph):
+        """The U-Net step as a callable `(x, t) -> eps`: a cached HIP graph (refilled with this clip's conditioning) or eager."""
+        unet = self.unet
+        if not use_graph:
+            def eager(x, t):
+                kw = {} if pose_feats is None else dict(pose_embedding_features=pose_feats, traj_features=traj)
+                return unet(x, torch.tensor(int(t), device=x.device), encoder_hidden_states=text, **kw).sample
+            return eager
+        key = (tuple(x_shape), tuple(text.shape), unet.dtype, pose_feats is not None, traj is not None,
+               _weights_version(unet))
+        r = self._runners.get(key)
+        if r is None:
+            for k in [k for k in self._runners if k[:-1] == key[:-1]]:      # same shapes, stale weights: drop the graph
+                del self._runners[k]
+            r = _GraphedUNet(unet, x_shape, text, pose_feats, traj, unet.dtype)
+            r.capture()
+            self._runners[key] = r
+        else:
+            r.set_conditioning(text, pose_feats, traj)
+        return r
+
+    def _finish(self, latents, output_type, return_dict):
+        if output_type == "latent":
+            video = latents
+        else:
+            video = self.decode_latents(latents)
+            if output_type == "tensor":
+                video = torch.from_numpy(video)
+        if not return_dict:
+            return video
+        return AnimationPipelineOutput(videos=video)
+
+    # ---- the plain denoising loop (BASELINE configs[1]) ----------------------------------------------
+    @torch.no_grad()
+    def __call__(self, prompt: Union[str, List[str], None], video_length: Optional[int], height: Optional[int] = None,
+                 width: Optional[int] = None, num_inference_steps: int = 50, guidance_scale: float = 7.5,
+                 negative_prompt=None, num_videos_per_prompt: Optional[int] = 1, eta: float = 0.0, generator=None,
+                 latents: Optional[torch.Tensor] = None, output_type: Optional[str] = "tensor",
+                 return_dict: bool = True, callback: Optional[Callable] = None, callback_steps: Optional[int] = 1,
+                 multidiff_total_steps: int = 1, multidiff_overlaps: int = 12, prompt_embeds=None,
+                 use_graph: bool = True, **kwargs):
+        unet = self.unet
+        device = next(unet.parameters()).device
+        height, width, do_cfg, batch_size, text = self._prologue(
+            prompt, height, width, callback_steps, latents, num_videos_per_prompt, guidance_scale, negative_prompt,
+            prompt_embeds, device, eta)
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        timesteps = self.scheduler._timesteps_host
+        single = video_length
+        video_length = multidiff_total_steps * (video_length - multidiff_overlaps) + multidiff_overlaps       # :369
+        latents = self.prepare_latents(batch_size * num_videos_per_prompt, unet.in_channels, video_length, height,
+                                       width, text.dtype, device, generator, latents).contiguous()
+        x_shape = (latents.shape[0] * (2 if do_cfg else 1), latents.shape[1], single) + tuple(latents.shape[3:])
+        run = self._runner(x_shape, text, None, None, use_graph)
+        stride = single - multidiff_overlaps
+        for i, t in enumerate(timesteps):
+            if multidiff_total_steps == 1:
+                x = torch.cat([latents] * 2) if do_cfg else latents
+                eps = run(x.to(unet.dtype), t)
+                latents = self.scheduler.step_cfg(eps, t, latents, guidance_scale, do_cfg)
+            else:                                       # sliding windows: average the guided predictions (:399-421)
+                full = torch.zeros_like(latents)
+                count = torch.zeros_like(latents)
+                for w in range(multidiff_total_steps):
+                    s0 = w * stride
+                    part = latents[:, :, s0:s0 + single].contiguous()
+                    x = torch.cat([part] * 2) if do_cfg else part
+                    eps = run(x.to(unet.dtype), t).float()
+                    if do_cfg:
+                        eu, ec = eps.chunk(2)
+                        eps = eu + guidance_scale * (ec - eu)
+                    full[:, :, s0:s0 + single] += eps
+                    count[:, :, s0:s0 + single] += 1
+                latents = self.scheduler.step_cfg((full / count).contiguous(), t, latents, 1.0, False)
+            if callback is not None and i % callback_steps == 0:
+                callback(i, t, latents)
+        return self._finish(latents, output_type, return_dict)
+
+
+class CameraObjCtrlPipeline(AnimationPipeline):
+    """Reference: pipeline_animation_cm_om.py:442-738 (a subclass of `AnimationPipeline` there too)."""
+
+    def __init__(self, vae, text_encoder, tokenizer, unet, scheduler, pose_encoder):
+        super().__init__(vae, text_encoder, tokenizer, unet, scheduler)
+        self.pose_encoder = pose_encoder
 
     # ---- the denoising loop (the metric's unit) ------------------------------------------------------
     @torch.no_grad()
@@ -123,24 +284,11 @@ class CameraObjCtrlPipeline:
                  multidiff_total_steps: int = 1, multidiff_overlaps: int = 12, prompt_embeds=None,
                  use_graph: bool = True, pose_embedding_unshuffled: bool = False, **kwargs):
         assert multidiff_total_steps == 1                                    # reference :690
-        if eta != 0.0:
-            raise NotImplementedError("eta > 0 is never used by FMC")
         unet = self.unet
-        height = height or unet.config.sample_size * self.vae_scale_factor
-        width = width or unet.config.sample_size * self.vae_scale_factor
-        if height % 8 != 0 or width % 8 != 0:
-            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
         device = pose_embedding.device
-        do_cfg = guidance_scale > 1.0
-        batch_size = 1
-        if latents is not None:
-            batch_size = latents.shape[0]
-        if isinstance(prompt, list):
-            batch_size = len(prompt)
-        if prompt_embeds is None:
-            prompt = prompt if isinstance(prompt, list) else [prompt] * batch_size
-            prompt_embeds = self._encode_prompt(prompt, device, num_videos_per_prompt, do_cfg, negative_prompt)
-        text = prompt_embeds.to(device=device, dtype=unet.dtype)
+        height, width, do_cfg, batch_size, text = self._prologue(
+            prompt, height, width, callback_steps, latents, num_videos_per_prompt, guidance_scale, negative_prompt,
+            prompt_embeds, device, eta)
 
         self.scheduler.set_timesteps(num_inference_steps, device=device)
         timesteps = self.scheduler._timesteps_host
@@ -155,6 +303,10 @@ class CameraObjCtrlPipeline:
             assert pose_embedding.ndim == 5
             bs = pose_embedding.shape[0]
             feats = self.pose_encoder(pose_embedding)
+        if bs != latents.shape[0] or (traj_features is not None and traj_features[0].shape[0] != latents.shape[0]):
+            # the reference fails here too (`hidden_states + traj_features[idx]` / the pose merge on mismatched batches)
+            raise ValueError(f"camera / OMC features cover {bs} clips but the latents hold {latents.shape[0]} "
+                             "(num_videos_per_prompt > 1 needs the conditioning repeated by the caller)")
         pose_feats = features_to_video(feats, bs)
         if do_cfg:
             pose_feats = [torch.cat([x, x], dim=0) for x in pose_feats]
@@ -164,42 +316,18 @@ class CameraObjCtrlPipeline:
 
         omcm_min_step = kwargs.get("omcm_min_step", 0)
         x_shape = (latents.shape[0] * (2 if do_cfg else 1),) + tuple(latents.shape[1:])
-        runners = {}
-
-        def run_unet(x, t, traj):
-            key = traj is not None
-            if not use_graph:
-                return unet(x, torch.tensor(int(t), device=device), encoder_hidden_states=text,
-                            pose_embedding_features=pose_feats, traj_features=traj).sample
-            if key not in runners:
-                r = _GraphedUNet(unet, x_shape, text, pose_feats, traj, unet.dtype)
-                r.capture()
-                runners[key] = r
-            return runners[key](x, t)
+        runs = {}
 
         for i, t in enumerate(timesteps):
             traj = traj_features
             if traj_features is not None and omcm_min_step > 0 and t < omcm_min_step:      # reference :682-685
                 traj = None
+            key = traj is not None
+            if key not in runs:
+                runs[key] = self._runner(x_shape, text, pose_feats, traj, use_graph)
             x = torch.cat([latents] * 2) if do_cfg else latents
-            eps = run_unet(x.to(unet.dtype), t, traj)
+            eps = runs[key](x.to(unet.dtype), t)
             latents = self.scheduler.step_cfg(eps, t, latents, guidance_scale, do_cfg)
             if callback is not None and i % callback_steps == 0:
                 callback(i, t, latents)
-
-        if output_type == "latent":
-            video = latents
-        else:
-            video = self.decode_latents(latents)
-            if output_type == "tensor":
-                video = torch.from_numpy(video)
-        if not return_dict:
-            return video
-        return AnimationPipelineOutput(videos=video)
-
-
-class AnimationPipeline(CameraObjCtrlPipeline):
-    """Plain text-to-video loop (reference :40-440): no pose encoder, base U-Net."""
-
-    def __init__(self, vae, text_encoder, tokenizer, unet, scheduler):
-        super().__init__(vae, text_encoder, tokenizer, unet, scheduler, None)
+        return self._finish(latents, output_type, return_dict)

@@ -11,8 +11,9 @@ clipping and the optimizer step -- plus the one exchange step of the path, the g
 * buckets are sized for xGMI (default 128 MiB: 7 point-to-point links per GPU, large messages amortise the ring
   latency; the whole OMC stage is 610 MB = 5 buckets) rather than DDP's 25 MiB NVSwitch default;
 * parameters that never receive a gradient (the Adapter's level-3 blocks, 60.6 M of 152.5 M params: hence the
-  reference's `find_unused_parameters=True`, train_cam_obj_ctrl.py:556) are handled by flushing unfinished buckets in
-  `finish()`: their slots just stay zero.
+  reference's `find_unused_parameters=True`, train_cam_obj_ctrl.py:556) are found in a discovery step and dropped from
+  the buckets (`grad = None`, as under DDP): they are neither shipped nor weight-decayed;
+* optional bf16 compression of the buckets on the wire.
 """
 from __future__ import annotations
 
@@ -53,60 +54,124 @@ def masked_mse_loss(model_pred: torch.Tensor, target: torch.Tensor, obj_masks: O
 
 
 class GradAllReducer:
-    """Bucketed, overlapped gradient all-reduce (mean over ranks) for the trainable subset of a model."""
+    """Bucketed, overlapped gradient all-reduce (mean over ranks) for the trainable subset of a model.
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 128 << 20, group=None):
+    * `find_unused=True` (the reference's `DDP(find_unused_parameters=True)`, train_cam_obj_ctrl.py:556): the FIRST step is
+      a discovery step -- a parameter counts as used when its gradient hook fired on ANY rank (one all-reduce of a
+      bitmap); unused parameters (the Adapter's level-3 blocks: 60.6 M of 152.5 M) are dropped from the buckets and get
+      `grad = None`, so they are neither shipped (242 MB of zeros per step) nor touched by AdamW's weight decay --
+      exactly what happens to them under DDP.
+    * `compress_dtype=torch.bfloat16`: the buckets travel as bf16 (half the xGMI bytes); accumulation, clipping and the
+      optimizer stay fp32.
+    * `overlap=False`: nothing is launched from inside `backward()`; `finish()` reduces the buckets afterwards.  This is
+      the mode for a HIP-graph-captured forward/backward (graph | all-reduce | graph, see bench.py --mode train).
+    * a second `backward()` before `zero_grad()` raises instead of silently using un-reduced gradients."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 128 << 20, group=None,
+                 overlap: bool = True, compress_dtype: Optional[torch.dtype] = None, find_unused: bool = True):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        params = [p for p in params if p.requires_grad]
+        self.bucket_bytes, self.overlap, self.compress_dtype = bucket_bytes, overlap, compress_dtype
+        self._all = [p for p in params if p.requires_grad]
+        self._discovering = find_unused
+        self._fired = set()
+        self._next = 0                              # first bucket not yet handed to the collective (launch order = index)
+        self.unused: List[torch.nn.Parameter] = []
         self.buckets: List[dict] = []
+        self._hooks = []
+        self._build(self._all)
+
+    # ---- bucket construction ---------------------------------------------------------------------------
+    def _build(self, params, old_grads=None):
+        for h in self._hooks:
+            h.remove()
+        self._hooks, self.buckets = [], []
         cur, cur_bytes = [], 0
         for p in reversed(params):                  # gradients become ready roughly in reverse registration order
             nbytes = p.numel() * p.element_size()
-            if cur and (cur_bytes + nbytes > bucket_bytes or cur[0].dtype != p.dtype or cur[0].device != p.device):
-                self._add_bucket(cur)
+            if cur and (cur_bytes + nbytes > self.bucket_bytes or cur[0].dtype != p.dtype or cur[0].device != p.device):
+                self._add_bucket(cur, old_grads)
                 cur, cur_bytes = [], 0
             cur.append(p)
             cur_bytes += nbytes
         if cur:
-            self._add_bucket(cur)
-        self._hooks = []
+            self._add_bucket(cur, old_grads)
         for bi, b in enumerate(self.buckets):
             for p in b["params"]:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
 
-    def _add_bucket(self, params):
+    def _add_bucket(self, params, old_grads=None):
         flat = torch.zeros(sum(p.numel() for p in params), dtype=params[0].dtype, device=params[0].device)
         off = 0
         for p in params:
-            p.grad = flat[off: off + p.numel()].view_as(p)        # autograd accumulates in place into this view
+            view = flat[off: off + p.numel()].view_as(p)
+            if old_grads is not None and id(p) in old_grads:
+                view.copy_(old_grads[id(p)])
+            p.grad = view                                         # autograd accumulates in place into this view
             off += p.numel()
-        self.buckets.append({"params": params, "flat": flat, "pending": len(params), "work": None, "launched": False})
+        self.buckets.append({"params": params, "flat": flat, "pending": len(params), "work": None, "launched": False,
+                             "comp": None})
 
     def _make_hook(self, bi):
-        def hook(_p):
+        def hook(p):
             b = self.buckets[bi]
+            if b["launched"]:
+                raise RuntimeError("GradAllReducer: a gradient arrived for a bucket that was already reduced -- several "
+                                   "backward() passes per step (gradient accumulation) are not supported; call zero_grad()")
+            self._fired.add(id(p))
             b["pending"] -= 1
-            if b["pending"] == 0:
-                self._launch(b)
+            if self.overlap and not self._discovering:
+                # collectives must be issued in the same order on every rank, and a parameter may be reached on some ranks
+                # only: buckets go out strictly in index order, a ready bucket waits for its predecessors
+                while self._next < len(self.buckets) and self.buckets[self._next]["pending"] == 0:
+                    self._launch(self.buckets[self._next])
+                    self._next += 1
         return hook
 
-    def _launch(self, b):
+    # ---- the exchange ----------------------------------------------------------------------------------
+    def _launch(self, b, async_op: bool = True):
         if b["launched"]:
             return
         b["launched"] = True
         if self.world > 1:
-            b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            buf = b["flat"]
+            if self.compress_dtype is not None and buf.dtype != self.compress_dtype:
+                b["comp"] = buf = b["flat"].to(self.compress_dtype)
+            b["work"] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+    def _prune_unused(self):
+        """End of the discovery step: used = hook fired on any rank."""
+        self._discovering = False
+        used = torch.tensor([1.0 if id(p) in self._fired else 0.0 for p in self._all], device=self._all[0].device)
+        if self.world > 1:
+            dist.all_reduce(used, op=dist.ReduceOp.MAX, group=self.group)
+        used = used.bool().tolist()
+        self.unused = [p for p, u in zip(self._all, used) if not u]
+        if not self.unused:
+            return
+        keep = [p for p, u in zip(self._all, used) if u]
+        old = {id(p): p.grad.detach().clone() for p in keep}
+        for p in self.unused:
+            p.grad = None
+        self._build(keep, old)
+        for b in self.buckets:                                    # this step's gradients are complete: nothing pending
+            b["pending"] = 0
 
     def finish(self) -> None:
         """Call after `loss.backward()`: flush buckets whose parameters never got a gradient, wait, average."""
+        if self._discovering:
+            self._prune_unused()
         for b in self.buckets:
             self._launch(b)
         for b in self.buckets:
             if b["work"] is not None:
-                b["work"].wait()
+                if hasattr(b["work"], "wait"):
+                    b["work"].wait()
                 b["work"] = None
             if self.world > 1:
+                if b["comp"] is not None:
+                    b["flat"].copy_(b["comp"])
+                    b["comp"] = None
                 b["flat"].mul_(1.0 / self.world)
 
     def zero_grad(self) -> None:
@@ -114,6 +179,7 @@ class GradAllReducer:
             b["flat"].zero_()
             b["pending"] = len(b["params"])
             b["launched"] = False
+        self._next = 0
         self._reinstall_views()      # an optimizer's zero_grad(set_to_none=True) may have dropped the views
 
     def _reinstall_views(self):
@@ -128,13 +194,48 @@ class GradAllReducer:
     def parameters(self):
         return [p for b in self.buckets for p in b["params"]]
 
+    def allreduce_bytes(self) -> int:
+        """bytes one step puts on the wire per rank (after pruning / compression)"""
+        e = torch.empty((), dtype=self.compress_dtype).element_size() if self.compress_dtype is not None else None
+        return sum(b["flat"].numel() * (e or b["flat"].element_size()) for b in self.buckets)
+
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:
-    """Rank-0 -> all copy of the module state (what the DDP constructor does once)."""
+    """Rank-0 -> all copy of the module state (what the DDP constructor does once).  c10d
+    collectives write their output without touching the tensor's version counter, and every derived-weight cache of the
+    models (fused QKV, channels-last / flipped filters, fp32 affine copies, interleaved GEGLU rows, batched temb) is keyed
+    on it: the received values therefore land through `copy_`, which bumps it."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            buf = t.detach().clone()
+            dist.broadcast(buf, src=src, group=group)
+            t.copy_(buf)
+
+
+def stage3_forward_backward(pose_adaptor, noise_scheduler, latents, noise, timesteps, encoder_hidden_states,
+                            plucker_embedding, traj_features_fn, obj_masks, sd_loss_weight=0.3, mask_loss_weight=1.0):
+    """add_noise -> Adapter -> U-Net -> loss -> backward (train_cam_obj_ctrl.py:802-915); returns the detached loss."""
+    noisy_latents = noise_scheduler.add_noise(latents, noise, timesteps)
+    traj_features = traj_features_fn()
+    model_pred = pose_adaptor(noisy_latents, timesteps, encoder_hidden_states=encoder_hidden_states,
+                              pose_embedding=plucker_embedding, traj_features=traj_features)
+    loss = masked_mse_loss(model_pred, noise, obj_masks, sd_loss_weight, mask_loss_weight)
+    loss.backward()
+    return loss.detach()
+
+
+def optimizer_update(trainable: Iterable[torch.nn.Parameter], optimizer, reducer: Optional["GradAllReducer"],
+                     max_grad_norm: float = 1.0) -> None:
+    """clip -> step -> zero (train_cam_obj_ctrl.py:917-943), on already averaged gradients."""
+    params = [p for p in trainable if p.requires_grad and p.grad is not None]
+    torch.nn.utils.clip_grad_norm_(params, max_grad_norm)
+    optimizer.step()
+    if reducer is not None:
+        reducer.zero_grad()
+    else:
+        optimizer.zero_grad(set_to_none=True)
 
 
 def stage3_training_step(pose_adaptor, omcm, noise_scheduler, optimizer, reducer: Optional[GradAllReducer], latents,
@@ -144,21 +245,12 @@ def stage3_training_step(pose_adaptor, omcm, noise_scheduler, optimizer, reducer
 
     `traj_features_fn()` must run the (trainable) Adapter, e.g. `lambda: get_traj_features_v2(infos, masks, omcm, ...)`.
     Returns the loss value (a 0-d tensor)."""
-    noisy_latents = noise_scheduler.add_noise(latents, noise, timesteps)
-    traj_features = traj_features_fn()
-    model_pred = pose_adaptor(noisy_latents, timesteps, encoder_hidden_states=encoder_hidden_states,
-                              pose_embedding=plucker_embedding, traj_features=traj_features)
-    loss = masked_mse_loss(model_pred, noise, obj_masks, sd_loss_weight, mask_loss_weight)
-    loss.backward()
+    loss = stage3_forward_backward(pose_adaptor, noise_scheduler, latents, noise, timesteps, encoder_hidden_states,
+                                   plucker_embedding, traj_features_fn, obj_masks, sd_loss_weight, mask_loss_weight)
     if reducer is not None:
         reducer.finish()
-    torch.nn.utils.clip_grad_norm_([p for p in omcm.parameters() if p.requires_grad], max_grad_norm)
-    optimizer.step()
-    if reducer is not None:
-        reducer.zero_grad()
-    else:
-        optimizer.zero_grad(set_to_none=True)
-    return loss.detach()
+    optimizer_update(omcm.parameters(), optimizer, reducer, max_grad_norm)
+    return loss
 
 
 def stage2_trainable_parameters(unet, pose_encoder) -> List[torch.nn.Parameter]:
@@ -181,10 +273,5 @@ def stage2_training_step(pose_adaptor, trainable: Iterable[torch.nn.Parameter], 
     loss.backward()
     if reducer is not None:
         reducer.finish()
-    torch.nn.utils.clip_grad_norm_([p for p in trainable if p.requires_grad], max_grad_norm)
-    optimizer.step()
-    if reducer is not None:
-        reducer.zero_grad()
-    else:
-        optimizer.zero_grad(set_to_none=True)
+    optimizer_update(trainable, optimizer, reducer, max_grad_norm)
     return loss.detach()

@@ -21,10 +21,14 @@ def unet_kwargs(widths=(64, 128, 256, 256), cross_dim=64, motion=True):
     return cfg
 
 
-def processor_kwargs(widths, lora=True):
-    return dict(add_spatial=False, spatial_attn_names="attn1", add_temporal=True, temporal_attn_names="0",
-                add_spatial_lora=lora, add_motion_lora=False,
-                lora_kwargs={"lora_rank": 2, "lora_scale": 1.0}, motion_lora_kwargs={"lora_rank": -1, "lora_scale": 1.0},
+def processor_kwargs(widths, lora=True, temporal=True, motion_lora=False):
+    """configs/obj.yaml / cam.yaml processor layout.  `temporal=False`: the Domain-LoRA-only model of BASELINE
+    configs[1] (LoRA on attn1 / attn2, plain temporal attention).  `motion_lora=True`: `LORAPoseAdaptorAttnProcessor`
+    (Camera Adapter + LoRA, rank C/4) on the temporal attention."""
+    return dict(add_spatial=False, spatial_attn_names="attn1", add_temporal=temporal, temporal_attn_names="0",
+                add_spatial_lora=lora, add_motion_lora=motion_lora,
+                lora_kwargs={"lora_rank": 2, "lora_scale": 1.0},
+                motion_lora_kwargs={"lora_rank": 4 if motion_lora else -1, "lora_scale": 1.0},
                 pose_feature_dimensions=list(widths), query_condition=True, key_value_condition=True, scale=1.0)
 
 
@@ -58,10 +62,10 @@ def reseed(module, seed, std=0.05, fan_in_gain=None):
 
 
 def build_oracle(widths=(64, 128, 256, 256), cross_dim=64, conditioned=True, lora=True, seed=0, fan_in_gain=None,
-                 enc_max_len=16):
+                 enc_max_len=16, motion_lora=False):
     unet = OM.UNet3DConditionModelCamObjCond(**unet_kwargs(widths, cross_dim))
     if conditioned:
-        unet.set_all_attn_processor(**processor_kwargs(widths, lora))
+        unet.set_all_attn_processor(**processor_kwargs(widths, lora, motion_lora=motion_lora))
         OM.patch_down_blocks_for_omc(unet)
     reseed(unet, seed, fan_in_gain=fan_in_gain)
     enc = reseed(OM.CameraPoseEncoder(**encoder_kwargs(widths, enc_max_len)), seed + 1, fan_in_gain=fan_in_gain) \
@@ -70,15 +74,31 @@ def build_oracle(widths=(64, 128, 256, 256), cross_dim=64, conditioned=True, lor
     return unet.eval(), (enc.eval() if enc else None), (ada.eval() if ada else None)
 
 
+def build_lora_only(widths=(64, 128, 256, 256), cross_dim=64, seed=0, fan_in_gain=None, device=None,
+                    dtype=torch.float32):
+    """BASELINE configs[1]: the 3-D U-Net with the Domain LoRA on every spatial attention (attn1 and attn2), plain
+    temporal attention, no camera / object conditioning.  Returns (oracle, product or None)."""
+    ou = OM.UNet3DConditionModelCamObjCond(**unet_kwargs(widths, cross_dim))
+    ou.set_all_attn_processor(**processor_kwargs(widths, True, temporal=False))
+    reseed(ou, seed, fan_in_gain=fan_in_gain).eval()
+    if device is None:
+        return ou, None
+    from synfmc_amd.models.unet import UNet3DConditionModel
+    pu = UNet3DConditionModel(**unet_kwargs(widths, cross_dim))       # the base model, as the plain pipeline uses it
+    pu.set_image_layer_lora(2)                                        # unet.py:407-421: rank = C // 2 (configs/lora.yaml)
+    pu.load_state_dict(ou.state_dict(), strict=True)
+    return ou, pu.to(device=device, dtype=dtype).eval().requires_grad_(False)
+
+
 def build_product(oracle_unet, oracle_enc, oracle_ada, widths=(64, 128, 256, 256), cross_dim=64, conditioned=True,
-                  lora=True, device="cuda", dtype=torch.float32, enc_max_len=16):
+                  lora=True, device="cuda", dtype=torch.float32, enc_max_len=16, motion_lora=False):
     from synfmc_amd.adapter import Adapter
     from synfmc_amd.models.pose_adaptor import CameraPoseEncoder
     from synfmc_amd.models.unet import UNet3DConditionModelCamObjCond
     from synfmc_amd.modified_modules import patch_unet_for_omc
     unet = UNet3DConditionModelCamObjCond(**unet_kwargs(widths, cross_dim))
     if conditioned:
-        unet.set_all_attn_processor(**processor_kwargs(widths, lora))
+        unet.set_all_attn_processor(**processor_kwargs(widths, lora, motion_lora=motion_lora))
         patch_unet_for_omc(unet)
     missing, unexpected = unet.load_state_dict(oracle_unet.state_dict(), strict=True)
     unet = unet.to(device=device, dtype=dtype).eval().requires_grad_(False)
@@ -128,3 +148,55 @@ def synthetic_clip(B=1, Fr=16, H=128, W=128, n_obj=3, cross_dim=64, seed=100):
         infos.append(fi)
         masks.append(fm)
     return dict(latents=latents, text=text, c2w=torch.from_numpy(c2w), K=K, infos=infos, masks=masks)
+
+
+class bf16_rounding:
+    """Context manager: run an oracle module "as bf16 storage would" -- every leaf module's output (Linear, Conv2d,
+    GroupNorm, LayerNorm, activations) is rounded to bf16 and the weights are bf16-rounded for the duration, while the
+    arithmetic stays the oracle's fp32.  The distance between this run and the plain fp32 oracle is the error the
+    bf16 FORMAT alone introduces through the depth of the network; a bf16 kernel path can be judged against it."""
+
+    def __init__(self, *modules):
+        self.modules = [m for m in modules if m is not None]
+        self.handles, self.saved = [], []
+
+    @staticmethod
+    def _round(x):
+        if torch.is_tensor(x) and x.is_floating_point():
+            return x.to(torch.bfloat16).to(x.dtype)
+        if isinstance(x, (tuple, list)):
+            return type(x)(bf16_rounding._round(v) for v in x)
+        return x
+
+    def __enter__(self):
+        for m in self.modules:
+            for sub in m.modules():
+                if not list(sub.children()):
+                    self.handles.append(sub.register_forward_hook(lambda _m, _i, out: bf16_rounding._round(out)))
+            for p in m.parameters():
+                self.saved.append((p, p.detach().clone()))      # the bf16 product stores every parameter in bf16
+                with torch.no_grad():
+                    p.copy_(p.to(torch.bfloat16).float())
+        return self
+
+    def __exit__(self, *exc):
+        for h in self.handles:
+            h.remove()
+        with torch.no_grad():
+            for p, v in self.saved:
+                p.copy_(v)
+        self.handles, self.saved = [], []
+        return False
+
+
+FULL_WIDTHS = (320, 640, 1280, 1280)
+FULL_CROSS_DIM = 768
+
+
+def full_width_case(seed=43, clip_seed=143, H=128, W=192, Fr=16):
+    """The benchmarked architecture (SD-1.5 widths 320/640/1280/1280, head dims 40/80/160, text width 768, CMC + OMC,
+    LoRA on the spatial attention) on a clip the CPU oracle finishes in seconds.  Weights are fan-in scaled
+    (`reseed(..., fan_in_gain=1.0)`): a variance-preserving net, so rel-inf errors measure arithmetic and not chaos."""
+    ou, oe, oa = build_oracle(FULL_WIDTHS, FULL_CROSS_DIM, seed=seed, fan_in_gain=1.0)
+    clip = synthetic_clip(B=1, Fr=Fr, H=H, W=W, cross_dim=FULL_CROSS_DIM, seed=clip_seed)
+    return ou, oe, oa, clip

@@ -158,50 +158,82 @@ import torch, torch.distributed as dist
 from synfmc_amd.training import GradAllReducer, broadcast_parameters
 dist.init_process_group("gloo", init_method="env://")
 r, w = dist.get_rank(), dist.get_world_size()
+mode = sys.argv[2]
 torch.manual_seed(100 + r)                       # different init per rank: broadcast must fix it
 net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 32), torch.nn.ReLU(),
                           torch.nn.Linear(32, 4))
-unused = torch.nn.Linear(8, 8)                   # never reached by the loss (like the Adapter's level 3)
-broadcast_parameters(net); broadcast_parameters(unused)
-params = list(net.parameters()) + list(unused.parameters())
-red = GradAllReducer(params, bucket_bytes=3000)  # several small buckets
+unused = torch.nn.Linear(8, 8)                   # never reached by the loss on any rank (like the Adapter's level 3)
+rank1_only = torch.nn.Linear(4, 4)               # reached on rank 1 only: must stay in the buckets everywhere
+v0 = [p._version for p in net.parameters()]
+broadcast_parameters(net); broadcast_parameters(unused); broadcast_parameters(rank1_only)
+assert all(p._version > a for p, a in zip(net.parameters(), v0))      # derived-weight caches keyed on _version see it
+params = list(net.parameters()) + list(unused.parameters()) + list(rank1_only.parameters())
+red = GradAllReducer(params, bucket_bytes=3000, overlap=(mode != "sync"),
+                     compress_dtype=torch.bfloat16 if mode == "bf16" else None)
 assert len(red.buckets) > 2
 x = torch.randn(5, 16, generator=torch.Generator().manual_seed(r))
-for step in range(2):
-    loss = net(x).pow(2).mean() * (step + 1)
+def fwd(ps, xx):
+    h = torch.relu(xx @ ps[0].t() + ps[1]); h = torch.relu(h @ ps[2].t() + ps[3]); return h @ ps[4].t() + ps[5]
+def loss_of(ps, extra, xx, rank, step):
+    y = fwd(ps, xx)
+    if rank == 1:
+        y = y @ extra[0].t() + extra[1]
+    return y.pow(2).mean() * (step + 1)
+for step in range(3):
+    loss = loss_of(list(net.parameters()), list(rank1_only.parameters()), x, r, step)
     loss.backward()
+    if step == 2:                                # a second backward in the same step must be refused, not mis-reduced
+        red.finish()
+        try:
+            loss_of(list(net.parameters()), list(rank1_only.parameters()), x, r, step).backward()
+            raised = False
+        except RuntimeError as e:
+            raised = "already reduced" in str(e)
+        if r == 0:
+            print(json.dumps({"step": step, "raised": raised}))
+        break
     red.finish()
-    got = torch.cat([p.grad.reshape(-1) for p in params]).clone()
-    # local reference: average of every rank's own gradient
+    live = list(net.parameters()) + list(rank1_only.parameters())
+    got = torch.cat([p.grad.reshape(-1) for p in live]).clone()
     ref_net = [p.detach().clone().requires_grad_(True) for p in net.parameters()]
-    def fwd(ps, xx):
-        h = torch.relu(xx @ ps[0].t() + ps[1]); h = torch.relu(h @ ps[2].t() + ps[3]); return h @ ps[4].t() + ps[5]
-    total = [torch.zeros_like(p) for p in ref_net]
+    ref_extra = [p.detach().clone().requires_grad_(True) for p in rank1_only.parameters()]
+    total = [torch.zeros_like(p) for p in ref_net + ref_extra]
     for rr in range(w):
         xr = torch.randn(5, 16, generator=torch.Generator().manual_seed(rr))
-        gs = torch.autograd.grad(fwd(ref_net, xr).pow(2).mean() * (step + 1), ref_net)
-        total = [t + g / w for t, g in zip(total, gs)]
-    want = torch.cat([t.reshape(-1) for t in total] + [torch.zeros(8 * 8 + 8)])
-    err = (got - want).abs().max().item()
+        gs = torch.autograd.grad(loss_of(ref_net, ref_extra, xr, rr, step), ref_net + ref_extra, allow_unused=True)
+        total = [t + (g / w if g is not None else 0) for t, g in zip(total, gs)]
+    want = torch.cat([t.reshape(-1) for t in total])
+    err = ((got - want).abs().max() / want.abs().max()).item()
+    unused_none = all(p.grad is None for p in unused.parameters())
+    n_bucket_params = sum(len(b["params"]) for b in red.buckets)
     red.zero_grad()
-    assert all(float(p.grad.abs().max()) == 0.0 for p in params)
+    assert all(float(p.grad.abs().max()) == 0.0 for p in live)
     if r == 0:
-        print(json.dumps({"step": step, "err": err, "buckets": len(red.buckets)}))
+        print(json.dumps({"step": step, "err": err, "buckets": len(red.buckets), "unused_none": unused_none,
+                          "n_unused": len(red.unused), "n_bucket_params": n_bucket_params,
+                          "wire_bytes": red.allreduce_bytes()}))
 dist.destroy_process_group()
 '''
 
 
-def test_two_rank_gloo_grad_allreduce(tmp_path):
+@pytest.mark.parametrize("mode,port,tol", [("overlap", 29732, 1e-6), ("sync", 29733, 1e-6), ("bf16", 29734, 2e-2)])
+def test_two_rank_gloo_grad_allreduce(tmp_path, mode, port, tol):
+    """2-rank all-reduce of the trainable subset: unused-parameter discovery (bitmap over ranks; a parameter used on one
+    rank only stays), overlapped / post-backward / bf16-compressed exchange, refusal of a second backward per step."""
     script = tmp_path / "reducer.py"
     script.write_text(_GLOO_REDUCER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29732", str(script), ROOT],
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT, mode],
                          capture_output=True, text=True, env=env, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
     import json
     lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 2 and all(l["err"] < 1e-6 for l in lines)
+    assert len(lines) == 3 and all(l["err"] < tol for l in lines[:2])
+    assert all(l["unused_none"] and l["n_unused"] == 2 and l["n_bucket_params"] == 8 for l in lines[:2])
+    n_live = 16 * 32 + 32 + 32 * 32 + 32 + 32 * 4 + 4 + 4 * 4 + 4
+    assert lines[1]["wire_bytes"] == n_live * (2 if mode == "bf16" else 4)
+    assert lines[2]["raised"] is True
 
 
 def test_loss_and_timestep_sampling_match_oracle():

@@ -1,0 +1,101 @@
+"""End-to-end parity of the gfx950 product path at the BENCHMARKED widths (SD-1.5: 320/640/1280/1280, head dims
+40/80/160, K up to 2560, text width 768, CMC + OMC, merged spatial LoRA) -- the configuration `bench.py` times -- on a
+16x128x192 clip the CPU oracle finishes in seconds.  The per-shape autotuner is free to pick any arm (plain tiles,
+split-K, stream-K, 8-phase), exactly as in the benchmark.
+
+Compared against (a) the oracle run here and (b) the stored output of the REFERENCE's own U-Net code
+(tests/golden/g5_unet_full_width.npz, made by make_golden_g5_full_width.py).
+
+Tolerances (rel-inf): fp32 storage 1e-3 (north-star).  bf16 storage: the bound is tied to what the bf16 FORMAT costs:
+the oracle itself, with every layer output and every weight rounded to bf16 (`common_models.bf16_rounding`), moves by
+`format_err` (1.5e-2 on this case); the bf16 kernel path must stay within 2.5x of that and below 4e-2 absolute.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+from einops import rearrange
+
+from oracle import conditioning as OC
+from tests import common_models as CM
+
+pytestmark = pytest.mark.gpu
+H, W = 128, 192
+
+
+def rel_inf(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.fixture(scope="module")
+def full():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g5_unet_full_width.npz"))
+    ou, oe, oa, clip = CM.full_width_case(int(g["seed"]), int(g["clip_seed"]), H, W)
+    assert sum(p.numel() for p in ou.parameters()) == int(g["n_params"])
+    t = torch.tensor([801])
+    with torch.no_grad():
+        pose_emb = rearrange(OC.to_plucker_embedding(clip["c2w"], clip["K"], (H, W)), "b f c h w -> b c f h w")
+        pose_feats = [rearrange(x, "(b f) c h w -> b c f h w", b=1) for x in oe(pose_emb)]
+        traj = OC.get_traj_features(clip["infos"], clip["masks"], oa)
+        ref = ou(clip["latents"], t, clip["text"], pose_embedding_features=pose_feats, traj_features=traj).sample
+        with CM.bf16_rounding(ou, oe, oa):
+            pf16 = [rearrange(x, "(b f) c h w -> b c f h w", b=1) for x in oe(pose_emb)]
+            tr16 = OC.get_traj_features(clip["infos"], clip["masks"], oa)
+            ref16 = ou(clip["latents"], t, clip["text"], pose_embedding_features=pf16, traj_features=tr16).sample
+    return dict(ou=ou, oe=oe, oa=oa, clip=clip, t=t, pose_emb=pose_emb, ref=ref, ref16=ref16, golden=g)
+
+
+def _product_forward(full, dtype):
+    from synfmc_amd.data.dataset import to_plucker_embedding
+    from synfmc_amd.models.pose_obj_adaptor import CamObjPoseAdaptor
+    from synfmc_amd.util import get_traj_features_v2
+    pu, pe, pa = CM.build_product(full["ou"], full["oe"], full["oa"], CM.FULL_WIDTHS, CM.FULL_CROSS_DIM, dtype=dtype)
+    clip = full["clip"]
+    with torch.no_grad():
+        emb = to_plucker_embedding(clip["c2w"].cuda(), clip["K"].cuda(), (H, W))              # Pluecker rays on the GPU
+        pose_emb = rearrange(emb, "b f c h w -> b c f h w").to(dtype)
+        tf = get_traj_features_v2(clip["infos"], clip["masks"], pa, False, 0.0, [False], "cuda", dtype)
+        wrapper = CamObjPoseAdaptor(pu, pe)
+        args = (clip["latents"].cuda().to(dtype), full["t"].cuda(), clip["text"].cuda().to(dtype), pose_emb)
+        out = wrapper(*args, tf)
+        out2 = wrapper(*args, tf)              # second call: autotuned arms + cached pose terms / fused weights in use
+        out0 = wrapper(*args, None)
+    torch.cuda.synchronize()
+    del pu, pe, pa
+    torch.cuda.empty_cache()
+    return out.float().cpu(), out2.float().cpu(), out0.float().cpu()
+
+
+def test_full_width_fp32_parity(full):
+    """fp32 storage (parity mode) at the benchmarked widths: 1e-3 rel-inf against the oracle and the reference golden."""
+    out, out2, out0 = _product_forward(full, torch.float32)
+    g = full["golden"]
+    e_oracle, e_gold = rel_inf(out, full["ref"]), rel_inf(out, torch.from_numpy(g["out"]))
+    print(f"full-width fp32: vs oracle {e_oracle:.3e}, vs reference golden {e_gold:.3e}, "
+          f"no-OMC vs golden {rel_inf(out0, torch.from_numpy(g['out_notraj'])):.3e}")
+    assert e_oracle < 1e-3 and e_gold < 1e-3
+    assert rel_inf(out2, full["ref"]) < 1e-3
+    assert rel_inf(out0, torch.from_numpy(g["out_notraj"])) < 1e-3
+    assert rel_inf(out, out0) > 1e-2                      # the OMC injection is visible at this precision
+
+
+def test_full_width_bf16_parity_and_format_share(full):
+    """bf16 storage at the benchmarked widths, and how much of its error is the FORMAT: the oracle under bf16 rounding
+    of every layer output and weight is `format_err` away from the fp32 oracle; the kernel path may not be much worse."""
+    out, out2, out0 = _product_forward(full, torch.bfloat16)
+    g = full["golden"]
+    format_err = rel_inf(full["ref16"], full["ref"])
+    e_oracle, e_gold = rel_inf(out, full["ref"]), rel_inf(out, torch.from_numpy(g["out"]))
+    e_vs16 = rel_inf(out, full["ref16"])
+    print(f"full-width bf16: vs fp32 oracle {e_oracle:.3e}, vs reference golden {e_gold:.3e}, vs bf16-rounded oracle "
+          f"{e_vs16:.3e}; bf16 format alone (rounded oracle vs fp32 oracle) {format_err:.3e}")
+    assert 2e-3 < format_err < 4e-2
+    assert e_oracle < 4e-2 and e_gold < 4e-2
+    assert e_oracle < 2.5 * format_err
+    assert rel_inf(out2, full["ref"]) < 4e-2
+    assert rel_inf(out0, torch.from_numpy(g["out_notraj"])) < 4e-2

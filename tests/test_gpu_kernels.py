@@ -210,6 +210,38 @@ def test_temporal_attention_native_and_reference_layouts(K, dtype, B, Fr, P, H, 
     assert rel_inf(out3.float(), ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("S,H,D", [(2560, 8, 40), (640, 8, 80), (160, 8, 160)])
+def test_spatial_attention_at_bench_size(K, dtype, S, H, D):
+    """The launches of the benchmarked U-Net (CFG batch 2 x 16 frames = 32 batch entries, 8 heads: 256 (batch, head)
+    pairs; q/k/v slices of ONE fused projection) -- the XCD-aware block map and the two-query-block path only show at
+    this grid size.  The oracle runs on a sample of batch entries (first, last, and one per XCD slot of the map)."""
+    B, C = 32, H * D
+    qkvo, qkvd = rnd((B, S, 3 * C), 50, dtype)
+    out = K.spatial_attention(qkvd[..., :C], qkvd[..., C:2 * C], qkvd[..., 2 * C:], H)
+    assert torch.isfinite(out).all()
+    sample = [0, 1, 7, 8, 13, 22, 30, 31]
+    ref = oracle_attention(qkvo[sample][..., :C], qkvo[sample][..., C:2 * C], qkvo[sample][..., 2 * C:], H)
+    assert rel_inf(out[sample].float(), ref) < TOL[dtype]
+    # every (batch, head) pair was written by its own workgroup: no pair may equal another entry's result
+    flat = out.float().view(B, -1)
+    assert (flat[1:] - flat[:-1]).abs().amax(dim=1).min() > 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Fr,P,H,D", [(16, 2560, 8, 40), (16, 640, 8, 80), (32, 4096, 8, 40)])
+def test_temporal_attention_at_bench_size(K, dtype, Fr, P, H, D):
+    """Level-0 / level-1 temporal attention of the benchmarked step (2 clips x 2560 pixels x 8 heads = 40 960 units)
+    and the level-0 shape of BASELINE configs[4] (32 frames, 64x64 latent), against the oracle on ALL units."""
+    B, C = 2, H * D
+    qkvo, qkvd = rnd((B, Fr, P, 3 * C), 51, dtype)
+    ref_in = qkvo.permute(0, 2, 1, 3).reshape(B * P, Fr, 3 * C)
+    ref = oracle_attention(ref_in[..., :C], ref_in[..., C:2 * C], ref_in[..., 2 * C:], H)
+    out = K.temporal_attention(qkvd[..., :C], qkvd[..., C:2 * C], qkvd[..., 2 * C:], H)
+    got = out.permute(0, 2, 1, 3).reshape(B * P, Fr, C)
+    assert rel_inf(got.float(), ref) < TOL[dtype]
+
+
 # ---------------------------------------------------------------------------------------------
 def test_plucker_against_golden_and_oracle(K, golden_dir):
     import os

@@ -171,3 +171,26 @@ def test_g5_reference_pipeline_loop(golden_dir):
             # the stub VAE round trip ((x*0.01/2+0.5) in fp32, then back) costs ~6e-8 * 200 absolute
             assert ((out - ref).abs().max() / ref.abs().max()).item() < 2e-5, key
     assert not np.allclose(gp["cfg2_gate700"], gp["cfg2_nogate"], atol=1e-4)
+
+
+def test_g5_full_width_oracle_matches_reference_code(golden_dir):
+    """The oracle at the BENCHMARKED widths (320/640/1280/1280, text 768, 1.39 B parameters) against the stored output
+    of the reference's own U-Net + camera-encoder code (make_golden_g5_full_width.py): same seeded weights and clip."""
+    import os
+    from einops import rearrange
+    from oracle import conditioning as OC
+    from tests import common_models as CM
+    g = np.load(os.path.join(golden_dir, "g5_unet_full_width.npz"))
+    H, W = (int(v) for v in g["hw"])
+    ou, oe, oa, clip = CM.full_width_case(int(g["seed"]), int(g["clip_seed"]), H, W)
+    assert sum(p.numel() for p in ou.parameters()) == int(g["n_params"])
+    with torch.no_grad():
+        pose_emb = rearrange(OC.to_plucker_embedding(clip["c2w"], clip["K"], (H, W)), "b f c h w -> b c f h w")
+        feats = oe(pose_emb)
+        assert np.allclose([float(x.double().sum()) for x in feats], g["enc_feat_sums"], rtol=1e-6)
+        pose_feats = [rearrange(x, "(b f) c h w -> b c f h w", b=1) for x in feats]
+        traj = OC.get_traj_features(clip["infos"], clip["masks"], oa)
+        out = ou(clip["latents"], torch.tensor([801]), clip["text"], pose_embedding_features=pose_feats,
+                 traj_features=traj).sample
+    ref = torch.from_numpy(g["out"])
+    assert float((out - ref).abs().max() / ref.abs().max()) < 1e-5
