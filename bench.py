@@ -14,14 +14,23 @@ the timed region starts.  Camera encoder / OMC adapter run once per clip, outsid
 reference pipeline (their time is reported separately in the JSON).
 
 Multi-GPU: clips are independent, so rank r denoises its own clip with no data-path collective ("scaling": "weak");
-the timed region is bracketed by barrier + synchronize and the MAX over ranks is used.
+the timed region is bracketed by barrier + synchronize and the MAX over ranks is used.  `python bench.py --gpus N` with
+no WORLD_SIZE in the environment starts the N ranks itself (re-exec under `torch.distributed.run`, 127.0.0.1 rendezvous);
+under an external launcher WORLD_SIZE must equal --gpus.  `n_gpus` in the JSON is the world size an RCCL all-reduce of
+ones returned, not an argument echo.
+
+Before anything is timed, ONE step of the benchmarked model is compared with the CPU oracle (same bf16-rounded weights,
+same noise / timestep / text / camera poses / object masks): `parity_rel_inf` in the JSON line.  The same oracle forward
+-- a CFG-batch-2 16x320x512 U-Net + CMC + OMC step on the host cores -- is the `cpu_baseline` sample.
 
 The JSON line also carries
   roofline     -- the dominant hand-written kernel (level-0 spatial self-attention, S=2560, d=40, 256 (batch,head)
                   pairs): algorithmic flops 4*B*H*S^2*d divided by its average launch duration measured here with
                   events on the launch stream; peak = 2.5 PFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md);
+  roofline_temporal -- the level-0 temporal attention kernel (HBM-bound): algorithmic bytes 4*N*F*H*D*2 / launch time
+                  against 8 TB/s;
   cpu_baseline -- the oracle (fp32 PyTorch restatement; the reference itself needs diffusers, not installable)
-                  timed on this node's host cores on a bounded sample and scaled by analytic FLOPs.
+                  timed on this node's host cores on ONE real step of the metric's configuration (no extrapolation).
 """
 from __future__ import annotations
 
@@ -50,12 +59,14 @@ def log(*a):
 
 
 def fast_init_(module: torch.nn.Module, seed: int, std: float = 0.02):
-    """Seeded random init on the module's device (N(0, std); norm gains around 1).  Zero-initialised layers of the
-    reference (qkv_merge, zero convs, LoRA up, proj_out) get values too so the conditioning paths do real work."""
+    """Seeded random init on the module's device, Kaiming-like as SURVEY.md section 8d prescribes: matrices / filters
+    N(0, 1/fan_in) (variance preserving, so the parity figure measures arithmetic and not a chaotic net), vectors N(0, std),
+    norm gains around 1.  Zero-initialised layers of the reference (qkv_merge, zero convs, LoRA up, proj_out) get values too
+    so the conditioning paths do real work."""
     g = torch.Generator(device=next(module.parameters()).device).manual_seed(seed)
     with torch.no_grad():
         for name, p in module.named_parameters():
-            p.normal_(0.0, std, generator=g)
+            p.normal_(0.0, std if p.ndim < 2 else p[0].numel() ** -0.5, generator=g)
             if p.ndim == 1 and "norm" in name and name.endswith("weight"):
                 p.add_(1.0)
 
@@ -138,84 +149,224 @@ def measure_conv_roofline(device, dtype, iters=20):
             "avg_launch_ms": round(ms, 4), "flops_per_launch": flops}
 
 
-def unet_flops(batch, h, w):
-    """Analytic forward FLOPs of the reference graph (un-merged LoRA) from a meta-device trace of the oracle."""
+def unet_flops(batch, h, w, executed=False):
+    """Analytic forward FLOPs from a meta-device trace of the oracle.  `executed=False`: the reference graph (LoRA as
+    separate `up(down(x))` GEMMs, text K/V projected once per FRAME).  `executed=True`: what the product launches --
+    LoRA merged into the projection weights, text K/V projected once per CLIP."""
     from torch.utils.flop_counter import FlopCounterMode
     from oracle import fmc_modules as OM
     from tests import common_models as CM
     with torch.device("meta"):
         u = OM.UNet3DConditionModelCamObjCond(**CM.unet_kwargs(WIDTHS, CROSS_DIM))
-        u.set_all_attn_processor(**CM.processor_kwargs(WIDTHS))
+        u.set_all_attn_processor(**CM.processor_kwargs(WIDTHS, lora=not executed))
         OM.patch_down_blocks_for_omc(u)
         x, text = torch.empty(batch, 4, FRAMES, h, w), torch.empty(batch, 77, CROSS_DIM)
         feats = [torch.empty(batch, c, FRAMES, h // s, w // s) for c, s in zip(WIDTHS, (1, 2, 4, 8))]
         with FlopCounterMode(display=False) as fc:
             u(x, torch.empty(batch, dtype=torch.long), text, pose_embedding_features=feats, traj_features=feats)
-    return float(fc.get_total_flops())
+    total = float(fc.get_total_flops())
+    if executed:      # 16 cross-attention layers: K and V of the 77 text tokens, (frames - 1) redundant copies per clip
+        per_level = {0: 5, 1: 5, 2: 5, 3: 1}                   # down 2 + up 3 per level, mid block at level 3
+        total -= sum(n * 2 * 2.0 * batch * (FRAMES - 1) * 77 * CROSS_DIM * WIDTHS[l] for l, n in per_level.items())
+    return total
 
 
-def cpu_baseline(budget_s=25.0):
-    """Oracle U-Net (+CMC+OMC injection), full width, fp32, on the host cores; bounded sample = 16x128x192 clip,
-    batch 1 (no CFG); scaled to the metric's unit by analytic FLOPs (the oracle is the 'port')."""
+def measure_temporal_roofline(device, dtype, iters=50):
+    """Level-0 temporal attention exactly as the U-Net launches it: q/k/v slices of one fused [2, 16, 2560, 960] projection
+    (CFG batch 2 clips x 2560 pixels x 8 heads x 16 frames).  HBM-bound: arithmetic intensity F/2 = 8 flop/B."""
+    from synfmc_amd import hip_ops as K
+    B, P, H, D = 2, (HEIGHT // 8) * (WIDTH // 8), 8, WIDTHS[0] // 8
+    C = H * D
+    qkv = torch.randn(B, FRAMES, P, 3 * C, device=device, dtype=dtype)
+    for _ in range(3):
+        K.self_attention_qkv(qkv, H, D ** -0.5, True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        K.self_attention_qkv(qkv, H, D ** -0.5, True)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    nbytes = 4.0 * B * P * FRAMES * C * 2                      # q, k, v read + o written, bf16
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": f"temporal_attn_kernel<bf16,d={D}> [2x{P} pixels x {H} heads, F={FRAMES}]",
+            "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+            "avg_launch_ms": round(ms, 5), "bytes_per_launch": nbytes,
+            # HBM-side bytes per launch from rocprofv3 PMC passes (profiles/r02_temporal_pmc.md); null until measured
+            "traffic": TEMPORAL_TRAFFIC_BYTES}
+
+
+TEMPORAL_TRAFFIC_BYTES = None
+
+
+def oracle_step(unet, enc, ada, clip, text2, latents, t, want_config1=True):
+    """ONE step of the metric's configuration on the host cores through the oracle (fp32 restatement of the reference),
+    with the benchmarked model's own (bf16-rounded) weights and the benchmark's own inputs: CFG-batch-2 16x320x512 U-Net +
+    CMC + OMC forward.  Returns (eps fp32 `[2,4,F,h,w]`, cpu_baseline dict).  The camera encoder and the OMC adapter run
+    once per clip outside the step, as in the pipeline; their time is reported but not part of the step."""
+    from einops import rearrange
+    from oracle import conditioning as OC
     from oracle import fmc_modules as OM
     from tests import common_models as CM
-    # oneDNN/OpenMP scaling collapses far below the 256 hardware threads of the GPU node (measured: 427 s with 256, 5.6 s with 64, 2.6 s with 32, 1.6 s with 16, 2.3 s with 8
-    # threads for the same sample), so the port is timed on a fixed, stated number of cores
+    # oneDNN / OpenMP scaling collapses far below the 256 hardware threads of the GPU node (same 16x128x192 sample: 2.3 s on
+    # 8 threads, 1.6 s on 16, 2.6 s on 32, 5.6 s on 64, 427 s on 256), so the port runs on a fixed, stated number of threads
     cores = min(os.cpu_count() or 1, int(os.environ.get("FMC_CPU_BASELINE_THREADS", "16")))
     torch.set_num_threads(cores)
-    sh, sw = 128 // 8, 192 // 8
+    t_build = time.time()
     with torch.device("meta"):
-        u = OM.UNet3DConditionModelCamObjCond(**CM.unet_kwargs(WIDTHS, CROSS_DIM))
-        u.set_all_attn_processor(**CM.processor_kwargs(WIDTHS))
-    u = u.to_empty(device="cpu").eval()
-    OM.patch_down_blocks_for_omc(u)
-    block = torch.randn(1 << 20, generator=torch.Generator().manual_seed(0)) * 0.02
-    with torch.no_grad():
-        for p in u.parameters():                      # cheap deterministic fill (values do not affect timing)
-            flat = p.view(-1)
-            n = flat.numel()
-            reps = (n + block.numel() - 1) // block.numel()
-            flat.copy_(block.repeat(reps)[:n])
-        for m in u.modules():
-            if isinstance(m, OM.PositionalEncoding):
-                m.pe.copy_(OM.PositionalEncoding(m.pe.shape[-1], max_len=m.pe.shape[1]).pe)
-    g = torch.Generator().manual_seed(1)
-    x, text = torch.randn(1, 4, FRAMES, sh, sw, generator=g), torch.randn(1, 77, CROSS_DIM, generator=g)
-    feats = [torch.randn(1, c, FRAMES, sh // s, sw // s, generator=g) * 0.1 for c, s in zip(WIDTHS, (1, 2, 4, 8))]
-    times = []
+        ou = OM.UNet3DConditionModelCamObjCond(**CM.unet_kwargs(WIDTHS, CROSS_DIM))
+        ou.set_all_attn_processor(**CM.processor_kwargs(WIDTHS))
+        oe = OM.CameraPoseEncoder(**CM.encoder_kwargs(WIDTHS, max(16, FRAMES)))
+        oa = OM.Adapter(**CM.adapter_kwargs(WIDTHS))
+    for o, p in ((ou, unet), (oe, enc), (oa, ada)):
+        o.to_empty(device="cpu")
+        o.load_state_dict({k: v.detach().float().cpu() for k, v in p.state_dict().items()}, strict=True)
+        o.eval()
+    OM.patch_down_blocks_for_omc(ou)
+    t_build = time.time() - t_build
     with torch.no_grad():
         t0 = time.time()
-        u(x, torch.tensor([801]), text, pose_embedding_features=feats, traj_features=feats)       # warm-up
-        warm = time.time() - t0
-        while len(times) < 3 and (sum(times) + warm) < budget_s:
+        pose_emb = rearrange(OC.to_plucker_embedding(clip["c2w"], clip["K"], (HEIGHT, WIDTH)), "b f c h w -> b c f h w")
+        pose = [rearrange(x, "(b f) c h w -> b c f h w", b=1) for x in oe(pose_emb)]
+        traj = OC.get_traj_features(clip["infos"], clip["masks"], oa)
+        t_cond = time.time() - t0
+        pose2 = [torch.cat([x, x]) for x in pose]                                     # pipeline_animation_cm_om.py:668-669
+        traj2 = [torch.cat([torch.zeros_like(x), x]) for x in traj]                   # :671-676
+        x2 = torch.cat([latents, latents]).to(torch.bfloat16).float()                 # the values the GPU path is fed
+        t0 = time.time()
+        eps = ou(x2, torch.tensor(int(t)), text2.float().cpu(), pose_embedding_features=pose2, traj_features=traj2).sample
+        t_step = time.time() - t0
+        t_c1 = None
+        if want_config1:           # BASELINE configs[0]: 1x16x256x256 fp32, base U-Net, plain processors, no adapters
+            ou.set_attn_processor(OM.AttnProcessor())
+            ou.set_mm_attn_processor(OM.AttnProcessor())
+            g = torch.Generator().manual_seed(7)
+            x1, txt1 = torch.randn(1, 4, 16, 32, 32, generator=g), torch.randn(1, 77, CROSS_DIM, generator=g)
             t0 = time.time()
-            u(x, torch.tensor([801]), text, pose_embedding_features=feats, traj_features=feats)
-            times.append(time.time() - t0)
-    t_sample = min(times) if times else warm
-    f_sample, f_step = unet_flops(1, sh, sw), unet_flops(2, HEIGHT // 8, WIDTH // 8)
-    return {"value": round(1.0 / (t_sample * f_step / f_sample), 6), "unit": "denoising steps/s", "cores": cores,
+            ou(x1, torch.tensor(500), txt1)
+            t_c1 = time.time() - t0
+    del ou, oe, oa
+    base = {"value": round(1.0 / t_step, 6), "unit": "denoising steps/s", "cores": cores, "host_cpus": os.cpu_count(),
             "kind": "port",
-            "sample": f"oracle fp32 full-width U-Net+CMC+OMC forward, 16x128x192 clip, batch 1: {t_sample:.2f} s "
-                      f"({f_sample / 1e12:.2f} TFLOP); scaled by FLOPs to a CFG-batch-2 16x320x512 step "
-                      f"({f_step / 1e12:.2f} TFLOP)"}
+            "sample": f"ONE real step of the metric's configuration, not extrapolated: oracle (fp32 restatement; the reference "
+                      f"needs diffusers) U-Net+CMC+OMC forward at CFG batch 2 on the 16x320x512 clip = {t_step:.2f} s on "
+                      f"{cores} threads (thread policy: min(cpu_count, 16), oneDNN scaling collapses beyond; first call, no "
+                      f"warm-up); conditioning once per clip (Pluecker + camera encoder + OMC adapter) {t_cond:.2f} s; "
+                      f"weights copy {t_build:.1f} s"
+                      + (f"; BASELINE configs[0] (1x16x256x256 fp32 base U-Net, no adapters) forward {t_c1:.2f} s = "
+                         f"{1.0 / t_c1:.4f} steps/s" if t_c1 else "")}
+    return eps, base
+
+
+# --------------------------------------------------------------------------------------------------------------
+# launch plumbing shared by every mode
+# --------------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def ensure_ranks(args) -> None:
+    """`--gpus N` must mean N ranks.  Without a launcher (no WORLD_SIZE in the environment) and N > 1 this process
+    re-executes itself under `python -m torch.distributed.run --nproc-per-node N` and exits with its status; under a
+    launcher a WORLD_SIZE that disagrees with --gpus is an error, not a warning."""
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus <= 1:
+            return
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        log(f"bench.py: starting {args.gpus} ranks: {' '.join(cmd)}")
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")))
+    world = int(os.environ["WORLD_SIZE"])
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+
+
+def init_ranks(backend: str, device):
+    """(rank, local_rank, world) with the world size VERIFIED by a collective: every rank contributes 1, the sum is what
+    `n_gpus` reports."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        kw = {"device_id": device} if backend == "nccl" else {}
+        dist.init_process_group(backend, **kw)
+        one = torch.ones(1, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(one)
+        if int(one.item()) != world:
+            raise SystemExit(f"bench.py: all-reduce of ones returned {int(one.item())}, expected {world}")
+        world = int(one.item())
+    return rank, local_rank, world
+
+
+def timed_region(step_fn, steps: int, warmup: int, world: int, sync) -> float:
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides; MAX over ranks (seconds)."""
+    for i in range(warmup):
+        step_fn(i)
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step_fn(warmup + i)
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        el = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if torch.cuda.is_available() and dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+    return elapsed
+
+
+def dry_run_main(args):
+    """Launcher / timing / JSON plumbing on CPU with the gloo backend and a stub step (no model, no kernels): what the 2-rank
+    CPU test of this entry point runs.  Never a measurement: the line says `"dry_run": true`."""
+    ensure_ranks(args)
+    rank, _, world = init_ranks("gloo", torch.device("cpu"))
+    x = torch.randn(64, 64, generator=torch.Generator().manual_seed(rank))
+
+    def step(i):
+        nonlocal x
+        x = torch.tanh(x @ x.t() / 64.0)
+
+    elapsed = timed_region(step, args.steps, args.warmup, world, lambda: None)
+    if rank == 0:
+        print(json.dumps({"metric": "DRY RUN (launcher / timing plumbing only)", "dry_run": True, "value": round(world * args.steps / elapsed, 4),
+                          "unit": "stub steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "stub", "parallelism": f"dp{world}", "backend": "gloo"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def train_main(args):
     """Secondary measurement: stage-3 (OMC) training steps/s, one clip per GPU, weak scaling, gradients averaged
-    over ranks by `synfmc_amd.training.GradAllReducer` (RCCL).  Reference loop: train_cam_obj_ctrl.py:782-943."""
-    rank = int(os.environ.get("RANK", "0"))
+    over ranks by `synfmc_amd.training.GradAllReducer` (RCCL).  Reference loop: train_cam_obj_ctrl.py:782-943.
+
+    HIP graphs: one rank = the whole step (forward, backward, clip, AdamW) in ONE graph.  Several ranks = graph A (forward +
+    backward into the flat gradient buckets) | RCCL all-reduce of the buckets (eager, a handful of large messages) | graph B
+    (clip + AdamW + zeroing): the step stays graph-replayed, only the exchange is issued from the host.  `--train-graph`
+    forces either form (or none) on any world size."""
+    ensure_ranks(args)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+    rank, local_rank, world = init_ranks("nccl", device)
     global FRAMES, HEIGHT, WIDTH
     FRAMES, HEIGHT, WIDTH = (int(v) for v in args.clip.lower().split("x"))
     dtype = torch.bfloat16
     from synfmc_amd.models.pose_obj_adaptor import CamObjPoseAdaptor
     from synfmc_amd.schedulers import DDIMScheduler
-    from synfmc_amd.training import GradAllReducer, biased_timesteps, broadcast_parameters, stage3_training_step
+    from synfmc_amd.training import (GradAllReducer, biased_timesteps, broadcast_parameters, optimizer_update,
+                                     stage3_forward_backward)
     from synfmc_amd.util import stack_object_inputs
     from synfmc_amd import hip_ops as K
     from synfmc_amd.models.pose_adaptor import features_to_video
@@ -226,10 +377,12 @@ def train_main(args):
     clip, _ = synthetic_inputs(rank, device)
     sched = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="linear",
                           steps_offset=1, clip_sample=False)
-    use_graph = world == 1 and not args.no_graph           # one rank: the whole step (fwd, bwd, clip, AdamW) is one HIP graph
-    opt = torch.optim.AdamW([p for p in ada.parameters()], lr=1e-6, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8,
-                            capturable=use_graph)
-    reducer = GradAllReducer(ada.parameters())
+    mode = args.train_graph or ("one" if world == 1 else "split")
+    if args.no_graph:
+        mode = "none"
+    # overlap (all-reduce launched from inside backward) cannot live inside a captured graph: graphed modes reduce after it
+    reducer = GradAllReducer(ada.parameters(), overlap=(mode == "none"),
+                             compress_dtype=torch.bfloat16 if args.grad_compress == "bf16" else None)
     wrapper = CamObjPoseAdaptor(unet, enc)
     poses, masks = stack_object_inputs(clip["infos"], clip["masks"], device)
     c2w, Kin = clip["c2w"].to(device), clip["K"].to(device)
@@ -244,7 +397,7 @@ def train_main(args):
         noise.copy_(torch.randn(latents.shape, device=device, dtype=dtype, generator=gen))
         t.copy_(biased_timesteps(1, 1000, 700, 0.8, device, gen))
 
-    def body():
+    def fwd_bwd():
         emb = K.plucker(Kin, c2w, HEIGHT, WIDTH, "bcfhw", dtype)      # on device, every step (reference: CPU + H2D)
 
         def traj_fn():
@@ -252,51 +405,77 @@ def train_main(args):
                 feats, m = K.omc_rasterize(poses, masks, "unshuffle8", dtype)
                 return features_to_video(ada(feats, m), 1)
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            return stage3_training_step(wrapper, ada, sched, opt, reducer, latents, noise, t, text, emb, traj_fn, obj_masks)
+            return stage3_forward_backward(wrapper, sched, latents, noise, t, text, emb, traj_fn, obj_masks)
 
-    if use_graph:
-        # eager warm-up on a side stream (autotune, MIOpen find, optimizer state), then capture the step once: eagerly the
-        # step is launch-bound (34 ms of kernels in 77 ms of wall clock on one GPU)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
+    # discovery step (eager): autotune, MIOpen find, and the reducer learns which parameters are never used (Adapter level 3)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        draw()
+        fwd_bwd()
+        reducer.finish()
+        reducer.zero_grad()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    trainable = reducer.parameters()                         # the used subset; the rest keeps grad = None (as under DDP)
+    opt = torch.optim.AdamW(trainable, lr=1e-6, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, capturable=mode != "none")
+
+    def update():
+        optimizer_update(trainable, opt, reducer, 1.0)
+
+    if mode == "none":
+        def step(_i=0):
+            draw()
+            loss = fwd_bwd()
+            reducer.finish()
+            update()
+            return loss
+    else:
+        with torch.cuda.stream(side):                        # eager warm-up of the optimizer state before capture
+            for _ in range(2):
                 draw()
-                body()
+                fwd_bwd()
+                reducer.finish()
+                update()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
         draw()
-        with torch.cuda.graph(graph):
-            static_loss = body()
+        if mode == "one":
+            assert world == 1, "--train-graph one needs a single rank (the exchange cannot be captured)"
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_loss = fwd_bwd()
+                reducer.finish()
+                update()
 
-        def step():
-            draw()
-            graph.replay()
-            return static_loss
-    else:
-        def step():
-            draw()
-            return body()
+            def step(_i=0):
+                draw()
+                graph.replay()
+                return static_loss
+        else:
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                static_loss = fwd_bwd()
+            reducer.finish()                                 # (eager; completes the step the capture recorded)
+            with torch.cuda.graph(gb, pool=ga.pool()):
+                update()
 
-    for _ in range(args.warmup):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+            def step(_i=0):
+                draw()
+                ga.replay()
+                for b in reducer.buckets:                    # what zero_grad() re-arms on the host side
+                    b["launched"] = False
+                reducer.finish()                             # RCCL all-reduce of the flat buckets + 1/world scaling
+                gb.replay()
+                return static_loss
+
+    loss = None
+
+    def run(i):
+        nonlocal loss
+        loss = step(i)
+
+    elapsed = timed_region(run, args.steps, args.warmup, world, torch.cuda.synchronize)
     assert torch.isfinite(loss).all()
     if rank == 0:
         print(json.dumps({
@@ -305,8 +484,10 @@ def train_main(args):
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "stage-3 (configs/obj.yaml) training step, 1 clip per GPU, AdamW, clip-norm 1.0, "
-                                   "bucketed RCCL all-reduce of 152.5M fp32 Adapter gradients",
-                       "hip_graph": use_graph, "parallelism": f"dp{world}", "allreduce_bytes": sum(b["flat"].numel() * 4 for b in reducer.buckets)},
+                                   "bucketed RCCL all-reduce of the USED Adapter gradients (level 3 never receives one)",
+                       "hip_graph": mode, "parallelism": f"dp{world}", "allreduce_bytes": reducer.allreduce_bytes(),
+                       "grad_compress": args.grad_compress, "unused_params": sum(p.numel() for p in reducer.unused),
+                       "trained_params": sum(p.numel() for p in trainable)},
             "last_loss": float(loss)}), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -319,7 +500,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle step (no parity_rel_inf, no cpu_baseline)")
     ap.add_argument("--guidance", type=float, default=8.0)
     ap.add_argument("--autotune-log", default=None, help="write the per-shape GEMM/conv arm timings to this file")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
@@ -328,24 +509,25 @@ def main():
                          "gradient all-reduce + AdamW), 16x256x384 like configs/obj.yaml")
     ap.add_argument("--clip", default="16x256x384", help="train mode: frames x height x width of the clip "
                     "(16x256x384 = configs/obj.yaml; 32x512x512 = BASELINE configs[4] in bf16)")
+    ap.add_argument("--train-graph", default=None, choices=["one", "split", "none"],
+                    help="train mode: one HIP graph for the whole step (1 rank) | graph + all-reduce + graph | eager")
+    ap.add_argument("--grad-compress", default="none", choices=["none", "bf16"], help="train mode: gradient buckets on the wire")
+    ap.add_argument("--dry-run", action="store_true", help="CPU / gloo stub of the launcher + timing + JSON plumbing (tests)")
     args = ap.parse_args()
+    if args.dry_run:
+        return dry_run_main(args)
     if args.mode == "train":
         return train_main(args)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    ensure_ranks(args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs MI355X GPUs: the HIP path has no CPU fallback")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
-    if world != args.gpus and rank == 0:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    rank, local_rank, world = init_ranks("nccl", device)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
-    from synfmc_amd.data.dataset import to_plucker_embedding
     from synfmc_amd.models.pose_adaptor import features_to_video
     from synfmc_amd.pipelines.pipeline_animation_cm_om import _GraphedUNet
     from synfmc_amd.schedulers import DDIMScheduler
@@ -385,6 +567,7 @@ def main():
 
     latents = clip["latents"].to(device).float().contiguous()
     x_shape = (2,) + tuple(latents.shape[1:])
+    parity, cpu = None, None
     with torch.no_grad():
         runner = _GraphedUNet(unet, x_shape, text2, pose_feats, traj_feats, dtype)
         if args.no_graph:
@@ -395,43 +578,39 @@ def main():
             runner.capture()
             unet_step = runner
 
-        def denoise_step(lat, t):
-            x = torch.cat([lat, lat]).to(dtype)
+        # ---- parity gate: one step of THIS model on THESE inputs against the CPU oracle, before anything is timed
+        if rank == 0 and not args.no_cpu_baseline:
+            t_par = 801
+            eps_gpu = unet_step(torch.cat([latents, latents]).to(dtype), t_par).float().cpu()
+            try:
+                eps_ref, cpu = oracle_step(unet, enc, ada, clip, text2, clip["latents"].float(), t_par)
+                parity = float((eps_gpu - eps_ref).abs().max() / eps_ref.abs().max())
+                log(f"[rank 0] parity of the benchmarked model vs the CPU oracle: rel-inf {parity:.3e} ({args.dtype}); "
+                    f"oracle step {1.0 / cpu['value']:.1f} s")
+                if world > 1:
+                    cpu = None                              # the baseline is reported at N = 1 only
+            except Exception as e:                          # the checker must never take the GPU number down with it
+                cpu = {"error": repr(e)}
+        if world > 1:
+            dist.barrier()
+
+        def denoise_step(i):
+            nonlocal latents
+            t = ts[i % len(ts)]
+            x = torch.cat([latents, latents]).to(dtype)
             eps = unet_step(x, t)
-            return sched.step_cfg(eps, t, lat, args.guidance, True)
+            latents = sched.step_cfg(eps, t, latents, args.guidance, True)
 
         ts = sched._timesteps_host
-        for i in range(args.warmup):
-            latents = denoise_step(latents, ts[i % len(ts)])
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            latents = denoise_step(latents, ts[(args.warmup + i) % len(ts)])
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
+        elapsed = timed_region(denoise_step, args.steps, args.warmup, world, torch.cuda.synchronize)
     assert torch.isfinite(latents).all(), "non-finite latents"
 
-    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
-
     if rank == 0:
-        roof = measure_attention_roofline(device, dtype) if dtype == torch.bfloat16 else None
-        roof_conv = measure_conv_roofline(device, dtype) if dtype == torch.bfloat16 else None
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                cpu = cpu_baseline()
-            except Exception as e:  # the baseline must never take the GPU number down with it
-                cpu = {"error": repr(e)}
-        f_step = unet_flops(2, HEIGHT // 8, WIDTH // 8)
+        bf = dtype == torch.bfloat16
+        roof = measure_attention_roofline(device, dtype) if bf else None
+        roof_conv = measure_conv_roofline(device, dtype) if bf else None
+        roof_temp = measure_temporal_roofline(device, dtype) if bf else None
+        f_ref, f_exec = unet_flops(2, HEIGHT // 8, WIDTH // 8), unet_flops(2, HEIGHT // 8, WIDTH // 8, executed=True)
         ms = elapsed / args.steps * 1e3
         out = {
             "metric": "denoising steps/sec, 16x320x512 bf16 U-Net+CMC+OMC",
@@ -443,10 +622,14 @@ def main():
                                    "configs/obj.yaml shapes; 1 clip per GPU",
                        "frames": FRAMES, "height": HEIGHT, "width": WIDTH, "guidance_scale": args.guidance,
                        "hip_graph": not args.no_graph, "parallelism": f"dp{world} (independent clips, no collective)"},
-            "unet_tflop_per_step_reference_graph": round(f_step / 1e12, 3),
-            "effective_tflops_per_gpu": round(f_step / 1e12 / (ms * 1e-3), 1),
+            "parity_rel_inf": parity,
+            "parity_note": "max|eps_gpu - eps_oracle| / max|eps_oracle| for one CFG-batch-2 step (t = 801) of the benchmarked "
+                           "model: same weights (bf16-rounded), noise, text, camera poses, object masks; oracle = fp32 CPU",
+            "unet_tflop_per_step_executed": round(f_exec / 1e12, 3),
+            "unet_tflop_per_step_reference_graph": round(f_ref / 1e12, 3),
+            "executed_tflops_per_gpu": round(f_exec / 1e12 / (ms * 1e-3), 1),
             "conditioning_once_per_clip_ms": round(cond_ms, 2),
-            "roofline": roof, "roofline_conv": roof_conv, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_conv": roof_conv, "roofline_temporal": roof_temp, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
         if args.autotune_log:

@@ -82,11 +82,15 @@ def rasterize_objects(obj_info: Sequence[Sequence[np.ndarray]], obj_mask: Sequen
     return rearrange(feats, "b f h w c -> (b f) c h w"), rearrange(msk, "b f h w c -> (b f) c h w")
 
 
-def get_traj_features(obj_info, obj_mask, omcm, dtype=torch.float32) -> List[torch.Tensor]:
-    """`get_traj_features_v2` with `cfg_random_null_om=False` (the only value the trainer
-    passes, train_cam_obj_ctrl.py:843): rasterise -> Adapter -> 4 x `b c f h w`."""
+def get_traj_features(obj_info, obj_mask, omcm, dtype=torch.float32, null_clips=()) -> List[torch.Tensor]:
+    """`get_traj_features_v2`: rasterise -> Adapter -> 4 x `b c f h w`.  The trainer passes
+    `cfg_random_null_om=False` (train_cam_obj_ctrl.py:843); with it on, the clips the reference's coin flip drops
+    (`null_clips` here) get their 13-channel FEATURES zeroed while the Adapter still receives their real mask
+    (util.py:194-205) -- the null condition is `mask pyramid * Adapter(0)`, i.e. the propagated biases, not zero."""
     Fr = len(obj_info[0])
     feats, msk = rasterize_objects(obj_info, obj_mask, dtype)
+    for b in null_clips:
+        feats[b * Fr:(b + 1) * Fr] = 0
     return [rearrange(t, "(b f) c h w -> b c f h w", f=Fr) for t in omcm(feats, msk)]
 
 

@@ -9,7 +9,9 @@ Layout: activations are channels-last.  `[N, S, C]` "tokens" are what the kernel
 """
 from __future__ import annotations
 
+import atexit
 import math
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -586,11 +588,13 @@ _sk_ws = {}
 
 
 def _streamk_workspace(device):
-    """[4 KiB of flags | fp32 partial tiles] for the stream-K arms: zero on first use, handed back zeroed by the kernel"""
-    ws = _sk_ws.get(device.index)
+    """[4 KiB of flags | fp32 partial tiles] for the stream-K arms: zero on first use, handed back zeroed by the kernel.
+    One per (device, stream): two streams running stream-K launches at once must not share flags / partial slots."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _sk_ws.get(key)
     if ws is None:
         ws = torch.zeros((4096 + 1024 * 256 * 256 * 4) // 4, dtype=torch.float32, device=device)
-        _sk_ws[device.index] = ws
+        _sk_ws[key] = ws
     return ws.data_ptr(), ws.numel() * 4
 
 
@@ -707,7 +711,83 @@ def conv3x3_bf16(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias: Optional[t
 _choice = {}
 _tune_log = {}      # key -> {arm: ms} measured when the choice was made
 _calls = {}         # key -> eager calls seen (graph replays do not pass through Python)
-AUTOTUNE = True
+# FMC_AUTOTUNE=0: never time anything -- unseen shapes take the static rule (reproducible arm choice for tests / goldens:
+# split-K and stream-K arms change the summation order, so a timing-dependent choice changes low-order bits run to run)
+AUTOTUNE = os.environ.get("FMC_AUTOTUNE", "1") != "0"
+# The measured table persists on disk, keyed by the sha256 of the library build and the device name: a second process
+# (the next sampling run, every rank of a multi-GPU job) starts tuned and picks the SAME arms.  FMC_AUTOTUNE_CACHE=path
+# moves the file, FMC_AUTOTUNE_CACHE=0 disables persistence.
+_CACHE_ENV = os.environ.get("FMC_AUTOTUNE_CACHE", "")
+_cache_state = {"loaded": False, "dirty": False, "meta": None}
+
+
+def _cache_path():
+    if _CACHE_ENV == "0":
+        return None
+    return _CACHE_ENV or os.path.join(os.path.dirname(_lib.LIB_PATH), "autotune_cache.json")
+
+
+def _cache_meta():
+    if _cache_state["meta"] is None:
+        import hashlib
+        with open(_lib.LIB_PATH, "rb") as f:
+            sha = hashlib.sha256(f.read()).hexdigest()[:16]
+        _cache_state["meta"] = {"lib_sha16": sha, "device": torch.cuda.get_device_name() if torch.cuda.is_available() else "cpu",
+                                "arms": list(GEMM_TILES)}
+    return _cache_state["meta"]
+
+
+def load_autotune_table(path: Optional[str] = None) -> int:
+    """Read a persisted arm table (ignored unless it was made by this library build on this device type and with this arm
+    list).  Returns the number of shapes loaded.  Called lazily by the first front-end call."""
+    import ast
+    import json
+    _cache_state["loaded"] = True
+    path = path or _cache_path()
+    if not path or not os.path.isfile(path):
+        return 0
+    try:
+        with open(path) as f:
+            blob = json.load(f)
+        if blob.get("meta") != _cache_meta():
+            return 0
+        n = 0
+        for k, v in blob["choices"].items():
+            key = ast.literal_eval(k)
+            if key not in _choice:
+                _choice[key] = int(v["arm"])
+                _tune_log[key] = {int(a): ms for a, ms in v.get("ms", {}).items()}
+                n += 1
+        return n
+    except Exception:                              # a corrupt cache must never take the run down: re-tune
+        return 0
+
+
+def save_autotune_table(path: Optional[str] = None) -> Optional[str]:
+    """Write the arm table next to the library (atomic rename); rank 0 / single process only is the caller's business."""
+    import json
+    path = path or _cache_path()
+    if not path or not _choice:
+        return None
+    blob = {"meta": _cache_meta(),
+            "choices": {repr(k): {"arm": v, "ms": _tune_log.get(k, {})} for k, v in _choice.items()}}
+    tmp = f"{path}.{os.getpid()}.tmp"
+    try:
+        with open(tmp, "w") as f:
+            json.dump(blob, f)
+        os.replace(tmp, path)
+    except OSError:
+        return None
+    _cache_state["dirty"] = False
+    return path
+
+
+def _save_at_exit():
+    if _cache_state["dirty"] and os.environ.get("RANK", "0") == "0":
+        save_autotune_table()
+
+
+atexit.register(_save_at_exit)
 GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 11,     # 8..10 (4-stage rings) exist but never won on the FMC shapes
               128 + 2, 128 + 3)                 # stream-K (persistent workgroups) on the two 1-per-CU geometries     # fmc_linear_bf16 / fmc_conv3x3_bf16 `tile` arms tried per shape
 
@@ -752,6 +832,8 @@ def _time_ms(fn, reps=8):
 
 def _pick(key, hip_fn, lib_fn, static_hip: bool, extra_arms=()) -> int:
     """0 = vendor library arm, 1..6 = fused gfx950 kernel with that tile geometry (`hip_fn(tile)`)."""
+    if not _cache_state["loaded"]:
+        load_autotune_table()
     use = _choice.get(key)
     _calls[key] = _calls.get(key, 0) + 1
     if use is None:
@@ -761,6 +843,7 @@ def _pick(key, hip_fn, lib_fn, static_hip: bool, extra_arms=()) -> int:
         use = min(times)[1]
         _choice[key] = use
         _tune_log[key] = {arm: round(ms, 4) for ms, arm in times}
+        _cache_state["dirty"] = True
     return use
 
 

@@ -150,6 +150,12 @@ class _DownBlock(_Block3D):
             outs += (_frames_back(x4, b, f),)
         if traj_features is not None:                      # modified_modules.py:115-117 / 172-174
             t = traj_features[self.traj_fea_idx]
+            hb = outs[-1].shape[0]
+            if tuple(t.shape[1:]) != tuple(outs[-1].shape[1:]) or t.shape[0] not in (hb, hb // 2) or (t.shape[0] != hb and hb % 2):
+                # the reference's `hidden_states + traj_features[idx]` raises on such a mismatch; here the features may cover
+                # the whole batch or exactly its conditioned (second) half under classifier-free guidance -- nothing else
+                raise ValueError(f"traj_features[{self.traj_fea_idx}] of shape {tuple(t.shape)} does not match hidden states "
+                                 f"{tuple(outs[-1].shape)} (batch must equal {hb}, or {hb // 2} = the conditioned CFG half)")
             h5 = outs[-1].permute(0, 2, 3, 4, 1)           # [B, F, h, w, C] storage order, contiguous
             t5 = t.permute(0, 2, 3, 4, 1)
             if not t5.is_contiguous():

@@ -105,8 +105,9 @@ class AnimationPipeline:
     vae_scale_factor = 8
 
     def __init__(self, vae, text_encoder, tokenizer, unet, scheduler):
+        from ..schedulers import coerce_scheduler
         self.vae, self.text_encoder, self.tokenizer = vae, text_encoder, tokenizer
-        self.unet, self.scheduler = unet, scheduler
+        self.unet, self.scheduler = unet, coerce_scheduler(scheduler)       # accepts a diffusers.DDIMScheduler as well
         self._runners = {}
 
     # ---- pieces outside the metric ------------------------------------------------------------------

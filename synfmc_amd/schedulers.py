@@ -89,3 +89,24 @@ class DDIMScheduler:
         x = sample.float().contiguous()
         out = self.step_cfg(model_output.to(torch.float32).contiguous(), int(timestep), x, 1.0, False)
         return DDIMSchedulerOutput(out.to(sample.dtype))
+
+
+def coerce_scheduler(scheduler):
+    """The reference's trainers hand the pipelines a `diffusers.DDIMScheduler` (train_cam_obj_ctrl.py:231, :497); the
+    loops here call `step_cfg` (the fused CFG + DDIM kernel).  A foreign scheduler object is therefore re-expressed as this
+    module's `DDIMScheduler` from its `.config` (same betas, offset and spacing); anything that is not a DDIM
+    configuration this path implements raises here rather than producing other numbers."""
+    if scheduler is None or hasattr(scheduler, "step_cfg"):
+        return scheduler
+    cfg = getattr(scheduler, "config", None)
+    if cfg is None:
+        raise TypeError(f"cannot use {type(scheduler).__name__} as the DDIM scheduler of the FMC pipelines")
+    get = (lambda k, d=None: cfg.get(k, d)) if hasattr(cfg, "get") else (lambda k, d=None: getattr(cfg, k, d))
+    if "DDIM" not in type(scheduler).__name__:
+        raise NotImplementedError(f"{type(scheduler).__name__}: the FMC pipelines are built for DDIMScheduler (configs/*.yaml)")
+    return DDIMScheduler(num_train_timesteps=get("num_train_timesteps", 1000), beta_start=get("beta_start", 0.0001),
+                         beta_end=get("beta_end", 0.02), beta_schedule=get("beta_schedule", "linear"),
+                         trained_betas=get("trained_betas"), clip_sample=get("clip_sample", True),
+                         set_alpha_to_one=get("set_alpha_to_one", True), steps_offset=get("steps_offset", 0),
+                         prediction_type=get("prediction_type", "epsilon"), thresholding=get("thresholding", False),
+                         timestep_spacing=get("timestep_spacing", "leading"))

@@ -39,11 +39,14 @@ def get_traj_features_v2(obj_info_list_list, obj_mask_list_list, omcm, cfg_rando
     B, Fr = len(obj_info_list_list), len(obj_info_list_list[0])
     device = torch.device("cuda", local_rank) if isinstance(local_rank, int) else torch.device(local_rank)
     poses, masks = stack_object_inputs(obj_info_list_list, obj_mask_list_list, device)
-    if cfg_random_null_om:                       # util.py:196-199: drop a clip's object condition at random
-        for i in range(B):
-            if not (random.random() > cfg_random_null_om_ratio):
-                masks[i * Fr:(i + 1) * Fr] = 0
     # a 3-D mask tells `Adapter.forward` that the features are already PixelUnshuffled + channels-last; calling
     # `omcm(...)` (not `omcm.module`) keeps DistributedDataParallel's forward hooks in the loop
     feats, mask = K.omc_rasterize(poses, masks, "unshuffle8", dtype)
+    if cfg_random_null_om:
+        # util.py:194-199: a dropped clip loses its 13-channel FEATURES only; the Adapter still receives its real mask, so
+        # the null condition is `mask pyramid * Adapter(0)` (the conv biases propagated), not zero
+        fv = feats.view(B, Fr, *feats.shape[1:])
+        for i in range(B):
+            if not (random.random() > cfg_random_null_om_ratio):
+                fv[i].zero_()
     return features_to_video(omcm(feats, mask), B)

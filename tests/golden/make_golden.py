@@ -169,6 +169,13 @@ def main():
                         raster=tap.x.numpy(), raster_mask=tap.m.numpy(),
                         **{f"feat_{i}": t.numpy() for i, t in enumerate(feats)})
 
+    # G3b: the classifier-free "null object condition" branch (util.py:194-199) with ratio 1.0 -> every clip dropped: the
+    # features are zeroed but the Adapter still gets the real mask
+    with torch.no_grad():
+        feats_null = get_traj_features_v2(infos, masks, ad, True, 1.0, [False], "cpu", torch.float32)
+    np.savez_compressed(os.path.join(HERE, "g3_traj_null.npz"),
+                        **{f"feat_{i}": t.numpy() for i, t in enumerate(feats_null)})
+
     # ---- G4: relative camera poses -------------------------------------------
     abs_rt = torch.from_numpy(smooth_c2w(1, 6, 41)[0][:, :3]).double()
     abs_rt[:, :, 3] *= 300.0

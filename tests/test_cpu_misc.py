@@ -246,3 +246,116 @@ def test_loss_and_timestep_sampling_match_oracle():
     t = biased_timesteps(20000, 1000, 700, 0.8, "cpu", torch.Generator().manual_seed(1))
     frac_hi = (t >= 700).float().mean().item()
     assert abs(frac_hi - 0.8) < 0.02 and int(t.min()) >= 0 and int(t.max()) < 1000
+
+
+_OVERLAY_WORKER = r'''
+import ast, sys, types, json
+sys.dont_write_bytecode = True
+root, ref = sys.argv[1], sys.argv[2]
+sys.path.insert(0, root)
+# third-party packages the trainers / the reference's data + logging modules import that this container lacks: inert stubs
+# (the user's environment has the real ones).  Nothing below stubs any `fmc` module.
+def stub(name, **attrs):
+    m = types.ModuleType(name); m.__dict__.update(attrs); sys.modules[name] = m
+    parent, _, leaf = name.rpartition(".")
+    if parent and parent in sys.modules: setattr(sys.modules[parent], leaf, m)
+    return m
+for name in ("decord", "cv2", "imageio", "nltk", "nltk.stem", "torchvision", "torchvision.transforms",
+             "torchvision.transforms.functional", "termcolor", "omegaconf"):
+    if name not in sys.modules:
+        try:
+            __import__(name)
+        except Exception:
+            stub(name)
+sys.modules["decord"].__dict__.setdefault("VideoReader", object); sys.modules["decord"].__dict__.setdefault("cpu", lambda *a, **k: None)
+sys.modules["nltk.stem"].__dict__.setdefault("WordNetLemmatizer", object); sys.modules["nltk.stem"].__dict__.setdefault("PorterStemmer", object)
+sys.modules["termcolor"].__dict__.setdefault("colored", lambda s, *a, **k: s)
+class _DDIM:                                                 # what `from diffusers import DDIMScheduler` yields in the trainers
+    def __init__(self, **kw):
+        self.config = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                           clip_sample=True, steps_offset=0, set_alpha_to_one=True, prediction_type="epsilon",
+                           timestep_spacing="leading"); self.config.update(kw)
+_DDIM.__name__ = "DDIMScheduler"
+stub("diffusers", AutoencoderKL=object, DDIMScheduler=_DDIM)
+stub("diffusers.optimization", get_scheduler=lambda *a, **k: None)
+stub("diffusers.utils", check_min_version=lambda v: None)
+stub("diffusers.models"); stub("diffusers.models.attention_processor", AttnProcessor=object)
+
+import synfmc_amd
+mode = synfmc_amd.install_as_fmc(ref)
+ns, done = {}, []
+for trainer in ("train_cam_obj_ctrl.py", "train_cam_ctrl.py"):
+    tree = ast.parse(open(f"{ref}/{trainer}").read())
+    for node in tree.body:                                   # the trainers' own top-level `from fmc... import ...` lines
+        if isinstance(node, ast.ImportFrom) and node.module and node.module.split(".")[0] == "fmc":
+            exec(compile(ast.Module([node], []), trainer, "exec"), ns)
+            done.append(f"{trainer}:{node.lineno}")
+import fmc.data.dataset, fmc.util, fmc.utils.util, fmc.data.utils
+out = {"mode": mode, "n_lines": len(done),
+       "unet": ns["UNet3DConditionModelCamObjCond"].__module__, "posecond": ns["UNet3DConditionModelPoseCond"].__module__,
+       "pipe": ns["CameraObjCtrlPipeline"].__module__, "pipe_cam": ns["CameraCtrlPipeline"].__module__,
+       "adapter": ns["Adapter"].__module__, "encoder": ns["CameraPoseEncoder"].__module__,
+       "wrapper": ns["CamObjPoseAdaptor"].__module__, "patch_fn": ns["Adapted_CrossAttnDownBlock3D_forward"].__module__,
+       "ray_condition": ns["ray_condition"].__module__, "traj": ns["get_traj_features_v2"].__module__,
+       "dataset_cls": ns["UnrealTrajVideoDataset"].__module__, "dataset_file": fmc.data.dataset.__file__,
+       "logger": ns["setup_logger"].__module__, "logger_file": fmc.utils.util.__file__,
+       "abs_matrix": ns["create_absolute_matrix_from_ref_cam_list"].__module__,
+       "kept_reference_fn": fmc.data.dataset._reference_ray_condition.__module__}
+# a diffusers-style scheduler object handed to the pipeline constructor is re-expressed as the native one
+from synfmc_amd.schedulers import DDIMScheduler
+pipe = ns["CameraObjCtrlPipeline"](None, None, None, None, _DDIM(beta_start=0.00085, beta_end=0.012, steps_offset=1,
+                                                               clip_sample=False), None)
+out["sched"] = [type(pipe.scheduler).__module__, pipe.scheduler.config.steps_offset, float(pipe.scheduler.betas[0])]
+print(json.dumps(out))
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/fmc"), reason="build container only: needs the reference checkout")
+def test_install_as_fmc_overlays_the_reference_package():
+    """`install_as_fmc(reference_root)`: every `from fmc... import ...` line of the two trainers resolves -- hot-path names
+    to this package, dataset classes / logging / pose math to the reference's own modules, with `ray_condition` and
+    `get_traj_features_v2` patched into them.  Runs in a subprocess (it rewires `sys.modules`); only third-party packages
+    missing from this container are stubbed, no `fmc` module is."""
+    import json
+    out = subprocess.run([sys.executable, "-c", _OVERLAY_WORKER, ROOT, "/root/reference"], capture_output=True, text=True,
+                         timeout=300, env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["mode"] == "overlay" and r["n_lines"] >= 17
+    for k in ("unet", "posecond", "pipe", "pipe_cam", "adapter", "encoder", "wrapper", "patch_fn", "ray_condition", "traj"):
+        assert r[k].startswith("synfmc_amd."), (k, r[k])
+    for k in ("dataset_cls", "logger", "abs_matrix", "kept_reference_fn"):
+        assert r[k].startswith("fmc."), (k, r[k])
+    assert r["dataset_file"].startswith("/root/reference/") and r["logger_file"].startswith("/root/reference/")
+    assert r["sched"][0] == "synfmc_amd.schedulers" and r["sched"][1] == 1 and abs(r["sched"][2] - 0.00085) < 1e-9
+
+
+def test_install_as_fmc_standalone_mode():
+    """Without a reference checkout on the path the package itself answers to `fmc` for the hot-path modules."""
+    code = ("import sys; sys.path.insert(0, sys.argv[1]); import synfmc_amd; m = synfmc_amd.install_as_fmc(); "
+            "from fmc.models.unet_cam_obj import UNet3DConditionModelCamObjCond as U; from fmc.adapter import Adapter; "
+            "from fmc.data.dataset import ray_condition; from fmc.util import get_traj_features_v2; print(m, U.__module__)")
+    out = subprocess.run([sys.executable, "-c", code, ROOT], capture_output=True, text=True, timeout=300, cwd="/tmp")
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[-2:] == ["standalone", "synfmc_amd.models.unet"]
+
+
+def test_bench_entry_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must become 2 ranks (re-exec under torch.distributed.run),
+    rendezvous on 127.0.0.1, time with barrier + max-over-ranks and print ONE JSON line whose `n_gpus` is the world size a
+    collective returned.  `--dry-run` swaps the model for a CPU stub and RCCL for gloo; the launcher / timing / JSON code is
+    the one the GPU runs use.  A WORLD_SIZE that disagrees with --gpus is an error."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "4",
+                          "--warmup", "1"], capture_output=True, text=True, env=env, timeout=300, cwd="/tmp")
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = lines[0]
+    assert r["n_gpus"] == 2 and r["steps"] == 4 and r["warmup"] == 1 and r["dry_run"] is True and r["scaling"] == "weak"
+    assert abs(r["value"] - 2 * 4 / (r["ms_per_step"] * 4e-3)) / r["value"] < 1e-2          # whole-job aggregate
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True,
+                         text=True, env=dict(env, WORLD_SIZE="3", RANK="0"), timeout=120, cwd="/tmp")
+    assert bad.returncode != 0 and "WORLD_SIZE=3" in (bad.stderr + bad.stdout)

@@ -279,6 +279,24 @@ def test_rasterize_against_golden(K, golden_dir):
     assert float(f0.abs().max()) == 0.0 and float(m0.abs().max()) == 0.0
 
 
+def test_get_traj_features_null_condition_against_reference_golden(K, golden_dir):
+    """`get_traj_features_v2(..., cfg_random_null_om=True, ratio)` on the GPU path against the reference's own outputs:
+    kept clip = golden G3, dropped clip = golden G3b (zero features, REAL mask -> the Adapter's propagated biases)."""
+    import os
+    from synfmc_amd.util import get_traj_features_v2
+    from tests.test_host_logic import _product_small_adapter
+    g, gn = np.load(os.path.join(golden_dir, "g3_traj.npz")), np.load(os.path.join(golden_dir, "g3_traj_null.npz"))
+    masks = [[torch.from_numpy(g["masks"][b, f]) for f in range(g["masks"].shape[1])] for b in range(g["masks"].shape[0])]
+    infos = [[g["infos"][b, f] for f in range(g["infos"].shape[1])] for b in range(g["infos"].shape[0])]
+    ad = _product_small_adapter(golden_dir, "cuda")
+    with torch.no_grad():
+        kept = get_traj_features_v2(infos, masks, ad, True, 0.0, [False], 0, torch.float32)
+        null = get_traj_features_v2(infos, masks, ad, True, 1.0, [False], 0, torch.float32)
+    for i in range(4):
+        assert rel_inf(kept[i], torch.from_numpy(g[f"feat_{i}"])) < 1e-4
+        assert rel_inf(null[i], torch.from_numpy(gn[f"feat_{i}"])) < 1e-4
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_mask_modulate_cascade(K, dtype):
     N, H, W = 3, 64, 96

@@ -220,3 +220,47 @@ def test_lora_pose_adaptor_processor_plumbing(stack, fake):
         out = pu(clip["latents"], stack["t"], clip["text"], pose_embedding_features=pose_feats,
                  traj_features=stack["traj"]).sample
     assert rel_inf(out, ref) < 1e-3
+
+
+def _product_small_adapter(golden_dir, device="cpu"):
+    import os
+    import numpy as np
+    from synfmc_amd.adapter import Adapter
+    g2 = np.load(os.path.join(golden_dir, "g2_adapter_small.npz"))
+    ad = Adapter(channels=[16, 32, 64, 64], nums_rb=2, cin=832, sk=True, use_conv=False, use_pre_zero_conv=True,
+                 use_post_zero_conv=True).eval()
+    ad.load_state_dict({k[4:]: torch.from_numpy(g2[k]) for k in g2.files if k.startswith("sd::")}, strict=True)
+    return ad.to(device)
+
+
+def test_get_traj_features_null_condition_matches_reference(golden_dir, fake):
+    """`cfg_random_null_om=True` (util.py:194-199): a dropped clip's FEATURES are zeroed, its mask still reaches the Adapter,
+    so the result is the mask pyramid times the propagated biases -- against the reference's own output (golden G3b)."""
+    import os
+    import numpy as np
+    from synfmc_amd.util import get_traj_features_v2
+    g, gn = np.load(os.path.join(golden_dir, "g3_traj.npz")), np.load(os.path.join(golden_dir, "g3_traj_null.npz"))
+    masks = [[torch.from_numpy(g["masks"][b, f]) for f in range(g["masks"].shape[1])] for b in range(g["masks"].shape[0])]
+    infos = [[g["infos"][b, f] for f in range(g["infos"].shape[1])] for b in range(g["infos"].shape[0])]
+    ad = _product_small_adapter(golden_dir)
+    with torch.no_grad():
+        kept = get_traj_features_v2(infos, masks, ad, True, 0.0, [False], "cpu", torch.float32)     # ratio 0: never dropped
+        null = get_traj_features_v2(infos, masks, ad, True, 1.0, [False], "cpu", torch.float32)     # ratio 1: always dropped
+    for i in range(4):
+        assert rel_inf(kept[i], torch.from_numpy(g[f"feat_{i}"])) < 1e-4
+        assert i > 0 or float(np.abs(gn[f"feat_{i}"]).max()) > 0      # (level 3 is one pixel whose nearest mask sample is 0)
+        assert rel_inf(null[i], torch.from_numpy(gn[f"feat_{i}"])) < 1e-4
+
+
+def test_traj_feature_batch_mismatch_raises(stack, fake):
+    """OMC features must cover the whole batch or exactly the conditioned CFG half; anything else raised in the reference
+    (`hidden_states + traj_features[idx]`) and must not be silently added to the trailing clips here."""
+    pu, pe, pa = CM.build_product(stack["ou"], stack["oe"], stack["oa"], W4, cross_dim=32, device="cpu")
+    clip = stack["clip"]
+    x3 = clip["latents"].repeat(3, 1, 1, 1, 1)
+    pf3 = [p.repeat(3, 1, 1, 1, 1) for p in stack["pose_feats"]]
+    with pytest.raises(ValueError, match="conditioned CFG half"):
+        pu(x3, stack["t"], clip["text"].repeat(3, 1, 1), pose_embedding_features=pf3, traj_features=stack["traj"])
+    bad = [t[:, :, :, :-1] for t in stack["traj"]]
+    with pytest.raises(ValueError, match="does not match"):
+        pu(clip["latents"], stack["t"], clip["text"], pose_embedding_features=stack["pose_feats"], traj_features=bad)

@@ -80,6 +80,13 @@ def test_g3_rasterise_and_traj_features(golden_dir):
     for i in range(4):
         assert out[i].shape == g[f"feat_{i}"].shape
         assert rel_inf(out[i], g[f"feat_{i}"]) < 1e-5
+    # G3b: cfg_random_null_om=True with ratio 1.0 (every clip dropped): zero features, REAL mask -> non-zero output
+    gn = np.load(os.path.join(golden_dir, "g3_traj_null.npz"))
+    with torch.no_grad():
+        out_null = C.get_traj_features(infos, masks, ad, null_clips=range(len(infos)))
+    for i in range(4):
+        assert i > 0 or float(np.abs(gn[f"feat_{i}"]).max()) > 0      # (level 3 is one pixel whose nearest mask sample is 0)
+        assert rel_inf(out_null[i], gn[f"feat_{i}"]) < 1e-5
 
 
 def test_g4_relative_pose(golden_dir):
