@@ -190,7 +190,10 @@ int fmc_cfg_ddim_step(const void* eps_uc, const float* x, float* x_out, int64_t 
  *   64-deep k-tiles in a 2-stage LDS ring; 4..6 = the same three with 32-deep k-tiles (half the LDS, twice the
  *   workgroups per CU); 7 = 256x128, 64-deep, 3 stages; 8 / 9 / 10 = 256x256 / 128x128 / 256x128, 32-deep, 4 stages
  *   (deeper rings keep more bytes in flight per CU); 11 = 128x320 (10 waves; spans N = 320 / 640 / 960 without padded
- *   columns).  Every arm computes the same function, bit for bit (callers may time them and keep
+ *   columns); 12 = 128x320, 32-deep, 4 stages; 13 / 14 = the 8-phase 256x256 kernel (8 waves of 128x64, the two wave rows
+ *   one barrier apart so each SIMD always has one wave on the matrix pipe and one loading; operands by half-tile
+ *   `buffer_load ... lds` with a counted vmcnt, 4 / 5 half-tiles ahead; falls back to 3 for a two-source A operand or
+ *   operands beyond 2 GiB).  Every arm computes the same function, bit for bit (callers may time them and keep
  *   the fastest).
  *   split_k > 1 (epilogue 0 only): the k-tiles of every output tile are dealt to split_k workgroups that write fp32
  *   partial sums to `workspace` (>= split_k * M * N * 4 bytes, 16-byte aligned, caller-owned scratch); a second kernel

@@ -32,6 +32,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -59,6 +60,7 @@ struct GemmParams {
     int sk;                           // stream-K: grid = sk persistent workgroups (a multiple of 8), each owning a
     int* sk_flags;                    //   contiguous range of (tile, k-tile) iterations; ws[block][BM][BN] partials
     int64_t sk_ws_bytes;
+    int64_t a_bytes;                  // 8-phase kernel: size of the A operand in bytes (buffer descriptor range)
 };
 
 // Launch-order index -> output tile.  Inside a group of `group_m` m-tiles the order is n-outer / m-inner, so the C
@@ -684,6 +686,489 @@ void gemm_kernel(const GemmParams P) {
     }  // segment loop
 }
 
+// =====================================================================================================================
+// The 8-phase 256x256 kernel (tile arms 13 / 14): 8 waves (2 along M x 4 along N), every wave a 128 x 64 output block as
+// 2 x 4 v_mfma_f32_32x32x16_bf16 accumulators (128 accumulator registers), BK = 64, TWO k-tile buffers in LDS.
+//
+// What differs from gemm_kernel above (whose 16-wave 256x256 tile re-reads every fragment by 4 waves -- the LDS port was its
+// bound, DESIGN.md section 5 -- and whose waves all load, wait, compute in lockstep):
+//   * a k-tile is FOUR phases; a phase = {LOAD: the ds_read_b128s of the fragments this phase needs + the LDS-DMA issue of one
+//     half-tile of a LATER k-tile + a counted vmcnt} | barrier | {8 MFMAs = one quadrant (64 rows x 32 columns) of the wave's
+//     block over the whole 64-deep k-tile, under s_setprio 1} | barrier;
+//   * the two wave rows run ONE BARRIER APART (wave row 1 passes an extra barrier before the loop, wave row 0 one after it): in
+//     every inter-barrier segment one wave of each SIMD issues MFMAs while the other wave of that SIMD does its LDS reads /
+//     DMA issue / waiting -- the matrix pipe never waits for a fragment;
+//   * operands are DMA'd in half-tiles ordered by first use -- A early rows (the first 64 of each wave row's 128), W early
+//     rows (the first 32 of each wave column's 64), W late, A late -- PF half-tiles ahead of their first read, never drained:
+//     `s_waitcnt vmcnt(2 (PF - 2))` at the end of LOAD(g) retires exactly what LOAD(g + 1) reads, the barrier after it
+//     publishes it (a wave reads DMA'd data one phase AFTER the wait that retired it, CDNA4 guide section 5); past the end of
+//     K the issue slot sends a dummy KiB to a scratch area so the count stays exact;
+//   * fragments per wave and k-tile: 16 A + 8 W ds_read_b128 (24 KiB) instead of 2 x 16 KiB x 4 re-reads.
+// WAR: slot(h) is re-filled at LOAD(h - PF); its previous content (h - 8) was last read at LOAD(h - 8) of the LATER wave row,
+// retired by that row's lgkmcnt(0) one segment on: safe for PF <= 6.
+template <int MODE, int EPI, int PF, bool SK>
+__global__ __launch_bounds__(512, 2)
+void gemm8_kernel(const GemmParams P) {
+    constexpr int BM = 256, BN = 256, BK = 64, NT = 512;
+    constexpr int STAGE_ELEMS = (BM + BN) * BK;      // 64 KiB per k-tile buffer
+    constexpr int VMW = 2 * (PF - 2);                // DMA instructions that may stay in flight at the end of a LOAD part
+    static_assert(PF >= 3 && PF <= 6, "prefetch distance (half-tiles)");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int nkt = P.K / BK;
+    // stream-K (SK): P.sk persistent workgroups (one per CU); the (tile, k-tile) iteration space of every XCD group is cut
+    // into equal contiguous ranges -- the index arithmetic, the hand-over protocol (owner = holder of a tile's FIRST k-tiles,
+    // reached at the END of its range; the other shares are produced at the START of theirs; sc0 sc1 payload + relaxed
+    // agent-scope flags; a workgroup only ever waits for lower block ids) are gemm_kernel's.  What differs: the fp32
+    // partials travel in ACCUMULATOR layout (slot[wave][register quad][lane] x 16 B: every store / load instruction moves one
+    // contiguous KiB), because producer and owner are the same code with the same lane <-> element map -- no LDS round.
+    int64_t sk_it = 0, sk_end = 0, sk_gbase = 0, sk_I = 0;
+    int sk_r = 0, sk_per = 1;
+    if (SK) {
+        const int T = P.tiles_m * P.tiles_n, x = blockIdx.x & 7, q = blockIdx.x >> 3;
+        sk_per = P.sk >> 3;
+        const int tg0 = (int)((int64_t)T * x / 8), tg1 = (int)((int64_t)T * (x + 1) / 8);
+        sk_gbase = (int64_t)tg0 * nkt;
+        sk_I = (int64_t)(tg1 - tg0) * nkt;
+        sk_r = sk_per - 1 - q;
+        sk_it = sk_gbase + sk_I * sk_r / sk_per;
+        sk_end = sk_gbase + sk_I * (sk_r + 1) / sk_per;
+    }
+    const __amdgpu_buffer_rsrc_t rsP = sk_rsrc(P.ws);
+    f32x16 acc[2][4];                                 // [ni][mi]: rows = n (registers), cols = m (lanes); zeroed right before the k loop
+    bf16x8 wf[2][4], af[2][4];                        // W fragments of both 32-column halves; A fragments of the current 64-row half
+    for (;;) {                                       // one pass per segment (exactly one without stream-K)
+    // Every per-lane index of a segment derives from a thread id the optimiser cannot see through: otherwise LICM hoists the
+    // whole epilogue's address arithmetic out of the persistent loop, keeps ~300 values alive across the main loop and
+    // spills them (the stream-K instantiations then need scratch memory, which costs ~30 us per LAUNCH).
+    int tid = threadIdx.x;
+    if (SK) asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int prow = lane >> 3, pch = lane & 7;      // my row / 16-byte chunk inside a 1-KiB DMA piece (8 rows x 128 B)
+    int tile_m, tile_n, kt0 = 0, nk = nkt, sk_np = 0;
+    bool sk_partial = false;
+    if (SK) {
+        if (sk_it >= sk_end) break;
+        const int lin = (int)(sk_it / nkt);
+        kt0 = (int)(sk_it - (int64_t)lin * nkt);
+        nk = (int)min((int64_t)nkt, kt0 + (sk_end - sk_it));
+        sk_it += nk - kt0;
+        lin_to_tile(lin, P, tile_m, tile_n);
+        sk_partial = kt0 > 0;
+        if (kt0 == 0 && nk < nkt) {                   // I hold the head of a cut tile: who holds the rest?
+            const int64_t tile_end = (int64_t)(lin + 1) * nkt;
+            int64_t e = sk_end;
+            while (e < tile_end) {
+                ++sk_np;
+                e = sk_gbase + sk_I * (sk_r + 1 + sk_np) / sk_per;
+            }
+        }
+    } else {
+        const int total = P.tiles_m * P.tiles_n;
+        const int id = blockIdx.x, q = total >> 3, r = total & 7, x = id & 7;
+        const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);   // XCD x owns a contiguous range
+        lin_to_tile(lin, P, tile_m, tile_n);
+    }
+    const int64_t m0 = (int64_t)tile_m * BM;
+    const int n0 = tile_n * BN;
+    // half-tiles stream in the order h = 4 t + {0: A early, 1: W early, 2: W late, 3: A late}
+
+    // ---- my DMA pieces: every half-tile is 16 pieces of 8 rows; wave w moves pieces u = 2w, 2w + 1 of each -----------------
+    // A piece u of (early | late): rows (u >> 3) * 128 + late * 64 + (u & 7) * 8 ..;  W piece u: rows (u >> 2) * 64 + late * 32 + (u & 3) * 8 ..
+    // The DMAs are BUFFER loads (`buffer_load_dwordx4 v_off, s[rsrc], s_off offen lds`): the per-lane byte offset of my
+    // (row, swizzled chunk) is loop invariant, the k position is a scalar offset, rows beyond M / N carry an offset
+    // beyond the descriptor's size and read as zeros -- no 64-bit address arithmetic, no zero page, no branch in the loop
+    // (an LDS-DMA piece costs its wave 60-185 cycles of issue time; what surrounds it is what can be saved).
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)P.a, 0, (int)P.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)P.w, 0, (int)((int64_t)P.N * P.K * 2), 0x00020000);
+    unsigned a_vo[4];                                // [late * 2 + i]: byte offset of my row start (token) / pixel (conv) + chunk; OOB = row beyond M
+    unsigned a_ok[4];                                // conv: bit t = tap t of my pixel lies inside the image; (ups == 1: (y << 16) | x instead)
+    unsigned w_vo[4];
+    int a_lds[4], w_lds[4];                          // wave-uniform LDS element offsets of the pieces inside a buffer
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int late = e >> 1, u = 2 * wave + (e & 1);
+        const int rowa = (u >> 3) * 128 + late * 64 + (u & 7) * 8;
+        a_lds[e] = rowa * BK;
+        const int lr = rowa + prow;
+        const int sc = swz<BK>(lr, pch);
+        const int64_t m = m0 + lr;
+        const bool ok = m < P.M;
+        a_ok[e] = 0;
+        if (MODE == 0) {
+            a_vo[e] = ok ? (unsigned)((m * P.lda + sc * 8) * 2) : OOB;
+        } else {
+            const int64_t mm = ok ? m : 0;
+            const int pix = (int)(mm % P.hw);
+            const int py = pix / P.img_w, px = pix - py * P.img_w;
+            const int64_t img = mm / P.hw;
+            if (P.ups == 1) {                         // half-resolution source: the tap's source pixel is computed per tap
+                a_vo[e] = ok ? (unsigned)((img * (int64_t)(P.hw >> 2) * P.cin + sc * 8) * 2) : OOB;
+                a_ok[e] = ((unsigned)py << 16) | (unsigned)px;
+            } else {
+                unsigned mask = 0;
+                for (int t = 0; t < 9; ++t) {
+                    const int dy = t / 3 - 1, dx = t % 3 - 1;
+                    const bool in = P.ups == 2 ? (2 * py + dy >= 0 && 2 * px + dx >= 0)      // (the high side is always inside)
+                                               : ((unsigned)(py + dy) < (unsigned)P.img_h && (unsigned)(px + dx) < (unsigned)P.img_w);
+                    mask |= (unsigned)in << t;
+                }
+                a_ok[e] = ok ? mask : 0u;
+                if (P.ups == 2) a_vo[e] = (unsigned)(((img * (int64_t)(P.hw << 2) + (int64_t)(2 * py) * (2 * P.img_w) + 2 * px) * P.cin + sc * 8) * 2);
+                else a_vo[e] = (unsigned)((mm * P.cin + sc * 8) * 2);
+            }
+        }
+        const int roww = (u >> 2) * 64 + late * 32 + (u & 3) * 8;
+        w_lds[e] = (BM + roww) * BK;
+        const int lw = roww + prow;
+        const int n = n0 + lw;
+        w_vo[e] = n < P.N ? (unsigned)(((int64_t)n * P.K + swz<BK>(lw, pch) * 8) * 2) : OOB;
+    }
+    // the k-tile the NEXT issue belongs to (scalars, advanced after its fourth half-tile; past the end of the k range the stream
+    // wraps to its first k-tile: the re-fetched data lands in a slot nobody reads any more, the addresses stay valid and the DMA
+    // count exact)
+    int it_kt = kt0, it_buf = 0, it_tap = 0, it_ci0 = 0;
+    auto seek = [&](int kt) {                         // (conv: k-tile -> (tap, channel chunk); one division per segment)
+        it_kt = kt;
+        if (MODE == 1) {
+            if (P.tap_outer) {
+                it_tap = kt * BK / P.cin;
+                it_ci0 = kt * BK - it_tap * P.cin;
+            } else {
+                const int chunk = kt / 9;
+                it_tap = kt - chunk * 9;
+                it_ci0 = chunk * BK;
+            }
+        }
+    };
+    seek(kt0);
+    auto advance = [&]() {
+        it_buf ^= 1;
+        if (++it_kt == nk) {                          // past the end of my k range: wrap to its first k-tile
+            seek(kt0);
+        } else if (MODE == 1) {
+            if (P.tap_outer) {
+                it_ci0 += BK;
+                if (it_ci0 == P.cin) { it_ci0 = 0; ++it_tap; }
+            } else if (++it_tap == 9) {               // (channel chunk outer, tap inner), see gemm_kernel
+                it_tap = 0;
+                it_ci0 += BK;
+            }
+        }
+    };
+    auto dma = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned voff, int soff, bf16_t* lds) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, (int)voff, soff, 0, 0);
+    };
+    auto issue = [&](int q) {                         // q: 0 = A early, 1 = W early, 2 = W late, 3 = A late (a constant at every call site)
+        bf16_t* stage = smem + it_buf * STAGE_ELEMS;
+        if (q == 1 || q == 2) {
+            const int e0 = (q - 1) * 2;
+            const int soff = (MODE == 1 ? it_tap * P.cin + it_ci0 : it_kt * BK) * 2;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) dma(rsW, w_vo[e0 + i], soff, stage + w_lds[e0 + i]);
+        } else {
+            const int e0 = q == 0 ? 0 : 2;
+            if (MODE == 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) dma(rsA, a_vo[e0 + i], it_kt * BK * 2, stage + a_lds[e0 + i]);
+            } else {
+                const int dy = (it_tap >= 3) + (it_tap >= 6) - 1, dx = it_tap - 3 * (dy + 1) - 1;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int e = e0 + i;
+                    unsigned vo;
+                    if (P.ups == 1) {                 // tap (y+dy, x+dx) of the upsampled image = source pixel (.. >> 1)
+                        const int py = (int)(a_ok[e] >> 16) + dy, px = (int)(a_ok[e] & 0xffffu) + dx;
+                        const bool in = (unsigned)py < (unsigned)P.img_h && (unsigned)px < (unsigned)P.img_w;
+                        vo = a_vo[e] + (unsigned)(((py >> 1) * (P.img_w >> 1) + (px >> 1)) * P.cin * 2);
+                        if (!in || a_vo[e] == OOB) vo = OOB;
+                    } else {
+                        const int shift = (P.ups == 2 ? (dy * 2 * P.img_w + dx) : (dy * P.img_w + dx)) * P.cin * 2;   // scalar, may be negative
+                        vo = ((a_ok[e] >> it_tap) & 1u) ? a_vo[e] + (unsigned)shift : OOB;
+                    }
+                    dma(rsA, vo, it_ci0 * 2, stage + a_lds[e]);
+                }
+            }
+        }
+        if (q == 3) advance();
+    };
+
+    auto read_w = [&](const bf16_t* Ws, int ni) {
+        const int rw = wc * 64 + ni * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            union { bf16x8 v; u32x4 u; } t;
+            t.u = *reinterpret_cast<const u32x4*>(Ws + rw * BK + swz<BK>(rw, 2 * ks + half) * 8);
+            wf[ni][ks] = t.v;
+        }
+    };
+    auto read_a = [&](const bf16_t* As, int mh) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int rm = wr * 128 + (2 * mh + j) * 32 + l31;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                union { bf16x8 v; u32x4 u; } t;
+                t.u = *reinterpret_cast<const u32x4*>(As + rm * BK + swz<BK>(rm, 2 * ks + half) * 8);
+                af[j][ks] = t.v;
+            }
+        }
+    };
+#define G8_MMA(NI, MH)                                                                                               \
+    do {                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        __builtin_amdgcn_s_barrier();                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        __builtin_amdgcn_s_setprio(1);                                                                               \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                             \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
+                acc[NI][2 * (MH) + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[NI][ks], af[j][ks], acc[NI][2 * (MH) + j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        __builtin_amdgcn_s_barrier();                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    } while (0)
+#define G8_FEED(C)                                                                                                   \
+    do {                                                                                                             \
+        issue(((C) + PF) & 3);                                                                                       \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");                                                   \
+    } while (0)
+
+    // ---- prologue: PF half-tiles in flight, the two that phase 0 reads retired and published -----------------------------------
+#pragma unroll
+    for (int h = 0; h < PF; ++h) issue(h & 3);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();        // wave row 1 runs one barrier behind wave row 0
+    __builtin_amdgcn_sched_barrier(0);
+    // (zeroed HERE, behind the scheduling fence: 128 live zeros across the segment set-up above is what the register allocator
+    // answers with accumulator-tuple spills in the persistent instantiations)
+    float zero_v = 0.f;
+    if (SK) asm volatile("" : "+v"(zero_v));          // (a zero the optimiser cannot hoist out of the persistent loop as 8 constant tuples)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = zero_v;
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int kt = 0; kt < nk - kt0; ++kt) {
+        const bf16_t* As = smem + (kt & 1) * STAGE_ELEMS;
+        const bf16_t* Ws = As + BM * BK;
+        read_w(Ws, 0);                                // phase 0: quadrant (rows 0-63, columns 0-31)
+        read_a(As, 0);
+        G8_FEED(0);
+        G8_MMA(0, 0);
+        read_w(Ws, 1);                                // phase 1: (rows 0-63, columns 32-63)
+        G8_FEED(1);
+        G8_MMA(1, 0);
+        read_a(As, 1);                                // phase 2: (rows 64-127, columns 32-63)
+        G8_FEED(2);
+        G8_MMA(1, 1);
+        G8_FEED(3);                                   // phase 3: (rows 64-127, columns 0-31): everything is in registers
+        G8_MMA(0, 1);
+    }
+#undef G8_MMA
+#undef G8_FEED
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the wrap-around DMAs of the tail have landed: LDS is free for the epilogue
+    __syncthreads();
+
+    if (SK && sk_partial) {                           // my share of a cut tile: accumulator-layout partial into my slot, then the flag
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    union { u32x4 u; f32x4 f; } t;
+                    t.f = f32x4{acc[ni][mi][4 * gq], acc[ni][mi][4 * gq + 1], acc[ni][mi][4 * gq + 2], acc[ni][mi][4 * gq + 3]};
+                    const int quad = (wave * 8 + ni * 4 + mi) * 4 + gq;
+                    __builtin_amdgcn_raw_buffer_store_b128(t.u, rsP, (int)(((int64_t)blockIdx.x * (BM * BN / 4) + quad * 64 + lane) * 16), 0, SK_SC);
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my sc1 payload stores have completed ...
+        __syncthreads();
+        if (tid == 0)                                     // ... everybody's have: raise the flag
+            __hip_atomic_store(P.sk_flags + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+    if (SK && sk_np > 0) {                            // owner of a cut tile: fold the other shares into my accumulators
+        if (tid == 0) {
+            for (int j = 1; j <= sk_np; ++j) {
+                const int* f = P.sk_flags + (blockIdx.x - 8 * j);
+                int spins = 0;                            // bounded: a bug must not hang the GPU
+                while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 22))
+                    __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        __syncthreads();
+        for (int j = 1; j <= sk_np; ++j) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {         // one accumulator block (4 x 16 B per lane) at a time: all 32 loads in
+                    u32x4 t[4];                           // flight at once need 128 registers next to the 128 accumulators
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int quad = (wave * 8 + ni * 4 + mi) * 4 + gq;
+                        t[gq] = __builtin_amdgcn_raw_buffer_load_b128(rsP, (int)(((int64_t)(blockIdx.x - 8 * j) * (BM * BN / 4) + quad * 64 + lane) * 16), 0, SK_SC);
+                    }
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        union { u32x4 u; f32x4 f; } c;
+                        c.u = t[gq];
+                        acc[ni][mi][4 * gq] += c.f[0]; acc[ni][mi][4 * gq + 1] += c.f[1];
+                        acc[ni][mi][4 * gq + 2] += c.f[2]; acc[ni][mi][4 * gq + 3] += c.f[3];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+        __syncthreads();                                  // everybody has read the partials: hand the flags back as zeros
+        if (tid == 0)
+            for (int j = 1; j <= sk_np; ++j)
+                __hip_atomic_store(P.sk_flags + (blockIdx.x - 8 * j), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    // ---- epilogue: the output tile is staged as bf16 in LDS, 128 rows (the same 64-row half of both wave rows) per pass,
+    // and leaves with whole-row 16-byte stores.  Residuals travel through the same staging rows first (whole-row 16-byte
+    // loads), every lane adds its own words to its accumulators in fp32: one rounding, as in gemm_kernel.
+    constexpr int ON = EPI == 1 ? BN / 2 : BN;        // output columns of the tile
+    constexpr int OP = ON + 8;                        // bf16 pitch of the staging rows
+    bf16_t* Os = smem;                                // [256][OP]
+    constexpr int CPR = ON / 8;                       // 16-byte chunks per staged row
+    constexpr int IT = 128 * CPR / NT;                // chunks per thread and pass
+    const int no0 = EPI == 1 ? n0 / 2 : n0;           // first output column of the tile
+    const int n_out = EPI == 1 ? P.N / 2 : P.N;
+    auto pass = [&](auto hp_c) {
+        constexpr int hp = decltype(hp_c)::value;     // compile-time: the accumulator blocks of a pass must be static indices
+        auto stage_rows = [&](const bf16_t* src, int64_t ld) {     // global [rows of this pass][ON] -> Os
+            u32x4 v[IT];
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int c = tid + it * NT, ri = c / CPR, ch = c - ri * CPR;
+                const int row = (ri >> 6) * 128 + hp * 64 + (ri & 63);
+                v[it] = *reinterpret_cast<const u32x4*>(src + min(m0 + row, P.M - 1) * ld + min(no0 + ch * 8, n_out - 8));
+            }
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int c = tid + it * NT, ri = c / CPR, ch = c - ri * CPR;
+                const int row = (ri >> 6) * 128 + hp * 64 + (ri & 63);
+                *reinterpret_cast<u32x4*>(Os + row * OP + ch * 8) = v[it];
+            }
+            __syncthreads();
+        };
+        if (EPI == 0) {
+            // alpha * (acc + bias) (+ temb) in the accumulator registers; bias / temb words are fetched where they are used
+            // (4 bf16 = one 8-byte load, L1 / L2 resident): holding all 32 bias values of a lane next to the 128 accumulators
+            // is what tipped the stream-K instantiations into scratch
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int nb = n0 + wc * 64 + ni * 32 + 8 * gq + 4 * half;
+                    float b4[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (P.bias) {
+                        const u32x2 t = *reinterpret_cast<const u32x2*>(P.bias + min(nb, P.N - 4));
+                        b4[0] = __uint_as_float(t[0] << 16); b4[1] = __uint_as_float(t[0] & 0xffff0000u);
+                        b4[2] = __uint_as_float(t[1] << 16); b4[3] = __uint_as_float(t[1] & 0xffff0000u);
+                    }
+#pragma unroll
+                    for (int j2 = 0; j2 < 2; ++j2) {
+                        const int mi = 2 * hp + j2, row = wr * 128 + mi * 32 + l31;
+                        float t4[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (MODE == 1 && P.temb) {
+                            const bf16_t* trow = P.temb + ((min(m0 + row, P.M - 1) / P.hw) / P.temb_div) * P.temb_ld;
+                            const u32x2 t = *reinterpret_cast<const u32x2*>(trow + min(nb, P.N - 4));
+                            t4[0] = __uint_as_float(t[0] << 16); t4[1] = __uint_as_float(t[0] & 0xffff0000u);
+                            t4[2] = __uint_as_float(t[1] << 16); t4[3] = __uint_as_float(t[1] & 0xffff0000u);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[ni][mi][4 * gq + j] = (acc[ni][mi][4 * gq + j] + b4[j]) * P.alpha + t4[j];
+                    }
+                }
+            // residual(s): stage, add my words
+#pragma unroll
+            for (int rz = 0; rz < 2; ++rz) {
+                const bf16_t* rp = rz == 0 ? P.res : P.res2;
+                if (!rp) break;
+                stage_rows(rp, P.ldres);
+#pragma unroll
+                for (int j2 = 0; j2 < 2; ++j2) {
+                    const int mi = 2 * hp + j2, row = wr * 128 + mi * 32 + l31;
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            const u32x2 t = *reinterpret_cast<const u32x2*>(Os + row * OP + wc * 64 + ni * 32 + 8 * gq + 4 * half);
+                            acc[ni][mi][4 * gq] += __uint_as_float(t[0] << 16); acc[ni][mi][4 * gq + 1] += __uint_as_float(t[0] & 0xffff0000u);
+                            acc[ni][mi][4 * gq + 2] += __uint_as_float(t[1] << 16); acc[ni][mi][4 * gq + 3] += __uint_as_float(t[1] & 0xffff0000u);
+                        }
+                }
+                __syncthreads();                      // everybody has picked up its words: the rows may be overwritten
+            }
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+                const int mi = 2 * hp + j2, row = wr * 128 + mi * 32 + l31;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        *reinterpret_cast<u32x2*>(Os + row * OP + wc * 64 + ni * 32 + 8 * gq + 4 * half) =
+                            u32x2{pack_bf2(acc[ni][mi][4 * gq], acc[ni][mi][4 * gq + 1]), pack_bf2(acc[ni][mi][4 * gq + 2], acc[ni][mi][4 * gq + 3])};
+                    }
+            }
+        } else {
+            // GEGLU: weight rows interleaved per 64 -> acc[0] = value, acc[1] = gate of the SAME 32 output columns
+            float ba[16], bg[16];
+            const bool cols_ok = n0 + wc * 64 < P.N;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int nb = n0 + wc * 64 + 8 * gq + 4 * half + j;
+                    ba[4 * gq + j] = (P.bias && cols_ok) ? bf2f(P.bias[nb]) : 0.f;
+                    bg[4 * gq + j] = (P.bias && cols_ok) ? bf2f(P.bias[nb + 32]) : 0.f;
+                }
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+                const int mi = 2 * hp + j2, row = wr * 128 + mi * 32 + l31;
+                const f32x16& av = acc[0][mi];
+                const f32x16& ag = acc[1][mi];
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (av[4 * gq + j] + ba[4 * gq + j]) * gelu_erf(ag[4 * gq + j] + bg[4 * gq + j]);
+                    *reinterpret_cast<u32x2*>(Os + row * OP + wc * 32 + 8 * gq + 4 * half) = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int it = 0; it < IT; ++it) {
+            const int c = tid + it * NT, ri = c / CPR, ch = c - ri * CPR;
+            const int row = (ri >> 6) * 128 + hp * 64 + (ri & 63);
+            const int64_t m = m0 + row;
+            const int no = no0 + ch * 8;
+            if (m < P.M && no < n_out)
+                *reinterpret_cast<u32x4*>(P.out + m * P.ldo + no) = *reinterpret_cast<const u32x4*>(Os + row * OP + ch * 8);
+        }
+        // (the next pass touches the other 128 staging rows: no barrier needed between the passes)
+    };
+    pass(std::integral_constant<int, 0>{});
+    pass(std::integral_constant<int, 1>{});
+    }  // (not a partial)
+    if (!SK) break;
+    __syncthreads();                                  // the staging rows alias the operand buffers of the next segment
+    }  // segment loop
+}
+
 int fmc_cu_count() {
     static int n = 0;
     if (!n) {
@@ -821,8 +1306,56 @@ void launch_gemm_g(GemmParams& P, hipStream_t st) {
     }
 }
 
+// the 8-phase 256x256 kernel: plain grid or stream-K (one persistent workgroup per CU); offsets of A and W must fit 32 bits
+template <int MODE, int EPI, int PF>
+void launch_gemm8(GemmParams& P, hipStream_t st) {
+    P.tiles_m = (int)((P.M + 255) / 256);
+    P.tiles_n = (P.N + 255) / 256;
+    P.group_m = 1;
+    static const int tap_outer = getenv("FMC_CONV_TAP_OUTER") ? atoi(getenv("FMC_CONV_TAP_OUTER")) : 0;
+    P.tap_outer = tap_outer;
+    if (gemm_group_m_override() > 0) {
+        P.group_m = gemm_group_m_override();
+    } else if (MODE == 0 && (int64_t)P.N * P.K * 2 > (int64_t)5 << 19) {     // as launch_gemm_g: square per-XCD footprint
+        const double c = fmin(32.0, (double)P.tiles_m * P.tiles_n / 8.0);
+        const int gm = (int)lround(sqrt(c));
+        if (gm > 1 && P.tiles_n * 2 > 3 * (c / gm)) P.group_m = gm;
+    }
+    constexpr size_t ring = (size_t)2 * 512 * 64 * sizeof(bf16_t) + 1024;
+    constexpr size_t staged = (size_t)256 * ((EPI == 1 ? 128 : 256) + 8) * sizeof(bf16_t);
+    constexpr size_t lds = staged > ring ? staged : ring;
+    static bool raised = false;
+    if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_kernel<MODE, EPI, PF, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_kernel<MODE, EPI, PF, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        raised = true;
+    }
+    if (P.sk) {
+        const int64_t iters = (int64_t)P.tiles_m * P.tiles_n * (P.K / 64);
+        const int g = fmc_cu_count() & ~7;                // one 128-KiB workgroup per CU
+        const int64_t need = (int64_t)g * 256 * 256 * (int64_t)sizeof(float) + 4096;
+        if (g >= 8 && iters >= 4 * (int64_t)g && P.sk_ws_bytes >= need && g * (int)sizeof(int) <= 4096) {
+            P.sk = g;
+            hipLaunchKernelGGL((gemm8_kernel<MODE, EPI, PF, true>), dim3((unsigned)g), dim3(512), lds, st, P);
+            return;
+        }
+        P.sk = 0;                                         // too little work (or workspace): the plain grid
+    }
+    hipLaunchKernelGGL((gemm8_kernel<MODE, EPI, PF, false>), dim3((unsigned)(P.tiles_m * P.tiles_n)), dim3(512), lds, st, P);
+}
+
+bool gemm8_ok(GemmParams& P) {
+    // operand sizes as the buffer descriptors see them (conv: the whole input tensor; token: up to the end of the last row)
+    const int64_t a_elems = P.hw > 1 ? (P.ups == 1 ? (P.M / 4) * (int64_t)P.cin : P.M * (int64_t)P.cin * (P.ups == 2 ? 4 : 1))
+                                     : (P.M - 1) * P.lda + P.K;
+    P.a_bytes = a_elems * 2;
+    return P.split_k == 1 && !P.a2 && P.a_bytes < ((int64_t)1 << 31) && (int64_t)P.N * P.K * 2 < ((int64_t)1 << 31);
+}
+
 // tile arms (fmc_hip.h): geometry x k-tile depth x ring depth
-constexpr int GEMM_TILE_MAX = 12;
+constexpr int GEMM_TILE_MAX = 14;
 
 // geometry: the largest tile that still gives every CU work and does not waste more than ~20 % of N
 template <int MODE, int EPI>
@@ -836,7 +1369,10 @@ void launch_gemm(GemmParams& P, int tile, hipStream_t st) {
         else if (tiles(256, 128) >= 256 && waste(128) <= 1.25) g = 2;
         else g = 1;
     }
+    if ((g == 13 || g == 14) && !gemm8_ok(P)) g = 3;      // 8-phase kernel: plain grid, 32-bit operand offsets
     switch (g) {
+        case 14: launch_gemm8<MODE, EPI, 5>(P, st); break;              // 8-phase 256x256, 5 half-tiles ahead
+        case 13: launch_gemm8<MODE, EPI, 4>(P, st); break;              // 8-phase 256x256, 4 half-tiles ahead
         case 12: launch_gemm_g<MODE, EPI, 2, 5, 32, 4>(P, st); break;   // 128x320, 32-deep k-tiles, 4-stage ring
         case 11: launch_gemm_g<MODE, EPI, 2, 5, 64, 2>(P, st); break;   // 128x320: 2 x 5 waves
         case 10: launch_gemm_g<MODE, EPI, 4, 2, 32, 4>(P, st); break;

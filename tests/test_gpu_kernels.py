@@ -499,8 +499,85 @@ def test_gemm_stream_k(K, tile):
     a, g = F.linear(xo, go).chunk(2, dim=-1)
     outg = K.linear_bf16(xd, wi, bi, geglu=True, tile=128 + tile)
     assert rel_inf(outg.float(), a * F.gelu(g)) < 1e-2
-    ws = K._sk_ws[torch.cuda.current_device()]
+    ws = K._sk_ws[(torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)]
     assert int(ws[:1024].view(torch.int32).abs().sum()) == 0                      # flags handed back as zeros
+
+
+@pytest.mark.parametrize("tile", [13, 14, 128 + 13, 128 + 14])
+def test_gemm_8phase_arms(K, tile):
+    """The 8-phase 256x256 kernel (staggered wave rows, half-tile DMA with counted vmcnt): ragged M / N (partial tiles),
+    K from one k-tile up, every epilogue (bias, alpha, one / two residuals, GEGLU, two-source A operand), the conv loader
+    (plain, + temb, + residual, upsample, stride 2), determinism, and repeated launches on fresh data (a racy schedule
+    shows up as rare wrong tiles)."""
+    dtype = torch.bfloat16
+    from synfmc_amd.models.layers import interleave_geglu
+    for (M, N, Kd) in [(4100, 1032, 1280), (256, 256, 64), (700, 320, 320), (5120, 1280, 128), (1000, 2560, 640)]:
+        wo, wd = rnd((N, Kd), 45, dtype, scale=Kd ** -0.5)
+        bo, bd = rnd((N,), 46, dtype)
+        for it in range(4):
+            xo, xd = rnd((M, Kd), 200 + it, dtype)
+            ro, rd = rnd((M, N), 300 + it, dtype)
+            r2o, r2d = rnd((M, N), 400 + it, dtype)
+            got = K.linear_bf16(xd, wd, bd, rd, 0.5, tile=tile)
+            assert rel_inf(got.float(), 0.5 * F.linear(xo, wo, bo) + ro) < 1e-2, (M, N, Kd, it)
+            if it == 0:
+                assert torch.equal(got, K.linear_bf16(xd, wd, bd, rd, 0.5, tile=tile))                      # deterministic
+                if tile < 128:                                                                              # == the plain kernel
+                    assert torch.equal(got, K.linear_bf16(xd, wd, bd, rd, 0.5, tile=1))
+                got2 = K.linear_bf16(xd, wd, None, rd, 1.0, tile=tile, residual2=r2d)
+                assert rel_inf(got2.float(), F.linear(xo, wo) + ro + r2o) < 1e-2
+                got0 = K.linear_bf16(xd, wd, bd, None, 1.0, tile=tile)
+                assert rel_inf(got0.float(), F.linear(xo, wo, bo)) < 1e-2
+    # two-source A operand (concat-free up blocks)
+    xo1, xd1 = rnd((900, 640), 50, dtype)
+    xo2, xd2 = rnd((900, 320), 51, dtype)
+    wo, wd = rnd((640, 960), 52, dtype, scale=960 ** -0.5)
+    got = K.linear_bf16(xd1, wd, None, None, 1.0, tile=tile, x2=xd2)
+    assert rel_inf(got.float(), F.linear(torch.cat([xo1, xo2], -1), wo)) < 1e-2
+    # GEGLU
+    M, Kd = 4100, 1280
+    go, gd = rnd((2048, Kd), 42, dtype, scale=Kd ** -0.5)
+    gbo, gbd = rnd((2048,), 40, dtype)
+    xo, xd = rnd((M, Kd), 41, dtype)
+    wi, bi = interleave_geglu(gd, gbd)
+    a, g = F.linear(xo, go, gbo).chunk(2, dim=-1)
+    outg = K.linear_bf16(xd, wi, bi, geglu=True, tile=tile)
+    assert rel_inf(outg.float(), a * F.gelu(g)) < 1e-2
+    # conv loader
+    co, cd = rnd((4, 320, 36, 30), 47, dtype)
+    fo, fd = rnd((328, 320, 3, 3), 44, dtype, scale=(9 * 320) ** -0.5)
+    to, td = rnd((4, 328), 43, dtype)
+    ro, rd = rnd((4, 328, 36, 30), 48, dtype)
+    x_nhwc, f_cl = cd.permute(0, 2, 3, 1).contiguous(), fd.contiguous(memory_format=torch.channels_last)
+    refc = F.conv2d(co, fo, None, 1, 1)
+    outc = K.conv3x3_bf16(x_nhwc, f_cl, None, td, None, tile=tile)
+    assert rel_inf(outc.permute(0, 3, 1, 2).float(), refc + to[:, :, None, None]) < 1e-2
+    outr = K.conv3x3_bf16(x_nhwc, f_cl, None, None, rd.permute(0, 2, 3, 1).contiguous(), tile=tile)
+    assert rel_inf(outr.permute(0, 3, 1, 2).float(), refc + ro) < 1e-2
+    outu = K.conv3x3_bf16(x_nhwc, f_cl, None, None, None, tile=tile, upsample=True)
+    assert rel_inf(outu.permute(0, 3, 1, 2).float(), F.conv2d(F.interpolate(co, scale_factor=2.0, mode="nearest"), fo, None, 1, 1)) < 1e-2
+    outs = K.conv3x3_bf16(x_nhwc, f_cl, None, None, None, tile=tile, stride2=True)
+    assert rel_inf(outs.permute(0, 3, 1, 2).float(), F.conv2d(co, fo, None, 2, 1)) < 1e-2
+    # bench-size conv, sampled check against the plain kernel (bit-identical: same products, same summation order per element)
+    co, cd = rnd((8, 640, 20, 32), 53, dtype)
+    fo, fd = rnd((640, 640, 3, 3), 54, dtype, scale=(9 * 640) ** -0.5)
+    x_nhwc, f_cl = cd.permute(0, 2, 3, 1).contiguous(), fd.contiguous(memory_format=torch.channels_last)
+    want = K.conv3x3_bf16(x_nhwc, f_cl, None, None, None, tile=3)
+    for it in range(6):
+        got = K.conv3x3_bf16(x_nhwc, f_cl, None, None, None, tile=tile)
+        assert torch.equal(got, want) if tile < 128 else rel_inf(got.float(), want.float()) < 4e-3          # (stream-K: other summation order)
+    if tile >= 128:                            # stream-K: big enough to be cut (>= 4 k-tiles per CU), many launches on fresh data, flags back to zero
+        M, N, Kd = 20480, 1280, 1280
+        wo, wd = rnd((N, Kd), 60, dtype, scale=Kd ** -0.5)
+        for it in range(8):
+            xo, xd = rnd((M, Kd), 500 + it, dtype)
+            ro, rd = rnd((M, N), 600 + it, dtype)
+            got = K.linear_bf16(xd, wd, None, rd, 1.0, tile=tile)
+            want = K.linear_bf16(xd, wd, None, rd, 1.0, tile=3)
+            assert rel_inf(got.float(), want.float()) < 8e-3, it                  # (one bf16 ulp of the largest output)
+            assert torch.equal(got, K.linear_bf16(xd, wd, None, rd, 1.0, tile=tile))                          # deterministic
+        ws = K._sk_ws[(torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)]
+        assert int(ws[:1024].view(torch.int32).abs().sum()) == 0
 
 
 def test_linear_bf16_geglu(K):
