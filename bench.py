@@ -373,6 +373,10 @@ def train_main(args):
     from tests import training_common as TC
     unet, enc, ada = build_models(device, dtype)
     ada = ada.float().requires_grad_(True)                  # fp32 master weights for the trainable Adapter
+    if args.fp8_temporal:
+        from synfmc_amd.models.motion_module import enable_fp8_temporal_attention
+        enable_fp8_temporal_attention(unet)
+        enable_fp8_temporal_attention(enc)
     broadcast_parameters(ada)
     clip, _ = synthetic_inputs(rank, device)
     sched = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="linear",
@@ -479,14 +483,15 @@ def train_main(args):
     assert torch.isfinite(loss).all()
     if rank == 0:
         print(json.dumps({
-            "metric": f"OMC-stage training steps/sec (secondary), {FRAMES}x{HEIGHT}x{WIDTH} bf16, frozen U-Net + trainable Adapter",
+            "metric": f"OMC-stage training steps/sec (secondary), {FRAMES}x{HEIGHT}x{WIDTH} bf16"
+                      f"{' + fp8 temporal attention' if args.fp8_temporal else ''}, frozen U-Net + trainable Adapter",
             "value": round(world * args.steps / elapsed, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "stage-3 (configs/obj.yaml) training step, 1 clip per GPU, AdamW, clip-norm 1.0, "
                                    "bucketed RCCL all-reduce of the USED Adapter gradients (level 3 never receives one)",
                        "hip_graph": mode, "parallelism": f"dp{world}", "allreduce_bytes": reducer.allreduce_bytes(),
-                       "grad_compress": args.grad_compress, "unused_params": sum(p.numel() for p in reducer.unused),
+                       "fp8_temporal_attention": args.fp8_temporal, "grad_compress": args.grad_compress, "unused_params": sum(p.numel() for p in reducer.unused),
                        "trained_params": sum(p.numel() for p in trainable)},
             "last_loss": float(loss)}), flush=True)
     if world > 1:
@@ -512,6 +517,8 @@ def main():
     ap.add_argument("--train-graph", default=None, choices=["one", "split", "none"],
                     help="train mode: one HIP graph for the whole step (1 rank) | graph + all-reduce + graph | eager")
     ap.add_argument("--grad-compress", default="none", choices=["none", "bf16"], help="train mode: gradient buckets on the wire")
+    ap.add_argument("--fp8-temporal", action="store_true",
+                    help="temporal attention on the fp8 path (e4m3 q|k|v from the QKV epilogue, fp8 MFMA): BASELINE configs[4]")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo stub of the launcher + timing + JSON plumbing (tests)")
     args = ap.parse_args()
     if args.dry_run:
@@ -536,6 +543,10 @@ def main():
 
     t_build = time.time()
     unet, enc, ada = build_models(device, dtype)
+    if args.fp8_temporal:
+        from synfmc_amd.models.motion_module import enable_fp8_temporal_attention
+        enable_fp8_temporal_attention(unet)
+        enable_fp8_temporal_attention(enc)
     clip, text2 = synthetic_inputs(rank, device)
     text2 = text2.to(dtype)
     torch.cuda.synchronize()
@@ -621,7 +632,8 @@ def main():
                                    "Camera Adapter (CMC) + Object Motion Control (OMC) features, DDIM step; "
                                    "configs/obj.yaml shapes; 1 clip per GPU",
                        "frames": FRAMES, "height": HEIGHT, "width": WIDTH, "guidance_scale": args.guidance,
-                       "hip_graph": not args.no_graph, "parallelism": f"dp{world} (independent clips, no collective)"},
+                       "hip_graph": not args.no_graph, "fp8_temporal_attention": args.fp8_temporal,
+                       "parallelism": f"dp{world} (independent clips, no collective)"},
             "parity_rel_inf": parity,
             "parity_note": "max|eps_gpu - eps_oracle| / max|eps_oracle| for one CFG-batch-2 step (t = 801) of the benchmarked "
                            "model: same weights (bf16-rounded), noise, text, camera poses, object masks; oracle = fp32 CPU",

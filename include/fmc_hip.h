@@ -257,6 +257,33 @@ int fmc_temporal_attn_bwd(const void* q, const void* k, const void* v, const voi
                           int64_t dq_clip_stride, int64_t dq_frame_stride, int64_t dq_pix_stride, float scale,
                           int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * fp8 temporal attention (BASELINE.json configs[4]).  Same chain as fmc_temporal_attn_fwd (attention_processor.py:267-281
+ * reached from motion_module.py:365-389), with Q, K, V stored as OCP e4m3 bytes + one fp32 scale per tensor
+ * (value = byte * scale).
+ *
+ * fmc_linear_fp8_qkv: the fused q | k | v projection `x @ w^T` (x [M, K] bf16 rows ldx apart, w [N = 3C, K] bf16, no bias:
+ *   to_q / to_k / to_v have none) on the 8-phase bf16 MFMA kernel with an e4m3 epilogue: column block b = n / C is written as
+ *   sat(acc * inv_scales[b]) to out_fp8 [M, N] bytes.  inv_scales: 3 device floats (1 / scale).  amax_bits (3 device words,
+ *   may be NULL): running max |acc| per block as float bit patterns (atomicMax) -- what a delayed-scaling policy derives the
+ *   next call's scales from.
+ * fmc_temporal_attn_fp8_fwd: S^T = K Q^T on v_mfma_f32_16x16x32_fp8_fp8, softmax in fp32, P V on the bf16 MFMA with V
+ *   converted e4m3 -> bf16 (exact); o is bf16.  q/k/v strides in bytes (multiples of 16), o strides in elements; scales = 3
+ *   device floats {scale_q, scale_k, scale_v}.  F in {16, 32}.
+ * fmc_temporal_attn_fp8_bwd: fmc_temporal_attn_bwd with e4m3 q, k, v (dequantised while staged; d_o, dq, dk, dv bf16).
+ * ------------------------------------------------------------------------------------------- */
+int fmc_linear_fp8_qkv(const void* x, const void* w, void* out_fp8, int64_t M, int N, int K, int64_t ldx,
+                       const void* inv_scales, void* amax_bits, void* stream);
+int fmc_temporal_attn_fp8_fwd(const void* q, const void* k, const void* v, void* o, const void* scales, int n_clips,
+                              int n_pix, int F, int H, int D, int64_t clip_stride, int64_t frame_stride,
+                              int64_t pix_stride, int64_t o_clip_stride, int64_t o_frame_stride, int64_t o_pix_stride,
+                              float scale, void* stream);
+int fmc_temporal_attn_fp8_bwd(const void* q, const void* k, const void* v, const void* scales, const void* d_o, void* dq,
+                              void* dk, void* dv, int n_clips, int n_pix, int F, int H, int D, int64_t clip_stride,
+                              int64_t frame_stride, int64_t pix_stride, int64_t do_clip_stride, int64_t do_frame_stride,
+                              int64_t do_pix_stride, int64_t dq_clip_stride, int64_t dq_frame_stride,
+                              int64_t dq_pix_stride, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,8 @@ struct GemmParams {
     int* sk_flags;                    //   contiguous range of (tile, k-tile) iterations; ws[block][BM][BN] partials
     int64_t sk_ws_bytes;
     int64_t a_bytes;                  // 8-phase kernel: size of the A operand in bytes (buffer descriptor range)
+    const float* q8_inv;              // EPI 2 (fp8 e4m3 output, three equal column blocks q | k | v): 1 / scale per block (device)
+    unsigned* q8_amax;                // EPI 2: running max |value| per block as float bits (device, atomicMax), may be NULL
 };
 
 // Launch-order index -> output tile.  Inside a group of `group_m` m-tiles the order is n-outer / m-inner, so the C
@@ -1037,13 +1039,13 @@ void gemm8_kernel(const GemmParams P) {
     // ---- epilogue: the output tile is staged as bf16 in LDS, 128 rows (the same 64-row half of both wave rows) per pass,
     // and leaves with whole-row 16-byte stores.  Residuals travel through the same staging rows first (whole-row 16-byte
     // loads), every lane adds its own words to its accumulators in fp32: one rounding, as in gemm_kernel.
-    constexpr int ON = EPI == 1 ? BN / 2 : BN;        // output columns of the tile
+    constexpr int ON = EPI != 0 ? BN / 2 : BN;        // output columns of the tile in 2-byte units (EPI 2: two fp8 per unit)
     constexpr int OP = ON + 8;                        // bf16 pitch of the staging rows
     bf16_t* Os = smem;                                // [256][OP]
     constexpr int CPR = ON / 8;                       // 16-byte chunks per staged row
     constexpr int IT = 128 * CPR / NT;                // chunks per thread and pass
-    const int no0 = EPI == 1 ? n0 / 2 : n0;           // first output column of the tile
-    const int n_out = EPI == 1 ? P.N / 2 : P.N;
+    const int no0 = EPI != 0 ? n0 / 2 : n0;           // first output column of the tile
+    const int n_out = EPI != 0 ? P.N / 2 : P.N;
     auto pass = [&](auto hp_c) {
         constexpr int hp = decltype(hp_c)::value;     // compile-time: the accumulator blocks of a pass must be static indices
         auto stage_rows = [&](const bf16_t* src, int64_t ld) {     // global [rows of this pass][ON] -> Os
@@ -1122,6 +1124,38 @@ void gemm8_kernel(const GemmParams P) {
                         *reinterpret_cast<u32x2*>(Os + row * OP + wc * 64 + ni * 32 + 8 * gq + 4 * half) =
                             u32x2{pack_bf2(acc[ni][mi][4 * gq], acc[ni][mi][4 * gq + 1]), pack_bf2(acc[ni][mi][4 * gq + 2], acc[ni][mi][4 * gq + 3])};
                     }
+            }
+        } else if (EPI == 2) {
+            // fp8 (OCP e4m3) output for the fused q | k | v projection of the fp8 temporal attention: value / scale[block],
+            // clamped to +-448, four consecutive columns of a lane = one 32-bit word.  A wave's 64 columns lie inside one of the
+            // three blocks (C % 64 == 0), so the running |max| of the block costs one atomicMax per wave and pass.
+            const int cq = P.N / 3;
+            const int blk = min((n0 + wc * 64) / cq, 2);
+            const float inv = P.q8_inv[blk];
+            float amax = 0.f;
+            unsigned char* Ob = reinterpret_cast<unsigned char*>(Os);
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+                const int mi = 2 * hp + j2, row = wr * 128 + mi * 32 + l31;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        float o[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float v = acc[ni][mi][4 * gq + j] * P.alpha;
+                            amax = fmaxf(amax, fabsf(v));
+                            o[j] = fminf(fmaxf(v * inv, -448.f), 448.f);
+                        }
+                        int w = __builtin_amdgcn_cvt_pk_fp8_f32(o[0], o[1], 0, false);
+                        w = __builtin_amdgcn_cvt_pk_fp8_f32(o[2], o[3], w, true);
+                        *reinterpret_cast<int*>(Ob + row * (OP * 2) + wc * 64 + ni * 32 + 8 * gq + 4 * half) = w;
+                    }
+            }
+            if (P.q8_amax && n0 + wc * 64 < P.N) {
+                amax = wave_max(amax);
+                if (lane == 0) atomicMax(P.q8_amax + blk, __float_as_uint(amax));     // (non-negative floats order like their bit patterns)
             }
         } else {
             // GEGLU: weight rows interleaved per 64 -> acc[0] = value, acc[1] = gate of the SAME 32 output columns
@@ -1322,7 +1356,7 @@ void launch_gemm8(GemmParams& P, hipStream_t st) {
         if (gm > 1 && P.tiles_n * 2 > 3 * (c / gm)) P.group_m = gm;
     }
     constexpr size_t ring = (size_t)2 * 512 * 64 * sizeof(bf16_t) + 1024;
-    constexpr size_t staged = (size_t)256 * ((EPI == 1 ? 128 : 256) + 8) * sizeof(bf16_t);
+    constexpr size_t staged = (size_t)256 * ((EPI != 0 ? 128 : 256) + 8) * sizeof(bf16_t);
     constexpr size_t lds = staged > ring ? staged : ring;
     static bool raised = false;
     if (!raised) {
@@ -1470,5 +1504,22 @@ extern "C" int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, 
     if (int rc = set_split_k(P, split_k, workspace, workspace_bytes, true, "conv3x3_bf16")) return rc;
     launch_gemm<1, 0>(P, tile, (hipStream_t)stream);
     FMC_CHECK_LAUNCH("fmc_conv3x3_bf16");
+    return 0;
+}
+
+extern "C" int fmc_linear_fp8_qkv(const void* x, const void* w, void* out_fp8, int64_t M, int N, int K, int64_t ldx,
+                                  const void* inv_scales, void* amax_bits, void* stream) {
+    if (!x || !w || !out_fp8 || !inv_scales) FMC_FAIL(FMC_E_NULL, "linear_fp8_qkv: NULL tensor");
+    if (M <= 0 || N <= 0 || K <= 0 || K % BK_MAX || N % 192 || ldx % 8)
+        FMC_FAIL(FMC_E_SHAPE, "linear_fp8_qkv: need K%%64==0, N = 3*C with C%%64==0, ldx%%8==0 (M=%lld N=%d K=%d)", (long long)M, N, K);
+    if (!fmc_aligned16(x) || !fmc_aligned16(w) || !fmc_aligned16(out_fp8)) FMC_FAIL(FMC_E_ALIGN, "linear_fp8_qkv: tensors must be 16-byte aligned");
+    GemmParams P{};
+    P.a = (const bf16_t*)x; P.w = (const bf16_t*)w; P.out = (bf16_t*)out_fp8;
+    P.M = M; P.N = N; P.K = K; P.lda = ldx; P.ldo = N / 2;            // output rows in 2-byte units (two fp8 each)
+    P.hw = 1; P.alpha = 1.f; P.temb_div = 1; P.split_k = 1;
+    P.q8_inv = (const float*)inv_scales; P.q8_amax = (unsigned*)amax_bits;
+    if (!gemm8_ok(P)) FMC_FAIL(FMC_E_SHAPE, "linear_fp8_qkv: operands beyond 2 GiB");
+    launch_gemm8<0, 2, 4>(P, (hipStream_t)stream);
+    FMC_CHECK_LAUNCH("fmc_linear_fp8_qkv");
     return 0;
 }

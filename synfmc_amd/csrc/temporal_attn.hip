@@ -216,6 +216,134 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TAParams P) {
 }
 
 // --------------------------------------------------------------------------------------------
+// fp8 variant (BASELINE configs[4]: "fp8 MFMA temporal attention").  Q, K, V arrive as OCP e4m3 bytes with one scale per
+// tensor (value = byte * scale; written by the QKV projection's epilogue, fmc_linear_fp8_qkv) -- the kernel is HBM bound, so
+// halving the bytes it reads is the point; O leaves as bf16.  S^T = K Q^T runs on v_mfma_f32_16x16x32_fp8_fp8 straight on
+// the staged bytes (the product of the two scales joins the softmax scale); P V keeps the bf16 MFMA with V converted
+// e4m3 -> bf16 in registers (exact), so against the oracle evaluated on the SAME fp8-rounded q, k, v the result carries only
+// the bf16 rounding of P and O, like the bf16 kernel.
+// --------------------------------------------------------------------------------------------
+struct TA8Params {
+    const unsigned char* q; const unsigned char* k; const unsigned char* v; bf16_t* o;
+    const float* scales;              // device: {scale_q, scale_k, scale_v}
+    int n_clips, n_pix, F, H, D, GH;
+    int64_t cs, fs, ps, ocs, ofs, ops;   // q/k/v strides in BYTES (= elements), o strides in bf16 elements
+    float scale_log2;
+};
+
+__device__ __forceinline__ float fp8_to_f32(unsigned char b) { return __builtin_amdgcn_cvt_f32_fp8((int)b, 0); }
+
+template <int FT, int NK32>
+__global__ __launch_bounds__(256) void temporal_attn_fp8_kernel(const TA8Params P) {
+    constexpr int F = FT * 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int D = P.D, GH = P.GH, CW = GH * D, CPR16 = CW / 16, PB = CW + 16;      // byte pitch of the fp8 rows
+    const int OPITCH = CW + 8;                                                      // bf16 pitch of the O rows
+    unsigned char* Qs = smem_raw;                    // [F][PB]
+    unsigned char* Ks = Qs + F * PB;
+    unsigned char* Vs = Ks + F * PB;
+    bf16_t* Os = reinterpret_cast<bf16_t*>(Vs + F * PB);   // [F][OPITCH]
+    const int tid = threadIdx.x, NTH = blockDim.x, wave = tid >> 6, NWV = NTH >> 6;
+    const int lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+
+    const int groups = P.H / GH;
+    int u = blockIdx.x;
+    const int hg = u % groups; u /= groups;
+    const int pix = u % P.n_pix;
+    const int clip = u / P.n_pix;
+    const int64_t in_off = (int64_t)clip * P.cs + (int64_t)pix * P.ps + (int64_t)hg * CW;
+    const int64_t out_off = (int64_t)clip * P.ocs + (int64_t)pix * P.ops + (int64_t)hg * CW;
+    const float sq = P.scales[0], sk = P.scales[1], sv = P.scales[2];
+    const float sl2 = P.scale_log2 * sq * sk;
+
+    const int chunks = F * CPR16;                    // 16 bytes = 16 channels per lane and load
+#pragma unroll 1
+    for (int which = 0; which < 3; ++which) {
+        const unsigned char* src = (which == 0 ? P.q : (which == 1 ? P.k : P.v)) + in_off;
+        unsigned char* dst = which == 0 ? Qs : (which == 1 ? Ks : Vs);
+#pragma unroll 5
+        for (int c = tid; c < chunks; c += NTH) {
+            const int f = c / CPR16, ch = c - f * CPR16;
+            *reinterpret_cast<u32x4*>(dst + f * PB + ch * 16) = *reinterpret_cast<const u32x4*>(src + (int64_t)f * P.fs + ch * 16);
+        }
+    }
+    __syncthreads();
+
+    for (int hh = wave; hh < GH; hh += NWV) {
+        const int hc = hh * D;
+#pragma unroll
+        for (int qt = 0; qt < FT; ++qt) {
+            long qf[NK32];
+#pragma unroll
+            for (int ks = 0; ks < NK32; ++ks) {
+                const int d0 = ks * 32 + lg * 8;
+                qf[ks] = d0 < D ? *reinterpret_cast<const long*>(Qs + (qt * 16 + l15) * PB + hc + d0) : 0L;
+            }
+            f32x4 s[FT];
+#pragma unroll
+            for (int kt = 0; kt < FT; ++kt) {
+                s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < NK32; ++ks) {
+                    const int d0 = ks * 32 + lg * 8;
+                    const long kf = d0 < D ? *reinterpret_cast<const long*>(Ks + (kt * 16 + l15) * PB + hc + d0) : 0L;
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(kf, qf[ks], s[kt], 0, 0, 0);
+                }
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < FT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s[kt][r] *= sl2; mx = fmaxf(mx, s[kt][r]); }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < FT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s[kt][r] = exp2f(s[kt][r] - mx); sum += s[kt][r]; }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.f / sum;
+            F4<bf16_t> pf[FT];
+#pragma unroll
+            for (int kt = 0; kt < FT; ++kt) {
+                float p4[4] = {s[kt][0] * inv, s[kt][1] * inv, s[kt][2] * inv, s[kt][3] * inv};
+                make_f4(p4, pf[kt]);
+            }
+            const int ndt = (D + 15) / 16;
+            for (int dt = 0; dt < ndt; ++dt) {
+                f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int dA = dt * 16 + l15;
+#pragma unroll
+                for (int kt = 0; kt < FT; ++kt) {
+                    float v4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        v4[i] = dA < D ? fp8_to_f32(Vs[(kt * 16 + lg * 4 + i) * PB + hc + dA]) : 0.f;
+                    F4<bf16_t> vf;
+                    make_f4(v4, vf);                 // e4m3 -> bf16 is exact
+                    mma_pv(vf, pf[kt], o);
+                }
+                const int dO = dt * 16 + lg * 4;
+                if (dO < D) {
+                    float o4[4] = {o[0] * sv, o[1] * sv, o[2] * sv, o[3] * sv};
+                    st4<bf16_t>(Os + (qt * 16 + l15) * OPITCH + hc + dO, o4);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    bf16_t* og = P.o + out_off;
+    const int CPR = CW / 8, ochunks = F * CPR;
+#pragma unroll 5
+    for (int c = tid; c < ochunks; c += NTH) {
+        const int f = c / CPR, ch = c - f * CPR;
+        *reinterpret_cast<u32x4*>(og + (int64_t)f * P.ofs + ch * 8) = *reinterpret_cast<const u32x4*>(Os + f * OPITCH + ch * 8);
+    }
+}
+
+// --------------------------------------------------------------------------------------------
 // Backward.  Same unit decomposition and staging as the forward; Q, K, V, dO in, dQ, dK, dV out (7 LDS tiles).
 // With P = softmax(S), S = scale * Q K^T:   dV = P^T dO,  dP = dO V^T,  dS = P .* (dP - rowsum(P .* dP)),
 // dQ = scale * dS K,  dK = scale * dS^T Q.  The 16x16 score tiles are computed twice, once per register layout:
@@ -230,7 +358,8 @@ struct TABwdParams {
     int n_clips, n_pix, F, H, D, GH;
     int64_t cs, fs, ps, ocs, ofs, ops, dcs, dfs, dps;
     float scale, scale_log2;
-};
+    const float* q8_scales;           // non-NULL: q, k, v are e4m3 bytes (strides in bytes) with these three scales; they are
+};                                    // dequantised while being staged, the arithmetic below is unchanged
 
 template <typename T> __device__ __forceinline__ void col_f4(const T* base, int pitch, bool valid, F4<T>& f) {
     float v4[4];
@@ -269,10 +398,23 @@ __global__ __launch_bounds__(256) void temporal_attn_bwd_kernel(const TABwdParam
     const int chunks = F * CPR;
 #pragma unroll 1
     for (int which = 0; which < 4; ++which) {
+        T* dst = which == 0 ? Qs : which == 1 ? Ks : which == 2 ? Vs : Gs;
+        if (P.q8_scales && which < 3) {
+            const unsigned char* src8 = (const unsigned char*)(which == 0 ? P.q : which == 1 ? P.k : P.v) + in_off;
+            const float sc = P.q8_scales[which];
+            for (int c = tid; c < chunks; c += NTH) {
+                const int f = c / CPR, ch = c - f * CPR;
+                const u32x2 w = *reinterpret_cast<const u32x2*>(src8 + (int64_t)f * P.fs + ch * 8);
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = fp8_to_f32((unsigned char)((w[i >> 2] >> (8 * (i & 3))) & 0xffu)) * sc;
+                Vec8<T>::store(dst + f * PITCH + ch * 8, v);
+            }
+            continue;
+        }
         const T* src = which == 0 ? (const T*)P.q + in_off : which == 1 ? (const T*)P.k + in_off
                      : which == 2 ? (const T*)P.v + in_off : (const T*)P.d_o + go_off;
         const int64_t fstride = which == 3 ? P.ofs : P.fs;
-        T* dst = which == 0 ? Qs : which == 1 ? Ks : which == 2 ? Vs : Gs;
 #pragma unroll 5
         for (int c = tid; c < chunks; c += NTH) {
             const int f = c / CPR, ch = c - f * CPR;
@@ -564,11 +706,110 @@ extern "C" int fmc_temporal_attn_bwd(const void* q, const void* k, const void* v
     P.ocs = do_clip_stride; P.ofs = do_frame_stride; P.ops = do_pix_stride;
     P.dcs = dq_clip_stride; P.dfs = dq_frame_stride; P.dps = dq_pix_stride;
     P.scale = scale; P.scale_log2 = scale * LOG2E;
+    P.q8_scales = nullptr;
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (dtype == FMC_BF16) rc = F == 16 ? dispatch_ta_bwd_k<bf16_t, 1>(P, st) : dispatch_ta_bwd_k<bf16_t, 2>(P, st);
     else rc = F == 16 ? dispatch_ta_bwd_k<float, 1>(P, st) : dispatch_ta_bwd_k<float, 2>(P, st);
     if (rc) return rc;
     FMC_CHECK_LAUNCH("fmc_temporal_attn_bwd");
+    return 0;
+}
+
+namespace {
+template <int FT, int NK32>
+void launch_ta8(const TA8Params& P, hipStream_t st) {
+    const int CW = P.GH * P.D;
+    const size_t lds = 3 * (size_t)(FT * 16) * (CW + 16) + sizeof(bf16_t) * (size_t)(FT * 16) * (CW + 8);
+    if (lds > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_attn_fp8_kernel<FT, NK32>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            raised = true;
+        }
+    }
+    const int waves = P.GH >= 4 ? 4 : (P.GH >= 2 ? 2 : 1);
+    dim3 grid((unsigned)((int64_t)P.n_clips * P.n_pix * (P.H / P.GH))), block(64 * waves);
+    hipLaunchKernelGGL((temporal_attn_fp8_kernel<FT, NK32>), grid, block, lds, st, P);
+}
+template <int FT>
+int dispatch_ta8(const TA8Params& P, hipStream_t st) {
+    switch ((P.D + 31) / 32) {
+        case 1: launch_ta8<FT, 1>(P, st); break;
+        case 2: launch_ta8<FT, 2>(P, st); break;
+        case 3: launch_ta8<FT, 3>(P, st); break;
+        case 4: launch_ta8<FT, 4>(P, st); break;
+        case 5: launch_ta8<FT, 5>(P, st); break;
+        default: FMC_FAIL(FMC_E_SHAPE, "temporal_attn_fp8: head dim %d > 160", P.D);
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" int fmc_temporal_attn_fp8_fwd(const void* q, const void* k, const void* v, void* o, const void* scales,
+                                         int n_clips, int n_pix, int F, int H, int D, int64_t clip_stride,
+                                         int64_t frame_stride, int64_t pix_stride, int64_t o_clip_stride,
+                                         int64_t o_frame_stride, int64_t o_pix_stride, float scale, void* stream) {
+    if (!q || !k || !v || !o || !scales) FMC_FAIL(FMC_E_NULL, "temporal_attn_fp8: NULL tensor");
+    if (n_clips <= 0 || n_pix <= 0 || H <= 0 || D <= 0 || D % 8 || D > 160 || (F != 16 && F != 32))
+        FMC_FAIL(FMC_E_SHAPE, "temporal_attn_fp8: need F in {16,32}, D%%8==0, D<=160 (F=%d H=%d D=%d)", F, H, D);
+    const int64_t strides[] = {clip_stride, frame_stride, pix_stride};
+    for (int64_t s : strides)
+        if (s % 16) FMC_FAIL(FMC_E_ALIGN, "temporal_attn_fp8: q/k/v strides must be multiples of 16 bytes");
+    const int64_t ostrides[] = {o_clip_stride, o_frame_stride, o_pix_stride};
+    for (int64_t s : ostrides)
+        if (s % 8) FMC_FAIL(FMC_E_ALIGN, "temporal_attn_fp8: o strides must be multiples of 8 elements");
+    if (!fmc_aligned16(q) || !fmc_aligned16(k) || !fmc_aligned16(v) || !fmc_aligned16(o))
+        FMC_FAIL(FMC_E_ALIGN, "temporal_attn_fp8: tensors must be 16-byte aligned");
+    TA8Params P;
+    P.q = (const unsigned char*)q; P.k = (const unsigned char*)k; P.v = (const unsigned char*)v; P.o = (bf16_t*)o;
+    P.scales = (const float*)scales;
+    P.n_clips = n_clips; P.n_pix = n_pix; P.F = F; P.H = H; P.D = D;
+    int gh = 1;                        // head group: GH*D channels <= 320 and a multiple of 16 bytes per staged row
+    for (int g = 1; g <= H; ++g)
+        if (H % g == 0 && g * D <= 320 && (g * D) % 16 == 0) gh = g;
+    if ((gh * D) % 16) FMC_FAIL(FMC_E_SHAPE, "temporal_attn_fp8: no head group with (GH*D) %% 16 == 0 (H=%d D=%d)", H, D);
+    P.GH = gh;
+    P.cs = clip_stride; P.fs = frame_stride; P.ps = pix_stride;
+    P.ocs = o_clip_stride; P.ofs = o_frame_stride; P.ops = o_pix_stride;
+    P.scale_log2 = scale * LOG2E;
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = F == 16 ? dispatch_ta8<1>(P, st) : dispatch_ta8<2>(P, st);
+    if (rc) return rc;
+    FMC_CHECK_LAUNCH("fmc_temporal_attn_fp8_fwd");
+    return 0;
+}
+
+extern "C" int fmc_temporal_attn_fp8_bwd(const void* q, const void* k, const void* v, const void* scales, const void* d_o,
+                                         void* dq, void* dk, void* dv, int n_clips, int n_pix, int F, int H, int D,
+                                         int64_t clip_stride, int64_t frame_stride, int64_t pix_stride,
+                                         int64_t do_clip_stride, int64_t do_frame_stride, int64_t do_pix_stride,
+                                         int64_t dq_clip_stride, int64_t dq_frame_stride, int64_t dq_pix_stride, float scale,
+                                         void* stream) {
+    if (!q || !k || !v || !scales || !d_o || !dq || !dk || !dv) FMC_FAIL(FMC_E_NULL, "temporal_attn_fp8_bwd: NULL tensor");
+    if (n_clips <= 0 || n_pix <= 0 || H <= 0 || D <= 0 || D % 8 || D > 160 || (F != 16 && F != 32))
+        FMC_FAIL(FMC_E_SHAPE, "temporal_attn_fp8_bwd: need F in {16,32}, D%%8==0, D<=160 (F=%d H=%d D=%d)", F, H, D);
+    const int64_t strides[] = {clip_stride, frame_stride, pix_stride, do_clip_stride, do_frame_stride, do_pix_stride,
+                               dq_clip_stride, dq_frame_stride, dq_pix_stride};
+    for (int64_t s : strides)
+        if (s % 8) FMC_FAIL(FMC_E_ALIGN, "temporal_attn_fp8_bwd: strides must be multiples of 8");
+    TABwdParams P;
+    P.q = q; P.k = k; P.v = v; P.d_o = d_o; P.dq = dq; P.dk = dk; P.dv = dv;
+    P.n_clips = n_clips; P.n_pix = n_pix; P.F = F; P.H = H; P.D = D;
+    int gh = 1;
+    for (int g = 1; g <= H; ++g)
+        if (H % g == 0 && g * D <= 320 && 7 * (size_t)F * (g * D + 8) * 2 <= 150 * 1024) gh = g;
+    if (7 * (size_t)F * (gh * D + 8) * 2 > 160 * 1024) FMC_FAIL(FMC_E_SHAPE, "temporal_attn_fp8_bwd: F=%d D=%d does not fit LDS", F, D);
+    P.GH = gh;
+    P.cs = clip_stride; P.fs = frame_stride; P.ps = pix_stride;          // bytes = elements for the e4m3 inputs
+    P.ocs = do_clip_stride; P.ofs = do_frame_stride; P.ops = do_pix_stride;
+    P.dcs = dq_clip_stride; P.dfs = dq_frame_stride; P.dps = dq_pix_stride;
+    P.scale = scale; P.scale_log2 = scale * LOG2E;
+    P.q8_scales = (const float*)scales;
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = F == 16 ? dispatch_ta_bwd_k<bf16_t, 1>(P, st) : dispatch_ta_bwd_k<bf16_t, 2>(P, st);
+    if (rc) return rc;
+    FMC_CHECK_LAUNCH("fmc_temporal_attn_fp8_bwd");
     return 0;
 }

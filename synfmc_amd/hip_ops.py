@@ -443,6 +443,114 @@ def _temporal_attention_raw(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, h
 
 
 # --------------------------------------------------------------------------------------------
+# fp8 (e4m3) temporal attention: QKV projection with an fp8 epilogue + attention on fp8 MFMA (BASELINE configs[4])
+# --------------------------------------------------------------------------------------------
+FP8_MAX = 448.0
+
+
+class Fp8QKVScales:
+    """Per-attention-module scale state for the fp8 q | k | v tensors (delayed scaling: the scales of call t come from the
+    running |max| the projection's epilogue recorded in call t - 1).  Everything lives on the device and is updated by
+    device ops only, so a captured HIP graph replays it.  `margin` leaves headroom for a max that grows between calls
+    (values beyond it saturate at +-448 * scale)."""
+
+    def __init__(self, device, margin: float = 1.25):
+        self.margin = margin
+        self.amax = torch.zeros(3, dtype=torch.float32, device=device)       # float bit patterns, written by atomicMax
+        self.scale = torch.ones(3, dtype=torch.float32, device=device)
+        self.inv_scale = torch.ones(3, dtype=torch.float32, device=device)
+        self.calibrated = False
+
+    def calibrate(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> None:
+        """First call: take the maxima from a bf16 projection."""
+        self.amax.copy_(torch.stack([q.abs().amax(), k.abs().amax(), v.abs().amax()]).float())
+        self.calibrated = True
+
+    def roll(self) -> None:
+        """scale <- margin * amax / 448, then restart the running max (device ops only)."""
+        torch.clamp(self.amax * (self.margin / FP8_MAX), min=1e-12, out=self.scale)
+        torch.reciprocal(self.scale, out=self.inv_scale)
+        self.amax.zero_()
+
+
+def linear_fp8_qkv(x: torch.Tensor, weight: torch.Tensor, scales: Fp8QKVScales) -> torch.Tensor:
+    """`x @ weight^T` -> `[..., 3C]` e4m3 bytes (torch.float8_e4m3fn), block b scaled by `scales.inv_scale[b]`; records |max|."""
+    _dev(x, weight)
+    N, Kd = weight.shape
+    assert x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.is_contiguous()
+    assert N % 192 == 0 and Kd % 64 == 0, "fp8 QKV projection needs C % 64 == 0 and K % 64 == 0"
+    M, ldx = _rows2d(x)
+    out = torch.empty(*x.shape[:-1], N, dtype=torch.float8_e4m3fn, device=x.device)
+    _lib.check(_lib.load().fmc_linear_fp8_qkv(x.data_ptr(), weight.data_ptr(), out.data_ptr(), M, N, Kd, ldx,
+                                              scales.inv_scale.data_ptr(), scales.amax.data_ptr(), _stream()),
+               "fmc_linear_fp8_qkv")
+    return out
+
+
+def _temporal_fp8_raw(qkv8: torch.Tensor, scale_dev: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
+    C = qkv8.shape[-1] // 3
+    q, k, v = qkv8[..., :C], qkv8[..., C:2 * C], qkv8[..., 2 * C:]
+    o = torch.empty(*qkv8.shape[:-1], C, dtype=torch.bfloat16, device=qkv8.device)
+    B, P, F, cs, fs, ps = _tstrides(q)
+    _, _, _, ocs, ofs, ops = _tstrides(o)
+    _lib.check(_lib.load().fmc_temporal_attn_fp8_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(),
+                                                     scale_dev.data_ptr(), B, P, F, heads, C // heads, cs, fs, ps, ocs, ofs,
+                                                     ops, float(scale), _stream()), "fmc_temporal_attn_fp8_fwd")
+    return o
+
+
+class _TemporalAttentionFp8(torch.autograd.Function):
+    """Projection (fp8 epilogue) + fp8 temporal attention as ONE autograd node: x -> o.  Backward: the attention backward
+    kernel dequantises the saved e4m3 q | k | v while staging them (straight-through w.r.t. the quantisation), writes one
+    fused bf16 dQ | dK | dV, and the projection's input gradient is `dqkv @ W` (frozen weight) -- or dW as well when the
+    weight trains (camera encoder)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, scales, heads, scale):
+        qkv8 = linear_fp8_qkv(x, weight, scales)
+        sc = scales.scale.clone()                     # the scales THIS call used (the state rolls on)
+        ctx.save_for_backward(x, weight, qkv8, sc)
+        ctx.heads, ctx.scale = heads, scale
+        return _temporal_fp8_raw(qkv8, sc, heads, scale)
+
+    @staticmethod
+    def backward(ctx, d_o):
+        x, weight, qkv8, sc = ctx.saved_tensors
+        C = qkv8.shape[-1] // 3
+        q, k, v = qkv8[..., :C], qkv8[..., C:2 * C], qkv8[..., 2 * C:]
+        d_o = d_o.contiguous()
+        dqkv = torch.empty(qkv8.shape, dtype=torch.bfloat16, device=qkv8.device)
+        dq, dk, dv = dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:]
+        B, P, F, cs, fs, ps = _tstrides(q)
+        _, _, _, ocs, ofs, ops = _tstrides(d_o)
+        _, _, _, dcs, dfs, dps = _tstrides(dq)
+        _lib.check(_lib.load().fmc_temporal_attn_fp8_bwd(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), sc.data_ptr(), d_o.data_ptr(), dq.data_ptr(), dk.data_ptr(),
+            dv.data_ptr(), B, P, F, ctx.heads, C // ctx.heads, cs, fs, ps, ocs, ofs, ops, dcs, dfs, dps, float(ctx.scale),
+            _stream()), "fmc_temporal_attn_fp8_bwd")
+        dx = torch.matmul(dqkv, weight) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.matmul(dqkv.reshape(-1, dqkv.shape[-1]).t(), x.reshape(-1, x.shape[-1]))
+        return dx, dw, None, None, None
+
+
+def temporal_attention_fp8(x: torch.Tensor, weight: torch.Tensor, scales: Fp8QKVScales, heads: int, scale: float):
+    """o = temporal_attention(split(x @ W_qkv^T)) with e4m3 q | k | v (native `[B, F, P, C]` tokens or `[N, F, C]`).
+    The first call on a fresh `scales` runs the bf16 path once to calibrate the maxima."""
+    if not scales.calibrated:
+        with torch.no_grad():
+            qkv = linear(x.detach(), weight.detach())
+            C = qkv.shape[-1] // 3
+            scales.calibrate(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:])
+    scales.roll()
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+        return _TemporalAttentionFp8.apply(x, weight, scales, heads, scale)
+    qkv8 = linear_fp8_qkv(x, weight, scales)
+    return _temporal_fp8_raw(qkv8, scales.scale, heads, scale)
+
+
+# --------------------------------------------------------------------------------------------
 # conditioning
 # --------------------------------------------------------------------------------------------
 def plucker(K: torch.Tensor, c2w: torch.Tensor, H: int, W: int, layout: str = "bfhwc",
@@ -714,6 +822,9 @@ _calls = {}         # key -> eager calls seen (graph replays do not pass through
 # FMC_AUTOTUNE=0: never time anything -- unseen shapes take the static rule (reproducible arm choice for tests / goldens:
 # split-K and stream-K arms change the summation order, so a timing-dependent choice changes low-order bits run to run)
 AUTOTUNE = os.environ.get("FMC_AUTOTUNE", "1") != "0"
+# FMC_DETERMINISTIC=1: the vendor convolution arm is never chosen (MIOpen's small-image 3x3 kernels accumulate with atomics:
+# bit-different results run to run, measured on the 4x4 level of the camera encoder); every fmc_* kernel is deterministic
+DETERMINISTIC = os.environ.get("FMC_DETERMINISTIC", "0") == "1"
 # The measured table persists on disk, keyed by the sha256 of the library build and the device name: a second process
 # (the next sampling run, every rank of a multi-GPU job) starts tuned and picks the SAME arms.  FMC_AUTOTUNE_CACHE=path
 # moves the file, FMC_AUTOTUNE_CACHE=0 disables persistence.
@@ -791,6 +902,8 @@ atexit.register(_save_at_exit)
 GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 11,     # 8..10, 12 (4-stage rings) exist but never won on the FMC shapes
               13,                            # the 8-phase 256x256 kernel (staggered wave rows, half-tile DMA, counted vmcnt)
               128 + 2, 128 + 3)              # stream-K (persistent workgroups) on the two 1-per-CU geometries
+if os.environ.get("FMC_GEMM_ARMS"):              # A/B switch: the arm list the autotuner may choose from, e.g. "1,2,3,11"
+    GEMM_TILES = tuple(int(a) for a in os.environ["FMC_GEMM_ARMS"].split(","))
 # fmc_linear_bf16 / fmc_conv3x3_bf16 `tile` arms tried per shape (14 = arm 13 with a deeper prefetch and 128 + 13 = its
 # stream-K form measured no better anywhere, tools/probe_g8.py)
 
@@ -837,12 +950,15 @@ def _pick(key, hip_fn, lib_fn, static_hip: bool, extra_arms=()) -> int:
     """0 = vendor library arm, 1..6 = fused gfx950 kernel with that tile geometry (`hip_fn(tile)`)."""
     if not _cache_state["loaded"]:
         load_autotune_table()
+    no_lib = DETERMINISTIC and key[0] == "conv"
+    if no_lib:
+        key = key + ("det",)
     use = _choice.get(key)
     _calls[key] = _calls.get(key, 0) + 1
     if use is None:
         if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
-            return 0 if not static_hip else -1          # -1: kernel's own geometry heuristic
-        times = [(_time_ms(lib_fn), 0)] + [(_time_ms(lambda t=t: hip_fn(t)), t) for t in GEMM_TILES + tuple(extra_arms)]
+            return 0 if not (static_hip or no_lib) else -1          # -1: kernel's own geometry heuristic
+        times = ([] if no_lib else [(_time_ms(lib_fn), 0)]) + [(_time_ms(lambda t=t: hip_fn(t)), t) for t in GEMM_TILES + tuple(extra_arms)]
         use = min(times)[1]
         _choice[key] = use
         _tune_log[key] = {arm: round(ms, 4) for ms, arm in times}

@@ -43,7 +43,13 @@ def _attention_core(attn, q_in: torch.Tensor, kv_in: Optional[torch.Tensor], tem
     heads = attn.heads
     w_a, w_b, w_o = attn.fused_weights(lora, lora_scale)
     c = attn.inner_dim
-    if kv_in is None:                                   # self attention: one [.., 3C] GEMM
+    fp8 = attn.__dict__.get("_fp8_scales") if (temporal and kv_in is None) else None
+    if (fp8 is not None and q_in.is_cuda and q_in.dtype == torch.bfloat16 and w_a.dtype == torch.bfloat16
+            and q_in.is_contiguous() and c % 64 == 0 and q_in.shape[-3 if q_in.ndim == 4 else -2] in (16, 32)):
+        # fp8 temporal attention (BASELINE configs[4]): the projection's epilogue emits e4m3 q | k | v with per-tensor
+        # scales, QK^T runs on the fp8 MFMA -- one autograd node from the normed tokens to the attention output
+        o = K.temporal_attention_fp8(q_in, w_a if w_a.is_contiguous() else w_a.contiguous(), fp8, heads, attn.scale)
+    elif kv_in is None:                                 # self attention: one [.., 3C] GEMM
         qkv = linear_op(q_in, w_a)
         o = K.self_attention_qkv(qkv, heads, attn.scale, temporal)      # q | k | v stay slices of the fused output
     else:                                               # cross attention: q GEMM + one [.., 2C] kv GEMM

@@ -33,6 +33,23 @@ class TemporalTransformer3DModelOutput:
         self.sample = sample
 
 
+def enable_fp8_temporal_attention(module: nn.Module, enabled: bool = True, margin: float = 1.25) -> int:
+    """Switch every `TemporalSelfAttention` under `module` (U-Net motion modules, camera encoder) to the fp8 path
+    (BASELINE.json configs[4]): e4m3 q | k | v from the QKV projection's epilogue with per-tensor delayed scaling, QK^T on the
+    fp8 MFMA (`fmc_linear_fp8_qkv`, `fmc_temporal_attn_fp8_fwd/_bwd`).  Returns the number of attention modules switched.
+    bf16 activations only; modules whose width is not a multiple of 64 keep the bf16 kernel."""
+    n = 0
+    for m in module.modules():
+        if isinstance(m, TemporalSelfAttention):
+            if enabled:
+                dev = next(m.parameters()).device
+                m.__dict__["_fp8_scales"] = K.Fp8QKVScales(dev, margin)
+            else:
+                m.__dict__.pop("_fp8_scales", None)
+            n += 1
+    return n
+
+
 def get_motion_module(in_channels, motion_module_type: str, motion_module_kwargs: dict):
     if motion_module_type == "Vanilla":
         return VanillaTemporalModule(in_channels=in_channels, **motion_module_kwargs)

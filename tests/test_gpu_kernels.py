@@ -242,6 +242,84 @@ def test_temporal_attention_at_bench_size(K, dtype, Fr, P, H, D):
     assert rel_inf(got.float(), ref) < TOL[dtype]
 
 
+# ---- fp8 (e4m3) temporal attention: BASELINE.json configs[4] -------------------------------------------------------------
+def _quant(x, scale):
+    """per-tensor e4m3 quantisation as the projection epilogue does it: sat(x / scale) -> float8_e4m3fn"""
+    return (x.float() / scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+
+
+@pytest.mark.parametrize("M,C,Kd", [(4100, 320, 320), (2048, 640, 640), (700, 64, 128)])
+def test_linear_fp8_qkv_epilogue(K, M, C, Kd):
+    """The fused q | k | v projection with the e4m3 epilogue against `quant((x @ W^T) / scale_block)` computed by torch
+    from the SAME bf16 operands, and the running |max| per block it records."""
+    xo, xd = rnd((M, Kd), 70, torch.bfloat16)
+    w = torch.randn(3 * C, Kd, generator=torch.Generator().manual_seed(71)) * Kd ** -0.5
+    w[C:2 * C] *= 3.0                                                        # three different ranges -> three different scales
+    wo, wd = w.bfloat16().float(), w.bfloat16().cuda()
+    ref = F.linear(xo, wo)                                                    # fp32 accumulate of the bf16 values
+    sc = K.Fp8QKVScales(xd.device, margin=1.25)
+    blocks = [ref[:, i * C:(i + 1) * C] for i in range(3)]
+    sc.calibrate(*[b.cuda() for b in blocks])
+    sc.roll()
+    out = K.linear_fp8_qkv(xd, wd, sc)
+    assert out.dtype == torch.float8_e4m3fn and out.shape == (M, 3 * C)
+    amax = sc.amax.cpu()
+    for i, b in enumerate(blocks):
+        assert abs(float(amax[i]) - float(b.abs().max())) < 2e-3 * float(b.abs().max())      # max |acc| of this call
+        s = float(sc.scale[i])
+        assert abs(s - 1.25 * float(b.abs().max()) / 448.0) < 1e-5 * s
+        got = out[:, i * C:(i + 1) * C].float().cpu() * s
+        want = _quant(b, s).float() * s
+        exact = (got == want).float().mean().item()
+        assert exact > 0.98, exact                                            # (ties at a rounding boundary may flip: other summation order)
+        # never more than one e4m3 step (2^-3 of the value's binade) apart
+        assert ((got - want).abs() <= 0.13 * torch.maximum(got.abs(), want.abs()).clamp_min(s * 2 ** -6)).all()
+
+
+@pytest.mark.parametrize("B,Fr,P,H,D", [(2, 16, 20, 8, 40), (1, 32, 6, 8, 40), (1, 32, 3, 8, 160), (1, 16, 9, 8, 80),
+                                        (2, 16, 7, 8, 8), (2, 32, 4096, 8, 40)])
+def test_temporal_attention_fp8_forward(K, B, Fr, P, H, D):
+    """fp8 temporal attention against the oracle evaluated on the SAME e4m3-rounded q, k, v (so the bound is the bf16
+    kernel's: bf16 rounding of P and O, 1e-2) -- incl. the level-0 shape of BASELINE configs[4] (32 frames, 64x64 latent)."""
+    C = H * D
+    g = torch.Generator().manual_seed(72)
+    qkv = torch.randn(B, Fr, P, 3 * C, generator=g)
+    qkv[..., C:2 * C] *= 2.0
+    scales = torch.tensor([qkv[..., :C].abs().max(), qkv[..., C:2 * C].abs().max(), qkv[..., 2 * C:].abs().max()]) * 1.25 / 448.0
+    q8 = torch.cat([_quant(qkv[..., i * C:(i + 1) * C], float(scales[i])) for i in range(3)], dim=-1)
+    deq = torch.cat([q8[..., i * C:(i + 1) * C].float() * float(scales[i]) for i in range(3)], dim=-1)
+    ref_in = deq.permute(0, 2, 1, 3).reshape(B * P, Fr, 3 * C)
+    ref = oracle_attention(ref_in[..., :C], ref_in[..., C:2 * C], ref_in[..., 2 * C:], H)
+    out = K._temporal_fp8_raw(q8.cuda(), scales.cuda(), H, D ** -0.5)
+    got = out.permute(0, 2, 1, 3).reshape(B * P, Fr, C)
+    assert out.dtype == torch.bfloat16 and rel_inf(got.float(), ref) < 1e-2
+
+
+def test_temporal_attention_fp8_autograd(K):
+    """x -> (QKV projection, e4m3 epilogue) -> fp8 attention as one autograd node: output and input / weight gradients
+    against torch autograd through `quantise (straight-through) -> softmax attention` on the same operands."""
+    B, Fr, P, H, D = 1, 16, 12, 8, 40
+    C = H * D
+    xo, xd = rnd((B, Fr, P, C), 73, torch.bfloat16)
+    wo, wd = rnd((3 * C, C), 74, torch.bfloat16, scale=C ** -0.5)
+    do, dd = rnd((B, Fr, P, C), 75, torch.bfloat16)
+    sc = K.Fp8QKVScales(xd.device)
+    xg, wg = xd.clone().requires_grad_(True), wd.clone().requires_grad_(True)
+    out = K.temporal_attention_fp8(xg, wg, sc, H, D ** -0.5)                 # (first call calibrates from a bf16 projection)
+    out.backward(dd)
+    scales = sc.scale.cpu()
+    xr, wr = xo.clone().requires_grad_(True), wo.clone().requires_grad_(True)
+    qkv = F.linear(xr, wr)
+    deq = torch.cat([_quant(qkv[..., i * C:(i + 1) * C].detach(), float(scales[i])).float() * float(scales[i]) for i in range(3)], -1)
+    qkv_ste = qkv + (deq - qkv).detach()                                      # straight-through estimator
+    t = qkv_ste.permute(0, 2, 1, 3).reshape(B * P, Fr, 3 * C)
+    ref = oracle_attention(t[..., :C], t[..., C:2 * C], t[..., 2 * C:], H).reshape(B, P, Fr, C).permute(0, 2, 1, 3)
+    ref.backward(do)
+    assert rel_inf(out.float(), ref) < 2e-2           # (+ fp8 ties of the projection output flipping against torch's summation order)
+    assert rel_inf(xg.grad.float(), xr.grad) < 3e-2
+    assert rel_inf(wg.grad.float(), wr.grad) < 3e-2
+
+
 # ---------------------------------------------------------------------------------------------
 def test_plucker_against_golden_and_oracle(K, golden_dir):
     import os

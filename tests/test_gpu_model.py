@@ -303,13 +303,15 @@ def test_animation_pipeline_multidiff_windows():
         pipe(None, 16, height=60, width=64, prompt_embeds=text2.cuda(), output_type="latent")
 
 
-def test_pipeline_graph_reuse_across_clips(stack):
+def test_pipeline_graph_reuse_across_clips(stack, monkeypatch):
     """The captured HIP graphs stay on the pipeline: a second clip of the same shape refills the static text / camera /
     OMC buffers and recomputes the Camera-Adapter pose terms in place (bf16 fast path), without a new capture."""
     from synfmc_amd.pipelines.pipeline_animation_cm_om import CameraObjCtrlPipeline
     from synfmc_amd.schedulers import DDIMScheduler
     kw = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1,
               clip_sample=False)
+    from synfmc_amd import hip_ops as K
+    monkeypatch.setattr(K, "DETERMINISTIC", True)      # no MIOpen arm (atomics: bit-different run to run): exact comparisons below
     pu, pe, pa = CM.build_product(stack["ou"], stack["oe"], stack["oa"], W4, dtype=torch.bfloat16)
     pipe = CameraObjCtrlPipeline(None, None, None, pu, DDIMScheduler(**kw), pe)
     clip_a = stack["clip"]
@@ -330,11 +332,9 @@ def test_pipeline_graph_reuse_across_clips(stack):
     assert rel_inf(refs[1], refs[0]) > 0.05                          # the clips differ
     for o, r in zip(outs, refs):
         assert rel_inf(o, r) < 8e-2
-    # the same clip through the same graph after another clip used it: bit-identical (no stale per-clip state).  The very
-    # first call is excluded from the exact comparison: the vendor-library convolutions of the camera encoder may pick
-    # another algorithm on their first (find-mode) call than on later ones
+    # the same clip through the same graph after another clip used it: bit-identical (no stale per-clip state)
     assert rel_inf(outs[3], outs[1]) < 1e-6
-    assert rel_inf(outs[2], outs[0]) < 5e-2
+    assert rel_inf(outs[2], outs[0]) < 1e-6
 
 
 # ---- a11: LORAPoseAdaptorAttnProcessor (attention_processor.py:296-420) ------------------------------------------------
@@ -375,3 +375,49 @@ def test_lora_pose_adaptor_processor_forward_and_gradients(stack, dtype, tol, gt
     assert abs(float(l_ref) - float(l_got)) < (1e-4 if dtype == torch.float32 else 2e-2) * abs(float(l_ref))
     err, scale = TC.compare(g_ref, g_got)
     assert scale > 0 and err < gtol
+
+
+# ---- BASELINE configs[4]: 32 frames, fp8 temporal attention, training step -----------------------------------------------
+def test_fp8_temporal_attention_frames32_forward_and_training():
+    """BASELINE.json configs[4] shape class on the reduced stack: 32-frame clip, CMC + OMC, every temporal attention (U-Net
+    motion modules and camera encoder) on the fp8 path -- e4m3 q | k | v out of the QKV projection epilogue with per-tensor
+    delayed scaling, QK^T on the fp8 MFMA.  Forward and stage-3 (Adapter) gradients against the fp32 oracle.  Stated
+    bounds: forward 6e-2, gradients 1e-1 rel-inf (measured 2.3e-2 / 1.0e-2; e4m3 carries 3 mantissa bits, 6 % per element on
+    q, k and v of 48 attention layers, next to the bf16 path's measured 1.6e-2 / 1.2e-2 on the same case)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tests import training_common as TC
+    from synfmc_amd.models.motion_module import enable_fp8_temporal_attention
+    from synfmc_amd.models.pose_obj_adaptor import CamObjPoseAdaptor
+    from synfmc_amd.util import get_traj_features_v2
+    dtype = torch.bfloat16
+    ou, oe, oa = CM.build_oracle(W4, seed=30, fan_in_gain=0.7, enc_max_len=32)
+    clip = CM.synthetic_clip(B=1, Fr=32, H=128, W=128, seed=130)
+    with torch.no_grad():
+        pose_emb = rearrange(OC.to_plucker_embedding(clip["c2w"], clip["K"], (128, 128)), "b f c h w -> b c f h w")
+        pose_feats = [rearrange(x, "(b f) c h w -> b c f h w", b=1) for x in oe(pose_emb)]
+        traj = OC.get_traj_features(clip["infos"], clip["masks"], oa)
+        t = torch.tensor([801])
+        ref = ou(clip["latents"], t, clip["text"], pose_embedding_features=pose_feats, traj_features=traj).sample
+    pu, pe, pa = CM.build_product(ou, oe, oa, W4, dtype=dtype, enc_max_len=32)
+    noise = torch.randn(clip["latents"].shape, generator=torch.Generator().manual_seed(12))
+    l_ref, g_ref = TC.oracle_grads(ou, oe, oa, clip, pose_emb, t, noise)
+    pa32 = pa.float()
+    res = {}
+    for fp8 in (False, True):
+        n = enable_fp8_temporal_attention(pu, fp8) + enable_fp8_temporal_attention(pe, fp8)
+        assert n == 40 + 8
+        with torch.no_grad():
+            tf = get_traj_features_v2(clip["infos"], clip["masks"], pa, False, 0.0, [False], "cuda", dtype)
+            for _ in range(2):                        # second call: scales from the first call's recorded maxima
+                out = CamObjPoseAdaptor(pu, pe)(clip["latents"].cuda().to(dtype), t.cuda(), clip["text"].cuda().to(dtype),
+                                                pose_emb.cuda().to(dtype), tf)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            l_got, g_got = TC.product_grads(pu, pe, pa32, clip, pose_emb, t, noise, "cuda", dtype)
+        err_g, scale = TC.compare(g_ref, g_got)
+        res[fp8] = (rel_inf(out.float(), ref), err_g, abs(float(l_ref) - float(l_got)) / abs(float(l_ref)))
+        print(f"fp8 temporal attention {'ON ' if fp8 else 'off'}: forward rel-inf {res[fp8][0]:.3e}, Adapter-gradient rel-inf "
+              f"{res[fp8][1]:.3e}, loss rel {res[fp8][2]:.3e}")
+    assert res[True][0] < 6e-2 and res[True][1] < 1e-1 and res[True][2] < 1e-2
+    assert res[False][0] < 6e-2 and res[False][1] < 1.5e-1
+    assert any(m.__dict__.get("_fp8_scales") is not None and m.__dict__["_fp8_scales"].calibrated for m in pu.modules())
