@@ -528,7 +528,9 @@ class _TemporalAttentionFp8(torch.autograd.Function):
             q.data_ptr(), k.data_ptr(), v.data_ptr(), sc.data_ptr(), d_o.data_ptr(), dq.data_ptr(), dk.data_ptr(),
             dv.data_ptr(), B, P, F, ctx.heads, C // ctx.heads, cs, fs, ps, ocs, ofs, ops, dcs, dfs, dps, float(ctx.scale),
             _stream()), "fmc_temporal_attn_fp8_bwd")
-        dx = torch.matmul(dqkv, weight) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:                  # frozen weight: own GEMM on the cached W^T; a training weight: plain matmul
+            dx = torch.matmul(dqkv, weight) if weight.requires_grad else linear_backward_data(dqkv, weight)
         dw = None
         if ctx.needs_input_grad[1]:
             dw = torch.matmul(dqkv.reshape(-1, dqkv.shape[-1]).t(), x.reshape(-1, x.shape[-1]))
@@ -1089,6 +1091,26 @@ def conv3x3_frozen(x, weight_cl, bias, temb=None, residual=None, temb_div: int =
     return _Conv3x3Frozen.apply(x, weight_cl, bias, temb, residual, temb_div)
 
 
+def _transposed_weight(weight: torch.Tensor) -> torch.Tensor:
+    """`W^T [K, N]` contiguous, cached ON the frozen weight (keyed by its version counter, like `_flipped_filter`): the
+    backward-data GEMM `dX = dY @ W` is `fmc_linear_bf16(dY, W^T)` -- both operands reduction-contiguous."""
+    hit = getattr(weight, "_fmc_wt", None)
+    if hit is None or hit[0] != weight._version:
+        hit = (weight._version, weight.detach().t().contiguous())
+        weight._fmc_wt = hit
+    return hit[1]
+
+
+def linear_backward_data(dy: torch.Tensor, weight: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
+    """`alpha * dY @ W` for a frozen `W [N, K]` on the fused gfx950 GEMM (autotuned like every projection)."""
+    if dy.is_cuda and dy.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.shape[0] % 64 == 0 \
+            and weight.shape[1] % 8 == 0:
+        with torch.no_grad():
+            return linear(dy if dy.is_contiguous() else dy.contiguous(), _transposed_weight(weight), None, None, alpha)
+    dx = torch.matmul(dy, weight)
+    return dx if alpha == 1.0 else dx * alpha
+
+
 class _LinearFrozen(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, alpha):
@@ -1101,14 +1123,49 @@ class _LinearFrozen(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (weight,) = ctx.saved_tensors
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.matmul(dy, weight)                 # [.., N] @ [N, K]
-            if ctx.alpha != 1.0:
-                dx = dx * ctx.alpha
+        dx = linear_backward_data(dy, weight, ctx.alpha) if ctx.needs_input_grad[0] else None
         return dx, None, None, (dy if ctx.has_res else None), None
 
 
 def linear_frozen(x, weight, bias=None, residual=None, alpha: float = 1.0):
     """`alpha * (x @ W^T + b) + residual` with frozen W, b; differentiable w.r.t. x and the residual."""
     return _LinearFrozen.apply(x, weight, bias, residual, alpha)
+
+
+class _Conv3x3Trainable(torch.autograd.Function):
+    """3x3 / stride 1 / pad 1 conv whose FILTER trains (OMC Adapter, camera encoder): forward and backward-data on the fused
+    gfx950 implicit-GEMM kernel (the filter is re-laid-out / flipped per step: it changes every step and is small next to
+    the activations); the weight gradient -- a reduction over pixels with both operands pixel-major -- is the one piece
+    still computed by the vendor library (`aten::convolution_backward`, MIOpen wrw), see DESIGN.md."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        with torch.no_grad():
+            w_cl = weight.detach().to(x.dtype).contiguous(memory_format=torch.channels_last)
+            b = None if bias is None else bias.detach().to(x.dtype)
+            return conv3x3(x, w_cl, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = dw = db = None
+        with torch.no_grad():
+            if ctx.needs_input_grad[0]:
+                w_flip = weight.detach().to(dy.dtype).flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
+                dx = conv3x3(dy, w_flip, None)
+            if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+                _, dw, db = torch.ops.aten.convolution_backward(
+                    dy, x, weight.to(x.dtype), [weight.shape[0]] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False,
+                    [0, 0], 1, [False, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]])
+                if dw is not None:
+                    dw = dw.to(weight.dtype)
+                if db is not None:
+                    db = db.to(weight.dtype)
+        return dx, dw, (db if ctx.has_bias else None)
+
+
+def conv3x3_trainable(x, weight, bias=None):
+    return _Conv3x3Trainable.apply(x, weight, bias)

@@ -102,6 +102,12 @@ class Conv2d(nn.Conv2d):
                 and self.in_channels % 64 == 0 and self.out_channels % 64 == 0):
             # frozen filter, activation gradient only (training stages 2-3): forward and backward-data on the gfx950 kernel
             return K.conv3x3_frozen(x, self._weight_cl(), self.bias, temb, residual, temb_div)
+        if (needs_grad and not upsample and temb is None and residual is None and self.kernel_size == (3, 3)
+                and self.stride == (1, 1) and self.padding == (1, 1) and self.dilation == (1, 1) and self.groups == 1
+                and x.is_cuda and x.dtype == torch.bfloat16 and self.in_channels % 64 == 0 and self.out_channels % 64 == 0
+                and self.weight.requires_grad):
+            # trainable filter under bf16 autocast (OMC Adapter / camera encoder): forward + backward-data on the gfx950 kernel
+            return K.conv3x3_trainable(x, self.weight, self.bias)
         if self.kernel_size == (3, 3) and self.dilation == (1, 1) and self.groups == 1 and x.is_cuda and not needs_grad:
             return K.conv3x3(x, self._weight_cl(), self.bias, temb, residual, self.stride, self.padding, temb_div,
                              upsample)
