@@ -60,6 +60,7 @@ struct GemmParams {
     int sk;                           // stream-K: grid = sk persistent workgroups (a multiple of 8), each owning a
     int* sk_flags;                    //   contiguous range of (tile, k-tile) iterations; ws[block][BM][BN] partials
     int64_t sk_ws_bytes;
+    int sk_maxseg;                    // 8-phase stream-K: workspace slots per workgroup (segments it may own)
     int64_t a_bytes;                  // 8-phase kernel: size of the A operand in bytes (buffer descriptor range)
     const float* q8_inv;              // EPI 2 (fp8 e4m3 output, three equal column blocks q | k | v): 1 / scale per block (device)
     unsigned* q8_amax;                // EPI 2: running max |value| per block as float bits (device, atomicMax), may be NULL
@@ -708,7 +709,7 @@ void gemm_kernel(const GemmParams P) {
 //   * fragments per wave and k-tile: 16 A + 8 W ds_read_b128 (24 KiB) instead of 2 x 16 KiB x 4 re-reads.
 // WAR: slot(h) is re-filled at LOAD(h - PF); its previous content (h - 8) was last read at LOAD(h - 8) of the LATER wave row,
 // retired by that row's lgkmcnt(0) one segment on: safe for PF <= 6.
-template <int MODE, int EPI, int PF, bool SK>
+template <int MODE, int EPI, int PF, int ROLE>
 __global__ __launch_bounds__(512, 2)
 void gemm8_kernel(const GemmParams P) {
     constexpr int BM = 256, BN = 256, BK = 64, NT = 512;
@@ -721,15 +722,21 @@ void gemm8_kernel(const GemmParams P) {
     const int wr = wave >> 2, wc = wave & 3;
 
     const int nkt = P.K / BK;
-    // stream-K (SK): P.sk persistent workgroups (one per CU); the (tile, k-tile) iteration space of every XCD group is cut
-    // into equal contiguous ranges -- the index arithmetic, the hand-over protocol (owner = holder of a tile's FIRST k-tiles,
-    // reached at the END of its range; the other shares are produced at the START of theirs; sc0 sc1 payload + relaxed
-    // agent-scope flags; a workgroup only ever waits for lower block ids) are gemm_kernel's.  What differs: the fp32
-    // partials travel in ACCUMULATOR layout (slot[wave][register quad][lane] x 16 B: every store / load instruction moves one
-    // contiguous KiB), because producer and owner are the same code with the same lane <-> element map -- no LDS round.
+    // ROLE 0: plain grid, one output tile per workgroup (main loop + epilogue).
+    // ROLE 1 + ROLE 2: stream-K as TWO launches.  ROLE 1 = P.sk persistent workgroups (one per CU); the (tile, k-tile) iteration
+    // space of every XCD group is cut into equal contiguous ranges, one per workgroup, so every CU does the same number of
+    // k-tiles whatever tiles / CUs is; every segment (= the part of one tile inside my range) leaves its fp32 accumulators in a
+    // workspace slot in ACCUMULATOR layout (slot[wave][register quad][lane] x 16 B: every store moves one contiguous KiB) and
+    // nothing else -- no epilogue code, no flags, no spinning.  ROLE 2 = one workgroup per output tile: it sums the slots of
+    // the segments that cover its tile (same lane <-> element map, so the sum lands in accumulator registers) and runs the normal
+    // epilogue.  The kernel boundary is the synchronisation; the summation order is fixed.  (A single persistent kernel that
+    // also finishes the tiles -- built first -- left the register allocator with two live versions of the 128 accumulators
+    // around the segment loop: 350-800 spilled registers, +22 us per launch.)  Costs 2 x M x N x 4 bytes of extra traffic:
+    // the arm for small outputs with a long reduction (the 10x16 / 5x8-level convolutions, M*N <= ~8 M elements).
+    constexpr bool SK = ROLE == 1;
     int64_t sk_it = 0, sk_end = 0, sk_gbase = 0, sk_I = 0;
-    int sk_r = 0, sk_per = 1;
-    if (SK) {
+    int sk_r = 0, sk_per = 1, sk_first = 0;
+    if (ROLE == 1) {
         const int T = P.tiles_m * P.tiles_n, x = blockIdx.x & 7, q = blockIdx.x >> 3;
         sk_per = P.sk >> 3;
         const int tg0 = (int)((int64_t)T * x / 8), tg1 = (int)((int64_t)T * (x + 1) / 8);
@@ -738,42 +745,75 @@ void gemm8_kernel(const GemmParams P) {
         sk_r = sk_per - 1 - q;
         sk_it = sk_gbase + sk_I * sk_r / sk_per;
         sk_end = sk_gbase + sk_I * (sk_r + 1) / sk_per;
+        sk_first = (int)(sk_it / nkt);
     }
     const __amdgpu_buffer_rsrc_t rsP = sk_rsrc(P.ws);
     f32x16 acc[2][4];                                 // [ni][mi]: rows = n (registers), cols = m (lanes); zeroed right before the k loop
     bf16x8 wf[2][4], af[2][4];                        // W fragments of both 32-column halves; A fragments of the current 64-row half
-    for (;;) {                                       // one pass per segment (exactly one without stream-K)
-    // Every per-lane index of a segment derives from a thread id the optimiser cannot see through: otherwise LICM hoists the
-    // whole epilogue's address arithmetic out of the persistent loop, keeps ~300 values alive across the main loop and
-    // spills them (the stream-K instantiations then need scratch memory, which costs ~30 us per LAUNCH).
+    for (;;) {                                       // one pass per segment (exactly one for ROLE 0 / 2)
     int tid = threadIdx.x;
-    if (SK) asm volatile("" : "+v"(tid));
+    if (SK) asm volatile("" : "+v"(tid));            // (per-lane indices of a segment must not be hoisted out of the persistent loop)
     const int lane = tid & 63;
     const int l31 = lane & 31, half = lane >> 5;
     const int prow = lane >> 3, pch = lane & 7;      // my row / 16-byte chunk inside a 1-KiB DMA piece (8 rows x 128 B)
-    int tile_m, tile_n, kt0 = 0, nk = nkt, sk_np = 0;
-    bool sk_partial = false;
-    if (SK) {
+    int tile_m, tile_n, kt0 = 0, nk = nkt, sk_slot = 0;
+    if (ROLE == 1) {
         if (sk_it >= sk_end) break;
         const int lin = (int)(sk_it / nkt);
         kt0 = (int)(sk_it - (int64_t)lin * nkt);
         nk = (int)min((int64_t)nkt, kt0 + (sk_end - sk_it));
         sk_it += nk - kt0;
+        sk_slot = blockIdx.x * P.sk_maxseg + (lin - sk_first);
         lin_to_tile(lin, P, tile_m, tile_n);
-        sk_partial = kt0 > 0;
-        if (kt0 == 0 && nk < nkt) {                   // I hold the head of a cut tile: who holds the rest?
-            const int64_t tile_end = (int64_t)(lin + 1) * nkt;
-            int64_t e = sk_end;
-            while (e < tile_end) {
-                ++sk_np;
-                e = sk_gbase + sk_I * (sk_r + 1 + sk_np) / sk_per;
-            }
-        }
     } else {
         const int total = P.tiles_m * P.tiles_n;
         const int id = blockIdx.x, q = total >> 3, r = total & 7, x = id & 7;
         const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);   // XCD x owns a contiguous range
         lin_to_tile(lin, P, tile_m, tile_n);
+        if (ROLE == 2) {
+            // the segments of ROLE 1 that cover tile `lin`: XCD group g holds tiles [T g / 8, T (g + 1) / 8); inside it range r of
+            // `per` covers iterations [I r / per, I (r + 1) / per) and was run by block (per - 1 - r) * 8 + g
+            const int T = total, per = P.sk >> 3;
+            int g = 0;
+            while ((int)((int64_t)T * (g + 1) / 8) <= lin) ++g;
+            const int tg0 = (int)((int64_t)T * g / 8), tg1 = (int)((int64_t)T * (g + 1) / 8);
+            const int64_t gbase = (int64_t)tg0 * nkt, I = (int64_t)(tg1 - tg0) * nkt;
+            const int64_t lo = (int64_t)lin * nkt - gbase, hi = lo + nkt;
+            int r0 = (int)(lo * per / I);
+            while (r0 + 1 < per && I * (r0 + 1) / per <= lo) ++r0;
+            while (r0 > 0 && I * r0 / per > lo) --r0;
+#pragma unroll
+            for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                for (int b2 = 0; b2 < 4; ++b2)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[a2][b2][e] = 0.f;
+#pragma unroll 1
+            for (int r2 = r0; r2 < per && I * r2 / per < hi; ++r2) {
+                const int64_t rs = I * r2 / per, re = I * (r2 + 1) / per;
+                if (min(re, hi) <= max(rs, lo)) continue;                    // (an empty range)
+                const int blk = (per - 1 - r2) * 8 + g;
+                const int slot = blk * P.sk_maxseg + (lin - (int)((gbase + rs) / nkt));
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) {
+                        u32x4 t[4];
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            const int quad = (wave * 8 + ni * 4 + mi) * 4 + gq;
+                            t[gq] = __builtin_amdgcn_raw_buffer_load_b128(rsP, (int)(((int64_t)slot * (BM * BN / 4) + quad * 64 + lane) * 16), 0, 0);
+                        }
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            union { u32x4 u; f32x4 f; } c;
+                            c.u = t[gq];
+                            acc[ni][mi][4 * gq] += c.f[0]; acc[ni][mi][4 * gq + 1] += c.f[1];
+                            acc[ni][mi][4 * gq + 2] += c.f[2]; acc[ni][mi][4 * gq + 3] += c.f[3];
+                        }
+                    }
+            }
+        }
     }
     const int64_t m0 = (int64_t)tile_m * BM;
     const int n0 = tile_n * BN;
@@ -941,6 +981,7 @@ void gemm8_kernel(const GemmParams P) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");                                                   \
     } while (0)
 
+    if constexpr (ROLE != 2) {
     // ---- prologue: PF half-tiles in flight, the two that phase 0 reads retired and published -----------------------------------
 #pragma unroll
     for (int h = 0; h < PF; ++h) issue(h & 3);
@@ -982,7 +1023,9 @@ void gemm8_kernel(const GemmParams P) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the wrap-around DMAs of the tail have landed: LDS is free for the epilogue
     __syncthreads();
 
-    if (SK && sk_partial) {                           // my share of a cut tile: accumulator-layout partial into my slot, then the flag
+    }  // (ROLE 2 has no main loop: its accumulators are the sums of the stored partials)
+
+    if constexpr (ROLE == 1) {                        // my segment's accumulators -> its workspace slot, accumulator layout
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -992,50 +1035,10 @@ void gemm8_kernel(const GemmParams P) {
                     union { u32x4 u; f32x4 f; } t;
                     t.f = f32x4{acc[ni][mi][4 * gq], acc[ni][mi][4 * gq + 1], acc[ni][mi][4 * gq + 2], acc[ni][mi][4 * gq + 3]};
                     const int quad = (wave * 8 + ni * 4 + mi) * 4 + gq;
-                    __builtin_amdgcn_raw_buffer_store_b128(t.u, rsP, (int)(((int64_t)blockIdx.x * (BM * BN / 4) + quad * 64 + lane) * 16), 0, SK_SC);
+                    __builtin_amdgcn_raw_buffer_store_b128(t.u, rsP, (int)(((int64_t)sk_slot * (BM * BN / 4) + quad * 64 + lane) * 16), 0, 0);
                 }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my sc1 payload stores have completed ...
-        __syncthreads();
-        if (tid == 0)                                     // ... everybody's have: raise the flag
-            __hip_atomic_store(P.sk_flags + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        continue;                                         // (the next segment's prologue only writes LDS, already released above)
     } else {
-    if (SK && sk_np > 0) {                            // owner of a cut tile: fold the other shares into my accumulators
-        if (tid == 0) {
-            for (int j = 1; j <= sk_np; ++j) {
-                const int* f = P.sk_flags + (blockIdx.x - 8 * j);
-                int spins = 0;                            // bounded: a bug must not hang the GPU
-                while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 22))
-                    __builtin_amdgcn_s_sleep(8);
-            }
-        }
-        __syncthreads();
-        for (int j = 1; j <= sk_np; ++j) {
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi) {         // one accumulator block (4 x 16 B per lane) at a time: all 32 loads in
-                    u32x4 t[4];                           // flight at once need 128 registers next to the 128 accumulators
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        const int quad = (wave * 8 + ni * 4 + mi) * 4 + gq;
-                        t[gq] = __builtin_amdgcn_raw_buffer_load_b128(rsP, (int)(((int64_t)(blockIdx.x - 8 * j) * (BM * BN / 4) + quad * 64 + lane) * 16), 0, SK_SC);
-                    }
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        union { u32x4 u; f32x4 f; } c;
-                        c.u = t[gq];
-                        acc[ni][mi][4 * gq] += c.f[0]; acc[ni][mi][4 * gq + 1] += c.f[1];
-                        acc[ni][mi][4 * gq + 2] += c.f[2]; acc[ni][mi][4 * gq + 3] += c.f[3];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-        }
-        __syncthreads();                                  // everybody has read the partials: hand the flags back as zeros
-        if (tid == 0)
-            for (int j = 1; j <= sk_np; ++j)
-                __hip_atomic_store(P.sk_flags + (blockIdx.x - 8 * j), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-
     // ---- epilogue: the output tile is staged as bf16 in LDS, 128 rows (the same 64-row half of both wave rows) per pass,
     // and leaves with whole-row 16-byte stores.  Residuals travel through the same staging rows first (whole-row 16-byte
     // loads), every lane adds its own words to its accumulators in fp32: one rounding, as in gemm_kernel.
@@ -1197,9 +1200,8 @@ void gemm8_kernel(const GemmParams P) {
     };
     pass(std::integral_constant<int, 0>{});
     pass(std::integral_constant<int, 1>{});
-    }  // (not a partial)
-    if (!SK) break;
-    __syncthreads();                                  // the staging rows alias the operand buffers of the next segment
+    break;
+    }  // (ROLE 0 / 2: epilogue)
     }  // segment loop
 }
 
@@ -1360,24 +1362,31 @@ void launch_gemm8(GemmParams& P, hipStream_t st) {
     constexpr size_t lds = staged > ring ? staged : ring;
     static bool raised = false;
     if (!raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_kernel<MODE, EPI, PF, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_kernel<MODE, EPI, PF, 0>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_kernel<MODE, EPI, PF, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_kernel<MODE, EPI, PF, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_kernel<MODE, EPI, PF, 2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         raised = true;
     }
+    const int tiles = P.tiles_m * P.tiles_n;
     if (P.sk) {
-        const int64_t iters = (int64_t)P.tiles_m * P.tiles_n * (P.K / 64);
-        const int g = fmc_cu_count() & ~7;                // one 128-KiB workgroup per CU
-        const int64_t need = (int64_t)g * 256 * 256 * (int64_t)sizeof(float) + 4096;
-        if (g >= 8 && iters >= 4 * (int64_t)g && P.sk_ws_bytes >= need && g * (int)sizeof(int) <= 4096) {
+        // stream-K = persistent main kernel (one 128-KiB workgroup per CU, partials only) + one finishing workgroup per tile
+        const int64_t iters = (int64_t)tiles * (P.K / 64);
+        const int g = fmc_cu_count() & ~7;
+        const int maxseg = (tiles + g - 1) / g + 2;       // a range of ceil(T / g) tiles' worth of k-tiles touches at most this many tiles
+        const int64_t need = (int64_t)g * maxseg * 256 * 256 * (int64_t)sizeof(float) + 4096;
+        if (g >= 8 && iters >= 2 * (int64_t)g && P.sk_ws_bytes >= need && need < ((int64_t)1 << 31)) {
             P.sk = g;
-            hipLaunchKernelGGL((gemm8_kernel<MODE, EPI, PF, true>), dim3((unsigned)g), dim3(512), lds, st, P);
+            P.sk_maxseg = maxseg;
+            hipLaunchKernelGGL((gemm8_kernel<MODE, EPI, PF, 1>), dim3((unsigned)g), dim3(512), lds, st, P);
+            hipLaunchKernelGGL((gemm8_kernel<MODE, EPI, PF, 2>), dim3((unsigned)tiles), dim3(512), lds, st, P);
             return;
         }
         P.sk = 0;                                         // too little work (or workspace): the plain grid
     }
-    hipLaunchKernelGGL((gemm8_kernel<MODE, EPI, PF, false>), dim3((unsigned)(P.tiles_m * P.tiles_n)), dim3(512), lds, st, P);
+    hipLaunchKernelGGL((gemm8_kernel<MODE, EPI, PF, 0>), dim3((unsigned)tiles), dim3(512), lds, st, P);
 }
 
 bool gemm8_ok(GemmParams& P) {

@@ -703,7 +703,7 @@ def _streamk_workspace(device):
     key = (device.index, torch.cuda.current_stream().cuda_stream)
     ws = _sk_ws.get(key)
     if ws is None:
-        ws = torch.zeros((4096 + 1024 * 256 * 256 * 4) // 4, dtype=torch.float32, device=device)
+        ws = torch.zeros((4096 + 1856 * 256 * 256 * 4) // 4, dtype=torch.float32, device=device)     # (8-phase arms: <= 7 slots per CU)
         _sk_ws[key] = ws
     return ws.data_ptr(), ws.numel() * 4
 

@@ -264,3 +264,94 @@ def test_traj_feature_batch_mismatch_raises(stack, fake):
     bad = [t[:, :, :, :-1] for t in stack["traj"]]
     with pytest.raises(ValueError, match="does not match"):
         pu(clip["latents"], stack["t"], clip["text"], pose_embedding_features=stack["pose_feats"], traj_features=bad)
+
+
+# ---- f4: checkpoint-directory round trip and the VAE / CLIP seam of the pipeline -------------------------------------------
+SD15_2D_CONFIG = {   # the keys of SD-1.5's `unet/config.json` (diffusers UNet2DConditionModel), at the test widths
+    "_class_name": "UNet2DConditionModel", "_diffusers_version": "0.6.0", "act_fn": "silu", "attention_head_dim": 8,
+    "block_out_channels": list(W4), "center_input_sample": False, "cross_attention_dim": 32,
+    "down_block_types": ["CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"],
+    "downsample_padding": 1, "flip_sin_to_cos": True, "freq_shift": 0, "in_channels": 4, "layers_per_block": 2,
+    "mid_block_scale_factor": 1, "norm_eps": 1e-05, "norm_num_groups": 32, "out_channels": 4, "sample_size": 16,
+    "up_block_types": ["UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"]}
+
+
+def test_from_pretrained_2d_checkpoint_directory_round_trip(tmp_path, stack, fake):
+    """`UNet3DConditionModelCamObjCond.from_pretrained_2d(path, subfolder, unet_additional_kwargs)` (unet.py:762-826) on a
+    checkpoint directory laid out like SD-1.5's: `unet/config.json` with the 2-D block types + `diffusion_pytorch_model.bin`
+    holding the 2-D (non motion-module) weights.  Block types are overridden, every 2-D key loads, exactly the motion-module
+    keys stay missing; after loading the motion-module weights on top the model reproduces the oracle."""
+    import json
+    import os
+    from synfmc_amd.models.unet import UNet3DConditionModelCamObjCond
+    from synfmc_amd.modified_modules import patch_unet_for_omc
+    ou = stack["ou"]
+    sd = ou.state_dict()
+    sd_2d = {k: v for k, v in sd.items() if "motion_modules." not in k and ".processor." not in k}
+    assert 0 < len(sd_2d) < len(sd)
+    unet_dir = tmp_path / "sd15" / "unet"
+    os.makedirs(unet_dir)
+    (unet_dir / "config.json").write_text(json.dumps(SD15_2D_CONFIG))
+    torch.save(sd_2d, unet_dir / "diffusion_pytorch_model.bin")
+    extra = {k: v for k, v in CM.unet_kwargs(W4, 32).items() if k.startswith("use_motion") or k.startswith("motion_module")}
+    unet = UNet3DConditionModelCamObjCond.from_pretrained_2d(str(tmp_path / "sd15"), subfolder="unet",
+                                                             unet_additional_kwargs=extra)
+    assert unet.config.block_out_channels == tuple(W4) or list(unet.config.block_out_channels) == list(W4)
+    got = unet.state_dict()
+    for k, v in sd_2d.items():
+        assert torch.equal(got[k], v), k
+    missing = [k for k in got if k not in sd_2d]
+    assert missing and all("motion_modules." in k for k in missing)
+    # the second stage of the reference's loading: processors installed, motion-module / adapter checkpoint on top
+    unet.set_all_attn_processor(**CM.processor_kwargs(W4))
+    patch_unet_for_omc(unet)
+    unet.load_state_dict({k: v for k, v in sd.items() if k not in sd_2d}, strict=False)
+    clip = stack["clip"]
+    with torch.no_grad():
+        out = unet.eval()(clip["latents"], stack["t"], clip["text"], pose_embedding_features=stack["pose_feats"],
+                          traj_features=stack["traj"]).sample
+    assert rel_inf(out, stack["ref"]) < 1e-3
+    with pytest.raises(RuntimeError, match="does not exist"):
+        UNet3DConditionModelCamObjCond.from_pretrained_2d(str(tmp_path / "nowhere"), subfolder="unet")
+
+
+def test_pipeline_with_tokenizer_text_encoder_and_vae(stack, fake):
+    """The seam either side of the loop (pipeline_animation_cm_om.py:465-560): prompt -> tokenizer -> text encoder (cond and
+    the empty negative prompt for the unconditional half), final latents -> `1/0.18215` -> per-frame `vae.decode` ->
+    `(x/2 + 0.5).clamp(0, 1)` video `[B, C, F, H, W]`, through duck-typed stand-ins (CLIP / the VAE themselves are third-party
+    models outside the hot path)."""
+    import types
+    from synfmc_amd.pipelines.pipeline_animation_cm_om import CameraObjCtrlPipeline
+    from synfmc_amd.schedulers import DDIMScheduler
+    clip = stack["clip"]
+    uncond = torch.randn(1, 77, 32, generator=torch.Generator().manual_seed(5))
+    seen = []
+
+    class Tok:
+        model_max_length = 77
+
+        def __call__(self, texts, **kw):
+            seen.append(list(texts))
+            return types.SimpleNamespace(input_ids=torch.tensor([[1 if t else 0] * 77 for t in texts]))
+
+    class TextEnc:
+        def __call__(self, ids):
+            return (torch.cat([clip["text"] if int(r[0]) else uncond for r in ids], 0),)
+
+    class Vae:
+        def decode(self, z):
+            assert z.shape[0] == 1 and z.ndim == 4            # one frame at a time, like the reference (:471-473)
+            return types.SimpleNamespace(sample=z[:, :3] * 0.18215 * 0.01)
+
+    kw = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1,
+              clip_sample=False)
+    pu, pe, pa = CM.build_product(stack["ou"], stack["oe"], stack["oa"], W4, cross_dim=32, device="cpu")
+    pipe = CameraObjCtrlPipeline(Vae(), TextEnc(), Tok(), pu, DDIMScheduler(**kw), pe)
+    common = dict(traj_features=stack["traj"], height=128, width=128, num_inference_steps=2, guidance_scale=2.0,
+                  latents=clip["latents"], use_graph=False)
+    video = pipe("a prompt", stack["pose_emb"], 16, **common).videos
+    assert seen == [["a prompt"], [""]]
+    lat = pipe(None, stack["pose_emb"], 16, output_type="latent", prompt_embeds=torch.cat([uncond, clip["text"]]), **common).videos
+    assert tuple(video.shape) == (1, 3, 16, 16, 16) and video.dtype == torch.float32
+    want = (lat[:, :3] * 0.01 / 2 + 0.5).clamp(0, 1)
+    assert rel_inf(video, want) < 1e-5
