@@ -903,11 +903,12 @@ def _save_at_exit():
 atexit.register(_save_at_exit)
 GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 11,     # 8..10, 12 (4-stage rings) exist but never won on the FMC shapes
               13,                            # the 8-phase 256x256 kernel (staggered wave rows, half-tile DMA, counted vmcnt)
-              128 + 2, 128 + 3)              # stream-K (persistent workgroups) on the two 1-per-CU geometries
+              128 + 2, 128 + 3,              # stream-K (persistent workgroups) on the two 1-per-CU geometries
+              128 + 13)                      # stream-K on the 8-phase kernel: persistent partial pass + one finishing workgroup per tile
 if os.environ.get("FMC_GEMM_ARMS"):              # A/B switch: the arm list the autotuner may choose from, e.g. "1,2,3,11"
     GEMM_TILES = tuple(int(a) for a in os.environ["FMC_GEMM_ARMS"].split(","))
-# fmc_linear_bf16 / fmc_conv3x3_bf16 `tile` arms tried per shape (14 = arm 13 with a deeper prefetch and 128 + 13 = its
-# stream-K form measured no better anywhere, tools/probe_g8.py)
+# fmc_linear_bf16 / fmc_conv3x3_bf16 `tile` arms tried per shape (14 = arm 13 with a deeper prefetch measured no better anywhere,
+# tools/probe_g8.py)
 
 
 def autotune_report():
