@@ -126,25 +126,29 @@ def measure_attention_roofline(device, dtype, iters=20):
 
 
 def measure_conv_roofline(device, dtype, iters=20):
-    """The GEMM / conv kernel is where most of the step goes (63 %): one of its launches exactly as the U-Net issues it
-    (level-1 ResNet conv, CFG batch 2 x 16 frames of 20x32, 640 -> 640, 256x256 tile), for the record next to the
-    attention roofline the north-star asks for."""
+    """The GEMM / conv kernels are where most of the step goes (78 %): one of their launches exactly as the U-Net issues it
+    (level-1 ResNet conv, CFG batch 2 x 16 frames of 20x32, 640 -> 640) through the same front-end, i.e. on the arm the
+    per-shape autotuner chose for it (reported), for the record next to the attention roofline the north-star asks for."""
     from synfmc_amd import hip_ops as K
     n, h, w, ci, co = 2 * FRAMES, HEIGHT // 16, WIDTH // 16, WIDTHS[1], WIDTHS[1]
-    x = torch.randn(n, h, w, ci, device=device, dtype=dtype)
+    x = torch.randn(n, h, w, ci, device=device, dtype=dtype).permute(0, 3, 1, 2)        # logical NCHW over channels-last storage
     wt = (torch.randn(co, ci, 3, 3, device=device, dtype=dtype) * 0.02).contiguous(memory_format=torch.channels_last)
     for _ in range(3):
-        K.conv3x3_bf16(x, wt, None, None, None, tile=3)
+        K.conv3x3(x, wt, None)
+    arm = K._choice.get(("conv", n, h, w, ci, co, False, False, False, False))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        K.conv3x3_bf16(x, wt, None, None, None, tile=3)
+        K.conv3x3(x, wt, None)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * n * h * w * 9 * ci * co
     achieved = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": f"gemm_kernel<conv3x3,256x256> [{n}x{h}x{w}, {ci}->{co}]", "achieved": round(achieved, 2),
+    names = {0: "vendor library", 3: "gemm_kernel<conv3x3,256x256,16 waves>", 13: "gemm8_kernel<conv3x3,256x256,8-phase>",
+             141: "gemm8_kernel<conv3x3,8-phase,stream-K>"}
+    return {"bound": "mfma", "kernel": f"{names.get(arm, f'fmc_conv3x3_bf16 arm {arm}')} [{n}x{h}x{w}, {ci}->{co}]",
+            "autotuned_arm": arm, "achieved": round(achieved, 2),
             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
             "avg_launch_ms": round(ms, 4), "flops_per_launch": flops}
 
@@ -192,11 +196,11 @@ def measure_temporal_roofline(device, dtype, iters=50):
     return {"bound": "hbm", "kernel": f"temporal_attn_kernel<bf16,d={D}> [2x{P} pixels x {H} heads, F={FRAMES}]",
             "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
             "avg_launch_ms": round(ms, 5), "bytes_per_launch": nbytes,
-            # HBM-side bytes per launch from rocprofv3 PMC passes (profiles/r02_temporal_pmc.md); null until measured
+            # HBM-side bytes per launch from rocprofv3 PMC passes (recorded, not re-measured here: profiles/r02_temporal_pmc.md)
             "traffic": TEMPORAL_TRAFFIC_BYTES}
 
 
-TEMPORAL_TRAFFIC_BYTES = None
+TEMPORAL_TRAFFIC_BYTES = 209.8e6      # 2 x FETCH_SIZE + WRITE_SIZE of this exact launch, tools/pmc_temporal.sh -> profiles/r02_temporal_pmc.md
 
 
 def oracle_step(unet, enc, ada, clip, text2, latents, t, want_config1=True):
