@@ -287,6 +287,19 @@ int fmc_temporal_attn_fp8_bwd(const void* q, const void* k, const void* v, const
                               int64_t do_pix_stride, int64_t dq_clip_stride, int64_t dq_frame_stride,
                               int64_t dq_pix_stride, float scale, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Layout pass of the 3x3-convolution WEIGHT gradient (the trainable convs of the OMC Adapter / camera encoder;
+ * `loss.backward()` at train_cam_obj_ctrl.py:915).  dW[co][dy][dx][ci] = sum_pixels dY[pixel, co] * X[pixel + tap, ci] is a GEMM
+ * whose reduction index is the pixel; this pass writes a [n, H, W, C] bf16 tensor channel-major over a zero-padded pixel index
+ * p = (img * (H + 2) + y + 1) * Wp + x + 1, Wp = round_up(W + 2, 8):
+ *     dst[s][c][guard + p] = src[img][y][x + s - shifts / 2]   (0 in the padding and up to row_len),
+ * shifts = 3 copies (dx = -1, 0, +1) for X, 1 for dY.  dW of one kernel row dy is then ONE
+ * fmc_linear_bf16(x = dst_X viewed as [3 Cin, row_len] + guard + (dy - 1) * Wp, w = dst_dY [Cout, K], K = row_len of dY)
+ * with split_k over the pixels: out[dx * Cin + ci][co].  (`hip_ops.conv3x3_weight_grad`)
+ * ------------------------------------------------------------------------------------------- */
+int fmc_nhwc_to_cmajor_padded(const void* src, void* dst, int n_img, int H, int W, int C, int64_t row_len, int guard,
+                              int shifts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -385,3 +385,67 @@ extern "C" int fmc_cfg_ddim_step(const void* eps_uc, const float* x, float* x_ou
     FMC_CHECK_LAUNCH("fmc_cfg_ddim_step");
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the 3x3 convolutions (training stages 2-3: OMC Adapter, camera encoder; train_cam_obj_ctrl.py:861-943).
+//   dW[co][dy][dx][ci] = sum over (img, y, x) of dY[img, y, x, co] * X[img, y + dy - 1, x + dx - 1, ci]
+// is a GEMM whose REDUCTION index is the pixel -- the slow index of both NHWC operands.  fmc_linear_bf16 wants both operands
+// reduction-contiguous, so this kernel re-lays them out pixel-minor over a zero-PADDED pixel index
+//   p = (img * Hp + yp) * Wp + xp,  Hp = H + 2, Wp = round_up(W + 2, 8),  (yp, xp) = (y + 1, x + 1)
+//   dst[s][c][G + p] = src[img][yp - 1][xp - 1 + (s - S/2)]   (0 outside the image / beyond the last image)
+// with S = 3 copies shifted by dx = -1, 0, +1 for X (S = 1 for dY) and G guard elements in front of every row.  A vertical
+// tap offset dy is then the POINTER offset dy * Wp (a multiple of 8 elements = 16 bytes: DMA-aligned), the rows (dx, ci) of
+// the three copies have one uniform stride, and the padding zeros of dY^T switch off every product that would wrap across
+// an image border.  dW for one dy = ONE fmc_linear_bf16 call [3 Cin x Lk] x [Cout x Lk]^T (split-K over the pixels).
+template <int TP>
+__global__ __launch_bounds__(256) void nhwc_to_cmajor_padded_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int n_img,
+                                                                    int H, int W, int C, int Hp, int Wp, int64_t row_len, int guard,
+                                                                    int shifts) {
+    __shared__ bf16_t tile[64][64 + 2];              // [position][channel]
+    const int s = blockIdx.z, c0 = blockIdx.y * 64;
+    const int64_t p0 = (int64_t)blockIdx.x * 64;     // first row position (guard included) of this tile
+    const int dx = s - shifts / 2;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int pos = (tid >> 3) + 32 * it, ch = (tid & 7) * 8;
+        const int64_t p = p0 + pos - guard;          // padded pixel index
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (p >= 0 && c0 + ch < C) {
+            const int64_t img = p / ((int64_t)Hp * Wp);
+            const int r = (int)(p - img * Hp * Wp), yp = r / Wp, xp = r - yp * Wp;
+            const int y = yp - 1, x = xp - 1 + dx;
+            if (img < n_img && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && xp - 1 >= -1 && xp - 1 <= W)
+                v = *reinterpret_cast<const u32x4*>(src + (((int64_t)img * H + y) * W + x) * C + c0 + ch);
+        }
+        union { u32x4 u; bf16_t e[8]; } t;
+        t.u = v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tile[pos][ch + i] = t.e[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c = (tid >> 3) + 32 * it, pc = (tid & 7) * 8;
+        if (c0 + c >= C || p0 + pc >= row_len) continue;
+        union { u32x4 u; bf16_t e[8]; } t;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t.e[i] = tile[pc + i][c];
+        *reinterpret_cast<u32x4*>(dst + ((int64_t)s * C + c0 + c) * row_len + p0 + pc) = t.u;
+    }
+}
+
+extern "C" int fmc_nhwc_to_cmajor_padded(const void* src, void* dst, int n_img, int H, int W, int C, int64_t row_len, int guard,
+                                         int shifts, void* stream) {
+    if (!src || !dst) FMC_FAIL(FMC_E_NULL, "nhwc_to_cmajor_padded: NULL tensor");
+    const int Hp = H + 2, Wp = (W + 2 + 7) / 8 * 8;
+    if (n_img <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || row_len % 8 || guard % 8 || guard < 0 || (shifts != 1 && shifts != 3) ||
+        row_len < guard + (int64_t)n_img * Hp * Wp)
+        FMC_FAIL(FMC_E_SHAPE, "nhwc_to_cmajor_padded: need C%%8==0, row_len%%8==0, guard%%8==0, shifts in {1,3}, row_len >= guard + n*Hp*Wp");
+    if (!fmc_aligned16(src) || !fmc_aligned16(dst)) FMC_FAIL(FMC_E_ALIGN, "nhwc_to_cmajor_padded: tensors must be 16-byte aligned");
+    dim3 grid((unsigned)((row_len + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)shifts);
+    hipLaunchKernelGGL((nhwc_to_cmajor_padded_kernel<64>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst,
+                       n_img, H, W, C, Hp, Wp, row_len, guard, shifts);
+    FMC_CHECK_LAUNCH("fmc_nhwc_to_cmajor_padded");
+    return 0;
+}

@@ -1133,11 +1133,42 @@ def linear_frozen(x, weight, bias=None, residual=None, alpha: float = 1.0):
     return _LinearFrozen.apply(x, weight, bias, residual, alpha)
 
 
+def conv3x3_weight_grad(x_nhwc: torch.Tensor, dy_nhwc: torch.Tensor) -> torch.Tensor:
+    """dW `[Cout, Cin, 3, 3]` (bf16, a permuted view) of a 3x3 / stride 1 / pad 1 convolution from its NHWC input and output
+    gradient: two `fmc_nhwc_to_cmajor_padded` layout passes + one split-K `fmc_linear_bf16` per kernel row (see fmc_hip.h)."""
+    _dev(x_nhwc, dy_nhwc)
+    n, H, W, cin = x_nhwc.shape
+    cout = dy_nhwc.shape[-1]
+    assert dy_nhwc.shape[:3] == x_nhwc.shape[:3] and x_nhwc.is_contiguous() and dy_nhwc.is_contiguous()
+    assert x_nhwc.dtype == torch.bfloat16 and dy_nhwc.dtype == torch.bfloat16 and cin % 8 == 0 and cout % 8 == 0
+    Hp, Wp = H + 2, (W + 2 + 7) // 8 * 8
+    Lk = (n * Hp * Wp + 63) // 64 * 64                 # reduction length (padded pixels), a multiple of the k-tile
+    G = Wp + 8                                          # guard in front of / behind every X^T row: a tap reaches +-Wp
+    Lg = Lk + 2 * G
+    lib = _lib.load()
+    xt = torch.empty(3, cin, Lg, dtype=torch.bfloat16, device=x_nhwc.device)
+    dyt = torch.empty(cout, Lk, dtype=torch.bfloat16, device=x_nhwc.device)
+    _lib.check(lib.fmc_nhwc_to_cmajor_padded(x_nhwc.data_ptr(), xt.data_ptr(), n, H, W, cin, Lg, G, 3, _stream()),
+               "fmc_nhwc_to_cmajor_padded")
+    _lib.check(lib.fmc_nhwc_to_cmajor_padded(dy_nhwc.data_ptr(), dyt.data_ptr(), n, H, W, cout, Lk, 0, 1, _stream()),
+               "fmc_nhwc_to_cmajor_padded")
+    rows = xt.view(3 * cin, Lg)
+    tiles = ((3 * cin + 127) // 128) * ((cout + 127) // 128)
+    split = 1
+    while split < 16 and tiles * split * 2 <= 512 and Lk // 64 >= split * 4:
+        split *= 2
+    out = []
+    for dy in range(3):
+        xs = rows[:, G + (dy - 1) * Wp: G + (dy - 1) * Wp + Lk]          # [3 Cin, Lk] view, row stride Lg
+        out.append(linear_bf16(xs, dyt, None, None, 1.0, tile=1, split_k=split))      # [dx * Cin + ci][co]
+    dwt = torch.stack(out)                                                # [dy][dx * Cin + ci][co]
+    return dwt.view(3, 3, cin, cout).permute(3, 2, 0, 1)                  # logical [Cout, Cin, ky, kx]
+
+
 class _Conv3x3Trainable(torch.autograd.Function):
-    """3x3 / stride 1 / pad 1 conv whose FILTER trains (OMC Adapter, camera encoder): forward and backward-data on the fused
-    gfx950 implicit-GEMM kernel (the filter is re-laid-out / flipped per step: it changes every step and is small next to
-    the activations); the weight gradient -- a reduction over pixels with both operands pixel-major -- is the one piece
-    still computed by the vendor library (`aten::convolution_backward`, MIOpen wrw), see DESIGN.md."""
+    """3x3 / stride 1 / pad 1 conv whose FILTER trains (OMC Adapter, camera encoder): forward, backward-data AND the weight
+    gradient on the gfx950 kernels -- forward / dX on the implicit-GEMM kernel (the filter is re-laid-out / flipped per step:
+    it changes every step and is small next to the activations), dW as pixel-reduction GEMMs (`conv3x3_weight_grad`)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -1157,14 +1188,10 @@ class _Conv3x3Trainable(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 w_flip = weight.detach().to(dy.dtype).flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
                 dx = conv3x3(dy, w_flip, None)
-            if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-                _, dw, db = torch.ops.aten.convolution_backward(
-                    dy, x, weight.to(x.dtype), [weight.shape[0]] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False,
-                    [0, 0], 1, [False, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]])
-                if dw is not None:
-                    dw = dw.to(weight.dtype)
-                if db is not None:
-                    db = db.to(weight.dtype)
+            if ctx.needs_input_grad[1]:
+                dw = conv3x3_weight_grad(x.permute(0, 2, 3, 1), dy.permute(0, 2, 3, 1)).to(weight.dtype)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = dy.sum(dim=(0, 2, 3), dtype=torch.float32).to(weight.dtype)
         return dx, dw, (db if ctx.has_bias else None)
 
 

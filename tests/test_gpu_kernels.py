@@ -658,6 +658,37 @@ def test_gemm_8phase_arms(K, tile):
         assert int(ws[:1024].view(torch.int32).abs().sum()) == 0
 
 
+@pytest.mark.parametrize("n,H,W,cin,cout", [(4, 12, 20, 64, 128), (16, 4, 6, 320, 320), (2, 32, 48, 320, 64), (3, 7, 9, 128, 72)])
+def test_conv3x3_weight_grad(K, n, H, W, cin, cout):
+    """dW of the 3x3 / stride 1 / pad 1 convolution as pixel-reduction GEMMs over the zero-padded, pixel-minor layouts
+    (`fmc_nhwc_to_cmajor_padded` + split-K `fmc_linear_bf16`) against autograd through F.conv2d on the same bf16 operands;
+    and the trainable-conv autograd node end to end (forward, dX, dW, db)."""
+    dtype = torch.bfloat16
+    xo, xd = rnd((n, cin, H, W), 80, dtype)
+    go, gd = rnd((n, cout, H, W), 81, dtype)
+    wo, wd = rnd((cout, cin, 3, 3), 82, dtype, scale=(9 * cin) ** -0.5)
+    wr = wo.clone().requires_grad_(True)
+    xr = xo.clone().requires_grad_(True)
+    F.conv2d(xr, wr, None, 1, 1).backward(go)
+    dw = K.conv3x3_weight_grad(xd.permute(0, 2, 3, 1).contiguous(), gd.permute(0, 2, 3, 1).contiguous())
+    assert dw.shape == (cout, cin, 3, 3)
+    assert rel_inf(dw.float(), wr.grad) < 1e-2
+    if cin % 64 == 0 and cout % 64 == 0:
+        bo, bd = rnd((cout,), 83, dtype)
+        x_cl = xd.contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        w32, b32 = wd.float().requires_grad_(True), bd.float().requires_grad_(True)
+        y = K.conv3x3_trainable(x_cl, w32, b32)
+        br = bo.clone().requires_grad_(True)
+        xr.grad = wr.grad = None
+        yr = F.conv2d(xr, wr, br, 1, 1)
+        assert rel_inf(y.float(), yr) < 1e-2
+        y.backward(gd.contiguous(memory_format=torch.channels_last))
+        yr.backward(go)
+        assert rel_inf(x_cl.grad.float(), xr.grad) < 1e-2
+        assert rel_inf(w32.grad, wr.grad) < 1e-2
+        assert rel_inf(b32.grad, br.grad) < 1e-2
+
+
 def test_linear_bf16_geglu(K):
     dtype = torch.bfloat16
     M, C, Cff = 513, 320, 1280
