@@ -61,6 +61,7 @@ struct GemmParams {
     int* sk_flags;                    //   contiguous range of (tile, k-tile) iterations; ws[block][BM][BN] partials
     int64_t sk_ws_bytes;
     int sk_maxseg;                    // 8-phase stream-K: workspace slots per workgroup (segments it may own)
+    int sk_whole;                     // 8-phase stream-K: 1 = the persistent pass (ROLE 3) finished the whole tiles itself
     int64_t a_bytes;                  // 8-phase kernel: size of the A operand in bytes (buffer descriptor range)
     const float* q8_inv;              // EPI 2 (fp8 e4m3 output, three equal column blocks q | k | v): 1 / scale per block (device)
     unsigned* q8_amax;                // EPI 2: running max |value| per block as float bits (device, atomicMax), may be NULL
@@ -729,14 +730,16 @@ void gemm8_kernel(const GemmParams P) {
     // workspace slot in ACCUMULATOR layout (slot[wave][register quad][lane] x 16 B: every store moves one contiguous KiB) and
     // nothing else -- no epilogue code, no flags, no spinning.  ROLE 2 = one workgroup per output tile: it sums the slots of
     // the segments that cover its tile (same lane <-> element map, so the sum lands in accumulator registers) and runs the normal
-    // epilogue.  The kernel boundary is the synchronisation; the summation order is fixed.  (A single persistent kernel that
+    // epilogue.  (ROLE 3 = a persistent pass that also finishes the tiles it holds whole, ROLE 2 then only the cut ones:
+    // measured slower -- the plain-epilogue instantiation spills again, and even the spill-free GEGLU one only ties the plain
+    // grid at 1600 tiles; not instantiated.)  The kernel boundary is the synchronisation; the summation order is fixed.  (A single persistent kernel that
     // also finishes the tiles -- built first -- left the register allocator with two live versions of the 128 accumulators
     // around the segment loop: 350-800 spilled registers, +22 us per launch.)  Costs 2 x M x N x 4 bytes of extra traffic:
     // the arm for small outputs with a long reduction (the 10x16 / 5x8-level convolutions, M*N <= ~8 M elements).
-    constexpr bool SK = ROLE == 1;
+    constexpr bool SK = ROLE == 1 || ROLE == 3;
     int64_t sk_it = 0, sk_end = 0, sk_gbase = 0, sk_I = 0;
     int sk_r = 0, sk_per = 1, sk_first = 0;
-    if (ROLE == 1) {
+    if (SK) {
         const int T = P.tiles_m * P.tiles_n, x = blockIdx.x & 7, q = blockIdx.x >> 3;
         sk_per = P.sk >> 3;
         const int tg0 = (int)((int64_t)T * x / 8), tg1 = (int)((int64_t)T * (x + 1) / 8);
@@ -757,7 +760,7 @@ void gemm8_kernel(const GemmParams P) {
     const int l31 = lane & 31, half = lane >> 5;
     const int prow = lane >> 3, pch = lane & 7;      // my row / 16-byte chunk inside a 1-KiB DMA piece (8 rows x 128 B)
     int tile_m, tile_n, kt0 = 0, nk = nkt, sk_slot = 0;
-    if (ROLE == 1) {
+    if (SK) {
         if (sk_it >= sk_end) break;
         const int lin = (int)(sk_it / nkt);
         kt0 = (int)(sk_it - (int64_t)lin * nkt);
@@ -782,6 +785,7 @@ void gemm8_kernel(const GemmParams P) {
             int r0 = (int)(lo * per / I);
             while (r0 + 1 < per && I * (r0 + 1) / per <= lo) ++r0;
             while (r0 > 0 && I * r0 / per > lo) --r0;
+            if (P.sk_whole && I * r0 / per <= lo && I * (r0 + 1) / per >= hi) return;   // a whole tile of one range: finished by the ROLE 3 pass
 #pragma unroll
             for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
@@ -1025,7 +1029,7 @@ void gemm8_kernel(const GemmParams P) {
 
     }  // (ROLE 2 has no main loop: its accumulators are the sums of the stored partials)
 
-    if constexpr (ROLE == 1) {                        // my segment's accumulators -> its workspace slot, accumulator layout
+    if (ROLE == 1 || (ROLE == 3 && (kt0 > 0 || nk < nkt))) {   // my segment's accumulators -> its workspace slot, accumulator layout
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -1052,18 +1056,25 @@ void gemm8_kernel(const GemmParams P) {
     auto pass = [&](auto hp_c) {
         constexpr int hp = decltype(hp_c)::value;     // compile-time: the accumulator blocks of a pass must be static indices
         auto stage_rows = [&](const bf16_t* src, int64_t ld) {     // global [rows of this pass][ON] -> Os
-            u32x4 v[IT];
+            // GR chunks per thread in flight at a time (512 threads x GR x 16 B per round): all IT at once cost 32 registers
+            // next to the 128 accumulators, which is what pushed the persistent instantiation into scratch
+            constexpr int GR = IT >= 4 ? 4 : IT;
 #pragma unroll
-            for (int it = 0; it < IT; ++it) {
-                const int c = tid + it * NT, ri = c / CPR, ch = c - ri * CPR;
-                const int row = (ri >> 6) * 128 + hp * 64 + (ri & 63);
-                v[it] = *reinterpret_cast<const u32x4*>(src + min(m0 + row, P.M - 1) * ld + min(no0 + ch * 8, n_out - 8));
-            }
+            for (int g0 = 0; g0 < IT; g0 += GR) {
+                u32x4 v[GR];
 #pragma unroll
-            for (int it = 0; it < IT; ++it) {
-                const int c = tid + it * NT, ri = c / CPR, ch = c - ri * CPR;
-                const int row = (ri >> 6) * 128 + hp * 64 + (ri & 63);
-                *reinterpret_cast<u32x4*>(Os + row * OP + ch * 8) = v[it];
+                for (int it = 0; it < GR; ++it) {
+                    const int c = tid + (g0 + it) * NT, ri = c / CPR, ch = c - ri * CPR;
+                    const int row = (ri >> 6) * 128 + hp * 64 + (ri & 63);
+                    v[it] = *reinterpret_cast<const u32x4*>(src + min(m0 + row, P.M - 1) * ld + min(no0 + ch * 8, n_out - 8));
+                }
+#pragma unroll
+                for (int it = 0; it < GR; ++it) {
+                    const int c = tid + (g0 + it) * NT, ri = c / CPR, ch = c - ri * CPR;
+                    const int row = (ri >> 6) * 128 + hp * 64 + (ri & 63);
+                    *reinterpret_cast<u32x4*>(Os + row * OP + ch * 8) = v[it];
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();
         };
@@ -1097,12 +1108,15 @@ void gemm8_kernel(const GemmParams P) {
                             acc[ni][mi][4 * gq + j] = (acc[ni][mi][4 * gq + j] + b4[j]) * P.alpha + t4[j];
                     }
                 }
-            // residual(s): stage, add my words
+            // residual(s): stage, add my words.  The additions are UNconditional (a missing residual contributes zero words):
+            // accumulators modified inside an `if` leave two versions of them alive at the join, which the register
+            // allocator resolves with copies and, in the persistent instantiation, spills
 #pragma unroll
             for (int rz = 0; rz < 2; ++rz) {
                 const bf16_t* rp = rz == 0 ? P.res : P.res2;
-                if (!rp) break;
-                stage_rows(rp, P.ldres);
+                const bool has = rp != nullptr;
+                if (has) stage_rows(rp, P.ldres);
+                const unsigned keep = has ? 0xffffffffu : 0u;
 #pragma unroll
                 for (int j2 = 0; j2 < 2; ++j2) {
                     const int mi = 2 * hp + j2, row = wr * 128 + mi * 32 + l31;
@@ -1110,12 +1124,13 @@ void gemm8_kernel(const GemmParams P) {
                     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                         for (int gq = 0; gq < 4; ++gq) {
-                            const u32x2 t = *reinterpret_cast<const u32x2*>(Os + row * OP + wc * 64 + ni * 32 + 8 * gq + 4 * half);
+                            u32x2 t = *reinterpret_cast<const u32x2*>(Os + row * OP + wc * 64 + ni * 32 + 8 * gq + 4 * half);
+                            t[0] &= keep; t[1] &= keep;
                             acc[ni][mi][4 * gq] += __uint_as_float(t[0] << 16); acc[ni][mi][4 * gq + 1] += __uint_as_float(t[0] & 0xffff0000u);
                             acc[ni][mi][4 * gq + 2] += __uint_as_float(t[1] << 16); acc[ni][mi][4 * gq + 3] += __uint_as_float(t[1] & 0xffff0000u);
                         }
                 }
-                __syncthreads();                      // everybody has picked up its words: the rows may be overwritten
+                if (has) __syncthreads();             // everybody has picked up its words: the rows may be overwritten
             }
 #pragma unroll
             for (int j2 = 0; j2 < 2; ++j2) {
@@ -1200,8 +1215,9 @@ void gemm8_kernel(const GemmParams P) {
     };
     pass(std::integral_constant<int, 0>{});
     pass(std::integral_constant<int, 1>{});
-    break;
-    }  // (ROLE 0 / 2: epilogue)
+    if (ROLE != 3) break;
+    __syncthreads();                                  // the staging rows alias the operand buffers of the next segment
+    }  // (epilogue)
     }  // segment loop
 }
 
@@ -1380,6 +1396,7 @@ void launch_gemm8(GemmParams& P, hipStream_t st) {
         if (g >= 8 && iters >= 2 * (int64_t)g && P.sk_ws_bytes >= need && need < ((int64_t)1 << 31)) {
             P.sk = g;
             P.sk_maxseg = maxseg;
+            P.sk_whole = 0;
             hipLaunchKernelGGL((gemm8_kernel<MODE, EPI, PF, 1>), dim3((unsigned)g), dim3(512), lds, st, P);
             hipLaunchKernelGGL((gemm8_kernel<MODE, EPI, PF, 2>), dim3((unsigned)tiles), dim3(512), lds, st, P);
             return;
