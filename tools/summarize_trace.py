@@ -9,6 +9,23 @@ import csv
 import sys
 
 
+def by_grid(path, nsteps=4):
+    """Per (kernel, grid size) time inside the steady-state window: separates the shapes one kernel template is launched on."""
+    rows = list(csv.DictReader(open(path)))
+    ddim = [r for r in rows if "cfg_ddim" in r["Kernel_Name"]]
+    t1, t0 = int(ddim[-1]["End_Timestamp"]), int(ddim[-1 - nsteps]["End_Timestamp"])
+    agg = collections.defaultdict(lambda: [0, 0])
+    for r in rows:
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if s > t0 and e <= t1:
+            a = agg[(r["Kernel_Name"].replace("void (anonymous namespace)::", "")[:58], r.get("Grid_Size_X", "?"), r.get("Workgroup_Size_X", "?"))]
+            a[0] += e - s
+            a[1] += 1
+    print("| ms/step | calls/step | avg us | grid | wg | kernel |\n|---|---|---|---|---|---|")
+    for (k, g, w), (d, c) in sorted(agg.items(), key=lambda x: -x[1][0])[:70]:
+        print(f"| {d / 1e6 / nsteps:.3f} | {c / nsteps:.1f} | {d / c / 1e3:.1f} | {g} | {w} | `{k}` |")
+
+
 def main(path, nsteps=4):
     rows = list(csv.DictReader(open(path)))
     ddim = [r for r in rows if "cfg_ddim" in r["Kernel_Name"]]
@@ -61,5 +78,7 @@ def main(path, nsteps=4):
         print(f"| {d / 1e6 / nsteps:.3f} | {c / nsteps:.1f} | {d / c / 1e3:.1f} | `{name}` |")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "--by-grid":
+    by_grid(sys.argv[1])
+elif __name__ == "__main__":
     main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 4)
