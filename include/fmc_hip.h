@@ -193,8 +193,9 @@ int fmc_cfg_ddim_step(const void* eps_uc, const float* x, float* x_out, int64_t 
  *   columns); 12 = 128x320, 32-deep, 4 stages; 13 / 14 = the 8-phase 256x256 kernel (8 waves of 128x64, the two wave rows
  *   one barrier apart so each SIMD always has one wave on the matrix pipe and one loading; operands by half-tile
  *   `buffer_load ... lds` with a counted vmcnt, 4 / 5 half-tiles ahead; falls back to 3 for a two-source A operand or
- *   operands beyond 2 GiB).  Every arm computes the same function, bit for bit (callers may time them and keep
- *   the fastest).
+ *   operands beyond 2 GiB).  Every arm computes the same function -- bit for bit among the plain-grid arms of one k-tile depth
+ *   (the 32-deep arms, split-K and stream-K add the same products in another order) -- so callers may time them and keep
+ *   the fastest.
  *   split_k > 1 (epilogue 0 only): the k-tiles of every output tile are dealt to split_k workgroups that write fp32
  *   partial sums to `workspace` (>= split_k * M * N * 4 bytes, 16-byte aligned, caller-owned scratch); a second kernel
  *   sums them in a fixed order and applies the epilogue.  For M*N too small to fill 256 CUs (the 5x8 level).
