@@ -275,7 +275,11 @@ int fmc_temporal_attn_bwd(const void* q, const void* k, const void* v, const voi
  *   converted e4m3 -> bf16 (exact); o is bf16.  q/k/v strides in bytes (multiples of 16), o strides in elements; scales = 3
  *   device floats {scale_q, scale_k, scale_v}.  F in {16, 32}.
  * fmc_temporal_attn_fp8_bwd: fmc_temporal_attn_bwd with e4m3 q, k, v (dequantised while staged; d_o, dq, dk, dv bf16).
+ * fmc_fp8_scales_roll: the delayed-scaling update, one tiny launch: scale[b] = max(margin * amax[b] / 448, 1e-12),
+ *   inv_scale[b] = 1 / scale[b], amax[b] = 0 for the three blocks (all fp32 device words; amax as written by the atomicMax of
+ *   non-negative float bit patterns).
  * ------------------------------------------------------------------------------------------- */
+int fmc_fp8_scales_roll(void* amax, void* scale, void* inv_scale, float margin, void* stream);
 int fmc_linear_fp8_qkv(const void* x, const void* w, void* out_fp8, int64_t M, int N, int K, int64_t ldx,
                        const void* inv_scales, void* amax_bits, void* stream);
 int fmc_temporal_attn_fp8_fwd(const void* q, const void* k, const void* v, void* o, const void* scales, int n_clips,

@@ -50,6 +50,7 @@ SIGNATURES = {
     "fmc_geglu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "fmc_spatial_attn_bwd": (c_int, [c_void_p] * 10 + [c_int] * 5 + [c_int64] * 10 + [c_int, c_float, c_int, c_void_p]),
     "fmc_temporal_attn_bwd": (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_int64] * 9 + [c_float, c_int, c_void_p]),
+    "fmc_fp8_scales_roll": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
     "fmc_linear_fp8_qkv": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
     "fmc_temporal_attn_fp8_fwd": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_int64] * 6 + [c_float, c_void_p]),
     "fmc_temporal_attn_fp8_bwd": (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_int64] * 9 + [c_float, c_void_p]),

@@ -1172,8 +1172,13 @@ void gemm8_kernel(const GemmParams P) {
                     }
             }
             if (P.q8_amax && n0 + wc * 64 < P.N) {
+                // running max: only a wave that RAISES it touches the word (a relaxed read first): 20 000 unconditional
+                // atomicMax on three addresses serialised in the L2 and cost the projection +50 us
                 amax = wave_max(amax);
-                if (lane == 0) atomicMax(P.q8_amax + blk, __float_as_uint(amax));     // (non-negative floats order like their bit patterns)
+                if (lane == 0) {
+                    const unsigned bits = __float_as_uint(amax);                      // (non-negative floats order like their bit patterns)
+                    if (bits > __hip_atomic_load(P.q8_amax + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(P.q8_amax + blk, bits);
+                }
             }
         } else {
             // GEGLU: weight rows interleaved per 64 -> acc[0] = value, acc[1] = gate of the SAME 32 output columns

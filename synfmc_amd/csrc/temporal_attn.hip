@@ -813,3 +813,23 @@ extern "C" int fmc_temporal_attn_fp8_bwd(const void* q, const void* k, const voi
     FMC_CHECK_LAUNCH("fmc_temporal_attn_fp8_bwd");
     return 0;
 }
+
+namespace {
+__global__ void fp8_scales_roll_kernel(float* amax, float* scale, float* inv_scale, float k) {
+    const int i = threadIdx.x;
+    if (i < 3) {
+        const float s = fmaxf(amax[i] * k, 1e-12f);
+        scale[i] = s;
+        inv_scale[i] = 1.f / s;
+        amax[i] = 0.f;
+    }
+}
+}  // namespace
+
+extern "C" int fmc_fp8_scales_roll(void* amax, void* scale, void* inv_scale, float margin, void* stream) {
+    if (!amax || !scale || !inv_scale) FMC_FAIL(FMC_E_NULL, "fp8_scales_roll: NULL tensor");
+    hipLaunchKernelGGL(fp8_scales_roll_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (float*)amax, (float*)scale, (float*)inv_scale,
+                       margin / 448.f);
+    FMC_CHECK_LAUNCH("fmc_fp8_scales_roll");
+    return 0;
+}

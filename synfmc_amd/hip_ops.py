@@ -467,10 +467,9 @@ class Fp8QKVScales:
         self.calibrated = True
 
     def roll(self) -> None:
-        """scale <- margin * amax / 448, then restart the running max (device ops only)."""
-        torch.clamp(self.amax * (self.margin / FP8_MAX), min=1e-12, out=self.scale)
-        torch.reciprocal(self.scale, out=self.inv_scale)
-        self.amax.zero_()
+        """scale <- margin * amax / 448, inv_scale <- 1 / scale, then restart the running max: one tiny launch."""
+        _lib.check(_lib.load().fmc_fp8_scales_roll(self.amax.data_ptr(), self.scale.data_ptr(), self.inv_scale.data_ptr(),
+                                                   float(self.margin), _stream()), "fmc_fp8_scales_roll")
 
 
 def linear_fp8_qkv(x: torch.Tensor, weight: torch.Tensor, scales: Fp8QKVScales) -> torch.Tensor:
