@@ -60,6 +60,10 @@ struct SAParams {
 //  * when the padded V^T tile has a spare row (odd NKS: D = 40, 80, ...) that row holds ones, so the PV MFMAs
 //    accumulate l = sum(p) in O^T row NDT*32-1 for free (and from the same rounded p as the numerator).
 constexpr float REF_LIMIT = 64.f;
+#ifndef SA_DBG
+#define SA_DBG 0   // timing knock-outs (tools/ubench): 1 no staging, 2 barriers only, 3 staging without barriers, 4 no exp, 5 no max, 6 neither;
+                   // pipelined kernel: 11 no LDS / DMA traffic, 12 no DMA, 13 no exp, 14 no barrier, 15 = 11 + 13; 20: cycle counters into `lse`
+#endif
 
 // max of three; this file is built with -fno-honor-nans so that the fmaxf chain selects v_max3_f32 without the NaN
 // canonicalisation (v_max x,x) of every MFMA output.  (Not inline asm: the compiler must see these reads to insert the
@@ -216,10 +220,10 @@ __device__ __forceinline__ void softmax_pv_perq(const T* __restrict__ Vt, f32x16
         }
 #pragma unroll
     for (int nq = 0; nq < NQ; ++nq) {
-        worst[nq] = fold_max(s[nq], worst[nq]);
+        if (SA_DBG != 5 && SA_DBG != 6) worst[nq] = fold_max(s[nq], worst[nq]);
         float p[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(s[nq][r]);
+        for (int r = 0; r < 16; ++r) p[r] = (SA_DBG == 4 || SA_DBG == 6) ? s[nq][r] * 0.001f : __builtin_amdgcn_exp2f(s[nq][r]);
         if (!LROW) {
             float psum = 0.f;
 #pragma unroll
@@ -270,6 +274,7 @@ __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 && NQ =
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int D = P.D, CH = D / 8;
+    const uint64_t dbg_c0 = SA_DBG >= 20 ? __builtin_readcyclecounter() : 0, dbg_r0 = SA_DBG >= 20 ? __builtin_amdgcn_s_memrealtime() : 0;
 
     // ---- block -> (bh, q-block), XCD aware -----------------------------------------------------
     int bh, qblk;
@@ -444,11 +449,12 @@ __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 && NQ =
 
         auto stage = [&](int tile) {
             if (tile > 0 || pass > 0) {             // tile 0 is already resident after the prologue
+                if (SA_DBG == 1) return;
                 if (pass > 0 && tile == 0 && PREFETCH) gload(0);
-                __syncthreads();  // previous tile fully consumed
-                if (PREFETCH) lstore(); else stage_rolled(tile * SA_BK);
-                __syncthreads();
-                if (PREFETCH && tile + 1 < ntiles) gload((tile + 1) * SA_BK);
+                if (SA_DBG != 3) __syncthreads();  // previous tile fully consumed
+                if (SA_DBG != 2) { if (PREFETCH) lstore(); else stage_rolled(tile * SA_BK); }
+                if (SA_DBG != 3) __syncthreads();
+                if (SA_DBG != 2) if (PREFETCH && tile + 1 < ntiles) gload((tile + 1) * SA_BK);
             }
         };
         // full tiles: no key masking anywhere, no branch in the body (a second path merging into the loop makes the
@@ -508,10 +514,400 @@ __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 && NQ =
                                   oacc[nq][dt][4 * g + 2] * inv, oacc[nq][dt][4 * g + 3] * inv);
                 }
             }
-            if (P.lse && half == 0)
+            if (SA_DBG < 20 && P.lse && half == 0)
                 P.lse[((int64_t)b * P.H + h) * P.Sq + qrow[nq]] = m_ref[nq] * 0.6931471805599453f + logf(l_tot);
         }
     }
+    if (SA_DBG >= 20 && P.lse && lane == 0) {
+        float* dst = P.lse + ((int64_t)blockIdx.x * 4 + wave) * 4;
+        dst[0] = (float)(__builtin_readcyclecounter() - dbg_c0); dst[1] = 0.f;
+        dst[2] = (float)(__builtin_amdgcn_s_memrealtime() - dbg_r0); dst[3] = (float)blockIdx.x;
+    }
+}
+
+
+// =====================================================================================================================
+// Software-pipelined kernel for the level-0 self-attention (bf16, D = 40, S_kv % 64 == 0, S_q % 256 == 0).
+//
+// Same fragment mapping, fixed-reference softmax (reference through the QK^T reduction) and ones-row denominator as
+// the NQ = 2 / MK / VR variant above; what changes is the instruction order and how the tiles get into LDS.
+// Knock-out timings of that variant (tools/ubench/sa_bench + SA_DBG) showed the matrix pipe 34 % busy although neither
+// the exp work (-8 % when removed) nor the barriers (0 %) nor the LDS bandwidth were the limit: the wave stalls on
+// its OWN dependencies (ds_read -> MFMA, MFMA -> v_exp, v_cvt -> MFMA), and a micro-benchmark
+// (tools/ubench/pingpong.hip) reaches 85-95 % matrix pipe occupancy with the same instruction mix once every MFMA is
+// followed by ~4 independent VALU.  So the sweep is a pipeline over units u = (tile, 32-key block, 32-query block),
+// one step per unit:
+//     matrix pipe:  QK^T of unit u+1 (3 MFMA)  and  P V of unit u-1 (4 MFMA), alternating
+//     VALU:         softmax numerators of unit u (16 v_exp + 8 v_cvt_pk), 3-4 after each MFMA
+//     LDS:          the fragments of the NEXT step's MFMAs, issued at the head of the step
+// Every operand of a step was produced a full step earlier.  `sched_barrier(0)` pins the order; the compiler still
+// inserts the wait counts and hazard nops.  Measured inside the kernel (SA_DBG=20: s_memtime / s_memrealtime): 2130
+// cycles per 64-key tile and wave with two waves per SIMD, i.e. the matrix pipe is 84 % busy during the sweep -- at a
+// shader clock of 1.5-1.6 GHz (the block-by-block kernel: 1.75 GHz): the launch is power limited, which is why the
+// gain in wall time (0.44 -> 0.36 ms) is smaller than the gain in cycles.
+// No running maximum: an out-of-range row shows as l > 2^64 at the end (the denominator rides in the PV MFMAs), the
+// workgroup then finds the exact row maxima in a plain sweep and repeats the pipelined sweep once (never on real
+// activations; adversarial test).
+//
+// The tiles are brought in by buffer_load ... lds (no staging registers, no ds_write).
+// A wave's DMA instruction writes 64 consecutive 16-byte chunks, so the tiles are unpadded (5 chunks per row):
+//   * K rows in key order; a b128 fragment read of 32 consecutive rows at 80-byte pitch is conflict free;
+//   * V rows at slot 16 (k/16) + (k/4)%4 + 4 (k%4) -- a 4x4 transpose inside every 16 keys -- so that the 4 consecutive keys
+//     a 16-lane group of ds_read_b64_tr_b16 touches start 16 banks apart;
+//   * what the padded layout kept in pad columns now comes from constant regions through per-lane base addresses (the
+//     immediates of the reads are shared by all lanes, so a region spans the largest immediate): the K chunk [1, 0 x7]
+//     for the upper-half lanes of k-step 2 (d = 40..47: the reference rides in the reduction), zeros for the lanes
+//     supplying V columns 40..59, the pattern [0, 0, 0, 1] for columns 60..63 (the denominator row).  Zeros rather
+//     than a neighbouring row's bytes: the kernel runs power limited (shader clock 1.55-1.75 GHz, tools/ubench) and a
+//     multiplier fed zeros costs less.
+// Four buffers; tile t+3 is requested in step 2 of tile t, behind the barrier that retires tile t-1's buffer.
+// Persistent workgroups (2 per CU) walk the (batch, head, 256-query block) items: the next item's DMAs and Q loads go
+// out together, and no workgroup launch sits between two items.
+struct PFrag { unsigned u[4]; };
+__device__ __forceinline__ bf16x8 as_frag(const PFrag& p) {
+    union { bf16x8 v; unsigned u[4]; } r;
+    r.u[0] = p.u[0]; r.u[1] = p.u[1]; r.u[2] = p.u[2]; r.u[3] = p.u[3];
+    return r.v;
+}
+__device__ __forceinline__ bf16x8 lds_frag(const bf16_t* p) {
+    union { bf16x8 v; u32x4 u; } r;
+    r.u = *reinterpret_cast<const u32x4*>(p);
+    return r.v;
+}
+#define P40_SB() __builtin_amdgcn_sched_barrier(0)
+#define P40_EXP(x) ((SA_DBG == 13 || SA_DBG == 15) ? (x) * 0.001f : __builtin_amdgcn_exp2f(x))
+constexpr int D40_TILE = SA_BK * 40;                                        // elements of one unpadded tile (5120 B)
+constexpr int D40_BUF = 2 * D40_TILE;                                       // K tile, then V tile
+constexpr int D40_KCONST = 4 * D40_BUF;                                     // [1, 0 x7] at +0 and at +32 rows (the two key blocks)
+constexpr int D40_DUMP = D40_KCONST + 16;                                   // 2 KB scratch for the two dummy DMAs (inside the gap)
+constexpr int D40_VZERO = D40_KCONST + 32 * 40 + 16;                        // 2048 elements of zeros
+constexpr int D40_VCONST = D40_VZERO + 2048;                                // 2048 elements of [0, 0, 0, 1]
+constexpr size_t D40_LDS = (size_t)(D40_VCONST + 2048) * 2;
+static_assert(D40_DUMP + 1024 <= D40_KCONST + 32 * 40, "scratch must fit between the two K constants");
+
+__global__ __launch_bounds__(256, 2) void sa40d_kernel(const SAParams P, const int nitems) {
+    constexpr int NKS = 3, D = 40, CH = 5, RP = 40;                        // RP: row pitch (elements) of both tiles
+    constexpr int KB_STEP = 32 * RP, VS_STEP = 16 * RP, V8 = 2 * RP;      // key block / 16-key group / keys +8 (2 slots)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const uint64_t dbg_c0 = SA_DBG >= 20 ? __builtin_readcyclecounter() : 0, dbg_r0 = SA_DBG >= 20 ? __builtin_amdgcn_s_memrealtime() : 0;
+    uint64_t dbg_sweep = 0;
+
+    // constant regions (once per workgroup)
+    if (tid < 16) smem[D40_KCONST + (tid >> 3) * KB_STEP + (tid & 7)] = ((tid & 7) == 0) ? f2bf(1.f) : (bf16_t)0;
+    for (int i = tid; i < 2048; i += 256) {
+        smem[D40_VZERO + i] = (bf16_t)0;
+        smem[D40_VCONST + i] = ((i & 3) == 3) ? f2bf(1.f) : (bf16_t)0;
+    }
+
+    // per-lane pieces of the DMA (see above): chunk c = 64 * block + lane of a tile -> (row or slot, chunk in row)
+    const int krsB = (int)P.krs * 2, tile_bytes = SA_BK * krsB;
+    auto vkey = [](int slot) { return (slot & ~15) + (slot & 3) * 4 + ((slot >> 2) & 3); };
+    const int c0 = wave * 64 + lane, c2 = 256 + lane;
+    const unsigned vo0 = (unsigned)((c0 / CH) * krsB + (c0 % CH) * 16);
+    const unsigned vo1 = (unsigned)(vkey(c0 / CH) * krsB + (c0 % CH) * 16);
+    const unsigned vo2 = wave == 0 ? (unsigned)((c2 / CH) * krsB + (c2 % CH) * 16)
+                                   : (wave == 1 ? (unsigned)(vkey(c2 / CH) * krsB + (c2 % CH) * 16) : 0x7fff0000u);
+    const int ld0 = wave * 512, ld1 = D40_TILE + wave * 512, ld2 = wave == 0 ? 4 * 512 : D40_TILE + 4 * 512;
+    const int kv_bytes = (int)(((int64_t)(P.Skv - 1) * P.krs + D) * 2);
+    const int ntiles = P.Skv / SA_BK;
+
+    // per-lane fragment addresses inside a buffer (elements).  K: row kb*32 + l31, chunk 2 ks + half.  V^T: slot
+    // 16 (2 kb + s2) + half + 4 r (+2 for keys +8), r = (l31 & 15) >> 2, columns dt*32 + (l31 >> 4)*16 + (l31 & 3)*4.
+    const int ka = l31 * RP + half * 8;
+    const int va = D40_TILE + (half + 4 * ((l31 & 15) >> 2)) * RP + (l31 >> 4) * 16 + (l31 & 3) * 4;
+    const bool kconst = half == 1;
+    const int vsel = (l31 >> 4) == 0 ? ((l31 & 3) >= 2 ? 1 : 0) : ((l31 & 3) == 3 ? 2 : 1);   // dt = 1: 0 data, 1 zeros, 2 [0,0,0,1]
+
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        int bh, qblk;
+        if (P.xcd_remap == 2) {
+            const int xcd = item & 7, within = item >> 3, per_b = P.H * P.nqblk;
+            const int rem = within % per_b;
+            bh = ((within / per_b) * 8 + xcd) * P.H + rem / P.nqblk;
+            qblk = rem % P.nqblk;
+        } else if (P.xcd_remap) {
+            const int xcd = item & 7, within = item >> 3;
+            bh = (within / P.nqblk) * 8 + xcd;
+            qblk = within % P.nqblk;
+        } else {
+            bh = item / P.nqblk;
+            qblk = item % P.nqblk;
+        }
+        const int b = bh / P.H, h = bh - b * P.H;
+        const bf16_t* qg = (const bf16_t*)P.q + (int64_t)b * P.qbs + (int64_t)h * D;
+        const bf16_t* kg = (const bf16_t*)P.k + (int64_t)(b / P.kv_batch_div) * P.kbs + (int64_t)h * D;
+        const bf16_t* vg = (const bf16_t*)P.v + (int64_t)(b / P.kv_batch_div) * P.kbs + (int64_t)h * D;
+        bf16_t* og = (bf16_t*)P.o + (int64_t)b * P.obs + (int64_t)h * D;
+        const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kg, 0, kv_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vg, 0, kv_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs2 = (wave & 1) ? rsV : rsK;
+        auto dma = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned voff, int soff, bf16_t* lds) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, (int)voff, soff, 0, 0);
+        };
+        auto stage_tile = [&](int tile, int buf) {
+            const int so = tile * tile_bytes;
+            bf16_t* base = smem + buf * D40_BUF;
+            dma(rsK, vo0, so, base + ld0);
+            dma(rsV, vo1, so, base + ld1);
+            dma(rs2, vo2, so, wave < 2 ? base + ld2 : smem + D40_DUMP + (wave - 2) * 512);
+        };
+        // fragment loads of key block kb out of buffer `buf`
+        auto kfrags = [&](const bf16_t* buf, int kb, bf16x8 (&kf)[NKS]) {
+            const bf16_t* k01 = buf + ka + kb * KB_STEP;
+            const bf16_t* k2 = kconst ? smem + D40_KCONST + kb * KB_STEP : k01 + 32;
+            kf[0] = lds_frag(k01); kf[1] = lds_frag(k01 + 16); kf[2] = lds_frag(k2);
+        };
+        auto vfrags = [&](const bf16_t* buf, int kb, bf16x8 (&vf)[2][2]) {
+            const bf16_t* v0 = buf + va + kb * 2 * VS_STEP;
+            const bf16_t* v1 = vsel == 0 ? v0 + 32 : smem + (vsel == 1 ? D40_VZERO : D40_VCONST) + kb * 2 * VS_STEP;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                union { bf16x8 v; sa_s4 h[2]; } r0, r1;
+                r0.h[0] = lds_tr16(v0 + s2 * VS_STEP); r0.h[1] = lds_tr16(v0 + s2 * VS_STEP + V8);
+                r1.h[0] = lds_tr16(v1 + s2 * VS_STEP); r1.h[1] = lds_tr16(v1 + s2 * VS_STEP + V8);
+                vf[s2][0] = r0.v; vf[s2][1] = r1.v;
+            }
+        };
+
+        // ---- item prologue: tiles 0..2 requested, then the Q^T fragments while they fly ---------------------------------
+        __syncthreads();                                   // the previous item's fragment reads (and the constants) are done
+        stage_tile(0, 0); stage_tile(1, 1); stage_tile(2, 2);
+        int qrow[2];
+        bf16x8 qf[2][NKS];
+#pragma unroll
+        for (int nq = 0; nq < 2; ++nq) {
+            qrow[nq] = (qblk * SA_WAVES + wave) * 64 + nq * 32 + l31;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const int d0 = ks * 16 + half * 8;
+                Frag<bf16_t> f;
+                if (d0 < D) {
+                    float qv[8];
+                    Vec8<bf16_t>::load(qg + (int64_t)qrow[nq] * P.qrs + d0, qv);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) qv[i] *= P.scale_log2;
+                    p_frag(qv, f);
+                } else {
+                    zero(f);
+                }
+                qf[nq][ks] = f.hi;
+            }
+        }
+        float m_ref[2];
+        auto set_ref = [&](int nq) {
+            const bf16_t mb = f2bf(-m_ref[nq]);
+            m_ref[nq] = -bf2f(mb);
+            union { bf16x8 v; bf16_t e[8]; } u;
+            u.v = qf[nq][NKS - 1];
+            if (half == 1) u.e[0] = mb;
+            qf[nq][NKS - 1] = u.v;
+        };
+        auto scores = [&](const bf16x8 (&kf)[NKS], int nq) {            // plain order, relative to whatever reference sits in qf
+            f32x16 sacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[nq][ks], sacc, 0, 0, 0);
+            return sacc;
+        };
+
+        f32x16 oacc[2][2];
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) { __syncthreads(); stage_tile(0, 0); stage_tile(1, 1); stage_tile(2, 2); }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            bf16x8 kf0[NKS], kf1[NKS], vf0[2][2], vf1[2][2];
+            kfrags(smem, 0, kf0);
+            if (pass == 0) {                   // reference: row maximum over tile 0 (finite: its keys exist)
+                kfrags(smem, 1, kf1);
+#pragma unroll
+                for (int nq = 0; nq < 2; ++nq) {
+                    float mx = fold_max(scores(kf0, nq), -INFINITY);
+                    mx = fold_max(scores(kf1, nq), mx);
+                    m_ref[nq] = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    set_ref(nq);
+                }
+            }
+#pragma unroll
+            for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[nq][dt][r] = 0.f;
+
+            // ---- pipeline fill: S of unit (0, kb0, q0); an all-zero P for the "previous" unit (times finite V of tile 0) ----
+            f32x16 sA, sB;
+            PFrag pA[2], pB[2];
+            vfrags(smem, 0, vf0);
+            vfrags(smem, 1, vf1);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pB[s2].u[i] = 0u;
+            sA = scores(kf0, 0);
+
+            // one pipeline step.  sS -> pS: softmax numerators of this unit; sQ = K(kfQ) Q^T(qfQ): the next unit's scores;
+            // oP += V^T(vfP) P^T(pP): the previous unit's output.  `head` issues this step's LDS / DMA traffic.
+            auto step = [&](const f32x16& sS, PFrag (&pS)[2], f32x16& sQ, const bf16x8 (&kfQ)[NKS], const bf16x8 (&qfQ)[NKS],
+                            const PFrag (&pP)[2], const bf16x8 (&vfP)[2][2], f32x16 (&oP)[2], auto&& head) {
+                float e[16];
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                P40_SB();
+                if (SA_DBG != 11 && SA_DBG != 15) head();
+                P40_SB();
+                sQ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfQ[0], qfQ[0], z, 0, 0, 0);
+                P40_SB();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) e[i] = P40_EXP(sS[i]);
+                P40_SB();
+                oP[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfP[0][0], as_frag(pP[0]), oP[0], 0, 0, 0);
+                P40_SB();
+                pS[0].u[0] = pack_bf2(e[0], e[1]); pS[0].u[1] = pack_bf2(e[2], e[3]);
+                e[4] = P40_EXP(sS[4]); e[5] = P40_EXP(sS[5]);
+                P40_SB();
+                sQ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfQ[1], qfQ[1], sQ, 0, 0, 0);
+                P40_SB();
+                e[6] = P40_EXP(sS[6]); e[7] = P40_EXP(sS[7]);
+                pS[0].u[2] = pack_bf2(e[4], e[5]);
+                e[8] = P40_EXP(sS[8]);
+                pS[0].u[3] = pack_bf2(e[6], e[7]);
+                P40_SB();
+                oP[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfP[0][1], as_frag(pP[0]), oP[1], 0, 0, 0);
+                P40_SB();
+                e[9] = P40_EXP(sS[9]); e[10] = P40_EXP(sS[10]); e[11] = P40_EXP(sS[11]);
+                P40_SB();
+                sQ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfQ[2], qfQ[2], sQ, 0, 0, 0);
+                P40_SB();
+                pS[1].u[0] = pack_bf2(e[8], e[9]); pS[1].u[1] = pack_bf2(e[10], e[11]);
+                e[12] = P40_EXP(sS[12]); e[13] = P40_EXP(sS[13]);
+                P40_SB();
+                oP[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfP[1][0], as_frag(pP[1]), oP[0], 0, 0, 0);
+                P40_SB();
+                e[14] = P40_EXP(sS[14]); e[15] = P40_EXP(sS[15]);
+                pS[1].u[2] = pack_bf2(e[12], e[13]);
+                P40_SB();
+                oP[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfP[1][1], as_frag(pP[1]), oP[1], 0, 0, 0);
+                P40_SB();
+                pS[1].u[3] = pack_bf2(e[14], e[15]);
+                P40_SB();
+            };
+
+            const uint64_t dbg_s0 = SA_DBG >= 20 ? __builtin_readcyclecounter() : 0;
+            for (int t = 0; t < ntiles; ++t) {
+                const bf16_t* cur = smem + (t & 3) * D40_BUF;
+                const bf16_t* nxt = smem + ((t + 1) & 3) * D40_BUF;
+                // step 0: unit (kb0, q0); QK^T of (kb0, q1); PV of the previous tile's (kb1, q1); K fragments of kb1
+                step(sA, pA, sB, kf0, qf[1], pB, vf1, oacc[1], [&] { kfrags(cur, 1, kf1); });
+                // step 1: unit (kb0, q1); QK^T of (kb1, q0); PV of (kb0, q0); V^T fragments of kb1
+                step(sB, pB, sA, kf1, qf[0], pA, vf0, oacc[0], [&] { vfrags(cur, 1, vf1); });
+                // behind this barrier every wave is done reading tile t-1's buffer (tile t+3 goes there) and tile t+1 has landed:
+                // the three youngest DMAs of a wave belong to tile t+2
+                if (SA_DBG != 11 && SA_DBG != 14 && SA_DBG != 15) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                // step 2: unit (kb1, q0); QK^T of (kb1, q1); PV of (kb0, q1); tile t+3 requested; K fragments of the next tile
+                step(sA, pA, sB, kf1, qf[1], pB, vf0, oacc[1], [&] {
+                    if (SA_DBG != 12) stage_tile(t + 3, (t + 3) & 3);
+                    kfrags(nxt, 0, kf0);
+                });
+                // step 3: unit (kb1, q1); QK^T of the next tile's (kb0, q0); PV of (kb1, q0); V^T fragments of the next tile's kb0
+                step(sB, pB, sA, kf0, qf[0], pA, vf1, oacc[0], [&] { vfrags(nxt, 0, vf0); });
+            }
+            if (SA_DBG >= 20) dbg_sweep += __builtin_readcyclecounter() - dbg_s0;
+            // drain: PV of the last unit
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    oacc[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[s2][dt], as_frag(pB[s2]), oacc[1][dt], 0, 0, 0);
+
+            // ---- did a row leave the range of the fixed reference?  (block-uniform) -----------------------------------------
+            bool bad = false;
+#pragma unroll
+            for (int nq = 0; nq < 2; ++nq) bad = bad || (half == 1 && oacc[nq][1][15] > 1.8446744e19f);
+            if (pass == 1 || !__syncthreads_or(bad)) break;
+            // exact row maxima in a plain sweep (tile by tile through buffer 0), then once more
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the out-of-range tiles the pipeline still had in flight
+            float worst[2] = {-INFINITY, -INFINITY};
+            for (int t = 0; t < ntiles; ++t) {
+                __syncthreads();
+                stage_tile(t, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                kfrags(smem, 0, kf0);
+                kfrags(smem, 1, kf1);
+#pragma unroll
+                for (int nq = 0; nq < 2; ++nq) {
+                    worst[nq] = fold_max(scores(kf0, nq), worst[nq]);
+                    worst[nq] = fold_max(scores(kf1, nq), worst[nq]);
+                }
+            }
+#pragma unroll
+            for (int nq = 0; nq < 2; ++nq) {
+                m_ref[nq] += fmaxf(worst[nq], __shfl_xor(worst[nq], 32, 64));
+                set_ref(nq);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // out-of-range tiles still in flight must not land in the next item's buffers
+
+        // ---- item epilogue ------------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int nq = 0; nq < 2; ++nq) {
+            const float l_tot = __shfl(oacc[nq][1][15], l31 + 32, 64);   // O^T row 63 (the [0,0,0,1] column of V): upper half, register 15
+            const float inv = 1.f / l_tot;
+            bf16_t* orow = og + (int64_t)qrow[nq] * P.ors;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = dt * 32 + 8 * g + 4 * half;
+                    if (d < D)
+                        store4<bf16_t>(orow + d, oacc[nq][dt][4 * g] * inv, oacc[nq][dt][4 * g + 1] * inv, oacc[nq][dt][4 * g + 2] * inv,
+                                       oacc[nq][dt][4 * g + 3] * inv);
+                }
+            }
+            if (SA_DBG < 20 && P.lse && half == 0) P.lse[((int64_t)b * P.H + h) * P.Sq + qrow[nq]] = m_ref[nq] * 0.6931471805599453f + logf(l_tot);
+        }
+    }
+    if (SA_DBG >= 20 && P.lse && lane == 0) {     // shader cycles: whole workgroup, pipelined sweeps; 100 MHz ticks: whole workgroup
+        float* dst = P.lse + ((int64_t)blockIdx.x * 4 + wave) * 4;
+        dst[0] = (float)(__builtin_readcyclecounter() - dbg_c0); dst[1] = (float)dbg_sweep;
+        dst[2] = (float)(__builtin_amdgcn_s_memrealtime() - dbg_r0); dst[3] = (float)blockIdx.x;
+    }
+}
+
+inline int sa_pipe_env() {            // FMC_SA_PIPE=0: the block-by-block kernel at d = 40 too (A/B); 4: persistent workgroups
+    static const int v = [] {
+        const char* e = getenv("FMC_SA_PIPE");
+        return e ? atoi(e) : 1;
+    }();
+    return v;
+}
+inline bool sa40_ok(const SAParams& P) {
+    return P.D == 40 && P.Skv % SA_BK == 0 && P.Skv >= 2 * SA_BK && P.Sq % 256 == 0 && P.krs * 2 * (int64_t)P.Skv < (1ll << 31) &&
+           sa_pipe_env() != 0;
+}
+inline void launch_sa40(const SAParams& Pin, hipStream_t st) {
+    SAParams P = Pin;
+    P.nqblk = P.Sq / 256;
+    const int nitems = P.B * P.H * P.nqblk;
+    // One workgroup per item by default: the hardware's dispatch balances the CUs inside an XCD (workgroup times spread
+    // 53..78 us, the XCDs' clocks 1.48..1.61 GHz); FMC_SA_PIPE=4 runs 2 persistent workgroups per CU over a static item
+    // list instead -- measured 4 % slower for that reason.
+    int grid = nitems;
+    if (sa_pipe_env() == 4) {
+        static const int resident = [] {
+            int dev = 0, cus = 256;
+            (void)hipGetDevice(&dev);
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            return 2 * cus;
+        }();
+        if (nitems > resident) grid = resident;
+    }
+    hipLaunchKernelGGL(sa40d_kernel, dim3((unsigned)grid), dim3(256), D40_LDS, st, P, nitems);
 }
 
 template <typename T, int NKS, bool SHORT_KV, bool PF, int NQ = 1, bool MK = false, bool VR = false>
@@ -649,6 +1045,11 @@ extern "C" int fmc_spatial_attn_fwd(const void* q, const void* k, const void* v,
         if (want == 0 || (want == 1 && (B * H) % 8 == 0)) P.xcd_remap = want;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == FMC_BF16 && sa40_ok(P)) {
+        launch_sa40(P, st);
+        FMC_CHECK_LAUNCH("fmc_spatial_attn_fwd");
+        return 0;
+    }
     int rc = (dtype == FMC_BF16) ? dispatch_sa<bf16_t>(P, st) : dispatch_sa<float>(P, st);
     if (rc) return rc;
     FMC_CHECK_LAUNCH("fmc_spatial_attn_fwd");

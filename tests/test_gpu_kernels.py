@@ -193,6 +193,63 @@ def test_spatial_attention_reference_redo(K, dtype, H, D):
     assert (lse.cpu() - lse_ref).abs().max() < (2e-3 if dtype == torch.float32 else 0.5)
 
 
+@pytest.mark.parametrize("B,S,Skv,H,fused", [(8, 256, 256, 8, True), (3, 512, 128, 8, False), (1, 256, 1536, 2, False),
+                                             (16, 768, 768, 8, True), (2, 256, 192, 5, False)])
+def test_spatial_attention_pipelined_d40(K, B, S, Skv, H, fused):
+    """The software-pipelined d = 40 kernel (bf16, S_q % 256 == 0, S_kv % 64 == 0: `sa40d_kernel`): every block -> XCD map
+    (batch % 8 == 0, (batch * heads) % 8 == 0, neither), 2 .. 24 K/V tiles (the 4-buffer DMA ring wraps, and with 2 or 3
+    tiles part of the prologue's requests are out of range), q/k/v as slices of one fused projection, LSE."""
+    D, dtype = 40, torch.bfloat16
+    C = H * D
+    if fused:
+        qkvo, qkvd = rnd((B, S, 3 * C), 60, dtype)
+        qo, ko, vo = qkvo[..., :C], qkvo[..., C:2 * C], qkvo[..., 2 * C:]
+        qd, kd, vd = qkvd[..., :C], qkvd[..., C:2 * C], qkvd[..., 2 * C:]
+    else:
+        qo, qd = rnd((B, S, C), 61, dtype)
+        ko, kd = rnd((B, Skv, C), 62, dtype)
+        vo, vd = rnd((B, Skv, C), 63, dtype)
+    ref = oracle_attention(qo, ko, vo, H)
+    out, lse = K.spatial_attention(qd, kd, vd, H, return_lse=True)
+    assert rel_inf(out.float(), ref) < TOL[dtype]
+    qh = qo.reshape(B, S, H, D).permute(0, 2, 1, 3)
+    kh = ko.reshape(B, Skv, H, D).permute(0, 2, 1, 3)
+    lse_ref = torch.logsumexp(qh @ kh.transpose(-1, -2) * D ** -0.5, dim=-1)
+    assert (lse.cpu() - lse_ref).abs().max() < 2e-2
+    # shared text-style K/V (kv batch = batch / frames) through the same kernel
+    if not fused and Skv == 128:
+        k1o, k1d = rnd((1, Skv, C), 64, dtype)
+        v1o, v1d = rnd((1, Skv, C), 65, dtype)
+        ref = oracle_attention(qo, k1o.expand(B, -1, -1), v1o.expand(B, -1, -1), H)
+        assert rel_inf(K.spatial_attention(qd, k1d, v1d, H).float(), ref) < TOL[dtype]
+
+
+def test_spatial_attention_pipelined_reference_redo(K):
+    """The pipelined kernel keeps no running maximum: a row whose logits leave the range of the first-tile reference shows as
+    an overflowing denominator, the workgroup finds the exact maxima in a plain sweep and repeats the pipelined one.  The
+    spike sits in tile 5 of 8 (behind the prologue's tiles); the other workgroup of the launch must be unaffected."""
+    B, S, H, D, dtype = 1, 512, 2, 40, torch.bfloat16
+    C = H * D
+    qo, qd = rnd((B, S, C), 70, dtype)
+    ko, kd = rnd((B, S, C), 71, dtype)
+    vo, vd = rnd((B, S, C), 72, dtype)
+    gain = 90.0 / float((qo[0, 7, :D] ** 2).sum() * D ** -0.5)
+    for t in (ko, kd):
+        t[0, 330] = (qo[0, 7] * gain).to(t.dtype)
+    ko[0, 330] = kd[0, 330].float().cpu()
+    spike = (qo[0, 7, :D] * ko[0, 330, :D]).sum() * D ** -0.5
+    assert spike * 1.4427 > 100.0, spike
+    ref = oracle_attention(qo, ko, vo, H)
+    out, lse = K.spatial_attention(qd, kd, vd, H, return_lse=True)
+    assert torch.isfinite(out).all()
+    assert rel_inf(out.float(), ref) < 5e-2                                     # |logit| ~ 100 in bf16, as in the test above
+    assert rel_inf(out[:, 256:].float(), ref[:, 256:]) < 5e-2                   # the other workgroup (no redo there; its logits against the spike key reach ~40)
+    qh = qo.view(B, S, H, D).permute(0, 2, 1, 3)
+    kh = ko.view(B, S, H, D).permute(0, 2, 1, 3)
+    lse_ref = torch.logsumexp(qh @ kh.transpose(-1, -2) * D ** -0.5, dim=-1)
+    assert (lse.cpu() - lse_ref).abs().max() < 0.5
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,Fr,P,H,D", [(2, 16, 20, 8, 40), (1, 16, 9, 8, 80), (2, 16, 5, 8, 160), (1, 32, 6, 8, 40),
                                         (1, 32, 3, 8, 160), (2, 16, 7, 4, 8), (1, 16, 4, 8, 16)])
