@@ -117,12 +117,15 @@ def measure_attention_roofline(device, dtype, iters=20):
     ms = e0.elapsed_time(e1) / iters
     flops = 4.0 * B * H * S * S * D
     achieved = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "spatial_attn_kernel<bf16,d=40,self> [B*H=256,S=2560]", "achieved": round(achieved, 2),
+    return {"bound": "mfma", "kernel": "sa40d_kernel (software-pipelined spatial self-attention, bf16, d=40) [B*H=256,S=2560]", "achieved": round(achieved, 2),
             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
             "avg_launch_ms": round(ms, 4), "flops_per_launch": flops,
             # HBM-side bytes per launch of this exact shape, from rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, the
-            # gfx950 correction of MI355X_MICROARCH.md); recorded, not re-measured here: profiles/r01_attn_pmc.md
-            "traffic": 259.6e6, "traffic_algorithmic": 4.0 * B * S * H * D * 2}
+            # gfx950 correction of MI355X_MICROARCH.md); recorded, not re-measured here: tools/pmc_attn40.sh -> profiles/r02_attn_pmc.md
+            "traffic": 250.6e6, "traffic_algorithmic": 4.0 * B * S * H * D * 2,
+            # the launch is power limited: shader clock measured inside the kernel (s_memtime / s_memrealtime, SA_DBG=20) and from
+            # GRBM_GUI_ACTIVE / duration; `peak` above is the 2.4 GHz figure
+            "shader_clock_ghz_under_load": 1.6, "matrix_pipe_busy": 0.65}
 
 
 def measure_conv_roofline(device, dtype, iters=20):

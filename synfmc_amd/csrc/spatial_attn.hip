@@ -581,7 +581,7 @@ constexpr int D40_BUF = 2 * D40_TILE;                                       // K
 constexpr int D40_KCONST = 4 * D40_BUF;                                     // [1, 0 x7] at +0 and at +32 rows (the two key blocks)
 constexpr int D40_DUMP = D40_KCONST + 16;                                   // 2 KB scratch for the two dummy DMAs (inside the gap)
 constexpr int D40_VZERO = D40_KCONST + 32 * 40 + 16;                        // 2048 elements of zeros
-constexpr int D40_VCONST = D40_VZERO + 2048;                                // 2048 elements of [0, 0, 0, 1]
+constexpr int D40_VCONST = D40_VZERO + 2048 + 8;                            // 2048 elements of [0, 0, 0, 1]; +8: not the zero region's banks
 constexpr size_t D40_LDS = (size_t)(D40_VCONST + 2048) * 2;
 static_assert(D40_DUMP + 1024 <= D40_KCONST + 32 * 40, "scratch must fit between the two K constants");
 

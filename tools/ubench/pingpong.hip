@@ -42,6 +42,7 @@ __device__ __forceinline__ void softmax_role(float (&x)[64], uint32_t (&pk)[32],
 template <int MODE, bool MAX3>
 __global__ __launch_bounds__(512) void pp_kernel(float* out, int iters, float seed) {
     const int wave = threadIdx.x >> 6;
+    const uint64_t c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
     f32x16 acc[4];
     for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     bf16x8 a, b;
@@ -79,6 +80,10 @@ __global__ __launch_bounds__(512) void pp_kernel(float* out, int iters, float se
     for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) s += acc[t][r];
     for (int i = 0; i < 32; ++i) s += (float)pk[i];
     if (s == 12345.678f) out[threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x < 256) {   // shader cycles and 100 MHz ticks of this workgroup
+        out[1024 + blockIdx.x * 2] = (float)(__builtin_readcyclecounter() - c0);
+        out[1024 + blockIdx.x * 2 + 1] = (float)(__builtin_amdgcn_s_memrealtime() - r0);
+    }
 }
 
 template <int MODE, bool MAX3> void run(const char* what, float* out) {
@@ -91,10 +96,15 @@ template <int MODE, bool MAX3> void run(const char* what, float* out) {
     float ms; hipEventElapsedTime(&ms, e0, e1);
     // grid / 256 workgroups per CU one after the other; per iteration per workgroup:
     const double us_it = ms * 1e3 / iters / (grid / 256);
-    printf("mode %d max3=%d  %-58s %8.3f us/iter  (~%5.0f cycles @2.4GHz)\n", MODE, (int)MAX3, what, us_it, us_it * 2400);
+    std::vector<float> h(512);
+    hipMemcpy(h.data(), out + 1024, 512 * 4, hipMemcpyDeviceToHost);
+    double c = 0, r = 0;
+    for (int i = 0; i < 256; ++i) { c += h[2 * i]; r += h[2 * i + 1]; }
+    const double ghz = c / (r * 10.0);
+    printf("mode %d max3=%d  %-58s %8.3f us/iter  %5.0f cycles/iter at the measured shader clock %.2f GHz\n", MODE, (int)MAX3, what, us_it, c / 256 / iters, ghz);
 }
 int main() {
-    float* out; hipMalloc(&out, 4096);
+    float* out; hipMalloc(&out, 8192);
     run<0, true>("matrix role only (28 MFMA, waves 0-3)", out);
     run<1, true>("softmax role only (64 exp+32 cvt+32 max3, waves 4-7)", out);
     run<1, false>("softmax role only, no max3", out);
