@@ -702,7 +702,11 @@ def _streamk_workspace(device):
     key = (device.index, torch.cuda.current_stream().cuda_stream)
     ws = _sk_ws.get(key)
     if ws is None:
-        ws = torch.zeros((4096 + 1856 * 256 * 256 * 4) // 4, dtype=torch.float32, device=device)     # (8-phase arms: <= 7 slots per CU)
+        # (8-phase arms: <= 7 slots per CU.)  Only the flag words must start at zero; the partial slots are written before they are
+        # read.  A full torch.zeros here was a 486 MB fill -- and, first reached under graph capture (the capture stream is a new
+        # key), one that was replayed with every step: 60 us of the 16x320x512 step.
+        ws = torch.empty((4096 + 1856 * 256 * 256 * 4) // 4, dtype=torch.float32, device=device)
+        ws[:1024].zero_()
         _sk_ws[key] = ws
     return ws.data_ptr(), ws.numel() * 4
 
