@@ -65,7 +65,10 @@ __device__ __forceinline__ void mma_qk(const F8<float>& a, const F8<float>& b, f
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.hi, acc, 0, 0, 0);
 }
 __device__ __forceinline__ void make_f4(const float (&v)[4], F4<bf16_t>& f) {
-    f.hi = s16x4{(short)f2bf(v[0]), (short)f2bf(v[1]), (short)f2bf(v[2]), (short)f2bf(v[3])};
+    union { s16x4 s; unsigned u[2]; } r;
+    r.u[0] = pack_bf2(v[0], v[1]);
+    r.u[1] = pack_bf2(v[2], v[3]);
+    f.hi = r.s;
 }
 __device__ __forceinline__ void make_f4(const float (&v)[4], F4<float>& f) {
     bf16_t h[4], l[4];
@@ -82,6 +85,9 @@ __device__ __forceinline__ void mma_pv(const F4<float>& a, const F4<float>& b, f
     acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.hi, b.lo, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.hi, b.hi, acc, 0, 0, 0);
 }
+template <typename T> __device__ __forceinline__ F4<T> tr_f4(s16x4 v);
+template <> __device__ __forceinline__ F4<bf16_t> tr_f4<bf16_t>(s16x4 v) { F4<bf16_t> f; f.hi = v; return f; }
+template <> __device__ __forceinline__ F4<float> tr_f4<float>(s16x4 v) { F4<float> f; f.hi = v; f.lo = v; return f; }   // (never taken: fp32 rows are not 2-byte)
 __device__ __forceinline__ float ldsf(const bf16_t* p) { return bf2f(*p); }
 __device__ __forceinline__ float ldsf(const float* p) { return *p; }
 
@@ -94,8 +100,8 @@ template <> __device__ __forceinline__ void st4<float>(float* p, const float (&v
 }
 
 // FT = F/16 frame tiles; NK32 = ceil(D/32) k-steps of the QK^T reduction
-template <typename T, int FT, int NK32>
-__global__ __launch_bounds__(256) void temporal_attn_kernel(const TAParams P) {
+template <typename T, int FT, int NK32, int NWV>     // NWV waves per unit (they split its heads)
+__global__ __launch_bounds__(64 * NWV) void temporal_attn_kernel(const TAParams P) {
     constexpr int F = FT * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int D = P.D, GH = P.GH, CW = GH * D, CPR = CW / 8, PITCH = CW + 8;
@@ -105,7 +111,8 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TAParams P) {
     // up to 4 waves per unit: they stage the rows together and split the unit's heads, so that the short dependent
     // chains of one head (LDS read -> MFMA -> softmax -> MFMA -> LDS write) overlap with other heads' (one wave per
     // unit ran at ~1 wave per SIMD -- the LDS footprint caps a CU at 5 units -- and every latency was exposed)
-    const int tid = threadIdx.x, NTH = blockDim.x, wave = tid >> 6, NWV = NTH >> 6;
+    constexpr int NTH = 64 * NWV;
+    const int tid = threadIdx.x, wave = tid >> 6;
     const int lane = tid & 63;
     const int l15 = lane & 15, lg = lane >> 4;
 
@@ -120,21 +127,63 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TAParams P) {
 
     // ---- stage Q, K, V: global -> LDS, 16 bytes per lane per load -------------------------------------
     const int chunks = F * CPR;
+    if constexpr (sizeof(T) == 2) {
+        // every 16-byte load of the unit (Q, K and V rows: 30 KB at F = 16) is in flight before the first LDS write: the unit pays ONE
+        // memory round trip (tensor by tensor, as first written, it paid three), and the rows pass through as raw words
+        constexpr int MAXC = (F * 40 + NTH - 1) / NTH;     // chunks per thread and tensor at the widest unit (CW = 320)
+        if (CPR <= 40 && MAXC <= 3) {               // (5 chunks per tensor in registers -- the 2-wave units at d = 160 -- measured slower than the loop)
+            u32x4 r[3][MAXC];
+#pragma unroll
+            for (int which = 0; which < 3; ++which) {
+                const T* src = (const T*)(which == 0 ? P.q : (which == 1 ? P.k : P.v)) + in_off;
+#pragma unroll
+                for (int j = 0; j < MAXC; ++j) {
+                    const int c = tid + j * NTH, f = c / CPR, ch = c - f * CPR;
+                    if (c < chunks) r[which][j] = *reinterpret_cast<const u32x4*>(src + (int64_t)f * P.fs + ch * 8);
+                }
+            }
+#pragma unroll
+            for (int which = 0; which < 3; ++which) {
+                T* dst = which == 0 ? Qs : (which == 1 ? Ks : Vs);
+#pragma unroll
+                for (int j = 0; j < MAXC; ++j) {
+                    const int c = tid + j * NTH, f = c / CPR, ch = c - f * CPR;
+                    if (c < chunks) *reinterpret_cast<u32x4*>(dst + f * PITCH + ch * 8) = r[which][j];
+                }
+            }
+        } else {
 #pragma unroll 1
-    for (int which = 0; which < 3; ++which) {
-        const T* src = (const T*)(which == 0 ? P.q : (which == 1 ? P.k : P.v)) + in_off;
-        T* dst = which == 0 ? Qs : (which == 1 ? Ks : Vs);
+            for (int which = 0; which < 3; ++which) {
+                const T* src = (const T*)(which == 0 ? P.q : (which == 1 ? P.k : P.v)) + in_off;
+                T* dst = which == 0 ? Qs : (which == 1 ? Ks : Vs);
 #pragma unroll 5
-        for (int c = tid; c < chunks; c += NTH) {
-            const int f = c / CPR, ch = c - f * CPR;
-            float v[8];
-            Vec8<T>::load(src + (int64_t)f * P.fs + ch * 8, v);
-            Vec8<T>::store(dst + f * PITCH + ch * 8, v);
+                for (int c = tid; c < chunks; c += NTH) {
+                    const int f = c / CPR, ch = c - f * CPR;
+                    *reinterpret_cast<u32x4*>(dst + f * PITCH + ch * 8) = *reinterpret_cast<const u32x4*>(src + (int64_t)f * P.fs + ch * 8);
+                }
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (int which = 0; which < 3; ++which) {
+            const T* src = (const T*)(which == 0 ? P.q : (which == 1 ? P.k : P.v)) + in_off;
+            T* dst = which == 0 ? Qs : (which == 1 ? Ks : Vs);
+#pragma unroll 5
+            for (int c = tid; c < chunks; c += NTH) {
+                const int f = c / CPR, ch = c - f * CPR;
+                float v[8];
+                Vec8<T>::load(src + (int64_t)f * P.fs + ch * 8, v);
+                Vec8<T>::store(dst + f * PITCH + ch * 8, v);
+            }
         }
     }
     __syncthreads();
 
-    for (int hh = wave; hh < GH; hh += NWV) {
+#define TA_EXP2(x) __builtin_amdgcn_exp2f(x)
+#ifndef TA_DBG
+#define TA_DBG 0      // timing knock-outs (tools/ubench/ta_bench): 1 no attention arithmetic (rows in, Q rows out)
+#endif
+    for (int hh = wave; hh < (TA_DBG == 1 ? 0 : GH); hh += NWV) {
         const int hc = hh * D;
 #pragma unroll
         for (int qt = 0; qt < FT; ++qt) {
@@ -169,7 +218,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TAParams P) {
 #pragma unroll
             for (int kt = 0; kt < FT; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { s[kt][r] = exp2f(s[kt][r] - mx); sum += s[kt][r]; }
+                for (int r = 0; r < 4; ++r) { s[kt][r] = TA_EXP2(s[kt][r] - mx); sum += s[kt][r]; }
             sum += __shfl_xor(sum, 16, 64);
             sum += __shfl_xor(sum, 32, 64);
             const float inv = 1.f / sum;
@@ -186,12 +235,23 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TAParams P) {
                 const int dA = dt * 16 + l15;       // channel of this lane's V^T row
 #pragma unroll
                 for (int kt = 0; kt < FT; ++kt) {
-                    float v4[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        v4[i] = dA < D ? ldsf(Vs + (kt * 16 + lg * 4 + i) * PITCH + hc + dA) : 0.f;
                     F4<T> vf;
-                    make_f4(v4, vf);
+                    if constexpr (sizeof(T) == 2) {
+                        // transpose read: inside a 16-lane group lane i supplies row (key) i/4, columns 4(i%4).. of the [4 keys][16 d] block and
+                        // receives column i -- keys lg*4..+3 of channel dt*16 + l15, the A fragment as it is (was: four 2-byte reads and
+                        // four conversions).  Channels >= D of the last block read the neighbouring head / the pad: those output rows
+                        // are never stored
+                        const bf16_t* vp = reinterpret_cast<const bf16_t*>(Vs) + (kt * 16 + lg * 4 + (l15 >> 2)) * PITCH + hc + dt * 16 + (l15 & 3) * 4;
+                        typedef short __attribute__((ext_vector_type(4))) ta_s4;
+                        const ta_s4 t4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ta_s4*)(vp));
+                        vf = tr_f4<T>(s16x4{t4[0], t4[1], t4[2], t4[3]});
+                    } else {
+                        float v4[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            v4[i] = dA < D ? ldsf(Vs + (kt * 16 + lg * 4 + i) * PITCH + hc + dA) : 0.f;
+                        make_f4(v4, vf);
+                    }
                     mma_pv(vf, pf[kt], o);
                 }
                 const int dO = dt * 16 + lg * 4;    // 4 consecutive output channels of query l15
@@ -209,9 +269,13 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TAParams P) {
 #pragma unroll 5
     for (int c = tid; c < chunks; c += NTH) {
         const int f = c / CPR, ch = c - f * CPR;
-        float v[8];
-        Vec8<T>::load(Qs + f * PITCH + ch * 8, v);
-        Vec8<T>::store(og + (int64_t)f * P.ofs + ch * 8, v);
+        if constexpr (sizeof(T) == 2) {
+            *reinterpret_cast<u32x4*>(og + (int64_t)f * P.ofs + ch * 8) = *reinterpret_cast<const u32x4*>(Qs + f * PITCH + ch * 8);
+        } else {
+            float v[8];
+            Vec8<T>::load(Qs + f * PITCH + ch * 8, v);
+            Vec8<T>::store(og + (int64_t)f * P.ofs + ch * 8, v);
+        }
     }
 }
 
@@ -257,14 +321,37 @@ __global__ __launch_bounds__(256) void temporal_attn_fp8_kernel(const TA8Params 
     const float sl2 = P.scale_log2 * sq * sk;
 
     const int chunks = F * CPR16;                    // 16 bytes = 16 channels per lane and load
+    constexpr int MAXC8 = (F * 20 + 255) / 256;      // chunks per thread and tensor at the widest unit on 256 threads
+    if (NTH == 256 && CPR16 <= 20) {                 // every load of the unit in flight before the first LDS write (one round trip, not three)
+        u32x4 r[3][MAXC8];
+#pragma unroll
+        for (int which = 0; which < 3; ++which) {
+            const unsigned char* src = (which == 0 ? P.q : (which == 1 ? P.k : P.v)) + in_off;
+#pragma unroll
+            for (int j = 0; j < MAXC8; ++j) {
+                const int c = tid + j * 256, f = c / CPR16, ch = c - f * CPR16;
+                if (c < chunks) r[which][j] = *reinterpret_cast<const u32x4*>(src + (int64_t)f * P.fs + ch * 16);
+            }
+        }
+#pragma unroll
+        for (int which = 0; which < 3; ++which) {
+            unsigned char* dst = which == 0 ? Qs : (which == 1 ? Ks : Vs);
+#pragma unroll
+            for (int j = 0; j < MAXC8; ++j) {
+                const int c = tid + j * 256, f = c / CPR16, ch = c - f * CPR16;
+                if (c < chunks) *reinterpret_cast<u32x4*>(dst + f * PB + ch * 16) = r[which][j];
+            }
+        }
+    } else {
 #pragma unroll 1
-    for (int which = 0; which < 3; ++which) {
-        const unsigned char* src = (which == 0 ? P.q : (which == 1 ? P.k : P.v)) + in_off;
-        unsigned char* dst = which == 0 ? Qs : (which == 1 ? Ks : Vs);
+        for (int which = 0; which < 3; ++which) {
+            const unsigned char* src = (which == 0 ? P.q : (which == 1 ? P.k : P.v)) + in_off;
+            unsigned char* dst = which == 0 ? Qs : (which == 1 ? Ks : Vs);
 #pragma unroll 5
-        for (int c = tid; c < chunks; c += NTH) {
-            const int f = c / CPR16, ch = c - f * CPR16;
-            *reinterpret_cast<u32x4*>(dst + f * PB + ch * 16) = *reinterpret_cast<const u32x4*>(src + (int64_t)f * P.fs + ch * 16);
+            for (int c = tid; c < chunks; c += NTH) {
+                const int f = c / CPR16, ch = c - f * CPR16;
+                *reinterpret_cast<u32x4*>(dst + f * PB + ch * 16) = *reinterpret_cast<const u32x4*>(src + (int64_t)f * P.fs + ch * 16);
+            }
         }
     }
     __syncthreads();
@@ -301,7 +388,7 @@ __global__ __launch_bounds__(256) void temporal_attn_fp8_kernel(const TA8Params 
 #pragma unroll
             for (int kt = 0; kt < FT; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { s[kt][r] = exp2f(s[kt][r] - mx); sum += s[kt][r]; }
+                for (int r = 0; r < 4; ++r) { s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - mx); sum += s[kt][r]; }
             sum += __shfl_xor(sum, 16, 64);
             sum += __shfl_xor(sum, 32, 64);
             const float inv = 1.f / sum;
@@ -396,8 +483,36 @@ __global__ __launch_bounds__(256) void temporal_attn_bwd_kernel(const TABwdParam
     const int64_t dq_off = (int64_t)clip * P.dcs + (int64_t)pix * P.dps + (int64_t)hg * CW;
 
     const int chunks = F * CPR;
+    bool staged = false;
+    if constexpr (sizeof(T) == 2 && FT == 1) {
+        if (NTH == 256 && CPR <= 40 && !P.q8_scales) {   // Q, K, V, dO rows: every load in flight before the first LDS write (one round trip, not four)
+            constexpr int MAXCB = (F * 40 + 255) / 256;
+            u32x4 r[4][MAXCB];
+#pragma unroll
+            for (int which = 0; which < 4; ++which) {
+                const T* src = which == 0 ? (const T*)P.q + in_off : which == 1 ? (const T*)P.k + in_off
+                             : which == 2 ? (const T*)P.v + in_off : (const T*)P.d_o + go_off;
+                const int64_t fstride = which == 3 ? P.ofs : P.fs;
+#pragma unroll
+                for (int j = 0; j < MAXCB; ++j) {
+                    const int c = tid + j * 256, f = c / CPR, ch = c - f * CPR;
+                    if (c < chunks) r[which][j] = *reinterpret_cast<const u32x4*>(src + (int64_t)f * fstride + ch * 8);
+                }
+            }
+#pragma unroll
+            for (int which = 0; which < 4; ++which) {
+                T* dst = which == 0 ? Qs : which == 1 ? Ks : which == 2 ? Vs : Gs;
+#pragma unroll
+                for (int j = 0; j < MAXCB; ++j) {
+                    const int c = tid + j * 256, f = c / CPR, ch = c - f * CPR;
+                    if (c < chunks) *reinterpret_cast<u32x4*>(dst + f * PITCH + ch * 8) = r[which][j];
+                }
+            }
+            staged = true;
+        }
+    }
 #pragma unroll 1
-    for (int which = 0; which < 4; ++which) {
+    for (int which = 0; which < (staged ? 0 : 4); ++which) {
         T* dst = which == 0 ? Qs : which == 1 ? Ks : which == 2 ? Vs : Gs;
         if (P.q8_scales && which < 3) {
             const unsigned char* src8 = (const unsigned char*)(which == 0 ? P.q : which == 1 ? P.k : P.v) + in_off;
@@ -465,7 +580,7 @@ __global__ __launch_bounds__(256) void temporal_attn_bwd_kernel(const TABwdParam
 #pragma unroll
             for (int kt = 0; kt < FT; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { s[kt][r] = exp2f(s[kt][r] - mx); sum += s[kt][r]; }
+                for (int r = 0; r < 4; ++r) { s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - mx); sum += s[kt][r]; }
             sum += __shfl_xor(sum, 16, 64);
             sum += __shfl_xor(sum, 32, 64);
             const float inv = 1.f / sum;
@@ -608,17 +723,22 @@ template <typename T, int FT, int NK32>
 void launch_ta(const TAParams& P, hipStream_t st) {
     const int CW = P.GH * P.D;
     const size_t lds = sizeof(T) * 3 * (size_t)(FT * 16) * (CW + 8);
-    if (lds > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_attn_kernel<T, FT, NK32>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            raised = true;
+    dim3 grid((unsigned)((int64_t)P.n_clips * P.n_pix * (P.H / P.GH)));
+    auto go = [&](auto nw) {                                          // the waves of a workgroup split the unit's heads
+        constexpr int NW = decltype(nw)::value;
+        if (lds > 64 * 1024) {
+            static bool raised = false;
+            if (!raised) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_attn_kernel<T, FT, NK32, NW>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                raised = true;
+            }
         }
-    }
-    const int waves = P.GH >= 4 ? 4 : (P.GH >= 2 ? 2 : 1);           // the waves of a workgroup split the unit's heads
-    dim3 grid((unsigned)((int64_t)P.n_clips * P.n_pix * (P.H / P.GH))), block(64 * waves);
-    hipLaunchKernelGGL((temporal_attn_kernel<T, FT, NK32>), grid, block, lds, st, P);
+        hipLaunchKernelGGL((temporal_attn_kernel<T, FT, NK32, NW>), grid, dim3(64 * NW), lds, st, P);
+    };
+    if (P.GH >= 4) go(std::integral_constant<int, 4>{});
+    else if (P.GH >= 2) go(std::integral_constant<int, 2>{});
+    else go(std::integral_constant<int, 1>{});
 }
 
 template <typename T, int FT>
