@@ -50,14 +50,16 @@ __device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((unsig
 // 8 consecutive activations <-> 8 floats, for both storage types
 template <typename T> struct Vec8;
 template <> struct Vec8<bf16_t> {
-    __device__ __forceinline__ static void load(const bf16_t* p, float (&v)[8]) {
-        u32x4 r = *reinterpret_cast<const u32x4*>(p);
+    typedef u32x4 raw_t;                                  // 8 elements as stored
+    __device__ __forceinline__ static raw_t load_raw(const bf16_t* p) { return *reinterpret_cast<const u32x4*>(p); }
+    __device__ __forceinline__ static void unpack(const raw_t& r, float (&v)[8]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             v[2 * i] = __uint_as_float(r[i] << 16);
             v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
         }
     }
+    __device__ __forceinline__ static void load(const bf16_t* p, float (&v)[8]) { unpack(load_raw(p), v); }
     __device__ __forceinline__ static void store(bf16_t* p, const float (&v)[8]) {
         u32x4 r;
 #pragma unroll
@@ -66,6 +68,14 @@ template <> struct Vec8<bf16_t> {
     }
 };
 template <> struct Vec8<float> {
+    struct raw_t { f32x4 a, b; };
+    __device__ __forceinline__ static raw_t load_raw(const float* p) {
+        return raw_t{*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4)};
+    }
+    __device__ __forceinline__ static void unpack(const raw_t& r, float (&v)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = r.a[i]; v[4 + i] = r.b[i]; }
+    }
     __device__ __forceinline__ static void load(const float* p, float (&v)[8]) {
         f32x4 a = *reinterpret_cast<const f32x4*>(p);
         f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);

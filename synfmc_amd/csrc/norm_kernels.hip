@@ -161,13 +161,19 @@ __global__ void gn_apply_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, 
                                     int rows_per_split, float eps, int act, const T* __restrict__ x2 = nullptr,
                                     int C1 = 0) {
     __shared__ float sh_mean[GN_MAX_G], sh_rstd[GN_MAX_G];
+    __shared__ float sh_part[GN_MAX_SPLIT * GN_MAX_G * 2];
     const int n = blockIdx.y, s = blockIdx.x, nsplit = gridDim.x;
     const int tid = threadIdx.x;
     const int cpg = C / G;
+    // the nsplit x G partial pairs of this sample: ONE global round trip for the whole workgroup (every thread fetches its share),
+    // then a fixed-order sum per group out of LDS.  (First version: thread g walked its nsplit partials through a loop of dependent
+    // global loads -- ~27 L2 round trips, ~10 us, in front of every workgroup's streaming part: a third of the launch.)
+    for (int i = tid; i < nsplit * G * 2; i += blockDim.x) sh_part[i] = part[(size_t)n * nsplit * G * 2 + i];
+    __syncthreads();
     for (int g = tid; g < G; g += blockDim.x) {
         double a = 0.0, b = 0.0;
         for (int k = 0; k < nsplit; ++k) {
-            const float* p = part + (((size_t)n * nsplit + k) * G + g) * 2;
+            const float* p = sh_part + ((size_t)k * G + g) * 2;
             a += (double)p[0];
             b += (double)p[1];
         }
@@ -239,7 +245,20 @@ __global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const T* __restrict__
                                                            float eps, int act, const T* __restrict__ x2, int C1) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][PL][CS] partial sums, then [2][CS] totals
     __shared__ float sh_mean[GN_MAX_G], sh_rstd[GN_MAX_G];
-    const int n = blockIdx.y, slab = blockIdx.x, tid = threadIdx.x;
+    // blockIdx -> (image, slab): workgroup ids go round-robin over the 8 XCDs, and a slab is an 80..160-byte run of every pixel row,
+    // i.e. it shares its 128-byte lines with the neighbouring slabs of the SAME image -- so all slabs of an image run on one XCD
+    // (ids = xcd mod 8) and its L2 fetches every line once; slab-fastest order had each line fetched by up to 8 L2s
+    // (52 MB level-1 launch: 20.6 -> see DESIGN us)
+    const int nslab = C / CS, tid = threadIdx.x;
+    int n, slab;
+    if (gridDim.y == 1) {
+        const int id = blockIdx.x, xcd = id & 7, within = id >> 3;
+        n = (within / nslab) * 8 + xcd;
+        slab = within % nslab;
+    } else {
+        n = blockIdx.y;
+        slab = blockIdx.x;
+    }
     const int CPS = CS / 8, cpg = C / G, GPB = CS / cpg;
     const int ch = tid % CPS, pl = tid / CPS;
     const int c0 = slab * CS + ch * 8;                             // my 8 channels (global index)
@@ -249,7 +268,13 @@ __global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const T* __restrict__
         xs = c0 < C1 ? C1 : C - C1;
         xb = c0 < C1 ? x + (size_t)n * HW * C1 + c0 : x2 + (size_t)n * HW * (C - C1) + (c0 - C1);
     }
-    float v[MAXCH][8];
+    // the slab stays in registers in its STORAGE type (bf16: 4 registers per 8-element chunk, unpacked where used; as fp32 the 16-chunk
+    // instantiation needed 182 VGPRs = 2 waves per SIMD, and a workgroup's load burst, reduction and store burst do not overlap with
+    // anything but other workgroups)
+    typename Vec8<T>::raw_t v[MAXCH];
+    float gm[8], bt[8];                                            // requested with the slab, not behind the reduction
+    Vec8<float>::load(gamma + c0, gm);
+    Vec8<float>::load(beta + c0, bt);
     float s1[8], s2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
@@ -258,13 +283,15 @@ __global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const T* __restrict__
 #pragma unroll
     for (int j = 0; j < MAXCH; ++j) {
         const int p = pl + PL * j;
-        Vec8<T>::load(xb + (size_t)(p < HW ? p : HW - 1) * xs, v[j]);
+        v[j] = Vec8<T>::load_raw(xb + (size_t)(p < HW ? p : HW - 1) * xs);
     }
 #pragma unroll
     for (int j = 0; j < MAXCH; ++j) {
         const float m = (pl + PL * j) < HW ? 1.f : 0.f;
+        float f[8];
+        Vec8<T>::unpack(v[j], f);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { const float t = v[j][i] * m; s1[i] += t; s2[i] += t * v[j][i]; }
+        for (int i = 0; i < 8; ++i) { const float t = f[i] * m; s1[i] += t; s2[i] += t * f[i]; }
     }
     float* l1 = smem;
     float* l2 = smem + (size_t)PL * CS;
@@ -298,19 +325,26 @@ __global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const T* __restrict__
     float aco[8], bco[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int c = c0 + i, gl = (ch * 8 + i) / cpg;
-        aco[i] = sh_rstd[gl] * gamma[c];
-        bco[i] = beta[c] - sh_mean[gl] * aco[i];
+        const int gl = (ch * 8 + i) / cpg;
+        aco[i] = sh_rstd[gl] * gm[i];
+        bco[i] = bt[i] - sh_mean[gl] * aco[i];
     }
     T* yb = y + (size_t)n * HW * C + c0;
+    if constexpr (sizeof(T) == 2) {
+        // (the raw words are "modified" here as far as the optimiser knows: it must unpack them again below instead of keeping the
+        // fp32 values of the statistics pass alive across the barriers)
+#pragma unroll
+        for (int j = 0; j < MAXCH; ++j) asm volatile("" : "+v"(v[j]));
+    }
 #pragma unroll
     for (int j = 0; j < MAXCH; ++j) {
         const int p = pl + PL * j;
         if (p < HW) {
-            float o[8];
+            float o[8], f[8];
+            Vec8<T>::unpack(v[j], f);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float z = v[j][i] * aco[i] + bco[i];
+                const float z = f[i] * aco[i] + bco[i];
                 o[i] = act ? silu_f(z) : z;
             }
             Vec8<T>::store(yb + (size_t)p * C, o);
@@ -353,6 +387,7 @@ template <typename T>
 static void launch_gn1(const Gn1Geom& g1, const void* x, void* y, const float* gamma, const float* beta, float* stats, int N,
                        int HW, int C, int G, float eps, int act, hipStream_t st, const void* x2, int C1) {
     dim3 grid1(C / g1.CS, N), block1(g1.block);
+    if (N % 8 == 0) grid1 = dim3((unsigned)(C / g1.CS) * N, 1);       // XCD-aware 1-D order (see the kernel)
     const size_t lds1 = (size_t)2 * g1.PL * g1.CS * sizeof(float);
     if (g1.chunks <= 8)
         hipLaunchKernelGGL((gn_fused_fwd_kernel<T, 8>), grid1, block1, lds1, st, (const T*)x, (T*)y, gamma, beta, stats, HW, C,
