@@ -15,6 +15,7 @@
 // S is recomputed in both 2 and 3 (7 matrix products instead of 5) in exchange for atomic-free, deterministic grads.
 // Algorithmic flops per backward = 14 * B*H*Sq*Skv*D (2.5x + 1 recompute of the forward's 4).
 #include "attn_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -30,6 +31,7 @@ struct SABwdParams {
     int kv_batch_div;
     float scale, scale_log2;
     int nblk;
+    int xcd;                                         // block -> (batch*head, block) map: all heads and blocks of a batch entry on one XCD
 };
 
 // ---- 1. D[b,h,q] = sum_d dO * O ------------------------------------------------------------------------------
@@ -82,6 +84,21 @@ __device__ __forceinline__ void stage_tile(const T* g, int64_t row_stride, int r
     }
 }
 
+// blockIdx -> (batch * H + head, block).  Workgroup ids go round-robin over the 8 XCDs; with the plain order the blocks of one (batch,
+// head) -- which all sweep the same K / V (or Q / dO) rows -- land on 8 different L2s, and a head's 80-byte row slice shares its
+// 128-byte lines with the neighbouring heads.  As in the forward kernel: everything of a batch entry on one XCD when the batch count allows.
+__device__ __forceinline__ void sab_decode(const SABwdParams& P, int id, int& bh, int& blk) {
+    if (P.xcd) {
+        const int xcd = id & 7, within = id >> 3, per_b = P.H * P.nblk;
+        const int rem = within % per_b;
+        bh = ((within / per_b) * 8 + xcd) * P.H + rem / P.nblk;
+        blk = rem % P.nblk;
+    } else {
+        bh = id / P.nblk;
+        blk = id % P.nblk;
+    }
+}
+
 // ---- 2. dQ -----------------------------------------------------------------------------------------------------
 template <typename T, int NKS>
 __global__ __launch_bounds__(256) void attn_dq_kernel(const SABwdParams P) {
@@ -93,7 +110,8 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(const SABwdParams P) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int D = P.D, CH = D / 8;
-    const int bh = blockIdx.x / P.nblk, qblk = blockIdx.x % P.nblk;
+    int bh, qblk;
+    sab_decode(P, blockIdx.x, bh, qblk);
     const int b = bh / P.H, h = bh - b * P.H;
     const T* qg = (const T*)P.q + (int64_t)b * P.qbs + (int64_t)h * D;
     const T* gg = (const T*)P.d_o + (int64_t)b * P.obs + (int64_t)h * D;
@@ -201,7 +219,8 @@ __global__ __launch_bounds__(64 * WAVES) void attn_dkdv_kernel(const SABwdParams
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int D = P.D, CH = D / 8;
-    const int bkvh = blockIdx.x / P.nblk, kblk = blockIdx.x % P.nblk;
+    int bkvh, kblk;
+    sab_decode(P, blockIdx.x, bkvh, kblk);
     const int bkv = bkvh / P.H, h = bkvh - bkv * P.H;
     const T* kg = (const T*)P.k + (int64_t)bkv * P.kbs + (int64_t)h * D;
     const T* vg = (const T*)P.v + (int64_t)bkv * P.kbs + (int64_t)h * D;
@@ -328,6 +347,7 @@ void launch_bwd(SABwdParams P, hipStream_t st) {
         static bool raised = false;
         raise_lds(&attn_dq_kernel<T, NKS>, lds, raised);
         P.nblk = (P.Sq + 127) / 128;
+        P.xcd = (P.B % 8 == 0 && !getenv("FMC_SAB_XCD0")) ? 1 : 0;
         hipLaunchKernelGGL((attn_dq_kernel<T, NKS>), dim3((unsigned)(P.B * P.H * P.nblk)), dim3(256), lds, st, P);
     }
     if (P.dk) {                                       // dk == dv == NULL: the key/value side needs no gradient
@@ -338,6 +358,7 @@ void launch_bwd(SABwdParams P, hipStream_t st) {
         raise_lds(&attn_dkdv_kernel<T, NKS, WAVES, BQ>, lds, raised);
         P.nblk = (P.Skv + BKV - 1) / BKV;
         const int bkv = P.B / P.kv_batch_div;
+        P.xcd = (bkv % 8 == 0 && !getenv("FMC_SAB_XCD0")) ? 1 : 0;
         hipLaunchKernelGGL((attn_dkdv_kernel<T, NKS, WAVES, BQ>), dim3((unsigned)(bkv * P.H * P.nblk)), dim3(64 * WAVES), lds, st, P);
     }
 }
