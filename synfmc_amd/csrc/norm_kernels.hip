@@ -560,6 +560,23 @@ __global__ __launch_bounds__(256) void layernorm_g_kernel(const T* __restrict__ 
                                                           const float* __restrict__ pe, int64_t M, float eps, int pe_inner,
                                                           int pe_frames) {
     constexpr int NCH = 5, C = LPR * NCH * 8, RPW = 64 / LPR;
+    // gamma / beta through LDS: requested together with the rows (read from global memory behind the statistics they were a second
+    // memory round trip in the life of every wave, which is one load burst, a reduction and one store burst long)
+    __shared__ __attribute__((aligned(16))) float sh_g[C], sh_b[C];
+    for (int i = threadIdx.x; i < C; i += 256) { sh_g[i] = gamma[i]; sh_b[i] = beta[i]; }
+    // positional-encoding rows the same way: the 4 * RPW * U consecutive rows of a workgroup lie in at most two frames (pe_inner rows
+    // per frame, >= the workgroup's rows whenever two frames suffice; otherwise the rows read pe from global memory as before)
+    __shared__ __attribute__((aligned(16))) float sh_pe[2][C];
+    const int64_t wg_row0 = (int64_t)blockIdx.x * (4 * RPW * U);
+    const int64_t wg_f0 = pe ? wg_row0 / pe_inner : 0;
+    const int64_t pe_next = (wg_f0 + 1) * pe_inner;           // first row of the workgroup's second frame
+    const bool pe_lds = pe && pe_inner >= 4 * RPW * U && 4 * RPW * U >= 32;   // (8 rows per workgroup at C = 1280: staging two PE rows costs as much as the rows)
+    if (pe_lds) {
+        for (int i = threadIdx.x; i < 2 * C; i += 256) {
+            const int which = i / C, c = i - which * C;
+            sh_pe[which][c] = pe[(size_t)((wg_f0 + which) % pe_frames) * C + c];
+        }
+    }
     const int lane = threadIdx.x & 63, t = lane % LPR, g = lane / LPR;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t row0 = wave * (RPW * U) + g;               // this group's rows: row0 + RPW*u
@@ -592,11 +609,12 @@ __global__ __launch_bounds__(256) void layernorm_g_kernel(const T* __restrict__ 
             for (int i = 0; i < 8; ++i) { const float d = v[u][j][i] - mean[u]; q += d * d; }
         rs[u] = rsqrtf(group_sum<LPR>(q) * (1.f / C) + eps);
     }
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         float gm[8], bt[8];
-        Vec8<float>::load(gamma + (j * LPR + t) * 8, gm);
-        Vec8<float>::load(beta + (j * LPR + t) * 8, bt);
+        Vec8<float>::load(sh_g + (j * LPR + t) * 8, gm);
+        Vec8<float>::load(sh_b + (j * LPR + t) * 8, bt);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t row = row0 + RPW * u;
@@ -606,7 +624,8 @@ __global__ __launch_bounds__(256) void layernorm_g_kernel(const T* __restrict__ 
             for (int i = 0; i < 8; ++i) o[i] = (v[u][j][i] - mean[u]) * rs[u] * gm[i] + bt[i];
             if (pe) {
                 float pv[8];
-                Vec8<float>::load(pe + (size_t)((row / pe_inner) % pe_frames) * C + (j * LPR + t) * 8, pv);
+                if (pe_lds) Vec8<float>::load(sh_pe[row >= pe_next ? 1 : 0] + (j * LPR + t) * 8, pv);   // (no 64-bit division per row)
+                else Vec8<float>::load(pe + (size_t)((row / pe_inner) % pe_frames) * C + (j * LPR + t) * 8, pv);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o[i] += pv[i];
             }

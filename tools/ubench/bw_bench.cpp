@@ -41,7 +41,8 @@ int main(int argc, char** argv) {
     gn_fn gn = lib ? (gn_fn)dlsym(lib, "fmc_groupnorm_silu_fwd") : nullptr;
     gnws_fn gnws = lib ? (gnws_fn)dlsym(lib, "fmc_groupnorm_workspace_bytes") : nullptr;
     const size_t maxb = (size_t)81920 * 1280 * 2;
-    uint16_t *x, *y; float *g, *b, *stats; void* ws;
+    uint16_t *x, *y; float *g, *b, *stats, *pe; void* ws;
+    hipMalloc(&pe, 16 * 1280 * 4); hipMemset(pe, 0, 16 * 1280 * 4);
     hipMalloc(&x, maxb); hipMalloc(&y, maxb); hipMalloc(&g, 8192 * 4); hipMalloc(&b, 8192 * 4); hipMalloc(&stats, 1 << 20); hipMalloc(&ws, 64 << 20);
     hipMemset(x, 0x3c, maxb); hipMemset(g, 0, 8192 * 4); hipMemset(b, 0, 8192 * 4);
     struct { int64_t M; int C; int n_img; } shapes[] = {{81920, 320, 32}, {20480, 640, 32}, {5120, 1280, 32}, {81920, 640, 32}, {81920, 1280, 32}};
@@ -59,6 +60,7 @@ int main(int argc, char** argv) {
             snprintf(nm, 96, "copy, grid-stride %d WGs, 4 in flight, nt", wg); rep(nm, timeit([&] { copy_stride<4, true><<<wg, 256>>>((const u32x4*)x, (u32x4*)y, n); }));
         }
         if (ln && s.C <= 1280) rep("fmc_layernorm_fwd", timeit([&] { ln(x, y, g, b, nullptr, s.M, s.C, 1e-5f, 1, 1, 0, nullptr); }));
+        if (ln && s.C <= 1280) rep("fmc_layernorm_fwd + positional encoding (16 frames)", timeit([&] { ln(x, y, g, b, pe, s.M, s.C, 1e-5f, (int)(s.M / 32), 16, 0, nullptr); }));
         if (gn) rep("fmc_groupnorm_silu_fwd (32 groups, SiLU)", timeit([&] { gn(x, y, g, b, stats, ws, s.n_img, (int)(s.M / s.n_img), s.C, 32, 1e-5f, 1, 0, nullptr, 0, nullptr); }));
     }
     return 0;
