@@ -482,6 +482,30 @@ def train_main(args):
 
     loss = None
 
+    if getattr(args, "torch_profile", None):                 # diagnostic: which call sites launch the torch elementwise / copy kernels
+        from torch.profiler import profile, ProfilerActivity
+        draw()
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+            fwd_bwd()
+            reducer.finish()
+            torch.cuda.synchronize()
+        import collections
+        agg = collections.defaultdict(lambda: [0.0, 0])
+        for ev in prof.events():
+            if ev.device_type.name != "CPU" or not ev.name.startswith("aten::") or ev.cpu_parent is not None and ev.cpu_parent.name.startswith("aten::"):
+                continue
+            dev_us = sum(k.duration for k in ev.kernels) if ev.kernels else 0.0
+            if dev_us <= 0:
+                continue
+            frames = [f for f in (ev.stack or []) if "synfmc_amd" in f or "bench.py" in f][:3]
+            key = (ev.name, " <- ".join(fr.split("/")[-1] for fr in frames))
+            agg[key][0] += dev_us
+            agg[key][1] += 1
+        with open(args.torch_profile, "w") as f:
+            for (name, where), (us, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:60]:
+                f.write(f"{us / 1e3:8.3f} ms {n:5d}x {name:28s} {where}\n")
+        reducer.zero_grad()
+
     def run(i):
         nonlocal loss
         loss = step(i)
@@ -526,6 +550,7 @@ def main():
     ap.add_argument("--grad-compress", default="none", choices=["none", "bf16"], help="train mode: gradient buckets on the wire")
     ap.add_argument("--fp8-temporal", action="store_true",
                     help="temporal attention on the fp8 path (e4m3 q|k|v from the QKV epilogue, fp8 MFMA): BASELINE configs[4]")
+    ap.add_argument("--torch-profile", default=None, help="train mode, diagnostic: write the device time of torch ops by call site (one eager step) to this file")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo stub of the launcher + timing + JSON plumbing (tests)")
     args = ap.parse_args()
     if args.dry_run:
