@@ -193,7 +193,11 @@ int fmc_cfg_ddim_step(const void* eps_uc, const float* x, float* x_out, int64_t 
  *   columns); 12 = 128x320, 32-deep, 4 stages; 13 / 14 = the 8-phase 256x256 kernel (8 waves of 128x64, the two wave rows
  *   one barrier apart so each SIMD always has one wave on the matrix pipe and one loading; operands by half-tile
  *   `buffer_load ... lds` with a counted vmcnt, 4 / 5 half-tiles ahead; falls back to 3 for a two-source A operand or
- *   operands beyond 2 GiB).  Every arm computes the same function -- bit for bit among the plain-grid arms of one k-tile depth
+ *   operands beyond 2 GiB); 15 = the persistent kernel of the K = 320 token projections (epilogue 0, N % 320 == 0, M % 64 == 0, one
+ *   residual at most: 5 waves keep the weights of a 320-column block in registers for the life of the workgroup, 64-row A tiles
+ *   arrive by LDS-DMA two tiles ahead, the residual rows are DMA'd into the output staging tile; the bias enters the accumulator
+ *   first, so it agrees with the other arms to the last bit or two, not bit for bit; anything else falls back to 5).
+ *   Every arm computes the same function -- bit for bit among the plain-grid arms of one k-tile depth
  *   (the 32-deep arms, split-K and stream-K add the same products in another order) -- so callers may time them and keep
  *   the fastest.
  *   split_k > 1 (epilogue 0 only): the k-tiles of every output tile are dealt to split_k workgroups that write fp32

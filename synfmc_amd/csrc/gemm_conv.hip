@@ -1411,6 +1411,213 @@ void launch_gemm8(GemmParams& P, hipStream_t st) {
     hipLaunchKernelGGL((gemm8_kernel<MODE, EPI, PF, 0>), dim3((unsigned)tiles), dim3(512), lds, st, P);
 }
 
+// =====================================================================================================================
+// W-stationary persistent kernel for the K = 320 token projections (arm 15; MODE 0, plain epilogue, N % 320 == 0).
+//
+// Why: at the 40x64 level (M = 81920) a projection with K = 320 is five k-tiles per output tile.  Knock-outs of the ring kernels
+// on M = 81920, N = K = 320 (tools/ubench/gemm_bench): 36 us as shipped, 12.5 us with the main loop removed (= the output stores:
+// 52 MB at write bandwidth), i.e. 23.5 us of main loop for 11 us of MFMA work and a 52 MB read -- every tile pays its prologue,
+// five DMA round trips and its epilogue one after the other, and the co-resident workgroups of a CU run in phase.
+// Here a workgroup of 5 waves owns ALL 320 columns of a column block and keeps the block's weights in REGISTERS for its whole
+// life (wave w: columns 64 w .. 64 w + 63, 20 k-steps x 2 fragments = 160 VGPRs); it walks its share of the 64-row A tiles:
+//   * the A tile (64 x 320, 40 KB) arrives by buffer_load ... lds in ONE burst, two tiles ahead, double-buffered;
+//   * 80 MFMAs per wave and tile straight from LDS fragments against the resident weights -- no W traffic at all after the prologue;
+//   * the epilogue goes through one bf16 staging tile that the residual rows were DMA'd into during the main loop (every lane
+//     adds its own words in fp32 and overwrites them), and leaves with whole-row 16-byte stores;
+//   * ONE `s_waitcnt vmcnt(0)` per tile, placed right after the MFMAs: by then the next A tile, this tile's residual rows and the
+//     previous tile's stores have had a whole main loop to finish, so it does not stall -- and it needs no assumption about the
+//     order in which loads and stores retire.
+// Loads of tile t+2 / t+1 and the stores of tile t are all in flight under the MFMAs of tile t+1: the kernel runs at the speed of
+// its bytes.
+// =====================================================================================================================
+constexpr int K320_K = 320, K320_BN = 320, K320_OP = K320_BN + 8;
+template <int MI> constexpr int k320_stage_chunks() { return ((32 * MI * (K320_OP / 8) + 63) / 64) * 64; }   // staging tile in 16-B chunks, whole DMA pieces
+template <int MI> constexpr size_t k320_lds() {
+    return (size_t)2 * 32 * MI * K320_K * 2 + (size_t)k320_stage_chunks<MI>() * 16 + K320_BN * sizeof(float);
+}
+
+template <int MI, bool HAS_RES>
+__global__ __launch_bounds__(320, 1) void gemm_k320_kernel(const GemmParams P) {
+    constexpr int K = K320_K, KS = K / 16, BM = 32 * MI, BN = K320_BN, OP = K320_OP, CPR = K / 8, OCPR = OP / 8;
+    constexpr int A_ELEMS = BM * K, A_PIECES = BM * CPR / 64, ST_PIECES = k320_stage_chunks<MI>() / 64;
+    constexpr int A_PPW = (A_PIECES + 4) / 5, ST_PPW = (ST_PIECES + 4) / 5;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* Abuf = reinterpret_cast<bf16_t*>(smem_raw);                         // [2][BM][K], chunk-swizzled rows
+    bf16_t* Os = Abuf + 2 * A_ELEMS;                                             // [BM][OP] staging: residual in, output out
+    float* bias_s = reinterpret_cast<float*>(Os + k320_stage_chunks<MI>() * 8);  // [BN]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int n0 = blockIdx.y * BN;
+    const int ntiles = (int)(P.M / BM);
+
+    // ---- resident weights: W^T fragments of my 64 columns, all 20 k-steps (A operand of the swapped product: rows = n) ----------
+    bf16x8 wf[KS][2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const bf16_t* wrow = P.w + (int64_t)(n0 + wave * 64 + ni * 32 + l31) * K + half * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            union { bf16x8 v; u32x4 u; } t;
+            t.u = *reinterpret_cast<const u32x4*>(wrow + ks * 16);
+            wf[ks][ni] = t.v;
+        }
+    }
+    for (int i = tid; i < BN; i += 320) bias_s[i] = P.bias ? bf2f(P.bias[n0 + i]) : 0.f;
+
+    // ---- DMA pieces (1 KiB = 64 lanes x 16 B, LDS-linear).  A: chunk L = 64 piece + lane -> row L / 40, physical chunk L % 40 holds
+    // logical chunk (L % 40) ^ ((row >> 1) & 7) (conflict-free b128 fragment reads at the 640-byte pitch).  Residual: L -> row L / 41,
+    // chunk L % 41 of the padded staging row (chunk 40 is the pad: out of range, zeros) -------------------------------------------
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)P.a, 0, (int)(((P.M - 1) * P.lda + K) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)(HAS_RES ? P.res + n0 : P.a), 0,
+                                                                         HAS_RES ? (int)(((P.M - 1) * P.ldres + BN) * 2) : 0, 0x00020000);
+    constexpr unsigned OOB = 0x7ffffff0u;
+    // (the per-lane offsets are recomputed at every request -- a dozen VALU per piece -- instead of living in 17 registers next to the
+    // 160 of the weights and the 64 accumulators)
+    int lane_v = lane, tid_v = tid;                      // (made opaque once per tile: see the loop)
+    auto a_vo = [&](int piece) {
+        const int L = piece * 64 + lane_v, row = L / CPR, phys = L - row * CPR;
+        return (unsigned)(row * (int)P.lda * 2 + (phys ^ ((row >> 1) & 7)) * 16);
+    };
+    auto r_vo = [&](int piece) {
+        const int L = piece * 64 + lane_v, row = L / OCPR, cc = L - row * OCPR;
+        return (row < BM && cc < BN / 8) ? (unsigned)(row * (int)P.ldres * 2 + cc * 16) : OOB;
+    };
+    auto dma = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned voff, int soff, bf16_t* lds) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, (int)voff, soff, 0, 0);
+    };
+    auto load_a = [&](int tile, int buf) {
+        const int soff = tile * BM * (int)P.lda * 2;
+#pragma unroll
+        for (int i = 0; i < A_PPW; ++i)
+            if (wave + 5 * i < A_PIECES) dma(rsA, a_vo(wave + 5 * i), soff, Abuf + buf * A_ELEMS + (wave + 5 * i) * 512);
+    };
+    auto load_res = [&](int tile) {
+        const int soff = tile * BM * (int)P.ldres * 2;
+#pragma unroll
+        for (int i = 0; i < ST_PPW; ++i)
+            if (wave + 5 * i < ST_PIECES) dma(rsR, r_vo(wave + 5 * i), soff, Os + (wave + 5 * i) * 512);
+    };
+
+    // fragment read offsets: row (mi*32 + l31), logical chunk 2 ks + half at physical chunk (2 ks + half) ^ sw, sw = (l31 >> 1) & 7.
+    // (2 ks) ^ x = 2 ks + x - 2 (x & (2 ks & 6)) for x = sw & 6: four per-lane constants, the rest is an immediate
+    const int sw = (l31 >> 1) & 7, x6 = sw & 6, b0 = half ^ (sw & 1);
+    int dsel[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) dsel[m] = l31 * K + (x6 - 2 * (x6 & (2 * m)) + b0) * 8;
+
+    int t = blockIdx.x;
+    if (t < ntiles) load_a(t, 0);
+    if (t + (int)gridDim.x < ntiles) load_a(t + gridDim.x, 1);
+    if (HAS_RES && t < ntiles) load_res(t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int it = 0; t < ntiles; t += gridDim.x, ++it) {
+        const bf16_t* As = Abuf + (it & 1) * A_ELEMS;
+        // per-lane offsets of the DMA requests and of the store loop are recomputed every tile from these: hoisted out of the persistent
+        // loop they were ~40 spilled registers, and every scratch reload is a VMEM operation whose wait also drains the DMA queue
+        asm volatile("" : "+v"(lane_v), "+v"(tid_v));
+        // the accumulators start from the bias (out = alpha * (acc + bias) + residual): eight b128 reads here, all in flight together,
+        // instead of one dependent LDS round trip in front of each of the epilogue's 16 word writes
+        f32x16 acc[2][MI];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + wave * 64 + a * 32 + 8 * g + 4 * half);
+#pragma unroll
+                for (int b = 0; b < MI; ++b)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[a][b][4 * g + j] = bv[j];
+            }
+        // ---- 20 k-steps: A^T fragments from LDS (next step's requested before this step's MFMAs), W from registers ------------
+        bf16x8 af[2][MI];
+        auto read_a = [&](int ks, bf16x8 (&f)[MI]) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                union { bf16x8 v; u32x4 u; } ta;
+                ta.u = *reinterpret_cast<const u32x4*>(As + mi * 32 * K + dsel[ks & 3] + ks * 16);
+                f[mi] = ta.v;
+            }
+        };
+        read_a(0, af[0]);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) read_a(ks + 1, af[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][ni], af[ks & 1][mi], acc[ni][mi], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // next A tile, this tile's residual rows (and the previous tile's stores) are done; everybody is done with As
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        asm volatile("" : "+v"(lane_v), "+v"(tid_v));       // (what the epilogue derives from the lane id is not kept alive across the MFMAs)
+        const int l31_e = lane_v & 31, half_e = (lane_v >> 5) & 1;
+        if (t + 2 * (int)gridDim.x < ntiles) load_a(t + 2 * gridDim.x, it & 1);
+
+        // ---- epilogue: alpha * acc (+ residual words from the staging tile, four words requested at a time), one rounding, into the
+        // staging tile ------------------------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                bf16_t* wbase = Os + (mi * 32 + l31_e) * OP + wave * 64 + ni * 32 + 4 * half_e;
+                u32x2 rw[4];
+                if (HAS_RES) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) rw[g] = *reinterpret_cast<const u32x2*>(wbase + 8 * g);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = P.alpha * acc[ni][mi][4 * g + j];
+                    if (HAS_RES) {
+                        o[0] += __uint_as_float(rw[g][0] << 16); o[1] += __uint_as_float(rw[g][0] & 0xffff0000u);
+                        o[2] += __uint_as_float(rw[g][1] << 16); o[3] += __uint_as_float(rw[g][1] & 0xffff0000u);
+                    }
+                    *reinterpret_cast<u32x2*>(wbase + 8 * g) = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+                }
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        {
+            bf16_t* og = P.out + (int64_t)t * BM * P.ldo + n0;
+#pragma unroll
+            for (int c = tid_v; c < BM * (BN / 8); c += 320) {
+                const int r = c / (BN / 8), ch = c - r * (BN / 8);
+                *reinterpret_cast<u32x4*>(og + (int64_t)r * P.ldo + ch * 8) = *reinterpret_cast<const u32x4*>(Os + r * OP + ch * 8);
+            }
+        }
+        if (HAS_RES) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // the staging tile has been read out
+            if (t + (int)gridDim.x < ntiles) load_res(t + gridDim.x);
+        }
+    }
+}
+
+bool gemm_k320_ok(const GemmParams& P) {
+    return P.hw <= 1 && P.K == K320_K && P.N % K320_BN == 0 && P.M % 64 == 0 && !P.a2 && !P.res2 && P.split_k == 1 && !P.sk && !P.temb &&
+           ((P.M - 1) * P.lda + P.K) * 2 < ((int64_t)1 << 31) && (!P.res || ((P.M - 1) * P.ldres + P.N) * 2 < ((int64_t)1 << 31));
+}
+
+void launch_gemm_k320(GemmParams& P, hipStream_t st) {
+    constexpr int MI = 2;
+    const int tiles = (int)(P.M / (32 * MI)), cus = fmc_cu_count();
+    dim3 grid((unsigned)(tiles < cus ? tiles : cus), (unsigned)(P.N / K320_BN));
+    const size_t lds = k320_lds<MI>();
+    static bool raised = false;
+    if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_k320_kernel<MI, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_k320_kernel<MI, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        raised = true;
+    }
+    if (P.res) hipLaunchKernelGGL((gemm_k320_kernel<MI, true>), grid, dim3(320), lds, st, P);
+    else hipLaunchKernelGGL((gemm_k320_kernel<MI, false>), grid, dim3(320), lds, st, P);
+}
+
 bool gemm8_ok(GemmParams& P) {
     // operand sizes as the buffer descriptors see them (conv: the whole input tensor; token: up to the end of the last row)
     const int64_t a_elems = P.hw > 1 ? (P.ups == 1 ? (P.M / 4) * (int64_t)P.cin : P.M * (int64_t)P.cin * (P.ups == 2 ? 4 : 1))
@@ -1420,7 +1627,7 @@ bool gemm8_ok(GemmParams& P) {
 }
 
 // tile arms (fmc_hip.h): geometry x k-tile depth x ring depth
-constexpr int GEMM_TILE_MAX = 14;
+constexpr int GEMM_TILE_MAX = 15;
 
 // geometry: the largest tile that still gives every CU work and does not waste more than ~20 % of N
 template <int MODE, int EPI>
@@ -1435,6 +1642,12 @@ void launch_gemm(GemmParams& P, int tile, hipStream_t st) {
         else g = 1;
     }
     if ((g == 13 || g == 14) && !gemm8_ok(P)) g = 3;      // 8-phase kernel: plain grid, 32-bit operand offsets
+    if (g == 15) {                                        // W-stationary persistent kernel of the K = 320 token projections
+        if constexpr (MODE == 0 && EPI == 0) {
+            if (gemm_k320_ok(P)) { launch_gemm_k320(P, st); return; }
+        }
+        g = 5;
+    }
     switch (g) {
         case 14: launch_gemm8<MODE, EPI, 5>(P, st); break;              // 8-phase 256x256, 5 half-tiles ahead
         case 13: launch_gemm8<MODE, EPI, 4>(P, st); break;              // 8-phase 256x256, 4 half-tiles ahead

@@ -906,6 +906,7 @@ def _save_at_exit():
 atexit.register(_save_at_exit)
 GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 11,     # 8..10, 12 (4-stage rings) exist but never won on the FMC shapes
               13,                            # the 8-phase 256x256 kernel (staggered wave rows, half-tile DMA, counted vmcnt)
+              15,                            # K = 320 token projections: persistent, weights resident in registers (falls back to 5 elsewhere)
               128 + 2, 128 + 3,              # stream-K (persistent workgroups) on the two 1-per-CU geometries
               128 + 13)                      # stream-K on the 8-phase kernel: persistent partial pass + one finishing workgroup per tile
 if os.environ.get("FMC_GEMM_ARMS"):              # A/B switch: the arm list the autotuner may choose from, e.g. "1,2,3,11"

@@ -638,6 +638,42 @@ def test_gemm_stream_k(K, tile):
     assert int(ws[:1024].view(torch.int32).abs().sum()) == 0                      # flags handed back as zeros
 
 
+def test_gemm_k320_weight_stationary_arm(K):
+    """Arm 15: the persistent kernel of the K = 320 projections (weights of a 320-column block resident in registers, A tiles by
+    LDS-DMA two tiles ahead, residual rows DMA'd into the output staging tile).  One .. many tiles per workgroup (the grid is
+    min(tiles, CUs)), 1 / 2 / 3 column blocks, every epilogue it takes (bias, alpha, residual), strided views of a fused projection
+    as the residual / output, repeated launches on fresh data; shapes it does not take (K != 320, M % 64 != 0, two residuals)
+    must fall back to the ring kernel with the same results."""
+    dtype = torch.bfloat16
+    for (M, N) in [(64, 320), (640, 320), (64 * 300, 640), (64 * 515, 960), (81920, 320)]:
+        wo, wd = rnd((N, 320), 145, dtype, scale=320 ** -0.5)
+        bo, bd = rnd((N,), 146, dtype)
+        for it in range(3):
+            xo, xd = rnd((M, 320), 500 + it, dtype)
+            ro, rd = rnd((M, N), 600 + it, dtype)
+            got = K.linear_bf16(xd, wd, bd, rd, 0.5, tile=15)
+            ref = K.linear_bf16(xd, wd, bd, rd, 0.5, tile=5)
+            assert rel_inf(got.float(), 0.5 * F.linear(xo, wo, bo) + ro) < 1e-2, (M, N, it)
+            assert rel_inf(got.float(), ref.float()) < 4e-3                          # (bias enters the accumulator first: last-bit differences)
+            if it == 0:
+                assert torch.equal(got, K.linear_bf16(xd, wd, bd, rd, 0.5, tile=15))   # deterministic
+                assert rel_inf(K.linear_bf16(xd, wd, None, None, 1.0, tile=15).float(), F.linear(xo, wo)) < 1e-2
+                assert rel_inf(K.linear_bf16(xd, wd, bd, None, 1.0, tile=15).float(), F.linear(xo, wo, bo)) < 1e-2
+    # fall-backs: same entry point, other kernels
+    xo, xd = rnd((700, 320), 147, dtype)
+    wo, wd = rnd((320, 320), 148, dtype, scale=320 ** -0.5)
+    ro, rd = rnd((700, 320), 149, dtype)
+    r2o, r2d = rnd((700, 320), 150, dtype)
+    assert rel_inf(K.linear_bf16(xd, wd, None, rd, 1.0, tile=15).float(), F.linear(xo, wo) + ro) < 1e-2          # M % 64 != 0
+    xo, xd = rnd((640, 320), 151, dtype)
+    ro, rd = rnd((640, 320), 152, dtype)
+    r2o, r2d = rnd((640, 320), 153, dtype)
+    assert rel_inf(K.linear_bf16(xd, wd, None, rd, 1.0, tile=15, residual2=r2d).float(), F.linear(xo, wo) + ro + r2o) < 1e-2
+    wo6, wd6 = rnd((320, 640), 154, dtype, scale=640 ** -0.5)
+    xo6, xd6 = rnd((640, 640), 155, dtype)
+    assert rel_inf(K.linear_bf16(xd6, wd6, None, None, 1.0, tile=15).float(), F.linear(xo6, wo6)) < 1e-2           # K != 320
+
+
 @pytest.mark.parametrize("tile", [13, 14, 128 + 13, 128 + 14])
 def test_gemm_8phase_arms(K, tile):
     """The 8-phase 256x256 kernel (staggered wave rows, half-tile DMA with counted vmcnt): ragged M / N (partial tiles),
