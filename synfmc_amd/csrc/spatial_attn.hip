@@ -300,6 +300,31 @@ __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 && NQ =
     const T* vg = (const T*)P.v + (int64_t)(b / P.kv_batch_div) * P.kbs + (int64_t)h * D;
     T* og = (T*)P.o + (int64_t)b * P.obs + (int64_t)h * D;
 
+    // K/V staging is split (T14-style): the 16-byte global loads of tile t+1 are issued right after tile t has been
+    // written to LDS and stay in flight under tile t's MFMAs; they are written to LDS after the next barrier.
+    constexpr int NSLOT = (SA_BK * NKS * 2 + 64 * SA_WAVES - 1) / (64 * SA_WAVES);   // 8-element chunks per thread
+    constexpr int RW = sizeof(T) * 2;                                                  // dwords per chunk
+    typedef uint32_t __attribute__((ext_vector_type(RW))) raw_t;
+    raw_t kreg[NSLOT], vreg[NSLOT];
+    auto gload = [&](int kv0) {
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) {
+            const int c = tid + j * 64 * SA_WAVES;
+            const int row = c / CH, ch = c - row * CH;
+            const int kv = kv0 + row;
+            if (c < SA_BK * CH && kv < P.Skv) {
+                kreg[j] = *reinterpret_cast<const raw_t*>(kg + (int64_t)kv * P.krs + ch * 8);
+                vreg[j] = *reinterpret_cast<const raw_t*>(vg + (int64_t)kv * P.krs + ch * 8);
+            } else {
+                kreg[j] = raw_t(0);
+                vreg[j] = raw_t(0);
+            }
+        }
+    };
+    // tile 0 is requested BEFORE the Q rows: the two round trips overlap (behind the Q fragments it was a second dependent one --
+    // the short cross-attention launches are a chain of such round trips: Q, tile 0, tile 1, stores)
+    if (PREFETCH) gload(0);
+
     // ---- Q^T fragments (B operand of S^T = K Q^T), kept in registers -----------------------------
     int qrow[NQ];
     Frag<T> qf[NQ][NKS];
@@ -334,27 +359,6 @@ __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 && NQ =
         for (int c = tid; c < SA_BK; c += 64 * SA_WAVES) Vt[VR ? c * VPR + NDT * 32 - 1 : (NDT * 32 - 1) * VP + c] = to_elem<T>(1.f);
     }
 
-    // K/V staging is split (T14-style): the 16-byte global loads of tile t+1 are issued right after tile t has been
-    // written to LDS and stay in flight under tile t's MFMAs; they are written to LDS after the next barrier.
-    constexpr int NSLOT = (SA_BK * NKS * 2 + 64 * SA_WAVES - 1) / (64 * SA_WAVES);   // 8-element chunks per thread
-    constexpr int RW = sizeof(T) * 2;                                                  // dwords per chunk
-    typedef uint32_t __attribute__((ext_vector_type(RW))) raw_t;
-    raw_t kreg[NSLOT], vreg[NSLOT];
-    auto gload = [&](int kv0) {
-#pragma unroll
-        for (int j = 0; j < NSLOT; ++j) {
-            const int c = tid + j * 64 * SA_WAVES;
-            const int row = c / CH, ch = c - row * CH;
-            const int kv = kv0 + row;
-            if (c < SA_BK * CH && kv < P.Skv) {
-                kreg[j] = *reinterpret_cast<const raw_t*>(kg + (int64_t)kv * P.krs + ch * 8);
-                vreg[j] = *reinterpret_cast<const raw_t*>(vg + (int64_t)kv * P.krs + ch * 8);
-            } else {
-                kreg[j] = raw_t(0);
-                vreg[j] = raw_t(0);
-            }
-        }
-    };
     auto lstore = [&]() {
 #pragma unroll
         for (int j = 0; j < NSLOT; ++j) {
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 && NQ =
     const int ntiles = (P.Skv + SA_BK - 1) / SA_BK, nfull = P.Skv / SA_BK;
 
     // ---- prologue: tile 0 -> LDS, reference m_ref = row maximum over its keys -----------------------
-    if (PREFETCH) { gload(0); lstore(); } else { stage_rolled(0); }
+    if (PREFETCH) { lstore(); } else { stage_rolled(0); }
     __syncthreads();
     if (PREFETCH && ntiles > 1) gload(SA_BK);
     float m_ref[NQ];

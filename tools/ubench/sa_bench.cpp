@@ -17,6 +17,8 @@ int main(int argc, char** argv) {
     if (argc < 2) { printf("usage: sa_bench lib.so [B S H D iters]\n"); return 2; }
     const int B = argc > 2 ? atoi(argv[2]) : 32, S = argc > 3 ? atoi(argv[3]) : 2560, H = argc > 4 ? atoi(argv[4]) : 8,
               D = argc > 5 ? atoi(argv[5]) : 40, iters = argc > 6 ? atoi(argv[6]) : 20;
+    const int Skv = argc > 7 ? atoi(argv[7]) : S, kvdiv = argc > 8 ? atoi(argv[8]) : 1;   // cross attention: K/V [B / kvdiv, Skv, 2C]
+    const bool cross = argc > 7;
     void* lib = dlopen(argv[1], RTLD_NOW);
     if (!lib) { printf("dlopen: %s\n", dlerror()); return 1; }
     sa_fn fn = (sa_fn)dlsym(lib, "fmc_spatial_attn_fwd");
@@ -35,8 +37,16 @@ int main(int argc, char** argv) {
     hipMalloc(&qkv, n * 2); hipMalloc(&o, (size_t)B * S * C * 2);
     hipMemcpy(qkv, h.data(), n * 2, hipMemcpyHostToDevice);
     hipMemset(o, 0, (size_t)B * S * C * 2);
+    std::vector<uint16_t> hkv;
+    uint16_t* kv = nullptr;
+    if (cross) {
+        hkv.resize((size_t)(B / kvdiv) * Skv * 2 * C);
+        for (size_t i = 0; i < hkv.size(); ++i) { float a = 0.f; for (int j = 0; j < 4; ++j) { rng = rng * 1664525u + 1013904223u; a += (float)(rng >> 8) * (1.f / 16777216.f) - 0.5f; } hkv[i] = f2bf(a * 1.73f); }
+        hipMalloc(&kv, hkv.size() * 2); hipMemcpy(kv, hkv.data(), hkv.size() * 2, hipMemcpyHostToDevice);
+    }
     const float scale = 1.f / std::sqrt((float)D);
     auto call = [&]() {
+        if (cross) return fn(qkv, kv, kv + C, o, lse, B, H, S, Skv, D, (int64_t)S * 3 * C, 3 * C, (int64_t)Skv * 2 * C, 2 * C, (int64_t)S * C, C, kvdiv, scale, 0, nullptr);
         return fn(qkv, qkv + C, qkv + 2 * C, o, lse, B, H, S, S, D, (int64_t)S * 3 * C, 3 * C, (int64_t)S * 3 * C, 3 * C, (int64_t)S * C, C, 1,
                   scale, /*FMC_BF16*/ 0, nullptr);
     };
@@ -49,7 +59,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < iters; ++i) call();
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= iters;
-    const double fl = 4.0 * B * H * (double)S * S * D;
+    const double fl = 4.0 * B * H * (double)S * Skv * D;
     // spot check: a few (b, h, q) rows against a double-precision softmax over the bf16 inputs
     std::vector<uint16_t> ho((size_t)B * S * C);
     hipMemcpy(ho.data(), o, ho.size() * 2, hipMemcpyDeviceToHost);
@@ -59,18 +69,21 @@ int main(int argc, char** argv) {
     for (auto& p : picks) {
         const int b = p[0], hh = p[1], qi = p[2] < S ? p[2] : S - 1;
         const uint16_t* base = h.data() + (size_t)b * S * 3 * C;
-        std::vector<double> sc(S);
+        const uint16_t* kb = cross ? hkv.data() + (size_t)(b / kvdiv) * Skv * 2 * C : base + C;
+        const uint16_t* vb = cross ? kb + C : base + 2 * C;
+        const int kvs = cross ? 2 * C : 3 * C;
+        std::vector<double> sc(Skv);
         double mx = -1e300;
-        for (int k = 0; k < S; ++k) {
+        for (int k = 0; k < Skv; ++k) {
             double a = 0;
-            for (int d = 0; d < D; ++d) a += (double)bf2f(base[(size_t)qi * 3 * C + hh * D + d]) * bf2f(base[(size_t)k * 3 * C + C + hh * D + d]);
+            for (int d = 0; d < D; ++d) a += (double)bf2f(base[(size_t)qi * 3 * C + hh * D + d]) * bf2f(kb[(size_t)k * kvs + hh * D + d]);
             sc[k] = a * scale; mx = std::max(mx, sc[k]);
         }
         double l = 0;
-        for (int k = 0; k < S; ++k) { sc[k] = std::exp(sc[k] - mx); l += sc[k]; }
+        for (int k = 0; k < Skv; ++k) { sc[k] = std::exp(sc[k] - mx); l += sc[k]; }
         for (int d = 0; d < D; ++d) {
             double a = 0;
-            for (int k = 0; k < S; ++k) a += sc[k] * bf2f(base[(size_t)k * 3 * C + 2 * C + hh * D + d]);
+            for (int k = 0; k < Skv; ++k) a += sc[k] * bf2f(vb[(size_t)k * kvs + hh * D + d]);
             a /= l;
             const double got = bf2f(ho[((size_t)b * S + qi) * C + hh * D + d]);
             worst = std::max(worst, std::fabs(got - a)); ref_max = std::max(ref_max, std::fabs(a));
