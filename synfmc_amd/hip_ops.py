@@ -953,7 +953,7 @@ def _time_ms(fn, reps=8):
     return ms
 
 
-def _pick(key, hip_fn, lib_fn, static_hip: bool, extra_arms=()) -> int:
+def _pick(key, hip_fn, lib_fn, static_hip: bool, extra_arms=(), k320: bool = False) -> int:
     """0 = vendor library arm, 1..6 = fused gfx950 kernel with that tile geometry (`hip_fn(tile)`)."""
     if not _cache_state["loaded"]:
         load_autotune_table()
@@ -965,7 +965,8 @@ def _pick(key, hip_fn, lib_fn, static_hip: bool, extra_arms=()) -> int:
     if use is None:
         if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
             return 0 if not (static_hip or no_lib) else -1          # -1: kernel's own geometry heuristic
-        times = ([] if no_lib else [(_time_ms(lib_fn), 0)]) + [(_time_ms(lambda t=t: hip_fn(t)), t) for t in GEMM_TILES + tuple(extra_arms)]
+        times = ([] if no_lib else [(_time_ms(lib_fn), 0)]) + [(_time_ms(lambda t=t: hip_fn(t)), t) for t in GEMM_TILES + tuple(extra_arms)
+                                                                if t != 15 or k320]   # (arm 15 exists for the K = 320 token projections only)
         use = min(times)[1]
         _choice[key] = use
         _tune_log[key] = {arm: round(ms, 4) for ms, arm in times}
@@ -1000,7 +1001,8 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     key = ("lin", M, N, Kd, bias is not None, (residual is not None) + (residual2 is not None),
            0 if x2 is None else x.shape[-1])
     hip = lambda tile: linear_bf16(x, weight, bias, residual, alpha, tile=tile, x2=x2, residual2=residual2)
-    use = _pick(key, hip, lib, Kd <= 640 and N <= 1024 and M >= 16384, split_arms(M, N, Kd))
+    use = _pick(key, hip, lib, Kd <= 640 and N <= 1024 and M >= 16384, split_arms(M, N, Kd),
+                k320=(Kd == 320 and N % 320 == 0 and M % 64 == 0 and x2 is None and residual2 is None))
     return lib() if use == 0 else hip(max(use, 0))
 
 
