@@ -1430,31 +1430,33 @@ void launch_gemm8(GemmParams& P, hipStream_t st) {
 // Loads of tile t+2 / t+1 and the stores of tile t are all in flight under the MFMAs of tile t+1: the kernel runs at the speed of
 // its bytes.
 // =====================================================================================================================
-constexpr int K320_K = 320, K320_BN = 320, K320_OP = K320_BN + 8;
-template <int MI> constexpr int k320_stage_chunks() { return ((32 * MI * (K320_OP / 8) + 63) / 64) * 64; }   // staging tile in 16-B chunks, whole DMA pieces
-template <int MI> constexpr size_t k320_lds() {
-    return (size_t)2 * 32 * MI * K320_K * 2 + (size_t)k320_stage_chunks<MI>() * 16 + K320_BN * sizeof(float);
+constexpr int K320_K = 320;
+// MI x NI 32x32 blocks per wave: the tile is 32 MI rows x 160 NI columns (5 waves side by side).  (2, 2) = 64 x 320: A is read once per 320
+// columns, one workgroup per CU; (1, 1) = 32 x 160: 80 weight registers per wave, three workgroups per CU (15 waves on 4 SIMDs)
+template <int MI, int NI> constexpr int k320_stage_chunks() { return ((32 * MI * ((160 * NI + 8) / 8) + 63) / 64) * 64; }   // staging tile in 16-B chunks, whole DMA pieces
+template <int MI, int NI> constexpr size_t k320_lds() {
+    return (size_t)2 * 32 * MI * K320_K * 2 + (size_t)k320_stage_chunks<MI, NI>() * 16 + 160 * NI * sizeof(float);
 }
 
-template <int MI, bool HAS_RES>
-__global__ __launch_bounds__(320, 1) void gemm_k320_kernel(const GemmParams P) {
-    constexpr int K = K320_K, KS = K / 16, BM = 32 * MI, BN = K320_BN, OP = K320_OP, CPR = K / 8, OCPR = OP / 8;
-    constexpr int A_ELEMS = BM * K, A_PIECES = BM * CPR / 64, ST_PIECES = k320_stage_chunks<MI>() / 64;
+template <int MI, int NI, bool HAS_RES>
+__global__ __launch_bounds__(320, (MI * NI == 1 ? 3 : (MI * NI == 2 ? 2 : 1))) void gemm_k320_kernel(const GemmParams P) {
+    constexpr int K = K320_K, KS = K / 16, BM = 32 * MI, BN = 160 * NI, OP = BN + 8, CPR = K / 8, OCPR = OP / 8, WC = 32 * NI;
+    constexpr int A_ELEMS = BM * K, A_PIECES = BM * CPR / 64, ST_PIECES = k320_stage_chunks<MI, NI>() / 64;
     constexpr int A_PPW = (A_PIECES + 4) / 5, ST_PPW = (ST_PIECES + 4) / 5;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* Abuf = reinterpret_cast<bf16_t*>(smem_raw);                         // [2][BM][K], chunk-swizzled rows
     bf16_t* Os = Abuf + 2 * A_ELEMS;                                             // [BM][OP] staging: residual in, output out
-    float* bias_s = reinterpret_cast<float*>(Os + k320_stage_chunks<MI>() * 8);  // [BN]
+    float* bias_s = reinterpret_cast<float*>(Os + k320_stage_chunks<MI, NI>() * 8);  // [BN]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int n0 = blockIdx.y * BN;
     const int ntiles = (int)(P.M / BM);
 
     // ---- resident weights: W^T fragments of my 64 columns, all 20 k-steps (A operand of the swapped product: rows = n) ----------
-    bf16x8 wf[KS][2];
+    bf16x8 wf[KS][NI];
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const bf16_t* wrow = P.w + (int64_t)(n0 + wave * 64 + ni * 32 + l31) * K + half * 8;
+    for (int ni = 0; ni < NI; ++ni) {
+        const bf16_t* wrow = P.w + (int64_t)(n0 + wave * WC + ni * 32 + l31) * K + half * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             union { bf16x8 v; u32x4 u; } t;
@@ -1519,12 +1521,12 @@ __global__ __launch_bounds__(320, 1) void gemm_k320_kernel(const GemmParams P) {
         asm volatile("" : "+v"(lane_v), "+v"(tid_v));
         // the accumulators start from the bias (out = alpha * (acc + bias) + residual): eight b128 reads here, all in flight together,
         // instead of one dependent LDS round trip in front of each of the epilogue's 16 word writes
-        f32x16 acc[2][MI];
+        f32x16 acc[NI][MI];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < NI; ++a)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + wave * 64 + a * 32 + 8 * g + 4 * half);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + wave * WC + a * 32 + 8 * g + 4 * half);
 #pragma unroll
                 for (int b = 0; b < MI; ++b)
 #pragma unroll
@@ -1546,7 +1548,7 @@ __global__ __launch_bounds__(320, 1) void gemm_k320_kernel(const GemmParams P) {
             if (ks + 1 < KS) read_a(ks + 1, af[(ks + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][ni], af[ks & 1][mi], acc[ni][mi], 0, 0, 0);
@@ -1561,10 +1563,10 @@ __global__ __launch_bounds__(320, 1) void gemm_k320_kernel(const GemmParams P) {
         // ---- epilogue: alpha * acc (+ residual words from the staging tile, four words requested at a time), one rounding, into the
         // staging tile ------------------------------------------------------------------------------------------------------------
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
-                bf16_t* wbase = Os + (mi * 32 + l31_e) * OP + wave * 64 + ni * 32 + 4 * half_e;
+                bf16_t* wbase = Os + (mi * 32 + l31_e) * OP + wave * WC + ni * 32 + 4 * half_e;
                 u32x2 rw[4];
                 if (HAS_RES) {
 #pragma unroll
@@ -1598,24 +1600,41 @@ __global__ __launch_bounds__(320, 1) void gemm_k320_kernel(const GemmParams P) {
     }
 }
 
+inline int gemm_k320_cfg() {          // FMC_K320_CFG = 22 (default) | 11 | 21 | 12: (MI, NI) blocks per wave (A/B)
+    static const int v = [] {
+        const char* e = getenv("FMC_K320_CFG");
+        return e ? atoi(e) : 22;
+    }();
+    return v;
+}
 bool gemm_k320_ok(const GemmParams& P) {
-    return P.hw <= 1 && P.K == K320_K && P.N % K320_BN == 0 && P.M % 64 == 0 && !P.a2 && !P.res2 && P.split_k == 1 && !P.sk && !P.temb &&
+    const int bn = (gemm_k320_cfg() % 10 == 1) ? 160 : 320;
+    return P.hw <= 1 && P.K == K320_K && P.N % bn == 0 && P.M % 64 == 0 && !P.a2 && !P.res2 && P.split_k == 1 && !P.sk && !P.temb &&
            ((P.M - 1) * P.lda + P.K) * 2 < ((int64_t)1 << 31) && (!P.res || ((P.M - 1) * P.ldres + P.N) * 2 < ((int64_t)1 << 31));
 }
 
-void launch_gemm_k320(GemmParams& P, hipStream_t st) {
-    constexpr int MI = 2;
-    const int tiles = (int)(P.M / (32 * MI)), cus = fmc_cu_count();
-    dim3 grid((unsigned)(tiles < cus ? tiles : cus), (unsigned)(P.N / K320_BN));
-    const size_t lds = k320_lds<MI>();
+template <int MI, int NI>
+void launch_gemm_k320_c(GemmParams& P, hipStream_t st) {
+    const size_t lds = k320_lds<MI, NI>();
+    const int per_cu = MI * NI == 1 ? 3 : (MI * NI == 2 ? 2 : 1);
+    const int tiles = (int)(P.M / (32 * MI)), slots = fmc_cu_count() * per_cu;
+    dim3 grid((unsigned)(tiles < slots ? tiles : slots), (unsigned)(P.N / (160 * NI)));
     static bool raised = false;
     if (!raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_k320_kernel<MI, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_k320_kernel<MI, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_k320_kernel<MI, NI, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_k320_kernel<MI, NI, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         raised = true;
     }
-    if (P.res) hipLaunchKernelGGL((gemm_k320_kernel<MI, true>), grid, dim3(320), lds, st, P);
-    else hipLaunchKernelGGL((gemm_k320_kernel<MI, false>), grid, dim3(320), lds, st, P);
+    if (P.res) hipLaunchKernelGGL((gemm_k320_kernel<MI, NI, true>), grid, dim3(320), lds, st, P);
+    else hipLaunchKernelGGL((gemm_k320_kernel<MI, NI, false>), grid, dim3(320), lds, st, P);
+}
+void launch_gemm_k320(GemmParams& P, hipStream_t st) {
+    switch (gemm_k320_cfg()) {
+        case 11: launch_gemm_k320_c<1, 1>(P, st); break;
+        case 21: launch_gemm_k320_c<2, 1>(P, st); break;
+        case 12: launch_gemm_k320_c<1, 2>(P, st); break;
+        default: launch_gemm_k320_c<2, 2>(P, st); break;
+    }
 }
 
 bool gemm8_ok(GemmParams& P) {
