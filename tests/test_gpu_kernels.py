@@ -641,8 +641,8 @@ def test_gemm_stream_k(K, tile):
 def test_gemm_k320_weight_stationary_arm(K):
     """Arm 15: the persistent kernel of the K = 320 projections (weights of a 320-column block resident in registers, A tiles by
     LDS-DMA two tiles ahead, residual rows DMA'd into the output staging tile).  One .. many tiles per workgroup (the grid is
-    min(tiles, CUs)), 1 / 2 / 3 column blocks, every epilogue it takes (bias, alpha, residual), strided views of a fused projection
-    as the residual / output, repeated launches on fresh data; shapes it does not take (K != 320, M % 64 != 0, two residuals)
+    min(tiles, CUs)), 1 / 2 / 3 column blocks, every epilogue it takes (bias, alpha, residual), column slices of wider tensors as x and
+    residual, repeated launches on fresh data; shapes it does not take (K != 320, M % 64 != 0, two residuals)
     must fall back to the ring kernel with the same results."""
     dtype = torch.bfloat16
     for (M, N) in [(64, 320), (640, 320), (64 * 300, 640), (64 * 515, 960), (81920, 320)]:
@@ -659,6 +659,12 @@ def test_gemm_k320_weight_stationary_arm(K):
                 assert torch.equal(got, K.linear_bf16(xd, wd, bd, rd, 0.5, tile=15))   # deterministic
                 assert rel_inf(K.linear_bf16(xd, wd, None, None, 1.0, tile=15).float(), F.linear(xo, wo)) < 1e-2
                 assert rel_inf(K.linear_bf16(xd, wd, bd, None, 1.0, tile=15).float(), F.linear(xo, wo, bo)) < 1e-2
+    # x and the residual as column slices of wider tensors (row strides 960 / 640 elements)
+    wo, wd = rnd((320, 320), 156, dtype, scale=320 ** -0.5)
+    bigx_o, bigx_d = rnd((1280, 960), 157, dtype)
+    bigr_o, bigr_d = rnd((1280, 640), 158, dtype)
+    got = K.linear_bf16(bigx_d[:, 320:640], wd, None, bigr_d[:, 320:], 1.0, tile=15)
+    assert rel_inf(got.float(), F.linear(bigx_o[:, 320:640], wo) + bigr_o[:, 320:]) < 1e-2
     # fall-backs: same entry point, other kernels
     xo, xd = rnd((700, 320), 147, dtype)
     wo, wd = rnd((320, 320), 148, dtype, scale=320 ** -0.5)
