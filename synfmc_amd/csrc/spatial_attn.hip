@@ -883,6 +883,189 @@ __global__ __launch_bounds__(256, 2) void sa40d_kernel(const SAParams P, const i
     }
 }
 
+// =====================================================================================================================
+// Text cross-attention (bf16, D = 40, H = 8, S_kv <= 96: the 77 text tokens), K / V stationary.
+//
+// The block-by-block kernel spends a 77-key launch on per-workgroup latencies (Q rows, K/V tile 0, a reference pass, tile 1,
+// two barriers each; 53 us at level 0 against 17 us for the launch's bytes).  Here a wave owns one head and keeps that head's K
+// fragments (3 key blocks x 3 k-steps) and V^T fragments (3 x 2 x 2, transposed once through a wave-private LDS tile with
+// ds_read_b64_tr_b16, ones in column 63 so that the PV MFMAs also produce the denominator) in REGISTERS for its whole life, and
+// walks 32-query units: Q fragments straight from global memory (the next unit's requested before this unit's MFMAs), 9 + 12
+// MFMAs, an exact softmax (all 96 scores of a query are in two lanes' registers: no online rescaling, no reference pass), 8-byte
+// stores.  No LDS traffic and no barrier after the prologue.  The 8 waves of a workgroup are the 8 heads of the same query rows,
+// so the 80-byte head slices of a row are touched together.
+// =====================================================================================================================
+constexpr int XA_VP = 64;                                                  // pitch (elements) of the wave-private V tile [96][64]
+__global__ __launch_bounds__(512, 1) void xattn40_kernel(const SAParams P, const int nq32, const int units_per_kvb, const int nkvb) {
+    constexpr int NKS = 3, NDT = 2, D = 40, NKB = 3;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, h = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    bf16_t* Vs = reinterpret_cast<bf16_t*>(smem_raw) + h * (96 * XA_VP);
+    const int kvb = blockIdx.x % nkvb, wg = blockIdx.x / nkvb, wgs = gridDim.x / nkvb;
+    const bf16_t* kg = (const bf16_t*)P.k + (int64_t)kvb * P.kbs + (int64_t)h * D;
+    const bf16_t* vg = (const bf16_t*)P.v + (int64_t)kvb * P.kbs + (int64_t)h * D;
+
+    // ---- K fragments (A operand of S^T = K Q^T: rows = keys), straight from global memory; keys >= S_kv and d >= 40 are zero ----------
+    bf16x8 kf[NKB][NKS];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int key = kb * 32 + l31, d0 = ks * 16 + half * 8;
+            union { bf16x8 v; u32x4 u; } t;
+            t.u = (key < P.Skv && d0 < D) ? *reinterpret_cast<const u32x4*>(kg + (int64_t)key * P.krs + d0) : u32x4{0u, 0u, 0u, 0u};
+            kf[kb][ks] = t.v;
+        }
+    // ---- V rows of my head -> wave-private LDS [96][64] (columns 40..62 zero, column 63 one), then the V^T fragments out of it ----------
+    {   // 96 rows x 5 data chunks = 480 chunks over 64 lanes: all 8 loads of a lane in flight before the first LDS write (a loop of
+        // load -> store pairs was 12 dependent round trips, most of this kernel's prologue); then the constant chunks 5..7
+        u32x4 w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = lane + 64 * j, row = c / 5, ch = c - row * 5;
+            w[j] = (c < 480 && row < P.Skv) ? *reinterpret_cast<const u32x4*>(vg + (int64_t)row * P.krs + ch * 8) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = lane + 64 * j, row = c / 5, ch = c - row * 5;
+            if (c < 480) *reinterpret_cast<u32x4*>(Vs + row * XA_VP + ch * 8) = w[j];
+        }
+        for (int c = lane; c < 96 * 3; c += 64) {
+            const int row = c / 3, ch = 5 + (c - row * 3);
+            u32x4 z = u32x4{0u, 0u, 0u, 0u};
+            if (ch == 7) z[3] = (unsigned)f2bf(1.f) << 16;
+            *reinterpret_cast<u32x4*>(Vs + row * XA_VP + ch * 8) = z;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (wave-private: no barrier)
+    bf16x8 vf[NKB][2][NDT];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const bf16_t* vp = Vs + (kb * 32 + s2 * 16 + half * 4 + ((l31 & 15) >> 2)) * XA_VP + dt * 32 + (l31 >> 4) * 16 + (l31 & 3) * 4;
+                union { bf16x8 v; sa_s4 hh[2]; } r;
+                r.hh[0] = lds_tr16(vp);
+                r.hh[1] = lds_tr16(vp + 8 * XA_VP);
+                vf[kb][s2][dt] = r.v;
+            }
+
+    auto load_q = [&](int u, bf16x8 (&qf)[NKS]) {
+        const int b = kvb * P.kv_batch_div + u / nq32, q = (u - (u / nq32) * nq32) * 32 + l31;
+        const bf16_t* qg = (const bf16_t*)P.q + (int64_t)b * P.qbs + (int64_t)q * P.qrs + h * D;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int d0 = ks * 16 + half * 8;
+            Frag<bf16_t> f;
+            if (d0 < D) {
+                float qv[8];
+                Vec8<bf16_t>::load(qg + d0, qv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) qv[i] *= P.scale_log2;
+                p_frag(qv, f);
+            } else {
+                zero(f);
+            }
+            qf[ks] = f.hi;
+        }
+    };
+
+    int u = wg;
+    bf16x8 qf[NKS], qn[NKS];
+    if (u < units_per_kvb) load_q(u, qf);
+    for (; u < units_per_kvb; u += wgs) {
+        if (u + wgs < units_per_kvb) load_q(u + wgs, qn);                      // the next unit's rows are on their way under this unit's work
+        f32x16 s[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb][ks], qf[ks], s[kb], 0, 0, 0);
+        }
+        // keys >= S_kv out; exact row maximum (a query's 96 scores: 48 here, 48 in lane ^ 32)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (key >= P.Skv) s[kb][r] = -INFINITY;
+                mx = fmaxf(mx, s[kb][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        f32x16 oacc[NDT];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            float pv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pv[r] = __builtin_amdgcn_exp2f(s[kb][r] - mx);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float p8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) p8[i] = pv[s2 * 8 + i];
+                Frag<bf16_t> pf;
+                p_frag(p8, pf);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kb][s2][dt], pf.hi, oacc[dt], 0, 0, 0);
+            }
+        }
+        const float l_tot = __shfl(oacc[NDT - 1][15], l31 + 32, 64);             // O^T row 63 (the ones column of V): upper half, register 15
+        const float inv = 1.f / l_tot;
+        const int b = kvb * P.kv_batch_div + u / nq32, q = (u - (u / nq32) * nq32) * 32 + l31;
+        bf16_t* orow = (bf16_t*)P.o + (int64_t)b * P.obs + (int64_t)q * P.ors + h * D;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = dt * 32 + 8 * g + 4 * half;
+                if (d < D)
+                    store4<bf16_t>(orow + d, oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv, oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
+            }
+        if (P.lse && half == 0) P.lse[((int64_t)b * P.H + h) * P.Sq + q] = mx * 0.6931471805599453f + logf(l_tot);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[ks] = qn[ks];
+    }
+}
+
+inline int sa_xattn_env() {           // FMC_SA_XATTN=0: the block-by-block kernel for the text cross-attention too (A/B)
+    static const int v = [] {
+        const char* e = getenv("FMC_SA_XATTN");
+        return e ? atoi(e) : 1;
+    }();
+    return v;
+}
+inline bool xattn40_ok(const SAParams& P) {
+    return P.D == 40 && P.H == 8 && P.Skv <= 96 && P.Skv >= 1 && P.Sq % 32 == 0 && P.B % P.kv_batch_div == 0 && sa_xattn_env() != 0;
+}
+inline void launch_xattn40(const SAParams& P, hipStream_t st) {
+    const int nkvb = P.B / P.kv_batch_div, nq32 = P.Sq / 32, units = P.kv_batch_div * nq32;
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n;
+    }();
+    int per = cus / nkvb;
+    if (per < 1) per = 1;
+    if (per > units) per = units;
+    const size_t lds = (size_t)8 * 96 * XA_VP * 2;
+    static bool raised = false;
+    if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn40_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        raised = true;
+    }
+    hipLaunchKernelGGL(xattn40_kernel, dim3((unsigned)(per * nkvb)), dim3(512), lds, st, P, nq32, units, nkvb);
+}
+
 inline int sa_pipe_env() {            // FMC_SA_PIPE=0: the block-by-block kernel at d = 40 too (A/B); 4: persistent workgroups
     static const int v = [] {
         const char* e = getenv("FMC_SA_PIPE");
@@ -1049,6 +1232,11 @@ extern "C" int fmc_spatial_attn_fwd(const void* q, const void* k, const void* v,
         if (want == 0 || (want == 1 && (B * H) % 8 == 0)) P.xcd_remap = want;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == FMC_BF16 && xattn40_ok(P)) {
+        launch_xattn40(P, st);
+        FMC_CHECK_LAUNCH("fmc_spatial_attn_fwd");
+        return 0;
+    }
     if (dtype == FMC_BF16 && sa40_ok(P)) {
         launch_sa40(P, st);
         FMC_CHECK_LAUNCH("fmc_spatial_attn_fwd");

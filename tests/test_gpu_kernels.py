@@ -224,6 +224,25 @@ def test_spatial_attention_pipelined_d40(K, B, S, Skv, H, fused):
         assert rel_inf(K.spatial_attention(qd, k1d, v1d, H).float(), ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("B,S,Skv,kvdiv", [(8, 64, 77, 4), (4, 256, 20, 1), (6, 32, 96, 2), (32, 640, 77, 16), (2, 96, 1, 2)])
+def test_text_cross_attention_kv_stationary(K, B, S, Skv, kvdiv):
+    """`xattn40_kernel` (bf16, d = 40, 8 heads, S_kv <= 96, S_q % 32 == 0): a wave keeps its head's K / V^T fragments in registers and walks
+    the query units of its text batch.  1 .. 96 keys (masking inside and across the three key blocks), K / V shared by `kvdiv` batch
+    entries, K / V as slices of one fused [.., 2C] projection, LSE."""
+    H, D, dtype = 8, 40, torch.bfloat16
+    C = H * D
+    qo, qd = rnd((B, S, C), 80, dtype)
+    kvo, kvd = rnd((B // kvdiv, Skv, 2 * C), 81, dtype)
+    kv_rep = kvo.repeat_interleave(kvdiv, dim=0)
+    ref = oracle_attention(qo, kv_rep[..., :C], kv_rep[..., C:], H)
+    out, lse = K.spatial_attention(qd, kvd[..., :C], kvd[..., C:], H, return_lse=True)
+    assert rel_inf(out.float(), ref) < TOL[dtype]
+    qh = qo.reshape(B, S, H, D).permute(0, 2, 1, 3)
+    kh = kv_rep[..., :C].reshape(B, Skv, H, D).permute(0, 2, 1, 3)
+    lse_ref = torch.logsumexp(qh @ kh.transpose(-1, -2) * D ** -0.5, dim=-1)
+    assert (lse.cpu() - lse_ref).abs().max() < 2e-2
+
+
 def test_spatial_attention_pipelined_reference_redo(K):
     """The pipelined kernel keeps no running maximum: a row whose logits leave the range of the first-tile reference shows as
     an overflowing denominator, the workgroup finds the exact maxima in a plain sweep and repeats the pipelined one.  The
