@@ -203,6 +203,8 @@ int fmc_cfg_ddim_step(const void* eps_uc, const float* x, float* x_out, int64_t 
  *   split_k > 1 (epilogue 0 only): the k-tiles of every output tile are dealt to split_k workgroups that write fp32
  *   partial sums to `workspace` (>= split_k * M * N * 4 bytes, 16-byte aligned, caller-owned scratch); a second kernel
  *   sums them in a fixed order and applies the epilogue.  For M*N too small to fill 256 CUs (the 5x8 level).
+ *   split_k == -2 (arms 13 / 14 only; other arms treat it as -1): the tiles of the whole rounds (tiles / CUs * CUs of them) run on the
+ *   plain grid and only the last partial round goes through the two stream-K launches below -- same workspace, same results as -1.
  *   split_k == -1: stream-K.  (On the 8-phase arms 13 / 14: TWO launches -- a persistent pass, one workgroup per CU, every
  *   segment's fp32 accumulators into a workspace slot in accumulator layout, then one workgroup per output tile that sums
  *   the slots covering its tile and runs the epilogue; workspace >= 4096 + CUs * (ceil(tiles / CUs) + 2) * 256 KiB, no

@@ -62,6 +62,8 @@ struct GemmParams {
     int64_t sk_ws_bytes;
     int sk_maxseg;                    // 8-phase stream-K: workspace slots per workgroup (segments it may own)
     int sk_whole;                     // 8-phase stream-K: 1 = the persistent pass (ROLE 3) finished the whole tiles itself
+    int sk_t0;                        // 8-phase hybrid: tiles [0, sk_t0) (launch order) run on the plain grid, only the rest is stream-K'd
+    int sk_hybrid;                    // split_k == -2 was asked for
     int64_t a_bytes;                  // 8-phase kernel: size of the A operand in bytes (buffer descriptor range)
     const float* q8_inv;              // EPI 2 (fp8 e4m3 output, three equal column blocks q | k | v): 1 / scale per block (device)
     unsigned* q8_amax;                // EPI 2: running max |value| per block as float bits (device, atomicMax), may be NULL
@@ -740,7 +742,7 @@ void gemm8_kernel(const GemmParams P) {
     int64_t sk_it = 0, sk_end = 0, sk_gbase = 0, sk_I = 0;
     int sk_r = 0, sk_per = 1, sk_first = 0;
     if (SK) {
-        const int T = P.tiles_m * P.tiles_n, x = blockIdx.x & 7, q = blockIdx.x >> 3;
+        const int T = P.tiles_m * P.tiles_n - P.sk_t0, x = blockIdx.x & 7, q = blockIdx.x >> 3;
         sk_per = P.sk >> 3;
         const int tg0 = (int)((int64_t)T * x / 8), tg1 = (int)((int64_t)T * (x + 1) / 8);
         sk_gbase = (int64_t)tg0 * nkt;
@@ -767,12 +769,13 @@ void gemm8_kernel(const GemmParams P) {
         nk = (int)min((int64_t)nkt, kt0 + (sk_end - sk_it));
         sk_it += nk - kt0;
         sk_slot = blockIdx.x * P.sk_maxseg + (lin - sk_first);
-        lin_to_tile(lin, P, tile_m, tile_n);
+        lin_to_tile(lin + P.sk_t0, P, tile_m, tile_n);
     } else {
-        const int total = P.tiles_m * P.tiles_n;
+        // (hybrid: the plain launch covers the first sk_t0 tiles of the launch order, the finishing launch the rest)
+        const int total = ROLE == 2 ? P.tiles_m * P.tiles_n - P.sk_t0 : (P.sk_t0 > 0 ? P.sk_t0 : P.tiles_m * P.tiles_n);
         const int id = blockIdx.x, q = total >> 3, r = total & 7, x = id & 7;
         const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);   // XCD x owns a contiguous range
-        lin_to_tile(lin, P, tile_m, tile_n);
+        lin_to_tile(ROLE == 2 ? lin + P.sk_t0 : lin, P, tile_m, tile_n);
         if (ROLE == 2) {
             // the segments of ROLE 1 that cover tile `lin`: XCD group g holds tiles [T g / 8, T (g + 1) / 8); inside it range r of
             // `per` covers iterations [I r / per, I (r + 1) / per) and was run by block (per - 1 - r) * 8 + g
@@ -1392,6 +1395,27 @@ void launch_gemm8(GemmParams& P, hipStream_t st) {
         raised = true;
     }
     const int tiles = P.tiles_m * P.tiles_n;
+    P.sk_t0 = 0;
+    if (P.sk && P.sk_hybrid) {
+        // hybrid: the whole rounds on the plain grid, only the last partial round through stream-K -- the partial traffic (2 x 256 KiB per
+        // segment) and the finishing launch then cover tiles % CUs tiles instead of all of them
+        const int g = fmc_cu_count() & ~7;
+        const int t0 = g >= 8 ? (tiles / g) * g : 0, rem = tiles - t0;
+        const int64_t iters = (int64_t)rem * (P.K / 64);
+        const int maxseg = (rem + g - 1) / (g > 0 ? g : 1) + 2;
+        const int64_t need = (int64_t)g * maxseg * 256 * 256 * (int64_t)sizeof(float) + 4096;
+        if (t0 > 0 && rem > 0 && iters >= 2 * (int64_t)g && P.sk_ws_bytes >= need && need < ((int64_t)1 << 31)) {
+            P.sk = g;
+            P.sk_maxseg = maxseg;
+            P.sk_whole = 0;
+            P.sk_t0 = t0;
+            hipLaunchKernelGGL((gemm8_kernel<MODE, EPI, PF, 1>), dim3((unsigned)g), dim3(512), lds, st, P);
+            hipLaunchKernelGGL((gemm8_kernel<MODE, EPI, PF, 0>), dim3((unsigned)t0), dim3(512), lds, st, P);
+            hipLaunchKernelGGL((gemm8_kernel<MODE, EPI, PF, 2>), dim3((unsigned)rem), dim3(512), lds, st, P);
+            return;
+        }
+        if (rem == 0) P.sk = 0;                           // whole rounds only: the plain grid (else: fewer tiles than CUs -> full stream-K below)
+    }
     if (P.sk) {
         // stream-K = persistent main kernel (one 128-KiB workgroup per CU, partials only) + one finishing workgroup per tile
         const int64_t iters = (int64_t)tiles * (P.K / 64);
@@ -1689,9 +1713,11 @@ int set_split_k(GemmParams& P, int split_k, void* workspace, int64_t workspace_b
     P.split_k = 1;
     P.ws = nullptr;
     P.sk = 0;
+    P.sk_t0 = 0;
     P.sk_flags = nullptr;
     P.sk_ws_bytes = 0;
-    if (split_k == -1) {                                 // stream-K: [4096 B of flags (zero on entry and on return) | partials]
+    P.sk_hybrid = split_k == -2;
+    if (split_k == -1 || split_k == -2) {                // stream-K: [4096 B of flags (zero on entry and on return) | partials]
         if (!workspace || !fmc_aligned16(workspace) || workspace_bytes < 8192)
             FMC_FAIL(FMC_E_NULL, "%s: stream-K needs a 16-byte aligned, zero-initialised workspace", who);
         P.sk = 1;

@@ -686,6 +686,8 @@ def cfg_ddim_step(eps: torch.Tensor, x: torch.Tensor, guidance: float, alpha_t: 
 # --------------------------------------------------------------------------------------------
 def _decode_arm(tile: int, split_k: int):
     """autotune arm id -> (tile geometry 0..6, split_k)"""
+    if tile >= 256:
+        return tile - 256, -2                           # whole rounds on the plain grid, the last partial round stream-K (8-phase arms)
     if tile >= 128:
         return tile - 128, -1                           # stream-K
     if tile >= 16:
@@ -712,7 +714,7 @@ def _streamk_workspace(device):
 
 
 def _splitk_workspace(device, split_k: int, M: int, N: int):
-    if split_k == -1:
+    if split_k in (-1, -2):
         return _streamk_workspace(device)
     if split_k <= 1:
         return None, 0
@@ -908,7 +910,8 @@ GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 11,     # 8..10, 12 (4-stage rings) exist but
               13,                            # the 8-phase 256x256 kernel (staggered wave rows, half-tile DMA, counted vmcnt)
               15,                            # K = 320 token projections: persistent, weights resident in registers (falls back to 5 elsewhere)
               128 + 2, 128 + 3,              # stream-K (persistent workgroups) on the two 1-per-CU geometries
-              128 + 13)                      # stream-K on the 8-phase kernel: persistent partial pass + one finishing workgroup per tile
+              128 + 13,                      # stream-K on the 8-phase kernel: persistent partial pass + one finishing workgroup per tile
+              256 + 13)                      # the same for the LAST PARTIAL ROUND of tiles only, the whole rounds on the plain grid
 if os.environ.get("FMC_GEMM_ARMS"):              # A/B switch: the arm list the autotuner may choose from, e.g. "1,2,3,11"
     GEMM_TILES = tuple(int(a) for a in os.environ["FMC_GEMM_ARMS"].split(","))
 # fmc_linear_bf16 / fmc_conv3x3_bf16 `tile` arms tried per shape (14 = arm 13 with a deeper prefetch measured no better anywhere,

@@ -699,7 +699,7 @@ def test_gemm_k320_weight_stationary_arm(K):
     assert rel_inf(K.linear_bf16(xd6, wd6, None, None, 1.0, tile=15).float(), F.linear(xo6, wo6)) < 1e-2           # K != 320
 
 
-@pytest.mark.parametrize("tile", [13, 14, 128 + 13, 128 + 14])
+@pytest.mark.parametrize("tile", [13, 14, 128 + 13, 128 + 14, 256 + 13])
 def test_gemm_8phase_arms(K, tile):
     """The 8-phase 256x256 kernel (staggered wave rows, half-tile DMA with counted vmcnt): ragged M / N (partial tiles),
     K from one k-tile up, every epilogue (bias, alpha, one / two residuals, GEGLU, two-source A operand), the conv loader
@@ -707,7 +707,8 @@ def test_gemm_8phase_arms(K, tile):
     shows up as rare wrong tiles)."""
     dtype = torch.bfloat16
     from synfmc_amd.models.layers import interleave_geglu
-    for (M, N, Kd) in [(4100, 1032, 1280), (256, 256, 64), (700, 320, 320), (5120, 1280, 128), (1000, 2560, 640)]:
+    # (5120 x 4096: 320 tiles on 256 CUs -- the hybrid arm 256 + 13 runs 256 of them on the plain grid and stream-Ks the other 64)
+    for (M, N, Kd) in [(4100, 1032, 1280), (256, 256, 64), (700, 320, 320), (5120, 1280, 128), (1000, 2560, 640), (5120, 4096, 640)]:
         wo, wd = rnd((N, Kd), 45, dtype, scale=Kd ** -0.5)
         bo, bd = rnd((N,), 46, dtype)
         for it in range(4):

@@ -37,7 +37,8 @@ int main(int argc, char** argv) {
     printf("M=%lld N=%d K=%d bias=%d residual=%d: %.2f GFLOP\n", (long long)M, N, K, use_bias, use_res, 2.0 * M * N * K / 1e9);
     for (int arm : arms) {
         int tile = arm & 15, split = 1;
-        if (arm >= 128) { tile = arm - 128; split = -1; }               // stream-K arms
+        if (arm >= 256) { tile = arm - 256; split = -2; }               // hybrid: whole rounds plain, the last partial round stream-K
+        else if (arm >= 128) { tile = arm - 128; split = -1; }          // stream-K arms
         else if (arm >= 16) { tile = arm & 15; split = 1 << (arm >> 4); }
         auto call = [&]() { return fn(x, w, use_bias ? b : nullptr, use_res ? r : nullptr, o, M, N, K, K, N, N, 1.f, 0, tile, split, ws, wsb, nullptr, 0, 0, nullptr, nullptr); };
         int rc = call();
