@@ -405,13 +405,17 @@ __global__ void gn_apply_bwd_kernel(const T* __restrict__ dy, const T* __restric
                                     const float* __restrict__ stats, const float* __restrict__ part, int HW, int C,
                                     int G, int tpr, int rpi, int rows_per_split, int act) {
     __shared__ float sh_m1[GN_MAX_G], sh_m2[GN_MAX_G];
+    __shared__ float sh_part[GN_MAX_SPLIT * GN_MAX_G * 2];
     const int n = blockIdx.y, s = blockIdx.x, nsplit = gridDim.x;
     const int tid = threadIdx.x;
     const int cpg = C / G;
+    // the sample's partial pairs in ONE global round trip (as in gn_apply_fwd_kernel; a chain of nsplit dependent loads per group before)
+    for (int i = tid; i < nsplit * G * 2; i += blockDim.x) sh_part[i] = part[(size_t)n * nsplit * G * 2 + i];
+    __syncthreads();
     for (int g = tid; g < G; g += blockDim.x) {
         double a = 0.0, b = 0.0;
         for (int k = 0; k < nsplit; ++k) {
-            const float* p = part + (((size_t)n * nsplit + k) * G + g) * 2;
+            const float* p = sh_part + ((size_t)k * G + g) * 2;
             a += (double)p[0];
             b += (double)p[1];
         }
@@ -438,19 +442,28 @@ __global__ void gn_apply_bwd_kernel(const T* __restrict__ dy, const T* __restric
     int row1 = row0 + rows_per_split;
     if (row1 > HW) row1 = HW;
     const size_t base = (size_t)n * HW * C + c0;
-    for (int r = row0 + rsub; r < row1; r += rpi) {
-        float v[8], d[8];
-        Vec8<T>::load(x + base + (size_t)r * C, v);
-        Vec8<T>::load(dy + base + (size_t)r * C, d);
+    // two rows per trip, loads first (branch-free, clamped): one row per trip left two 16-byte loads in flight per thread
+    for (int r = row0 + rsub; r < row1; r += 2 * rpi) {
+        float v[2][8], d[2][8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float z = v[i] * aco[i] + bco[i];
-            float dz = act ? d[i] * dsilu_f(z) : d[i];
-            float dxh = dz * gm[i];
-            float xh = (v[i] - mu[i]) * rs[i];
-            v[i] = rs[i] * (dxh - m1[i] - xh * m2[i]);
+        for (int u = 0; u < 2; ++u) {
+            const int rr = r + u * rpi < row1 ? r + u * rpi : row1 - 1;
+            Vec8<T>::load(x + base + (size_t)rr * C, v[u]);
+            Vec8<T>::load(dy + base + (size_t)rr * C, d[u]);
         }
-        Vec8<T>::store(dx + base + (size_t)r * C, v);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int rr = r + u * rpi;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float z = v[u][i] * aco[i] + bco[i];
+                float dz = act ? d[u][i] * dsilu_f(z) : d[u][i];
+                float dxh = dz * gm[i];
+                float xh = (v[u][i] - mu[i]) * rs[i];
+                v[u][i] = rs[i] * (dxh - m1[i] - xh * m2[i]);
+            }
+            if (rr < row1) Vec8<T>::store(dx + base + (size_t)rr * C, v[u]);
+        }
     }
 }
 
