@@ -1611,8 +1611,7 @@ __global__ __launch_bounds__(320, (MI * NI == 1 ? 3 : (MI * NI == 2 ? 2 : 1))) v
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         {
             bf16_t* og = P.out + (int64_t)t * BM * P.ldo + n0;
-#pragma unroll
-            for (int c = tid_v; c < BM * (BN / 8); c += 320) {
+            for (int c = tid_v; c < BM * (BN / 8); c += 320) {     // (a run-time loop: unrolled, its 8 staged chunks spill next to the resident weights)
                 const int r = c / (BN / 8), ch = c - r * (BN / 8);
                 *reinterpret_cast<u32x4*>(og + (int64_t)r * P.ldo + ch * 8) = *reinterpret_cast<const u32x4*>(Os + r * OP + ch * 8);
             }
