@@ -240,6 +240,35 @@ int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, const void*
                      int upsample2x, int tile, int split_k, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * fp32-storage ("parity") mode of the two GEMMs above: split-bf16 x3 on the SAME kernels.
+ * The reference's CPU path is fp32 (north_star: outputs within 1e-3 rel-inf of it); the bf16 product path can only be held
+ * to bf16's own rounding against it.  To check the hand-written tile maps, operand loaders (token / implicit 3x3 conv /
+ * upsample / stride 2), fragment layouts, split-K order and epilogue arithmetic at fp32 accuracy, every fp32 operand is
+ * split into bf16 `hi` and bf16 `lo = bf16(x - hi)` (x = hi + lo to ~2^-17 relative) and laid out along the reduction:
+ *     activation rows  [hi | hi | lo]      weight rows  [hi | lo | hi]       (three blocks of K columns each)
+ * so that ONE bf16 MFMA GEMM over K3 = 3 K accumulates hi hi' + hi lo' + lo hi' in fp32 -- the fp32 product up to the
+ * dropped lo lo' term (2^-18).  Same call sites as fmc_linear_bf16 / fmc_conv3x3_bf16 when the model is held in fp32
+ * (fmc/models/attention_processor.py:50-69,255-283, motion_module.py:219,228,284, unet_blocks.py:306-317,625).
+ *
+ * fmc_split_bf16x3: src fp32 [rows, C] (rows `ld_src` floats apart) -> dst bf16 [rows, 3 K] (rows `ld_dst` apart), columns
+ *   [col0, col0 + C) of each of the three K-blocks; role 0 = activation pattern, 1 = weight pattern.  col0 / K let a
+ *   two-source operand (`x2` of fmc_linear_bf16) be written into one buffer.  For the convolution the rows are pixels
+ *   (C = K = Cin: x3 is [n, H, W, 3 Cin]) resp. (Cout, tap) pairs (w3 is [Cout, 3, 3, 3 Cin]).  C, K, col0 % 8 == 0.
+ * fmc_linear_x3_f32 / fmc_conv3x3_x3_f32: as fmc_linear_bf16 / fmc_conv3x3_bf16 on such operands (K3 = 3 K, Cin3 = 3 Cin),
+ *   with bias / temb / residual(s) / out in FP32 (strides in floats, % 4 == 0) and the whole epilogue (bias, alpha, temb,
+ *   residuals, exact-erf GEGLU) in fp32 straight from the accumulator registers.  tile: arms 1..14 (15 falls back to 5);
+ *   split_k >= 1 only (no stream-K); no two-source operand (split both sources into one x3).
+ * ------------------------------------------------------------------------------------------- */
+int fmc_split_bf16x3(const float* src, void* dst, int64_t rows, int C, int64_t ld_src, int64_t ld_dst, int col0, int K,
+                     int role, void* stream);
+int fmc_linear_x3_f32(const void* x3, const void* w3, const float* bias, const float* residual, float* out, int64_t M, int N,
+                      int K3, int64_t ldx, int64_t ldres, int64_t ldo, float alpha, int epilogue, int tile, int split_k,
+                      void* workspace, int64_t workspace_bytes, const float* residual2, void* stream);
+int fmc_conv3x3_x3_f32(const void* x3, const void* w3, const float* bias, const float* temb, const float* residual, float* out,
+                       int n_img, int H, int W, int Cin3, int Cout, int64_t temb_row_stride, int temb_img_div,
+                       int upsample2x, int tile, int split_k, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Backward entry points (training stages 2/3 of the reference: the U-Net is frozen but the activation gradient
  * flows through every layer back to the OMC / CMC injection points, train_cam_obj_ctrl.py:917-929,
  * train_cam_ctrl.py:626-650; in the reference this is PyTorch autograd through the same call sites as the forwards).

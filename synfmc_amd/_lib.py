@@ -45,6 +45,11 @@ SIGNATURES = {
     "fmc_linear_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64,
                                 c_int64, c_int64, c_float, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int,
                                 c_void_p, c_void_p]),
+    "fmc_split_bf16x3": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "fmc_linear_x3_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64,
+                                  c_int64, c_int64, c_float, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
+    "fmc_conv3x3_x3_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                   c_int, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "fmc_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float,
                                   c_int, c_void_p]),
     "fmc_geglu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),

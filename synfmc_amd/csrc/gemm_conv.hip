@@ -67,7 +67,46 @@ struct GemmParams {
     int64_t a_bytes;                  // 8-phase kernel: size of the A operand in bytes (buffer descriptor range)
     const float* q8_inv;              // EPI 2 (fp8 e4m3 output, three equal column blocks q | k | v): 1 / scale per block (device)
     unsigned* q8_amax;                // EPI 2: running max |value| per block as float bits (device, atomicMax), may be NULL
+    int f32io;                        // fp32-storage ("parity") mode: A / W are split-bf16 x3 operands (fmc_split_bf16x3), bias / temb /
+                                      // residual(s) / out are FP32 tensors (the bf16_t pointers above are reinterpreted), see epi_f32_*
 };
+
+// ---- fp32-storage mode: the epilogue straight from the accumulator registers, fp32 in, fp32 out ---------------------------
+// The split-bf16 x3 operands ([hi | hi | lo] x [hi | lo | hi] along K, fp32 accumulate) give the fp32 product to ~2^-17; this
+// epilogue keeps bias / alpha / temb / residual(s) / GEGLU in fp32 as well, so the SAME tile maps, loaders, fragment layouts
+// and reduction orders the bf16 product path runs are checked against the fp32 CPU oracle at 1e-3 instead of 1e-2.
+// A lane holds 4 consecutive output columns of one row per accumulator register quad: one f32x4 store per quad.
+template <int MODE>
+__device__ __forceinline__ void epi_f32_quad(const GemmParams& P, const float (&a)[4], int64_t m, int n) {
+    if (m >= P.M || n >= P.N) return;
+    const float* bias = reinterpret_cast<const float*>(P.bias);
+    const float* temb = reinterpret_cast<const float*>(P.temb);
+    const float* res = reinterpret_cast<const float*>(P.res);
+    const float* res2 = reinterpret_cast<const float*>(P.res2);
+    float* out = reinterpret_cast<float*>(P.out);
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (a[j] + (bias ? bias[n + j] : 0.f)) * P.alpha;
+    if (MODE == 1 && temb) v += *reinterpret_cast<const f32x4*>(temb + ((m / P.hw) / P.temb_div) * P.temb_ld + n);
+    if (res) v += *reinterpret_cast<const f32x4*>(res + m * P.ldres + n);
+    if (res2) v += *reinterpret_cast<const f32x4*>(res2 + m * P.ldres + n);
+    *reinterpret_cast<f32x4*>(out + m * P.ldo + n) = v;
+}
+// GEGLU: `av` / `ag` = value and gate accumulators of the same 4 output columns; nb = weight row of the first value column
+__device__ __forceinline__ void epi_f32_geglu_quad(const GemmParams& P, const float (&av)[4], const float (&ag)[4], int64_t m, int nb, int no) {
+    if (m >= P.M || no >= P.N / 2) return;
+    const float* bias = reinterpret_cast<const float*>(P.bias);
+    float* out = reinterpret_cast<float*>(P.out);
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float g = ag[j] + (bias ? bias[nb + 32 + j] : 0.f);
+        // exact erf here (libdevice): the fast polynomial of gelu_erf is a bf16-grade approximation (1.5e-7 absolute is fine,
+        // but parity mode should not depend on it)
+        v[j] = (av[j] + (bias ? bias[nb + j] : 0.f)) * (0.5f * g * (1.f + erff(g * 0.70710678118654752f)));
+    }
+    *reinterpret_cast<f32x4*>(out + m * P.ldo + no) = v;
+}
 
 // Launch-order index -> output tile.  Inside a group of `group_m` m-tiles the order is n-outer / m-inner, so the C
 // workgroups an XCD runs at any moment cover ~group_m m-tiles x C/group_m n-tiles: each k-step they pull group_m
@@ -405,6 +444,29 @@ void gemm_kernel(const GemmParams P) {
             while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 22))
                 __builtin_amdgcn_s_sleep(8);
         }
+    }
+
+    // ---- fp32-storage mode (never with stream-K; split-K writes its raw partials below and splitk_reduce_kernel finishes) ------
+    if (!SK && P.f32io && P.split_k == 1) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int64_t m = m0 + wm * (32 * MI) + mi * 32 + l31;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (EPI == 1) {
+                    const float av[4] = {acc[0][mi][4 * g], acc[0][mi][4 * g + 1], acc[0][mi][4 * g + 2], acc[0][mi][4 * g + 3]};
+                    const float ag[4] = {acc[1][mi][4 * g], acc[1][mi][4 * g + 1], acc[1][mi][4 * g + 2], acc[1][mi][4 * g + 3]};
+                    epi_f32_geglu_quad(P, av, ag, m, n0 + wn * 64 + 8 * g + 4 * half, n0 / 2 + wn * 32 + 8 * g + 4 * half);
+                } else {
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        const float a4[4] = {acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]};
+                        epi_f32_quad<MODE>(P, a4, m, n0 + wn * 64 + ni * 32 + 8 * g + 4 * half);
+                    }
+                }
+            }
+        }
+        break;
     }
 
     // ---- GEGLU epilogue of the plain grid: in registers.  The weight rows are interleaved per 64 so that acc[0] holds the
@@ -1046,6 +1108,29 @@ void gemm8_kernel(const GemmParams P) {
                 }
         continue;                                         // (the next segment's prologue only writes LDS, already released above)
     } else {
+    if constexpr (ROLE == 0 && EPI != 2) {
+        if (P.f32io) {                                    // fp32-storage mode: see epi_f32_quad
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int64_t m = m0 + wr * 128 + mi * 32 + l31;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    if (EPI == 1) {
+                        const float av[4] = {acc[0][mi][4 * gq], acc[0][mi][4 * gq + 1], acc[0][mi][4 * gq + 2], acc[0][mi][4 * gq + 3]};
+                        const float ag[4] = {acc[1][mi][4 * gq], acc[1][mi][4 * gq + 1], acc[1][mi][4 * gq + 2], acc[1][mi][4 * gq + 3]};
+                        epi_f32_geglu_quad(P, av, ag, m, n0 + wc * 64 + 8 * gq + 4 * half, n0 / 2 + wc * 32 + 8 * gq + 4 * half);
+                    } else {
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+                            const float a4[4] = {acc[ni][mi][4 * gq], acc[ni][mi][4 * gq + 1], acc[ni][mi][4 * gq + 2], acc[ni][mi][4 * gq + 3]};
+                            epi_f32_quad<MODE>(P, a4, m, n0 + wc * 64 + ni * 32 + 8 * gq + 4 * half);
+                        }
+                    }
+                }
+            }
+            break;
+        }
+    }
     // ---- epilogue: the output tile is staged as bf16 in LDS, 128 rows (the same 64-row half of both wave rows) per pass,
     // and leaves with whole-row 16-byte stores.  Residuals travel through the same staging rows first (whole-row 16-byte
     // loads), every lane adds its own words to its accumulators in fp32: one rounding, as in gemm_kernel.
@@ -1272,6 +1357,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams P) 
         Vec8<float>::load(P.ws + ((int64_t)sp * P.M + m) * P.N + n, t);
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] += t[k];
+    }
+    if (P.f32io) {                                        // fp32-storage mode: fp32 bias / temb / residual(s) / out
+        const float* bias = reinterpret_cast<const float*>(P.bias);
+        const float* temb = reinterpret_cast<const float*>(P.temb);
+        const float* res = reinterpret_cast<const float*>(P.res);
+        const float* res2 = reinterpret_cast<const float*>(P.res2);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[k] = (v[k] + (bias ? bias[n + k] : 0.f)) * P.alpha;
+            if (temb) v[k] += temb[((m / P.hw) / P.temb_div) * P.temb_ld + n + k];
+            if (res) v[k] += res[m * P.ldres + n + k];
+            if (res2) v[k] += res2[m * P.ldres + n + k];
+        }
+        Vec8<float>::store(reinterpret_cast<float*>(P.out) + m * P.ldo + n, v);
+        return;
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = (v[k] + (P.bias ? bf2f(P.bias[n + k]) : 0.f)) * P.alpha;
@@ -1632,7 +1732,7 @@ inline int gemm_k320_cfg() {          // FMC_K320_CFG = 22 (default) | 11 | 21 |
 }
 bool gemm_k320_ok(const GemmParams& P) {
     const int bn = (gemm_k320_cfg() % 10 == 1) ? 160 : 320;
-    return P.hw <= 1 && P.K == K320_K && P.N % bn == 0 && P.M % 64 == 0 && !P.a2 && !P.res2 && P.split_k == 1 && !P.sk && !P.temb &&
+    return !P.f32io && P.hw <= 1 && P.K == K320_K && P.N % bn == 0 && P.M % 64 == 0 && !P.a2 && !P.res2 && P.split_k == 1 && !P.sk && !P.temb &&
            ((P.M - 1) * P.lda + P.K) * 2 < ((int64_t)1 << 31) && (!P.res || ((P.M - 1) * P.ldres + P.N) * 2 < ((int64_t)1 << 31));
 }
 
@@ -1737,13 +1837,14 @@ int set_split_k(GemmParams& P, int split_k, void* workspace, int64_t workspace_b
 
 }  // namespace
 
-extern "C" int fmc_linear_bf16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,
-                               int N, int K, int64_t ldx, int64_t ldres, int64_t ldo, float alpha, int epilogue, int tile,
-                               int split_k, void* workspace, int64_t workspace_bytes, const void* x2, int64_t ldx2,
-                               int k_split, const void* residual2, void* stream) {
+static int linear_impl(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,
+                       int N, int K, int64_t ldx, int64_t ldres, int64_t ldo, float alpha, int epilogue, int tile,
+                       int split_k, void* workspace, int64_t workspace_bytes, const void* x2, int64_t ldx2,
+                       int k_split, const void* residual2, void* stream, int f32io) {
     if (!x || !w || !out) FMC_FAIL(FMC_E_NULL, "linear_bf16: NULL tensor");
-    if (M <= 0 || N <= 0 || K <= 0 || K % BK_MAX || N % 8 || ldx % 8 || ldo % 8 || (residual && ldres % 8))
+    if (M <= 0 || N <= 0 || K <= 0 || K % BK_MAX || N % 8 || ldx % 8 || ldo % (f32io ? 4 : 8) || (residual && ldres % (f32io ? 4 : 8)))
         FMC_FAIL(FMC_E_SHAPE, "linear_bf16: need K%%64==0, N%%8==0 and strides %%8==0 (M=%lld N=%d K=%d)", (long long)M, N, K);
+    if (f32io && (x2 || split_k < 0)) FMC_FAIL(FMC_E_SHAPE, "linear_x3_f32: no two-source operand (split it into one buffer) and no stream-K");
     if (epilogue != 0 && epilogue != 1) FMC_FAIL(FMC_E_SHAPE, "linear_bf16: epilogue %d", epilogue);
     if (epilogue == 1 && (N % 64 || residual)) FMC_FAIL(FMC_E_SHAPE, "linear_bf16: GEGLU needs N%%64==0 and no residual");
     if (!fmc_aligned16(x) || !fmc_aligned16(w) || !fmc_aligned16(out) || (residual && !fmc_aligned16(residual)) ||
@@ -1756,6 +1857,7 @@ extern "C" int fmc_linear_bf16(const void* x, const void* w, const void* bias, c
     P.res = (const bf16_t*)residual; P.res2 = (const bf16_t*)residual2; P.out = (bf16_t*)out;
     P.M = M; P.N = N; P.K = K; P.lda = ldx; P.ldres = ldres; P.ldo = ldo;
     P.img_h = P.img_w = P.cin = 0; P.hw = 1; P.alpha = alpha; P.temb_ld = 0; P.temb_div = 1; P.ups = 0;
+    P.f32io = f32io;
     if (x2 && (k_split <= 0 || k_split >= K || k_split % BK_MAX || ldx2 % 8 || !fmc_aligned16(x2)))
         FMC_FAIL(FMC_E_SHAPE, "linear_bf16: two-source input needs 0 < k_split < K, k_split %% 64 == 0 (k_split=%d K=%d)", k_split, K);
     P.a2 = (const bf16_t*)x2; P.lda2 = ldx2; P.ksplit = x2 ? k_split : 0;
@@ -1767,10 +1869,26 @@ extern "C" int fmc_linear_bf16(const void* x, const void* w, const void* bias, c
     return 0;
 }
 
-extern "C" int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, const void* temb, const void* residual,
-                                void* out, int n_img, int H, int W, int Cin, int Cout, int64_t temb_row_stride,
-                                int temb_img_div, int upsample2x, int tile, int split_k,
-                                void* workspace, int64_t workspace_bytes, void* stream) {
+extern "C" int fmc_linear_bf16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,
+                               int N, int K, int64_t ldx, int64_t ldres, int64_t ldo, float alpha, int epilogue, int tile,
+                               int split_k, void* workspace, int64_t workspace_bytes, const void* x2, int64_t ldx2,
+                               int k_split, const void* residual2, void* stream) {
+    return linear_impl(x, w, bias, residual, out, M, N, K, ldx, ldres, ldo, alpha, epilogue, tile, split_k, workspace,
+                       workspace_bytes, x2, ldx2, k_split, residual2, stream, 0);
+}
+
+extern "C" int fmc_linear_x3_f32(const void* x3, const void* w3, const float* bias, const float* residual, float* out, int64_t M,
+                                 int N, int K3, int64_t ldx, int64_t ldres, int64_t ldo, float alpha, int epilogue, int tile,
+                                 int split_k, void* workspace, int64_t workspace_bytes, const float* residual2, void* stream) {
+    if (K3 % 3 || (K3 / 3) % 8) FMC_FAIL(FMC_E_SHAPE, "linear_x3_f32: K3 = 3 K of the split operands (K3=%d)", K3);
+    return linear_impl(x3, w3, bias, residual, out, M, N, K3, ldx, ldres, ldo, alpha, epilogue, tile, split_k, workspace,
+                       workspace_bytes, nullptr, 0, 0, residual2, stream, 1);
+}
+
+static int conv3x3_impl(const void* x, const void* w, const void* bias, const void* temb, const void* residual,
+                        void* out, int n_img, int H, int W, int Cin, int Cout, int64_t temb_row_stride,
+                        int temb_img_div, int upsample2x, int tile, int split_k,
+                        void* workspace, int64_t workspace_bytes, void* stream, int f32io) {
     if (!x || !w || !out) FMC_FAIL(FMC_E_NULL, "conv3x3_bf16: NULL tensor");
     if (n_img <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % BK_MAX || Cout % 8)
         FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: need Cin%%64==0 and Cout%%8==0 (Cin=%d Cout=%d)", Cin, Cout);
@@ -1783,7 +1901,9 @@ extern "C" int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, 
     P.M = (int64_t)n_img * H * W; P.N = Cout; P.K = 9 * Cin; P.lda = Cin; P.ldres = Cout; P.ldo = Cout;
     P.a2 = nullptr; P.lda2 = 0; P.ksplit = 0;
     P.img_h = H; P.img_w = W; P.cin = Cin; P.hw = H * W; P.alpha = 1.f;
-    if (temb && (temb_img_div < 1 || temb_row_stride % 8)) FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: temb_img_div >= 1, temb_row_stride %% 8 == 0");
+    if (temb && (temb_img_div < 1 || temb_row_stride % (f32io ? 4 : 8))) FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: temb_img_div >= 1, temb_row_stride %% 8 == 0");
+    P.f32io = f32io;
+    if (f32io && split_k < 0) FMC_FAIL(FMC_E_SHAPE, "conv3x3_x3_f32: no stream-K in fp32-storage mode");
     P.temb_ld = temb_row_stride; P.temb_div = temb_img_div < 1 ? 1 : temb_img_div;
     if (upsample2x < 0 || upsample2x > 2) FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: resample mode %d", upsample2x);
     if (upsample2x == 1 && ((H | W) & 1)) FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: upsample2x needs even H, W (the OUTPUT size)");
@@ -1792,6 +1912,61 @@ extern "C" int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, 
     if (int rc = set_split_k(P, split_k, workspace, workspace_bytes, true, "conv3x3_bf16")) return rc;
     launch_gemm<1, 0>(P, tile, (hipStream_t)stream);
     FMC_CHECK_LAUNCH("fmc_conv3x3_bf16");
+    return 0;
+}
+
+extern "C" int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, const void* temb, const void* residual,
+                                void* out, int n_img, int H, int W, int Cin, int Cout, int64_t temb_row_stride,
+                                int temb_img_div, int upsample2x, int tile, int split_k,
+                                void* workspace, int64_t workspace_bytes, void* stream) {
+    return conv3x3_impl(x, w, bias, temb, residual, out, n_img, H, W, Cin, Cout, temb_row_stride, temb_img_div, upsample2x, tile,
+                        split_k, workspace, workspace_bytes, stream, 0);
+}
+
+extern "C" int fmc_conv3x3_x3_f32(const void* x3, const void* w3, const float* bias, const float* temb, const float* residual,
+                                  float* out, int n_img, int H, int W, int Cin3, int Cout, int64_t temb_row_stride,
+                                  int temb_img_div, int upsample2x, int tile, int split_k,
+                                  void* workspace, int64_t workspace_bytes, void* stream) {
+    if (Cin3 % 3) FMC_FAIL(FMC_E_SHAPE, "conv3x3_x3_f32: Cin3 = 3 Cin of the split operands (Cin3=%d)", Cin3);
+    return conv3x3_impl(x3, w3, bias, temb, residual, out, n_img, H, W, Cin3, Cout, temb_row_stride, temb_img_div, upsample2x, tile,
+                        split_k, workspace, workspace_bytes, stream, 1);
+}
+
+// ---- fp32 -> split-bf16 x3 operand (see fmc_hip.h) ---------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t rows, int C,
+                                                           int64_t ld_src, int64_t ld_dst, int col0, int K, int role) {
+    const int cpr = C / 8;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * cpr) return;
+    const int64_t r = idx / cpr;
+    const int c = (int)(idx - r * cpr) * 8;
+    float v[8];
+    Vec8<float>::load(src + r * ld_src + c, v);
+    bf16x8 hi, lo;
+    split_bf16x8(v, hi, lo);
+    union { bf16x8 v; u32x4 u; } h, l;
+    h.v = hi; l.v = lo;
+    bf16_t* d = dst + r * ld_dst + col0 + c;
+    // activation: [hi | hi | lo];  weight: [hi | lo | hi]  ->  sum over 3K = hi hi' + hi lo' + lo hi'
+    *reinterpret_cast<u32x4*>(d) = h.u;
+    *reinterpret_cast<u32x4*>(d + K) = role == 0 ? h.u : l.u;
+    *reinterpret_cast<u32x4*>(d + 2 * (int64_t)K) = role == 0 ? l.u : h.u;
+}
+}  // namespace
+
+extern "C" int fmc_split_bf16x3(const float* src, void* dst, int64_t rows, int C, int64_t ld_src, int64_t ld_dst, int col0, int K,
+                                int role, void* stream) {
+    if (!src || !dst) FMC_FAIL(FMC_E_NULL, "split_bf16x3: NULL tensor");
+    if (rows <= 0 || C <= 0 || C % 8 || K % 8 || col0 % 8 || col0 < 0 || col0 + C > K || ld_src % 4 || ld_dst % 8 || ld_dst < 3 * (int64_t)K ||
+        (role != 0 && role != 1))
+        FMC_FAIL(FMC_E_SHAPE, "split_bf16x3: rows=%lld C=%d K=%d col0=%d ld_src=%lld ld_dst=%lld role=%d", (long long)rows, C, K, col0,
+                 (long long)ld_src, (long long)ld_dst, role);
+    if (!fmc_aligned16(src) || !fmc_aligned16(dst)) FMC_FAIL(FMC_E_ALIGN, "split_bf16x3: tensors must be 16-byte aligned");
+    const int64_t chunks = rows * (C / 8);
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       (bf16_t*)dst, rows, C, ld_src, ld_dst, col0, K, role);
+    FMC_CHECK_LAUNCH("fmc_split_bf16x3");
     return 0;
 }
 

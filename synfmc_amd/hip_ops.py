@@ -818,6 +818,123 @@ def conv3x3_bf16(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias: Optional[t
 
 
 # --------------------------------------------------------------------------------------------
+# fp32-storage ("parity") mode of the two GEMMs: split-bf16 x3 operands on the same gfx950 kernels, fp32 epilogue
+# (include/fmc_hip.h: fmc_split_bf16x3 / fmc_linear_x3_f32 / fmc_conv3x3_x3_f32).  FMC_F32_GEMM=0 sends fp32 projections /
+# convolutions back to the vendor libraries (A/B: which part of a parity figure is the product path's own indexing).
+# --------------------------------------------------------------------------------------------
+F32_GEMM = os.environ.get("FMC_F32_GEMM", "1") != "0"
+f32_gemm_calls = {"linear": 0, "geglu": 0, "conv3x3": 0}      # launches through the split-bf16 x3 entry points (tests assert on these)
+
+
+def split_bf16x3(src: torch.Tensor, role: int, dst: Optional[torch.Tensor] = None, col0: int = 0, K: Optional[int] = None) -> torch.Tensor:
+    """fp32 `[..., C]` (dense last dim, uniformly strided rows) -> bf16 `[rows, 3 K]`: activation (role 0) `[hi | hi | lo]`, weight
+    (role 1) `[hi | lo | hi]`; `dst` / `col0` / `K` place a second source into the same buffer (two-source operands)."""
+    _dev(src)
+    assert src.dtype == torch.float32
+    C = src.shape[-1]
+    rows, ld = _rows2d(src)
+    K = C if K is None else K
+    if dst is None:
+        dst = torch.empty(rows, 3 * K, dtype=torch.bfloat16, device=src.device)
+    assert dst.shape == (rows, 3 * K) and dst.is_contiguous()
+    _lib.check(_lib.load().fmc_split_bf16x3(src.data_ptr(), dst.data_ptr(), rows, C, ld, 3 * K, col0, K, role, _stream()),
+               "fmc_split_bf16x3")
+    return dst
+
+
+def _split_weight_cached(weight: torch.Tensor, rows: int, C: int) -> torch.Tensor:
+    """`[hi | lo | hi]` form of a frozen fp32 weight viewed as `[rows, C]`, cached on the tensor per version (views miss: re-split)."""
+    hit = getattr(weight, "_fmc_w3", None)
+    if hit is None or hit[0] != (weight._version, weight.data_ptr()):
+        w2 = weight.detach()
+        w2 = w2.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(rows, C) if weight.ndim == 4 else w2.reshape(rows, C)
+        hit = ((weight._version, weight.data_ptr()), split_bf16x3(w2.contiguous(), 1))
+        try:
+            weight._fmc_w3 = hit
+        except Exception:
+            pass
+    return hit[1]
+
+
+def _f32_arm(key_bf16, tile: int) -> int:
+    """Parity mode runs the arm the bf16 product path chose for the same problem when that is a plain-grid arm (so the checked
+    code is the timed code); stream-K forms map to their plain geometry, the vendor arm / arm 15 to the kernel's own rule."""
+    if tile:
+        return tile
+    use = _choice.get(key_bf16, 0)
+    if use >= 256:
+        use -= 256
+    elif use >= 128:
+        use -= 128
+    return use if 1 <= use <= 14 else 0
+
+
+def linear_f32(x: torch.Tensor, weight: torch.Tensor, bias=None, residual=None, alpha: float = 1.0, geglu: bool = False,
+               tile: int = 0, split_k: int = 1, x2=None, residual2=None) -> torch.Tensor:
+    """`linear_bf16` for fp32 tensors: split-bf16 x3 operands, fp32 accumulate, fp32 epilogue (fmc_linear_x3_f32)."""
+    tile, split_k = _decode_arm(tile, split_k)
+    if split_k < 1:
+        split_k = 1
+    _dev(x, weight, bias, residual, x2)
+    N, Kd = weight.shape
+    M, _ = _rows2d(x)
+    if x2 is None:
+        x3 = split_bf16x3(x, 0)
+    else:
+        k1 = x.shape[-1]
+        assert k1 + x2.shape[-1] == Kd and _rows2d(x2)[0] == M
+        x3 = torch.empty(M, 3 * Kd, dtype=torch.bfloat16, device=x.device)
+        split_bf16x3(x, 0, x3, 0, Kd)
+        split_bf16x3(x2, 0, x3, k1, Kd)
+    w3 = _split_weight_cached(weight, N, Kd)
+    n_out = N // 2 if geglu else N
+    out = torch.empty(*x.shape[:-1], n_out, dtype=torch.float32, device=x.device)
+    ldres = 0
+    if residual is not None:
+        assert residual.shape == out.shape and residual.dtype == torch.float32
+        _, ldres = _rows2d(residual)
+    if residual2 is not None:
+        assert residual is not None and residual2.shape == out.shape and _rows2d(residual2)[1] == ldres
+    b = None if bias is None else bias.float()
+    ws, ws_bytes = _splitk_workspace(x.device, split_k, M, N)
+    f32_gemm_calls["geglu" if geglu else "linear"] += 1
+    _lib.check(_lib.load().fmc_linear_x3_f32(x3.data_ptr(), w3.data_ptr(), _p(b), _p(residual), out.data_ptr(), M, N, 3 * Kd,
+                                             3 * Kd, ldres, n_out, float(alpha), int(geglu), int(tile), int(split_k), ws, ws_bytes,
+                                             _p(residual2), _stream()), "fmc_linear_x3_f32")
+    return out
+
+
+def conv3x3_f32(x_nhwc: torch.Tensor, weight: torch.Tensor, bias=None, temb=None, residual_nhwc=None, tile: int = 0,
+                split_k: int = 1, temb_div: int = 1, upsample: bool = False, stride2: bool = False) -> torch.Tensor:
+    """`conv3x3_bf16` for fp32 tensors (x `[N, H, W, Cin]` contiguous, weight logical `[Cout, Cin, 3, 3]`)."""
+    tile, split_k = _decode_arm(tile, split_k)
+    if split_k < 1:
+        split_k = 1
+    _dev(x_nhwc, weight, bias, temb, residual_nhwc)
+    n, h, w, cin = x_nhwc.shape
+    if upsample:
+        h, w = 2 * h, 2 * w
+    if stride2:
+        assert not upsample and h % 2 == 0 and w % 2 == 0
+        h, w = h // 2, w // 2
+    cout = weight.shape[0]
+    assert x_nhwc.is_contiguous() and x_nhwc.dtype == torch.float32
+    assert temb is None or (temb.stride(1) == 1 and temb.shape == (n // temb_div, cout) and temb.dtype == torch.float32)
+    assert residual_nhwc is None or (residual_nhwc.is_contiguous() and residual_nhwc.shape == (n, h, w, cout))
+    x3 = split_bf16x3(x_nhwc.view(-1, cin), 0)
+    w3 = _split_weight_cached(weight, cout * 9, cin)
+    out = torch.empty(n, h, w, cout, dtype=torch.float32, device=x_nhwc.device)
+    b = None if bias is None else bias.float()
+    ws, ws_bytes = _splitk_workspace(x_nhwc.device, split_k, n * h * w, cout)
+    f32_gemm_calls["conv3x3"] += 1
+    _lib.check(_lib.load().fmc_conv3x3_x3_f32(x3.data_ptr(), w3.data_ptr(), _p(b), _p(temb), _p(residual_nhwc), out.data_ptr(),
+                                              n, h, w, 3 * cin, cout, 0 if temb is None else temb.stride(0), int(temb_div),
+                                              2 if stride2 else int(upsample), int(tile), int(split_k), ws, ws_bytes, _stream()),
+               "fmc_conv3x3_x3_f32")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
 # projection / convolution front-ends: pick, per problem shape, between the fused gfx950 kernel and the vendor
 # library call (+ separate epilogue passes).  The choice is measured once per shape on the first eager call (the
 # pipelines run eager warm-up steps before capturing a HIP graph) and cached; while a graph is being captured an
@@ -993,6 +1110,12 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         return y if alpha == 1.0 else y * alpha
 
     N, Kd = weight.shape
+    if (F32_GEMM and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and Kd % 64 == 0 and N % 8 == 0
+            and x.shape[-1] % 8 == 0 and (x.is_contiguous() or x.ndim == 2) and (x2 is None or x2.is_contiguous())
+            and (residual is None or residual.dtype == torch.float32)):
+        M = x.numel() // x.shape[-1]
+        key = ("lin", M, N, Kd, bias is not None, (residual is not None) + (residual2 is not None), 0 if x2 is None else x.shape[-1])
+        return linear_f32(x, weight, bias, residual, alpha, tile=_f32_arm(key, 0), x2=x2, residual2=residual2)
     ok = x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and Kd % 64 == 0 and N % 8 == 0
     if x2 is None:
         ok = ok and linear_supported(x, weight)
@@ -1014,6 +1137,10 @@ def geglu_linear(x: torch.Tensor, weight: torch.Tensor, bias, weight_il: torch.T
     `bias_il` are the tile-interleaved copies the fused kernel wants (`models.layers.interleave_geglu`)."""
     import torch.nn.functional as F
     lib = lambda: geglu(F.linear(x, weight, bias))
+    if (F32_GEMM and x.is_cuda and x.dtype == torch.float32 and weight_il.dtype == torch.float32 and weight_il.shape[0] % 64 == 0
+            and weight_il.shape[1] % 64 == 0 and x.is_contiguous()):
+        N, Kd = weight.shape
+        return linear_f32(x, weight_il, bias_il, geglu=True, tile=_f32_arm(("geglu", x.numel() // Kd, N, Kd), 0))
     if not linear_supported(x, weight_il) or weight_il.shape[0] % 64 or (x.ndim > 2 and not x.is_contiguous()):
         return lib()
     N, Kd = weight.shape
@@ -1038,6 +1165,19 @@ def conv3x3(x_nchw: torch.Tensor, weight_cl: torch.Tensor, bias, temb=None, resi
             y = y + residual_nchw
         return y
 
+    if (F32_GEMM and x_nchw.is_cuda and x_nchw.dtype == torch.float32 and weight_cl.dtype == torch.float32
+            and tuple(weight_cl.shape[2:]) == (3, 3) and tuple(padding) == (1, 1) and weight_cl.shape[1] % 64 == 0
+            and weight_cl.shape[0] % 8 == 0 and (tuple(stride) == (1, 1) or (tuple(stride) == (2, 2) and not upsample
+                                                                           and x_nchw.shape[-1] % 2 == 0 and x_nchw.shape[-2] % 2 == 0))):
+        n, cin, h, w = x_nchw.shape
+        x = x_nchw.permute(0, 2, 3, 1)
+        r = None if residual_nchw is None else residual_nchw.permute(0, 2, 3, 1)
+        if x.is_contiguous() and (r is None or r.is_contiguous()) and (temb is None or temb.stride(1) == 1):
+            s2 = tuple(stride) == (2, 2)
+            ho, wo = (2 * h, 2 * w) if upsample else ((h // 2, w // 2) if s2 else (h, w))
+            key = ("conv", n, ho, wo, cin, weight_cl.shape[0], temb is not None, r is not None, upsample, s2)
+            return conv3x3_f32(x, weight_cl, bias, temb, r, tile=_f32_arm(key, 0), temb_div=temb_div, upsample=upsample,
+                               stride2=s2).permute(0, 3, 1, 2)
     if not conv3x3_supported(x_nchw, weight_cl, stride, padding):
         return lib()
     n, cin, h, w = x_nchw.shape

@@ -146,6 +146,10 @@ def linear_op(x, weight, bias=None, residual=None, alpha: float = 1.0, x2=None):
             x, x2 = torch.cat([x, x2], dim=-1), None
         if not weight.requires_grad and (bias is None or not bias.requires_grad):   # frozen layer, activation gradient only
             return K.linear_frozen(x, weight, bias, residual, alpha)
+    elif (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and K.F32_GEMM and not
+          (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (residual is not None and residual.requires_grad)
+                                        or (x2 is not None and x2.requires_grad)))):
+        return K.linear(x, weight, bias, residual, alpha, x2)      # fp32 storage (parity mode): split-bf16 x3 on the same kernels
     if x2 is not None:
         x = torch.cat([x, x2], dim=-1)
     y = F.linear(x, weight, bias)
@@ -399,7 +403,8 @@ class GEGLU(nn.Module):
 
     def forward(self, hidden_states, scale: float = 1.0):
         w = self.proj.weight
-        if hidden_states.is_cuda and hidden_states.dtype == torch.bfloat16 and w.shape[0] % 256 == 0 \
+        if hidden_states.is_cuda and (hidden_states.dtype == torch.bfloat16 or (hidden_states.dtype == torch.float32 and K.F32_GEMM)) \
+                and hidden_states.dtype == w.dtype and w.shape[0] % 256 == 0 \
                 and not (torch.is_grad_enabled() and (w.requires_grad or hidden_states.requires_grad)):
             key = (w.data_ptr(), w._version)
             hit = self.__dict__.get("_il")

@@ -73,7 +73,14 @@ def _product_forward(full, dtype):
 
 def test_full_width_fp32_parity(full):
     """fp32 storage (parity mode) at the benchmarked widths: 1e-3 rel-inf against the oracle and the reference golden."""
+    from synfmc_amd import hip_ops as K
+    before = dict(K.f32_gemm_calls)
     out, out2, out0 = _product_forward(full, torch.float32)
+    ran = {k: K.f32_gemm_calls[k] - before[k] for k in before}
+    print(f"full-width fp32: launches on the hand-written GEMM / conv kernels (split-bf16 x3): {ran}")
+    # every projection / GEGLU / 3x3 conv of the three forwards ran on fmc_linear_x3_f32 / fmc_conv3x3_x3_f32 -- the product's own tile
+    # maps, loaders and epilogue indexing -- not on hipBLASLt / MIOpen (3 forwards x (22 ResNet blocks x 2 convs + up / down samplers))
+    assert ran["conv3x3"] >= 3 * 44 and ran["geglu"] >= 3 * 36 and ran["linear"] >= 3 * 250, ran
     g = full["golden"]
     e_oracle, e_gold = rel_inf(out, full["ref"]), rel_inf(out, torch.from_numpy(g["out"]))
     print(f"full-width fp32: vs oracle {e_oracle:.3e}, vs reference golden {e_gold:.3e}, "
@@ -95,6 +102,10 @@ def test_full_width_bf16_parity_and_format_share(full):
     print(f"full-width bf16: vs fp32 oracle {e_oracle:.3e}, vs reference golden {e_gold:.3e}, vs bf16-rounded oracle "
           f"{e_vs16:.3e}; bf16 format alone (rounded oracle vs fp32 oracle) {format_err:.3e}")
     assert 2e-3 < format_err < 4e-2
+    # two evaluations that round to bf16 at DIFFERENT points (the rounded oracle after every layer, the kernels once per fused
+    # group) are two samples of the same format noise: they sit ~sqrt(2) x format_err apart (measured 1.5x).  What isolates the
+    # kernels' own error is test_full_width_fp32_parity, which runs the same GEMM / conv / attention kernels on split-bf16 x3 operands.
+    assert e_vs16 < 2.0 * format_err
     assert e_oracle < 4e-2 and e_gold < 4e-2
     assert e_oracle < 2.5 * format_err
     assert rel_inf(out2, full["ref"]) < 4e-2

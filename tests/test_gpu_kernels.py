@@ -35,6 +35,27 @@ def rel_inf(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
+def assert_bf16_close(got, ref, mag, what=""):
+    """Element-wise bound for a kernel that rounds ONCE to bf16 from an fp32 accumulator: |got - ref| <= 2^-8 |ref| + 1e-5 mag,
+    `ref` the exact result on the same (rounded) inputs, `mag` the sum of |terms| behind every element (fp32 accumulation error of
+    kernel and reference).  A mis-indexed tile / row / column fails this where a max-norm `rel_inf` can hide it."""
+    got, ref, mag = got.detach().double().cpu(), ref.detach().double().cpu(), mag.detach().double().cpu()
+    err = (got - ref).abs()
+    bound = 2.0 ** -8 * ref.abs() + 1e-5 * mag
+    bad = err > bound
+    assert not bool(bad.any()), (f"{what}: {int(bad.sum())} / {bad.numel()} elements beyond the bf16 bound, worst "
+                                 f"err {float((err - bound).max()):.3e} at {tuple(int(i) for i in (err - bound).flatten().argmax().unsqueeze(0))}")
+
+
+def assert_f32_close(got, ref, mag, what=""):
+    """fp32-storage (split-bf16 x3) kernels: every product carries <= ~3 * 2^-18 relative error (dropped lo*lo + the two split
+    remainders), so |got - ref| <= 2e-5 * sum |terms| element by element."""
+    got, ref, mag = got.detach().double().cpu(), ref.detach().double().cpu(), mag.detach().double().cpu()
+    err = (got - ref).abs()
+    bad = err > 2e-5 * mag
+    assert not bool(bad.any()), f"{what}: {int(bad.sum())} / {bad.numel()} elements beyond 2e-5 * |terms|, worst {float((err / mag.clamp_min(1e-30)).max()):.3e}"
+
+
 def rnd(shape, seed, dtype, scale=1.0, shift=0.0):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(*shape, generator=g) * scale + shift
@@ -515,9 +536,11 @@ def test_linear_bf16_fused_epilogue(K, M, N, Kd, bias, res, alpha):
     wo, wd = rnd((N, Kd), 61, dtype, scale=Kd ** -0.5)
     bo, bd = rnd((N,), 62, dtype)
     ro, rd = rnd((M, N), 63, dtype)
-    ref = F.linear(xo, wo, bo if bias else None) * alpha + (ro if res else 0)
+    ref = F.linear(xo.double(), wo.double(), bo.double() if bias else None) * alpha + (ro.double() if res else 0)
+    mag = (xo.abs().double() @ wo.abs().double().t() + (bo.abs().double() if bias else 0)) * abs(alpha) + (ro.abs().double() if res else 0)
     out = K.linear_bf16(xd, wd, bd if bias else None, rd if res else None, alpha)
     assert rel_inf(out.float(), ref) < 1e-2
+    assert_bf16_close(out, ref, mag, "linear_bf16")
     # strided input rows (a slice of a wider matrix)
     wide = torch.cat([xd, xd], dim=1)
     out2 = K.linear_bf16(wide[:, Kd:], wd, bd if bias else None, rd if res else None, alpha)
@@ -532,16 +555,16 @@ def test_gemm_tile_geometries_agree(K, tile):
     wo, wd = rnd((328, 320), 68, dtype, scale=320 ** -0.5)
     bo, bd = rnd((328,), 69, dtype)
     ro, rd = rnd((777, 328), 59, dtype)
-    ref = F.linear(xo, wo, bo) + ro
+    ref = F.linear(xo.double(), wo.double(), bo.double()) + ro.double()
     out = K.linear_bf16(xd, wd, bd, rd, 1.0, tile=tile)
-    assert rel_inf(out.float(), ref) < 1e-2
+    assert_bf16_close(out, ref, xo.abs().double() @ wo.abs().double().t() + bo.abs() + ro.abs(), f"linear tile {tile}")
     assert torch.equal(out, K.linear_bf16(xd, wd, bd, rd, 1.0, tile=1))         # same accumulation order in every arm
     co, cd = rnd((2, 128, 11, 13), 58, dtype)
     fo, fd = rnd((72, 128, 3, 3), 57, dtype, scale=(9 * 128) ** -0.5)
-    refc = F.conv2d(co, fo, None, 1, 1)
+    refc = F.conv2d(co.double(), fo.double(), None, 1, 1)
     outc = K.conv3x3_bf16(cd.permute(0, 2, 3, 1).contiguous(), fd.contiguous(memory_format=torch.channels_last), None,
                           None, None, tile=tile)
-    assert rel_inf(outc.permute(0, 3, 1, 2).float(), refc) < 1e-2
+    assert_bf16_close(outc.permute(0, 3, 1, 2), refc, F.conv2d(co.abs().double(), fo.abs().double(), None, 1, 1), f"conv tile {tile}")
     from synfmc_amd.models.layers import interleave_geglu
     go, gd = rnd((512, 320), 56, dtype, scale=320 ** -0.5)
     wi, bi = interleave_geglu(gd, None)
@@ -717,6 +740,9 @@ def test_gemm_8phase_arms(K, tile):
             r2o, r2d = rnd((M, N), 400 + it, dtype)
             got = K.linear_bf16(xd, wd, bd, rd, 0.5, tile=tile)
             assert rel_inf(got.float(), 0.5 * F.linear(xo, wo, bo) + ro) < 1e-2, (M, N, Kd, it)
+            if it == 0 and M * N <= 6_000_000:
+                assert_bf16_close(got, 0.5 * F.linear(xo.double(), wo.double(), bo.double()) + ro.double(),
+                                  0.5 * (xo.abs().double() @ wo.abs().double().t() + bo.abs()) + ro.abs(), f"8-phase arm {tile} {(M, N, Kd)}")
             if it == 0:
                 assert torch.equal(got, K.linear_bf16(xd, wd, bd, rd, 0.5, tile=tile))                      # deterministic
                 if tile < 128:                                                                              # == the plain kernel
@@ -1018,3 +1044,84 @@ def test_gaussian_circle_masks_match_oracle(K):
     ref = np.stack([OC.gaussian_circle_mask(H, W, c[:2], c[2]) for c in circ]).reshape(4, 6, H, W)
     assert np.abs(out.cpu().numpy() - ref).max() < 2e-6
     assert ((out.cpu().numpy() > 0) == (ref > 0)).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# fp32-storage ("parity") mode of the GEMM / conv kernels: split-bf16 x3 operands on the SAME tile maps, loaders and fragment
+# layouts (fmc_split_bf16x3, fmc_linear_x3_f32, fmc_conv3x3_x3_f32), checked element by element against an fp64 reference
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 11, 13, 1 + 16, 2 + 32])
+def test_linear_f32_split3(K, tile):
+    g = torch.Generator().manual_seed(900)
+    for (M, N, Kd) in [(777, 328, 320), (4100, 1032, 1280), (130, 64, 64)]:
+        x, w = torch.randn(M, Kd, generator=g), torch.randn(N, Kd, generator=g) * Kd ** -0.5
+        b, r, r2 = torch.randn(N, generator=g), torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
+        mag = x.abs().double() @ w.abs().double().t()
+        ref = F.linear(x.double(), w.double())
+        xd, wd, bd, rd, r2d = x.cuda(), w.cuda(), b.cuda(), r.cuda(), r2.cuda()
+        got = K.linear_f32(xd, wd, None, None, 1.0, tile=tile)
+        assert got.dtype == torch.float32
+        assert_f32_close(got, ref, mag, f"plain {tile} {(M, N, Kd)}")
+        got = K.linear_f32(xd, wd, bd, rd, 0.5, tile=tile)
+        assert_f32_close(got, 0.5 * (ref + b.double()) + r.double(), 0.5 * (mag + b.abs()) + r.abs(), f"bias+res {tile}")
+        got = K.linear_f32(xd, wd, None, rd, 0.7, tile=tile, residual2=r2d)
+        assert_f32_close(got, 0.7 * ref + r.double() + r2.double(), 0.7 * mag + r.abs() + r2.abs(), f"two residuals {tile}")
+        # strided rows (a column slice of a wider matrix)
+        wide = torch.cat([xd, xd], dim=1)
+        assert torch.equal(K.linear_f32(wide[:, Kd:], wd, None, None, 1.0, tile=tile), K.linear_f32(xd, wd, None, None, 1.0, tile=tile))
+    # two-source operand
+    x1, x2 = torch.randn(900, 640, generator=g), torch.randn(900, 320, generator=g)
+    w = torch.randn(640, 960, generator=g) * 960 ** -0.5
+    xc = torch.cat([x1, x2], -1)
+    got = K.linear_f32(x1.cuda(), w.cuda(), None, None, 1.0, tile=tile, x2=x2.cuda())
+    assert_f32_close(got, F.linear(xc.double(), w.double()), xc.abs().double() @ w.abs().double().t(), f"two-source {tile}")
+    if tile < 16:                                             # GEGLU (no split-K)
+        from synfmc_amd.models.layers import interleave_geglu
+        x = torch.randn(1000, 320, generator=g)
+        w, b = torch.randn(512, 320, generator=g) * 320 ** -0.5, torch.randn(512, generator=g)
+        wi, bi = interleave_geglu(w.cuda(), b.cuda())
+        a, gt = F.linear(x.double(), w.double(), b.double()).chunk(2, dim=-1)
+        ma, mg = (x.abs().double() @ w.abs().double().t() + b.abs()).chunk(2, dim=-1)
+        got = K.linear_f32(x.cuda(), wi, bi, geglu=True, tile=tile)
+        # d(a gelu(g)) <= |gelu(g)| da + |a| |gelu'| dg, |gelu'| <= 1.13
+        bound_mag = F.gelu(gt).abs() * ma + 1.13 * a.abs() * mg + 1e-3
+        assert_f32_close(got, a * F.gelu(gt), bound_mag, f"geglu {tile}")
+
+
+@pytest.mark.parametrize("tile", [0, 1, 3, 5, 11, 13, 2 + 16])
+def test_conv3x3_f32_split3(K, tile):
+    g = torch.Generator().manual_seed(901)
+    x = torch.randn(4, 320, 18, 14, generator=g)
+    w = torch.randn(328, 320, 3, 3, generator=g) * (9 * 320) ** -0.5
+    b, t, r = torch.randn(328, generator=g), torch.randn(2, 328, generator=g), torch.randn(4, 328, 18, 14, generator=g)
+    xd = x.cuda().permute(0, 2, 3, 1).contiguous()
+    wd = w.cuda().contiguous(memory_format=torch.channels_last)
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    mag = F.conv2d(x.abs().double(), w.abs().double(), None, 1, 1)
+    got = K.conv3x3_f32(xd, wd, None, None, None, tile=tile)
+    assert_f32_close(got.permute(0, 3, 1, 2), ref, mag, f"conv {tile}")
+    got = K.conv3x3_f32(xd, wd, b.cuda(), t.cuda(), r.cuda().permute(0, 2, 3, 1).contiguous(), tile=tile, temb_div=2)
+    tt = t.repeat_interleave(2, dim=0)[:, :, None, None].double()
+    assert_f32_close(got.permute(0, 3, 1, 2), ref + b.double()[None, :, None, None] + tt + r.double(),
+                     mag + b.abs()[None, :, None, None] + tt.abs() + r.abs(), f"conv + bias + temb + residual {tile}")
+    got = K.conv3x3_f32(xd, wd, None, None, None, tile=tile, upsample=True)
+    xu = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    assert_f32_close(got.permute(0, 3, 1, 2), F.conv2d(xu.double(), w.double(), None, 1, 1),
+                     F.conv2d(xu.abs().double(), w.abs().double(), None, 1, 1), f"conv upsample {tile}")
+    got = K.conv3x3_f32(xd, wd, None, None, None, tile=tile, stride2=True)
+    assert_f32_close(got.permute(0, 3, 1, 2), F.conv2d(x.double(), w.double(), None, 2, 1),
+                     F.conv2d(x.abs().double(), w.abs().double(), None, 2, 1), f"conv stride 2 {tile}")
+
+
+def test_f32_front_ends_take_the_split3_path(K):
+    """`hip_ops.linear` / `conv3x3` / `geglu_linear` on fp32 tensors run the gfx950 kernels (not F.linear / F.conv2d): results
+    equal the explicit split-bf16 x3 calls bit for bit."""
+    g = torch.Generator().manual_seed(902)
+    x, w, b = torch.randn(2, 300, 320, generator=g).cuda(), (torch.randn(640, 320, generator=g) * 0.05).cuda(), torch.randn(640, generator=g).cuda()
+    r = torch.randn(2, 300, 640, generator=g).cuda()
+    assert torch.equal(K.linear(x, w, b, r, 0.5), K.linear_f32(x, w, b, r, 0.5))
+    xc = torch.randn(2, 64, 9, 7, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    wc = (torch.randn(72, 64, 3, 3, generator=g) * 0.05).cuda().contiguous(memory_format=torch.channels_last)
+    got = K.conv3x3(xc, wc, None)
+    assert torch.equal(got, K.conv3x3_f32(xc.permute(0, 2, 3, 1), wc).permute(0, 3, 1, 2))
+    assert rel_inf(got, F.conv2d(xc.cpu().double(), wc.cpu().double(), None, 1, 1)) < 1e-5
