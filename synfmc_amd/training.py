@@ -65,7 +65,14 @@ class GradAllReducer:
       optimizer stay fp32.
     * `overlap=False`: nothing is launched from inside `backward()`; `finish()` reduces the buckets afterwards.  This is
       the mode for a HIP-graph-captured forward/backward (graph | all-reduce | graph, see bench.py --mode train).
-    * a second `backward()` before `zero_grad()` raises instead of silently using un-reduced gradients."""
+    * a second `backward()` before `zero_grad()` raises instead of silently using un-reduced gradients.
+    * a pruned parameter that IS reached on a later step (DDP re-detects unused parameters every iteration) is noticed by
+      `finish()` -- its `.grad` is no longer None on some rank; one 1-element MAX all-reduce per step is the price -- its
+      gradient is averaged over the ranks in a one-off collective for that step, and `zero_grad()` re-admits it to the buckets
+      for good.  Ranks therefore never step on a rank-local gradient.  Build the optimizer over ALL trainable parameters (as the
+      reference does): it skips `grad is None`; a HIP-graph-captured step needs a static set and cannot re-admit -- there the
+      check fires at capture time.
+    * the discovery step must run EAGERLY: under capture / replay the hooks do not fire and everything would look unused."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 128 << 20, group=None,
                  overlap: bool = True, compress_dtype: Optional[torch.dtype] = None, find_unused: bool = True):
@@ -79,6 +86,8 @@ class GradAllReducer:
         self.unused: List[torch.nn.Parameter] = []
         self.buckets: List[dict] = []
         self._hooks = []
+        self._readmit: List[torch.nn.Parameter] = []     # pruned parameters that received a gradient after all (see finish)
+        self.readmitted = 0                             # how many were ever re-admitted (reported / tested)
         self._build(self._all)
 
     # ---- bucket construction ---------------------------------------------------------------------------
@@ -141,11 +150,17 @@ class GradAllReducer:
 
     def _prune_unused(self):
         """End of the discovery step: used = hook fired on any rank."""
+        if self._all[0].is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("GradAllReducer: the discovery step (first finish()) must run eagerly -- gradient hooks do not "
+                               "fire under HIP-graph capture, every parameter would be classified unused")
         self._discovering = False
         used = torch.tensor([1.0 if id(p) in self._fired else 0.0 for p in self._all], device=self._all[0].device)
         if self.world > 1:
             dist.all_reduce(used, op=dist.ReduceOp.MAX, group=self.group)
         used = used.bool().tolist()
+        if not any(used):
+            raise RuntimeError("GradAllReducer: no gradient hook fired on any rank in the discovery step (was backward() run, "
+                               "eagerly, before finish()?)")
         self.unused = [p for p, u in zip(self._all, used) if not u]
         if not self.unused:
             return
@@ -173,8 +188,50 @@ class GradAllReducer:
                     b["flat"].copy_(b["comp"])
                     b["comp"] = None
                 b["flat"].mul_(1.0 / self.world)
+        if self.unused:
+            self._reduce_late_gradients()
+
+    def _reduce_late_gradients(self) -> None:
+        """A pruned parameter has a gradient on some rank (autograd gave it a fresh rank-local `.grad`): average it over the ranks now,
+        re-admit it to the buckets at the next `zero_grad()`.  Same collectives in the same order on every rank."""
+        capturing = self._all[0].is_cuda and torch.cuda.is_current_stream_capturing()
+        late_here = any(p.grad is not None for p in self.unused)
+        if capturing:
+            if late_here:
+                raise RuntimeError("GradAllReducer: a parameter pruned as unused received a gradient inside a HIP-graph capture; a "
+                                   "captured step needs a static parameter set -- run this step eagerly so that it is re-admitted")
+            return                                               # (a captured step cannot negotiate: the check above is the guard)
+        dev = self._all[0].device
+        if self.world > 1:
+            flag = torch.tensor([1.0 if late_here else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            late_any = bool(flag.item() > 0)
+        else:
+            late_any = late_here
+        if not late_any:
+            return
+        bits = torch.tensor([1.0 if p.grad is not None else 0.0 for p in self.unused], device=dev)
+        if self.world > 1:
+            dist.all_reduce(bits, op=dist.ReduceOp.MAX, group=self.group)
+        bits = bits.bool().tolist()
+        readmit = [p for p, u in zip(self.unused, bits) if u]
+        for p in readmit:
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            if self.world > 1:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+                g.mul_(1.0 / self.world)
+            p.grad = g
+        self._readmit = readmit
+        self.readmitted += len(readmit)
 
     def zero_grad(self) -> None:
+        if self._readmit:                                        # rebuild the buckets with the re-admitted parameters (original order)
+            ids = {id(p) for p in self._readmit} | {id(p) for b in self.buckets for p in b["params"]}
+            self.unused = [p for p in self.unused if id(p) not in ids]
+            self._readmit = []
+            self._build([p for p in self._all if id(p) in ids])
+        for p in self.unused:
+            p.grad = None
         for b in self.buckets:
             b["flat"].zero_()
             b["pending"] = len(b["params"])

@@ -236,6 +236,82 @@ def test_two_rank_gloo_grad_allreduce(tmp_path, mode, port, tol):
     assert lines[2]["raised"] is True
 
 
+_GLOO_LATE = r'''
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from synfmc_amd.training import GradAllReducer, broadcast_parameters
+dist.init_process_group("gloo", init_method="env://")
+r, w = dist.get_rank(), dist.get_world_size()
+torch.manual_seed(7)
+net = torch.nn.Linear(8, 8)
+late = torch.nn.Linear(8, 8)                     # unused in the discovery step, reached on RANK 1 ONLY from step 2 on
+broadcast_parameters(net); broadcast_parameters(late)
+params = list(net.parameters()) + list(late.parameters())
+red = GradAllReducer(params, bucket_bytes=200, overlap=True)
+x = torch.randn(4, 8, generator=torch.Generator().manual_seed(10 + r))
+def loss_of(ps, ls, xx, rank, step):
+    y = xx @ ps[0].t() + ps[1]
+    if step >= 2 and rank == 1:
+        y = y @ ls[0].t() + ls[1]
+    return y.pow(2).mean()
+out = []
+for step in range(4):
+    loss_of(list(net.parameters()), list(late.parameters()), x, r, step).backward()
+    red.finish()
+    ref_n = [p.detach().clone().requires_grad_(True) for p in net.parameters()]
+    ref_l = [p.detach().clone().requires_grad_(True) for p in late.parameters()]
+    total = [torch.zeros_like(p) for p in ref_n + ref_l]
+    for rr in range(w):
+        xr = torch.randn(4, 8, generator=torch.Generator().manual_seed(10 + rr))
+        gs = torch.autograd.grad(loss_of(ref_n, ref_l, xr, rr, step), ref_n + ref_l, allow_unused=True)
+        total = [t + (g / w if g is not None else 0) for t, g in zip(total, gs)]
+    err = 0.0
+    for p, t in zip(list(net.parameters()) + list(late.parameters()), total):
+        if p.grad is None:
+            err = max(err, float(t.abs().max()))                 # a None gradient is only right where the mean gradient is zero
+        else:
+            err = max(err, float((p.grad - t).abs().max()))
+    out.append({"step": step, "err": err, "n_unused": len(red.unused), "readmitted": red.readmitted,
+                "late_grad_none": all(p.grad is None for p in late.parameters()),
+                "n_bucket_params": sum(len(b["params"]) for b in red.buckets)})
+    red.zero_grad()
+# every rank must have reached the same verdicts
+flat = torch.tensor([float(o["n_unused"]) for o in out] + [float(o["readmitted"]) for o in out])
+other = flat.clone(); dist.all_reduce(other, op=dist.ReduceOp.MAX)
+assert torch.equal(flat, other)
+if r == 0:
+    print(json.dumps(out))
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_late_gradient_is_readmitted(tmp_path):
+    """A parameter pruned as unused in the discovery step and reached LATER, on one rank only (ADVICE round 2): its gradient is averaged
+    over the ranks in that very step (no rank steps on a rank-local gradient) and it is back in the buckets from the next one."""
+    script = tmp_path / "late.py"
+    script.write_text(_GLOO_LATE)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29741", str(script), ROOT],
+                         capture_output=True, text=True, env=env, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    o = json.loads([l for l in out.stdout.splitlines() if l.startswith("[")][-1])
+    assert all(s["err"] < 1e-6 for s in o), o
+    assert o[0]["n_unused"] == 2 and o[1]["n_unused"] == 2 and o[0]["late_grad_none"] and o[1]["late_grad_none"]
+    assert o[2]["readmitted"] == 2 and not o[2]["late_grad_none"]               # averaged in the step it appeared ...
+    assert o[3]["n_unused"] == 0 and o[3]["n_bucket_params"] == 4                # ... and bucketed afterwards
+
+
+def test_discovery_step_must_see_a_gradient():
+    from synfmc_amd.training import GradAllReducer
+    lin = torch.nn.Linear(4, 4)
+    red = GradAllReducer(lin.parameters())
+    with pytest.raises(RuntimeError, match="no gradient hook fired"):
+        red.finish()
+
+
 def test_loss_and_timestep_sampling_match_oracle():
     from oracle import pipeline as OP
     from synfmc_amd.training import biased_timesteps, masked_mse_loss
