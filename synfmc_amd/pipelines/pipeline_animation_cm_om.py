@@ -55,7 +55,9 @@ class _GraphedUNet:
     def _call(self):
         kw = {}
         if self.pose is not None:
-            kw = dict(pose_embedding_features=self.pose, traj_features=self.traj)
+            kw = dict(pose_embedding_features=self.pose)
+            if self.traj is not None or getattr(self.unet, "_pass_traj_none", False):   # (the CMC-only model takes no traj_features)
+                kw["traj_features"] = self.traj
         return self.unet(self.x, self.t, encoder_hidden_states=self.text, **kw).sample
 
     def capture(self):
@@ -193,7 +195,11 @@ class AnimationPipeline:
         unet = self.unet
         if not use_graph:
             def eager(x, t):
-                kw = {} if pose_feats is None else dict(pose_embedding_features=pose_feats, traj_features=traj)
+                kw = {}
+                if pose_feats is not None:
+                    kw["pose_embedding_features"] = pose_feats
+                    if traj is not None or getattr(unet, "_pass_traj_none", False):    # (UNet3DConditionModelPoseCond takes no traj_features)
+                        kw["traj_features"] = traj
                 return unet(x, torch.tensor(int(t), device=x.device), encoder_hidden_states=text, **kw).sample
             return eager
         key = (tuple(x_shape), tuple(text.shape), unet.dtype, pose_feats is not None, traj is not None,
