@@ -161,11 +161,11 @@ def recorded_counters(kernel: str) -> dict:
     return out
 
 
-def measure_attention_roofline(device, dtype, iters=20):
+def measure_attention_roofline(device, dtype, iters=20, clips=2):
     """Level-0 spatial self-attention exactly as the U-Net launches it: q/k/v are slices of one fused [32, 2560, 960]
-    projection (CFG batch 2 x 16 frames, 8 heads x 40)."""
+    projection (CFG batch 2 x 16 frames, 8 heads x 40; `clips` = 1 for a training step)."""
     from synfmc_amd import hip_ops as K
-    B, S, H, D = 2 * FRAMES, (HEIGHT // 8) * (WIDTH // 8), 8, WIDTHS[0] // 8
+    B, S, H, D = clips * FRAMES, (HEIGHT // 8) * (WIDTH // 8), 8, WIDTHS[0] // 8
     C = H * D
     qkv = torch.randn(B, S, 3 * C, device=device, dtype=dtype)
     q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
@@ -180,12 +180,13 @@ def measure_attention_roofline(device, dtype, iters=20):
     ms = e0.elapsed_time(e1) / iters
     flops = 4.0 * B * H * S * S * D
     achieved = flops / (ms * 1e-3) / 1e12
-    out = {"bound": "mfma", "kernel": "sa40d_kernel (software-pipelined spatial self-attention, bf16, d=40) [B*H=256,S=2560]", "achieved": round(achieved, 2),
+    out = {"bound": "mfma", "kernel": f"sa40d_kernel (software-pipelined spatial self-attention, bf16, d=40) [B*H={B * H},S={S}]", "achieved": round(achieved, 2),
            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
            "avg_launch_ms": round(ms, 4), "flops_per_launch": flops, "traffic_algorithmic": 4.0 * B * S * H * D * 2}
     # HBM-side bytes per launch of this exact shape, matrix-pipe duty and shader clock: hardware counters, recorded by
     # tools/collect_roofline_counters.py (separate rocprofv3 --pmc passes) and only quoted for the kernel sources they were taken on
-    out.update(recorded_counters("sa40d"))
+    if (B, S) == (32, 2560):                          # (the counters were collected on the metric's launch shape)
+        out.update(recorded_counters("sa40d"))
     return out
 
 
@@ -267,6 +268,31 @@ def measure_temporal_roofline(device, dtype, iters=50):
            "avg_launch_ms": round(ms, 5), "bytes_per_launch": nbytes}
     out.update(recorded_counters("temporal"))
     return out
+
+
+def measure_temporal_fp8_roofline(device, iters=50):
+    """Level-0 temporal attention of a TRAINING step on the fp8 path (BASELINE configs[4]): e4m3 q | k | v of one clip
+    ([1, F, pixels, 3 x 320] bytes out of the QKV projection's epilogue) -> bf16 o.  HBM-bound: 3 + 2 bytes per (token, channel)."""
+    from synfmc_amd import hip_ops as K
+    P, H, D = (HEIGHT // 8) * (WIDTH // 8), 8, WIDTHS[0] // 8
+    C = H * D
+    qkv8 = (torch.randn(1, FRAMES, P, 3 * C, device=device) * 0.5).to(torch.float8_e4m3fn)
+    sc = torch.ones(3, dtype=torch.float32, device=device)
+    for _ in range(3):
+        K._temporal_fp8_raw(qkv8, sc, H, D ** -0.5)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        K._temporal_fp8_raw(qkv8, sc, H, D ** -0.5)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    nbytes = 5.0 * P * FRAMES * C
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": f"temporal_attn_fp8_kernel<d={D}> [1x{P} pixels x {H} heads, F={FRAMES}; e4m3 q|k|v, bf16 o]",
+            "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+            "avg_launch_ms": round(ms, 5), "bytes_per_launch": nbytes, "traffic": None,
+            "traffic_note": "PMC traffic of this launch: profiles/r02_temporal_pmc.md (136.5 MB at F=16, CFG batch 2); not re-collected for this shape"}
 
 
 def oracle_step(unet, enc, ada, clip, text2, latents, t, want_config1=True, config="obj"):
@@ -522,7 +548,10 @@ def train_main(args):
         torch.cuda.synchronize()
         draw()
         if mode == "one":
-            assert world == 1, "--train-graph one needs a single rank (the exchange cannot be captured)"
+            # one rank: the whole step is one graph.  Several ranks (opt-in, `--train-graph one`): the bucket all-reduces are CAPTURED
+            # with the step -- RCCL collectives are capturable stream operations, c10d registers the communicator with the capture --
+            # so the exchange replays from the graph behind the Adapter's backward without a host round trip.  The default on
+            # several ranks stays `split` until this form has run on an 8-GPU node (tests/test_gpu_multi.py tries both).
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 static_loss = fwd_bwd()
@@ -582,19 +611,34 @@ def train_main(args):
 
     elapsed = timed_region(run, args.steps, args.warmup, world, torch.cuda.synchronize)
     assert torch.isfinite(loss).all()
+    # every rank holds the same averaged gradients / parameters: the first trained tensor must agree bit for bit across ranks
+    params_equal = None
+    if world > 1:
+        probe = trainable[0].detach().float().reshape(-1)[:4096].clone()
+        lo, hi = probe.clone(), probe.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        params_equal = bool(torch.equal(lo, hi))
+        assert params_equal, "trained parameters differ across ranks after the all-reduced steps"
     if rank == 0:
+        with torch.no_grad():
+            roof = measure_attention_roofline(device, dtype, clips=1)
+            roof_t = measure_temporal_fp8_roofline(device) if args.fp8_temporal else None
         print(json.dumps({
             "metric": f"OMC-stage training steps/sec (secondary), {FRAMES}x{HEIGHT}x{WIDTH} bf16"
                       f"{' + fp8 temporal attention' if args.fp8_temporal else ''}, frozen U-Net + trainable Adapter",
             "value": round(world * args.steps / elapsed, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (e4m3 q|k|v in the temporal attention)" if args.fp8_temporal else "bf16",
+            "data": "synthetic",
             "config": {"workload": "stage-3 (configs/obj.yaml) training step, 1 clip per GPU, AdamW, clip-norm 1.0, "
                                    "bucketed RCCL all-reduce of the USED Adapter gradients (level 3 never receives one)",
                        "hip_graph": mode, "parallelism": f"dp{world}", "allreduce_bytes": reducer.allreduce_bytes(),
                        "fp8_temporal_attention": args.fp8_temporal, "grad_compress": args.grad_compress, "unused_params": sum(p.numel() for p in reducer.unused),
-                       "trained_params": sum(p.numel() for p in trainable)},
-            "last_loss": float(loss)}), flush=True)
+                       "trained_params": sum(p.numel() for p in trainable), "baseline_config": "train32" if args.config == "train32" else None,
+                       "parameters_bit_equal_across_ranks": params_equal},
+            "last_loss": float(loss), "roofline": roof, "roofline_temporal": roof_t, "cpu_baseline": None,
+            "cpu_baseline_note": "reported with the metric's configuration only (python bench.py)"}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -1314,6 +1314,426 @@ void gemm8_kernel(const GemmParams P) {
     }  // segment loop
 }
 
+// =====================================================================================================================
+// The 160 x 320 kernel (tile arm 16): the 8-phase schedule of gemm8_kernel on a tile that DIVIDES the FMC problem sizes.
+//
+// Why: every token / pixel count of the U-Net is a multiple of 160 rows x 256 CUs at the two levels that hold 2/3 of the GEMM time
+// (M = 81920 = 512 x 160 at 40x64, M = 20480 = 128 x 160 at 20x32), and every width there is a multiple of 320 (N = 320, 640, 960, 1920,
+// 2560, 5120).  256 x 256 tiles pay for that twice -- padded columns (N = 320 runs as 512: 37 % of the MFMAs multiply zeros; 640 as 768)
+// and tile quantisation (640 or 240 or 400 workgroups on 256 CUs: 78-94 % of a round is filled).  With 160 x 320 tiles the level-0
+// launches are exactly 2 / 6 / 16 rounds of 256 workgroups and the level-1 launches exactly 1 / 3 / 8: no padded column, no partial round.
+//
+// Geometry: 8 waves = 2 (m) x 4 (n), a wave computes 80 x 80 outputs as 5 x 5 v_mfma_f32_16x16x32_bf16 accumulators (100 registers; 80
+// is not a multiple of 32, hence the 16-wide MFMA; products are "swapped" as everywhere in this file: MFMA A operand = W rows, so a
+// lane holds 4 consecutive output columns of one row).  BK = 64, two k-tile buffers of 60 KiB (A 160 rows, W 320 rows, 128-byte rows
+// with the same XOR chunk swizzle: the 16-lane groups of a ds_read_b128 of a 16x16x32 fragment (rows l % 16, chunk 4 ks + l / 16) hit 16
+// distinct bank slots, checked against the lane-group table of MI355X_MICROARCH.md).
+//
+// Schedule (as gemm8_kernel: a phase = {LOAD: ds_reads + one DMA slot + counted vmcnt} | barrier | {MFMAs under s_setprio 1} | barrier,
+// the two wave rows one barrier apart so every SIMD has one wave on the matrix pipe and one loading):
+//   phase 0: W fragments of k-step 0 (5) + A fragments of m-blocks 0-1 (2) -> 10 MFMAs      phase 1: A m-blocks 2-4 (3) -> 15 MFMAs
+//   phase 2 / 3: the same for k-step 1.
+// DMA: a k-tile is 60 one-KiB pieces (8 rows x 128 B); they stream as 4 slots of 16 (2 per wave; 4 dummies keep every wave's vmcnt
+// arithmetic identical): q0 = W rows 0-127, q1 = W 128-255, q2 = W 256-319 + the A rows phase 0 reads (m-blocks 0-1 of both wave
+// rows), q3 = the other A rows.  Slot h = 4 kt + q is issued at LOAD(h - 5) and retired by the `vmcnt(4)` at the end of LOAD(h - 3):
+// q0-q2 of k-tile kt are published by the barrier before LOAD(0, kt), q3 by the one before LOAD(1, kt) -- data is read one phase after
+// the wait that retired it.  WAR: q0 of k-tile kt overwrites W rows of k-tile kt - 2 at LOAD(3, kt - 2); their last reader is the late
+// wave row's LOAD(2, kt - 2), retired by its lgkmcnt(0) one segment earlier (the same margin as gemm8_kernel's).
+// Epilogue: bias / alpha / temb in registers, residual(s) through the bf16 staging tile, whole-row 16-byte stores; GEGLU with the
+// weight rows ordered [160 value rows | 160 gate rows] per tile (layers.interleave_geglu(block=160)): the gate waves (n >= 160) leave
+// gelu(gate) in LDS as fp32, the value waves multiply -- one rounding, as the other arms.
+// =====================================================================================================================
+template <int MODE, int EPI>
+__global__ __launch_bounds__(512, 2)
+void gemm160_kernel(const GemmParams P) {
+    constexpr int BM = 160, BN = 320, BK = 64, NT = 512;
+    constexpr int STAGE_ELEMS = (BM + BN) * BK;      // 60 KiB per k-tile buffer
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int l15 = lane & 15, kq = lane >> 4;       // fragment row / k-group of 8 (output: column quad)
+    const int prow = lane >> 3, pch = lane & 7;      // my row / 16-byte chunk inside a 1-KiB DMA piece
+
+    const int nkt = P.K / BK;
+    int tile_m, tile_n;
+    {
+        const int total = P.tiles_m * P.tiles_n;
+        const int id = blockIdx.x, q = total >> 3, r = total & 7, x = id & 7;
+        const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);   // XCD x owns a contiguous range
+        lin_to_tile(lin, P, tile_m, tile_n);
+    }
+    const int64_t m0 = (int64_t)tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    // ---- my DMA pieces.  Slot q, entry i = 2 wave + j (j = 0, 1):  q0: W piece i;  q1: W piece 16 + i;  q2: i < 8: W piece 32 + i,
+    // else A early piece;  q3: i < 12: A late piece, else a dummy.  A early pieces (rows of m-blocks 0-1 of both wave rows): {0..3, 10..13};
+    // late: {4..9, 14..19}.  Per wave: W entries we = 0..5 (q0 j0, q0 j1, q1 j0, q1 j1, q2 j0, q2 j1), A entries ae = 0..3 (q2 j0/j1, q3 j0/j1).
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)P.a, 0, (int)P.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)P.w, 0, (int)((int64_t)P.N * P.K * 2), 0x00020000);
+    unsigned w_vo[6];
+    int w_lds[6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+        const int piece = (e >> 1) * 16 + 2 * wave + (e & 1);          // q2 entries only exist for waves 0-3 (piece 32..39)
+        const bool exists = piece < 40;
+        const int roww = piece * 8;
+        w_lds[e] = (BM + roww) * BK;
+        const int lw = roww + prow;
+        const int n = n0 + lw;
+        w_vo[e] = (exists && n < P.N) ? (unsigned)(((int64_t)n * P.K + swz<BK>(lw, pch) * 8) * 2) : OOB;
+        if (!exists) w_lds[e] = 2 * STAGE_ELEMS;                       // (never issued: see issue())
+    }
+    unsigned a_vo[4], a_ok[4];
+    int a_lds[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        int piece = -1;
+        if (e < 2) {                                                   // q2, entries i = 8..15 -> waves 4..7
+            const int i = 2 * wave + e - 8;
+            if (i >= 0) piece = i < 4 ? i : 6 + i;                     // {0,1,2,3, 10,11,12,13}
+        } else {                                                       // q3, entries i = 0..11 -> waves 0..5
+            const int i = 2 * wave + (e - 2);
+            if (i < 12) piece = i < 6 ? 4 + i : 8 + i;                 // {4..9, 14..19}
+        }
+        a_vo[e] = OOB; a_ok[e] = 0; a_lds[e] = 2 * STAGE_ELEMS;        // dummy: zeros into the scratch KiB behind the buffers
+        if (piece >= 0) {
+            const int rowa = piece * 8;
+            a_lds[e] = rowa * BK;
+            const int lr = rowa + prow;
+            const int sc = swz<BK>(lr, pch);
+            const int64_t m = m0 + lr;
+            const bool ok = m < P.M;
+            if (MODE == 0) {
+                a_vo[e] = ok ? (unsigned)((m * P.lda + sc * 8) * 2) : OOB;
+            } else {
+                const int64_t mm = ok ? m : 0;
+                const int pix = (int)(mm % P.hw);
+                const int py = pix / P.img_w, px = pix - py * P.img_w;
+                const int64_t img = mm / P.hw;
+                if (P.ups == 1) {
+                    a_vo[e] = ok ? (unsigned)((img * (int64_t)(P.hw >> 2) * P.cin + sc * 8) * 2) : OOB;
+                    a_ok[e] = ((unsigned)py << 16) | (unsigned)px;
+                } else {
+                    unsigned mask = 0;
+                    for (int t = 0; t < 9; ++t) {
+                        const int dy = t / 3 - 1, dx = t % 3 - 1;
+                        const bool in = P.ups == 2 ? (2 * py + dy >= 0 && 2 * px + dx >= 0)
+                                                   : ((unsigned)(py + dy) < (unsigned)P.img_h && (unsigned)(px + dx) < (unsigned)P.img_w);
+                        mask |= (unsigned)in << t;
+                    }
+                    a_ok[e] = ok ? mask : 0u;
+                    if (P.ups == 2) a_vo[e] = (unsigned)(((img * (int64_t)(P.hw << 2) + (int64_t)(2 * py) * (2 * P.img_w) + 2 * px) * P.cin + sc * 8) * 2);
+                    else a_vo[e] = (unsigned)((mm * P.cin + sc * 8) * 2);
+                }
+            }
+        }
+    }
+    // the k-tile the NEXT slot belongs to (scalars; past the end of K the stream wraps to valid addresses, the count stays exact)
+    int it_kt = 0, it_buf = 0, it_tap = 0, it_ci0 = 0;
+    auto advance = [&]() {
+        it_buf ^= 1;
+        if (++it_kt == nkt) {
+            it_kt = 0; it_tap = 0; it_ci0 = 0;
+        } else if (MODE == 1) {
+            if (++it_tap == 9) {                      // (channel chunk outer, tap inner), see gemm_kernel
+                it_tap = 0;
+                it_ci0 += BK;
+            }
+        }
+    };
+    auto dma = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned voff, int soff, bf16_t* lds) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, (int)voff, soff, 0, 0);
+    };
+    auto issue_w = [&](int e, bf16_t* stage) {
+        const int soff = (MODE == 1 ? it_tap * P.cin + it_ci0 : it_kt * BK) * 2;
+        dma(rsW, w_vo[e], soff, w_lds[e] == 2 * STAGE_ELEMS ? smem + 2 * STAGE_ELEMS : stage + w_lds[e]);
+    };
+    auto issue_a = [&](int e, bf16_t* stage) {
+        bf16_t* dst = a_lds[e] == 2 * STAGE_ELEMS ? smem + 2 * STAGE_ELEMS : stage + a_lds[e];
+        if (MODE == 0) {
+            dma(rsA, a_vo[e], it_kt * BK * 2, dst);
+        } else {
+            const int dy = (it_tap >= 3) + (it_tap >= 6) - 1, dx = it_tap - 3 * (dy + 1) - 1;
+            unsigned vo;
+            if (P.ups == 1) {
+                const int py = (int)(a_ok[e] >> 16) + dy, px = (int)(a_ok[e] & 0xffffu) + dx;
+                const bool in = (unsigned)py < (unsigned)P.img_h && (unsigned)px < (unsigned)P.img_w;
+                vo = a_vo[e] + (unsigned)(((py >> 1) * (P.img_w >> 1) + (px >> 1)) * P.cin * 2);
+                if (!in || a_vo[e] == OOB) vo = OOB;
+            } else {
+                const int shift = (P.ups == 2 ? (dy * 2 * P.img_w + dx) : (dy * P.img_w + dx)) * P.cin * 2;
+                vo = ((a_ok[e] >> it_tap) & 1u) ? a_vo[e] + (unsigned)shift : OOB;
+            }
+            dma(rsA, vo, it_ci0 * 2, dst);
+        }
+    };
+    auto issue = [&](int q) {                          // q = slot of the k-tile the stream is in (a constant at every call site)
+        bf16_t* stage = smem + it_buf * STAGE_ELEMS;
+        if (q == 0) { issue_w(0, stage); issue_w(1, stage); }
+        else if (q == 1) { issue_w(2, stage); issue_w(3, stage); }
+        else if (q == 2) {
+            if (wave < 4) { issue_w(4, stage); issue_w(5, stage); }
+            else { issue_a(0, stage); issue_a(1, stage); }
+        } else {
+            issue_a(2, stage); issue_a(3, stage);      // (waves 6, 7: dummies)
+            advance();
+        }
+    };
+
+    f32x4 acc[5][5];                                   // [mb][nb]: 4 consecutive n (registers) of row m = l15
+    bf16x8 wf[5], af[3];
+    auto read_w = [&](const bf16_t* Ws, int ks) {
+#pragma unroll
+        for (int nb = 0; nb < 5; ++nb) {
+            const int rw = wc * 80 + nb * 16 + l15;
+            union { bf16x8 v; u32x4 u; } t;
+            t.u = *reinterpret_cast<const u32x4*>(Ws + rw * BK + swz<BK>(rw, 4 * ks + kq) * 8);
+            wf[nb] = t.v;
+        }
+    };
+    auto read_a = [&](const bf16_t* As, int ks, int mb0, int cnt) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (j < cnt) {
+                const int rm = wr * 80 + (mb0 + j) * 16 + l15;
+                union { bf16x8 v; u32x4 u; } t;
+                t.u = *reinterpret_cast<const u32x4*>(As + rm * BK + swz<BK>(rm, 4 * ks + kq) * 8);
+                af[j] = t.v;
+            }
+        }
+    };
+#define G160_MMA(MB0, CNT)                                                                                           \
+    do {                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        __builtin_amdgcn_s_barrier();                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        __builtin_amdgcn_s_setprio(1);                                                                               \
+        _Pragma("unroll") for (int j = 0; j < (CNT); ++j)                                                            \
+            _Pragma("unroll") for (int nb = 0; nb < 5; ++nb)                                                         \
+                acc[(MB0) + j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], af[j], acc[(MB0) + j][nb], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        __builtin_amdgcn_s_barrier();                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    } while (0)
+#define G160_FEED(Q)                                                                                                 \
+    do {                                                                                                             \
+        issue(Q);                                                                                                    \
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                             \
+    } while (0)
+
+    // ---- prologue: slots 0..4 (k-tile 0 + q0 of k-tile 1) in flight, q0-q2 of k-tile 0 retired and published ---------------------
+    issue(0); issue(1); issue(2); issue(3); issue(0);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();        // wave row 1 runs one barrier behind wave row 0
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+        for (int b = 0; b < 5; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bf16_t* As = smem + (kt & 1) * STAGE_ELEMS;
+        const bf16_t* Ws = As + BM * BK;
+        read_w(Ws, 0);                                // phase 0
+        read_a(As, 0, 0, 2);
+        G160_FEED(1);
+        G160_MMA(0, 2);
+        read_a(As, 0, 2, 3);                          // phase 1
+        G160_FEED(2);
+        G160_MMA(2, 3);
+        read_w(Ws, 1);                                // phase 2
+        read_a(As, 1, 0, 2);
+        G160_FEED(3);
+        G160_MMA(0, 2);
+        read_a(As, 1, 2, 3);                          // phase 3
+        G160_FEED(0);
+        G160_MMA(2, 3);
+    }
+#undef G160_MMA
+#undef G160_FEED
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the wrap-around DMAs of the tail have landed: LDS is free for the epilogue
+    __syncthreads();
+
+    // ---- epilogue --------------------------------------------------------------------------------------------------------------------
+    // my outputs: acc[mb][nb][j] = out[m0 + 80 wr + 16 mb + l15][n0 + 80 wc + 16 nb + 4 kq + j]
+    if (P.f32io) {                                    // fp32-storage mode: see epi_f32_quad
+#pragma unroll
+        for (int mb = 0; mb < 5; ++mb) {
+            const int64_t m = m0 + wr * 80 + mb * 16 + l15;
+#pragma unroll
+            for (int nb = 0; nb < 5; ++nb) {
+                const float a4[4] = {acc[mb][nb][0], acc[mb][nb][1], acc[mb][nb][2], acc[mb][nb][3]};
+                const int tn = wc * 80 + nb * 16 + 4 * kq;     // column inside the tile
+                if (EPI == 1) {
+                    // (fp32 parity mode keeps it simple: gate columns through LDS as below would need the same code; the gate waves
+                    // write, the value waves read -- done here with the same staging region, fp32)
+                    float* G = reinterpret_cast<float*>(smem_raw);
+                    if (wc >= 2) *reinterpret_cast<f32x4*>(G + (wr * 80 + mb * 16 + l15) * 164 + (tn - 160)) = f32x4{a4[0], a4[1], a4[2], a4[3]};
+                } else {
+                    epi_f32_quad<MODE>(P, a4, m, n0 + tn);
+                }
+            }
+        }
+        if (EPI == 1) {
+            __syncthreads();
+            const float* G = reinterpret_cast<const float*>(smem_raw);
+            if (wc < 2) {
+#pragma unroll
+                for (int mb = 0; mb < 5; ++mb) {
+                    const int64_t m = m0 + wr * 80 + mb * 16 + l15;
+#pragma unroll
+                    for (int nb = 0; nb < 5; ++nb) {
+                        const int tn = wc * 80 + nb * 16 + 4 * kq;
+                        const f32x4 g = *reinterpret_cast<const f32x4*>(G + (wr * 80 + mb * 16 + l15) * 164 + tn);
+                        const float av[4] = {acc[mb][nb][0], acc[mb][nb][1], acc[mb][nb][2], acc[mb][nb][3]};
+                        const float ag[4] = {g[0], g[1], g[2], g[3]};
+                        // weight rows of tile t: [320 t, 320 t + 160) value, [+160, +320) gate -> bias of the gate = bias[.. + 160]
+                        if (m < P.M && n0 / 2 + tn < P.N / 2) {
+                            const float* bias = reinterpret_cast<const float*>(P.bias);
+                            float* out = reinterpret_cast<float*>(P.out);
+                            f32x4 v;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float gg = ag[j] + (bias ? bias[n0 + 160 + tn + j] : 0.f);
+                                v[j] = (av[j] + (bias ? bias[n0 + tn + j] : 0.f)) * (0.5f * gg * (1.f + erff(gg * 0.70710678118654752f)));
+                            }
+                            *reinterpret_cast<f32x4*>(out + m * P.ldo + n0 / 2 + tn) = v;
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
+    if (EPI == 1) {
+        // GEGLU: tile columns [0, 160) = value, [160, 320) = gate of the SAME 160 outputs.  Two passes of 80 rows (one wave row each):
+        // gate waves leave gelu(gate + bias) as fp32 in G [80][164], value waves multiply and stage bf16 in Os [80][168], then whole rows leave.
+        float* G = reinterpret_cast<float*>(smem_raw);                     // 52 480 B
+        bf16_t* Os = reinterpret_cast<bf16_t*>(smem_raw + 80 * 164 * 4);   // 26 880 B
+        constexpr int OP = 168;
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            if (wr == pass && wc >= 2) {
+#pragma unroll
+                for (int nb = 0; nb < 5; ++nb) {
+                    const int tn = (wc - 2) * 80 + nb * 16 + 4 * kq;
+                    float bg[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (P.bias) {
+                        const u32x2 t = *reinterpret_cast<const u32x2*>(P.bias + min(n0 + 160 + tn, P.N - 4));
+                        bg[0] = __uint_as_float(t[0] << 16); bg[1] = __uint_as_float(t[0] & 0xffff0000u);
+                        bg[2] = __uint_as_float(t[1] << 16); bg[3] = __uint_as_float(t[1] & 0xffff0000u);
+                    }
+#pragma unroll
+                    for (int mb = 0; mb < 5; ++mb)
+                        *reinterpret_cast<f32x4*>(G + (mb * 16 + l15) * 164 + tn) =
+                            f32x4{gelu_erf(acc[mb][nb][0] + bg[0]), gelu_erf(acc[mb][nb][1] + bg[1]), gelu_erf(acc[mb][nb][2] + bg[2]),
+                                  gelu_erf(acc[mb][nb][3] + bg[3])};
+                }
+            }
+            __syncthreads();
+            if (wr == pass && wc < 2) {
+#pragma unroll
+                for (int nb = 0; nb < 5; ++nb) {
+                    const int tn = wc * 80 + nb * 16 + 4 * kq;
+                    float ba[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (P.bias) {
+                        const u32x2 t = *reinterpret_cast<const u32x2*>(P.bias + min(n0 + tn, P.N - 4));
+                        ba[0] = __uint_as_float(t[0] << 16); ba[1] = __uint_as_float(t[0] & 0xffff0000u);
+                        ba[2] = __uint_as_float(t[1] << 16); ba[3] = __uint_as_float(t[1] & 0xffff0000u);
+                    }
+#pragma unroll
+                    for (int mb = 0; mb < 5; ++mb) {
+                        const f32x4 g = *reinterpret_cast<const f32x4*>(G + (mb * 16 + l15) * 164 + tn);
+                        *reinterpret_cast<u32x2*>(Os + (mb * 16 + l15) * OP + tn) =
+                            u32x2{pack_bf2((acc[mb][nb][0] + ba[0]) * g[0], (acc[mb][nb][1] + ba[1]) * g[1]),
+                                  pack_bf2((acc[mb][nb][2] + ba[2]) * g[2], (acc[mb][nb][3] + ba[3]) * g[3])};
+                    }
+                }
+            }
+            __syncthreads();
+            for (int c = tid; c < 80 * 20; c += NT) {                     // 80 rows x 20 chunks of 8 outputs
+                const int r = c / 20, ch = c - r * 20;
+                const int64_t m = m0 + pass * 80 + r;
+                const int no = n0 / 2 + ch * 8;
+                if (m < P.M && no < P.N / 2)
+                    *reinterpret_cast<u32x4*>(P.out + m * P.ldo + no) = *reinterpret_cast<const u32x4*>(Os + r * OP + ch * 8);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    {
+        constexpr int OP = BN + 8;                         // bf16 pitch of the staging rows (656 B: 16-byte aligned)
+        bf16_t* Os = smem;                                 // [160][OP] = 104 960 B
+        constexpr int CPR = BN / 8;                        // 40 chunks per row
+        // alpha * (acc + bias) (+ temb) in the accumulator registers
+#pragma unroll
+        for (int nb = 0; nb < 5; ++nb) {
+            const int n = n0 + wc * 80 + nb * 16 + 4 * kq;
+            float b4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (P.bias) {
+                const u32x2 t = *reinterpret_cast<const u32x2*>(P.bias + min(n, P.N - 4));
+                b4[0] = __uint_as_float(t[0] << 16); b4[1] = __uint_as_float(t[0] & 0xffff0000u);
+                b4[2] = __uint_as_float(t[1] << 16); b4[3] = __uint_as_float(t[1] & 0xffff0000u);
+            }
+#pragma unroll
+            for (int mb = 0; mb < 5; ++mb) {
+                float t4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (MODE == 1 && P.temb) {
+                    const int64_t m = min(m0 + wr * 80 + mb * 16 + l15, P.M - 1);
+                    const u32x2 t = *reinterpret_cast<const u32x2*>(P.temb + ((m / P.hw) / P.temb_div) * P.temb_ld + min(n, P.N - 4));
+                    t4[0] = __uint_as_float(t[0] << 16); t4[1] = __uint_as_float(t[0] & 0xffff0000u);
+                    t4[2] = __uint_as_float(t[1] << 16); t4[3] = __uint_as_float(t[1] & 0xffff0000u);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[mb][nb][j] = (acc[mb][nb][j] + b4[j]) * P.alpha + t4[j];
+            }
+        }
+        // residual(s): whole-row 16-byte loads into the staging tile, every lane adds its own words in fp32
+#pragma unroll 1
+        for (int rz = 0; rz < 2; ++rz) {
+            const bf16_t* rp = rz == 0 ? P.res : P.res2;
+            if (rp == nullptr) continue;                   // (uniform)
+            for (int c = tid; c < BM * CPR; c += NT) {
+                const int r = c / CPR, ch = c - r * CPR;
+                *reinterpret_cast<u32x4*>(Os + r * OP + ch * 8) =
+                    *reinterpret_cast<const u32x4*>(rp + min(m0 + r, P.M - 1) * P.ldres + min(n0 + ch * 8, P.N - 8));
+            }
+            __syncthreads();
+#pragma unroll
+            for (int mb = 0; mb < 5; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 5; ++nb) {
+                    const u32x2 t = *reinterpret_cast<const u32x2*>(Os + (wr * 80 + mb * 16 + l15) * OP + wc * 80 + nb * 16 + 4 * kq);
+                    acc[mb][nb][0] += __uint_as_float(t[0] << 16); acc[mb][nb][1] += __uint_as_float(t[0] & 0xffff0000u);
+                    acc[mb][nb][2] += __uint_as_float(t[1] << 16); acc[mb][nb][3] += __uint_as_float(t[1] & 0xffff0000u);
+                }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int mb = 0; mb < 5; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 5; ++nb)
+                *reinterpret_cast<u32x2*>(Os + (wr * 80 + mb * 16 + l15) * OP + wc * 80 + nb * 16 + 4 * kq) =
+                    u32x2{pack_bf2(acc[mb][nb][0], acc[mb][nb][1]), pack_bf2(acc[mb][nb][2], acc[mb][nb][3])};
+        __syncthreads();
+        for (int c = tid; c < BM * CPR; c += NT) {
+            const int r = c / CPR, ch = c - r * CPR;
+            const int64_t m = m0 + r;
+            const int n = n0 + ch * 8;
+            if (m < P.M && n < P.N)
+                *reinterpret_cast<u32x4*>(P.out + m * P.ldo + n) = *reinterpret_cast<const u32x4*>(Os + r * OP + ch * 8);
+        }
+    }
+}
+
 int fmc_cu_count() {
     static int n = 0;
     if (!n) {
@@ -1760,6 +2180,33 @@ void launch_gemm_k320(GemmParams& P, hipStream_t st) {
     }
 }
 
+// arm 16: plain grid only (whole rounds are the point); N must be a multiple of 320 (GEGLU: weight rows per tile = [160 value | 160 gate])
+bool gemm160_ok(const GemmParams& P) {
+    return P.N % 320 == 0 && P.split_k == 1 && !P.sk && !P.a2;
+}
+template <int MODE, int EPI>
+void launch_gemm160(GemmParams& P, hipStream_t st) {
+    P.tiles_m = (int)((P.M + 159) / 160);
+    P.tiles_n = P.N / 320;
+    P.group_m = 1;
+    P.tap_outer = 0;
+    if (gemm_group_m_override() > 0) {
+        P.group_m = gemm_group_m_override();
+    } else if (MODE == 0 && (int64_t)P.N * P.K * 2 > (int64_t)5 << 19) {     // as launch_gemm8: square per-XCD footprint in bytes
+        const double c = fmin(32.0, (double)P.tiles_m * P.tiles_n / 8.0);
+        const int gm = (int)lround(sqrt(c * 2.0));
+        if (gm > 1 && P.tiles_n * 2 > 3 * (c / gm)) P.group_m = gm;
+    }
+    constexpr size_t lds = (size_t)2 * (160 + 320) * 64 * sizeof(bf16_t) + 1024;          // two k-tile buffers + the dummies' KiB
+    static_assert(lds >= (size_t)160 * 328 * 2 && lds >= (size_t)160 * 164 * 4, "epilogue staging fits the operand buffers");
+    static bool raised = false;
+    if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm160_kernel<MODE, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        raised = true;
+    }
+    hipLaunchKernelGGL((gemm160_kernel<MODE, EPI>), dim3((unsigned)(P.tiles_m * P.tiles_n)), dim3(512), lds, st, P);
+}
+
 bool gemm8_ok(GemmParams& P) {
     // operand sizes as the buffer descriptors see them (conv: the whole input tensor; token: up to the end of the last row)
     const int64_t a_elems = P.hw > 1 ? (P.ups == 1 ? (P.M / 4) * (int64_t)P.cin : P.M * (int64_t)P.cin * (P.ups == 2 ? 4 : 1))
@@ -1769,7 +2216,7 @@ bool gemm8_ok(GemmParams& P) {
 }
 
 // tile arms (fmc_hip.h): geometry x k-tile depth x ring depth
-constexpr int GEMM_TILE_MAX = 15;
+constexpr int GEMM_TILE_MAX = 16;
 
 // geometry: the largest tile that still gives every CU work and does not waste more than ~20 % of N
 template <int MODE, int EPI>
@@ -1782,6 +2229,10 @@ void launch_gemm(GemmParams& P, int tile, hipStream_t st) {
         if (tiles(256, 256) >= 256 && waste(256) <= 1.2) g = 3;
         else if (tiles(256, 128) >= 256 && waste(128) <= 1.25) g = 2;
         else g = 1;
+    }
+    if (g == 16) {                                        // 160 x 320 tiles (8-phase schedule, 16x16x32 MFMA): N % 320 == 0, plain grid
+        if (gemm8_ok(P) && gemm160_ok(P)) { launch_gemm160<MODE, EPI>(P, st); return; }
+        g = 13;
     }
     if ((g == 13 || g == 14) && !gemm8_ok(P)) g = 3;      // 8-phase kernel: plain grid, 32-bit operand offsets
     if (g == 15) {                                        // W-stationary persistent kernel of the K = 320 token projections
