@@ -866,7 +866,7 @@ def _f32_arm(key_bf16, tile: int) -> int:
         use -= 256
     elif use >= 128:
         use -= 128
-    return use if 1 <= use <= 14 else 0
+    return use if (1 <= use <= 14 or use == 16) else 0
 
 
 def linear_f32(x: torch.Tensor, weight: torch.Tensor, bias=None, residual=None, alpha: float = 1.0, geglu: bool = False,
@@ -1026,6 +1026,7 @@ atexit.register(_save_at_exit)
 GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 11,     # 8..10, 12 (4-stage rings) exist but never won on the FMC shapes
               13,                            # the 8-phase 256x256 kernel (staggered wave rows, half-tile DMA, counted vmcnt)
               15,                            # K = 320 token projections: persistent, weights resident in registers (falls back to 5 elsewhere)
+              16,                            # 160 x 320 tiles on the 8-phase schedule: whole rounds / no padded columns for N = 320 k (falls back to 13)
               128 + 2, 128 + 3,              # stream-K (persistent workgroups) on the two 1-per-CU geometries
               128 + 13,                      # stream-K on the 8-phase kernel: persistent partial pass + one finishing workgroup per tile
               256 + 13)                      # the same for the LAST PARTIAL ROUND of tiles only, the whole rounds on the plain grid
@@ -1082,11 +1083,13 @@ def _pick(key, hip_fn, lib_fn, static_hip: bool, extra_arms=(), k320: bool = Fal
         key = key + ("det",)
     use = _choice.get(key)
     _calls[key] = _calls.get(key, 0) + 1
+    n320 = (key[5] if key[0] == "conv" else key[2]) % 320 == 0
     if use is None:
         if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
             return 0 if not (static_hip or no_lib) else -1          # -1: kernel's own geometry heuristic
         times = ([] if no_lib else [(_time_ms(lib_fn), 0)]) + [(_time_ms(lambda t=t: hip_fn(t)), t) for t in GEMM_TILES + tuple(extra_arms)
-                                                                if t != 15 or k320]   # (arm 15 exists for the K = 320 token projections only)
+                                                                if (t != 15 or k320)    # (arm 15 exists for the K = 320 token projections only,
+                                                                and (t != 16 or n320)]  #  arm 16 for outputs whose width is a multiple of 320)
         use = min(times)[1]
         _choice[key] = use
         _tune_log[key] = {arm: round(ms, 4) for ms, arm in times}
@@ -1132,20 +1135,30 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return lib() if use == 0 else hip(max(use, 0))
 
 
-def geglu_linear(x: torch.Tensor, weight: torch.Tensor, bias, weight_il: torch.Tensor, bias_il) -> torch.Tensor:
+def geglu_linear(x: torch.Tensor, weight: torch.Tensor, bias, weight_il: torch.Tensor, bias_il, weight_il160=None,
+                 bias_il160=None) -> torch.Tensor:
     """GEGLU feed-forward input projection: `a * gelu(g)`, `a, g = (x @ weight^T + bias).chunk(2)`.  `weight_il` /
-    `bias_il` are the tile-interleaved copies the fused kernel wants (`models.layers.interleave_geglu`)."""
+    `bias_il` are the tile-interleaved copies the fused kernel wants (`models.layers.interleave_geglu`); `weight_il160` /
+    `bias_il160` the [160 value | 160 gate] order of arm 16 (without them arm 16 is not a candidate)."""
     import torch.nn.functional as F
     lib = lambda: geglu(F.linear(x, weight, bias))
     if (F32_GEMM and x.is_cuda and x.dtype == torch.float32 and weight_il.dtype == torch.float32 and weight_il.shape[0] % 64 == 0
             and weight_il.shape[1] % 64 == 0 and x.is_contiguous()):
         N, Kd = weight.shape
-        return linear_f32(x, weight_il, bias_il, geglu=True, tile=_f32_arm(("geglu", x.numel() // Kd, N, Kd), 0))
+        arm = _f32_arm(("geglu", x.numel() // Kd, N, Kd), 0)
+        if arm == 16 and weight_il160 is not None:
+            return linear_f32(x, weight_il160, bias_il160, geglu=True, tile=16)
+        return linear_f32(x, weight_il, bias_il, geglu=True, tile=0 if arm == 16 else arm)
     if not linear_supported(x, weight_il) or weight_il.shape[0] % 64 or (x.ndim > 2 and not x.is_contiguous()):
         return lib()
     N, Kd = weight.shape
     M = x.numel() // Kd
-    hip = lambda tile: linear_bf16(x, weight_il, bias_il, geglu=True, tile=tile)
+    has160 = weight_il160 is not None and N % 320 == 0
+
+    def hip(tile):
+        if tile == 16:                                  # (without the 160-block order arm 16 would silently pair wrong rows: route it to 13)
+            return linear_bf16(x, weight_il160, bias_il160, geglu=True, tile=16) if has160 else linear_bf16(x, weight_il, bias_il, geglu=True, tile=13)
+        return linear_bf16(x, weight_il, bias_il, geglu=True, tile=tile)
     use = _pick(("geglu", M, N, Kd), hip, lib, M >= 65536)
     return lib() if use == 0 else hip(max(use, 0))
 

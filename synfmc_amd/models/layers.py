@@ -385,14 +385,15 @@ class Attention(nn.Module):
         return fused
 
 
-def interleave_geglu(weight: torch.Tensor, bias: Optional[torch.Tensor]):
-    """Row order `fmc_linear_bf16(epilogue=GEGLU)` expects: per 64 rows, 32 value rows then their 32 gate rows (so any
-    tile width that is a multiple of 64 holds matching value / gate columns)."""
+def interleave_geglu(weight: torch.Tensor, bias: Optional[torch.Tensor], block: int = 32):
+    """Row order `fmc_linear_bf16(epilogue=GEGLU)` expects: per 2 * block rows, `block` value rows then their `block` gate rows.
+    block = 32 (the default: any tile width that is a multiple of 64 holds matching value / gate columns) for every arm but
+    16, whose 160 x 320 tiles want [160 value | 160 gate] (block = 160)."""
     two_cff, k = weight.shape
     cff = two_cff // 2
-    assert cff % 32 == 0
-    w = weight.view(2, cff // 32, 32, k).permute(1, 0, 2, 3).reshape(two_cff, k).contiguous()
-    b = None if bias is None else bias.view(2, cff // 32, 32).permute(1, 0, 2).reshape(two_cff).contiguous()
+    assert cff % block == 0
+    w = weight.view(2, cff // block, block, k).permute(1, 0, 2, 3).reshape(two_cff, k).contiguous()
+    b = None if bias is None else bias.view(2, cff // block, block).permute(1, 0, 2).reshape(two_cff).contiguous()
     return w, b
 
 
@@ -410,9 +411,11 @@ class GEGLU(nn.Module):
             hit = self.__dict__.get("_il")
             if hit is None or hit[0] != key:
                 with torch.no_grad():
-                    hit = (key, interleave_geglu(w.detach(), None if self.proj.bias is None else self.proj.bias.detach()))
+                    b = None if self.proj.bias is None else self.proj.bias.detach()
+                    il160 = interleave_geglu(w.detach(), b, 160) if (w.shape[0] // 2) % 160 == 0 else (None, None)
+                    hit = (key, interleave_geglu(w.detach(), b) + il160)
                 self.__dict__["_il"] = hit
-            return K.geglu_linear(hidden_states, w, self.proj.bias, hit[1][0], hit[1][1])
+            return K.geglu_linear(hidden_states, w, self.proj.bias, hit[1][0], hit[1][1], hit[1][2], hit[1][3])
         return K.geglu(self.proj(hidden_states))
 
 
