@@ -684,8 +684,14 @@ def cfg_ddim_step(eps: torch.Tensor, x: torch.Tensor, guidance: float, alpha_t: 
 # --------------------------------------------------------------------------------------------
 # bf16 MFMA GEMM / implicit 3x3 conv with fused epilogues
 # --------------------------------------------------------------------------------------------
+ARM_160 = 512
+
+
 def _decode_arm(tile: int, split_k: int):
-    """autotune arm id -> (tile geometry 0..6, split_k)"""
+    """autotune arm id -> (C-ABI tile id, split_k).  Ids 16..127 encode split-K (geometry + 16 log2(split)), 128+ / 256+ stream-K and its
+    hybrid; ARM_160 (512) is the C-ABI tile 16, the 160 x 320 kernel."""
+    if tile == ARM_160:
+        return 16, 1
     if tile >= 256:
         return tile - 256, -2                           # whole rounds on the plain grid, the last partial round stream-K (8-phase arms)
     if tile >= 128:
@@ -866,7 +872,7 @@ def _f32_arm(key_bf16, tile: int) -> int:
         use -= 256
     elif use >= 128:
         use -= 128
-    return use if (1 <= use <= 14 or use == 16) else 0
+    return use if (1 <= use <= 14 or use == ARM_160) else 0
 
 
 def linear_f32(x: torch.Tensor, weight: torch.Tensor, bias=None, residual=None, alpha: float = 1.0, geglu: bool = False,
@@ -1026,7 +1032,7 @@ atexit.register(_save_at_exit)
 GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 11,     # 8..10, 12 (4-stage rings) exist but never won on the FMC shapes
               13,                            # the 8-phase 256x256 kernel (staggered wave rows, half-tile DMA, counted vmcnt)
               15,                            # K = 320 token projections: persistent, weights resident in registers (falls back to 5 elsewhere)
-              16,                            # 160 x 320 tiles on the 8-phase schedule: whole rounds / no padded columns for N = 320 k (falls back to 13)
+              ARM_160,                       # 160 x 320 tiles on the 8-phase schedule: whole rounds / no padded columns for N = 320 k (falls back to 13)
               128 + 2, 128 + 3,              # stream-K (persistent workgroups) on the two 1-per-CU geometries
               128 + 13,                      # stream-K on the 8-phase kernel: persistent partial pass + one finishing workgroup per tile
               256 + 13)                      # the same for the LAST PARTIAL ROUND of tiles only, the whole rounds on the plain grid
@@ -1089,7 +1095,7 @@ def _pick(key, hip_fn, lib_fn, static_hip: bool, extra_arms=(), k320: bool = Fal
             return 0 if not (static_hip or no_lib) else -1          # -1: kernel's own geometry heuristic
         times = ([] if no_lib else [(_time_ms(lib_fn), 0)]) + [(_time_ms(lambda t=t: hip_fn(t)), t) for t in GEMM_TILES + tuple(extra_arms)
                                                                 if (t != 15 or k320)    # (arm 15 exists for the K = 320 token projections only,
-                                                                and (t != 16 or n320)]  #  arm 16 for outputs whose width is a multiple of 320)
+                                                                and (t != ARM_160 or n320)]  #  arm 16 for outputs whose width is a multiple of 320)
         use = min(times)[1]
         _choice[key] = use
         _tune_log[key] = {arm: round(ms, 4) for ms, arm in times}
@@ -1146,9 +1152,9 @@ def geglu_linear(x: torch.Tensor, weight: torch.Tensor, bias, weight_il: torch.T
             and weight_il.shape[1] % 64 == 0 and x.is_contiguous()):
         N, Kd = weight.shape
         arm = _f32_arm(("geglu", x.numel() // Kd, N, Kd), 0)
-        if arm == 16 and weight_il160 is not None:
-            return linear_f32(x, weight_il160, bias_il160, geglu=True, tile=16)
-        return linear_f32(x, weight_il, bias_il, geglu=True, tile=0 if arm == 16 else arm)
+        if arm == ARM_160 and weight_il160 is not None:
+            return linear_f32(x, weight_il160, bias_il160, geglu=True, tile=ARM_160)
+        return linear_f32(x, weight_il, bias_il, geglu=True, tile=0 if arm == ARM_160 else arm)
     if not linear_supported(x, weight_il) or weight_il.shape[0] % 64 or (x.ndim > 2 and not x.is_contiguous()):
         return lib()
     N, Kd = weight.shape
@@ -1156,8 +1162,8 @@ def geglu_linear(x: torch.Tensor, weight: torch.Tensor, bias, weight_il: torch.T
     has160 = weight_il160 is not None and N % 320 == 0
 
     def hip(tile):
-        if tile == 16:                                  # (without the 160-block order arm 16 would silently pair wrong rows: route it to 13)
-            return linear_bf16(x, weight_il160, bias_il160, geglu=True, tile=16) if has160 else linear_bf16(x, weight_il, bias_il, geglu=True, tile=13)
+        if tile == ARM_160:                             # (without the 160-block order this arm would silently pair wrong rows: route it to 13)
+            return linear_bf16(x, weight_il160, bias_il160, geglu=True, tile=ARM_160) if has160 else linear_bf16(x, weight_il, bias_il, geglu=True, tile=13)
         return linear_bf16(x, weight_il, bias_il, geglu=True, tile=tile)
     use = _pick(("geglu", M, N, Kd), hip, lib, M >= 65536)
     return lib() if use == 0 else hip(max(use, 0))

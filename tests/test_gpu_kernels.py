@@ -1143,23 +1143,23 @@ def test_gemm_160x320_arm(K):
         for it in range(3):
             xo, xd = rnd((M, Kd), 700 + it, dtype)
             ro, rd = rnd((M, N), 800 + it, dtype)
-            got = K.linear_bf16(xd, wd, bd, rd, 0.5, tile=16)
+            got = K.linear_bf16(xd, wd, bd, rd, 0.5, tile=512)
             ref = 0.5 * F.linear(xo.double(), wo.double(), bo.double()) + ro.double()
             mag = 0.5 * (xo.abs().double() @ wo.abs().double().t() + bo.abs()) + ro.abs()
             assert_bf16_close(got, ref, mag, f"arm 16 {(M, N, Kd)} it {it}")
             if it == 0:
-                assert torch.equal(got, K.linear_bf16(xd, wd, bd, rd, 0.5, tile=16))                       # deterministic
+                assert torch.equal(got, K.linear_bf16(xd, wd, bd, rd, 0.5, tile=512))                       # deterministic
                 r2o, r2d = rnd((M, N), 900, dtype)
-                got2 = K.linear_bf16(xd, wd, None, rd, 1.0, tile=16, residual2=r2d)
+                got2 = K.linear_bf16(xd, wd, None, rd, 1.0, tile=512, residual2=r2d)
                 assert_bf16_close(got2, F.linear(xo.double(), wo.double()) + ro.double() + r2o.double(),
                                   xo.abs().double() @ wo.abs().double().t() + ro.abs() + r2o.abs(), "arm 16 two residuals")
-                got0 = K.linear_bf16(xd, wd, bd, None, 1.0, tile=16)
+                got0 = K.linear_bf16(xd, wd, bd, None, 1.0, tile=512)
                 assert_bf16_close(got0, F.linear(xo.double(), wo.double(), bo.double()), xo.abs().double() @ wo.abs().double().t() + bo.abs(),
                                   "arm 16 bias only")
     # N not a multiple of 320: falls back to the 8-phase 256 x 256 kernel (same function)
     xo, xd = rnd((700, 320), 41, dtype)
     wo, wd = rnd((328, 320), 42, dtype, scale=320 ** -0.5)
-    assert torch.equal(K.linear_bf16(xd, wd, None, None, 1.0, tile=16), K.linear_bf16(xd, wd, None, None, 1.0, tile=13))
+    assert torch.equal(K.linear_bf16(xd, wd, None, None, 1.0, tile=512), K.linear_bf16(xd, wd, None, None, 1.0, tile=13))
     # GEGLU
     for (M, N, Kd) in [(4100, 2560, 320), (1000, 640, 640)]:
         go, gd = rnd((N, Kd), 42, dtype, scale=Kd ** -0.5)
@@ -1168,7 +1168,7 @@ def test_gemm_160x320_arm(K):
         wi, bi = interleave_geglu(gd, gbd, 160)
         a, g = F.linear(xo.double(), go.double(), gbo.double()).chunk(2, dim=-1)
         ma, mg = (xo.abs().double() @ go.abs().double().t() + gbo.abs()).chunk(2, dim=-1)
-        outg = K.linear_bf16(xd, wi, bi, geglu=True, tile=16)
+        outg = K.linear_bf16(xd, wi, bi, geglu=True, tile=512)
         assert_bf16_close(outg, a * F.gelu(g), F.gelu(g).abs() * ma + 1.13 * a.abs() * mg + 1e-3, f"arm 16 geglu {(M, N, Kd)}")
         wi32, bi32 = interleave_geglu(gd, gbd)
         assert rel_inf(outg.float(), K.linear_bf16(xd, wi32, bi32, geglu=True, tile=3).float()) < 8e-3      # (one bf16 ulp of the largest output)
@@ -1180,15 +1180,15 @@ def test_gemm_160x320_arm(K):
     x_nhwc, f_cl = cd.permute(0, 2, 3, 1).contiguous(), fd.contiguous(memory_format=torch.channels_last)
     refc = F.conv2d(co.double(), fo.double(), None, 1, 1)
     magc = F.conv2d(co.abs().double(), fo.abs().double(), None, 1, 1)
-    outc = K.conv3x3_bf16(x_nhwc, f_cl, None, td, None, tile=16)
+    outc = K.conv3x3_bf16(x_nhwc, f_cl, None, td, None, tile=512)
     assert_bf16_close(outc.permute(0, 3, 1, 2), refc + to.double()[:, :, None, None], magc + to.abs()[:, :, None, None], "arm 16 conv + temb")
-    outr = K.conv3x3_bf16(x_nhwc, f_cl, None, None, rd.permute(0, 2, 3, 1).contiguous(), tile=16)
+    outr = K.conv3x3_bf16(x_nhwc, f_cl, None, None, rd.permute(0, 2, 3, 1).contiguous(), tile=512)
     assert_bf16_close(outr.permute(0, 3, 1, 2), refc + ro.double(), magc + ro.abs(), "arm 16 conv + residual")
     xu = F.interpolate(co, scale_factor=2.0, mode="nearest")
-    outu = K.conv3x3_bf16(x_nhwc, f_cl, None, None, None, tile=16, upsample=True)
+    outu = K.conv3x3_bf16(x_nhwc, f_cl, None, None, None, tile=512, upsample=True)
     assert_bf16_close(outu.permute(0, 3, 1, 2), F.conv2d(xu.double(), fo.double(), None, 1, 1), F.conv2d(xu.abs().double(), fo.abs().double(), None, 1, 1),
                       "arm 16 conv upsample")
-    outs = K.conv3x3_bf16(x_nhwc, f_cl, None, None, None, tile=16, stride2=True)
+    outs = K.conv3x3_bf16(x_nhwc, f_cl, None, None, None, tile=512, stride2=True)
     assert_bf16_close(outs.permute(0, 3, 1, 2), F.conv2d(co.double(), fo.double(), None, 2, 1), F.conv2d(co.abs().double(), fo.abs().double(), None, 2, 1),
                       "arm 16 conv stride 2")
     # bench-size conv against the plain kernel, many launches
@@ -1196,20 +1196,20 @@ def test_gemm_160x320_arm(K):
     fo, fd = rnd((640, 640, 3, 3), 54, dtype, scale=(9 * 640) ** -0.5)
     x_nhwc, f_cl = cd.permute(0, 2, 3, 1).contiguous(), fd.contiguous(memory_format=torch.channels_last)
     want = K.conv3x3_bf16(x_nhwc, f_cl, None, None, None, tile=3)
-    first = K.conv3x3_bf16(x_nhwc, f_cl, None, None, None, tile=16)
+    first = K.conv3x3_bf16(x_nhwc, f_cl, None, None, None, tile=512)
     assert rel_inf(first.float(), want.float()) < 8e-3
     for it in range(8):
-        assert torch.equal(K.conv3x3_bf16(x_nhwc, f_cl, None, None, None, tile=16), first)
+        assert torch.equal(K.conv3x3_bf16(x_nhwc, f_cl, None, None, None, tile=512), first)
     # fp32-storage mode
     g = torch.Generator().manual_seed(903)
     x, w = torch.randn(777, 320, generator=g), torch.randn(640, 320, generator=g) * 320 ** -0.5
     b, r = torch.randn(640, generator=g), torch.randn(777, 640, generator=g)
-    got = K.linear_f32(x.cuda(), w.cuda(), b.cuda(), r.cuda(), 0.5, tile=16)
+    got = K.linear_f32(x.cuda(), w.cuda(), b.cuda(), r.cuda(), 0.5, tile=512)
     assert_f32_close(got, 0.5 * (F.linear(x.double(), w.double()) + b.double()) + r.double(),
                      0.5 * (x.abs().double() @ w.abs().double().t() + b.abs()) + r.abs(), "arm 16 fp32")
     gw, gb = torch.randn(640, 320, generator=g) * 320 ** -0.5, torch.randn(640, generator=g)
     wi, bi = interleave_geglu(gw.cuda(), gb.cuda(), 160)
     a, gt = F.linear(x.double(), gw.double(), gb.double()).chunk(2, dim=-1)
     ma, mg = (x.abs().double() @ gw.abs().double().t() + gb.abs()).chunk(2, dim=-1)
-    got = K.linear_f32(x.cuda(), wi, bi, geglu=True, tile=16)
+    got = K.linear_f32(x.cuda(), wi, bi, geglu=True, tile=512)
     assert_f32_close(got, a * F.gelu(gt), F.gelu(gt).abs() * ma + 1.13 * a.abs() * mg + 1e-3, "arm 16 fp32 geglu")

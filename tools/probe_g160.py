@@ -11,7 +11,7 @@ from synfmc_amd import hip_ops as K
 from synfmc_amd.models.layers import interleave_geglu
 
 dev = torch.device("cuda")
-ARMS = [3, 5, 11, 13, 15, 16]
+ARMS = [3, 5, 11, 13, 15, 512]
 bf = torch.bfloat16
 
 
@@ -28,14 +28,14 @@ def lin(M, N, Kd, bias=True, res=False, geglu=False):
         if t == 15 and (geglu or Kd != 320 or N % 320):
             continue
         if geglu:
-            fn = (lambda: K.linear_bf16(x, w160, b160, geglu=True, tile=16)) if t == 16 else (lambda t=t: K.linear_bf16(x, w32, b32, geglu=True, tile=t))
+            fn = (lambda: K.linear_bf16(x, w160, b160, geglu=True, tile=512)) if t == 512 else (lambda t=t: K.linear_bf16(x, w32, b32, geglu=True, tile=t))
         else:
             fn = lambda t=t: K.linear_bf16(x, w, b, r, 1.0, tile=t)
         out[t] = K._time_ms(fn)
     fl = 2.0 * M * N * Kd
     best = min(out, key=out.get)
     print(f"{'geglu' if geglu else 'lin':5s} M={M:6d} N={N:5d} K={Kd:5d} res={int(res)}  " + "  ".join(f"{t}:{v * 1e3:7.1f}us" for t, v in out.items())
-          + f"   arm16 {fl / out[16] / 1e9:6.0f} TF/s, best other {fl / min(v for t, v in out.items() if t != 16) / 1e9:6.0f} (arm {best})", flush=True)
+          + f"   arm16 {fl / out[512] / 1e9:6.0f} TF/s, best other {fl / min(v for t, v in out.items() if t != 512) / 1e9:6.0f} (arm {best})", flush=True)
 
 
 def conv(n, h, w_, ci, co, temb=False, res=False, ups=False):
@@ -51,7 +51,7 @@ def conv(n, h, w_, ci, co, temb=False, res=False, ups=False):
     fl = 2.0 * n * h * w_ * 9 * ci * co
     best = min(out, key=out.get)
     print(f"conv  {n}x{h}x{w_} {ci:4d}->{co:4d} temb={int(temb)} res={int(res)} ups={int(ups)}  " + "  ".join(f"{t}:{v * 1e3:7.1f}us" for t, v in out.items())
-          + f"   arm16 {fl / out[16] / 1e9:6.0f} TF/s, best other {fl / min(v for t, v in out.items() if t != 16) / 1e9:6.0f} (arm {best})", flush=True)
+          + f"   arm16 {fl / out[512] / 1e9:6.0f} TF/s, best other {fl / min(v for t, v in out.items() if t != 512) / 1e9:6.0f} (arm {best})", flush=True)
 
 
 if __name__ == "__main__":
