@@ -1315,7 +1315,7 @@ void gemm8_kernel(const GemmParams P) {
 }
 
 // =====================================================================================================================
-// The 160 x 320 kernel (tile arm 16): the 8-phase schedule of gemm8_kernel on a tile that DIVIDES the FMC problem sizes.
+// The 160 x 320 kernel (C-ABI tile 16): the staggered-phase schedule of gemm8_kernel on a tile that DIVIDES the FMC problem sizes.
 //
 // Why: every token / pixel count of the U-Net is a multiple of 160 rows x 256 CUs at the two levels that hold 2/3 of the GEMM time
 // (M = 81920 = 512 x 160 at 40x64, M = 20480 = 128 x 160 at 20x32), and every width there is a multiple of 320 (N = 320, 640, 960, 1920,
@@ -1325,38 +1325,50 @@ void gemm8_kernel(const GemmParams P) {
 //
 // Geometry: 8 waves = 2 (m) x 4 (n), a wave computes 80 x 80 outputs as 5 x 5 v_mfma_f32_16x16x32_bf16 accumulators (100 registers; 80
 // is not a multiple of 32, hence the 16-wide MFMA; products are "swapped" as everywhere in this file: MFMA A operand = W rows, so a
-// lane holds 4 consecutive output columns of one row).  BK = 64, two k-tile buffers of 60 KiB (A 160 rows, W 320 rows, 128-byte rows
-// with the same XOR chunk swizzle: the 16-lane groups of a ds_read_b128 of a 16x16x32 fragment (rows l % 16, chunk 4 ks + l / 16) hit 16
-// distinct bank slots, checked against the lane-group table of MI355X_MICROARCH.md).
+// lane holds 4 consecutive output columns of one row).
 //
-// Schedule (as gemm8_kernel: a phase = {LOAD: ds_reads + one DMA slot + counted vmcnt} | barrier | {MFMAs under s_setprio 1} | barrier,
-// the two wave rows one barrier apart so every SIMD has one wave on the matrix pipe and one loading):
-//   phase 0: W fragments of k-step 0 (5) + A fragments of m-blocks 0-1 (2) -> 10 MFMAs      phase 1: A m-blocks 2-4 (3) -> 15 MFMAs
-//   phase 2 / 3: the same for k-step 1.
-// DMA: a k-tile is 60 one-KiB pieces (8 rows x 128 B); they stream as 4 slots of 16 (2 per wave; 4 dummies keep every wave's vmcnt
-// arithmetic identical): q0 = W rows 0-127, q1 = W 128-255, q2 = W 256-319 + the A rows phase 0 reads (m-blocks 0-1 of both wave
-// rows), q3 = the other A rows.  Slot h = 4 kt + q is issued at LOAD(h - 5) and retired by the `vmcnt(4)` at the end of LOAD(h - 3):
-// q0-q2 of k-tile kt are published by the barrier before LOAD(0, kt), q3 by the one before LOAD(1, kt) -- data is read one phase after
-// the wait that retired it.  WAR: q0 of k-tile kt overwrites W rows of k-tile kt - 2 at LOAD(3, kt - 2); their last reader is the late
-// wave row's LOAD(2, kt - 2), retired by its lgkmcnt(0) one segment earlier (the same margin as gemm8_kernel's).
-// Epilogue: bias / alpha / temb in registers, residual(s) through the bf16 staging tile, whole-row 16-byte stores; GEGLU with the
-// weight rows ordered [160 value rows | 160 gate rows] per tile (layers.interleave_geglu(block=160)): the gate waves (n >= 160) leave
-// gelu(gate) in LDS as fp32, the value waves multiply -- one rounding, as the other arms.
+// Schedule.  The reduction is cut into 32-deep SUB-TILES (one MFMA k-step): a sub-tile is 30 KiB in LDS (A 160 rows, W 320 rows of 64
+// bytes), FIVE of them form a ring (150 KiB).  One phase per sub-tile:
+//     {LOAD: the 10 ds_read_b128 of the sub-tile's fragments + the DMA of the sub-tile THREE ahead + `s_waitcnt vmcnt(8)`} | barrier |
+//     {25 MFMAs under s_setprio 1} | barrier,
+// the two wave rows one barrier apart, so on every SIMD one wave runs its 25 MFMAs (425 cycles) while the other loads.  (The first
+// version used gemm8_kernel's 64-deep k-tiles with four 10 / 15-MFMA phases each: 2.1 us per 64-deep step = 32 % of the matrix pipe --
+// the fixed cost of a phase (two barriers, an LDS round trip, a counted vmcnt) was paid twice as often as here.)  A sub-tile's DMA is 30
+// one-KiB pieces (16 rows x 64 B; 4 instructions per wave, 2 dummies keep every wave's vmcnt arithmetic identical); sub-tile s is
+// issued at LOAD(s - 3) into buffer s % 5, whose previous content (s - 5) was last read at LOAD(s - 5): two whole phases earlier for
+// both wave rows (WAR safe with a phase to spare); `vmcnt(8)` at the end of LOAD(g) retires sub-tile g + 1, the barrier publishes it,
+// LOAD(g + 1) reads it (a wave reads DMA'd data one phase after the wait that retired it).  Past the end of K the stream wraps to
+// valid addresses so the count stays exact.
+// LDS image: 64-byte rows, 16-byte chunk c of row r at physical chunk c ^ (3 * ((r >> 3) & 1)): the four 16-lane groups of a
+// ds_read_b128 of a 16x16x32 fragment (lane l: row l % 16, chunk l / 16) then hit 16 distinct 16-byte slots of the 256-byte bank row
+// (checked against the lane-group table of MI355X_MICROARCH.md); the DMA applies the same involution to its SOURCE chunk.
+// Conv mode walks (64-channel chunk, tap, 32-channel half): the two halves of a 128-byte line are fetched in consecutive phases.
+// Epilogue: bias / alpha / temb in registers, residual(s) through the bf16 staging tile, whole-row 16-byte stores.  GEGLU: weight rows
+// ordered [8 value | 8 gate] per 16 (layers.interleave_geglu(block=8)), so lane l holds values where lane l ^ 32 holds the gates of
+// the same outputs; one v_permlane32_swap per register pair of two blocks gives every lane a (value, gate) pair -- all 64 lanes gate.
 // =====================================================================================================================
+__device__ __forceinline__ void lane32_swap(float& lo_keeps, float& hi_keeps) {
+    // lanes 0-31 of `hi_keeps` <-> lanes 32-63 of `lo_keeps`:  afterwards lo_keeps = [lo_keeps.low | hi_keeps.low], hi_keeps = [lo_keeps.high | hi_keeps.high]
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo_keeps), __float_as_uint(hi_keeps), false, false);
+    lo_keeps = __uint_as_float(r[0]);
+    hi_keeps = __uint_as_float(r[1]);
+}
+
 template <int MODE, int EPI>
 __global__ __launch_bounds__(512, 2)
 void gemm160_kernel(const GemmParams P) {
-    constexpr int BM = 160, BN = 320, BK = 64, NT = 512;
-    constexpr int STAGE_ELEMS = (BM + BN) * BK;      // 60 KiB per k-tile buffer
+    constexpr int BM = 160, BN = 320, BK = 32, NT = 512, NBUF = 5;
+    constexpr int SUB_ELEMS = (BM + BN) * BK;        // 30 KiB per sub-tile buffer
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int l15 = lane & 15, kq = lane >> 4;       // fragment row / k-group of 8 (output: column quad)
-    const int prow = lane >> 3, pch = lane & 7;      // my row / 16-byte chunk inside a 1-KiB DMA piece
+    const int l15 = lane & 15, kq = lane >> 4;       // fragment row / 16-byte k chunk (output: column quad)
+    const int prow = lane >> 2, pch = lane & 3;      // my row / physical chunk inside a 1-KiB DMA piece (16 rows x 64 B)
+    const int psrc = pch ^ (3 * ((prow >> 3) & 1));  // the LOGICAL chunk that lives there
 
-    const int nkt = P.K / BK;
+    const int nks = P.K / BK;
     int tile_m, tile_n;
     {
         const int total = P.tiles_m * P.tiles_n;
@@ -1367,55 +1379,35 @@ void gemm160_kernel(const GemmParams P) {
     const int64_t m0 = (int64_t)tile_m * BM;
     const int n0 = tile_n * BN;
 
-    // ---- my DMA pieces.  Slot q, entry i = 2 wave + j (j = 0, 1):  q0: W piece i;  q1: W piece 16 + i;  q2: i < 8: W piece 32 + i,
-    // else A early piece;  q3: i < 12: A late piece, else a dummy.  A early pieces (rows of m-blocks 0-1 of both wave rows): {0..3, 10..13};
-    // late: {4..9, 14..19}.  Per wave: W entries we = 0..5 (q0 j0, q0 j1, q1 j0, q1 j1, q2 j0, q2 j1), A entries ae = 0..3 (q2 j0/j1, q3 j0/j1).
+    // ---- my DMA pieces: entry i = 4 wave + e; i < 20: W piece i (rows 16 i ..), 20 <= i < 30: A piece i - 20, else a dummy -------------
     constexpr unsigned OOB = 0x80000000u;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)P.a, 0, (int)P.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)P.w, 0, (int)((int64_t)P.N * P.K * 2), 0x00020000);
-    unsigned w_vo[6];
-    int w_lds[6];
-#pragma unroll
-    for (int e = 0; e < 6; ++e) {
-        const int piece = (e >> 1) * 16 + 2 * wave + (e & 1);          // q2 entries only exist for waves 0-3 (piece 32..39)
-        const bool exists = piece < 40;
-        const int roww = piece * 8;
-        w_lds[e] = (BM + roww) * BK;
-        const int lw = roww + prow;
-        const int n = n0 + lw;
-        w_vo[e] = (exists && n < P.N) ? (unsigned)(((int64_t)n * P.K + swz<BK>(lw, pch) * 8) * 2) : OOB;
-        if (!exists) w_lds[e] = 2 * STAGE_ELEMS;                       // (never issued: see issue())
-    }
-    unsigned a_vo[4], a_ok[4];
-    int a_lds[4];
+    unsigned e_vo[4], e_ok[4];
+    int e_lds[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        int piece = -1;
-        if (e < 2) {                                                   // q2, entries i = 8..15 -> waves 4..7
-            const int i = 2 * wave + e - 8;
-            if (i >= 0) piece = i < 4 ? i : 6 + i;                     // {0,1,2,3, 10,11,12,13}
-        } else {                                                       // q3, entries i = 0..11 -> waves 0..5
-            const int i = 2 * wave + (e - 2);
-            if (i < 12) piece = i < 6 ? 4 + i : 8 + i;                 // {4..9, 14..19}
-        }
-        a_vo[e] = OOB; a_ok[e] = 0; a_lds[e] = 2 * STAGE_ELEMS;        // dummy: zeros into the scratch KiB behind the buffers
-        if (piece >= 0) {
-            const int rowa = piece * 8;
-            a_lds[e] = rowa * BK;
-            const int lr = rowa + prow;
-            const int sc = swz<BK>(lr, pch);
+        const int i = 4 * wave + e;
+        e_vo[e] = OOB; e_ok[e] = 0; e_lds[e] = NBUF * SUB_ELEMS;         // dummy: zeros into the scratch KiB behind the ring
+        if (i < 20) {
+            const int lw = 16 * i + prow, n = n0 + lw;
+            e_lds[e] = (BM + 16 * i) * BK;
+            e_vo[e] = n < P.N ? (unsigned)(((int64_t)n * P.K + psrc * 8) * 2) : OOB;
+        } else if (i < 30) {
+            const int lr = 16 * (i - 20) + prow;
+            e_lds[e] = 16 * (i - 20) * BK;
             const int64_t m = m0 + lr;
             const bool ok = m < P.M;
             if (MODE == 0) {
-                a_vo[e] = ok ? (unsigned)((m * P.lda + sc * 8) * 2) : OOB;
+                e_vo[e] = ok ? (unsigned)((m * P.lda + psrc * 8) * 2) : OOB;
             } else {
                 const int64_t mm = ok ? m : 0;
                 const int pix = (int)(mm % P.hw);
                 const int py = pix / P.img_w, px = pix - py * P.img_w;
                 const int64_t img = mm / P.hw;
                 if (P.ups == 1) {
-                    a_vo[e] = ok ? (unsigned)((img * (int64_t)(P.hw >> 2) * P.cin + sc * 8) * 2) : OOB;
-                    a_ok[e] = ((unsigned)py << 16) | (unsigned)px;
+                    e_vo[e] = ok ? (unsigned)((img * (int64_t)(P.hw >> 2) * P.cin + psrc * 8) * 2) : OOB;
+                    e_ok[e] = ((unsigned)py << 16) | (unsigned)px;
                 } else {
                     unsigned mask = 0;
                     for (int t = 0; t < 9; ++t) {
@@ -1424,110 +1416,86 @@ void gemm160_kernel(const GemmParams P) {
                                                    : ((unsigned)(py + dy) < (unsigned)P.img_h && (unsigned)(px + dx) < (unsigned)P.img_w);
                         mask |= (unsigned)in << t;
                     }
-                    a_ok[e] = ok ? mask : 0u;
-                    if (P.ups == 2) a_vo[e] = (unsigned)(((img * (int64_t)(P.hw << 2) + (int64_t)(2 * py) * (2 * P.img_w) + 2 * px) * P.cin + sc * 8) * 2);
-                    else a_vo[e] = (unsigned)((mm * P.cin + sc * 8) * 2);
+                    e_ok[e] = ok ? mask : 0u;
+                    if (P.ups == 2) e_vo[e] = (unsigned)(((img * (int64_t)(P.hw << 2) + (int64_t)(2 * py) * (2 * P.img_w) + 2 * px) * P.cin + psrc * 8) * 2);
+                    else e_vo[e] = (unsigned)((mm * P.cin + psrc * 8) * 2);
                 }
             }
         }
     }
-    // the k-tile the NEXT slot belongs to (scalars; past the end of K the stream wraps to valid addresses, the count stays exact)
-    int it_kt = 0, it_buf = 0, it_tap = 0, it_ci0 = 0;
+    const bool w_wave = wave < 5, a_first = wave >= 5;   // waves 0-4: four W pieces each; waves 5-7: A pieces (wave 7: two A + two dummies)
+    // the sub-tile the NEXT issue belongs to (scalars).  Conv: (64-channel chunk, tap, 32-channel half)
+    int it_s = 0, it_buf = 0, it_tap = 0, it_ci0 = 0, it_half = 0;
     auto advance = [&]() {
-        it_buf ^= 1;
-        if (++it_kt == nkt) {
-            it_kt = 0; it_tap = 0; it_ci0 = 0;
+        it_buf = it_buf + 1 == NBUF ? 0 : it_buf + 1;
+        if (++it_s == nks) {
+            it_s = 0; it_tap = 0; it_ci0 = 0; it_half = 0;
         } else if (MODE == 1) {
-            if (++it_tap == 9) {                      // (channel chunk outer, tap inner), see gemm_kernel
-                it_tap = 0;
-                it_ci0 += BK;
+            if (++it_half == 2) {
+                it_half = 0;
+                if (++it_tap == 9) { it_tap = 0; it_ci0 += 64; }
             }
         }
     };
     auto dma = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned voff, int soff, bf16_t* lds) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, (int)voff, soff, 0, 0);
     };
-    auto issue_w = [&](int e, bf16_t* stage) {
-        const int soff = (MODE == 1 ? it_tap * P.cin + it_ci0 : it_kt * BK) * 2;
-        dma(rsW, w_vo[e], soff, w_lds[e] == 2 * STAGE_ELEMS ? smem + 2 * STAGE_ELEMS : stage + w_lds[e]);
-    };
-    auto issue_a = [&](int e, bf16_t* stage) {
-        bf16_t* dst = a_lds[e] == 2 * STAGE_ELEMS ? smem + 2 * STAGE_ELEMS : stage + a_lds[e];
-        if (MODE == 0) {
-            dma(rsA, a_vo[e], it_kt * BK * 2, dst);
+    auto issue = [&]() {
+        bf16_t* stage = smem + it_buf * SUB_ELEMS;
+        const int kw = (MODE == 1 ? it_tap * P.cin + it_ci0 + it_half * 32 : it_s * BK) * 2;     // byte offset inside a W row
+        if (w_wave) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dma(rsW, e_vo[e], kw, stage + e_lds[e]);
         } else {
             const int dy = (it_tap >= 3) + (it_tap >= 6) - 1, dx = it_tap - 3 * (dy + 1) - 1;
-            unsigned vo;
-            if (P.ups == 1) {
-                const int py = (int)(a_ok[e] >> 16) + dy, px = (int)(a_ok[e] & 0xffffu) + dx;
-                const bool in = (unsigned)py < (unsigned)P.img_h && (unsigned)px < (unsigned)P.img_w;
-                vo = a_vo[e] + (unsigned)(((py >> 1) * (P.img_w >> 1) + (px >> 1)) * P.cin * 2);
-                if (!in || a_vo[e] == OOB) vo = OOB;
-            } else {
-                const int shift = (P.ups == 2 ? (dy * 2 * P.img_w + dx) : (dy * P.img_w + dx)) * P.cin * 2;
-                vo = ((a_ok[e] >> it_tap) & 1u) ? a_vo[e] + (unsigned)shift : OOB;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bf16_t* dst = e_lds[e] == NBUF * SUB_ELEMS ? smem + NBUF * SUB_ELEMS : stage + e_lds[e];
+                if (MODE == 0) {
+                    dma(rsA, e_vo[e], it_s * BK * 2, dst);
+                } else {
+                    unsigned vo;
+                    if (P.ups == 1) {
+                        const int py = (int)(e_ok[e] >> 16) + dy, px = (int)(e_ok[e] & 0xffffu) + dx;
+                        const bool in = (unsigned)py < (unsigned)P.img_h && (unsigned)px < (unsigned)P.img_w;
+                        vo = e_vo[e] + (unsigned)(((py >> 1) * (P.img_w >> 1) + (px >> 1)) * P.cin * 2);
+                        if (!in || e_vo[e] == OOB) vo = OOB;
+                    } else {
+                        const int shift = (P.ups == 2 ? (dy * 2 * P.img_w + dx) : (dy * P.img_w + dx)) * P.cin * 2;
+                        vo = ((e_ok[e] >> it_tap) & 1u) ? e_vo[e] + (unsigned)shift : OOB;
+                    }
+                    dma(rsA, vo, (it_ci0 + it_half * 32) * 2, dst);
+                }
             }
-            dma(rsA, vo, it_ci0 * 2, dst);
         }
+        advance();
     };
-    auto issue = [&](int q) {                          // q = slot of the k-tile the stream is in (a constant at every call site)
-        bf16_t* stage = smem + it_buf * STAGE_ELEMS;
-        if (q == 0) { issue_w(0, stage); issue_w(1, stage); }
-        else if (q == 1) { issue_w(2, stage); issue_w(3, stage); }
-        else if (q == 2) {
-            if (wave < 4) { issue_w(4, stage); issue_w(5, stage); }
-            else { issue_a(0, stage); issue_a(1, stage); }
-        } else {
-            issue_a(2, stage); issue_a(3, stage);      // (waves 6, 7: dummies)
-            advance();
-        }
-    };
+    (void)a_first;
 
     f32x4 acc[5][5];                                   // [mb][nb]: 4 consecutive n (registers) of row m = l15
-    bf16x8 wf[5], af[3];
-    auto read_w = [&](const bf16_t* Ws, int ks) {
+    bf16x8 wf[5], af[5];
+    // fragment address of (block row 0, my lane): row l15, logical chunk kq
+    const int frag_off = l15 * BK + (kq ^ (3 * ((l15 >> 3) & 1))) * 8;
+    auto read_frags = [&](const bf16_t* sub) {
+        const bf16_t* Ws = sub + BM * BK + (wc * 80) * BK + frag_off;
+        const bf16_t* As = sub + (wr * 80) * BK + frag_off;
 #pragma unroll
         for (int nb = 0; nb < 5; ++nb) {
-            const int rw = wc * 80 + nb * 16 + l15;
             union { bf16x8 v; u32x4 u; } t;
-            t.u = *reinterpret_cast<const u32x4*>(Ws + rw * BK + swz<BK>(rw, 4 * ks + kq) * 8);
+            t.u = *reinterpret_cast<const u32x4*>(Ws + nb * 16 * BK);
             wf[nb] = t.v;
         }
-    };
-    auto read_a = [&](const bf16_t* As, int ks, int mb0, int cnt) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            if (j < cnt) {
-                const int rm = wr * 80 + (mb0 + j) * 16 + l15;
-                union { bf16x8 v; u32x4 u; } t;
-                t.u = *reinterpret_cast<const u32x4*>(As + rm * BK + swz<BK>(rm, 4 * ks + kq) * 8);
-                af[j] = t.v;
-            }
+        for (int mb = 0; mb < 5; ++mb) {
+            union { bf16x8 v; u32x4 u; } t;
+            t.u = *reinterpret_cast<const u32x4*>(As + mb * 16 * BK);
+            af[mb] = t.v;
         }
     };
-#define G160_MMA(MB0, CNT)                                                                                           \
-    do {                                                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        __builtin_amdgcn_s_barrier();                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        __builtin_amdgcn_s_setprio(1);                                                                               \
-        _Pragma("unroll") for (int j = 0; j < (CNT); ++j)                                                            \
-            _Pragma("unroll") for (int nb = 0; nb < 5; ++nb)                                                         \
-                acc[(MB0) + j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], af[j], acc[(MB0) + j][nb], 0, 0, 0); \
-        __builtin_amdgcn_s_setprio(0);                                                                               \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        __builtin_amdgcn_s_barrier();                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-    } while (0)
-#define G160_FEED(Q)                                                                                                 \
-    do {                                                                                                             \
-        issue(Q);                                                                                                    \
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                             \
-    } while (0)
 
-    // ---- prologue: slots 0..4 (k-tile 0 + q0 of k-tile 1) in flight, q0-q2 of k-tile 0 retired and published ---------------------
-    issue(0); issue(1); issue(2); issue(3); issue(0);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // ---- prologue: sub-tiles 0, 1, 2 in flight, sub-tile 0 retired and published -----------------------------------------------------
+    issue(); issue(); issue();
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();        // wave row 1 runs one barrier behind wave row 0
     __builtin_amdgcn_sched_barrier(0);
@@ -1537,32 +1505,101 @@ void gemm160_kernel(const GemmParams P) {
         for (int b = 0; b < 5; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     __builtin_amdgcn_sched_barrier(0);
 
-    for (int kt = 0; kt < nkt; ++kt) {
-        const bf16_t* As = smem + (kt & 1) * STAGE_ELEMS;
-        const bf16_t* Ws = As + BM * BK;
-        read_w(Ws, 0);                                // phase 0
-        read_a(As, 0, 0, 2);
-        G160_FEED(1);
-        G160_MMA(0, 2);
-        read_a(As, 0, 2, 3);                          // phase 1
-        G160_FEED(2);
-        G160_MMA(2, 3);
-        read_w(Ws, 1);                                // phase 2
-        read_a(As, 1, 0, 2);
-        G160_FEED(3);
-        G160_MMA(0, 2);
-        read_a(As, 1, 2, 3);                          // phase 3
-        G160_FEED(0);
-        G160_MMA(2, 3);
+    int rbuf = 0;
+    for (int g = 0; g < nks; ++g) {
+        read_frags(smem + rbuf * SUB_ELEMS);
+        rbuf = rbuf + 1 == NBUF ? 0 : rbuf + 1;
+        issue();                                      // sub-tile g + 3
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mb = 0; mb < 5; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 5; ++nb)
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], af[mb], acc[mb][nb], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
     }
-#undef G160_MMA
-#undef G160_FEED
     if (wr == 0) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the wrap-around DMAs of the tail have landed: LDS is free for the epilogue
     __syncthreads();
 
     // ---- epilogue --------------------------------------------------------------------------------------------------------------------
-    // my outputs: acc[mb][nb][j] = out[m0 + 80 wr + 16 mb + l15][n0 + 80 wc + 16 nb + 4 kq + j]
+    // my outputs: acc[mb][nb][j] = (row m0 + 80 wr + 16 mb + l15, tile column 80 wc + 16 nb + 4 kq + j)
+    if (EPI == 1) {
+        // GEGLU.  Weight rows per 16: [8 value | 8 gate] -> lanes with kq < 2 hold values of outputs 4 kq .. 4 kq + 3 of the block, lanes with
+        // kq >= 2 (= lane + 32) the gates of the same outputs.  Blocks are paired (nb 0-1, 2-3 of a row block; the nb = 4 blocks of row
+        // blocks 0-1, 2-3; (4, 4) alone): after the half-wave swap the low lanes hold (value, gate) of the first block of a pair, the high
+        // lanes of the second.  Output column of a block: 40 wc + 8 nb + 4 (kq & 1) inside the tile's 160.
+        const bool hi = lane >= 32;
+        const int oq = 4 * (kq & 1);
+        auto gate_pair = [&](f32x4& x, f32x4& y, int mbx, int nbx, int mby, int nby, bool single) {
+            // x, y: two blocks; returns in x the gated outputs of (hi ? block y : block x), row / column through the out-params below
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                                 // x = [x.value | y.value], y = [x.gate | y.gate]
+                float xa = x[j], ya = y[j];
+                lane32_swap(xa, ya);
+                x[j] = xa; y[j] = ya;
+            }
+            const int nbm = hi ? nby : nbx;
+            const int tn = wc * 80 + nbm * 16;                            // first weight row of my block inside the tile
+            float o[4];
+            if (P.f32io) {
+                const float* bias = reinterpret_cast<const float*>(P.bias);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float gg = y[j] + (bias ? bias[n0 + tn + 8 + oq + j] : 0.f);
+                    o[j] = (x[j] + (bias ? bias[n0 + tn + oq + j] : 0.f)) * (0.5f * gg * (1.f + erff(gg * 0.70710678118654752f)));
+                }
+            } else {
+                float bv[4] = {0.f, 0.f, 0.f, 0.f}, bg[4] = {0.f, 0.f, 0.f, 0.f};
+                if (P.bias) {
+                    const u32x2 t = *reinterpret_cast<const u32x2*>(P.bias + n0 + tn + oq);
+                    const u32x2 u = *reinterpret_cast<const u32x2*>(P.bias + n0 + tn + 8 + oq);
+                    bv[0] = __uint_as_float(t[0] << 16); bv[1] = __uint_as_float(t[0] & 0xffff0000u);
+                    bv[2] = __uint_as_float(t[1] << 16); bv[3] = __uint_as_float(t[1] & 0xffff0000u);
+                    bg[0] = __uint_as_float(u[0] << 16); bg[1] = __uint_as_float(u[0] & 0xffff0000u);
+                    bg[2] = __uint_as_float(u[1] << 16); bg[3] = __uint_as_float(u[1] & 0xffff0000u);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (x[j] + bv[j]) * gelu_erf(y[j] + bg[j]);
+            }
+            const int mbm = hi ? mby : mbx;
+            const int row = wr * 80 + mbm * 16 + l15, col = wc * 40 + nbm * 8 + oq;      // inside the tile's [160][160] outputs
+            if (single && hi) return;                                     // (the unpaired block: the high lanes hold nothing)
+            if (P.f32io) {
+                const int64_t m = m0 + row;
+                if (m < P.M) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(P.out) + m * P.ldo + n0 / 2 + col) = f32x4{o[0], o[1], o[2], o[3]};
+            } else {
+                *reinterpret_cast<u32x2*>(smem + row * 168 + col) = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+            }
+        };
+#pragma unroll
+        for (int mb = 0; mb < 5; ++mb) {
+            gate_pair(acc[mb][0], acc[mb][1], mb, 0, mb, 1, false);
+            gate_pair(acc[mb][2], acc[mb][3], mb, 2, mb, 3, false);
+        }
+        gate_pair(acc[0][4], acc[1][4], 0, 4, 1, 4, false);
+        gate_pair(acc[2][4], acc[3][4], 2, 4, 3, 4, false);
+        {
+            f32x4 none = f32x4{0.f, 0.f, 0.f, 0.f};
+            gate_pair(acc[4][4], none, 4, 4, 4, 4, true);
+        }
+        if (P.f32io) return;
+        __syncthreads();
+        for (int c = tid; c < BM * 20; c += NT) {                          // 160 rows x 20 chunks of 8 outputs
+            const int r = c / 20, ch = c - r * 20;
+            const int64_t m = m0 + r;
+            if (m < P.M)
+                *reinterpret_cast<u32x4*>(P.out + m * P.ldo + n0 / 2 + ch * 8) = *reinterpret_cast<const u32x4*>(smem + r * 168 + ch * 8);
+        }
+        return;
+    }
     if (P.f32io) {                                    // fp32-storage mode: see epi_f32_quad
 #pragma unroll
         for (int mb = 0; mb < 5; ++mb) {
@@ -1570,102 +1607,8 @@ void gemm160_kernel(const GemmParams P) {
 #pragma unroll
             for (int nb = 0; nb < 5; ++nb) {
                 const float a4[4] = {acc[mb][nb][0], acc[mb][nb][1], acc[mb][nb][2], acc[mb][nb][3]};
-                const int tn = wc * 80 + nb * 16 + 4 * kq;     // column inside the tile
-                if (EPI == 1) {
-                    // (fp32 parity mode keeps it simple: gate columns through LDS as below would need the same code; the gate waves
-                    // write, the value waves read -- done here with the same staging region, fp32)
-                    float* G = reinterpret_cast<float*>(smem_raw);
-                    if (wc >= 2) *reinterpret_cast<f32x4*>(G + (wr * 80 + mb * 16 + l15) * 164 + (tn - 160)) = f32x4{a4[0], a4[1], a4[2], a4[3]};
-                } else {
-                    epi_f32_quad<MODE>(P, a4, m, n0 + tn);
-                }
+                epi_f32_quad<MODE>(P, a4, m, n0 + wc * 80 + nb * 16 + 4 * kq);
             }
-        }
-        if (EPI == 1) {
-            __syncthreads();
-            const float* G = reinterpret_cast<const float*>(smem_raw);
-            if (wc < 2) {
-#pragma unroll
-                for (int mb = 0; mb < 5; ++mb) {
-                    const int64_t m = m0 + wr * 80 + mb * 16 + l15;
-#pragma unroll
-                    for (int nb = 0; nb < 5; ++nb) {
-                        const int tn = wc * 80 + nb * 16 + 4 * kq;
-                        const f32x4 g = *reinterpret_cast<const f32x4*>(G + (wr * 80 + mb * 16 + l15) * 164 + tn);
-                        const float av[4] = {acc[mb][nb][0], acc[mb][nb][1], acc[mb][nb][2], acc[mb][nb][3]};
-                        const float ag[4] = {g[0], g[1], g[2], g[3]};
-                        // weight rows of tile t: [320 t, 320 t + 160) value, [+160, +320) gate -> bias of the gate = bias[.. + 160]
-                        if (m < P.M && n0 / 2 + tn < P.N / 2) {
-                            const float* bias = reinterpret_cast<const float*>(P.bias);
-                            float* out = reinterpret_cast<float*>(P.out);
-                            f32x4 v;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const float gg = ag[j] + (bias ? bias[n0 + 160 + tn + j] : 0.f);
-                                v[j] = (av[j] + (bias ? bias[n0 + tn + j] : 0.f)) * (0.5f * gg * (1.f + erff(gg * 0.70710678118654752f)));
-                            }
-                            *reinterpret_cast<f32x4*>(out + m * P.ldo + n0 / 2 + tn) = v;
-                        }
-                    }
-                }
-            }
-        }
-        return;
-    }
-    if (EPI == 1) {
-        // GEGLU: tile columns [0, 160) = value, [160, 320) = gate of the SAME 160 outputs.  Two passes of 80 rows (one wave row each):
-        // gate waves leave gelu(gate + bias) as fp32 in G [80][164], value waves multiply and stage bf16 in Os [80][168], then whole rows leave.
-        float* G = reinterpret_cast<float*>(smem_raw);                     // 52 480 B
-        bf16_t* Os = reinterpret_cast<bf16_t*>(smem_raw + 80 * 164 * 4);   // 26 880 B
-        constexpr int OP = 168;
-#pragma unroll 1
-        for (int pass = 0; pass < 2; ++pass) {
-            if (wr == pass && wc >= 2) {
-#pragma unroll
-                for (int nb = 0; nb < 5; ++nb) {
-                    const int tn = (wc - 2) * 80 + nb * 16 + 4 * kq;
-                    float bg[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (P.bias) {
-                        const u32x2 t = *reinterpret_cast<const u32x2*>(P.bias + min(n0 + 160 + tn, P.N - 4));
-                        bg[0] = __uint_as_float(t[0] << 16); bg[1] = __uint_as_float(t[0] & 0xffff0000u);
-                        bg[2] = __uint_as_float(t[1] << 16); bg[3] = __uint_as_float(t[1] & 0xffff0000u);
-                    }
-#pragma unroll
-                    for (int mb = 0; mb < 5; ++mb)
-                        *reinterpret_cast<f32x4*>(G + (mb * 16 + l15) * 164 + tn) =
-                            f32x4{gelu_erf(acc[mb][nb][0] + bg[0]), gelu_erf(acc[mb][nb][1] + bg[1]), gelu_erf(acc[mb][nb][2] + bg[2]),
-                                  gelu_erf(acc[mb][nb][3] + bg[3])};
-                }
-            }
-            __syncthreads();
-            if (wr == pass && wc < 2) {
-#pragma unroll
-                for (int nb = 0; nb < 5; ++nb) {
-                    const int tn = wc * 80 + nb * 16 + 4 * kq;
-                    float ba[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (P.bias) {
-                        const u32x2 t = *reinterpret_cast<const u32x2*>(P.bias + min(n0 + tn, P.N - 4));
-                        ba[0] = __uint_as_float(t[0] << 16); ba[1] = __uint_as_float(t[0] & 0xffff0000u);
-                        ba[2] = __uint_as_float(t[1] << 16); ba[3] = __uint_as_float(t[1] & 0xffff0000u);
-                    }
-#pragma unroll
-                    for (int mb = 0; mb < 5; ++mb) {
-                        const f32x4 g = *reinterpret_cast<const f32x4*>(G + (mb * 16 + l15) * 164 + tn);
-                        *reinterpret_cast<u32x2*>(Os + (mb * 16 + l15) * OP + tn) =
-                            u32x2{pack_bf2((acc[mb][nb][0] + ba[0]) * g[0], (acc[mb][nb][1] + ba[1]) * g[1]),
-                                  pack_bf2((acc[mb][nb][2] + ba[2]) * g[2], (acc[mb][nb][3] + ba[3]) * g[3])};
-                    }
-                }
-            }
-            __syncthreads();
-            for (int c = tid; c < 80 * 20; c += NT) {                     // 80 rows x 20 chunks of 8 outputs
-                const int r = c / 20, ch = c - r * 20;
-                const int64_t m = m0 + pass * 80 + r;
-                const int no = n0 / 2 + ch * 8;
-                if (m < P.M && no < P.N / 2)
-                    *reinterpret_cast<u32x4*>(P.out + m * P.ldo + no) = *reinterpret_cast<const u32x4*>(Os + r * OP + ch * 8);
-            }
-            __syncthreads();
         }
         return;
     }
@@ -1679,7 +1622,7 @@ void gemm160_kernel(const GemmParams P) {
             const int n = n0 + wc * 80 + nb * 16 + 4 * kq;
             float b4[4] = {0.f, 0.f, 0.f, 0.f};
             if (P.bias) {
-                const u32x2 t = *reinterpret_cast<const u32x2*>(P.bias + min(n, P.N - 4));
+                const u32x2 t = *reinterpret_cast<const u32x2*>(P.bias + n);
                 b4[0] = __uint_as_float(t[0] << 16); b4[1] = __uint_as_float(t[0] & 0xffff0000u);
                 b4[2] = __uint_as_float(t[1] << 16); b4[3] = __uint_as_float(t[1] & 0xffff0000u);
             }
@@ -1688,7 +1631,7 @@ void gemm160_kernel(const GemmParams P) {
                 float t4[4] = {0.f, 0.f, 0.f, 0.f};
                 if (MODE == 1 && P.temb) {
                     const int64_t m = min(m0 + wr * 80 + mb * 16 + l15, P.M - 1);
-                    const u32x2 t = *reinterpret_cast<const u32x2*>(P.temb + ((m / P.hw) / P.temb_div) * P.temb_ld + min(n, P.N - 4));
+                    const u32x2 t = *reinterpret_cast<const u32x2*>(P.temb + ((m / P.hw) / P.temb_div) * P.temb_ld + n);
                     t4[0] = __uint_as_float(t[0] << 16); t4[1] = __uint_as_float(t[0] & 0xffff0000u);
                     t4[2] = __uint_as_float(t[1] << 16); t4[3] = __uint_as_float(t[1] & 0xffff0000u);
                 }
@@ -1704,7 +1647,7 @@ void gemm160_kernel(const GemmParams P) {
             for (int c = tid; c < BM * CPR; c += NT) {
                 const int r = c / CPR, ch = c - r * CPR;
                 *reinterpret_cast<u32x4*>(Os + r * OP + ch * 8) =
-                    *reinterpret_cast<const u32x4*>(rp + min(m0 + r, P.M - 1) * P.ldres + min(n0 + ch * 8, P.N - 8));
+                    *reinterpret_cast<const u32x4*>(rp + min(m0 + r, P.M - 1) * P.ldres + n0 + ch * 8);
             }
             __syncthreads();
 #pragma unroll
@@ -1727,9 +1670,8 @@ void gemm160_kernel(const GemmParams P) {
         for (int c = tid; c < BM * CPR; c += NT) {
             const int r = c / CPR, ch = c - r * CPR;
             const int64_t m = m0 + r;
-            const int n = n0 + ch * 8;
-            if (m < P.M && n < P.N)
-                *reinterpret_cast<u32x4*>(P.out + m * P.ldo + n) = *reinterpret_cast<const u32x4*>(Os + r * OP + ch * 8);
+            if (m < P.M)
+                *reinterpret_cast<u32x4*>(P.out + m * P.ldo + n0 + ch * 8) = *reinterpret_cast<const u32x4*>(Os + r * OP + ch * 8);
         }
     }
 }
@@ -2180,7 +2122,7 @@ void launch_gemm_k320(GemmParams& P, hipStream_t st) {
     }
 }
 
-// arm 16: plain grid only (whole rounds are the point); N must be a multiple of 320 (GEGLU: weight rows per tile = [160 value | 160 gate])
+// tile 16: plain grid only (whole rounds are the point); N must be a multiple of 320 (GEGLU: weight rows per 16 = [8 value | 8 gate])
 bool gemm160_ok(const GemmParams& P) {
     return P.N % 320 == 0 && P.split_k == 1 && !P.sk && !P.a2;
 }
@@ -2197,7 +2139,7 @@ void launch_gemm160(GemmParams& P, hipStream_t st) {
         const int gm = (int)lround(sqrt(c * 2.0));
         if (gm > 1 && P.tiles_n * 2 > 3 * (c / gm)) P.group_m = gm;
     }
-    constexpr size_t lds = (size_t)2 * (160 + 320) * 64 * sizeof(bf16_t) + 1024;          // two k-tile buffers + the dummies' KiB
+    constexpr size_t lds = (size_t)5 * (160 + 320) * 32 * sizeof(bf16_t) + 1024;          // five sub-tile buffers + the dummies' KiB
     static_assert(lds >= (size_t)160 * 328 * 2 && lds >= (size_t)160 * 164 * 4, "epilogue staging fits the operand buffers");
     static bool raised = false;
     if (!raised) {

@@ -1145,7 +1145,7 @@ def geglu_linear(x: torch.Tensor, weight: torch.Tensor, bias, weight_il: torch.T
                  bias_il160=None) -> torch.Tensor:
     """GEGLU feed-forward input projection: `a * gelu(g)`, `a, g = (x @ weight^T + bias).chunk(2)`.  `weight_il` /
     `bias_il` are the tile-interleaved copies the fused kernel wants (`models.layers.interleave_geglu`); `weight_il160` /
-    `bias_il160` the [160 value | 160 gate] order of arm 16 (without them arm 16 is not a candidate)."""
+    `bias_il160` the [8 value | 8 gate]-per-16 order of the 160 x 320 arm (without them arm 16 is not a candidate)."""
     import torch.nn.functional as F
     lib = lambda: geglu(F.linear(x, weight, bias))
     if (F32_GEMM and x.is_cuda and x.dtype == torch.float32 and weight_il.dtype == torch.float32 and weight_il.shape[0] % 64 == 0

@@ -388,7 +388,7 @@ class Attention(nn.Module):
 def interleave_geglu(weight: torch.Tensor, bias: Optional[torch.Tensor], block: int = 32):
     """Row order `fmc_linear_bf16(epilogue=GEGLU)` expects: per 2 * block rows, `block` value rows then their `block` gate rows.
     block = 32 (the default: any tile width that is a multiple of 64 holds matching value / gate columns) for every arm but
-    16, whose 160 x 320 tiles want [160 value | 160 gate] (block = 160)."""
+    16, whose 16-wide MFMA blocks want [8 value | 8 gate] (block = 8)."""
     two_cff, k = weight.shape
     cff = two_cff // 2
     assert cff % block == 0
@@ -412,7 +412,7 @@ class GEGLU(nn.Module):
             if hit is None or hit[0] != key:
                 with torch.no_grad():
                     b = None if self.proj.bias is None else self.proj.bias.detach()
-                    il160 = interleave_geglu(w.detach(), b, 160) if (w.shape[0] // 2) % 160 == 0 else (None, None)
+                    il160 = interleave_geglu(w.detach(), b, 8) if (w.shape[0] // 2) % 160 == 0 else (None, None)
                     hit = (key, interleave_geglu(w.detach(), b) + il160)
                 self.__dict__["_il"] = hit
             return K.geglu_linear(hidden_states, w, self.proj.bias, hit[1][0], hit[1][1], hit[1][2], hit[1][3])

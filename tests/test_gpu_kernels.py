@@ -1132,7 +1132,7 @@ def test_f32_front_ends_take_the_split3_path(K):
 # ---------------------------------------------------------------------------------------------
 def test_gemm_160x320_arm(K):
     """Ragged M (partial last tile), 1 / 2 / 3 / 8 column tiles, K from one k-tile up, every epilogue (bias, alpha, one / two
-    residuals, GEGLU with the [160 value | 160 gate] row order), the conv loader (plain, + temb, + residual, upsample, stride 2),
+    residuals, GEGLU with the [8 value | 8 gate] row order), the conv loader (plain, + temb, + residual, upsample, stride 2),
     the fp32-storage mode, determinism, repeated launches on fresh data (a racy schedule shows as rare wrong tiles), and the
     fall-back when N is not a multiple of 320."""
     dtype = torch.bfloat16
@@ -1165,7 +1165,7 @@ def test_gemm_160x320_arm(K):
         go, gd = rnd((N, Kd), 42, dtype, scale=Kd ** -0.5)
         gbo, gbd = rnd((N,), 40, dtype)
         xo, xd = rnd((M, Kd), 41, dtype)
-        wi, bi = interleave_geglu(gd, gbd, 160)
+        wi, bi = interleave_geglu(gd, gbd, 8)
         a, g = F.linear(xo.double(), go.double(), gbo.double()).chunk(2, dim=-1)
         ma, mg = (xo.abs().double() @ go.abs().double().t() + gbo.abs()).chunk(2, dim=-1)
         outg = K.linear_bf16(xd, wi, bi, geglu=True, tile=512)
@@ -1208,7 +1208,7 @@ def test_gemm_160x320_arm(K):
     assert_f32_close(got, 0.5 * (F.linear(x.double(), w.double()) + b.double()) + r.double(),
                      0.5 * (x.abs().double() @ w.abs().double().t() + b.abs()) + r.abs(), "arm 16 fp32")
     gw, gb = torch.randn(640, 320, generator=g) * 320 ** -0.5, torch.randn(640, generator=g)
-    wi, bi = interleave_geglu(gw.cuda(), gb.cuda(), 160)
+    wi, bi = interleave_geglu(gw.cuda(), gb.cuda(), 8)
     a, gt = F.linear(x.double(), gw.double(), gb.double()).chunk(2, dim=-1)
     ma, mg = (x.abs().double() @ gw.abs().double().t() + gb.abs()).chunk(2, dim=-1)
     got = K.linear_f32(x.cuda(), wi, bi, geglu=True, tile=512)

@@ -23,7 +23,7 @@ def lin(M, N, Kd, bias=True, res=False, geglu=False):
     out = {}
     if geglu:
         w32, b32 = interleave_geglu(w, b)
-        w160, b160 = interleave_geglu(w, b, 160)
+        w160, b160 = interleave_geglu(w, b, 8)
     for t in ARMS:
         if t == 15 and (geglu or Kd != 320 or N % 320):
             continue
