@@ -1327,26 +1327,28 @@ void gemm8_kernel(const GemmParams P) {
 // is not a multiple of 32, hence the 16-wide MFMA; products are "swapped" as everywhere in this file: MFMA A operand = W rows, so a
 // lane holds 4 consecutive output columns of one row).
 //
-// Operand path: REGISTER staged, not LDS-DMA.  Measured on this kernel (tools/probe_g160_dbg*.py, knock-outs of the main loop): the
-// `buffer_load ... lds` stream of the first two versions took 221 us of a 222 us launch on its own -- with or without the MFMAs, with or
-// without the waits, on 8 workgroups or on 256: the LDS-DMA path moves ~12-16 bytes per clock and CU (one lane's dwordx4 per cycle), i.e.
-// 6-9 TB/s chip-wide whatever the caches do.  That is the "operand stream" ceiling every DMA-fed kernel of this file sits under (the
-// 256 x 256 8-phase kernel needs 32 B/clk for a busy matrix pipe and gets 17).  Ordinary vector loads return 64 B/clk/CU and ds_write_b128
-// stores ~80 B/clk, so the sub-tiles travel global -> VGPRs -> LDS here.
-//
-// Schedule.  The reduction is cut into 32-deep SUB-TILES (one MFMA k-step): a sub-tile is 30 KiB (A 160 rows, W 320 rows of 64 bytes) =
-// 30 one-KiB pieces of 16 rows, 4 per wave (2 dummies keep every wave's vmcnt arithmetic identical).  A wave keeps THREE sub-tiles in
-// flight in 3 x 16 registers; LDS holds two sub-tile buffers (60 KiB).  One phase per sub-tile g:
-//     {LOAD: the 10 ds_read_b128 of sub-tile g's fragments; `s_waitcnt vmcnt(8)` -> my pieces of sub-tile g + 1 have arrived: 4
-//      ds_write_b128 into the other buffer; 4 buffer_load_dwordx4 of sub-tile g + 4 into the registers just freed; lgkmcnt(0)} | barrier |
+// Schedule.  The reduction is cut into 32-deep SUB-TILES (one MFMA k-step): a sub-tile is 30 KiB in LDS (A 160 rows, W 320 rows of 64
+// bytes), FIVE of them form a ring (150 KiB).  One phase per sub-tile:
+//     {LOAD: the 10 ds_read_b128 of the sub-tile's fragments + the DMA of the sub-tile THREE ahead + `s_waitcnt vmcnt(8)`} | barrier |
 //     {25 MFMAs under s_setprio 1} | barrier,
-// the two wave rows one barrier apart, so on every SIMD one wave runs its 25 MFMAs (425 cycles) while the other loads.  A load has
-// three phases to land.  LDS hazards: sub-tile g + 1 overwrites g - 1, whose reads (both wave rows) were retired by the lgkmcnt(0) in
-// front of the barrier that ended LOAD(g - 1); its writes are retired the same way before the barrier LOAD(g + 1) starts behind.
+// the two wave rows one barrier apart, so on every SIMD one wave runs its 25 MFMAs (425 cycles) while the other loads.  (The first
+// version used gemm8_kernel's 64-deep k-tiles with four 10 / 15-MFMA phases each: 2.1 us per 64-deep step = 32 % of the matrix pipe --
+// the fixed cost of a phase (two barriers, an LDS round trip, a counted vmcnt) was paid twice as often as here.)  A sub-tile's DMA is 30
+// one-KiB pieces (16 rows x 64 B; 4 instructions per wave, 2 dummies keep every wave's vmcnt arithmetic identical); sub-tile s is
+// issued at LOAD(s - 3) into buffer s % 5, whose previous content (s - 5) was last read at LOAD(s - 5): two whole phases earlier for
+// both wave rows (WAR safe with a phase to spare); `vmcnt(8)` at the end of LOAD(g) retires sub-tile g + 1, the barrier publishes it,
+// LOAD(g + 1) reads it (a wave reads DMA'd data one phase after the wait that retired it).  Past the end of K the stream wraps to
+// valid addresses so the count stays exact.
+// What bounds the loop (measured, tools/probe_g160_dbg*.py + tools/ubench/cu_bw): the DMA instruction stream.  With the 32 DMA
+// instructions per sub-tile and CU taken out, the conv 32x20x32 640->640 launch drops from 222 to 113 us; with them in but pointed out of
+// range (no memory traffic at all) it stays at 194; the stream alone (no MFMA, no ds_read, no barrier, no wait) takes 221 us on 8
+// workgroups and on 256.  So it is neither HBM / Infinity Cache / L2 bandwidth nor latency, but ~15 ns per `buffer_load ... lds` wave
+// instruction and CU, serial to the matrix work.  Tried on top and dropped: a register-staged stream (global -> VGPR ring of 3
+// sub-tiles -> ds_write_b128, 2 LDS buffers; latency-bound at the same ~1.2 us per sub-tile: 217 vs 198 us), half of the DMAs behind the
+// wave's own MFMAs (no change), reduction start offsets skewed across the co-resident workgroups (no change).
 // LDS image: 64-byte rows, 16-byte chunk c of row r at physical chunk c ^ (3 * ((r >> 3) & 1)): the four 16-lane groups of a
 // ds_read_b128 of a 16x16x32 fragment (lane l: row l % 16, chunk l / 16) then hit 16 distinct 16-byte slots of the 256-byte bank row
-// (checked against the lane-group table of MI355X_MICROARCH.md); a piece's ds_write_b128 (lane l: row l / 4, physical chunk l % 4)
-// writes 8-lane groups of 128 contiguous bytes.  Past the end of K the load stream wraps to valid addresses so the count stays exact.
+// (checked against the lane-group table of MI355X_MICROARCH.md); the DMA applies the same involution to its SOURCE chunk.
 // Conv mode walks (64-channel chunk, tap, 32-channel half): the two halves of a 128-byte line are fetched in consecutive phases.
 // Epilogue: bias / alpha / temb in registers, residual(s) through the bf16 staging tile, whole-row 16-byte stores.  GEGLU: weight rows
 // ordered [8 value | 8 gate] per 16 (layers.interleave_geglu(block=8)), so lane l holds values where lane l ^ 32 holds the gates of
@@ -1362,7 +1364,7 @@ __device__ __forceinline__ void lane32_swap(float& lo_keeps, float& hi_keeps) {
 template <int MODE, int EPI>
 __global__ __launch_bounds__(512, 2)
 void gemm160_kernel(const GemmParams P) {
-    constexpr int BM = 160, BN = 320, BK = 32, NT = 512, NBUF = 2;
+    constexpr int BM = 160, BN = 320, BK = 32, NT = 512, NBUF = 5;
     constexpr int SUB_ELEMS = (BM + BN) * BK;        // 30 KiB per sub-tile buffer
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
@@ -1393,7 +1395,7 @@ void gemm160_kernel(const GemmParams P) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int i = 4 * wave + e;
-        e_vo[e] = OOB; e_ok[e] = 0; e_lds[e] = NBUF * SUB_ELEMS;         // dummy: loaded (zeros, out of range) for the count, never stored
+        e_vo[e] = OOB; e_ok[e] = 0; e_lds[e] = NBUF * SUB_ELEMS;         // dummy: zeros into the scratch KiB behind the ring
         if (i < 20) {
             const int lw = 16 * i + prow, n = n0 + lw;
             e_lds[e] = (BM + 16 * i) * BK;
@@ -1442,18 +1444,22 @@ void gemm160_kernel(const GemmParams P) {
             }
         }
     };
-    // ---- operand stream: 4 x 16-byte loads per wave and sub-tile into a register set --------------------------------------------------
-    auto fetch = [&](u32x4 (&set)[4]) {
+    auto dma = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned voff, int soff, bf16_t* lds) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, (int)voff, soff, 0, 0);
+    };
+    auto issue = [&]() {
+        bf16_t* stage = smem + it_buf * SUB_ELEMS;
         const int kw = (MODE == 1 ? it_tap * P.cin + it_ci0 + it_half * 32 : it_s * BK) * 2;     // byte offset inside a W row
         if (w_wave) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) set[e] = __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)e_vo[e], kw, 0);
+            for (int e = 0; e < 4; ++e) dma(rsW, e_vo[e], kw, stage + e_lds[e]);
         } else {
             const int dy = (it_tap >= 3) + (it_tap >= 6) - 1, dx = it_tap - 3 * (dy + 1) - 1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+                bf16_t* dst = e_lds[e] == NBUF * SUB_ELEMS ? smem + NBUF * SUB_ELEMS : stage + e_lds[e];
                 if (MODE == 0) {
-                    set[e] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)e_vo[e], it_s * BK * 2, 0);
+                    dma(rsA, e_vo[e], it_s * BK * 2, dst);
                 } else {
                     unsigned vo;
                     if (P.ups == 1) {
@@ -1465,18 +1471,11 @@ void gemm160_kernel(const GemmParams P) {
                         const int shift = (P.ups == 2 ? (dy * 2 * P.img_w + dx) : (dy * P.img_w + dx)) * P.cin * 2;
                         vo = ((e_ok[e] >> it_tap) & 1u) ? e_vo[e] + (unsigned)shift : OOB;
                     }
-                    set[e] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)vo, (it_ci0 + it_half * 32) * 2, 0);
+                    dma(rsA, vo, (it_ci0 + it_half * 32) * 2, dst);
                 }
             }
         }
         advance();
-    };
-    // my 16 bytes of piece e land at (row prow, physical chunk pch) of the piece: element offset e_lds[e] + prow * 32 + pch * 8
-    const int st_off = prow * BK + pch * 8;
-    auto stash = [&](const u32x4 (&set)[4], bf16_t* sub) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (e_lds[e] != NBUF * SUB_ELEMS) *reinterpret_cast<u32x4*>(sub + e_lds[e] + st_off) = set[e];     // (wave-uniform: dummies are dropped)
     };
     (void)a_first;
 
@@ -1501,13 +1500,9 @@ void gemm160_kernel(const GemmParams P) {
         }
     };
 
-    // ---- prologue: sub-tiles 0, 1, 2 requested; sub-tile 0 into LDS buffer 0 and published; sub-tile 3 requested ----------------------
-    u32x4 s0[4], s1[4], s2[4];
-    fetch(s0); fetch(s1); fetch(s2);
+    // ---- prologue: sub-tiles 0, 1, 2 in flight, sub-tile 0 retired and published -----------------------------------------------------
+    issue(); issue(); issue();
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    stash(s0, smem);
-    fetch(s0);                                        // sub-tile 3
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();        // wave row 1 runs one barrier behind wave row 0
     __builtin_amdgcn_sched_barrier(0);
@@ -1517,17 +1512,12 @@ void gemm160_kernel(const GemmParams P) {
         for (int b = 0; b < 5; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     __builtin_amdgcn_sched_barrier(0);
 
-    // phase g: `nxt` holds sub-tile g + 1 (the oldest request in flight); it is written to the other LDS buffer and re-used for g + 4
-    auto phase = [&](int g, u32x4 (&nxt)[4]) {
-        bf16_t* cur = smem + (g & 1) * SUB_ELEMS;
-        bf16_t* oth = smem + ((g + 1) & 1) * SUB_ELEMS;
-        read_frags(cur);
+    int rbuf = 0;
+    for (int g = 0; g < nks; ++g) {
+        read_frags(smem + rbuf * SUB_ELEMS);
+        rbuf = rbuf + 1 == NBUF ? 0 : rbuf + 1;
+        issue();                                      // sub-tile g + 3
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        stash(nxt, oth);
-        __builtin_amdgcn_sched_barrier(0);
-        fetch(nxt);                                   // sub-tile g + 4
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -1541,14 +1531,9 @@ void gemm160_kernel(const GemmParams P) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-    };
-    for (int g = 0; g < nks; g += 3) {                // sub-tile s lives in register set s % 3: s1 holds g + 1 at g = 0 (mod 3)
-        phase(g, s1);
-        if (g + 1 < nks) phase(g + 1, s2);
-        if (g + 2 < nks) phase(g + 2, s0);
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the wrap-around requests of the tail)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the wrap-around DMAs of the tail have landed: LDS is free for the epilogue
     __syncthreads();
 
     // ---- epilogue --------------------------------------------------------------------------------------------------------------------
@@ -2161,7 +2146,7 @@ void launch_gemm160(GemmParams& P, hipStream_t st) {
         const int gm = (int)lround(sqrt(c * 2.0));
         if (gm > 1 && P.tiles_n * 2 > 3 * (c / gm)) P.group_m = gm;
     }
-    constexpr size_t lds = (size_t)160 * 328 * sizeof(bf16_t);           // the epilogue's staging tile; the two 30-KiB sub-tile buffers alias it
+    constexpr size_t lds = (size_t)5 * (160 + 320) * 32 * sizeof(bf16_t) + 1024;          // five sub-tile buffers + the dummies' KiB
     static_assert(lds >= (size_t)160 * 328 * 2 && lds >= (size_t)160 * 164 * 4, "epilogue staging fits the operand buffers");
     static bool raised = false;
     if (!raised) {
