@@ -669,6 +669,8 @@ def main():
                     help="which BASELINE.json configuration: obj = configs[3], the metric's workload (default); cam = configs[2] (CMC only); "
                          "lora = configs[1] (Domain-LoRA only, 50-step DDIM loop); train32 = configs[4] (32x512x512 stage-3 training step, "
                          "fp8 temporal attention; = --mode train --clip 32x512x512 --fp8-temporal)")
+    ap.add_argument("--no-cfg-shared", action="store_true", help="A/B: compute the CFG batch's identical prefix (conv_in, first ResNet block, "
+                    "first self-attention) for both halves instead of once")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo stub of the launcher + timing + JSON plumbing (tests)")
     args = ap.parse_args()
     if args.dry_run:
@@ -739,6 +741,8 @@ def main():
     latents = clip["latents"].to(device).float().contiguous()
     x_shape = (2,) + tuple(latents.shape[1:])
     parity, cpu, parity_tol = None, None, (4e-2 if dtype == torch.bfloat16 else 1e-3)
+    # every step feeds the U-Net cat([latents, latents]) (as the reference pipeline does): the prefix the two halves share runs once
+    unet.cfg_shared_input = not args.no_cfg_shared
     with torch.no_grad():
         runner = _GraphedUNet(unet, x_shape, text2, pose_feats, traj_feats, dtype)
         if args.no_graph:
@@ -802,6 +806,9 @@ def main():
         roof_temp = measure_temporal_roofline(device, dtype) if bf else None
         f_ref = unet_flops(2, HEIGHT // 8, WIDTH // 8, config=cfg)
         f_exec = unet_flops(2, HEIGHT // 8, WIDTH // 8, executed=True, config=cfg)
+        if unet.cfg_shared_input:                       # one clip's worth of conv_in, ResNet block 0, proj_in, QKV, self-attention, out-projection
+            toks, c0 = FRAMES * (HEIGHT // 8) * (WIDTH // 8), WIDTHS[0]
+            f_exec -= 2.0 * toks * (9 * 4 * c0 + 2 * 9 * c0 * c0 + c0 * c0 + 3 * c0 * c0 + c0 * c0) + 4.0 * FRAMES * ((HEIGHT // 8) * (WIDTH // 8)) ** 2 * c0
         ms = elapsed / args.steps * 1e3
         out = {
             "metric": CONFIGS[cfg]["metric"],
@@ -811,6 +818,7 @@ def main():
             "config": {"workload": CONFIGS[cfg]["workload"], "baseline_config": cfg,
                        "frames": FRAMES, "height": HEIGHT, "width": WIDTH, "guidance_scale": args.guidance,
                        "hip_graph": not args.no_graph, "fp8_temporal_attention": args.fp8_temporal,
+                       "cfg_shared_prefix": bool(unet.cfg_shared_input),
                        "parallelism": f"dp{world} (independent clips, no collective)"},
             "parity_rel_inf": parity, "parity_gate": parity_tol if parity is not None else None,
             "parity_note": ("max|eps_gpu - eps_oracle| / max|eps_oracle| for one CFG-batch-2 step (t = 801) of the benchmarked "

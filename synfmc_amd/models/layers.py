@@ -249,6 +249,8 @@ class ResnetBlock2D(nn.Module):
         t, div = None, 1
         if self._t_pre is not None:
             t, div = self._t_pre
+            if t.shape[0] * div > input_tensor.shape[0]:               # shared CFG prefix: the block sees one half of the batch
+                t = t[: input_tensor.shape[0] // div]
         elif self.time_emb_proj is not None and temb is not None:
             t = self.time_emb_proj(F.silu(temb))                       # [N, Cout], rides in conv1's epilogue
         if skip is not None and self.conv_shortcut is None:
@@ -453,12 +455,15 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim, dropout=dropout, activation_fn=activation_fn, final_dropout=final_dropout)
 
     def forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None,
-                encoder_attention_mask=None, timestep=None, cross_attention_kwargs=None, class_labels=None):
+                encoder_attention_mask=None, timestep=None, cross_attention_kwargs=None, class_labels=None,
+                cfg_expand: bool = False):
         kw = dict(cross_attention_kwargs) if cross_attention_kwargs is not None else {}
         kw.pop("gligen", None)
         # `attn(...) + hidden_states` / `ff(...) + hidden_states`: the residual rides in the output projection's epilogue
         hidden_states = self.attn1(self.norm1(hidden_states), encoder_hidden_states=None,
                                    attention_mask=attention_mask, _residual=hidden_states, **kw)
+        if cfg_expand:          # shared classifier-free-guidance prefix ends here: the text cross-attention is the first op that tells the halves apart
+            hidden_states = torch.cat([hidden_states, hidden_states], dim=0)
         if self.attn2 is not None:
             hidden_states = self.attn2(self.norm2(hidden_states), encoder_hidden_states=encoder_hidden_states,
                                        attention_mask=encoder_attention_mask, _residual=hidden_states, **kw)
@@ -494,16 +499,21 @@ class Transformer2DModel(nn.Module):
 
     def forward(self, hidden_states, encoder_hidden_states=None, timestep=None, class_labels=None,
                 cross_attention_kwargs=None, attention_mask=None, encoder_attention_mask=None,
-                return_dict: bool = True):
+                return_dict: bool = True, cfg_expand: bool = False):
+        """`cfg_expand`: `hidden_states` holds ONE copy of the two identical halves of a classifier-free-guidance batch; everything
+        up to and including the self-attention runs once, the output covers both halves (see UNet3DConditionModel.cfg_shared_input)."""
         n, c, h, w = hidden_states.shape
         residual = to_tokens(hidden_states)
         x = K.groupnorm_silu(residual, f32_param(self.norm, "weight"), f32_param(self.norm, "bias"),
                              self.norm.num_groups, self.norm.eps, False)
         x = linear_op(x, self.proj_in.weight.view(self.proj_in.out_channels, c), self.proj_in.bias)
-        for blk in self.transformer_blocks:
+        for bi, blk in enumerate(self.transformer_blocks):
             x = blk(x, attention_mask=attention_mask, encoder_hidden_states=encoder_hidden_states,
                     encoder_attention_mask=encoder_attention_mask, timestep=timestep,
-                    cross_attention_kwargs=cross_attention_kwargs, class_labels=class_labels)
+                    cross_attention_kwargs=cross_attention_kwargs, class_labels=class_labels,
+                    **({"cfg_expand": True} if (cfg_expand and bi == 0) else {}))
+        if cfg_expand:
+            residual = torch.cat([residual, residual], dim=0)
         x = linear_op(x, self.proj_out.weight.view(c, self.proj_out.in_channels), self.proj_out.bias, residual)
         out = from_tokens(x, h, w)
         return Transformer2DModelOutput(out) if return_dict else (out,)

@@ -104,12 +104,17 @@ class _Block3D(nn.Module):
             kw = {"scale": ms} if kw is None else {**kw, "scale": ms}
         return {} if kw is None else kw
 
-    def _layer(self, i, x4, b, f, temb_rep, text, cross_kw, motion_kw, skip4=None):
+    def _layer(self, i, x4, b, f, temb_rep, text, cross_kw, motion_kw, skip4=None, cfg_expand=False):
         """x4: `(b f) c h w`.  resnet -> [transformer] -> [motion module].  `skip4`: up-block skip connection, the
-        resnet input is `cat([x4, skip4], 1)`."""
+        resnet input is `cat([x4, skip4], 1)`.  `cfg_expand`: x4 is one copy of a CFG batch's identical halves (b = the FULL batch)."""
+        if cfg_expand and temb_rep is not None:
+            temb_rep = temb_rep[: x4.shape[0]]
         x4 = self.resnets[i](x4, temb_rep, skip=skip4)
         if self.has_cross_attention:
-            x4 = self.attentions[i](x4, encoder_hidden_states=text, cross_attention_kwargs=cross_kw).sample
+            x4 = self.attentions[i](x4, encoder_hidden_states=text, cross_attention_kwargs=cross_kw,
+                                    **({"cfg_expand": True} if cfg_expand else {})).sample
+        elif cfg_expand:
+            x4 = torch.cat([x4, x4], dim=0)
         mm = self.motion_modules[i] if len(self.motion_modules) else None
         if mm is not None:
             x5 = mm(_frames_back(x4, b, f), encoder_hidden_states=text, cross_attention_kwargs=motion_kw)
@@ -144,9 +149,13 @@ class _DownBlock(_Block3D):
         self._check_ckpt()
         x4, b, f = _frames_first(hidden_states)
         temb_rep = None if self.resnets[0]._t_pre is not None else temb.repeat_interleave(f, dim=0)
+        # shared CFG prefix (set by the U-Net for its first down block only): the input holds ONE copy of the two identical halves
+        cfg_half = bool(self.__dict__.pop("_cfg_half_input", False))
+        if cfg_half:
+            b = 2 * b
         outs = ()
         for i in range(len(self.resnets)):
-            x4 = self._layer(i, x4, b, f, temb_rep, text, cross_kw, motion_kw)
+            x4 = self._layer(i, x4, b, f, temb_rep, text, cross_kw, motion_kw, cfg_expand=cfg_half and i == 0)
             outs += (_frames_back(x4, b, f),)
         if traj_features is not None:                      # modified_modules.py:115-117 / 172-174
             t = traj_features[self.traj_fea_idx]

@@ -22,6 +22,7 @@ base U-Net, no pose encoder, sliding-window "multidiff" blending included.
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, List, Optional, Union
 
 import numpy as np
@@ -177,6 +178,9 @@ class AnimationPipeline:
         width = width or unet.config.sample_size * self.vae_scale_factor
         self.check_inputs(prompt, height, width, callback_steps)
         do_cfg = guidance_scale > 1.0
+        # the loops below feed the U-Net `cat([latents] * 2)` under classifier-free guidance: its two halves are identical until the
+        # first text cross-attention, and the U-Net may compute that prefix once (UNet3DConditionModel.cfg_shared_input; FMC_CFG_SHARED=0: A/B)
+        unet.cfg_shared_input = bool(do_cfg) and os.environ.get("FMC_CFG_SHARED", "1") != "0"
         batch_size = 1
         if latents is not None:
             batch_size = latents.shape[0]
@@ -203,7 +207,7 @@ class AnimationPipeline:
                 return unet(x, torch.tensor(int(t), device=x.device), encoder_hidden_states=text, **kw).sample
             return eager
         key = (tuple(x_shape), tuple(text.shape), unet.dtype, pose_feats is not None, traj is not None,
-               _weights_version(unet))
+               bool(getattr(unet, "cfg_shared_input", False)), _weights_version(unet))
         r = self._runners.get(key)
         if r is None:
             for k in [k for k in self._runners if k[:-1] == key[:-1]]:      # same shapes, stale weights: drop the graph
@@ -216,6 +220,7 @@ class AnimationPipeline:
         return r
 
     def _finish(self, latents, output_type, return_dict):
+        self.unet.cfg_shared_input = False                 # (a direct `unet(...)` call by the user gets the plain path)
         if output_type == "latent":
             video = latents
         else:

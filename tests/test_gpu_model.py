@@ -450,3 +450,25 @@ def test_fp8_temporal_attention_frames32_forward_and_training():
     assert res[True][0] < 6e-2 and res[True][1] < 1e-1 and res[True][2] < 1e-2
     assert res[False][0] < 6e-2 and res[False][1] < 1.5e-1
     assert any(m.__dict__.get("_fp8_scales") is not None and m.__dict__["_fp8_scales"].calibrated for m in pu.modules())
+
+
+def test_cfg_shared_prefix_equals_the_plain_path(stack):
+    """`unet.cfg_shared_input`: with the two halves of the batch identical (the pipelines' `cat([latents] * 2)`), computing conv_in, the
+    first ResNet block and the first self-attention once and duplicating gives the plain path's output -- fp32 to round-off, bf16 to the
+    arm-dependent summation order of two differently shaped launches."""
+    clip = stack["clip"]
+    g = torch.Generator().manual_seed(11)
+    text2 = torch.cat([torch.randn(1, 77, 64, generator=g), clip["text"]])
+    for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
+        pu, pe, pa = CM.build_product(stack["ou"], stack["oe"], stack["oa"], W4, dtype=dtype)
+        dev = lambda x: x.to("cuda", dtype)
+        x2 = dev(torch.cat([clip["latents"], clip["latents"]]))
+        pose2 = [dev(torch.cat([p, p])) for p in stack["pose_feats"]]
+        traj = [dev(t) for t in stack["traj"]]                                  # conditioned half only: feature_add skips the first
+        with torch.no_grad():
+            plain = pu(x2, torch.tensor(801, device="cuda"), dev(text2), pose_embedding_features=pose2, traj_features=traj).sample
+            pu.cfg_shared_input = True
+            shared = pu(x2, torch.tensor(801, device="cuda"), dev(text2), pose_embedding_features=pose2, traj_features=traj).sample
+            pu.cfg_shared_input = False
+        assert shared.shape == plain.shape and rel_inf(shared, plain) < tol
+        assert rel_inf(plain[0], plain[1]) > 1e-3                               # (the halves do differ downstream)
