@@ -1683,6 +1683,271 @@ void gemm160_kernel(const GemmParams P) {
     }
 }
 
+// =====================================================================================================================
+// gemm160p_kernel: the PERSISTENT form of gemm160_kernel for the token projections (MODE 0, M % 160 == 0, more tiles than CUs).
+//
+// At K = 320 / 640 a 160 x 320 tile is 10 / 20 sub-tiles of main loop (5-11 us) between a prologue that waits for the first operands
+// (~1.5-2 us: nothing to compute yet) and an epilogue (gate / residual / stage / store: 3-5 us) during which nothing is loaded: a third
+// of the launch.  Here one workgroup per CU walks tiles id, id + CUs, ... and the operand stream never stops at a tile boundary: the
+// DMA of the NEXT tile's first two sub-tiles is issued in the last two phases of the current tile and lands under its epilogue.  For
+// that the epilogue stages through its own LDS region (a three-buffer ring of 30-KiB sub-tiles + 54 KiB of staging = 145 KiB) -- the
+// ring is never drained.
+// vmcnt bookkeeping across the boundary (stores count in vmcnt on gfx9-class hardware): every thread issues EXACTLY S_EPI global stores
+// per tile (a thread without a last chunk repeats its previous one: same bytes, same address), so in the first phase after an epilogue
+// `vmcnt(S_EPI + 4)` retires the sub-tile that was requested BEFORE the stores without waiting for their acknowledgements; one phase
+// later the plain `vmcnt(4)` does wait for them, a whole phase after they were issued.
+// Ring: lead 2 (sub-tile g + 2 is requested at LOAD(g) into the buffer LOAD(g - 1) read; every LOAD ends with lgkmcnt(0) in front of
+// its barrier, so those reads -- of both wave rows -- are complete).  Everything else (geometry, staggered wave rows, LDS image, GEGLU by
+// half-wave swap) is gemm160_kernel's.
+// =====================================================================================================================
+template <int EPI>
+__global__ __launch_bounds__(512, 2)
+void gemm160p_kernel(const GemmParams P) {
+    constexpr int BM = 160, BN = 320, BK = 32, NT = 512, NBUF = 3;
+    constexpr int SUB_ELEMS = (BM + BN) * BK;        // 30 KiB per sub-tile buffer
+    constexpr int S_EPI = EPI == 1 ? 7 : 14;         // global stores per thread and tile (see the header)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+    bf16_t* Os = smem + NBUF * SUB_ELEMS + 512;      // staging: [80][328] (plain epilogue, per pass) or [160][168] (GEGLU)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int prow = lane >> 2, pch = lane & 3;
+    const int psrc = pch ^ (3 * ((prow >> 3) & 1));
+    const int nks = P.K / BK;
+    const int total = P.tiles_m * P.tiles_n;
+    auto tile_of = [&](int id, int& tm, int& tn) {
+        const int q = total >> 3, r = total & 7, x = id & 7;
+        const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);   // XCD x owns a contiguous range
+        lin_to_tile(lin, P, tm, tn);
+    };
+
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)P.a, 0, (int)P.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)P.w, 0, (int)((int64_t)P.N * P.K * 2), 0x00020000);
+    // ---- the operand stream: entry i = 4 wave + e; i < 20: W piece i, 20 <= i < 30: A piece i - 20, else a dummy ---------------------
+    unsigned e_vo[4];
+    int e_lds[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = 4 * wave + e;
+        e_lds[e] = i < 20 ? (BM + 16 * i) * BK : (i < 30 ? 16 * (i - 20) * BK : NBUF * SUB_ELEMS);
+    }
+    const bool w_wave = wave < 5;
+    int s_tile = blockIdx.x, it_s = 0, it_buf = 0;
+    auto stream_setup = [&]() {                       // per-lane source offsets of the stream's current tile (or out of range past the last)
+        int tm = 0, tn = 0;
+        const bool live = s_tile < total;
+        if (live) tile_of(s_tile, tm, tn);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = 4 * wave + e;
+            unsigned vo = OOB;
+            if (live && i < 20) {
+                const int n = tn * BN + 16 * i + prow;
+                vo = (unsigned)(((int64_t)n * P.K + psrc * 8) * 2);
+            } else if (live && i < 30) {
+                const int64_t m = (int64_t)tm * BM + 16 * (i - 20) + prow;
+                vo = (unsigned)((m * P.lda + psrc * 8) * 2);
+            }
+            e_vo[e] = vo;
+        }
+    };
+    auto issue = [&]() {
+        bf16_t* stage = smem + it_buf * SUB_ELEMS;
+        const int soff = it_s * BK * 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bf16_t* dst = e_lds[e] == NBUF * SUB_ELEMS ? smem + NBUF * SUB_ELEMS : stage + e_lds[e];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_wave ? rsW : rsA, (__attribute__((address_space(3))) void*)dst, 16, (int)e_vo[e], soff, 0, 0);
+        }
+        it_buf = it_buf + 1 == NBUF ? 0 : it_buf + 1;
+        if (++it_s == nks) {
+            it_s = 0;
+            s_tile += gridDim.x;
+            stream_setup();
+        }
+    };
+
+    f32x4 acc[5][5];
+    bf16x8 wf[5], af[5];
+    const int frag_off = l15 * BK + (kq ^ (3 * ((l15 >> 3) & 1))) * 8;
+    auto read_frags = [&](const bf16_t* sub) {
+        const bf16_t* Ws = sub + BM * BK + (wc * 80) * BK + frag_off;
+        const bf16_t* As = sub + (wr * 80) * BK + frag_off;
+#pragma unroll
+        for (int nb = 0; nb < 5; ++nb) {
+            union { bf16x8 v; u32x4 u; } t;
+            t.u = *reinterpret_cast<const u32x4*>(Ws + nb * 16 * BK);
+            wf[nb] = t.v;
+        }
+#pragma unroll
+        for (int mb = 0; mb < 5; ++mb) {
+            union { bf16x8 v; u32x4 u; } t;
+            t.u = *reinterpret_cast<const u32x4*>(As + mb * 16 * BK);
+            af[mb] = t.v;
+        }
+    };
+
+    // ---- prologue: sub-tiles 0, 1 of my first tile requested, sub-tile 0 retired and published ------------------------------------------
+    stream_setup();
+    issue(); issue();
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();        // wave row 1 runs one barrier behind wave row 0
+    int rbuf = 0;
+    bool after_epi = false;                           // S_EPI stores sit between the two youngest sub-tile requests and the next one
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        int tile_m, tile_n;
+        tile_of(tile, tile_m, tile_n);
+        const int64_t m0 = (int64_t)tile_m * BM;
+        const int n0 = tile_n * BN;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+#pragma unroll
+            for (int b = 0; b < 5; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_sched_barrier(0);
+        for (int g = 0; g < nks; ++g) {
+            read_frags(smem + rbuf * SUB_ELEMS);
+            rbuf = rbuf + 1 == NBUF ? 0 : rbuf + 1;
+            issue();                                  // sub-tile g + 2 (of this tile or the next)
+            if (g == 0 && after_epi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S_EPI + 4) : "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int mb = 0; mb < 5; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 5; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], af[mb], acc[mb][nb], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();    // the wave rows meet for the epilogue
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- epilogue through Os (the ring keeps streaming) ------------------------------------------------------------------------------
+        if (EPI == 1) {
+            const bool hi = lane >= 32;
+            const int oq = 4 * (kq & 1);
+            auto gate_pair = [&](f32x4& x, f32x4& y, int mbx, int nbx, int mby, int nby, bool single) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {             // x = [x.value | y.value], y = [x.gate | y.gate]
+                    float xa = x[j], ya = y[j];
+                    lane32_swap(xa, ya);
+                    x[j] = xa; y[j] = ya;
+                }
+                const int nbm = hi ? nby : nbx, mbm = hi ? mby : mbx;
+                const int tn = wc * 80 + nbm * 16;
+                float bv[4] = {0.f, 0.f, 0.f, 0.f}, bg[4] = {0.f, 0.f, 0.f, 0.f};
+                if (P.bias) {
+                    const u32x2 t = *reinterpret_cast<const u32x2*>(P.bias + n0 + tn + oq);
+                    const u32x2 u = *reinterpret_cast<const u32x2*>(P.bias + n0 + tn + 8 + oq);
+                    bv[0] = __uint_as_float(t[0] << 16); bv[1] = __uint_as_float(t[0] & 0xffff0000u);
+                    bv[2] = __uint_as_float(t[1] << 16); bv[3] = __uint_as_float(t[1] & 0xffff0000u);
+                    bg[0] = __uint_as_float(u[0] << 16); bg[1] = __uint_as_float(u[0] & 0xffff0000u);
+                    bg[2] = __uint_as_float(u[1] << 16); bg[3] = __uint_as_float(u[1] & 0xffff0000u);
+                }
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (x[j] + bv[j]) * gelu_erf(y[j] + bg[j]);
+                if (single && hi) return;
+                *reinterpret_cast<u32x2*>(Os + (wr * 80 + mbm * 16 + l15) * 168 + wc * 40 + nbm * 8 + oq) = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+            };
+#pragma unroll
+            for (int mb = 0; mb < 5; ++mb) {
+                gate_pair(acc[mb][0], acc[mb][1], mb, 0, mb, 1, false);
+                gate_pair(acc[mb][2], acc[mb][3], mb, 2, mb, 3, false);
+            }
+            gate_pair(acc[0][4], acc[1][4], 0, 4, 1, 4, false);
+            gate_pair(acc[2][4], acc[3][4], 2, 4, 3, 4, false);
+            {
+                f32x4 none = f32x4{0.f, 0.f, 0.f, 0.f};
+                gate_pair(acc[4][4], none, 4, 4, 4, 4, true);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < S_EPI; ++it) {                         // 160 rows x 20 chunks = 3200 = 6.25 per thread: the 7th repeats the 6th
+                int c = tid + it * NT;
+                if (c >= BM * 20) c -= NT;
+                const int r = c / 20, ch = c - r * 20;
+                *reinterpret_cast<u32x4*>(P.out + (m0 + r) * P.ldo + n0 / 2 + ch * 8) = *reinterpret_cast<const u32x4*>(Os + r * 168 + ch * 8);
+            }
+            __syncthreads();                                             // Os is free again
+        } else {
+            constexpr int OP = BN + 8, CPR = BN / 8;                     // staging rows of 328 bf16, 40 chunks per row
+            // alpha * (acc + bias) in the accumulator registers
+#pragma unroll
+            for (int nb = 0; nb < 5; ++nb) {
+                const int n = n0 + wc * 80 + nb * 16 + 4 * kq;
+                float b4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (P.bias) {
+                    const u32x2 t = *reinterpret_cast<const u32x2*>(P.bias + n);
+                    b4[0] = __uint_as_float(t[0] << 16); b4[1] = __uint_as_float(t[0] & 0xffff0000u);
+                    b4[2] = __uint_as_float(t[1] << 16); b4[3] = __uint_as_float(t[1] & 0xffff0000u);
+                }
+#pragma unroll
+                for (int mb = 0; mb < 5; ++mb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[mb][nb][j] = (acc[mb][nb][j] + b4[j]) * P.alpha;
+            }
+#pragma unroll 1
+            for (int pass = 0; pass < 2; ++pass) {                       // rows [80 pass, 80 pass + 80): wave row `pass`
+#pragma unroll 1
+                for (int rz = 0; rz < 2; ++rz) {
+                    const bf16_t* rp = rz == 0 ? P.res : P.res2;
+                    if (rp == nullptr) continue;                       // (uniform)
+                    for (int c = tid; c < 80 * CPR; c += NT) {
+                        const int r = c / CPR, ch = c - r * CPR;
+                        *reinterpret_cast<u32x4*>(Os + r * OP + ch * 8) =
+                            *reinterpret_cast<const u32x4*>(rp + (m0 + pass * 80 + r) * P.ldres + n0 + ch * 8);
+                    }
+                    __syncthreads();
+                    if (wr == pass) {
+#pragma unroll
+                        for (int mb = 0; mb < 5; ++mb)
+#pragma unroll
+                            for (int nb = 0; nb < 5; ++nb) {
+                                const u32x2 t = *reinterpret_cast<const u32x2*>(Os + (mb * 16 + l15) * OP + wc * 80 + nb * 16 + 4 * kq);
+                                acc[mb][nb][0] += __uint_as_float(t[0] << 16); acc[mb][nb][1] += __uint_as_float(t[0] & 0xffff0000u);
+                                acc[mb][nb][2] += __uint_as_float(t[1] << 16); acc[mb][nb][3] += __uint_as_float(t[1] & 0xffff0000u);
+                            }
+                    }
+                    __syncthreads();
+                }
+                if (wr == pass) {
+#pragma unroll
+                    for (int mb = 0; mb < 5; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < 5; ++nb)
+                            *reinterpret_cast<u32x2*>(Os + (mb * 16 + l15) * OP + wc * 80 + nb * 16 + 4 * kq) =
+                                u32x2{pack_bf2(acc[mb][nb][0], acc[mb][nb][1]), pack_bf2(acc[mb][nb][2], acc[mb][nb][3])};
+                }
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < S_EPI / 2; ++it) {                 // 80 rows x 40 chunks = 3200 = 6.25 per thread: the 7th repeats the 6th
+                    int c = tid + it * NT;
+                    if (c >= 80 * CPR) c -= NT;
+                    const int r = c / CPR, ch = c - r * CPR;
+                    *reinterpret_cast<u32x4*>(P.out + (m0 + pass * 80 + r) * P.ldo + n0 + ch * 8) = *reinterpret_cast<const u32x4*>(Os + r * OP + ch * 8);
+                }
+                __syncthreads();                                         // Os is free again
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (wr == 1) __builtin_amdgcn_s_barrier();    // and part again for the next tile's phases
+        after_epi = true;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the requests past my last tile: out of range, zeros into the scratch KiB / dead buffers)
+}
+
 int fmc_cu_count() {
     static int n = 0;
     if (!n) {
@@ -2152,6 +2417,21 @@ void launch_gemm160(GemmParams& P, hipStream_t st) {
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm160_kernel<MODE, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         raised = true;
+    }
+    if constexpr (MODE == 0) {
+        // more tiles than CUs on a token projection: the persistent form (the next tile's operands stream in under this tile's epilogue)
+        static const int persist = getenv("FMC_G160_PERSIST") ? atoi(getenv("FMC_G160_PERSIST")) : 1;
+        const int cus = fmc_cu_count() & ~7;
+        if (persist && !P.f32io && P.M % 160 == 0 && P.tiles_m * P.tiles_n > cus && cus >= 8) {
+            constexpr size_t ldsp = (size_t)3 * (160 + 320) * 32 * sizeof(bf16_t) + 1024 + (EPI == 1 ? (size_t)160 * 168 * 2 : (size_t)80 * 328 * 2);
+            static bool raisedp = false;
+            if (!raisedp) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm160p_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+                raisedp = true;
+            }
+            hipLaunchKernelGGL((gemm160p_kernel<EPI>), dim3((unsigned)cus), dim3(512), ldsp, st, P);
+            return;
+        }
     }
     hipLaunchKernelGGL((gemm160_kernel<MODE, EPI>), dim3((unsigned)(P.tiles_m * P.tiles_n)), dim3(512), lds, st, P);
 }

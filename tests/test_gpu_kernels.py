@@ -1213,3 +1213,43 @@ def test_gemm_160x320_arm(K):
     ma, mg = (x.abs().double() @ gw.abs().double().t() + gb.abs()).chunk(2, dim=-1)
     got = K.linear_f32(x.cuda(), wi, bi, geglu=True, tile=512)
     assert_f32_close(got, a * F.gelu(gt), F.gelu(gt).abs() * ma + 1.13 * a.abs() * mg + 1e-3, "arm 16 fp32 geglu")
+
+
+def test_gemm_160x320_persistent_form(K):
+    """More 160 x 320 tiles than CUs on a token projection: arm 512 runs gemm160p_kernel (one workgroup per CU walks the tiles, the next
+    tile's operands stream in under the epilogue; exact-count stores around the counted vmcnt).  Every epilogue, several launches on fresh
+    data, against an fp64 reference element by element and against the 8-phase arm."""
+    dtype = torch.bfloat16
+    from synfmc_amd.models.layers import interleave_geglu
+    for (M, N, Kd) in [(81920, 320, 320), (41600, 640, 320), (48000, 960, 640), (81920, 320, 1280)]:
+        wo, wd = rnd((N, Kd), 45, dtype, scale=Kd ** -0.5)
+        bo, bd = rnd((N,), 46, dtype)
+        for it in range(3):
+            xo, xd = rnd((M, Kd), 710 + it, dtype)
+            ro, rd = rnd((M, N), 810 + it, dtype)
+            got = K.linear_bf16(xd, wd, bd, rd, 0.5, tile=512)
+            ref = 0.5 * F.linear(xo.double(), wo.double(), bo.double()) + ro.double()
+            mag = 0.5 * (xo.abs().double() @ wo.abs().double().t() + bo.abs()) + ro.abs()
+            assert_bf16_close(got, ref, mag, f"persistent {(M, N, Kd)} it {it}")
+            assert torch.equal(got, K.linear_bf16(xd, wd, bd, rd, 0.5, tile=512))
+            if it == 0:
+                r2o, r2d = rnd((M, N), 910, dtype)
+                got2 = K.linear_bf16(xd, wd, None, rd, 1.0, tile=512, residual2=r2d)
+                assert_bf16_close(got2, F.linear(xo.double(), wo.double()) + ro.double() + r2o.double(),
+                                  xo.abs().double() @ wo.abs().double().t() + ro.abs() + r2o.abs(), "persistent, two residuals")
+                got0 = K.linear_bf16(xd, wd, None, None, 1.0, tile=512)
+                assert rel_inf(got0.float(), K.linear_bf16(xd, wd, None, None, 1.0, tile=13).float()) < 8e-3
+    for (M, N, Kd) in [(48000, 2560, 320), (20480, 5120, 640)]:
+        go, gd = rnd((N, Kd), 42, dtype, scale=Kd ** -0.5)
+        gbo, gbd = rnd((N,), 40, dtype)
+        wi, bi = interleave_geglu(gd, gbd, 8)
+        wi32, bi32 = interleave_geglu(gd, gbd)
+        for it in range(3):
+            xo, xd = rnd((M, Kd), 720 + it, dtype)
+            outg = K.linear_bf16(xd, wi, bi, geglu=True, tile=512)
+            assert torch.equal(outg, K.linear_bf16(xd, wi, bi, geglu=True, tile=512))
+            assert rel_inf(outg.float(), K.linear_bf16(xd, wi32, bi32, geglu=True, tile=3).float()) < 8e-3
+            if it == 0:
+                a, g = F.linear(xo.double(), go.double(), gbo.double()).chunk(2, dim=-1)
+                ma, mg = (xo.abs().double() @ go.abs().double().t() + gbo.abs()).chunk(2, dim=-1)
+                assert_bf16_close(outg, a * F.gelu(g), F.gelu(g).abs() * ma + 1.13 * a.abs() * mg + 1e-3, f"persistent geglu {(M, N, Kd)}")
