@@ -1375,12 +1375,21 @@ void gemm160_kernel(const GemmParams P) {
     const int prow = lane >> 2, pch = lane & 3;      // my row / physical chunk inside a 1-KiB DMA piece (16 rows x 64 B)
     const int psrc = pch ^ (3 * ((prow >> 3) & 1));  // the LOGICAL chunk that lives there
 
-    const int nks = P.K / BK;
+    int nks = P.K / BK, ks0 = 0;                      // my range of sub-tiles: [ks0, ks0 + nks)
     int tile_m, tile_n;
+    const int split = P.split_k > 1 ? (int)(blockIdx.x % P.split_k) : 0;
     {
         const int total = P.tiles_m * P.tiles_n;
-        const int id = blockIdx.x, q = total >> 3, r = total & 7, x = id & 7;
-        const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);   // XCD x owns a contiguous range
+        int lin = blockIdx.x;
+        if (P.split_k > 1) {                          // split-K: the splits of a tile are neighbours in launch order; fp32 partials -> P.ws,
+            lin = blockIdx.x / P.split_k;             // splitk_reduce_kernel sums them in a fixed order and applies the epilogue
+            const int per = ((nks + P.split_k - 1) / P.split_k + 1) & ~1;
+            ks0 = split * per;
+            nks = max(0, min(nks, ks0 + per) - ks0);
+        } else {
+            const int id = blockIdx.x, q = total >> 3, r = total & 7, x = id & 7;
+            lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);   // XCD x owns a contiguous range
+        }
         lin_to_tile(lin, P, tile_m, tile_n);
     }
     const int64_t m0 = (int64_t)tile_m * BM;
@@ -1433,10 +1442,18 @@ void gemm160_kernel(const GemmParams P) {
     const bool w_wave = wave < 5, a_first = wave >= 5;   // waves 0-4: four W pieces each; waves 5-7: A pieces (wave 7: two A + two dummies)
     // the sub-tile the NEXT issue belongs to (scalars).  Conv: (64-channel chunk, tap, 32-channel half)
     int it_s = 0, it_buf = 0, it_tap = 0, it_ci0 = 0, it_half = 0;
+    auto seek0 = [&]() {                               // to the first sub-tile of my range
+        it_s = ks0;
+        if (MODE == 1) {
+            const int chunk = ks0 / 18, rem = ks0 - chunk * 18;
+            it_ci0 = chunk * 64; it_tap = rem >> 1; it_half = rem & 1;
+        }
+    };
+    seek0();
     auto advance = [&]() {
         it_buf = it_buf + 1 == NBUF ? 0 : it_buf + 1;
-        if (++it_s == nks) {
-            it_s = 0; it_tap = 0; it_ci0 = 0; it_half = 0;
+        if (++it_s == ks0 + nks || nks == 0) {
+            seek0();
         } else if (MODE == 1) {
             if (++it_half == 2) {
                 it_half = 0;
@@ -1538,6 +1555,17 @@ void gemm160_kernel(const GemmParams P) {
 
     // ---- epilogue --------------------------------------------------------------------------------------------------------------------
     // my outputs: acc[mb][nb][j] = (row m0 + 80 wr + 16 mb + l15, tile column 80 wc + 16 nb + 4 kq + j)
+    if (EPI == 0 && P.split_k > 1) {                  // raw fp32 partial sums of my k range
+#pragma unroll
+        for (int mb = 0; mb < 5; ++mb) {
+            const int64_t m = m0 + wr * 80 + mb * 16 + l15;
+            if (m >= P.M) continue;
+#pragma unroll
+            for (int nb = 0; nb < 5; ++nb)
+                *reinterpret_cast<f32x4*>(P.ws + ((int64_t)split * P.M + m) * P.N + n0 + wc * 80 + nb * 16 + 4 * kq) = acc[mb][nb];
+        }
+        return;
+    }
     if (EPI == 1) {
         // GEGLU.  Weight rows per 16: [8 value | 8 gate] -> lanes with kq < 2 hold values of outputs 4 kq .. 4 kq + 3 of the block, lanes with
         // kq >= 2 (= lane + 32) the gates of the same outputs.  Blocks are paired (nb 0-1, 2-3 of a row block; the nb = 4 blocks of row
@@ -2396,7 +2424,7 @@ void launch_gemm_k320(GemmParams& P, hipStream_t st) {
 
 // tile 16: plain grid only (whole rounds are the point); N must be a multiple of 320 (GEGLU: weight rows per 16 = [8 value | 8 gate])
 bool gemm160_ok(const GemmParams& P) {
-    return P.N % 320 == 0 && P.split_k == 1 && !P.sk && !P.a2;
+    return P.N % 320 == 0 && !P.sk && !P.a2;           // (split_k > 1: plain epilogue only -- set_split_k has checked)
 }
 template <int MODE, int EPI>
 void launch_gemm160(GemmParams& P, hipStream_t st) {
@@ -2417,6 +2445,14 @@ void launch_gemm160(GemmParams& P, hipStream_t st) {
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm160_kernel<MODE, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         raised = true;
+    }
+    if (P.split_k > 1) {
+        if constexpr (EPI == 0) {
+            hipLaunchKernelGGL((gemm160_kernel<MODE, 0>), dim3((unsigned)(P.tiles_m * P.tiles_n * P.split_k)), dim3(512), lds, st, P);
+            const int64_t chunks = P.M * (P.N / 8);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, P);
+        }
+        return;
     }
     if constexpr (MODE == 0) {
         // more tiles than CUs on a token projection: the persistent form (the next tile's operands stream in under this tile's epilogue)
@@ -2460,7 +2496,11 @@ void launch_gemm(GemmParams& P, int tile, hipStream_t st) {
         else g = 1;
     }
     if (g == 16) {                                        // 160 x 320 tiles (8-phase schedule, 16x16x32 MFMA): N % 320 == 0, plain grid
-        if (gemm8_ok(P) && gemm160_ok(P)) { launch_gemm160<MODE, EPI>(P, st); return; }
+        const int sk_keep = P.split_k;
+        P.split_k = 1;
+        const bool fits = gemm8_ok(P);                    // (32-bit operand offsets; sets P.a_bytes)
+        P.split_k = sk_keep;
+        if (fits && gemm160_ok(P)) { launch_gemm160<MODE, EPI>(P, st); return; }
         g = 13;
     }
     if ((g == 13 || g == 14) && !gemm8_ok(P)) g = 3;      // 8-phase kernel: plain grid, 32-bit operand offsets

@@ -690,8 +690,8 @@ ARM_160 = 512
 def _decode_arm(tile: int, split_k: int):
     """autotune arm id -> (C-ABI tile id, split_k).  Ids 16..127 encode split-K (geometry + 16 log2(split)), 128+ / 256+ stream-K and its
     hybrid; ARM_160 (512) is the C-ABI tile 16, the 160 x 320 kernel."""
-    if tile == ARM_160:
-        return 16, 1
+    if ARM_160 <= tile < ARM_160 + 5:                  # 512 + log2(split): the 160 x 320 kernel, split-K 1 / 2 / 4 / 8 / 16
+        return 16, 1 << (tile - ARM_160)
     if tile >= 256:
         return tile - 256, -2                           # whole rounds on the plain grid, the last partial round stream-K (8-phase arms)
     if tile >= 128:
@@ -736,6 +736,9 @@ def split_arms(M: int, N: int, Kd: int):
     arms = [t + 16 * si for si in (1, 2) for t in (1, 2, 9)]
     if tiles <= 128 and Kd >= 4096:
         arms += [1 + 16 * 3, 9 + 16 * 3]
+    if N % 320 == 0:                                    # 160 x 320 tiles with split-K: as many workgroups as CUs, whole rounds
+        t160 = ((M + 159) // 160) * (N // 320)
+        arms += [ARM_160 + si for si in (1, 2, 3, 4) if 128 <= t160 * (1 << si) <= 512 and Kd // 32 >= 8 * (1 << si)]
     return tuple(arms)
 
 
@@ -1095,7 +1098,7 @@ def _pick(key, hip_fn, lib_fn, static_hip: bool, extra_arms=(), k320: bool = Fal
             return 0 if not (static_hip or no_lib) else -1          # -1: kernel's own geometry heuristic
         times = ([] if no_lib else [(_time_ms(lib_fn), 0)]) + [(_time_ms(lambda t=t: hip_fn(t)), t) for t in GEMM_TILES + tuple(extra_arms)
                                                                 if (t != 15 or k320)    # (arm 15 exists for the K = 320 token projections only,
-                                                                and (t != ARM_160 or n320)]  #  arm 16 for outputs whose width is a multiple of 320)
+                                                                and (not (ARM_160 <= t < ARM_160 + 5) or n320)]  #  arm 16 for outputs whose width is a multiple of 320)
         use = min(times)[1]
         _choice[key] = use
         _tune_log[key] = {arm: round(ms, 4) for ms, arm in times}
