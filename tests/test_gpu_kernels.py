@@ -1253,3 +1253,28 @@ def test_gemm_160x320_persistent_form(K):
                 a, g = F.linear(xo.double(), go.double(), gbo.double()).chunk(2, dim=-1)
                 ma, mg = (xo.abs().double() @ go.abs().double().t() + gbo.abs()).chunk(2, dim=-1)
                 assert_bf16_close(outg, a * F.gelu(g), F.gelu(g).abs() * ma + 1.13 * a.abs() * mg + 1e-3, f"persistent geglu {(M, N, Kd)}")
+
+
+@pytest.mark.parametrize("tile", [513, 514, 515])
+def test_gemm_160x320_split_k(K, tile):
+    """Arm 512 + log2(split): the 160 x 320 kernel writes fp32 partial sums of 2 / 4 / 8 k ranges, splitk_reduce_kernel finishes (the
+    5x8-level shapes: 32 tiles cannot fill 256 CUs)."""
+    dtype = torch.bfloat16
+    for (M, N, Kd) in [(1280, 1280, 2560), (1300, 640, 1280), (160, 320, 64)]:
+        xo, xd = rnd((M, Kd), 730, dtype)
+        wo, wd = rnd((N, Kd), 731, dtype, scale=Kd ** -0.5)
+        bo, bd = rnd((N,), 732, dtype)
+        ro, rd = rnd((M, N), 733, dtype)
+        got = K.linear_bf16(xd, wd, bd, rd, 0.5, tile=tile)
+        assert_bf16_close(got, 0.5 * F.linear(xo.double(), wo.double(), bo.double()) + ro.double(),
+                          0.5 * (xo.abs().double() @ wo.abs().double().t() + bo.abs()) + ro.abs(), f"split-K arm {tile} {(M, N, Kd)}")
+        assert torch.equal(got, K.linear_bf16(xd, wd, bd, rd, 0.5, tile=tile))
+    co, cd = rnd((32, 1280, 5, 8), 734, dtype)
+    fo, fd = rnd((1280, 1280, 3, 3), 735, dtype, scale=(9 * 1280) ** -0.5)
+    to, td = rnd((32, 1280), 736, dtype)
+    ro, rd = rnd((32, 1280, 5, 8), 737, dtype)
+    x_nhwc, f_cl = cd.permute(0, 2, 3, 1).contiguous(), fd.contiguous(memory_format=torch.channels_last)
+    got = K.conv3x3_bf16(x_nhwc, f_cl, None, td, rd.permute(0, 2, 3, 1).contiguous(), tile=tile)
+    ref = F.conv2d(co.double(), fo.double(), None, 1, 1) + to.double()[:, :, None, None] + ro.double()
+    mag = F.conv2d(co.abs().double(), fo.abs().double(), None, 1, 1) + to.abs()[:, :, None, None] + ro.abs()
+    assert_bf16_close(got.permute(0, 3, 1, 2), ref, mag, f"split-K arm {tile} conv 5x8")

@@ -54,7 +54,22 @@ def conv(n, h, w_, ci, co, temb=False, res=False, ups=False):
           + f"   arm16 {fl / out[512] / 1e9:6.0f} TF/s, best other {fl / min(v for t, v in out.items() if t != 512) / 1e9:6.0f} (arm {best})", flush=True)
 
 
+def small():
+    global ARMS
+    ARMS = [1 + 32, 2 + 32, 128 + 13, 256 + 13, 513, 514, 515]
+    x = torch.randn(32, 5, 8, 1280, device=dev, dtype=bf)
+    f = (torch.randn(1280, 1280, 3, 3, device=dev, dtype=bf) * (9 * 1280) ** -0.5).contiguous(memory_format=torch.channels_last)
+    x2 = torch.randn(32, 5, 8, 2560, device=dev, dtype=bf)
+    f2 = (torch.randn(1280, 2560, 3, 3, device=dev, dtype=bf) * (9 * 2560) ** -0.5).contiguous(memory_format=torch.channels_last)
+    x3 = torch.randn(32, 10, 16, 1280, device=dev, dtype=bf)
+    for name, xx, ff in (("conv 5x8 1280->1280", x, f), ("conv 5x8 2560->1280", x2, f2), ("conv 10x16 1280->1280", x3, f)):
+        print(name, "  ".join(f"{t}:{K._time_ms(lambda t=t: K.conv3x3_bf16(xx, ff, None, None, None, tile=t)) * 1e3:7.1f}us" for t in ARMS), flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "small":
+        small()
+        sys.exit(0)
     conv(32, 40, 64, 320, 320, temb=True)
     conv(32, 40, 64, 320, 320, res=True)
     conv(32, 40, 64, 640, 320, temb=True)
