@@ -1,0 +1,121 @@
+"""Decoder half of diffusers' `AutoencoderKL` (SD-1.5 VAE) on the gfx950 stack -- the step AFTER the denoising loop
+(`fmc/pipelines/pipeline_animation_cm_om.py:465-478`: `self.vae.decode(latents[i:i+1]).sample`, frame by frame).
+
+Same sub-module / parameter names as the diffusers class (`post_quant_conv`, `decoder.conv_in`, `decoder.mid_block.{resnets,attentions}`,
+`decoder.up_blocks.{i}.{resnets,upsamplers}`, `decoder.conv_norm_out`, `decoder.conv_out`), so an SD-1.5 `vae/diffusion_pytorch_model.*`
+state dict loads with `strict=False` (the encoder half is not built: FMC only decodes; `load_decoder_state_dict` filters the keys).
+
+What runs where: GroupNorm(+SiLU) = `fmc_groupnorm_silu_fwd`; every 3x3 convolution with Cin % 64 == 0 and Cout % 8 == 0 (all but `conv_in`,
+4 -> 512, and `conv_out`, 128 -> 3) = `fmc_conv3x3_bf16` with the residual in its epilogue and the nearest-2x upsample folded into its
+operand addressing; the mid-block attention's projections = `fmc_linear_bf16`; its single-head d = 512 softmax(QK^T)V goes through
+`torch.nn.functional.scaled_dot_product_attention` (the hand-written attention kernels are built for the U-Net's d = 40 / 80 / 160), as do
+the two edge convolutions (`F.conv2d`).  Outside the metric (BASELINE.json: VAE / CLIP excluded)."""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .layers import Conv2d, GroupNorm, Linear, ResnetBlock2D, Upsample2D, from_tokens, linear_op, to_tokens
+
+
+class DecoderOutput:
+    def __init__(self, sample):
+        self.sample = sample
+
+
+class VaeAttention(nn.Module):
+    """diffusers `Attention(512, heads=1, dim_head=512, norm_num_groups=32, residual_connection=True, bias=True)` as the VAE mid block
+    builds it: GroupNorm -> q, k, v -> softmax(q k^T / sqrt(d)) v -> to_out.0 -> + input."""
+
+    def __init__(self, channels: int, groups: int = 32, eps: float = 1e-6):
+        super().__init__()
+        self.group_norm = GroupNorm(num_groups=groups, num_channels=channels, eps=eps, affine=True)
+        self.to_q, self.to_k, self.to_v = Linear(channels, channels), Linear(channels, channels), Linear(channels, channels)
+        self.to_out = nn.ModuleList([Linear(channels, channels), nn.Dropout(0.0)])
+        self.scale = channels ** -0.5
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        n, c, h, w = x.shape
+        res = to_tokens(x)                                             # [n, h w, c]
+        t = to_tokens(self.group_norm(x))
+        q, k, v = self.to_q(t), self.to_k(t), self.to_v(t)
+        o = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None], scale=self.scale)[:, 0]
+        return from_tokens(linear_op(o.contiguous(), self.to_out[0].weight, self.to_out[0].bias, res), h, w)
+
+
+class _MidBlock(nn.Module):
+    def __init__(self, c, groups, eps):
+        super().__init__()
+        self.attentions = nn.ModuleList([VaeAttention(c, groups, eps)])
+        self.resnets = nn.ModuleList([ResnetBlock2D(in_channels=c, out_channels=c, temb_channels=None, groups=groups, eps=eps)
+                                      for _ in range(2)])
+
+    def forward(self, x):
+        return self.resnets[1](self.attentions[0](self.resnets[0](x, None)), None)
+
+
+class _UpDecoderBlock(nn.Module):
+    def __init__(self, cin, cout, layers, add_upsample, groups, eps):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(in_channels=cin if i == 0 else cout, out_channels=cout, temb_channels=None,
+                                                    groups=groups, eps=eps) for i in range(layers)])
+        self.upsamplers = nn.ModuleList([Upsample2D(cout, use_conv=True, out_channels=cout)]) if add_upsample else None
+
+    def forward(self, x):
+        for r in self.resnets:
+            x = r(x, None)
+        if self.upsamplers is not None:
+            x = self.upsamplers[0](x)
+        return x
+
+
+class Decoder(nn.Module):
+    def __init__(self, in_channels=4, out_channels=3, block_out_channels: Sequence[int] = (128, 256, 512, 512), layers_per_block=2,
+                 norm_num_groups=32, eps=1e-6):
+        super().__init__()
+        rev = list(reversed(block_out_channels))
+        self.conv_in = Conv2d(in_channels, rev[0], kernel_size=3, stride=1, padding=1)
+        self.mid_block = _MidBlock(rev[0], norm_num_groups, eps)
+        blocks, prev = [], rev[0]
+        for i, c in enumerate(rev):
+            blocks.append(_UpDecoderBlock(prev, c, layers_per_block + 1, i != len(rev) - 1, norm_num_groups, eps))
+            prev = c
+        self.up_blocks = nn.ModuleList(blocks)
+        self.conv_norm_out = GroupNorm(num_groups=norm_num_groups, num_channels=rev[-1], eps=eps, affine=True)
+        self.conv_act = nn.SiLU()
+        self.conv_out = Conv2d(rev[-1], out_channels, kernel_size=3, stride=1, padding=1)
+
+    def forward(self, z):
+        x = self.conv_in(z.contiguous(memory_format=torch.channels_last))
+        x = self.mid_block(x)
+        for b in self.up_blocks:
+            x = b(x)
+        return self.conv_out(self.conv_norm_out(x, act=True))
+
+
+class AutoencoderKL(nn.Module):
+    """`AutoencoderKL(...).decode(z).sample` (`[N, 4, h, w]` latents already divided by the scaling factor -> `[N, 3, 8h, 8w]`)."""
+
+    def __init__(self, in_channels=3, out_channels=3, block_out_channels: Sequence[int] = (128, 256, 512, 512), layers_per_block=2,
+                 latent_channels=4, norm_num_groups=32, scaling_factor=0.18215, **_unused):
+        super().__init__()
+        self.scaling_factor = scaling_factor
+        self.post_quant_conv = Conv2d(latent_channels, latent_channels, kernel_size=1)
+        self.decoder = Decoder(latent_channels, out_channels, block_out_channels, layers_per_block, norm_num_groups)
+
+    @property
+    def dtype(self):
+        return self.post_quant_conv.weight.dtype
+
+    def decode(self, z: torch.Tensor, return_dict: bool = True):
+        z = z.to(self.dtype)
+        x = self.decoder(F.conv2d(z, self.post_quant_conv.weight, self.post_quant_conv.bias))
+        return DecoderOutput(x) if return_dict else (x,)
+
+    def load_decoder_state_dict(self, state_dict, strict: bool = True):
+        """Load a full AutoencoderKL state dict, ignoring the encoder / quant_conv halves FMC never runs."""
+        sd = {k: v for k, v in state_dict.items() if k.startswith(("decoder.", "post_quant_conv."))}
+        return self.load_state_dict(sd, strict=strict)

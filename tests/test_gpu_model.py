@@ -472,3 +472,87 @@ def test_cfg_shared_prefix_equals_the_plain_path(stack):
             pu.cfg_shared_input = False
         assert shared.shape == plain.shape and rel_inf(shared, plain) < tol
         assert rel_inf(plain[0], plain[1]) > 1e-3                               # (the halves do differ downstream)
+
+
+# ---- f4: the steps either side of the denoising loop (pipeline_animation_cm_om.py:465-478, 480-568) -----------------------------------
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
+def test_vae_decoder_matches_restatement(dtype, tol):
+    """`AutoencoderKL.decode` (decoder half) against the plain-PyTorch restatement of diffusers' decoder (oracle/vae_restated.py)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import vae_restated as OV
+    from synfmc_amd.models.vae import AutoencoderKL
+    widths = (64, 128, 128, 128)
+    ref = CM.reseed(OV.AutoencoderKLDecoderOnly(widths), 70, fan_in_gain=1.0).eval()
+    vae = AutoencoderKL(block_out_channels=widths)
+    vae.load_decoder_state_dict(ref.state_dict(), strict=True)
+    vae = vae.to("cuda", dtype).eval().requires_grad_(False)
+    z = torch.randn(3, 4, 16, 24, generator=torch.Generator().manual_seed(71))
+    with torch.no_grad():
+        want = ref.decode(z)
+        got = vae.decode(z.cuda()).sample
+    assert got.shape == (3, 3, 128, 192) and rel_inf(got, want) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 4e-2)])
+def test_clip_text_encoder_matches_transformers(dtype, tol):
+    """`CLIPTextModel` against the real `transformers.CLIPTextModel` (random init, state dict copied over)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import transformers
+    from synfmc_amd.models.clip_text import CLIPTextConfig, CLIPTextModel
+    kw = dict(vocab_size=1000, hidden_size=128, intermediate_size=512, num_hidden_layers=3, num_attention_heads=2,
+              max_position_embeddings=77, hidden_act="quick_gelu")
+    torch.manual_seed(72)
+    ref = transformers.CLIPTextModel(transformers.CLIPTextConfig(**kw, bos_token_id=998, eos_token_id=999, pad_token_id=0)).eval()
+    mine = CLIPTextModel(CLIPTextConfig(**kw, eos_token_id=999))
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    mine = mine.to("cuda", dtype).eval().requires_grad_(False)
+    g = torch.Generator().manual_seed(73)
+    ids = torch.randint(1, 998, (4, 77), generator=g)
+    ids[:, 0] = 998
+    for i, n in enumerate((5, 20, 76, 40)):
+        ids[i, n] = 999
+        ids[i, n + 1:] = 0
+    with torch.no_grad():
+        want = ref(ids)
+        got = mine(ids.cuda())
+    assert rel_inf(got[0], want.last_hidden_state) < tol
+    assert rel_inf(got.pooler_output, want.pooler_output) < tol
+
+
+def test_pipeline_end_to_end_with_text_encoder_and_vae(stack):
+    """prompt ids -> CLIP text encoder -> denoising loop -> VAE decode, all on the product stack (reduced widths): the video is finite,
+    in [0, 1], of the right shape, and equals decoding the loop's latents by hand."""
+    from synfmc_amd.models.clip_text import CLIPTextConfig, CLIPTextModel
+    from synfmc_amd.models.vae import AutoencoderKL
+    from synfmc_amd.pipelines.pipeline_animation_cm_om import CameraObjCtrlPipeline
+    from synfmc_amd.schedulers import DDIMScheduler
+
+    class Tok:                                               # a stand-in tokenizer (the real one is a vocabulary file, not arithmetic)
+        model_max_length = 77
+
+        def __call__(self, texts, padding=None, max_length=77, truncation=True, return_tensors="pt"):
+            ids = torch.zeros(len(texts), 77, dtype=torch.long)
+            for i, t in enumerate(texts):
+                codes = [997] + [3 + (ord(ch) % 900) for ch in t][:75] + [998]
+                ids[i, :len(codes)] = torch.tensor(codes)
+            return type("E", (), {"input_ids": ids})()
+
+    torch.manual_seed(74)
+    te = CLIPTextModel(CLIPTextConfig(vocab_size=1000, hidden_size=64, intermediate_size=256, num_hidden_layers=2, num_attention_heads=1,
+                                      eos_token_id=998)).cuda().eval().requires_grad_(False)
+    vae = AutoencoderKL(block_out_channels=(64, 64, 64, 64)).cuda().eval().requires_grad_(False)
+    pu, pe, pa = CM.build_product(stack["ou"], stack["oe"], stack["oa"], W4)
+    kw = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
+    pipe = CameraObjCtrlPipeline(vae, te, Tok(), pu, DDIMScheduler(**kw), pe)
+    clip = stack["clip"]
+    common = dict(video_length=16, traj_features=[t.cuda() for t in stack["traj"]], height=128, width=128, num_inference_steps=3,
+                  guidance_scale=2.0, latents=clip["latents"].cuda())
+    video = pipe("a car turns left", stack["pose_emb"].cuda(), output_type="tensor", **common).videos
+    assert tuple(video.shape) == (1, 3, 16, 128, 128) and torch.isfinite(video).all() and 0.0 <= float(video.min()) and float(video.max()) <= 1.0
+    lat = pipe("a car turns left", stack["pose_emb"].cuda(), output_type="latent", **common).videos
+    by_hand = pipe.decode_latents(lat)
+    assert rel_inf(torch.from_numpy(by_hand), video) < 1e-5
+    other = pipe("two dogs", stack["pose_emb"].cuda(), output_type="latent", **common).videos
+    assert rel_inf(other, lat) > 1e-3                         # the prompt reaches the U-Net

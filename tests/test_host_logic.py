@@ -391,3 +391,33 @@ def test_pipeline_without_classifier_free_guidance(stack, fake):
                guidance_scale=1.0, latents=clip["latents"], output_type="latent", prompt_embeds=clip["text"],
                use_graph=False).videos
     assert rel_inf(out, ref) < 2e-3
+
+
+def test_vae_and_clip_state_dict_keys():
+    """f4: `synfmc_amd.models.clip_text.CLIPTextModel` carries exactly `transformers.CLIPTextModel`'s keys (and accepts the `text_model.`-prefixed
+    form of older checkpoints); `synfmc_amd.models.vae.AutoencoderKL` carries the decoder-side keys of diffusers' AutoencoderKL as the restated
+    oracle lists them, and drops the encoder half of a full checkpoint."""
+    import transformers
+    from oracle import vae_restated as OV
+    from synfmc_amd.models.clip_text import CLIPTextConfig, CLIPTextModel
+    from synfmc_amd.models.vae import AutoencoderKL
+    kw = dict(vocab_size=100, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=1, max_position_embeddings=77)
+    with torch.device("meta"):
+        ref = transformers.CLIPTextModel(transformers.CLIPTextConfig(**kw, bos_token_id=98, eos_token_id=99, pad_token_id=0))
+        mine = CLIPTextModel(CLIPTextConfig(**kw))
+    strip = lambda k: k[len("text_model."):] if k.startswith("text_model.") else k
+    want = {strip(k): tuple(v.shape) for k, v in ref.state_dict().items() if not k.endswith("position_ids")}
+    assert {k: tuple(v.shape) for k, v in mine.state_dict().items()} == want
+    real = CLIPTextModel(CLIPTextConfig(**kw))
+    real.load_state_dict({"text_model." + k: v for k, v in real.state_dict().items()}, strict=True)      # transformers-4.x style keys
+    widths = (64, 64, 128, 128)
+    ov = OV.AutoencoderKLDecoderOnly(widths)
+    vae = AutoencoderKL(block_out_channels=widths)
+    assert {k: tuple(v.shape) for k, v in vae.state_dict().items()} == {k: tuple(v.shape) for k, v in ov.state_dict().items()}
+    full = dict(ov.state_dict())
+    full["encoder.conv_in.weight"] = torch.zeros(1)
+    full["quant_conv.weight"] = torch.zeros(1)
+    vae.load_decoder_state_dict(full, strict=True)
+    for k in ("decoder.mid_block.attentions.0.to_q.weight", "decoder.up_blocks.2.resnets.0.conv_shortcut.weight",
+              "decoder.up_blocks.0.upsamplers.0.conv.weight", "decoder.conv_norm_out.weight", "post_quant_conv.bias"):
+        assert k in vae.state_dict()
