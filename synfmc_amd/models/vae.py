@@ -5,11 +5,11 @@ Same sub-module / parameter names as the diffusers class (`post_quant_conv`, `de
 `decoder.up_blocks.{i}.{resnets,upsamplers}`, `decoder.conv_norm_out`, `decoder.conv_out`), so an SD-1.5 `vae/diffusion_pytorch_model.*`
 state dict loads with `strict=False` (the encoder half is not built: FMC only decodes; `load_decoder_state_dict` filters the keys).
 
-What runs where: GroupNorm(+SiLU) = `fmc_groupnorm_silu_fwd`; every 3x3 convolution with Cin % 64 == 0 and Cout % 8 == 0 (all but `conv_in`,
-4 -> 512, and `conv_out`, 128 -> 3) = `fmc_conv3x3_bf16` with the residual in its epilogue and the nearest-2x upsample folded into its
-operand addressing; the mid-block attention's projections = `fmc_linear_bf16`; its single-head d = 512 softmax(QK^T)V goes through
-`torch.nn.functional.scaled_dot_product_attention` (the hand-written attention kernels are built for the U-Net's d = 40 / 80 / 160), as do
-the two edge convolutions (`F.conv2d`).  Outside the metric (BASELINE.json: VAE / CLIP excluded)."""
+What runs where: GroupNorm(+SiLU) = `fmc_groupnorm_silu_fwd`; every 3x3 convolution = `fmc_conv3x3_bf16` with the residual in its epilogue
+and the nearest-2x upsample folded into its operand addressing (the two edge convolutions, `conv_in` 4 -> 512 and `conv_out` 128 -> 3, with
+zero-padded channels); the mid-block attention's projections = `fmc_linear_bf16`; its single-head d = 512 softmax(QK^T)V goes through
+`torch.nn.functional.scaled_dot_product_attention` (the hand-written attention kernels are built for the U-Net's d = 40 / 80 / 160).
+Outside the metric (BASELINE.json: VAE / CLIP excluded)."""
 from __future__ import annotations
 
 from typing import Optional, Sequence
@@ -19,6 +19,33 @@ import torch.nn.functional as F
 from torch import nn
 
 from .layers import Conv2d, GroupNorm, Linear, ResnetBlock2D, Upsample2D, from_tokens, linear_op, to_tokens
+
+
+def _padded_conv3x3(conv: Conv2d, x: torch.Tensor, act_dtype_ok: bool = True) -> torch.Tensor:
+    """The two edge convolutions (conv_in 4 -> C, conv_out C -> 3) on the hand-written implicit-GEMM kernel: input channels are zero-padded
+    to 64 and output channels to 8 (zero filters), the result is sliced back -- MIOpen is not involved anywhere in the decoder."""
+    from .. import hip_ops as K
+    if not x.is_cuda or torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
+        return F.conv2d(x, conv.weight, conv.bias, 1, 1)
+    cout, cin = conv.weight.shape[:2]
+    cin_p, cout_p = (cin + 63) // 64 * 64, (cout + 7) // 8 * 8
+    key = (conv.weight.data_ptr(), conv.weight._version)
+    hit = conv.__dict__.get("_padded")
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            w = torch.zeros(cout_p, cin_p, 3, 3, dtype=conv.weight.dtype, device=conv.weight.device)
+            w[:cout, :cin] = conv.weight
+            b = torch.zeros(cout_p, dtype=conv.weight.dtype, device=conv.weight.device)
+            if conv.bias is not None:
+                b[:cout] = conv.bias
+            hit = (key, w.contiguous(memory_format=torch.channels_last), b)
+        conv.__dict__["_padded"] = hit
+    if cin_p != cin:
+        xp = torch.zeros(x.shape[0], cin_p, x.shape[2], x.shape[3], dtype=x.dtype, device=x.device).contiguous(memory_format=torch.channels_last)
+        xp[:, :cin] = x
+        x = xp
+    y = K.conv3x3(x.contiguous(memory_format=torch.channels_last), hit[1], hit[2])
+    return y[:, :cout]
 
 
 class DecoderOutput:
@@ -89,11 +116,11 @@ class Decoder(nn.Module):
         self.conv_out = Conv2d(rev[-1], out_channels, kernel_size=3, stride=1, padding=1)
 
     def forward(self, z):
-        x = self.conv_in(z.contiguous(memory_format=torch.channels_last))
+        x = _padded_conv3x3(self.conv_in, z)
         x = self.mid_block(x)
         for b in self.up_blocks:
             x = b(x)
-        return self.conv_out(self.conv_norm_out(x, act=True))
+        return _padded_conv3x3(self.conv_out, self.conv_norm_out(x, act=True))
 
 
 class AutoencoderKL(nn.Module):
