@@ -242,7 +242,7 @@ template <typename T, int MAXCH>
 __global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ stats, int HW, int C, int G, int CS, int PL,
-                                                           float eps, int act, const T* __restrict__ x2, int C1) {
+                                                           float eps, int act, const T* __restrict__ x2, int C1, int xcd_order) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][PL][CS] partial sums, then [2][CS] totals
     __shared__ float sh_mean[GN_MAX_G], sh_rstd[GN_MAX_G];
     // blockIdx -> (image, slab): workgroup ids go round-robin over the 8 XCDs, and a slab is an 80..160-byte run of every pixel row,
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const T* __restrict__
     // (52 MB level-1 launch: 20.6 -> see DESIGN us)
     const int nslab = C / CS, tid = threadIdx.x;
     int n, slab;
-    if (gridDim.y == 1) {
+    if (xcd_order) {                              // (an explicit flag: a 2-D grid of ONE image also has gridDim.y == 1)
         const int id = blockIdx.x, xcd = id & 7, within = id >> 3;
         n = (within / nslab) * 8 + xcd;
         slab = within % nslab;
@@ -387,14 +387,15 @@ template <typename T>
 static void launch_gn1(const Gn1Geom& g1, const void* x, void* y, const float* gamma, const float* beta, float* stats, int N,
                        int HW, int C, int G, float eps, int act, hipStream_t st, const void* x2, int C1) {
     dim3 grid1(C / g1.CS, N), block1(g1.block);
-    if (N % 8 == 0) grid1 = dim3((unsigned)(C / g1.CS) * N, 1);       // XCD-aware 1-D order (see the kernel)
+    const int xcd_order = N % 8 == 0;
+    if (xcd_order) grid1 = dim3((unsigned)(C / g1.CS) * N, 1);        // XCD-aware 1-D order (see the kernel)
     const size_t lds1 = (size_t)2 * g1.PL * g1.CS * sizeof(float);
     if (g1.chunks <= 8)
         hipLaunchKernelGGL((gn_fused_fwd_kernel<T, 8>), grid1, block1, lds1, st, (const T*)x, (T*)y, gamma, beta, stats, HW, C,
-                           G, g1.CS, g1.PL, eps, act, (const T*)x2, C1);
+                           G, g1.CS, g1.PL, eps, act, (const T*)x2, C1, xcd_order);
     else
         hipLaunchKernelGGL((gn_fused_fwd_kernel<T, GN1_MAXCH>), grid1, block1, lds1, st, (const T*)x, (T*)y, gamma, beta,
-                           stats, HW, C, G, g1.CS, g1.PL, eps, act, (const T*)x2, C1);
+                           stats, HW, C, G, g1.CS, g1.PL, eps, act, (const T*)x2, C1, xcd_order);
 }
 
 
