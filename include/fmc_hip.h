@@ -240,6 +240,24 @@ int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, const void*
                      int upsample2x, int tile, int split_k, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * GroupNorm statistics out of the producing GEMM / conv epilogue (reference sites: the GroupNorms of diffusers'
+ * ResnetBlock2D / Transformer2DModel and of the motion module, fmc/models/unet_blocks.py:306-317, fmc/models/motion_module.py:177).
+ * fmc_linear_bf16_gn / fmc_conv3x3_bf16_gn = fmc_linear_bf16 (epilogue 0) / fmc_conv3x3_bf16 on tile 16 (160 x 320 tiles; N resp. Cout % 320
+ *   == 0, pixels per image gn_hw resp. H W % 160 == 0, M % gn_hw == 0) that ALSO write, per (image, 160-row tile of the image, group of
+ *   N / 32 channels), the pair (sum, sum of squares) of the rounded bf16 outputs: gn_partials [M / gn_hw][gn_hw / 160][32][2] fp32.
+ * fmc_groupnorm_apply_fwd = the second pass of fmc_groupnorm_silu_fwd alone: combines `partials [N][part_splits][G][2]` (fp64, fixed
+ *   order), writes mean / rstd to stats and y = act(GroupNorm(x)).  The first pass (one more read of x) is not launched.
+ * ------------------------------------------------------------------------------------------- */
+int fmc_linear_bf16_gn(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int N, int K,
+                       int64_t ldx, int64_t ldres, int64_t ldo, float alpha, const void* residual2, float* gn_partials, int gn_hw,
+                       void* stream);
+int fmc_conv3x3_bf16_gn(const void* x, const void* w, const void* bias, const void* temb, const void* residual, void* out, int n_img,
+                        int H, int W, int Cin, int Cout, int64_t temb_row_stride, int temb_img_div, int upsample2x,
+                        float* gn_partials, void* stream);
+int fmc_groupnorm_apply_fwd(const void* x, void* y, const float* gamma, const float* beta, float* stats, const float* partials,
+                            int part_splits, int N, int HW, int C, int G, float eps, int act, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * fp32-storage ("parity") mode of the two GEMMs above: split-bf16 x3 on the SAME kernels.
  * The reference's CPU path is fp32 (north_star: outputs within 1e-3 rel-inf of it); the bf16 product path can only be held
  * to bf16's own rounding against it.  To check the hand-written tile maps, operand loaders (token / implicit 3x3 conv /

@@ -67,6 +67,8 @@ struct GemmParams {
     int64_t a_bytes;                  // 8-phase kernel: size of the A operand in bytes (buffer descriptor range)
     const float* q8_inv;              // EPI 2 (fp8 e4m3 output, three equal column blocks q | k | v): 1 / scale per block (device)
     unsigned* q8_amax;                // EPI 2: running max |value| per block as float bits (device, atomicMax), may be NULL
+    float* gn_part;                   // gemm160 kernels, plain bf16 epilogue: per-(image, 160-row tile, group of N / 32 channels) partial
+    int gn_hw;                        //   (sum, sum of squares) of the ROUNDED outputs -> gn_part[img][hw / 160][32][2]; gn_hw = pixels per image
     int f32io;                        // fp32-storage ("parity") mode: A / W are split-bf16 x3 operands (fmc_split_bf16x3), bias / temb /
                                       // residual(s) / out are FP32 tensors (the bf16_t pointers above are reinterpreted), see epi_f32_*
 };
@@ -1314,6 +1316,40 @@ void gemm8_kernel(const GemmParams P) {
     }  // segment loop
 }
 
+// ---- GroupNorm statistics out of the producing GEMM / conv epilogue ----------------------------------------
+// The consumer of most level-0 outputs is a GroupNorm(32 groups) over the same tensor; its first pass (`gn_partial_kernel`) re-reads the
+// whole tensor only to sum x and x^2 per (image, group).  The 160 x 320 kernels have the finished bf16 tile in LDS anyway: thread t sums
+// group t % GT (GT = 320 / cpg groups per tile) over rows t / GT, t / GT + RP, ... from the staged tile -- the ROUNDED values, exactly what
+// gn_partial would read -- the 512 / GT partial pairs of a group are added in a fixed order, and the tile's pair lands in
+// gn_part[image][tile of the image][group][2], the layout `gn_apply_fwd_kernel` combines in fp64 (deterministic: no atomics).
+__device__ __forceinline__ void gn_tile_accumulate(const bf16_t* Os, int OP, int rows, int cpg, int tid, float& s, float& ss) {
+    const int GT = 320 / cpg, gl = tid % GT, rp = tid / GT, RP = 512 / GT;
+    for (int r = rp; r < rows; r += RP) {
+        const unsigned* w = reinterpret_cast<const unsigned*>(Os + r * OP + gl * cpg);
+        for (int k = 0; k < cpg / 2; ++k) {
+            const unsigned u = w[k];
+            const float a = __uint_as_float(u << 16), b = __uint_as_float(u & 0xffff0000u);
+            s += a + b;
+            ss += a * a + b * b;
+        }
+    }
+}
+__device__ __forceinline__ void gn_tile_finish(const GemmParams& P, float* red, int64_t m0, int n0, int cpg, int tid, float s, float ss) {
+    const int GT = 320 / cpg, RP = 512 / GT;
+    red[2 * tid] = s;
+    red[2 * tid + 1] = ss;
+    __syncthreads();
+    if (tid < GT) {
+        float a = 0.f, b = 0.f;
+        for (int k = 0; k < RP; ++k) { a += red[2 * (tid + k * GT)]; b += red[2 * (tid + k * GT) + 1]; }
+        const int64_t img = m0 / P.gn_hw;
+        const int nsplit = P.gn_hw / 160, sp = (int)((m0 - img * P.gn_hw) / 160);
+        float* dst = P.gn_part + ((img * nsplit + sp) * 32 + (n0 / cpg + tid)) * 2;
+        dst[0] = a;
+        dst[1] = b;
+    }
+}
+
 // =====================================================================================================================
 // The 160 x 320 kernel (C-ABI tile 16): the staggered-phase schedule of gemm8_kernel on a tile that DIVIDES the FMC problem sizes.
 //
@@ -1702,12 +1738,15 @@ void gemm160_kernel(const GemmParams P) {
                 *reinterpret_cast<u32x2*>(Os + (wr * 80 + mb * 16 + l15) * OP + wc * 80 + nb * 16 + 4 * kq) =
                     u32x2{pack_bf2(acc[mb][nb][0], acc[mb][nb][1]), pack_bf2(acc[mb][nb][2], acc[mb][nb][3])};
         __syncthreads();
+        float gs = 0.f, gss = 0.f;
+        if (P.gn_part) gn_tile_accumulate(Os, OP, BM, P.N / 32, tid, gs, gss);
         for (int c = tid; c < BM * CPR; c += NT) {
             const int r = c / CPR, ch = c - r * CPR;
             const int64_t m = m0 + r;
             if (m < P.M)
                 *reinterpret_cast<u32x4*>(P.out + m * P.ldo + n0 + ch * 8) = *reinterpret_cast<const u32x4*>(Os + r * OP + ch * 8);
         }
+        if (P.gn_part) gn_tile_finish(P, reinterpret_cast<float*>(smem_raw + (size_t)BM * OP * 2), m0, n0, P.N / 32, tid, gs, gss);
     }
 }
 
@@ -1926,6 +1965,7 @@ void gemm160p_kernel(const GemmParams P) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[mb][nb][j] = (acc[mb][nb][j] + b4[j]) * P.alpha;
             }
+            float gs = 0.f, gss = 0.f;
 #pragma unroll 1
             for (int pass = 0; pass < 2; ++pass) {                       // rows [80 pass, 80 pass + 80): wave row `pass`
 #pragma unroll 1
@@ -1959,6 +1999,7 @@ void gemm160p_kernel(const GemmParams P) {
                                 u32x2{pack_bf2(acc[mb][nb][0], acc[mb][nb][1]), pack_bf2(acc[mb][nb][2], acc[mb][nb][3])};
                 }
                 __syncthreads();
+                if (P.gn_part) gn_tile_accumulate(Os, OP, 80, P.N / 32, tid, gs, gss);
 #pragma unroll
                 for (int it = 0; it < S_EPI / 2; ++it) {                 // 80 rows x 40 chunks = 3200 = 6.25 per thread: the 7th repeats the 6th
                     int c = tid + it * NT;
@@ -1967,6 +2008,10 @@ void gemm160p_kernel(const GemmParams P) {
                     *reinterpret_cast<u32x4*>(P.out + (m0 + pass * 80 + r) * P.ldo + n0 + ch * 8) = *reinterpret_cast<const u32x4*>(Os + r * OP + ch * 8);
                 }
                 __syncthreads();                                         // Os is free again
+            }
+            if (P.gn_part) {
+                gn_tile_finish(P, reinterpret_cast<float*>(Os + 80 * OP), m0, n0, P.N / 32, tid, gs, gss);
+                __syncthreads();                                         // (the reduction scratch is re-used by the next tile)
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -2459,7 +2504,7 @@ void launch_gemm160(GemmParams& P, hipStream_t st) {
         static const int persist = getenv("FMC_G160_PERSIST") ? atoi(getenv("FMC_G160_PERSIST")) : 1;
         const int cus = fmc_cu_count() & ~7;
         if (persist && !P.f32io && P.M % 160 == 0 && P.tiles_m * P.tiles_n > cus && cus >= 8) {
-            constexpr size_t ldsp = (size_t)3 * (160 + 320) * 32 * sizeof(bf16_t) + 1024 + (EPI == 1 ? (size_t)160 * 168 * 2 : (size_t)80 * 328 * 2);
+            constexpr size_t ldsp = (size_t)3 * (160 + 320) * 32 * sizeof(bf16_t) + 1024 + (EPI == 1 ? (size_t)160 * 168 * 2 : (size_t)80 * 328 * 2 + 4096);
             static bool raisedp = false;
             if (!raisedp) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm160p_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
@@ -2560,7 +2605,7 @@ int set_split_k(GemmParams& P, int split_k, void* workspace, int64_t workspace_b
 static int linear_impl(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,
                        int N, int K, int64_t ldx, int64_t ldres, int64_t ldo, float alpha, int epilogue, int tile,
                        int split_k, void* workspace, int64_t workspace_bytes, const void* x2, int64_t ldx2,
-                       int k_split, const void* residual2, void* stream, int f32io) {
+                       int k_split, const void* residual2, void* stream, int f32io, void* gn_partials = nullptr, int gn_hw = 0) {
     if (!x || !w || !out) FMC_FAIL(FMC_E_NULL, "linear_bf16: NULL tensor");
     if (M <= 0 || N <= 0 || K <= 0 || K % BK_MAX || N % 8 || ldx % 8 || ldo % (f32io ? 4 : 8) || (residual && ldres % (f32io ? 4 : 8)))
         FMC_FAIL(FMC_E_SHAPE, "linear_bf16: need K%%64==0, N%%8==0 and strides %%8==0 (M=%lld N=%d K=%d)", (long long)M, N, K);
@@ -2578,6 +2623,10 @@ static int linear_impl(const void* x, const void* w, const void* bias, const voi
     P.M = M; P.N = N; P.K = K; P.lda = ldx; P.ldres = ldres; P.ldo = ldo;
     P.img_h = P.img_w = P.cin = 0; P.hw = 1; P.alpha = alpha; P.temb_ld = 0; P.temb_div = 1; P.ups = 0;
     P.f32io = f32io;
+    if (gn_partials && (f32io || epilogue != 0 || tile != 16 || split_k != 1 || gn_hw <= 0 || gn_hw % 160 || M % gn_hw || N % 320 || x2 ||
+                        ((M - 1) * ldx + K) * 2 >= ((int64_t)1 << 31) || (int64_t)N * K * 2 >= ((int64_t)1 << 31)))
+        FMC_FAIL(FMC_E_SHAPE, "linear_bf16: GroupNorm partials come out of tile 16's plain bf16 epilogue only (N %% 320 == 0, pixels per image %% 160 == 0)");
+    P.gn_part = (float*)gn_partials; P.gn_hw = gn_hw;
     if (x2 && (k_split <= 0 || k_split >= K || k_split % BK_MAX || ldx2 % 8 || !fmc_aligned16(x2)))
         FMC_FAIL(FMC_E_SHAPE, "linear_bf16: two-source input needs 0 < k_split < K, k_split %% 64 == 0 (k_split=%d K=%d)", k_split, K);
     P.a2 = (const bf16_t*)x2; P.lda2 = ldx2; P.ksplit = x2 ? k_split : 0;
@@ -2597,6 +2646,14 @@ extern "C" int fmc_linear_bf16(const void* x, const void* w, const void* bias, c
                        workspace_bytes, x2, ldx2, k_split, residual2, stream, 0);
 }
 
+extern "C" int fmc_linear_bf16_gn(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,
+                                  int N, int K, int64_t ldx, int64_t ldres, int64_t ldo, float alpha, const void* residual2,
+                                  float* gn_partials, int gn_hw, void* stream) {
+    if (!gn_partials) FMC_FAIL(FMC_E_NULL, "linear_bf16_gn: NULL gn_partials");
+    return linear_impl(x, w, bias, residual, out, M, N, K, ldx, ldres, ldo, alpha, 0, 16, 1, nullptr, 0, nullptr, 0, 0, residual2, stream, 0,
+                       gn_partials, gn_hw);
+}
+
 extern "C" int fmc_linear_x3_f32(const void* x3, const void* w3, const float* bias, const float* residual, float* out, int64_t M,
                                  int N, int K3, int64_t ldx, int64_t ldres, int64_t ldo, float alpha, int epilogue, int tile,
                                  int split_k, void* workspace, int64_t workspace_bytes, const float* residual2, void* stream) {
@@ -2608,7 +2665,7 @@ extern "C" int fmc_linear_x3_f32(const void* x3, const void* w3, const float* bi
 static int conv3x3_impl(const void* x, const void* w, const void* bias, const void* temb, const void* residual,
                         void* out, int n_img, int H, int W, int Cin, int Cout, int64_t temb_row_stride,
                         int temb_img_div, int upsample2x, int tile, int split_k,
-                        void* workspace, int64_t workspace_bytes, void* stream, int f32io) {
+                        void* workspace, int64_t workspace_bytes, void* stream, int f32io, void* gn_partials = nullptr) {
     if (!x || !w || !out) FMC_FAIL(FMC_E_NULL, "conv3x3_bf16: NULL tensor");
     if (n_img <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % BK_MAX || Cout % 8)
         FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: need Cin%%64==0 and Cout%%8==0 (Cin=%d Cout=%d)", Cin, Cout);
@@ -2623,6 +2680,10 @@ static int conv3x3_impl(const void* x, const void* w, const void* bias, const vo
     P.img_h = H; P.img_w = W; P.cin = Cin; P.hw = H * W; P.alpha = 1.f;
     if (temb && (temb_img_div < 1 || temb_row_stride % (f32io ? 4 : 8))) FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: temb_img_div >= 1, temb_row_stride %% 8 == 0");
     P.f32io = f32io;
+    if (gn_partials && (f32io || tile != 16 || split_k != 1 || (H * W) % 160 || Cout % 320 ||
+                        (int64_t)n_img * H * W * Cin * 2 * (upsample2x == 2 ? 4 : 1) >= ((int64_t)1 << 31) || (int64_t)Cout * 9 * Cin * 2 >= ((int64_t)1 << 31)))
+        FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: GroupNorm partials come out of tile 16's plain bf16 epilogue only (Cout %% 320 == 0, H W %% 160 == 0)");
+    P.gn_part = (float*)gn_partials; P.gn_hw = H * W;
     if (f32io && split_k < 0) FMC_FAIL(FMC_E_SHAPE, "conv3x3_x3_f32: no stream-K in fp32-storage mode");
     P.temb_ld = temb_row_stride; P.temb_div = temb_img_div < 1 ? 1 : temb_img_div;
     if (upsample2x < 0 || upsample2x > 2) FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: resample mode %d", upsample2x);
@@ -2641,6 +2702,14 @@ extern "C" int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, 
                                 void* workspace, int64_t workspace_bytes, void* stream) {
     return conv3x3_impl(x, w, bias, temb, residual, out, n_img, H, W, Cin, Cout, temb_row_stride, temb_img_div, upsample2x, tile,
                         split_k, workspace, workspace_bytes, stream, 0);
+}
+
+extern "C" int fmc_conv3x3_bf16_gn(const void* x, const void* w, const void* bias, const void* temb, const void* residual,
+                                   void* out, int n_img, int H, int W, int Cin, int Cout, int64_t temb_row_stride,
+                                   int temb_img_div, int upsample2x, float* gn_partials, void* stream) {
+    if (!gn_partials) FMC_FAIL(FMC_E_NULL, "conv3x3_bf16_gn: NULL gn_partials");
+    return conv3x3_impl(x, w, bias, temb, residual, out, n_img, H, W, Cin, Cout, temb_row_stride, temb_img_div, upsample2x, 16, 1,
+                        nullptr, 0, stream, 0, gn_partials);
 }
 
 extern "C" int fmc_conv3x3_x3_f32(const void* x3, const void* w3, const float* bias, const float* temb, const float* residual,

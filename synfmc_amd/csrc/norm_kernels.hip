@@ -159,10 +159,11 @@ __global__ void gn_apply_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, 
                                     const float* __restrict__ beta, const float* __restrict__ part,
                                     float* __restrict__ stats, int HW, int C, int G, int tpr, int rpi,
                                     int rows_per_split, float eps, int act, const T* __restrict__ x2 = nullptr,
-                                    int C1 = 0) {
+                                    int C1 = 0, int part_splits = 0) {
     __shared__ float sh_mean[GN_MAX_G], sh_rstd[GN_MAX_G];
     __shared__ float sh_part[GN_MAX_SPLIT * GN_MAX_G * 2];
-    const int n = blockIdx.y, s = blockIdx.x, nsplit = gridDim.x;
+    // part_splits > 0: the partial pairs come from the PRODUCER of x (a GEMM / conv epilogue, one slab per 160-row tile of the image)
+    const int n = blockIdx.y, s = blockIdx.x, nsplit = part_splits > 0 ? part_splits : (int)gridDim.x;
     const int tid = threadIdx.x;
     const int cpg = C / G;
     // the nsplit x G partial pairs of this sample: ONE global round trip for the whole workgroup (every thread fetches its share),
@@ -853,6 +854,25 @@ extern "C" int fmc_groupnorm_silu_fwd(const void* x, void* y, const float* gamma
                            part, stats, HW, C, G, g.tpr, g.rpi, g.rows_per_split, eps, act, (const float*)x2, C1);
     }
     FMC_CHECK_LAUNCH("fmc_groupnorm_silu_fwd");
+    return 0;
+}
+
+extern "C" int fmc_groupnorm_apply_fwd(const void* x, void* y, const float* gamma, const float* beta, float* stats,
+                                       const float* partials, int part_splits, int N, int HW, int C, int G, float eps, int act,
+                                       int dtype, void* stream) {
+    if (int rc = gn_check(x, y, N, HW, C, G, dtype)) return rc;
+    if (!gamma || !beta || !stats || !partials) FMC_FAIL(FMC_E_NULL, "groupnorm_apply_fwd: NULL gamma/beta/stats/partials");
+    if (part_splits < 1 || part_splits > GN_MAX_SPLIT) FMC_FAIL(FMC_E_SHAPE, "groupnorm_apply_fwd: part_splits %d (1..%d)", part_splits, GN_MAX_SPLIT);
+    hipStream_t st = (hipStream_t)stream;
+    GnGeom g = gn_geom(HW, C);
+    dim3 grid(g.split, N), block(g.block);
+    if (dtype == FMC_BF16)
+        hipLaunchKernelGGL((gn_apply_fwd_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)x, (bf16_t*)y, gamma, beta, partials, stats, HW,
+                           C, G, g.tpr, g.rpi, g.rows_per_split, eps, act, (const bf16_t*)nullptr, 0, part_splits);
+    else
+        hipLaunchKernelGGL((gn_apply_fwd_kernel<float>), grid, block, 0, st, (const float*)x, (float*)y, gamma, beta, partials, stats, HW, C,
+                           G, g.tpr, g.rpi, g.rows_per_split, eps, act, (const float*)nullptr, 0, part_splits);
+    FMC_CHECK_LAUNCH("fmc_groupnorm_apply_fwd");
     return 0;
 }
 

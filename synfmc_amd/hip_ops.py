@@ -83,6 +83,41 @@ def groupnorm_silu_raw(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
     return y, stats
 
 
+# GroupNorm statistics out of the producing GEMM / conv epilogue (fmc_linear_bf16_gn / fmc_conv3x3_bf16_gn -> fmc_groupnorm_apply_fwd).
+# A producer that emitted them tags its output tensor: `out._fmc_gn = (partials [n_img, hw / 160, 32, 2], C)`; views made by the layout helpers
+# carry the tag, any arithmetic on the tensor makes a new, untagged one.  FMC_GN_EPILOGUE=0: A/B switch.
+GN_EPILOGUE = os.environ.get("FMC_GN_EPILOGUE", "1") != "0"
+gn_epilogue_calls = {"emitted": 0, "consumed": 0}
+GN_MIN_HW = 2048                    # below that the single-pass GroupNorm kernel reads x once anyway
+
+
+def gn_emit_ok(M: int, N: int, Kd: int, hw: int, dtype) -> bool:
+    return (GN_EPILOGUE and dtype == torch.bfloat16 and hw >= GN_MIN_HW and hw % 160 == 0 and M % hw == 0 and N % 320 == 0 and Kd % 64 == 0
+            and not torch.is_grad_enabled())
+
+
+def carry_gn(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    tag = getattr(src, "_fmc_gn", None)
+    if tag is not None:
+        dst._fmc_gn = tag
+    return dst
+
+
+def groupnorm_apply(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, act: bool,
+                    partials: torch.Tensor) -> torch.Tensor:
+    """GroupNorm(+SiLU) of `[N, S, C]` tokens whose per-(image, tile, group) sums the producer already wrote (`partials [N, splits, G, 2]`)."""
+    _dev(x, gamma, beta, partials)
+    N, S, C = x.shape
+    assert x.is_contiguous() and partials.shape[0] == N and partials.shape[2] == groups and partials.dtype == torch.float32
+    y = torch.empty_like(x)
+    stats = torch.empty(N, groups, 2, dtype=torch.float32, device=x.device)
+    gn_epilogue_calls["consumed"] += 1
+    _lib.check(_lib.load().fmc_groupnorm_apply_fwd(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats.data_ptr(),
+                                                   partials.data_ptr(), partials.shape[1], N, S, C, groups, float(eps), int(act), _dt(x),
+                                                   _stream()), "fmc_groupnorm_apply_fwd")
+    return y
+
+
 class _GroupNormSiLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, groups, eps, act):
@@ -107,9 +142,13 @@ class _GroupNormSiLU(torch.autograd.Function):
         return dx, None, None, None, None, None
 
 
-def groupnorm_silu(x, gamma, beta, groups: int, eps: float, act: bool, x2=None) -> torch.Tensor:
+def groupnorm_silu(x, gamma, beta, groups: int, eps: float, act: bool, x2=None, gn_tag=None) -> torch.Tensor:
     """GroupNorm over `[N, S, C]` tokens (statistics per sample and group over S x C/G) + optional SiLU.
-    gamma/beta: fp32 `[C]`.  `x2`: second channel block (the result normalises `cat([x, x2], -1)` without building it)."""
+    gamma/beta: fp32 `[C]`.  `x2`: second channel block (the result normalises `cat([x, x2], -1)` without building it).
+    `gn_tag`: the `_fmc_gn` tag of the tensor x is a view of -- its producer's partial sums replace the statistics pass."""
+    if (gn_tag is not None and x2 is None and groups == 32 and gn_tag[1] == x.shape[-1] and gn_tag[0].shape[0] == x.shape[0]
+            and gn_tag[0].shape[1] * 160 == x.shape[1] and not torch.is_grad_enabled()):
+        return groupnorm_apply(x, gamma, beta, groups, eps, act, gn_tag[0])
     if torch.is_grad_enabled() and (x.requires_grad or (x2 is not None and x2.requires_grad)):
         if x2 is not None:
             x = torch.cat([x, x2], dim=-1)
@@ -826,6 +865,37 @@ def conv3x3_bf16(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias: Optional[t
     return out
 
 
+def linear_gn(x: torch.Tensor, weight: torch.Tensor, bias, residual, alpha: float, residual2, hw: int):
+    """`linear_bf16` on the 160 x 320 kernel + the GroupNorm partial sums of the output: (out, partials [M / hw, hw / 160, 32, 2])."""
+    _dev(x, weight, bias, residual)
+    N, Kd = weight.shape
+    M, ldx = _rows2d(x)
+    out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
+    part = torch.empty(M // hw, hw // 160, 32, 2, dtype=torch.float32, device=x.device)
+    ldres = 0 if residual is None else _rows2d(residual)[1]
+    gn_epilogue_calls["emitted"] += 1
+    _lib.check(_lib.load().fmc_linear_bf16_gn(x.data_ptr(), weight.data_ptr(), _p(bias), _p(residual), out.data_ptr(), M, N, Kd, ldx, ldres, N,
+                                              float(alpha), _p(residual2), part.data_ptr(), int(hw), _stream()), "fmc_linear_bf16_gn")
+    out._fmc_gn = (part, N)
+    return out
+
+
+def conv3x3_gn(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias, temb, residual_nhwc, temb_div: int, upsample: bool, stride2: bool):
+    n, h, w, cin = x_nhwc.shape
+    if upsample:
+        h, w = 2 * h, 2 * w
+    if stride2:
+        h, w = h // 2, w // 2
+    cout = weight_cl.shape[0]
+    out = torch.empty(n, h, w, cout, dtype=x_nhwc.dtype, device=x_nhwc.device)
+    part = torch.empty(n, (h * w) // 160, 32, 2, dtype=torch.float32, device=x_nhwc.device)
+    gn_epilogue_calls["emitted"] += 1
+    _lib.check(_lib.load().fmc_conv3x3_bf16_gn(x_nhwc.data_ptr(), weight_cl.data_ptr(), _p(bias), _p(temb), _p(residual_nhwc), out.data_ptr(),
+                                               n, h, w, cin, cout, 0 if temb is None else temb.stride(0), int(temb_div),
+                                               2 if stride2 else int(upsample), part.data_ptr(), _stream()), "fmc_conv3x3_bf16_gn")
+    return out, (part, cout)
+
+
 # --------------------------------------------------------------------------------------------
 # fp32-storage ("parity") mode of the two GEMMs: split-bf16 x3 operands on the same gfx950 kernels, fp32 epilogue
 # (include/fmc_hip.h: fmc_split_bf16x3 / fmc_linear_x3_f32 / fmc_conv3x3_x3_f32).  FMC_F32_GEMM=0 sends fp32 projections /
@@ -1108,7 +1178,7 @@ def _pick(key, hip_fn, lib_fn, static_hip: bool, extra_arms=(), k320: bool = Fal
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
            residual: Optional[torch.Tensor] = None, alpha: float = 1.0, x2: Optional[torch.Tensor] = None,
-           residual2: Optional[torch.Tensor] = None) -> torch.Tensor:
+           residual2: Optional[torch.Tensor] = None, gn_hw: int = 0) -> torch.Tensor:
     """`alpha * (x @ weight^T + bias) + residual [+ residual2]` for bf16 device tensors (see `linear_bf16`).  With `x2`
     the input is the concat `[x, x2]` along the last dim; the fused kernel reads the two tensors in place."""
     import torch.nn.functional as F
@@ -1136,6 +1206,11 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     if not ok or (x.ndim > 2 and not x.is_contiguous()):
         return lib()
     M = x.numel() // x.shape[-1]
+    if (gn_hw and x2 is None and x.is_contiguous() and gn_emit_ok(M, N, Kd, gn_hw, x.dtype)
+            and (residual is None or (residual.is_contiguous() and residual.dtype == x.dtype))
+            and (residual2 is None or residual2.is_contiguous())):
+        # the consumer is a GroupNorm at a level where it would read x twice: the 160 x 320 kernel emits the statistics from its epilogue
+        return linear_gn(x, weight, bias, residual, alpha, residual2, gn_hw)
     key = ("lin", M, N, Kd, bias is not None, (residual is not None) + (residual2 is not None),
            0 if x2 is None else x.shape[-1])
     hip = lambda tile: linear_bf16(x, weight, bias, residual, alpha, tile=tile, x2=x2, residual2=residual2)
@@ -1173,7 +1248,7 @@ def geglu_linear(x: torch.Tensor, weight: torch.Tensor, bias, weight_il: torch.T
 
 
 def conv3x3(x_nchw: torch.Tensor, weight_cl: torch.Tensor, bias, temb=None, residual_nchw=None, stride=(1, 1),
-            padding=(1, 1), temb_div: int = 1, upsample: bool = False) -> torch.Tensor:
+            padding=(1, 1), temb_div: int = 1, upsample: bool = False, emit_gn: bool = False) -> torch.Tensor:
     """3x3 conv on a logical NCHW / physical channels-last tensor with `+ temb[:, :, None, None]` and `+ residual`.
     Returns a logical NCHW view over channels-last storage."""
     import torch.nn.functional as F
@@ -1213,6 +1288,11 @@ def conv3x3(x_nchw: torch.Tensor, weight_cl: torch.Tensor, bias, temb=None, resi
     stride2 = tuple(stride) == (2, 2)
     if stride2:
         h, w = h // 2, w // 2
+    if emit_gn and gn_emit_ok(n * h * w, cout, 9 * cin, h * w, x.dtype):
+        y, tag = conv3x3_gn(x, weight_cl, bias, temb, r, temb_div, upsample, stride2)
+        y = y.permute(0, 3, 1, 2)
+        y._fmc_gn = tag
+        return y
     key = ("conv", n, h, w, cin, cout, temb is not None, r is not None, upsample, stride2)
     hip = lambda tile: conv3x3_bf16(x, weight_cl, bias, temb, r, tile=tile, temb_div=temb_div,
                                     upsample=upsample, stride2=stride2).permute(0, 3, 1, 2)

@@ -31,13 +31,13 @@ def to_tokens(x: torch.Tensor) -> torch.Tensor:
     t = x.permute(0, 2, 3, 1)
     if not t.is_contiguous():
         t = t.contiguous()
-    return t.view(n, h * w, c)
+    return K.carry_gn(x, t.view(n, h * w, c))
 
 
 def from_tokens(t: torch.Tensor, h: int, w: int) -> torch.Tensor:
     """contiguous `[N, h*w, C]` tokens -> logical `[N, C, h, w]` view over channels-last storage."""
     n, _, c = t.shape
-    return t.view(n, h, w, c).permute(0, 3, 1, 2)
+    return K.carry_gn(t, t.view(n, h, w, c).permute(0, 3, 1, 2))
 
 
 def f32_param(mod: nn.Module, name: str) -> torch.Tensor:
@@ -63,7 +63,7 @@ class GroupNorm(nn.GroupNorm):
         """`x2`: second channel block -- normalises `cat([x, x2], 1)` without building it."""
         n, c, h, w = x.shape
         y = K.groupnorm_silu(to_tokens(x), f32_param(self, "weight"), f32_param(self, "bias"), self.num_groups,
-                             self.eps, act, None if x2 is None else to_tokens(x2))
+                             self.eps, act, None if x2 is None else to_tokens(x2), gn_tag=getattr(x, "_fmc_gn", None))
         return from_tokens(y, h, w)
 
 
@@ -80,7 +80,7 @@ class Conv2d(nn.Conv2d):
 
     def forward(self, x: torch.Tensor, scale: float = 1.0, temb: Optional[torch.Tensor] = None,
                 residual: Optional[torch.Tensor] = None, temb_div: int = 1, upsample: bool = False,
-                x2: Optional[torch.Tensor] = None) -> torch.Tensor:
+                x2: Optional[torch.Tensor] = None, emit_gn: bool = False) -> torch.Tensor:
         """conv(x) [+ temb[:, :, None, None]] [+ residual]; the two extras ride in the kernel epilogue when the
         gfx950 implicit-GEMM conv / GEMM is used.  `temb_div` > 1: image i uses temb row i // temb_div.
         `upsample`: conv(nearest-2x(x)) with the upsample folded into the kernel's operand addressing."""
@@ -88,7 +88,8 @@ class Conv2d(nn.Conv2d):
             n, c, h, w = x.shape
             assert temb is None
             y = linear_op(to_tokens(x), self.weight.view(self.out_channels, self.in_channels), self.bias,
-                          None if residual is None else to_tokens(residual), 1.0, None if x2 is None else to_tokens(x2))
+                          None if residual is None else to_tokens(residual), 1.0, None if x2 is None else to_tokens(x2),
+                          gn_hw=h * w if emit_gn else 0)
             return from_tokens(y, h, w)
         assert x2 is None, "two-source input: 1x1 convs only"
         if not x.is_contiguous(memory_format=torch.channels_last):
@@ -110,7 +111,7 @@ class Conv2d(nn.Conv2d):
             return K.conv3x3_trainable(x, self.weight, self.bias)
         if self.kernel_size == (3, 3) and self.dilation == (1, 1) and self.groups == 1 and x.is_cuda and not needs_grad:
             return K.conv3x3(x, self._weight_cl(), self.bias, temb, residual, self.stride, self.padding, temb_div,
-                             upsample)
+                             upsample, emit_gn=emit_gn)
         if upsample:
             x = F.interpolate(x, scale_factor=2.0, mode="nearest")
         y = F.conv2d(x, self._weight_cl(), self.bias, self.stride, self.padding, self.dilation, self.groups)
@@ -134,14 +135,14 @@ class Conv2d(nn.Conv2d):
         return hit[1]
 
 
-def linear_op(x, weight, bias=None, residual=None, alpha: float = 1.0, x2=None):
+def linear_op(x, weight, bias=None, residual=None, alpha: float = 1.0, x2=None, gn_hw: int = 0):
     """`alpha * (x @ W^T + b) + residual`: fused gfx950 GEMM or hipBLASLt + epilogue passes (`hip_ops.linear`) for
     frozen bf16 weights on the GPU, plain autograd ops otherwise."""
     if x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16:
         grad = torch.is_grad_enabled()
         if not (grad and (x.requires_grad or weight.requires_grad or (residual is not None and residual.requires_grad)
                           or (x2 is not None and x2.requires_grad))):
-            return K.linear(x, weight, bias, residual, alpha, x2)
+            return K.linear(x, weight, bias, residual, alpha, x2, gn_hw=gn_hw)
         if x2 is not None:
             x, x2 = torch.cat([x, x2], dim=-1), None
         if not weight.requires_grad and (bias is None or not bias.requires_grad):   # frozen layer, activation gradient only
@@ -255,10 +256,12 @@ class ResnetBlock2D(nn.Module):
             t = self.time_emb_proj(F.silu(temb))                       # [N, Cout], rides in conv1's epilogue
         if skip is not None and self.conv_shortcut is None:
             input_tensor, skip = torch.cat([input_tensor, skip], dim=1), None
-        h = self.conv1(self.norm1(input_tensor, act=True, x2=skip), temb=t, temb_div=div)
+        # both convolutions feed a GroupNorm (norm2 here, the next module's norm behind conv2): where that norm would read its input
+        # twice (the 40x64 level) the conv's epilogue emits its statistics (`emit_gn`, hip_ops.gn_emit_ok)
+        h = self.conv1(self.norm1(input_tensor, act=True, x2=skip), temb=t, temb_div=div, emit_gn=True)
         if self.conv_shortcut is not None:
             input_tensor = self.conv_shortcut(input_tensor, x2=skip)
-        out = self.conv2(self.norm2(h, act=True), residual=input_tensor)   # `input + h` rides in conv2's epilogue
+        out = self.conv2(self.norm2(h, act=True), residual=input_tensor, emit_gn=True)   # `input + h` rides in conv2's epilogue
         return out if self.output_scale_factor == 1.0 else out / self.output_scale_factor
 
 
@@ -505,7 +508,7 @@ class Transformer2DModel(nn.Module):
         n, c, h, w = hidden_states.shape
         residual = to_tokens(hidden_states)
         x = K.groupnorm_silu(residual, f32_param(self.norm, "weight"), f32_param(self.norm, "bias"),
-                             self.norm.num_groups, self.norm.eps, False)
+                             self.norm.num_groups, self.norm.eps, False, gn_tag=getattr(hidden_states, "_fmc_gn", None))
         x = linear_op(x, self.proj_in.weight.view(self.proj_in.out_channels, c), self.proj_in.bias)
         for bi, blk in enumerate(self.transformer_blocks):
             x = blk(x, attention_mask=attention_mask, encoder_hidden_states=encoder_hidden_states,
@@ -514,6 +517,7 @@ class Transformer2DModel(nn.Module):
                     **({"cfg_expand": True} if (cfg_expand and bi == 0) else {}))
         if cfg_expand:
             residual = torch.cat([residual, residual], dim=0)
-        x = linear_op(x, self.proj_out.weight.view(c, self.proj_out.in_channels), self.proj_out.bias, residual)
+        x = linear_op(x, self.proj_out.weight.view(c, self.proj_out.in_channels), self.proj_out.bias, residual,
+                      gn_hw=h * w)                                   # (the motion module / next ResNet block opens with a GroupNorm)
         out = from_tokens(x, h, w)
         return Transformer2DModelOutput(out) if return_dict else (out,)

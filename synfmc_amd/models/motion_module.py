@@ -196,13 +196,13 @@ class TemporalTransformer3DModel(nn.Module):
             t = t.contiguous()
         residual = t.view(b * f, h * w, c)
         x = K.groupnorm_silu(residual, f32_param(self.norm, "weight"), f32_param(self.norm, "bias"),
-                             self.norm.num_groups, self.norm.eps, False)
+                             self.norm.num_groups, self.norm.eps, False, gn_tag=getattr(hidden_states, "_fmc_gn", None))
         x = linear_op(x, self.proj_in.weight, self.proj_in.bias).view(b, f, h * w, -1)
         for block in self.transformer_blocks:
             x = block(x, encoder_hidden_states=encoder_hidden_states, attention_mask=attention_mask,
                       cross_attention_kwargs=cross_attention_kwargs)
-        x = linear_op(x.view(b * f, h * w, -1), self.proj_out.weight, self.proj_out.bias, residual)
-        return x.view(b, f, h, w, c).permute(0, 4, 1, 2, 3)
+        x = linear_op(x.view(b * f, h * w, -1), self.proj_out.weight, self.proj_out.bias, residual, gn_hw=h * w)
+        return K.carry_gn(x, x.view(b, f, h, w, c).permute(0, 4, 1, 2, 3))   # (the next ResNet block / conv_norm_out opens with a GroupNorm)
 
 
 class VanillaTemporalModule(nn.Module):

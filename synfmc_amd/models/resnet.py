@@ -16,7 +16,11 @@ def _frames_first(x: torch.Tensor):
     t = x.permute(0, 2, 3, 4, 1)
     if not t.is_contiguous():
         t = t.contiguous()
-    return t.view(b * f, h, w, c).permute(0, 3, 1, 2), b, f
+    y = t.view(b * f, h, w, c).permute(0, 3, 1, 2)
+    tag = getattr(x, "_fmc_gn", None)
+    if tag is not None:
+        y._fmc_gn = tag
+    return y, b, f
 
 
 def _frames_back(y: torch.Tensor, b: int, f: int):
@@ -24,7 +28,11 @@ def _frames_back(y: torch.Tensor, b: int, f: int):
     t = y.permute(0, 2, 3, 1)
     if not t.is_contiguous():
         t = t.contiguous()
-    return t.view(b, f, h, w, c).permute(0, 4, 1, 2, 3)
+    out = t.view(b, f, h, w, c).permute(0, 4, 1, 2, 3)
+    tag = getattr(y, "_fmc_gn", None)
+    if tag is not None:
+        out._fmc_gn = tag
+    return out
 
 
 class InflatedConv3d(Conv2d):

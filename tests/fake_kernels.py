@@ -7,7 +7,7 @@ import torch
 import torch.nn.functional as F
 
 
-def groupnorm_silu(x, gamma, beta, groups, eps, act, x2=None):
+def groupnorm_silu(x, gamma, beta, groups, eps, act, x2=None, gn_tag=None):
     if x2 is not None:
         x = torch.cat([x, x2], dim=-1)
     y = F.group_norm(x.float().permute(0, 2, 1), groups, gamma.float(), beta.float(), eps)

@@ -78,7 +78,12 @@ def _step(g6, dtype, monkeypatch):
 
 
 def test_bench_step_16x320x512_bf16_vs_reference_golden(g6, monkeypatch):
+    from synfmc_amd import hip_ops as K
+    before = dict(K.gn_epilogue_calls)
     eager, graph, notraj, _ = _step(g6, torch.bfloat16, monkeypatch)
+    used = {k: K.gn_epilogue_calls[k] - before[k] for k in before}
+    print(f"GroupNorm statistics from producing epilogues: {used}")
+    assert used["consumed"] >= 3 * 15                                        # (3 eager forwards; the 40x64-level single-source GroupNorms)
     ref = g6["eps"]
     e = rel_inf(eager, ref)
     print(f"16x320x512 CFG-2 step, bf16: rel-inf vs the reference code's output {e:.3e}")

@@ -1279,3 +1279,50 @@ def test_gemm_160x320_split_k(K, tile):
     ref = F.conv2d(co.double(), fo.double(), None, 1, 1) + to.double()[:, :, None, None] + ro.double()
     mag = F.conv2d(co.abs().double(), fo.abs().double(), None, 1, 1) + to.abs()[:, :, None, None] + ro.abs()
     assert_bf16_close(got.permute(0, 3, 1, 2), ref, mag, f"split-K arm {tile} conv 5x8")
+
+
+def test_groupnorm_statistics_from_the_producing_epilogue(K):
+    """f1: the 160 x 320 kernels (plain grid: conv; persistent: token projection with residual) emit per-(image, tile, group) sums of
+    their rounded outputs; `fmc_groupnorm_apply_fwd` normalises with them.  Same result as the two-pass GroupNorm on the same tensor
+    (to the last bf16 ulp: other fp32 partial-sum order), and vs the fp32 oracle."""
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(950)
+    gamma, beta = (torch.randn(320, generator=g) + 1.0).cuda(), torch.randn(320, generator=g).cuda()
+    # conv producer: 8 images of 40 x 64, 320 -> 320, + temb, + residual
+    co, cd = rnd((8, 320, 40, 64), 951, dtype)
+    fo, fd = rnd((320, 320, 3, 3), 952, dtype, scale=(9 * 320) ** -0.5)
+    ro, rd = rnd((8, 320, 40, 64), 953, dtype)
+    x_cl, f_cl, r_cl = cd.contiguous(memory_format=torch.channels_last), fd.contiguous(memory_format=torch.channels_last), rd.contiguous(memory_format=torch.channels_last)
+    before = dict(K.gn_epilogue_calls)
+    y = K.conv3x3(x_cl, f_cl, None, None, r_cl, emit_gn=True)
+    assert K.gn_epilogue_calls["emitted"] == before["emitted"] + 1 and getattr(y, "_fmc_gn", None) is not None
+    plain = K.conv3x3_bf16(x_cl.permute(0, 2, 3, 1), f_cl, None, None, r_cl.permute(0, 2, 3, 1), tile=512)
+    assert torch.equal(y.permute(0, 2, 3, 1), plain)                                      # the emission does not change the output
+    tok = y.permute(0, 2, 3, 1).reshape(8, 2560, 320)
+    part, C = y._fmc_gn
+    want_s = tok.float().view(8, 16, 160, 32, 10).sum(dim=(2, 4))
+    want_ss = (tok.float() ** 2).view(8, 16, 160, 32, 10).sum(dim=(2, 4))
+    assert rel_inf(part[..., 0], want_s) < 1e-4 and rel_inf(part[..., 1], want_ss) < 1e-5
+    for act in (True, False):
+        got = K.groupnorm_silu(tok, gamma, beta, 32, 1e-5, act, gn_tag=y._fmc_gn)
+        two = K.groupnorm_silu(tok, gamma, beta, 32, 1e-5, act)
+        ref = F.group_norm(tok.float().cpu().permute(0, 2, 1), 32, gamma.cpu(), beta.cpu(), 1e-5)
+        ref = (F.silu(ref) if act else ref).permute(0, 2, 1)
+        assert rel_inf(got.float(), ref) < 1e-2 and rel_inf(got.float(), two.float()) < 4e-3
+    assert K.gn_epilogue_calls["consumed"] == before["consumed"] + 2
+    # token producer (persistent kernel: 512 tiles), residual + bias
+    xo, xd = rnd((32, 2560, 320), 954, dtype)
+    wo, wd = rnd((320, 320), 955, dtype, scale=320 ** -0.5)
+    bo, bd = rnd((320,), 956, dtype)
+    ro, rd = rnd((32, 2560, 320), 957, dtype)
+    out = K.linear(xd, wd, bd, rd, 1.0, gn_hw=2560)
+    assert getattr(out, "_fmc_gn", None) is not None
+    assert torch.equal(out, K.linear_bf16(xd, wd, bd, rd, 1.0, tile=512))
+    part = out._fmc_gn[0]
+    want_s = out.float().view(32, 16, 160, 32, 10).sum(dim=(2, 4))
+    assert part.shape == (32, 16, 32, 2) and rel_inf(part[..., 0], want_s) < 1e-4
+    got = K.groupnorm_silu(out, gamma, beta, 32, 1e-6, False, gn_tag=out._fmc_gn)
+    assert rel_inf(got.float(), K.groupnorm_silu(out, gamma, beta, 32, 1e-6, False).float()) < 4e-3
+    # not eligible (20x32 level: the single-pass GroupNorm reads x once anyway): no tag
+    x1, w1 = rnd((8, 640, 640), 958, dtype)[1], rnd((640, 640), 959, dtype, scale=640 ** -0.5)[1]
+    assert getattr(K.linear(x1, w1, None, None, 1.0, gn_hw=640), "_fmc_gn", None) is None
