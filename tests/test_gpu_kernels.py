@@ -1281,6 +1281,7 @@ def test_gemm_160x320_split_k(K, tile):
     assert_bf16_close(got.permute(0, 3, 1, 2), ref, mag, f"split-K arm {tile} conv 5x8")
 
 
+@torch.no_grad()
 def test_groupnorm_statistics_from_the_producing_epilogue(K):
     """f1: the 160 x 320 kernels (plain grid: conv; persistent: token projection with residual) emit per-(image, tile, group) sums of
     their rounded outputs; `fmc_groupnorm_apply_fwd` normalises with them.  Same result as the two-pass GroupNorm on the same tensor
