@@ -41,7 +41,13 @@ def main(path, nsteps=4):
     print(f"window: {nsteps} steps, {(t1 - t0) / 1e6 / nsteps:.3f} ms/step wall, {busy / 1e6 / nsteps:.3f} ms/step kernel-busy\n")
     cat = collections.defaultdict(float)
     for k, (d, c) in agg.items():
-        if "gemm_k320_kernel" in k:
+        if "gemm160p_kernel" in k:
+            cat["linear (fmc gemm160p_kernel, persistent 160x320)"] += d
+        elif "gemm160_kernel<1" in k:
+            cat["conv3x3 (fmc gemm160_kernel, 160x320)"] += d
+        elif "gemm160_kernel<0" in k:
+            cat["linear (fmc gemm160_kernel, 160x320)"] += d
+        elif "gemm_k320_kernel" in k:
             cat["linear (fmc gemm_k320_kernel, weight-stationary)"] += d
         elif "gemm8_kernel<1" in k:
             cat["conv3x3 (fmc gemm8_kernel, 8-phase)"] += d
