@@ -758,6 +758,20 @@ def _streamk_workspace(device):
     return ws.data_ptr(), ws.numel() * 4
 
 
+def prepare_streamk_workspace(stream) -> None:
+    """Create and zero the stream-K workspace of `stream` EAGERLY.  Call before capturing a HIP graph on that stream: first reached under
+    capture, the flag words' zero fill is only recorded into THAT graph, and a second graph captured on the same stream and replayed first
+    would run the flag-based stream-K arms on uninitialised flags."""
+    with torch.cuda.stream(stream):
+        _streamk_workspace(torch.device("cuda", torch.cuda.current_device()))
+    stream.synchronize()
+
+
+def release_streamk_workspace(stream) -> None:
+    """Drop the workspace of a stream that is going away (a discarded graph runner): 486 MB per key otherwise stay allocated."""
+    _sk_ws.pop((torch.cuda.current_device(), stream.cuda_stream), None)
+
+
 def _splitk_workspace(device, split_k: int, M: int, N: int):
     if split_k in (-1, -2):
         return _streamk_workspace(device)
@@ -1343,14 +1357,23 @@ def conv3x3_frozen(x, weight_cl, bias, temb=None, residual=None, temb_div: int =
     return _Conv3x3Frozen.apply(x, weight_cl, bias, temb, residual, temb_div)
 
 
+_wt_cache = {}
+
+
 def _transposed_weight(weight: torch.Tensor) -> torch.Tensor:
-    """`W^T [K, N]` contiguous, cached ON the frozen weight (keyed by its version counter, like `_flipped_filter`): the
-    backward-data GEMM `dX = dY @ W` is `fmc_linear_bf16(dY, W^T)` -- both operands reduction-contiguous."""
-    hit = getattr(weight, "_fmc_wt", None)
-    if hit is None or hit[0] != weight._version:
-        hit = (weight._version, weight.detach().t().contiguous())
-        weight._fmc_wt = hit
-    return hit[1]
+    """`W^T [K, N]` contiguous: the backward-data GEMM `dX = dY @ W` is `fmc_linear_bf16(dY, W^T)` -- both operands
+    reduction-contiguous.  Cached by STORAGE (pointer, offset, shape, version), not on the tensor object: frozen weights reached
+    through a fresh view every call (`weight.view(out, in)` of a 1x1 conv, merged / re-fused weights) hit the cache too.  Entries
+    whose storage was freed and re-used are told apart by the version / shape in the key at worst they are re-made; the cache is
+    bounded."""
+    key = (weight.untyped_storage().data_ptr(), weight.storage_offset(), tuple(weight.shape), weight._version, weight.dtype)
+    hit = _wt_cache.get(key)
+    if hit is None:
+        if len(_wt_cache) > 4096:
+            _wt_cache.clear()
+        hit = weight.detach().t().contiguous()
+        _wt_cache[key] = hit
+    return hit
 
 
 def linear_backward_data(dy: torch.Tensor, weight: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:

@@ -62,19 +62,37 @@ class _GraphedUNet:
         return self.unet(self.x, self.t, encoder_hidden_states=self.text, **kw).sample
 
     def capture(self):
+        from .. import hip_ops as K
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):
                 self._call()
         torch.cuda.current_stream().wait_stream(side)
+        self._cap_stream = torch.cuda.Stream()
+        K.prepare_streamk_workspace(self._cap_stream)      # allocated and zeroed eagerly, not inside the capture
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        self._cap_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.graph(self.graph, stream=self._cap_stream):
             self.out = self._call()
+        torch.cuda.current_stream().wait_stream(self._cap_stream)
         # per-clip constants the processors computed during the warm-up (Camera-Adapter pose terms `s (W pose + b)`): the
         # graph reads them by address, so this runner keeps them alive and refreshes them in place for a new clip
         self._pose_terms = [(m, m.__dict__["_pose_term_cache"]) for m in self.unet.modules()
                             if m.__dict__.get("_pose_term_cache") is not None]
+        # `set_conditioning` recomputes the pose terms from the `pose_view` tensors: that is only right while they ALIAS this runner's
+        # static camera buffers (channels-last storage: the token view is free).  A layout that forced a private copy would replay the
+        # next clip with this clip's camera term -- such a runner re-captures instead of refilling.
+        mine = {p.untyped_storage().data_ptr() for p in (self.pose or [])}
+        self._refillable = all(view.untyped_storage().data_ptr() in mine for _, (_, _, view) in self._pose_terms)
+
+    def __del__(self):
+        try:
+            from .. import hip_ops as K
+            if getattr(self, "_cap_stream", None) is not None:
+                K.release_streamk_workspace(self._cap_stream)
+        except Exception:
+            pass
 
     def set_conditioning(self, text, pose_feats, traj_feats):
         """New clip, same shapes: refill the static buffers, recompute the pose terms into the tensors the graph reads."""
@@ -84,6 +102,11 @@ class _GraphedUNet:
             dst.copy_(src)
         for dst, src in zip(self.traj or [], traj_feats or []):
             dst.copy_(src)
+        if not getattr(self, "_refillable", True):           # (pose terms were computed from private copies: capture again on the new buffers)
+            for mod, _ in self._pose_terms:
+                mod.__dict__.pop("_pose_term_cache", None)
+            self.capture()
+            return
         for mod, (key, term, pose_view) in self._pose_terms:
             pf = pose_view if pose_view.is_contiguous() else pose_view.contiguous()
             term.copy_(K.linear(pf, mod.qkv_merge.weight, mod.qkv_merge.bias, None, key[-1]))
@@ -96,7 +119,20 @@ class _GraphedUNet:
 
 
 def _weights_version(module) -> int:
-    return sum(p._version for p in module.parameters())
+    """Fingerprint of everything a captured graph of `module` reads by address or was specialised on: identity, storage and version of
+    every parameter and buffer (`p.data = ...`, `load_state_dict(assign=True)`, in-place updates), the attention-processor classes, and
+    the module flags that change the launched kernels (fp8 temporal attention, LoRA / pose scales)."""
+    items = [(id(t), t.data_ptr(), t._version) for t in list(module.parameters()) + list(module.buffers())]
+    flags = []
+    for m in module.modules():
+        proc = m.__dict__.get("processor") or m._modules.get("processor") if hasattr(m, "_modules") else None
+        if proc is not None:
+            flags.append((type(proc).__name__, getattr(proc, "scale", None), getattr(proc, "lora_scale", None)))
+        for name in ("_fp8_scales", "lora_scale", "motion_lora_scale"):
+            v = m.__dict__.get(name)
+            if v is not None:
+                flags.append((name, id(v) if not isinstance(v, (int, float)) else v))
+    return hash((tuple(items), tuple(flags)))
 
 
 class AnimationPipeline:
