@@ -1357,22 +1357,26 @@ def conv3x3_frozen(x, weight_cl, bias, temb=None, residual=None, temb_div: int =
     return _Conv3x3Frozen.apply(x, weight_cl, bias, temb, residual, temb_div)
 
 
-_wt_cache = {}
-
-
 def _transposed_weight(weight: torch.Tensor) -> torch.Tensor:
     """`W^T [K, N]` contiguous: the backward-data GEMM `dX = dY @ W` is `fmc_linear_bf16(dY, W^T)` -- both operands
-    reduction-contiguous.  Cached by STORAGE (pointer, offset, shape, version), not on the tensor object: frozen weights reached
-    through a fresh view every call (`weight.view(out, in)` of a 1x1 conv, merged / re-fused weights) hit the cache too.  Entries
-    whose storage was freed and re-used are told apart by the version / shape in the key at worst they are re-made; the cache is
-    bounded."""
-    key = (weight.untyped_storage().data_ptr(), weight.storage_offset(), tuple(weight.shape), weight._version, weight.dtype)
-    hit = _wt_cache.get(key)
+    reduction-contiguous.  Cached ON THE TENSOR THAT OWNS THE STORAGE (`weight._base` for a view, else the weight itself), keyed by
+    (offset, shape, strides, version): frozen weights reached through a fresh view every call (`weight.view(out, in)` of a 1x1 conv) hit
+    the cache, and the entry dies with its owner.  (A module-level dict keyed by the storage pointer -- the first form of this cache --
+    handed a freed weight's W^T to the next model whose weight landed on the same address with the same shape: wrong gradients,
+    silently.)"""
+    owner = weight._base if weight._base is not None else weight
+    key = (weight.storage_offset(), tuple(weight.shape), tuple(weight.stride()), weight._version, weight.dtype)
+    cache = getattr(owner, "_fmc_wt", None)
+    if cache is None or cache[0] != owner._version:
+        cache = (owner._version, {})
+        try:
+            owner._fmc_wt = cache
+        except Exception:                                   # (an owner that takes no attributes: transpose per call)
+            pass
+    hit = cache[1].get(key)
     if hit is None:
-        if len(_wt_cache) > 4096:
-            _wt_cache.clear()
         hit = weight.detach().t().contiguous()
-        _wt_cache[key] = hit
+        cache[1][key] = hit
     return hit
 
 

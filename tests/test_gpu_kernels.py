@@ -1327,3 +1327,25 @@ def test_groupnorm_statistics_from_the_producing_epilogue(K):
     # not eligible (20x32 level: the single-pass GroupNorm reads x once anyway): no tag
     x1, w1 = rnd((8, 640, 640), 958, dtype)[1], rnd((640, 640), 959, dtype, scale=640 ** -0.5)[1]
     assert getattr(K.linear(x1, w1, None, None, 1.0, gn_hw=640), "_fmc_gn", None) is None
+
+
+def test_linear_backward_data_cache_dies_with_its_weight(K):
+    """`linear_frozen`'s backward uses a cached W^T.  The cache lives on the tensor that owns the storage: a second weight of the same
+    shape that lands on the freed first one's address must get ITS transpose (a storage-pointer-keyed cache returned the first one's --
+    found as a 0.39 rel-inf Adapter gradient late in a long test session), and a fresh `view` of a frozen weight must hit the cache."""
+    g = torch.Generator().manual_seed(77)
+    dy = torch.randn(256, 128, generator=g).to("cuda", torch.bfloat16)
+    ptrs = set()
+    for rep in range(4):
+        w = (torch.randn(128, 192, generator=g) * 0.1).to("cuda", torch.bfloat16)
+        ptrs.add(w.data_ptr())
+        got = K.linear_backward_data(dy, w)
+        ref = dy.float() @ w.float()
+        assert_bf16_close(got.float().cpu(), ref.cpu(), (dy.float().abs() @ w.float().abs()).cpu(), f"rep {rep}")
+        del w, got
+    assert len(ptrs) < 4, "the allocator never re-used an address: the test did not exercise the stale-cache case"
+    w4 = (torch.randn(128, 192, 1, 1, generator=g) * 0.1).to("cuda", torch.bfloat16)
+    t0 = K._transposed_weight(w4.view(128, 192))
+    assert K._transposed_weight(w4.view(128, 192)) is t0
+    w4.mul_(2.0)                                           # a new version of the owner: re-made
+    assert torch.equal(K._transposed_weight(w4.view(128, 192)), w4.view(128, 192).t().contiguous())
