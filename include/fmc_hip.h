@@ -196,7 +196,12 @@ int fmc_cfg_ddim_step(const void* eps_uc, const float* x, float* x_out, int64_t 
  *   operands beyond 2 GiB); 15 = the persistent kernel of the K = 320 token projections (epilogue 0, N % 320 == 0, M % 64 == 0, one
  *   residual at most: 5 waves keep the weights of a 320-column block in registers for the life of the workgroup, 64-row A tiles
  *   arrive by LDS-DMA two tiles ahead, the residual rows are DMA'd into the output staging tile; the bias enters the accumulator
- *   first, so it agrees with the other arms to the last bit or two, not bit for bit; anything else falls back to 5).
+ *   first, so it agrees with the other arms to the last bit or two, not bit for bit; anything else falls back to 5);
+ *   16 = 160 x 320 tiles (8 waves of 80 x 80 on the 16x16x32 MFMA, 32-deep sub-tiles in a 5-buffer LDS-DMA ring, one phase per sub-tile;
+ *   N % 320 == 0, otherwise falls back to 13; token projections with more tiles than CUs and M % 160 == 0 run its persistent form, in which
+ *   the next tile's operands stream in under the epilogue; GEGLU wants weight rows ordered [8 value | 8 gate] per 16);
+ *   17 = the persistent form on 256 x 320 tiles (5 operand requests per 40 MFMAs and wave instead of 4 per 25), GEGLU epilogue only,
+ *   M % 256 == 0 and more tiles than CUs -- anything else falls back to 16; same weight row order and bit-identical results.
  *   Every arm computes the same function -- bit for bit among the plain-grid arms of one k-tile depth
  *   (the 32-deep arms, split-K and stream-K add the same products in another order) -- so callers may time them and keep
  *   the fastest.

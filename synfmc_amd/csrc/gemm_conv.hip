@@ -1767,14 +1767,21 @@ void gemm160_kernel(const GemmParams P) {
 // its barrier, so those reads -- of both wave rows -- are complete).  Everything else (geometry, staggered wave rows, LDS image, GEGLU by
 // half-wave swap) is gemm160_kernel's.
 // =====================================================================================================================
-template <int EPI>
+// MB = 16-row blocks per wave row: 5 = the 160 x 320 tile above; 8 = a 256 x 320 tile (GEGLU only, arm 17) -- a wave then issues 5 operand
+// requests for 40 MFMAs per sub-tile instead of 4 for 25: a `buffer_load ... lds` blocks its wave for ~140 ns whatever else the CU does
+// (tools/ubench/dma_mfma), so requests per MFMA is what this loop's speed follows.
+template <int EPI, int MB>
 __global__ __launch_bounds__(512, 2)
 void gemm160p_kernel(const GemmParams P) {
-    constexpr int BM = 160, BN = 320, BK = 32, NT = 512, NBUF = 3;
-    constexpr int SUB_ELEMS = (BM + BN) * BK;        // 30 KiB per sub-tile buffer
-    constexpr int S_EPI = EPI == 1 ? 7 : 14;         // global stores per thread and tile (see the header)
+    constexpr int BM = 32 * MB, BN = 320, BK = 32, NT = 512, NBUF = 3;
+    constexpr int NE = (20 + BM / 16 + 7) / 8;       // operand requests per wave and sub-tile (20 W pieces + BM / 16 A pieces + dummies)
+    static_assert(20 % NE == 0, "a wave's requests are all W or all A");
+    constexpr int SUB_ELEMS = (BM + BN) * BK;        // 30 (36) KiB per sub-tile buffer
+    constexpr int S_EPI = MB == 5 ? (EPI == 1 ? 7 : 14) : 10;   // global stores per thread and tile (see the header)
+    static_assert(MB == 5 || (MB == 8 && EPI == 1), "the 256-row tile has the GEGLU epilogue only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+    auto lds0 = (__attribute__((address_space(3))) unsigned char*)smem_raw;
     bf16_t* Os = smem + NBUF * SUB_ELEMS + 512;      // staging: [80][328] (plain epilogue, per pass) or [160][168] (GEGLU)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -1794,27 +1801,27 @@ void gemm160p_kernel(const GemmParams P) {
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)P.a, 0, (int)P.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)P.w, 0, (int)((int64_t)P.N * P.K * 2), 0x00020000);
     // ---- the operand stream: entry i = 4 wave + e; i < 20: W piece i, 20 <= i < 30: A piece i - 20, else a dummy ---------------------
-    unsigned e_vo[4];
-    int e_lds[4];
+    unsigned e_vo[NE];
+    int e_lds[NE];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int i = 4 * wave + e;
-        e_lds[e] = i < 20 ? (BM + 16 * i) * BK : (i < 30 ? 16 * (i - 20) * BK : NBUF * SUB_ELEMS);
+    for (int e = 0; e < NE; ++e) {
+        const int i = NE * wave + e;
+        e_lds[e] = i < 20 ? (BM + 16 * i) * BK : (i < 20 + BM / 16 ? 16 * (i - 20) * BK : NBUF * SUB_ELEMS);
     }
-    const bool w_wave = wave < 5;
+    const bool w_wave = wave < 20 / NE;
     int s_tile = blockIdx.x, it_s = 0, it_buf = 0;
     auto stream_setup = [&]() {                       // per-lane source offsets of the stream's current tile (or out of range past the last)
         int tm = 0, tn = 0;
         const bool live = s_tile < total;
         if (live) tile_of(s_tile, tm, tn);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int i = 4 * wave + e;
+        for (int e = 0; e < NE; ++e) {
+            const int i = NE * wave + e;
             unsigned vo = OOB;
             if (live && i < 20) {
                 const int n = tn * BN + 16 * i + prow;
                 vo = (unsigned)(((int64_t)n * P.K + psrc * 8) * 2);
-            } else if (live && i < 30) {
+            } else if (live && i < 20 + BM / 16) {
                 const int64_t m = (int64_t)tm * BM + 16 * (i - 20) + prow;
                 vo = (unsigned)((m * P.lda + psrc * 8) * 2);
             }
@@ -1822,12 +1829,11 @@ void gemm160p_kernel(const GemmParams P) {
         }
     };
     auto issue = [&]() {
-        bf16_t* stage = smem + it_buf * SUB_ELEMS;
         const int soff = it_s * BK * 2;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            bf16_t* dst = e_lds[e] == NBUF * SUB_ELEMS ? smem + NBUF * SUB_ELEMS : stage + e_lds[e];
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_wave ? rsW : rsA, (__attribute__((address_space(3))) void*)dst, 16, (int)e_vo[e], soff, 0, 0);
+        for (int e = 0; e < NE; ++e) {                // (LDS destinations as wave-uniform 32-bit offsets: they travel through M0)
+            const int dst = e_lds[e] == NBUF * SUB_ELEMS ? NBUF * SUB_ELEMS : it_buf * SUB_ELEMS + e_lds[e];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_wave ? rsW : rsA, (__attribute__((address_space(3))) void*)(lds0 + 2 * dst), 16, (int)e_vo[e], soff, 0, 0);
         }
         it_buf = it_buf + 1 == NBUF ? 0 : it_buf + 1;
         if (++it_s == nks) {
@@ -1837,12 +1843,12 @@ void gemm160p_kernel(const GemmParams P) {
         }
     };
 
-    f32x4 acc[5][5];
-    bf16x8 wf[5], af[5];
+    f32x4 acc[MB][5];
+    bf16x8 wf[5], af[MB];
     const int frag_off = l15 * BK + (kq ^ (3 * ((l15 >> 3) & 1))) * 8;
     auto read_frags = [&](const bf16_t* sub) {
         const bf16_t* Ws = sub + BM * BK + (wc * 80) * BK + frag_off;
-        const bf16_t* As = sub + (wr * 80) * BK + frag_off;
+        const bf16_t* As = sub + (wr * 16 * MB) * BK + frag_off;
 #pragma unroll
         for (int nb = 0; nb < 5; ++nb) {
             union { bf16x8 v; u32x4 u; } t;
@@ -1850,7 +1856,7 @@ void gemm160p_kernel(const GemmParams P) {
             wf[nb] = t.v;
         }
 #pragma unroll
-        for (int mb = 0; mb < 5; ++mb) {
+        for (int mb = 0; mb < MB; ++mb) {
             union { bf16x8 v; u32x4 u; } t;
             t.u = *reinterpret_cast<const u32x4*>(As + mb * 16 * BK);
             af[mb] = t.v;
@@ -1860,7 +1866,7 @@ void gemm160p_kernel(const GemmParams P) {
     // ---- prologue: sub-tiles 0, 1 of my first tile requested, sub-tile 0 retired and published ------------------------------------------
     stream_setup();
     issue(); issue();
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NE) : "memory");
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();        // wave row 1 runs one barrier behind wave row 0
     int rbuf = 0;
@@ -1872,7 +1878,7 @@ void gemm160p_kernel(const GemmParams P) {
         const int n0 = tile_n * BN;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int a = 0; a < 5; ++a)
+        for (int a = 0; a < MB; ++a)
 #pragma unroll
             for (int b = 0; b < 5; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
         __builtin_amdgcn_sched_barrier(0);
@@ -1880,15 +1886,15 @@ void gemm160p_kernel(const GemmParams P) {
             read_frags(smem + rbuf * SUB_ELEMS);
             rbuf = rbuf + 1 == NBUF ? 0 : rbuf + 1;
             issue();                                  // sub-tile g + 2 (of this tile or the next)
-            if (g == 0 && after_epi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S_EPI + 4) : "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (g == 0 && after_epi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S_EPI + NE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NE) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int mb = 0; mb < 5; ++mb)
+            for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < 5; ++nb)
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], af[mb], acc[mb][nb], 0, 0, 0);
@@ -1926,29 +1932,47 @@ void gemm160p_kernel(const GemmParams P) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (x[j] + bv[j]) * gelu_erf(y[j] + bg[j]);
                 if (single && hi) return;
-                *reinterpret_cast<u32x2*>(Os + (wr * 80 + mbm * 16 + l15) * 168 + wc * 40 + nbm * 8 + oq) = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+                *reinterpret_cast<u32x2*>(Os + ((MB == 5 ? wr * 80 : 0) + mbm * 16 + l15) * 168 + wc * 40 + nbm * 8 + oq) = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
             };
+            auto gate_all = [&]() {
 #pragma unroll
-            for (int mb = 0; mb < 5; ++mb) {
-                gate_pair(acc[mb][0], acc[mb][1], mb, 0, mb, 1, false);
-                gate_pair(acc[mb][2], acc[mb][3], mb, 2, mb, 3, false);
-            }
-            gate_pair(acc[0][4], acc[1][4], 0, 4, 1, 4, false);
-            gate_pair(acc[2][4], acc[3][4], 2, 4, 3, 4, false);
-            {
-                f32x4 none = f32x4{0.f, 0.f, 0.f, 0.f};
-                gate_pair(acc[4][4], none, 4, 4, 4, 4, true);
-            }
-            __syncthreads();
+                for (int mb = 0; mb < MB; ++mb) {
+                    gate_pair(acc[mb][0], acc[mb][1], mb, 0, mb, 1, false);
+                    gate_pair(acc[mb][2], acc[mb][3], mb, 2, mb, 3, false);
+                }
 #pragma unroll
-            for (int it = 0; it < S_EPI; ++it) {                         // 160 rows x 20 chunks = 3200 = 6.25 per thread: the 7th repeats the 6th
-                int c = tid + it * NT;
-                if (c >= BM * 20) c -= NT;
-                const int r = c / 20, ch = c - r * 20;
-                *reinterpret_cast<u32x4*>(P.out + (m0 + r) * P.ldo + n0 / 2 + ch * 8) = *reinterpret_cast<const u32x4*>(Os + r * 168 + ch * 8);
+                for (int mb = 0; mb + 1 < MB; mb += 2) gate_pair(acc[mb][4], acc[mb + 1][4], mb, 4, mb + 1, 4, false);
+                if (MB & 1) {
+                    f32x4 none = f32x4{0.f, 0.f, 0.f, 0.f};
+                    gate_pair(acc[MB - 1][4], none, MB - 1, 4, MB - 1, 4, true);
+                }
+            };
+            if constexpr (MB == 5) {
+                gate_all();
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < S_EPI; ++it) {                     // 160 rows x 20 chunks = 3200 = 6.25 per thread: the 7th repeats the 6th
+                    int c = tid + it * NT;
+                    if (c >= BM * 20) c -= NT;
+                    const int r = c / 20, ch = c - r * 20;
+                    *reinterpret_cast<u32x4*>(P.out + (m0 + r) * P.ldo + n0 / 2 + ch * 8) = *reinterpret_cast<const u32x4*>(Os + r * 168 + ch * 8);
+                }
+                __syncthreads();                                         // Os is free again
+            } else {
+#pragma unroll 1
+                for (int pass = 0; pass < 2; ++pass) {                   // one wave row (128 rows) per pass through the [128][168] staging tile
+                    if (wr == pass) gate_all();
+                    __syncthreads();
+#pragma unroll
+                    for (int it = 0; it < S_EPI / 2; ++it) {             // 128 rows x 20 chunks = 2560 = 5 per thread
+                        const int c = tid + it * NT;
+                        const int r = c / 20, ch = c - r * 20;
+                        *reinterpret_cast<u32x4*>(P.out + (m0 + pass * 128 + r) * P.ldo + n0 / 2 + ch * 8) = *reinterpret_cast<const u32x4*>(Os + r * 168 + ch * 8);
+                    }
+                    __syncthreads();                                     // Os is free again
+                }
             }
-            __syncthreads();                                             // Os is free again
-        } else {
+        } else if constexpr (MB == 5) {
             constexpr int OP = BN + 8, CPR = BN / 8;                     // staging rows of 328 bf16, 40 chunks per row
             // alpha * (acc + bias) in the accumulator registers
 #pragma unroll
@@ -2507,14 +2531,41 @@ void launch_gemm160(GemmParams& P, hipStream_t st) {
             constexpr size_t ldsp = (size_t)3 * (160 + 320) * 32 * sizeof(bf16_t) + 1024 + (EPI == 1 ? (size_t)160 * 168 * 2 : (size_t)80 * 328 * 2 + 4096);
             static bool raisedp = false;
             if (!raisedp) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm160p_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm160p_kernel<EPI, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
                 raisedp = true;
             }
-            hipLaunchKernelGGL((gemm160p_kernel<EPI>), dim3((unsigned)cus), dim3(512), ldsp, st, P);
+            hipLaunchKernelGGL((gemm160p_kernel<EPI, 5>), dim3((unsigned)cus), dim3(512), ldsp, st, P);
             return;
         }
     }
     hipLaunchKernelGGL((gemm160_kernel<MODE, EPI>), dim3((unsigned)(P.tiles_m * P.tiles_n)), dim3(512), lds, st, P);
+}
+
+// tile 17: 256 x 320 tiles, persistent, GEGLU epilogue only (the feed-forward input projections: M % 256 == 0, more tiles than CUs)
+bool gemm256p_ok(const GemmParams& P) {
+    const int cus = fmc_cu_count() & ~7;
+    return P.N % 320 == 0 && P.M % 256 == 0 && !P.sk && !P.a2 && P.split_k == 1 && !P.f32io && cus >= 8 && (P.M / 256) * (P.N / 320) > cus;
+}
+void launch_gemm256p(GemmParams& P, hipStream_t st) {
+    P.tiles_m = (int)(P.M / 256);
+    P.tiles_n = P.N / 320;
+    P.group_m = 1;
+    P.tap_outer = 0;
+    if (gemm_group_m_override() > 0) {
+        P.group_m = gemm_group_m_override();
+    } else if ((int64_t)P.N * P.K * 2 > (int64_t)5 << 19) {                   // as launch_gemm160: square per-XCD footprint in bytes
+        const double c = fmin(32.0, (double)P.tiles_m * P.tiles_n / 8.0);
+        const int gm = (int)lround(sqrt(c * 1.25));
+        if (gm > 1 && P.tiles_n * 2 > 3 * (c / gm)) P.group_m = gm;
+    }
+    constexpr size_t ldsp = (size_t)3 * (256 + 320) * 32 * sizeof(bf16_t) + 1024 + (size_t)128 * 168 * 2;
+    static_assert(ldsp <= 160 * 1024, "ring + staging fit the LDS");
+    static bool raised = false;
+    if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm160p_kernel<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+        raised = true;
+    }
+    hipLaunchKernelGGL((gemm160p_kernel<1, 8>), dim3((unsigned)(fmc_cu_count() & ~7)), dim3(512), ldsp, st, P);
 }
 
 bool gemm8_ok(GemmParams& P) {
@@ -2526,7 +2577,7 @@ bool gemm8_ok(GemmParams& P) {
 }
 
 // tile arms (fmc_hip.h): geometry x k-tile depth x ring depth
-constexpr int GEMM_TILE_MAX = 16;
+constexpr int GEMM_TILE_MAX = 17;
 
 // geometry: the largest tile that still gives every CU work and does not waste more than ~20 % of N
 template <int MODE, int EPI>
@@ -2539,6 +2590,12 @@ void launch_gemm(GemmParams& P, int tile, hipStream_t st) {
         if (tiles(256, 256) >= 256 && waste(256) <= 1.2) g = 3;
         else if (tiles(256, 128) >= 256 && waste(128) <= 1.25) g = 2;
         else g = 1;
+    }
+    if (g == 17) {                                        // 256 x 320 persistent tiles, GEGLU only; anything else takes the 160 x 320 kernel
+        if constexpr (MODE == 0 && EPI == 1) {
+            if (gemm8_ok(P) && gemm256p_ok(P)) { launch_gemm256p(P, st); return; }
+        }
+        g = 16;
     }
     if (g == 16) {                                        // 160 x 320 tiles (8-phase schedule, 16x16x32 MFMA): N % 320 == 0, plain grid
         const int sk_keep = P.split_k;

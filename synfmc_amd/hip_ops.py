@@ -724,11 +724,14 @@ def cfg_ddim_step(eps: torch.Tensor, x: torch.Tensor, guidance: float, alpha_t: 
 # bf16 MFMA GEMM / implicit 3x3 conv with fused epilogues
 # --------------------------------------------------------------------------------------------
 ARM_160 = 512
+ARM_256 = 528                       # C-ABI tile 17: persistent 256 x 320 tiles, GEGLU projections only (falls back to tile 16)
 
 
 def _decode_arm(tile: int, split_k: int):
     """autotune arm id -> (C-ABI tile id, split_k).  Ids 16..127 encode split-K (geometry + 16 log2(split)), 128+ / 256+ stream-K and its
     hybrid; ARM_160 (512) is the C-ABI tile 16, the 160 x 320 kernel."""
+    if tile == ARM_256:
+        return 17, 1
     if ARM_160 <= tile < ARM_160 + 5:                  # 512 + log2(split): the 160 x 320 kernel, split-K 1 / 2 / 4 / 8 / 16
         return 16, 1 << (tile - ARM_160)
     if tile >= 256:
@@ -1182,7 +1185,7 @@ def _pick(key, hip_fn, lib_fn, static_hip: bool, extra_arms=(), k320: bool = Fal
             return 0 if not (static_hip or no_lib) else -1          # -1: kernel's own geometry heuristic
         times = ([] if no_lib else [(_time_ms(lib_fn), 0)]) + [(_time_ms(lambda t=t: hip_fn(t)), t) for t in GEMM_TILES + tuple(extra_arms)
                                                                 if (t != 15 or k320)    # (arm 15 exists for the K = 320 token projections only,
-                                                                and (not (ARM_160 <= t < ARM_160 + 5) or n320)]  #  arm 16 for outputs whose width is a multiple of 320)
+                                                                and (not (ARM_160 <= t < ARM_160 + 5 or t == ARM_256) or n320)]  #  arm 16 for outputs whose width is a multiple of 320)
         use = min(times)[1]
         _choice[key] = use
         _tune_log[key] = {arm: round(ms, 4) for ms, arm in times}
@@ -1254,9 +1257,11 @@ def geglu_linear(x: torch.Tensor, weight: torch.Tensor, bias, weight_il: torch.T
     has160 = weight_il160 is not None and N % 320 == 0
 
     def hip(tile):
-        if tile == ARM_160:                             # (without the 160-block order this arm would silently pair wrong rows: route it to 13)
-            return linear_bf16(x, weight_il160, bias_il160, geglu=True, tile=ARM_160) if has160 else linear_bf16(x, weight_il, bias_il, geglu=True, tile=13)
+        if tile in (ARM_160, ARM_256):                  # (without the 160-block order these arms would silently pair wrong rows: route them to 13)
+            return linear_bf16(x, weight_il160, bias_il160, geglu=True, tile=tile) if has160 else linear_bf16(x, weight_il, bias_il, geglu=True, tile=13)
         return linear_bf16(x, weight_il, bias_il, geglu=True, tile=tile)
+    # (ARM_256, the persistent 256 x 320 form, is selectable but not a candidate: measured 235 / 153 / 134 us against ARM_160's 203 / 153 / 130 us on
+    #  the three U-Net levels, tools/probe_g256.py -- DESIGN.md section 6, round 3.  FMC_GEMM_ARMS=...,528 offers it.)
     use = _pick(("geglu", M, N, Kd), hip, lib, M >= 65536)
     return lib() if use == 0 else hip(max(use, 0))
 

@@ -1349,3 +1349,36 @@ def test_linear_backward_data_cache_dies_with_its_weight(K):
     assert K._transposed_weight(w4.view(128, 192)) is t0
     w4.mul_(2.0)                                           # a new version of the owner: re-made
     assert torch.equal(K._transposed_weight(w4.view(128, 192)), w4.view(128, 192).t().contiguous())
+
+
+def test_gemm_256x320_persistent_geglu(K):
+    """Arm 528 (C-ABI tile 17): gemm160p_kernel<1, 8> -- persistent 256 x 320 tiles, 5 operand requests and 40 MFMAs per wave and sub-tile,
+    GEGLU by half-wave swap, two 128-row passes through the staging tile.  Element-wise against an fp64 reference, bit-equal to the
+    160 x 320 arm (same products in the same order per output), deterministic over launches on fresh data; shapes it does not take
+    (M % 256 != 0, too few tiles, plain epilogue) must fall back to tile 16 and give the same function."""
+    dtype = torch.bfloat16
+    from synfmc_amd.models.layers import interleave_geglu
+    for (M, N, Kd) in [(81920, 2560, 320), (20480, 5120, 640), (66560, 640, 64)]:
+        go, gd = rnd((N, Kd), 42, dtype, scale=Kd ** -0.5)
+        gbo, gbd = rnd((N,), 40, dtype)
+        wi, bi = interleave_geglu(gd, gbd, 8)
+        for it in range(3):
+            xo, xd = rnd((M, Kd), 730 + it, dtype)
+            outg = K.linear_bf16(xd, wi, bi, geglu=True, tile=K.ARM_256)
+            assert torch.equal(outg, K.linear_bf16(xd, wi, bi, geglu=True, tile=K.ARM_256))
+            assert torch.equal(outg, K.linear_bf16(xd, wi, bi, geglu=True, tile=K.ARM_160))
+            if it == 0:
+                a, g = F.linear(xo.double(), go.double(), gbo.double()).chunk(2, dim=-1)
+                ma, mg = (xo.abs().double() @ go.abs().double().t() + gbo.abs()).chunk(2, dim=-1)
+                assert_bf16_close(outg, a * F.gelu(g), F.gelu(g).abs() * ma + 1.13 * a.abs() * mg + 1e-3, f"256x320 geglu {(M, N, Kd)}")
+                outn = K.linear_bf16(xd, wi, None, geglu=True, tile=K.ARM_256)                       # no bias
+                a0, g0 = F.linear(xo.double(), go.double()).chunk(2, dim=-1)
+                assert_bf16_close(outn, a0 * F.gelu(g0), F.gelu(g0).abs() * ma + 1.13 * a0.abs() * mg + 1e-3, "256x320 geglu, no bias")
+    # fall-backs: ragged M, few tiles, plain epilogue
+    go, gd = rnd((640, 320), 42, dtype, scale=320 ** -0.5)
+    wi, bi = interleave_geglu(gd, None, 8)
+    for M in (4100, 2560):
+        xo, xd = rnd((M, 320), 41, dtype)
+        assert torch.equal(K.linear_bf16(xd, wi, None, geglu=True, tile=K.ARM_256), K.linear_bf16(xd, wi, None, geglu=True, tile=K.ARM_160))
+    xo, xd = rnd((81920, 320), 43, dtype)
+    assert torch.equal(K.linear_bf16(xd, gd, None, None, 1.0, tile=K.ARM_256), K.linear_bf16(xd, gd, None, None, 1.0, tile=K.ARM_160))
