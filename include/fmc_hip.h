@@ -256,6 +256,16 @@ int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, const void*
 int fmc_linear_bf16_gn(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int N, int K,
                        int64_t ldx, int64_t ldres, int64_t ldo, float alpha, const void* residual2, float* gn_partials, int gn_hw,
                        void* stream);
+/* fmc_linear_bf16_ln = fmc_linear_bf16 (epilogue 0, tile 16, persistent form) for N == 320 that ALSO writes the CONSUMER's LayerNorm of the
+ *   rows it produces (diffusers BasicTransformerBlock norm1 / norm2 / norm3 behind proj_in / attn1 / attn2, and the motion module's norms
+ *   behind proj_in / the attention blocks: fmc/models/motion_module.py:282-288,355): a 160 x 320 tile holds whole rows, so
+ *   ln_out[m, :] = (out[m, :] - mean) * rstd * ln_gamma + ln_beta (+ ln_pe[(m / ln_pe_inner) % ln_pe_frames, :]) is computed from the
+ *   bf16-rounded rows in the staging tile (two-pass statistics, as fmc_layernorm_fwd) and out is never read again by a LayerNorm launch.
+ *   Needs bf16, N == 320, M % 160 == 0, M / 160 > CUs, ln_pe_inner % 160 == 0 (a tile lies in one frame); ln_out contiguous [M, 320];
+ *   gamma / beta / pe fp32.  Anything else is FMC_E_SHAPE (callers fall back to fmc_linear_bf16 + fmc_layernorm_fwd). */
+int fmc_linear_bf16_ln(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int N, int K,
+                       int64_t ldx, int64_t ldres, int64_t ldo, float alpha, const void* residual2, void* ln_out, const float* ln_gamma,
+                       const float* ln_beta, float ln_eps, const float* ln_pe, int ln_pe_inner, int ln_pe_frames, void* stream);
 int fmc_conv3x3_bf16_gn(const void* x, const void* w, const void* bias, const void* temb, const void* residual, void* out, int n_img,
                         int H, int W, int Cin, int Cout, int64_t temb_row_stride, int temb_img_div, int upsample2x,
                         float* gn_partials, void* stream);

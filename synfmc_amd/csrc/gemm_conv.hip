@@ -69,6 +69,9 @@ struct GemmParams {
     unsigned* q8_amax;                // EPI 2: running max |value| per block as float bits (device, atomicMax), may be NULL
     float* gn_part;                   // gemm160 kernels, plain bf16 epilogue: per-(image, 160-row tile, group of N / 32 channels) partial
     int gn_hw;                        //   (sum, sum of squares) of the ROUNDED outputs -> gn_part[img][hw / 160][32][2]; gn_hw = pixels per image
+    bf16_t* ln_out;                   // gemm160p_kernel, plain epilogue, N == 320: ALSO write LayerNorm(out rows) * gamma + beta (+ pe row) here
+    const float* ln_gamma; const float* ln_beta; const float* ln_pe;   //   (the consumer's norm: the tile holds whole rows, x is not read again);
+    float ln_eps; int ln_pe_inner, ln_pe_frames;                        //   pe row of output row m = ((m / ln_pe_inner) % ln_pe_frames), ln_pe_inner % 160 == 0
     int f32io;                        // fp32-storage ("parity") mode: A / W are split-bf16 x3 operands (fmc_split_bf16x3), bias / temb /
                                       // residual(s) / out are FP32 tensors (the bf16_t pointers above are reinterpreted), see epi_f32_*
 };
@@ -1770,19 +1773,27 @@ void gemm160_kernel(const GemmParams P) {
 // MB = 16-row blocks per wave row: 5 = the 160 x 320 tile above; 8 = a 256 x 320 tile (GEGLU only, arm 17) -- a wave then issues 5 operand
 // requests for 40 MFMAs per sub-tile instead of 4 for 25: a `buffer_load ... lds` blocks its wave for ~140 ns whatever else the CU does
 // (tools/ubench/dma_mfma), so requests per MFMA is what this loop's speed follows.
-template <int EPI, int MB>
+// LN = 1 (plain epilogue, N == 320: the tile holds WHOLE output rows): the epilogue also writes the consumer's LayerNorm of the rows it
+// just produced, from the bf16-ROUNDED rows in the staging tile: statistics by 4 lanes per row (16-byte reads, one pass, two shuffles),
+// `(v - mean) * rstd * gamma + (beta + pe row)` in place by (8-column chunk, row group) threads that keep their gamma / beta in registers,
+// whole-row stores.  (Statistics and normalisation straight from the accumulator registers -- the first form -- cost 110-200 spilled
+// registers, reloaded inside the main loop.)  The separate LayerNorm launch and its read of the tensor disappear.
+template <int EPI, int MB, int LN = 0>
 __global__ __launch_bounds__(512, 2)
 void gemm160p_kernel(const GemmParams P) {
     constexpr int BM = 32 * MB, BN = 320, BK = 32, NT = 512, NBUF = 3;
     constexpr int NE = (20 + BM / 16 + 7) / 8;       // operand requests per wave and sub-tile (20 W pieces + BM / 16 A pieces + dummies)
     static_assert(20 % NE == 0, "a wave's requests are all W or all A");
     constexpr int SUB_ELEMS = (BM + BN) * BK;        // 30 (36) KiB per sub-tile buffer
-    constexpr int S_EPI = MB == 5 ? (EPI == 1 ? 7 : 14) : 10;   // global stores per thread and tile (see the header)
+    constexpr int S_EPI = MB == 5 ? (EPI == 1 ? 7 : 14 * (1 + LN)) : 10;   // global stores per thread and tile (see the header)
+    static_assert(!LN || (EPI == 0 && MB == 5), "LayerNorm rides in the plain epilogue of the 160-row tile");
     static_assert(MB == 5 || (MB == 8 && EPI == 1), "the 256-row tile has the GEGLU epilogue only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
     auto lds0 = (__attribute__((address_space(3))) unsigned char*)smem_raw;
     bf16_t* Os = smem + NBUF * SUB_ELEMS + 512;      // staging: [80][328] (plain epilogue, per pass) or [160][168] (GEGLU)
+    float* lnS = reinterpret_cast<float*>(Os + 80 * (BN + 8));   // LN: [gamma 320 | beta + pe row 320 | (mean, rstd) x 80 rows]  (shares the GroupNorm scratch)
+    if (LN && threadIdx.x < 320) lnS[threadIdx.x] = P.ln_gamma[threadIdx.x];   // (published by the main loop's barriers long before the first epilogue)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1974,6 +1985,8 @@ void gemm160p_kernel(const GemmParams P) {
             }
         } else if constexpr (MB == 5) {
             constexpr int OP = BN + 8, CPR = BN / 8;                     // staging rows of 328 bf16, 40 chunks per row
+            if (LN && tid < 320)                                         // beta + the positional-encoding row of this tile's frame (tile-uniform)
+                lnS[320 + tid] = P.ln_beta[tid] + (P.ln_pe ? P.ln_pe[(size_t)((m0 / P.ln_pe_inner) % P.ln_pe_frames) * 320 + tid] : 0.f);
             // alpha * (acc + bias) in the accumulator registers
 #pragma unroll
             for (int nb = 0; nb < 5; ++nb) {
@@ -2025,11 +2038,61 @@ void gemm160p_kernel(const GemmParams P) {
                 __syncthreads();
                 if (P.gn_part) gn_tile_accumulate(Os, OP, 80, P.N / 32, tid, gs, gss);
 #pragma unroll
-                for (int it = 0; it < S_EPI / 2; ++it) {                 // 80 rows x 40 chunks = 3200 = 6.25 per thread: the 7th repeats the 6th
+                for (int it = 0; it < 7; ++it) {                         // 80 rows x 40 chunks = 3200 = 6.25 per thread: the 7th repeats the 6th
                     int c = tid + it * NT;
                     if (c >= 80 * CPR) c -= NT;
                     const int r = c / CPR, ch = c - r * CPR;
                     *reinterpret_cast<u32x4*>(P.out + (m0 + pass * 80 + r) * P.ldo + n0 + ch * 8) = *reinterpret_cast<const u32x4*>(Os + r * OP + ch * 8);
+                }
+                if (LN) {
+                    // (1) statistics of the 80 staged (rounded) rows: 4 lanes per row, 16-byte reads, one pass (sum, sum of squares), two shuffles
+                    if (tid < 320) {
+                        const int r = tid >> 2, q = tid & 3;
+                        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 10; ++i) {
+                            const u32x4 x4 = *reinterpret_cast<const u32x4*>(Os + r * OP + (q + 4 * i) * 8);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float lo = __uint_as_float(x4[j] << 16), hi = __uint_as_float(x4[j] & 0xffff0000u);
+                                s1 += lo + hi;
+                                s2 += lo * lo + hi * hi;
+                            }
+                        }
+                        s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2);
+                        s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2);
+                        const float mean = s1 * (1.f / 320.f);
+                        if (q == 0) *reinterpret_cast<f32x2_t*>(lnS + 640 + 2 * r) = f32x2_t{mean, rsqrtf(fmaxf(s2 * (1.f / 320.f) - mean * mean, 0.f) + P.ln_eps)};
+                    }
+                    __syncthreads();                                     // (also: every thread's copy of the rows to `out` has left the staging tile)
+                    // (2) normalise in place: thread = (chunk column, row group) -- gamma / beta' of its 8 columns in registers, rows rg, rg + 12, ...
+                    if (tid < 480) {
+                        const int ch = tid % 40, rg = tid / 40;
+                        const f32x4 g0 = *reinterpret_cast<const f32x4*>(lnS + ch * 8), g1 = *reinterpret_cast<const f32x4*>(lnS + ch * 8 + 4);
+                        const f32x4 b0 = *reinterpret_cast<const f32x4*>(lnS + 320 + ch * 8), b1 = *reinterpret_cast<const f32x4*>(lnS + 324 + ch * 8);
+#pragma unroll 1
+                        for (int r = rg; r < 80; r += 12) {
+                            u32x4* px = reinterpret_cast<u32x4*>(Os + r * OP + ch * 8);
+                            const u32x4 x4 = *px;
+                            const f32x2_t st = *reinterpret_cast<const f32x2_t*>(lnS + 640 + 2 * r);
+                            const float m = st[0], rs = st[1];
+                            u32x4 o4;
+                            o4[0] = pack_bf2((__uint_as_float(x4[0] << 16) - m) * rs * g0[0] + b0[0], (__uint_as_float(x4[0] & 0xffff0000u) - m) * rs * g0[1] + b0[1]);
+                            o4[1] = pack_bf2((__uint_as_float(x4[1] << 16) - m) * rs * g0[2] + b0[2], (__uint_as_float(x4[1] & 0xffff0000u) - m) * rs * g0[3] + b0[3]);
+                            o4[2] = pack_bf2((__uint_as_float(x4[2] << 16) - m) * rs * g1[0] + b1[0], (__uint_as_float(x4[2] & 0xffff0000u) - m) * rs * g1[1] + b1[1]);
+                            o4[3] = pack_bf2((__uint_as_float(x4[3] << 16) - m) * rs * g1[2] + b1[2], (__uint_as_float(x4[3] & 0xffff0000u) - m) * rs * g1[3] + b1[3]);
+                            *px = o4;
+                        }
+                    }
+                    __syncthreads();
+                    // (3) whole-row stores of the LayerNorm output
+#pragma unroll
+                    for (int it = 0; it < 7; ++it) {
+                        int c = tid + it * NT;
+                        if (c >= 80 * CPR) c -= NT;
+                        const int r = c / CPR, ch = c - r * CPR;
+                        *reinterpret_cast<u32x4*>(P.ln_out + (m0 + pass * 80 + r) * (int64_t)BN + ch * 8) = *reinterpret_cast<const u32x4*>(Os + r * OP + ch * 8);
+                    }
                 }
                 __syncthreads();                                         // Os is free again
             }
@@ -2528,16 +2591,25 @@ void launch_gemm160(GemmParams& P, hipStream_t st) {
         static const int persist = getenv("FMC_G160_PERSIST") ? atoi(getenv("FMC_G160_PERSIST")) : 1;
         const int cus = fmc_cu_count() & ~7;
         if (persist && !P.f32io && P.M % 160 == 0 && P.tiles_m * P.tiles_n > cus && cus >= 8) {
-            constexpr size_t ldsp = (size_t)3 * (160 + 320) * 32 * sizeof(bf16_t) + 1024 + (EPI == 1 ? (size_t)160 * 168 * 2 : (size_t)80 * 328 * 2 + 4096);
+            constexpr size_t ldsp = (size_t)3 * (160 + 320) * 32 * sizeof(bf16_t) + 1024 + (EPI == 1 ? (size_t)160 * 168 * 2 : (size_t)80 * 328 * 2 + 5120);
             static bool raisedp = false;
             if (!raisedp) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm160p_kernel<EPI, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+                if constexpr (EPI == 0)
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm160p_kernel<0, 5, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
                 raisedp = true;
+            }
+            if constexpr (EPI == 0) {
+                if (P.ln_out) {                               // (linear_impl has checked N == 320 and no GroupNorm partials)
+                    hipLaunchKernelGGL((gemm160p_kernel<0, 5, 1>), dim3((unsigned)cus), dim3(512), ldsp, st, P);
+                    return;
+                }
             }
             hipLaunchKernelGGL((gemm160p_kernel<EPI, 5>), dim3((unsigned)cus), dim3(512), ldsp, st, P);
             return;
         }
     }
+    P.ln_out = nullptr;                                       // (not reached with ln_out set: fmc_linear_bf16_ln checks the persistent form's conditions)
     hipLaunchKernelGGL((gemm160_kernel<MODE, EPI>), dim3((unsigned)(P.tiles_m * P.tiles_n)), dim3(512), lds, st, P);
 }
 
@@ -2662,7 +2734,9 @@ int set_split_k(GemmParams& P, int split_k, void* workspace, int64_t workspace_b
 static int linear_impl(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,
                        int N, int K, int64_t ldx, int64_t ldres, int64_t ldo, float alpha, int epilogue, int tile,
                        int split_k, void* workspace, int64_t workspace_bytes, const void* x2, int64_t ldx2,
-                       int k_split, const void* residual2, void* stream, int f32io, void* gn_partials = nullptr, int gn_hw = 0) {
+                       int k_split, const void* residual2, void* stream, int f32io, void* gn_partials = nullptr, int gn_hw = 0,
+                       void* ln_out = nullptr, const float* ln_gamma = nullptr, const float* ln_beta = nullptr, float ln_eps = 0.f,
+                       const float* ln_pe = nullptr, int ln_pe_inner = 1, int ln_pe_frames = 1) {
     if (!x || !w || !out) FMC_FAIL(FMC_E_NULL, "linear_bf16: NULL tensor");
     if (M <= 0 || N <= 0 || K <= 0 || K % BK_MAX || N % 8 || ldx % 8 || ldo % (f32io ? 4 : 8) || (residual && ldres % (f32io ? 4 : 8)))
         FMC_FAIL(FMC_E_SHAPE, "linear_bf16: need K%%64==0, N%%8==0 and strides %%8==0 (M=%lld N=%d K=%d)", (long long)M, N, K);
@@ -2684,6 +2758,16 @@ static int linear_impl(const void* x, const void* w, const void* bias, const voi
                         ((M - 1) * ldx + K) * 2 >= ((int64_t)1 << 31) || (int64_t)N * K * 2 >= ((int64_t)1 << 31)))
         FMC_FAIL(FMC_E_SHAPE, "linear_bf16: GroupNorm partials come out of tile 16's plain bf16 epilogue only (N %% 320 == 0, pixels per image %% 160 == 0)");
     P.gn_part = (float*)gn_partials; P.gn_hw = gn_hw;
+    if (ln_out) {
+        const int cus = fmc_cu_count() & ~7;
+        if (f32io || epilogue != 0 || tile != 16 || split_k != 1 || gn_partials || x2 || N != 320 || M % 160 || M / 160 <= cus || cus < 8 || !ln_gamma ||
+            !ln_beta || !fmc_aligned16(ln_out) || (ln_pe && (ln_pe_inner <= 0 || ln_pe_inner % 160 || ln_pe_frames <= 0)) ||
+            ((M - 1) * ldx + K) * 2 >= ((int64_t)1 << 31) || (getenv("FMC_G160_PERSIST") && atoi(getenv("FMC_G160_PERSIST")) == 0))
+            FMC_FAIL(FMC_E_SHAPE, "linear_bf16_ln: the LayerNorm output comes out of tile 16's persistent form only (bf16, N == 320, M %% 160 == 0, "
+                                  "M / 160 > CUs, plain epilogue, positional-encoding frames of a multiple of 160 rows)");
+    }
+    P.ln_out = (bf16_t*)ln_out; P.ln_gamma = ln_gamma; P.ln_beta = ln_beta; P.ln_eps = ln_eps; P.ln_pe = ln_pe;
+    P.ln_pe_inner = ln_pe_inner; P.ln_pe_frames = ln_pe_frames;
     if (x2 && (k_split <= 0 || k_split >= K || k_split % BK_MAX || ldx2 % 8 || !fmc_aligned16(x2)))
         FMC_FAIL(FMC_E_SHAPE, "linear_bf16: two-source input needs 0 < k_split < K, k_split %% 64 == 0 (k_split=%d K=%d)", k_split, K);
     P.a2 = (const bf16_t*)x2; P.lda2 = ldx2; P.ksplit = x2 ? k_split : 0;
@@ -2709,6 +2793,15 @@ extern "C" int fmc_linear_bf16_gn(const void* x, const void* w, const void* bias
     if (!gn_partials) FMC_FAIL(FMC_E_NULL, "linear_bf16_gn: NULL gn_partials");
     return linear_impl(x, w, bias, residual, out, M, N, K, ldx, ldres, ldo, alpha, 0, 16, 1, nullptr, 0, nullptr, 0, 0, residual2, stream, 0,
                        gn_partials, gn_hw);
+}
+
+extern "C" int fmc_linear_bf16_ln(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,
+                                  int N, int K, int64_t ldx, int64_t ldres, int64_t ldo, float alpha, const void* residual2,
+                                  void* ln_out, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* ln_pe,
+                                  int ln_pe_inner, int ln_pe_frames, void* stream) {
+    if (!ln_out || !ln_gamma || !ln_beta) FMC_FAIL(FMC_E_NULL, "linear_bf16_ln: NULL ln_out / gamma / beta");
+    return linear_impl(x, w, bias, residual, out, M, N, K, ldx, ldres, ldo, alpha, 0, 16, 1, nullptr, 0, nullptr, 0, 0, residual2, stream, 0,
+                       nullptr, 0, ln_out, ln_gamma, ln_beta, ln_eps, ln_pe, ln_pe_inner, ln_pe_frames);
 }
 
 extern "C" int fmc_linear_x3_f32(const void* x3, const void* w3, const float* bias, const float* residual, float* out, int64_t M,

@@ -882,6 +882,73 @@ def conv3x3_bf16(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias: Optional[t
     return out
 
 
+LN_EPILOGUE = os.environ.get("FMC_LN_EPILOGUE", "1") != "0"      # A/B switch: the consumer's LayerNorm out of the producing GEMM's epilogue
+ln_epilogue_calls = {"emitted": 0, "consumed": 0}
+
+
+class LnSpec:
+    """The LayerNorm a GEMM output feeds (`fmc_linear_bf16_ln`): fp32 gamma / beta, eps, optional positional-encoding table `[>= frames, C]`
+    with `pe[(row // pe_inner) % pe_frames]` added after normalising; `key` identifies the consumer (module, pe arguments)."""
+    __slots__ = ("gamma", "beta", "eps", "pe", "pe_inner", "pe_frames", "key")
+
+    def __init__(self, gamma, beta, eps, pe, pe_inner, pe_frames, key):
+        self.gamma, self.beta, self.eps, self.pe, self.pe_inner, self.pe_frames, self.key = gamma, beta, eps, pe, pe_inner, pe_frames, key
+
+
+_cu_count = {}
+
+
+def _cus(device) -> int:
+    n = _cu_count.get(device.index)
+    if n is None:
+        n = _cu_count[device.index] = torch.cuda.get_device_properties(device).multi_processor_count & ~7
+    return n
+
+
+def ln_emit_ok(x: torch.Tensor, weight: torch.Tensor, residual, residual2, ln: LnSpec) -> bool:
+    N, Kd = weight.shape
+    M = x.numel() // x.shape[-1]
+    return (LN_EPILOGUE and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
+            and x.is_contiguous() and weight.is_contiguous() and N == 320 and Kd % 64 == 0 and M % 160 == 0 and M // 160 > _cus(x.device)
+            and ln.gamma.numel() == 320 and ln.gamma.dtype == torch.float32 and ln.beta.dtype == torch.float32
+            and (ln.pe is None or (ln.pe.dtype == torch.float32 and ln.pe.is_contiguous() and ln.pe.shape[-1] == 320 and ln.pe_inner % 160 == 0
+                                   and ln.pe.shape[0] >= ln.pe_frames))
+            and (residual is None or (residual.is_contiguous() and residual.dtype == x.dtype))
+            and (residual2 is None or residual2.is_contiguous()) and M * max(Kd, 320) * 2 < (1 << 31) and os.environ.get("FMC_G160_PERSIST", "1") != "0")
+
+
+def carry_ln(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    tag = getattr(src, "_fmc_ln", None)
+    if tag is not None:
+        dst._fmc_ln = tag
+    return dst
+
+
+def take_ln(x: torch.Tensor, key) -> Optional[torch.Tensor]:
+    """LayerNorm(x) if x's producer already wrote it for exactly this consumer, else None."""
+    tag = getattr(x, "_fmc_ln", None)
+    if tag is None or tag[1] != key or torch.is_grad_enabled():
+        return None
+    ln_epilogue_calls["consumed"] += 1
+    return tag[0].view(x.shape)
+
+
+def linear_ln(x: torch.Tensor, weight: torch.Tensor, bias, residual, alpha: float, residual2, ln: LnSpec) -> torch.Tensor:
+    """`linear_bf16` on the persistent 160 x 320 kernel that also writes the consumer's LayerNorm: out carries `_fmc_ln = (ln_out, key)`."""
+    _dev(x, weight, bias, residual, ln.gamma, ln.beta, ln.pe)
+    N, Kd = weight.shape
+    M, ldx = _rows2d(x)
+    out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
+    ln_out = torch.empty_like(out)
+    ldres = 0 if residual is None else _rows2d(residual)[1]
+    ln_epilogue_calls["emitted"] += 1
+    _lib.check(_lib.load().fmc_linear_bf16_ln(x.data_ptr(), weight.data_ptr(), _p(bias), _p(residual), out.data_ptr(), M, N, Kd, ldx, ldres, N,
+                                              float(alpha), _p(residual2), ln_out.data_ptr(), ln.gamma.data_ptr(), ln.beta.data_ptr(), float(ln.eps),
+                                              _p(ln.pe), int(ln.pe_inner), int(ln.pe_frames), _stream()), "fmc_linear_bf16_ln")
+    out._fmc_ln = (ln_out, ln.key)
+    return out
+
+
 def linear_gn(x: torch.Tensor, weight: torch.Tensor, bias, residual, alpha: float, residual2, hw: int):
     """`linear_bf16` on the 160 x 320 kernel + the GroupNorm partial sums of the output: (out, partials [M / hw, hw / 160, 32, 2])."""
     _dev(x, weight, bias, residual)
@@ -1195,7 +1262,7 @@ def _pick(key, hip_fn, lib_fn, static_hip: bool, extra_arms=(), k320: bool = Fal
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
            residual: Optional[torch.Tensor] = None, alpha: float = 1.0, x2: Optional[torch.Tensor] = None,
-           residual2: Optional[torch.Tensor] = None, gn_hw: int = 0) -> torch.Tensor:
+           residual2: Optional[torch.Tensor] = None, gn_hw: int = 0, ln: Optional["LnSpec"] = None) -> torch.Tensor:
     """`alpha * (x @ weight^T + bias) + residual [+ residual2]` for bf16 device tensors (see `linear_bf16`).  With `x2`
     the input is the concat `[x, x2]` along the last dim; the fused kernel reads the two tensors in place."""
     import torch.nn.functional as F
@@ -1223,6 +1290,9 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     if not ok or (x.ndim > 2 and not x.is_contiguous()):
         return lib()
     M = x.numel() // x.shape[-1]
+    if ln is not None and x2 is None and not gn_hw and ln_emit_ok(x, weight, residual, residual2, ln):
+        # the consumer is a LayerNorm and the 160 x 320 tile holds whole rows (N == 320): it leaves the epilogue too, x is not read again
+        return linear_ln(x, weight, bias, residual, alpha, residual2, ln)
     if (gn_hw and x2 is None and x.is_contiguous() and gn_emit_ok(M, N, Kd, gn_hw, x.dtype)
             and (residual is None or (residual.is_contiguous() and residual.dtype == x.dtype))
             and (residual2 is None or residual2.is_contiguous())):

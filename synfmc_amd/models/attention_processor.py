@@ -57,7 +57,8 @@ def _attention_core(attn, q_in: torch.Tensor, kv_in: Optional[torch.Tensor], tem
         q = linear_op(q_in, w_a)
         kv = linear_op(kv_in, w_b)
         o = K.cross_attention_q_kv(q, kv, heads, attn.scale)
-    return linear_op(o, w_o, attn.to_out[0].bias, residual)
+    # (`_next_ln`: the LayerNorm the block applies to `attn(x) + x` -- set by the block, consumed by hip_ops.linear when the tile holds whole rows)
+    return linear_op(o, w_o, attn.to_out[0].bias, residual, ln=attn.__dict__.get("_next_ln") if residual is not None else None)
 
 
 def _fusable(attn, residual, shape4):

@@ -68,8 +68,18 @@ class GroupNorm(nn.GroupNorm):
 
 
 class LayerNorm(nn.LayerNorm):
+    def ln_spec(self, pe: Optional[torch.Tensor] = None, pe_inner: int = 1, pe_frames: int = 1):
+        """What a producing GEMM needs to write this norm's output from its own epilogue (`hip_ops.linear(..., ln=...)`)."""
+        return K.LnSpec(f32_param(self, "weight"), f32_param(self, "bias"), self.eps, pe, pe_inner, pe_frames, self._ln_key(pe, pe_inner, pe_frames))
+
+    def _ln_key(self, pe, pe_inner, pe_frames):
+        return (id(self), self.weight._version, self.bias._version, None if pe is None else (pe.data_ptr(), pe._version), pe_inner, pe_frames)
+
     def forward(self, x: torch.Tensor, pe: Optional[torch.Tensor] = None, pe_inner: int = 1,
                 pe_frames: int = 1) -> torch.Tensor:
+        done = K.take_ln(x, self._ln_key(pe, pe_inner, pe_frames))      # the producer of x has written LayerNorm(x) already
+        if done is not None:
+            return done
         if not x.is_contiguous():
             x = x.contiguous()
         return K.layernorm(x, f32_param(self, "weight"), f32_param(self, "bias"), self.eps, pe, pe_inner, pe_frames)
@@ -135,14 +145,14 @@ class Conv2d(nn.Conv2d):
         return hit[1]
 
 
-def linear_op(x, weight, bias=None, residual=None, alpha: float = 1.0, x2=None, gn_hw: int = 0):
+def linear_op(x, weight, bias=None, residual=None, alpha: float = 1.0, x2=None, gn_hw: int = 0, ln=None):
     """`alpha * (x @ W^T + b) + residual`: fused gfx950 GEMM or hipBLASLt + epilogue passes (`hip_ops.linear`) for
     frozen bf16 weights on the GPU, plain autograd ops otherwise."""
     if x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16:
         grad = torch.is_grad_enabled()
         if not (grad and (x.requires_grad or weight.requires_grad or (residual is not None and residual.requires_grad)
                           or (x2 is not None and x2.requires_grad))):
-            return K.linear(x, weight, bias, residual, alpha, x2, gn_hw=gn_hw)
+            return K.linear(x, weight, bias, residual, alpha, x2, gn_hw=gn_hw, ln=ln)
         if x2 is not None:
             x, x2 = torch.cat([x, x2], dim=-1), None
         if not weight.requires_grad and (bias is None or not bias.requires_grad):   # frozen layer, activation gradient only
@@ -462,6 +472,11 @@ class BasicTransformerBlock(nn.Module):
                 cfg_expand: bool = False):
         kw = dict(cross_attention_kwargs) if cross_attention_kwargs is not None else {}
         kw.pop("gligen", None)
+        # the LayerNorm behind each attention leaves its output projection's epilogue where the tile holds whole rows (hip_ops.linear_ln)
+        nxt = self.norm2 if self.attn2 is not None else self.norm3
+        self.attn1.__dict__["_next_ln"] = None if (cfg_expand or torch.is_grad_enabled()) else nxt.ln_spec()
+        if self.attn2 is not None:
+            self.attn2.__dict__["_next_ln"] = None if torch.is_grad_enabled() else self.norm3.ln_spec()
         # `attn(...) + hidden_states` / `ff(...) + hidden_states`: the residual rides in the output projection's epilogue
         hidden_states = self.attn1(self.norm1(hidden_states), encoder_hidden_states=None,
                                    attention_mask=attention_mask, _residual=hidden_states, **kw)
@@ -509,7 +524,8 @@ class Transformer2DModel(nn.Module):
         residual = to_tokens(hidden_states)
         x = K.groupnorm_silu(residual, f32_param(self.norm, "weight"), f32_param(self.norm, "bias"),
                              self.norm.num_groups, self.norm.eps, False, gn_tag=getattr(hidden_states, "_fmc_gn", None))
-        x = linear_op(x, self.proj_in.weight.view(self.proj_in.out_channels, c), self.proj_in.bias)
+        x = linear_op(x, self.proj_in.weight.view(self.proj_in.out_channels, c), self.proj_in.bias,
+                      ln=None if torch.is_grad_enabled() else self.transformer_blocks[0].norm1.ln_spec())
         for bi, blk in enumerate(self.transformer_blocks):
             x = blk(x, attention_mask=attention_mask, encoder_hidden_states=encoder_hidden_states,
                     encoder_attention_mask=encoder_attention_mask, timestep=timestep,

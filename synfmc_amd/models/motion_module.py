@@ -147,6 +147,15 @@ class TemporalTransformerBlock(nn.Module):
             frames, inner = hidden_states.shape[1], hidden_states.shape[2]
         else:
             frames, inner = hidden_states.shape[1], 1
+        def spec(i):                                    # the norm (+ positional encoding) in front of attention block i, or the FF norm
+            if torch.is_grad_enabled():
+                return None
+            if i >= len(self.attention_blocks):
+                return self.ff_norm.ln_spec()
+            enc = self.attention_blocks[i].pos_encoder
+            return self.norms[i].ln_spec() if enc is None else self.norms[i].ln_spec(enc.table(), inner, frames)
+        for i, attention_block in enumerate(self.attention_blocks):
+            attention_block.__dict__["_next_ln"] = spec(i + 1)
         for attention_block, norm in zip(self.attention_blocks, self.norms):
             pe = attention_block.pos_encoder
             if pe is not None:       # LayerNorm and `pos_encoder(norm(x))` in one pass (motion_module.py:288,355)
@@ -197,7 +206,13 @@ class TemporalTransformer3DModel(nn.Module):
         residual = t.view(b * f, h * w, c)
         x = K.groupnorm_silu(residual, f32_param(self.norm, "weight"), f32_param(self.norm, "bias"),
                              self.norm.num_groups, self.norm.eps, False, gn_tag=getattr(hidden_states, "_fmc_gn", None))
-        x = linear_op(x, self.proj_in.weight, self.proj_in.bias).view(b, f, h * w, -1)
+        blk0 = self.transformer_blocks[0]
+        ln0 = None
+        if not torch.is_grad_enabled():                  # the first block's first norm (+ PE) leaves proj_in's epilogue
+            enc0 = blk0.attention_blocks[0].pos_encoder
+            ln0 = blk0.norms[0].ln_spec() if enc0 is None else blk0.norms[0].ln_spec(enc0.table(), h * w, f)
+        x = linear_op(x, self.proj_in.weight, self.proj_in.bias, ln=ln0)
+        x = K.carry_ln(x, x.view(b, f, h * w, -1))
         for block in self.transformer_blocks:
             x = block(x, encoder_hidden_states=encoder_hidden_states, attention_mask=attention_mask,
                       cross_attention_kwargs=cross_attention_kwargs)

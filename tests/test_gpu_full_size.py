@@ -79,11 +79,13 @@ def _step(g6, dtype, monkeypatch):
 
 def test_bench_step_16x320x512_bf16_vs_reference_golden(g6, monkeypatch):
     from synfmc_amd import hip_ops as K
-    before = dict(K.gn_epilogue_calls)
+    before, before_ln = dict(K.gn_epilogue_calls), dict(K.ln_epilogue_calls)
     eager, graph, notraj, _ = _step(g6, torch.bfloat16, monkeypatch)
     used = {k: K.gn_epilogue_calls[k] - before[k] for k in before}
-    print(f"GroupNorm statistics from producing epilogues: {used}")
+    used_ln = {k: K.ln_epilogue_calls[k] - before_ln[k] for k in before_ln}
+    print(f"GroupNorm statistics from producing epilogues: {used}; LayerNorms written by producing epilogues: {used_ln}")
     assert used["consumed"] >= 3 * 15                                        # (3 eager forwards; the 40x64-level single-source GroupNorms)
+    assert used_ln["consumed"] >= 3 * 25 and used_ln["consumed"] == used_ln["emitted"]   # (the 40x64-level LayerNorms; none written in vain)
     ref = g6["eps"]
     e = rel_inf(eager, ref)
     print(f"16x320x512 CFG-2 step, bf16: rel-inf vs the reference code's output {e:.3e}")

@@ -1382,3 +1382,58 @@ def test_gemm_256x320_persistent_geglu(K):
         assert torch.equal(K.linear_bf16(xd, wi, None, geglu=True, tile=K.ARM_256), K.linear_bf16(xd, wi, None, geglu=True, tile=K.ARM_160))
     xo, xd = rnd((81920, 320), 43, dtype)
     assert torch.equal(K.linear_bf16(xd, gd, None, None, 1.0, tile=K.ARM_256), K.linear_bf16(xd, gd, None, None, 1.0, tile=K.ARM_160))
+
+
+@torch.no_grad()
+def test_linear_with_the_consumers_layernorm_in_its_epilogue(K):
+    """`fmc_linear_bf16_ln` (persistent 160 x 320 kernel, N == 320): `out` is bit-identical to the plain launch; `ln_out` is the LayerNorm
+    (+ positional-encoding row of the tile's frame) of the ROUNDED rows -- element-wise against an fp64 LayerNorm of `out`, and within one
+    bf16 ulp of what `fmc_layernorm_fwd` makes of the same tensor.  Several launches on fresh data (exact-count stores around the counted
+    vmcnt double with the second output), bias / residual / two residuals, K = 320 and 1280; ineligible shapes carry no tag."""
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    gamma, beta = (1.0 + 0.3 * torch.randn(320, generator=g)).cuda(), (0.2 * torch.randn(320, generator=g)).cuda()
+    pe = torch.randn(32, 320, generator=g).cuda()
+    for (M, Kd, frames, inner) in [(81920, 320, 16, 2560), (81920, 1280, 16, 2560), (48000, 320, 3, 16000)]:
+        wo, wd = rnd((320, Kd), 45, dtype, scale=Kd ** -0.5)
+        bo, bd = rnd((320,), 46, dtype)
+        for it in range(3):
+            xo, xd = rnd((M, Kd), 740 + it, dtype)
+            ro, rd = rnd((M, 320), 840 + it, dtype)
+            use_pe = it != 1
+            spec = K.LnSpec(gamma, beta, 1e-5, pe if use_pe else None, inner if use_pe else 1, frames if use_pe else 1, ("test", it))
+            assert K.ln_emit_ok(xd, wd, rd, None, spec)
+            got = K.linear(xd, wd, bd, rd, 0.5, ln=spec)
+            want = K.linear_bf16(xd, wd, bd, rd, 0.5, tile=512)
+            assert torch.equal(got, want), f"out differs from the plain launch {(M, Kd)} it {it}"
+            ln_out, key = got._fmc_ln
+            assert key == ("test", it) and K.take_ln(got, ("other",)) is None and torch.equal(K.take_ln(got, key), ln_out)
+            o64 = got.double().cpu()
+            mu, var = o64.mean(-1, keepdim=True), o64.var(-1, unbiased=False, keepdim=True)
+            ref = (o64 - mu) / torch.sqrt(var + 1e-5) * gamma.double().cpu() + beta.double().cpu()
+            mag = ((o64 - mu).abs() / torch.sqrt(var + 1e-5) * gamma.double().cpu().abs() + beta.double().cpu().abs())
+            if use_pe:
+                rows = (torch.arange(M) // inner) % frames
+                ref = ref + pe.double().cpu()[rows]
+                mag = mag + pe.double().cpu()[rows].abs()
+            assert_bf16_close(ln_out, ref, 8.0 * mag + 1.0, f"ln_out {(M, Kd)} it {it}")
+            sep = K.layernorm(got, gamma, beta, 1e-5, pe if use_pe else None, inner if use_pe else 1, frames if use_pe else 1)
+            d = (ln_out.float() - sep.float()).abs()
+            assert float((d / sep.float().abs().clamp_min(1e-2)).max()) < 2.0 ** -6, "more than a bf16 ulp or two from the LayerNorm kernel"
+            assert float((d > 0).float().mean()) < 0.02
+            if it == 0:
+                assert torch.equal(K.linear(xd, wd, bd, rd, 0.5, ln=spec)._fmc_ln[0], ln_out)                     # deterministic
+                r2o, r2d = rnd((M, 320), 940, dtype)
+                got2 = K.linear(xd, wd, None, rd, 1.0, residual2=r2d, ln=spec)
+                assert torch.equal(got2, K.linear_bf16(xd, wd, None, rd, 1.0, tile=512, residual2=r2d))
+                assert rel_inf(got2._fmc_ln[0].float(), K.layernorm(got2, gamma, beta, 1e-5, pe, inner, frames).float()) < 8e-3
+    # ineligible: too few tiles, N != 320, frames that are not whole tiles -> plain result, no tag
+    xo, xd = rnd((20480, 320), 41, dtype)
+    wo, wd = rnd((320, 320), 42, dtype, scale=320 ** -0.5)
+    spec = K.LnSpec(gamma, beta, 1e-5, None, 1, 1, ("t",))
+    assert getattr(K.linear(xd, wd, None, None, 1.0, ln=spec), "_fmc_ln", None) is None
+    xo, xd = rnd((81920, 320), 43, dtype)
+    assert getattr(K.linear(xd, wd, None, None, 1.0, ln=K.LnSpec(gamma, beta, 1e-5, pe, 2000, 16, ("t",))), "_fmc_ln", None) is None
+    w6o, w6d = rnd((640, 320), 44, dtype, scale=320 ** -0.5)
+    g6 = torch.ones(640, device="cuda")
+    assert getattr(K.linear(xd, w6d, None, None, 1.0, ln=K.LnSpec(g6, g6, 1e-5, None, 1, 1, ("t",))), "_fmc_ln", None) is None
