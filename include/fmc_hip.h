@@ -265,7 +265,17 @@ int fmc_linear_bf16_gn(const void* x, const void* w, const void* bias, const voi
  *   gamma / beta / pe fp32.  Anything else is FMC_E_SHAPE (callers fall back to fmc_linear_bf16 + fmc_layernorm_fwd). */
 int fmc_linear_bf16_ln(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int N, int K,
                        int64_t ldx, int64_t ldres, int64_t ldo, float alpha, const void* residual2, void* ln_out, const float* ln_gamma,
-                       const float* ln_beta, float ln_eps, const float* ln_pe, int ln_pe_inner, int ln_pe_frames, void* stream);
+                       const float* ln_beta, float ln_eps, const float* ln_pe, int ln_pe_inner, int ln_pe_frames, float* ln_stats, void* stream);
+/* ... or, with ln_out == NULL and ln_stats != NULL, only the rows' statistics: ln_stats[M][2] = (mean, rstd) fp32 -- for a consumer that is a
+ * GEMM and applies the LayerNorm itself:
+ * fmc_linear_bf16_lnc = LayerNorm(x) @ w^T + b computed WITHOUT materialising LayerNorm(x): with w_gamma = w diag(gamma) (bf16),
+ *   ln_c[n] = sum_k w_gamma[n, k] and ln_bias = w beta + b (fp32 [N]),   out[m, n] = rstd[m] (x[m, :] . w_gamma[n, :] - mean[m] ln_c[n]) + ln_bias[n]
+ *   in the epilogue of tile 16's persistent form (epilogue 0, or 1 = GEGLU on [8 value | 8 gate]-ordered rows, ln_c / ln_bias in the same
+ *   order); the products are exact in fp32 (bf16 x bf16), so the only new rounding is that of w gamma to bf16, in place of LayerNorm(x) to
+ *   bf16.  Call sites: attn1 / attn2.to_q / the GEGLU projection behind norm1 / norm2 / norm3 of diffusers' BasicTransformerBlock and behind
+ *   the motion module's ff_norm (fmc/models/motion_module.py:295-299).  Needs bf16, N % 320 == 0, M % 160 == 0, more 160 x 320 tiles than CUs. */
+int fmc_linear_bf16_lnc(const void* x, const void* w_gamma, void* out, int64_t M, int N, int K, int64_t ldx, int64_t ldo, int epilogue,
+                        const float* ln_stats, const float* ln_c, const float* ln_bias, void* stream);
 int fmc_conv3x3_bf16_gn(const void* x, const void* w, const void* bias, const void* temb, const void* residual, void* out, int n_img,
                         int H, int W, int Cin, int Cout, int64_t temb_row_stride, int temb_img_div, int upsample2x,
                         float* gn_partials, void* stream);

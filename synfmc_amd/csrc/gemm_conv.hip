@@ -72,6 +72,9 @@ struct GemmParams {
     bf16_t* ln_out;                   // gemm160p_kernel, plain epilogue, N == 320: ALSO write LayerNorm(out rows) * gamma + beta (+ pe row) here
     const float* ln_gamma; const float* ln_beta; const float* ln_pe;   //   (the consumer's norm: the tile holds whole rows, x is not read again);
     float ln_eps; int ln_pe_inner, ln_pe_frames;                        //   pe row of output row m = ((m / ln_pe_inner) % ln_pe_frames), ln_pe_inner % 160 == 0
+    float* ln_stats;                  // ... or only the rows' (mean, rstd) -> ln_stats[M][2], for a consumer GEMM that applies the LayerNorm itself:
+    const float* lnc_stats; const float* lnc_c; const float* lnc_bias;  // gemm160p_kernel as that consumer (W pre-scaled by gamma): out = rstd[m] (acc -
+                                      //   mean[m] c[n]) + lnc_bias[n], c[n] = sum_k W'[n, k], lnc_bias = W beta + bias (fp32 [N]); alpha 1, no bf16 bias
     int f32io;                        // fp32-storage ("parity") mode: A / W are split-bf16 x3 operands (fmc_split_bf16x3), bias / temb /
                                       // residual(s) / out are FP32 tensors (the bf16_t pointers above are reinterpreted), see epi_f32_*
 };
@@ -1778,22 +1781,24 @@ void gemm160_kernel(const GemmParams P) {
 // `(v - mean) * rstd * gamma + (beta + pe row)` in place by (8-column chunk, row group) threads that keep their gamma / beta in registers,
 // whole-row stores.  (Statistics and normalisation straight from the accumulator registers -- the first form -- cost 110-200 spilled
 // registers, reloaded inside the main loop.)  The separate LayerNorm launch and its read of the tensor disappear.
-template <int EPI, int MB, int LN = 0>
+template <int EPI, int MB, int LN = 0, int LNC = 0>
 __global__ __launch_bounds__(512, 2)
 void gemm160p_kernel(const GemmParams P) {
     constexpr int BM = 32 * MB, BN = 320, BK = 32, NT = 512, NBUF = 3;
     constexpr int NE = (20 + BM / 16 + 7) / 8;       // operand requests per wave and sub-tile (20 W pieces + BM / 16 A pieces + dummies)
     static_assert(20 % NE == 0, "a wave's requests are all W or all A");
     constexpr int SUB_ELEMS = (BM + BN) * BK;        // 30 (36) KiB per sub-tile buffer
-    constexpr int S_EPI = MB == 5 ? (EPI == 1 ? 7 : 14 * (1 + LN)) : 10;   // global stores per thread and tile (see the header)
+    constexpr int S_EPI = MB == 5 ? (EPI == 1 ? 7 : (LN == 1 ? 28 : (LN == 2 ? 16 : 14))) : 10;   // global stores per thread and tile (see the header)
     static_assert(!LN || (EPI == 0 && MB == 5), "LayerNorm rides in the plain epilogue of the 160-row tile");
     static_assert(MB == 5 || (MB == 8 && EPI == 1), "the 256-row tile has the GEGLU epilogue only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
     auto lds0 = (__attribute__((address_space(3))) unsigned char*)smem_raw;
     bf16_t* Os = smem + NBUF * SUB_ELEMS + 512;      // staging: [80][328] (plain epilogue, per pass) or [160][168] (GEGLU)
-    float* lnS = reinterpret_cast<float*>(Os + 80 * (BN + 8));   // LN: [gamma 320 | beta + pe row 320 | (mean, rstd) x 80 rows]  (shares the GroupNorm scratch)
-    if (LN && threadIdx.x < 320) lnS[threadIdx.x] = P.ln_gamma[threadIdx.x];   // (published by the main loop's barriers long before the first epilogue)
+    // LN: [gamma 320 | beta + pe row 320 | (mean, rstd) x 80 rows]; LNC: [c 320 | bias' 320 | (mean, rstd) x BM rows]  (behind the staging tile;
+    // shares the GroupNorm scratch)
+    float* lnS = reinterpret_cast<float*>(Os + (EPI == 1 ? (MB == 5 ? 160 : 128) * 168 : 80 * (BN + 8)));
+    if (LN == 1 && threadIdx.x < 320) lnS[threadIdx.x] = P.ln_gamma[threadIdx.x];   // (published by the main loop's barriers long before the first epilogue)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1887,6 +1892,15 @@ void gemm160p_kernel(const GemmParams P) {
         tile_of(tile, tile_m, tile_n);
         const int64_t m0 = (int64_t)tile_m * BM;
         const int n0 = tile_n * BN;
+        // LNC: this tile's row statistics and column constants are requested NOW (three loads per thread, every lane active so that all
+        // waves count alike) and parked in LDS at the head of the epilogue -- read there from global memory they were two exposed round trips per tile
+        f32x2_t pre_st = f32x2_t{0.f, 0.f};
+        float pre_c = 0.f, pre_b = 0.f;
+        if (LNC) {
+            pre_st = *reinterpret_cast<const f32x2_t*>(P.lnc_stats + (m0 + tid % BM) * 2);
+            pre_c = P.lnc_c[n0 + tid % BN];
+            pre_b = P.lnc_bias[n0 + tid % BN];
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int a = 0; a < MB; ++a)
@@ -1897,7 +1911,7 @@ void gemm160p_kernel(const GemmParams P) {
             read_frags(smem + rbuf * SUB_ELEMS);
             rbuf = rbuf + 1 == NBUF ? 0 : rbuf + 1;
             issue();                                  // sub-tile g + 2 (of this tile or the next)
-            if (g == 0 && after_epi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S_EPI + NE) : "memory");
+            if (g == 0 && after_epi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S_EPI + NE + 3 * LNC) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NE) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -1916,11 +1930,24 @@ void gemm160p_kernel(const GemmParams P) {
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();    // the wave rows meet for the epilogue
         __builtin_amdgcn_sched_barrier(0);
+        if (LNC) {                                    // lnS: [c 320 | bias' 320 | (mean, rstd) x BM]
+            if (tid < BM) *reinterpret_cast<f32x2_t*>(lnS + 640 + 2 * tid) = pre_st;
+            if (tid < BN) { lnS[tid] = pre_c; lnS[320 + tid] = pre_b; }
+            __syncthreads();
+        }
 
         // ---- epilogue through Os (the ring keeps streaming) ------------------------------------------------------------------------------
         if (EPI == 1) {
             const bool hi = lane >= 32;
             const int oq = 4 * (kq & 1);
+            float lmu[MB], lrs[MB];                                      // (mean, rstd) of my rows when this GEMM applies its input's LayerNorm
+            if (LNC) {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const f32x2_t t = *reinterpret_cast<const f32x2_t*>(lnS + 640 + (wr * 16 * MB + mb * 16 + l15) * 2);
+                    lmu[mb] = t[0]; lrs[mb] = t[1];
+                }
+            }
             auto gate_pair = [&](f32x4& x, f32x4& y, int mbx, int nbx, int mby, int nby, bool single) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {             // x = [x.value | y.value], y = [x.gate | y.gate]
@@ -1931,6 +1958,13 @@ void gemm160p_kernel(const GemmParams P) {
                 const int nbm = hi ? nby : nbx, mbm = hi ? mby : mbx;
                 const int tn = wc * 80 + nbm * 16;
                 float bv[4] = {0.f, 0.f, 0.f, 0.f}, bg[4] = {0.f, 0.f, 0.f, 0.f};
+                if (LNC) {                        // the LayerNorm of my A rows, applied here (W carries gamma): see GemmParams
+                    const float mu = hi ? lmu[mby] : lmu[mbx], rs = hi ? lrs[mby] : lrs[mbx];
+                    const f32x4 cv = *reinterpret_cast<const f32x4*>(lnS + tn + oq), cg = *reinterpret_cast<const f32x4*>(lnS + tn + 8 + oq);
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(lnS + 320 + tn + oq), b1 = *reinterpret_cast<const f32x4*>(lnS + 320 + tn + 8 + oq);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { x[j] = rs * (x[j] - mu * cv[j]); y[j] = rs * (y[j] - mu * cg[j]); bv[j] = b0[j]; bg[j] = b1[j]; }
+                } else
                 if (P.bias) {
                     const u32x2 t = *reinterpret_cast<const u32x2*>(P.bias + n0 + tn + oq);
                     const u32x2 u = *reinterpret_cast<const u32x2*>(P.bias + n0 + tn + 8 + oq);
@@ -1985,8 +2019,25 @@ void gemm160p_kernel(const GemmParams P) {
             }
         } else if constexpr (MB == 5) {
             constexpr int OP = BN + 8, CPR = BN / 8;                     // staging rows of 328 bf16, 40 chunks per row
-            if (LN && tid < 320)                                         // beta + the positional-encoding row of this tile's frame (tile-uniform)
+            if (LN == 1 && tid < 320)                                    // beta + the positional-encoding row of this tile's frame (tile-uniform)
                 lnS[320 + tid] = P.ln_beta[tid] + (P.ln_pe ? P.ln_pe[(size_t)((m0 / P.ln_pe_inner) % P.ln_pe_frames) * 320 + tid] : 0.f);
+            if (LNC) {                                           // the LayerNorm of my A rows, applied here (W carries gamma): see GemmParams
+                float mu[5], rs[5];
+#pragma unroll
+                for (int mb = 0; mb < 5; ++mb) {
+                    const f32x2_t t = *reinterpret_cast<const f32x2_t*>(lnS + 640 + (wr * 80 + mb * 16 + l15) * 2);
+                    mu[mb] = t[0]; rs[mb] = t[1];
+                }
+#pragma unroll
+                for (int nb = 0; nb < 5; ++nb) {
+                    const int n = n0 + wc * 80 + nb * 16 + 4 * kq;
+                    const f32x4 c4 = *reinterpret_cast<const f32x4*>(lnS + n - n0), b4 = *reinterpret_cast<const f32x4*>(lnS + 320 + n - n0);
+#pragma unroll
+                    for (int mb = 0; mb < 5; ++mb)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[mb][nb][j] = rs[mb] * (acc[mb][nb][j] - mu[mb] * c4[j]) + b4[j];
+                }
+            } else
             // alpha * (acc + bias) in the accumulator registers
 #pragma unroll
             for (int nb = 0; nb < 5; ++nb) {
@@ -2065,8 +2116,12 @@ void gemm160p_kernel(const GemmParams P) {
                         if (q == 0) *reinterpret_cast<f32x2_t*>(lnS + 640 + 2 * r) = f32x2_t{mean, rsqrtf(fmaxf(s2 * (1.f / 320.f) - mean * mean, 0.f) + P.ln_eps)};
                     }
                     __syncthreads();                                     // (also: every thread's copy of the rows to `out` has left the staging tile)
+                    if (LN == 2) {                                       // the consumer GEMM normalises: it only needs (mean, rstd) per row; one store per thread
+                        const int r = tid % 80;
+                        *reinterpret_cast<f32x2_t*>(P.ln_stats + (m0 + pass * 80 + r) * 2) = *reinterpret_cast<const f32x2_t*>(lnS + 640 + 2 * r);
+                    }
                     // (2) normalise in place: thread = (chunk column, row group) -- gamma / beta' of its 8 columns in registers, rows rg, rg + 12, ...
-                    if (tid < 480) {
+                    if (LN == 1 && tid < 480) {
                         const int ch = tid % 40, rg = tid / 40;
                         const f32x4 g0 = *reinterpret_cast<const f32x4*>(lnS + ch * 8), g1 = *reinterpret_cast<const f32x4*>(lnS + ch * 8 + 4);
                         const f32x4 b0 = *reinterpret_cast<const f32x4*>(lnS + 320 + ch * 8), b1 = *reinterpret_cast<const f32x4*>(lnS + 324 + ch * 8);
@@ -2084,10 +2139,10 @@ void gemm160p_kernel(const GemmParams P) {
                             *px = o4;
                         }
                     }
-                    __syncthreads();
+                    if (LN == 1) __syncthreads();
                     // (3) whole-row stores of the LayerNorm output
 #pragma unroll
-                    for (int it = 0; it < 7; ++it) {
+                    for (int it = 0; it < (LN == 1 ? 7 : 0); ++it) {
                         int c = tid + it * NT;
                         if (c >= 80 * CPR) c -= NT;
                         const int r = c / CPR, ch = c - r * CPR;
@@ -2591,17 +2646,28 @@ void launch_gemm160(GemmParams& P, hipStream_t st) {
         static const int persist = getenv("FMC_G160_PERSIST") ? atoi(getenv("FMC_G160_PERSIST")) : 1;
         const int cus = fmc_cu_count() & ~7;
         if (persist && !P.f32io && P.M % 160 == 0 && P.tiles_m * P.tiles_n > cus && cus >= 8) {
-            constexpr size_t ldsp = (size_t)3 * (160 + 320) * 32 * sizeof(bf16_t) + 1024 + (EPI == 1 ? (size_t)160 * 168 * 2 : (size_t)80 * 328 * 2 + 5120);
+            constexpr size_t ldsp = (size_t)3 * (160 + 320) * 32 * sizeof(bf16_t) + 1024 + (EPI == 1 ? (size_t)160 * 168 * 2 + 4096 : (size_t)80 * 328 * 2 + 5120);
             static bool raisedp = false;
             if (!raisedp) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm160p_kernel<EPI, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
-                if constexpr (EPI == 0)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm160p_kernel<EPI, 5, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+                if constexpr (EPI == 0) {
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm160p_kernel<0, 5, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm160p_kernel<0, 5, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+                }
                 raisedp = true;
+            }
+            if (P.lnc_stats) {                                // this GEMM applies the LayerNorm of its input rows (linear_impl has checked the rest)
+                hipLaunchKernelGGL((gemm160p_kernel<EPI, 5, 0, 1>), dim3((unsigned)cus), dim3(512), ldsp, st, P);
+                return;
             }
             if constexpr (EPI == 0) {
                 if (P.ln_out) {                               // (linear_impl has checked N == 320 and no GroupNorm partials)
                     hipLaunchKernelGGL((gemm160p_kernel<0, 5, 1>), dim3((unsigned)cus), dim3(512), ldsp, st, P);
+                    return;
+                }
+                if (P.ln_stats) {
+                    hipLaunchKernelGGL((gemm160p_kernel<0, 5, 2>), dim3((unsigned)cus), dim3(512), ldsp, st, P);
                     return;
                 }
             }
@@ -2609,7 +2675,7 @@ void launch_gemm160(GemmParams& P, hipStream_t st) {
             return;
         }
     }
-    P.ln_out = nullptr;                                       // (not reached with ln_out set: fmc_linear_bf16_ln checks the persistent form's conditions)
+    // (not reached with ln_out / ln_stats / lnc_stats set: linear_impl checks the persistent form's conditions)
     hipLaunchKernelGGL((gemm160_kernel<MODE, EPI>), dim3((unsigned)(P.tiles_m * P.tiles_n)), dim3(512), lds, st, P);
 }
 
@@ -2736,7 +2802,8 @@ static int linear_impl(const void* x, const void* w, const void* bias, const voi
                        int split_k, void* workspace, int64_t workspace_bytes, const void* x2, int64_t ldx2,
                        int k_split, const void* residual2, void* stream, int f32io, void* gn_partials = nullptr, int gn_hw = 0,
                        void* ln_out = nullptr, const float* ln_gamma = nullptr, const float* ln_beta = nullptr, float ln_eps = 0.f,
-                       const float* ln_pe = nullptr, int ln_pe_inner = 1, int ln_pe_frames = 1) {
+                       const float* ln_pe = nullptr, int ln_pe_inner = 1, int ln_pe_frames = 1, float* ln_stats = nullptr,
+                       const float* lnc_stats = nullptr, const float* lnc_c = nullptr, const float* lnc_bias = nullptr) {
     if (!x || !w || !out) FMC_FAIL(FMC_E_NULL, "linear_bf16: NULL tensor");
     if (M <= 0 || N <= 0 || K <= 0 || K % BK_MAX || N % 8 || ldx % 8 || ldo % (f32io ? 4 : 8) || (residual && ldres % (f32io ? 4 : 8)))
         FMC_FAIL(FMC_E_SHAPE, "linear_bf16: need K%%64==0, N%%8==0 and strides %%8==0 (M=%lld N=%d K=%d)", (long long)M, N, K);
@@ -2758,14 +2825,26 @@ static int linear_impl(const void* x, const void* w, const void* bias, const voi
                         ((M - 1) * ldx + K) * 2 >= ((int64_t)1 << 31) || (int64_t)N * K * 2 >= ((int64_t)1 << 31)))
         FMC_FAIL(FMC_E_SHAPE, "linear_bf16: GroupNorm partials come out of tile 16's plain bf16 epilogue only (N %% 320 == 0, pixels per image %% 160 == 0)");
     P.gn_part = (float*)gn_partials; P.gn_hw = gn_hw;
-    if (ln_out) {
+    if (lnc_stats) {                                          // consumer: LayerNorm of the A rows applied in the epilogue (W pre-scaled by gamma)
         const int cus = fmc_cu_count() & ~7;
-        if (f32io || epilogue != 0 || tile != 16 || split_k != 1 || gn_partials || x2 || N != 320 || M % 160 || M / 160 <= cus || cus < 8 || !ln_gamma ||
-            !ln_beta || !fmc_aligned16(ln_out) || (ln_pe && (ln_pe_inner <= 0 || ln_pe_inner % 160 || ln_pe_frames <= 0)) ||
+        if (f32io || tile != 16 || split_k != 1 || gn_partials || ln_out || ln_stats || x2 || bias || residual || residual2 || alpha != 1.f || N % 320 ||
+            M % 160 || (M / 160) * (N / 320) <= cus || cus < 8 || !lnc_c || !lnc_bias || !fmc_aligned16(lnc_c) || !fmc_aligned16(lnc_bias) ||
+            ((M - 1) * ldx + K) * 2 >= ((int64_t)1 << 31) || (int64_t)N * K * 2 >= ((int64_t)1 << 31) ||
+            (getenv("FMC_G160_PERSIST") && atoi(getenv("FMC_G160_PERSIST")) == 0))
+            FMC_FAIL(FMC_E_SHAPE, "linear_bf16_lnc: tile 16's persistent form only (bf16, N %% 320 == 0, M %% 160 == 0, more tiles than CUs, no bf16 bias / "
+                                  "residual, alpha 1)");
+    }
+    P.lnc_stats = lnc_stats; P.lnc_c = lnc_c; P.lnc_bias = lnc_bias;
+    if (ln_out || ln_stats) {
+        const int cus = fmc_cu_count() & ~7;
+        if ((ln_out != nullptr) == (ln_stats != nullptr)) FMC_FAIL(FMC_E_NULL, "linear_bf16_ln: exactly one of ln_out / ln_stats");
+        if (f32io || epilogue != 0 || tile != 16 || split_k != 1 || gn_partials || x2 || N != 320 || M % 160 || M / 160 <= cus || cus < 8 ||
+            (ln_out && (!ln_gamma || !ln_beta || !fmc_aligned16(ln_out))) || (ln_stats && ((uintptr_t)ln_stats & 7)) || (ln_pe && (ln_pe_inner <= 0 || ln_pe_inner % 160 || ln_pe_frames <= 0)) ||
             ((M - 1) * ldx + K) * 2 >= ((int64_t)1 << 31) || (getenv("FMC_G160_PERSIST") && atoi(getenv("FMC_G160_PERSIST")) == 0))
             FMC_FAIL(FMC_E_SHAPE, "linear_bf16_ln: the LayerNorm output comes out of tile 16's persistent form only (bf16, N == 320, M %% 160 == 0, "
                                   "M / 160 > CUs, plain epilogue, positional-encoding frames of a multiple of 160 rows)");
     }
+    P.ln_stats = ln_stats;
     P.ln_out = (bf16_t*)ln_out; P.ln_gamma = ln_gamma; P.ln_beta = ln_beta; P.ln_eps = ln_eps; P.ln_pe = ln_pe;
     P.ln_pe_inner = ln_pe_inner; P.ln_pe_frames = ln_pe_frames;
     if (x2 && (k_split <= 0 || k_split >= K || k_split % BK_MAX || ldx2 % 8 || !fmc_aligned16(x2)))
@@ -2798,10 +2877,18 @@ extern "C" int fmc_linear_bf16_gn(const void* x, const void* w, const void* bias
 extern "C" int fmc_linear_bf16_ln(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,
                                   int N, int K, int64_t ldx, int64_t ldres, int64_t ldo, float alpha, const void* residual2,
                                   void* ln_out, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* ln_pe,
-                                  int ln_pe_inner, int ln_pe_frames, void* stream) {
-    if (!ln_out || !ln_gamma || !ln_beta) FMC_FAIL(FMC_E_NULL, "linear_bf16_ln: NULL ln_out / gamma / beta");
+                                  int ln_pe_inner, int ln_pe_frames, float* ln_stats, void* stream) {
+    if (!ln_out && !ln_stats) FMC_FAIL(FMC_E_NULL, "linear_bf16_ln: NULL ln_out and ln_stats");
+    if (ln_out && (!ln_gamma || !ln_beta)) FMC_FAIL(FMC_E_NULL, "linear_bf16_ln: NULL gamma / beta");
     return linear_impl(x, w, bias, residual, out, M, N, K, ldx, ldres, ldo, alpha, 0, 16, 1, nullptr, 0, nullptr, 0, 0, residual2, stream, 0,
-                       nullptr, 0, ln_out, ln_gamma, ln_beta, ln_eps, ln_pe, ln_pe_inner, ln_pe_frames);
+                       nullptr, 0, ln_out, ln_gamma, ln_beta, ln_eps, ln_pe, ln_pe_inner, ln_pe_frames, ln_stats);
+}
+
+extern "C" int fmc_linear_bf16_lnc(const void* x, const void* w_gamma, void* out, int64_t M, int N, int K, int64_t ldx, int64_t ldo, int epilogue,
+                                   const float* ln_stats, const float* ln_c, const float* ln_bias, void* stream) {
+    if (!ln_stats || !ln_c || !ln_bias) FMC_FAIL(FMC_E_NULL, "linear_bf16_lnc: NULL ln_stats / ln_c / ln_bias");
+    return linear_impl(x, w_gamma, nullptr, nullptr, out, M, N, K, ldx, 0, ldo, 1.f, epilogue, 16, 1, nullptr, 0, nullptr, 0, 0, nullptr, stream, 0,
+                       nullptr, 0, nullptr, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr, ln_stats, ln_c, ln_bias);
 }
 
 extern "C" int fmc_linear_x3_f32(const void* x3, const void* w3, const float* bias, const float* residual, float* out, int64_t M,

@@ -889,10 +889,11 @@ ln_epilogue_calls = {"emitted": 0, "consumed": 0}
 class LnSpec:
     """The LayerNorm a GEMM output feeds (`fmc_linear_bf16_ln`): fp32 gamma / beta, eps, optional positional-encoding table `[>= frames, C]`
     with `pe[(row // pe_inner) % pe_frames]` added after normalising; `key` identifies the consumer (module, pe arguments)."""
-    __slots__ = ("gamma", "beta", "eps", "pe", "pe_inner", "pe_frames", "key")
+    __slots__ = ("gamma", "beta", "eps", "pe", "pe_inner", "pe_frames", "key", "stats_only")
 
-    def __init__(self, gamma, beta, eps, pe, pe_inner, pe_frames, key):
+    def __init__(self, gamma, beta, eps, pe, pe_inner, pe_frames, key, stats_only: bool = False):
         self.gamma, self.beta, self.eps, self.pe, self.pe_inner, self.pe_frames, self.key = gamma, beta, eps, pe, pe_inner, pe_frames, key
+        self.stats_only = stats_only                    # the consumer is a GEMM that applies the norm itself (`linear_lnc`): only (mean, rstd) per row
 
 
 _cu_count = {}
@@ -927,10 +928,83 @@ def carry_ln(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
 def take_ln(x: torch.Tensor, key) -> Optional[torch.Tensor]:
     """LayerNorm(x) if x's producer already wrote it for exactly this consumer, else None."""
     tag = getattr(x, "_fmc_ln", None)
-    if tag is None or tag[1] != key or torch.is_grad_enabled():
+    if tag is None or tag[1] != key or torch.is_grad_enabled() or tag[2]:
         return None
     ln_epilogue_calls["consumed"] += 1
     return tag[0].view(x.shape)
+
+
+def take_ln_stats(x: torch.Tensor, key) -> Optional[torch.Tensor]:
+    """(mean, rstd) `[M, 2]` fp32 of x's rows if x's producer wrote them for exactly this consumer, else None."""
+    tag = getattr(x, "_fmc_ln", None)
+    if tag is None or tag[1] != key or torch.is_grad_enabled() or not tag[2]:
+        return None
+    return tag[0]
+
+
+def pending_ln(x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
+    """x itself (a fresh view, so the tag stays off the residual stream's tensor) marked "LayerNorm still to be applied": the next
+    `linear` / `geglu_linear` applies it in its epilogue (`linear_lnc`) or, where it cannot, materialises it first (`resolve_pending_ln`).
+    Only call sites whose consumer is one of those two may ask for this (LayerNorm.forward(defer=True))."""
+    v = x.view(x.shape)
+    v._fmc_pending_ln = (stats, gamma, beta, eps)
+    return v
+
+
+def resolve_pending_ln(x: torch.Tensor) -> torch.Tensor:
+    pend = getattr(x, "_fmc_pending_ln", None)
+    if pend is None:
+        return x
+    ln_epilogue_calls["materialised"] = ln_epilogue_calls.get("materialised", 0) + 1
+    return _layernorm_raw(x.contiguous(), pend[1], pend[2], pend[3], None, 1, 1)
+
+
+def _ln_folded_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):
+    """(W diag(gamma) in bf16, c[n] = sum_k of it, W beta + bias) for `fmc_linear_bf16_lnc`; cached on the tensor that owns W's storage."""
+    owner = weight._base if weight._base is not None else weight
+    key = (weight.storage_offset(), tuple(weight.shape), weight._version, gamma.data_ptr(), gamma._version, beta.data_ptr(), beta._version,
+           None if bias is None else (bias.data_ptr(), bias._version))
+    cache = getattr(owner, "_fmc_lnw", None)
+    if cache is None or cache[0] != owner._version:
+        cache = (owner._version, {})
+        try:
+            owner._fmc_lnw = cache
+        except Exception:
+            pass
+    hit = cache[1].get(key)
+    if hit is None:
+        with torch.no_grad():
+            w32 = weight.detach().float()
+            wg = (w32 * gamma.float()[None, :]).to(torch.bfloat16).contiguous()
+            b = w32 @ beta.float()
+            if bias is not None:
+                b = b + bias.detach().float()
+            hit = (wg, wg.float().sum(dim=1).contiguous(), b.contiguous())
+        cache[1][key] = hit
+    return hit
+
+
+def lnc_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    N, Kd = weight.shape
+    M = x.numel() // x.shape[-1]
+    return (LN_EPILOGUE and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
+            and x.is_contiguous() and N % 320 == 0 and Kd % 64 == 0 and M % 160 == 0 and (M // 160) * (N // 320) > _cus(x.device)
+            and M * max(Kd, 320) * 2 < (1 << 31) and N * Kd * 2 < (1 << 31) and os.environ.get("FMC_G160_PERSIST", "1") != "0")
+
+
+def linear_lnc(x: torch.Tensor, weight: torch.Tensor, bias, pend, geglu: bool = False) -> torch.Tensor:
+    """`LayerNorm(x) @ weight^T + bias` (or its GEGLU) with the norm applied in the GEMM's epilogue from the producer's (mean, rstd)."""
+    stats, gamma, beta, _ = pend
+    wg, c, b = _ln_folded_weight(weight, bias, gamma, beta)
+    _dev(x, wg, c, b, stats)
+    N, Kd = weight.shape
+    M, ldx = _rows2d(x)
+    n_out = N // 2 if geglu else N
+    out = torch.empty(*x.shape[:-1], n_out, dtype=x.dtype, device=x.device)
+    ln_epilogue_calls["consumed"] += 1
+    _lib.check(_lib.load().fmc_linear_bf16_lnc(x.data_ptr(), wg.data_ptr(), out.data_ptr(), M, N, Kd, ldx, n_out, int(geglu), stats.data_ptr(),
+                                               c.data_ptr(), b.data_ptr(), _stream()), "fmc_linear_bf16_lnc")
+    return out
 
 
 def linear_ln(x: torch.Tensor, weight: torch.Tensor, bias, residual, alpha: float, residual2, ln: LnSpec) -> torch.Tensor:
@@ -939,13 +1013,17 @@ def linear_ln(x: torch.Tensor, weight: torch.Tensor, bias, residual, alpha: floa
     N, Kd = weight.shape
     M, ldx = _rows2d(x)
     out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
-    ln_out = torch.empty_like(out)
     ldres = 0 if residual is None else _rows2d(residual)[1]
     ln_epilogue_calls["emitted"] += 1
+    if ln.stats_only:
+        stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+        ln_out = None
+    else:
+        stats, ln_out = None, torch.empty_like(out)
     _lib.check(_lib.load().fmc_linear_bf16_ln(x.data_ptr(), weight.data_ptr(), _p(bias), _p(residual), out.data_ptr(), M, N, Kd, ldx, ldres, N,
-                                              float(alpha), _p(residual2), ln_out.data_ptr(), ln.gamma.data_ptr(), ln.beta.data_ptr(), float(ln.eps),
-                                              _p(ln.pe), int(ln.pe_inner), int(ln.pe_frames), _stream()), "fmc_linear_bf16_ln")
-    out._fmc_ln = (ln_out, ln.key)
+                                              float(alpha), _p(residual2), _p(ln_out), ln.gamma.data_ptr(), ln.beta.data_ptr(), float(ln.eps),
+                                              _p(ln.pe), int(ln.pe_inner), int(ln.pe_frames), _p(stats), _stream()), "fmc_linear_bf16_ln")
+    out._fmc_ln = (stats, ln.key, True) if ln.stats_only else (ln_out, ln.key, False)
     return out
 
 
@@ -1266,6 +1344,12 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     """`alpha * (x @ weight^T + bias) + residual [+ residual2]` for bf16 device tensors (see `linear_bf16`).  With `x2`
     the input is the concat `[x, x2]` along the last dim; the fused kernel reads the two tensors in place."""
     import torch.nn.functional as F
+    pend = getattr(x, "_fmc_pending_ln", None)
+    if pend is not None:                                # x's LayerNorm is still to be applied (LayerNorm.forward(defer=True))
+        if (x2 is None and residual is None and residual2 is None and alpha == 1.0 and not gn_hw and ln is None and weight.is_contiguous()
+                and lnc_ok(x, weight)):
+            return linear_lnc(x, weight, bias, pend)
+        x = resolve_pending_ln(x)
 
     def lib():
         xin = x if x2 is None else torch.cat([x, x2], dim=-1)
@@ -1312,6 +1396,11 @@ def geglu_linear(x: torch.Tensor, weight: torch.Tensor, bias, weight_il: torch.T
     `bias_il` are the tile-interleaved copies the fused kernel wants (`models.layers.interleave_geglu`); `weight_il160` /
     `bias_il160` the [8 value | 8 gate]-per-16 order of the 160 x 320 arm (without them arm 16 is not a candidate)."""
     import torch.nn.functional as F
+    pend = getattr(x, "_fmc_pending_ln", None)
+    if pend is not None:
+        if weight_il160 is not None and weight_il160.is_contiguous() and lnc_ok(x, weight_il160):
+            return linear_lnc(x, weight_il160, bias_il160, pend, geglu=True)
+        x = resolve_pending_ln(x)
     lib = lambda: geglu(F.linear(x, weight, bias))
     if (F32_GEMM and x.is_cuda and x.dtype == torch.float32 and weight_il.dtype == torch.float32 and weight_il.shape[0] % 64 == 0
             and weight_il.shape[1] % 64 == 0 and x.is_contiguous()):

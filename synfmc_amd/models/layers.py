@@ -68,16 +68,25 @@ class GroupNorm(nn.GroupNorm):
 
 
 class LayerNorm(nn.LayerNorm):
-    def ln_spec(self, pe: Optional[torch.Tensor] = None, pe_inner: int = 1, pe_frames: int = 1):
-        """What a producing GEMM needs to write this norm's output from its own epilogue (`hip_ops.linear(..., ln=...)`)."""
-        return K.LnSpec(f32_param(self, "weight"), f32_param(self, "bias"), self.eps, pe, pe_inner, pe_frames, self._ln_key(pe, pe_inner, pe_frames))
+    def ln_spec(self, pe: Optional[torch.Tensor] = None, pe_inner: int = 1, pe_frames: int = 1, stats_only: bool = False):
+        """What a producing GEMM needs to write this norm's output (or, `stats_only`, its rows' mean / rstd for a consumer GEMM that
+        applies the norm itself) from its own epilogue (`hip_ops.linear(..., ln=...)`)."""
+        return K.LnSpec(f32_param(self, "weight"), f32_param(self, "bias"), self.eps, pe, pe_inner, pe_frames, self._ln_key(pe, pe_inner, pe_frames),
+                        stats_only)
 
     def _ln_key(self, pe, pe_inner, pe_frames):
         return (id(self), self.weight._version, self.bias._version, None if pe is None else (pe.data_ptr(), pe._version), pe_inner, pe_frames)
 
     def forward(self, x: torch.Tensor, pe: Optional[torch.Tensor] = None, pe_inner: int = 1,
-                pe_frames: int = 1) -> torch.Tensor:
-        done = K.take_ln(x, self._ln_key(pe, pe_inner, pe_frames))      # the producer of x has written LayerNorm(x) already
+                pe_frames: int = 1, defer: bool = False) -> torch.Tensor:
+        """`defer`: the caller hands the result straight to `linear_op` / the GEGLU projection; when x's producer left the rows' statistics,
+        x comes back marked "norm pending" and that GEMM applies it in its epilogue -- LayerNorm(x) is never written."""
+        key = self._ln_key(pe, pe_inner, pe_frames)
+        if defer and pe is None:
+            stats = K.take_ln_stats(x, key)
+            if stats is not None:
+                return K.pending_ln(x, stats, f32_param(self, "weight"), f32_param(self, "bias"), self.eps)
+        done = K.take_ln(x, key)                                        # the producer of x has written LayerNorm(x) already
         if done is not None:
             return done
         if not x.is_contiguous():
@@ -148,6 +157,8 @@ class Conv2d(nn.Conv2d):
 def linear_op(x, weight, bias=None, residual=None, alpha: float = 1.0, x2=None, gn_hw: int = 0, ln=None):
     """`alpha * (x @ W^T + b) + residual`: fused gfx950 GEMM or hipBLASLt + epilogue passes (`hip_ops.linear`) for
     frozen bf16 weights on the GPU, plain autograd ops otherwise."""
+    if getattr(x, "_fmc_pending_ln", None) is not None and not (x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and not torch.is_grad_enabled()):
+        x = K.resolve_pending_ln(x)                     # (never on the paths that defer a norm; kept so that a pending norm cannot be dropped)
     if x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16:
         grad = torch.is_grad_enabled()
         if not (grad and (x.requires_grad or weight.requires_grad or (residual is not None and residual.requires_grad)
@@ -431,7 +442,7 @@ class GEGLU(nn.Module):
                     hit = (key, interleave_geglu(w.detach(), b) + il160)
                 self.__dict__["_il"] = hit
             return K.geglu_linear(hidden_states, w, self.proj.bias, hit[1][0], hit[1][1], hit[1][2], hit[1][3])
-        return K.geglu(self.proj(hidden_states))
+        return K.geglu(self.proj(K.resolve_pending_ln(hidden_states)))
 
 
 class FeedForward(nn.Module):
@@ -473,19 +484,21 @@ class BasicTransformerBlock(nn.Module):
         kw = dict(cross_attention_kwargs) if cross_attention_kwargs is not None else {}
         kw.pop("gligen", None)
         # the LayerNorm behind each attention leaves its output projection's epilogue where the tile holds whole rows (hip_ops.linear_ln)
+        # ... as its rows' statistics only: every norm of this block feeds a GEMM (QKV / to_q / the GEGLU projection), which applies it in its
+        # own epilogue on gamma-scaled weights (hip_ops.linear_lnc, `defer=True` below) -- LayerNorm(x) is neither written nor read.
         nxt = self.norm2 if self.attn2 is not None else self.norm3
-        self.attn1.__dict__["_next_ln"] = None if (cfg_expand or torch.is_grad_enabled()) else nxt.ln_spec()
+        self.attn1.__dict__["_next_ln"] = None if (cfg_expand or torch.is_grad_enabled()) else nxt.ln_spec(stats_only=True)
         if self.attn2 is not None:
-            self.attn2.__dict__["_next_ln"] = None if torch.is_grad_enabled() else self.norm3.ln_spec()
+            self.attn2.__dict__["_next_ln"] = None if torch.is_grad_enabled() else self.norm3.ln_spec(stats_only=True)
         # `attn(...) + hidden_states` / `ff(...) + hidden_states`: the residual rides in the output projection's epilogue
-        hidden_states = self.attn1(self.norm1(hidden_states), encoder_hidden_states=None,
+        hidden_states = self.attn1(self.norm1(hidden_states, defer=True), encoder_hidden_states=None,
                                    attention_mask=attention_mask, _residual=hidden_states, **kw)
         if cfg_expand:          # shared classifier-free-guidance prefix ends here: the text cross-attention is the first op that tells the halves apart
             hidden_states = torch.cat([hidden_states, hidden_states], dim=0)
         if self.attn2 is not None:
-            hidden_states = self.attn2(self.norm2(hidden_states), encoder_hidden_states=encoder_hidden_states,
+            hidden_states = self.attn2(self.norm2(hidden_states, defer=True), encoder_hidden_states=encoder_hidden_states,
                                        attention_mask=encoder_attention_mask, _residual=hidden_states, **kw)
-        return self.ff(self.norm3(hidden_states), residual=hidden_states)
+        return self.ff(self.norm3(hidden_states, defer=True), residual=hidden_states)
 
 
 class Transformer2DModelOutput:
@@ -525,7 +538,7 @@ class Transformer2DModel(nn.Module):
         x = K.groupnorm_silu(residual, f32_param(self.norm, "weight"), f32_param(self.norm, "bias"),
                              self.norm.num_groups, self.norm.eps, False, gn_tag=getattr(hidden_states, "_fmc_gn", None))
         x = linear_op(x, self.proj_in.weight.view(self.proj_in.out_channels, c), self.proj_in.bias,
-                      ln=None if torch.is_grad_enabled() else self.transformer_blocks[0].norm1.ln_spec())
+                      ln=None if torch.is_grad_enabled() else self.transformer_blocks[0].norm1.ln_spec(stats_only=True))
         for bi, blk in enumerate(self.transformer_blocks):
             x = blk(x, attention_mask=attention_mask, encoder_hidden_states=encoder_hidden_states,
                     encoder_attention_mask=encoder_attention_mask, timestep=timestep,

@@ -151,7 +151,7 @@ class TemporalTransformerBlock(nn.Module):
             if torch.is_grad_enabled():
                 return None
             if i >= len(self.attention_blocks):
-                return self.ff_norm.ln_spec()
+                return self.ff_norm.ln_spec(stats_only=True)         # (feeds the GEGLU projection only: applied in that GEMM's epilogue)
             enc = self.attention_blocks[i].pos_encoder
             return self.norms[i].ln_spec() if enc is None else self.norms[i].ln_spec(enc.table(), inner, frames)
         for i, attention_block in enumerate(self.attention_blocks):
@@ -164,7 +164,7 @@ class TemporalTransformerBlock(nn.Module):
                 n = norm(hidden_states)
             hidden_states = attention_block(n, encoder_hidden_states=None, attention_mask=attention_mask,
                                             _pe_applied=True, _residual=hidden_states, **cross_attention_kwargs)
-        return self.ff(self.ff_norm(hidden_states), residual=hidden_states)
+        return self.ff(self.ff_norm(hidden_states, defer=True), residual=hidden_states)
 
 
 class TemporalTransformer3DModel(nn.Module):

@@ -86,6 +86,7 @@ def test_bench_step_16x320x512_bf16_vs_reference_golden(g6, monkeypatch):
     print(f"GroupNorm statistics from producing epilogues: {used}; LayerNorms written by producing epilogues: {used_ln}")
     assert used["consumed"] >= 3 * 15                                        # (3 eager forwards; the 40x64-level single-source GroupNorms)
     assert used_ln["consumed"] >= 3 * 25 and used_ln["consumed"] == used_ln["emitted"]   # (the 40x64-level LayerNorms; none written in vain)
+    assert used_ln.get("materialised", 0) == 0                                             # (no deferred norm had to be materialised after all)
     ref = g6["eps"]
     e = rel_inf(eager, ref)
     print(f"16x320x512 CFG-2 step, bf16: rel-inf vs the reference code's output {e:.3e}")

@@ -1406,7 +1406,8 @@ def test_linear_with_the_consumers_layernorm_in_its_epilogue(K):
             got = K.linear(xd, wd, bd, rd, 0.5, ln=spec)
             want = K.linear_bf16(xd, wd, bd, rd, 0.5, tile=512)
             assert torch.equal(got, want), f"out differs from the plain launch {(M, Kd)} it {it}"
-            ln_out, key = got._fmc_ln
+            ln_out, key, stats_only = got._fmc_ln
+            assert not stats_only
             assert key == ("test", it) and K.take_ln(got, ("other",)) is None and torch.equal(K.take_ln(got, key), ln_out)
             o64 = got.double().cpu()
             mu, var = o64.mean(-1, keepdim=True), o64.var(-1, unbiased=False, keepdim=True)
@@ -1437,3 +1438,62 @@ def test_linear_with_the_consumers_layernorm_in_its_epilogue(K):
     w6o, w6d = rnd((640, 320), 44, dtype, scale=320 ** -0.5)
     g6 = torch.ones(640, device="cuda")
     assert getattr(K.linear(xd, w6d, None, None, 1.0, ln=K.LnSpec(g6, g6, 1e-5, None, 1, 1, ("t",))), "_fmc_ln", None) is None
+
+
+@torch.no_grad()
+def test_layernorm_applied_in_the_consuming_gemm(K):
+    """`fmc_linear_bf16_ln(ln_stats=...)` + `fmc_linear_bf16_lnc`: the producer's epilogue leaves (mean, rstd) of its rounded output rows,
+    the consumer GEMM runs on gamma-scaled weights and applies `rstd (acc - mean c) + (W beta + b)` -- LayerNorm(x) is never written.
+    Against an fp64 LayerNorm + projection of the SAME bf16 producer output (so the bound is the usual one for a bf16 GEMM: the
+    gamma-scaled weights are rounded where the unfused path rounds the normalised activations), plain and GEGLU epilogues, a non-zero
+    row mean (cancellation in `acc - mean c`), several launches; and the front-end's fall-back when the consumer is not eligible."""
+    dtype = torch.bfloat16
+    from synfmc_amd.models.layers import interleave_geglu
+    g = torch.Generator().manual_seed(6)
+    gamma, beta = (1.0 + 0.3 * torch.randn(320, generator=g)).cuda(), (0.2 * torch.randn(320, generator=g)).cuda()
+    M = 81920
+    wo, wd = rnd((320, 320), 45, dtype, scale=320 ** -0.5)
+    for it in range(3):
+        xo, xd = rnd((M, 320), 750 + it, dtype)
+        ro, rd = rnd((M, 320), 850 + it, dtype)
+        rd = (rd.float() + (3.0 if it == 2 else 0.0)).to(dtype)                                     # it 2: rows with mean ~ 3 sigma
+        spec = K.LnSpec(gamma, beta, 1e-5, None, 1, 1, ("t", it), stats_only=True)
+        h = K.linear(xd, wd, None, rd, 1.0, ln=spec)
+        assert torch.equal(h, K.linear_bf16(xd, wd, None, rd, 1.0, tile=512))
+        stats = K.take_ln_stats(h, ("t", it))
+        assert stats is not None and K.take_ln(h, ("t", it)) is None
+        h64 = h.double().cpu()
+        mu, var = h64.mean(-1), h64.var(-1, unbiased=False)
+        assert float((stats[:, 0].double().cpu() - mu).abs().max()) < 1e-5 * (1.0 + float(mu.abs().max()))
+        assert float((stats[:, 1].double().cpu() * torch.sqrt(var + 1e-5) - 1.0).abs().max()) < 1e-4
+        ln64 = (h64 - mu[:, None]) / torch.sqrt(var + 1e-5)[:, None] * gamma.double().cpu() + beta.double().cpu()
+        pend = K.pending_ln(h, stats, gamma, beta, 1e-5)
+        for (N, bias_on) in [(960, False), (320, True)]:
+            qo, qd = rnd((N, 320), 47 + N, dtype, scale=320 ** -0.5)
+            bo, bd = rnd((N,), 48, dtype)
+            got = K.linear(pend, qd, bd if bias_on else None)
+            ref = F.linear(ln64, qo.double(), bo.double() if bias_on else None)
+            mag = ln64.abs() @ qo.abs().double().t() + (bo.abs().double() if bias_on else 0.0)
+            assert got.shape == (M, N)
+            assert float(((got.double().cpu() - ref).abs() / (2.0 ** -7 * mag + 2.0 ** -8 * ref.abs() + 1e-3)).max()) < 1.0, f"lnc plain N={N} it={it}"
+            unfused = K.linear(K.layernorm(h, gamma, beta, 1e-5), qd, bd if bias_on else None)
+            assert rel_inf(got.float(), unfused.float()) < 2e-2
+        go, gd = rnd((2560, 320), 42, dtype, scale=320 ** -0.5)
+        gbo, gbd = rnd((2560,), 40, dtype)
+        wi32, bi32 = interleave_geglu(gd, gbd)
+        wi8, bi8 = interleave_geglu(gd, gbd, 8)
+        before = dict(K.ln_epilogue_calls)
+        outg = K.geglu_linear(pend, gd, gbd, wi32, bi32, wi8, bi8)
+        assert K.ln_epilogue_calls["consumed"] == before["consumed"] + 1 and K.ln_epilogue_calls.get("materialised", 0) == before.get("materialised", 0)
+        a, gt = F.linear(ln64, go.double(), gbo.double()).chunk(2, dim=-1)
+        ma, mg = (ln64.abs() @ go.abs().double().t() + gbo.abs().double()).chunk(2, dim=-1)
+        refg = a * F.gelu(gt)
+        magg = F.gelu(gt).abs() * ma + 1.13 * a.abs() * mg
+        assert float(((outg.double().cpu() - refg).abs() / (2.0 ** -7 * magg + 2.0 ** -8 * refg.abs() + 2e-3)).max()) < 1.0, f"lnc geglu it={it}"
+        assert torch.equal(outg, K.geglu_linear(pend, gd, gbd, wi32, bi32, wi8, bi8))
+    # not eligible (N % 320 != 0): the front-end materialises the norm and gives the unfused result
+    qo, qd = rnd((328, 320), 49, dtype, scale=320 ** -0.5)
+    before = K.ln_epilogue_calls.get("materialised", 0)
+    got = K.linear(pend, qd, None)
+    assert K.ln_epilogue_calls.get("materialised", 0) == before + 1
+    assert torch.equal(got, K.linear(K.layernorm(h, gamma, beta, 1e-5), qd, None))
