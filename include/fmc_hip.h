@@ -319,6 +319,14 @@ int fmc_conv3x3_x3_f32(const void* x3, const void* w3, const float* bias, const 
 /* dX (and optionally dgamma / dbeta, fp32 [C], ACCUMULATED into: zero them first) of fmc_layernorm_fwd. */
 int fmc_layernorm_bwd(const void* dy, const void* x, const float* gamma, void* dx, float* dgamma, float* dbeta,
                       int64_t M, int C, float eps, int dtype, void* stream);
+/* The same two backward passes with an ADDEND (shape of dx, may be NULL): dx = addend + dX(norm).  In `h + f(norm(h))` -- every residual
+ * connection of the U-Net (diffusers ResnetBlock2D / BasicTransformerBlock, fmc/models/motion_module.py:282-300) -- h receives a gradient
+ * along the skip and one through the norm; autograd sums them with an elementwise kernel per connection (303 launches per training step,
+ * train_cam_obj_ctrl.py:915); a norm node that owns both uses of h takes the skip gradient here instead. */
+int fmc_layernorm_bwd_add(const void* dy, const void* x, const float* gamma, void* dx, float* dgamma, float* dbeta, const void* addend,
+                          int64_t M, int C, float eps, int dtype, void* stream);
+int fmc_groupnorm_silu_bwd_add(const void* dy, const void* x, void* dx, const float* gamma, const float* beta, const float* stats,
+                               void* workspace, int N, int HW, int C, int G, int act, const void* addend, int dtype, void* stream);
 /* dX [M, 2*Cff] of fmc_geglu_fwd from dy [M, Cff] and the forward input x. */
 int fmc_geglu_bwd(const void* dy, const void* x, void* dx, int64_t M, int Cff, int dtype, void* stream);
 /* dQ, dK, dV of fmc_spatial_attn_fwd.  o / lse are the forward's outputs, d_o has o's strides, dvec is a

@@ -62,6 +62,10 @@ SIGNATURES = {
                                    c_int, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "fmc_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float,
                                   c_int, c_void_p]),
+    "fmc_layernorm_bwd_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float,
+                                      c_int, c_void_p]),
+    "fmc_groupnorm_silu_bwd_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                           c_int, c_void_p, c_int, c_void_p]),
     "fmc_geglu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "fmc_spatial_attn_bwd": (c_int, [c_void_p] * 10 + [c_int] * 5 + [c_int64] * 10 + [c_int, c_float, c_int, c_void_p]),
     "fmc_temporal_attn_bwd": (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_int64] * 9 + [c_float, c_int, c_void_p]),

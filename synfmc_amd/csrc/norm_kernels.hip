@@ -405,7 +405,9 @@ template <typename T>
 __global__ void gn_apply_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dx,
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                     const float* __restrict__ stats, const float* __restrict__ part, int HW, int C,
-                                    int G, int tpr, int rpi, int rows_per_split, int act) {
+                                    int G, int tpr, int rpi, int rows_per_split, int act, const T* __restrict__ addend = nullptr) {
+    // addend (same shape as dx): the gradient that reaches x along its OTHER use, the skip connection around the normalised branch
+    // (`h + f(norm(h))`): dx = addend + dX(norm) in this pass instead of a separate elementwise add per residual connection.
     __shared__ float sh_m1[GN_MAX_G], sh_m2[GN_MAX_G];
     __shared__ float sh_part[GN_MAX_SPLIT * GN_MAX_G * 2];
     const int n = blockIdx.y, s = blockIdx.x, nsplit = gridDim.x;
@@ -446,12 +448,13 @@ __global__ void gn_apply_bwd_kernel(const T* __restrict__ dy, const T* __restric
     const size_t base = (size_t)n * HW * C + c0;
     // two rows per trip, loads first (branch-free, clamped): one row per trip left two 16-byte loads in flight per thread
     for (int r = row0 + rsub; r < row1; r += 2 * rpi) {
-        float v[2][8], d[2][8];
+        float v[2][8], d[2][8], ad[2][8];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int rr = r + u * rpi < row1 ? r + u * rpi : row1 - 1;
             Vec8<T>::load(x + base + (size_t)rr * C, v[u]);
             Vec8<T>::load(dy + base + (size_t)rr * C, d[u]);
+            if (addend) Vec8<T>::load(addend + base + (size_t)rr * C, ad[u]);
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -463,6 +466,7 @@ __global__ void gn_apply_bwd_kernel(const T* __restrict__ dy, const T* __restric
                 float dxh = dz * gm[i];
                 float xh = (v[u][i] - mu[i]) * rs[i];
                 v[u][i] = rs[i] * (dxh - m1[i] - xh * m2[i]);
+                if (addend) v[u][i] += ad[u][i];
             }
             if (rr < row1) Vec8<T>::store(dx + base + (size_t)rr * C, v[u]);
         }
@@ -699,7 +703,7 @@ __global__ void geglu_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t
 template <typename T, int NCH>
 __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
                                      T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                     int64_t M, int C, float eps) {
+                                     int64_t M, int C, float eps, const T* __restrict__ addend = nullptr) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int wpb = blockDim.x >> 6;
@@ -761,6 +765,12 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restri
                 float o[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o[i] = rstd * (d[k][i] - m1 - v[k][i] * m2);
+                if (addend) {                            // + the gradient along the skip connection around the normalised branch
+                    float a8[8];
+                    Vec8<T>::load(addend + row * C + ch * 8, a8);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o[i] += a8[i];
+                }
                 Vec8<T>::store(dx + row * C + ch * 8, o);
             }
         }
@@ -876,12 +886,12 @@ extern "C" int fmc_groupnorm_apply_fwd(const void* x, void* y, const float* gamm
     return 0;
 }
 
-extern "C" int fmc_groupnorm_silu_bwd(const void* dy, const void* x, void* dx, const float* gamma, const float* beta,
-                                      const float* stats, void* workspace, int N, int HW, int C, int G, int act,
-                                      int dtype, void* stream) {
+extern "C" int fmc_groupnorm_silu_bwd_add(const void* dy, const void* x, void* dx, const float* gamma, const float* beta,
+                                          const float* stats, void* workspace, int N, int HW, int C, int G, int act,
+                                          const void* addend, int dtype, void* stream) {
     if (int rc = gn_check(x, dx, N, HW, C, G, dtype)) return rc;
     if (!dy || !gamma || !beta || !stats || !workspace) FMC_FAIL(FMC_E_NULL, "groupnorm_bwd: NULL argument");
-    if (!fmc_aligned16(dy)) FMC_FAIL(FMC_E_ALIGN, "groupnorm_bwd: dy must be 16-byte aligned");
+    if (!fmc_aligned16(dy) || (addend && !fmc_aligned16(addend))) FMC_FAIL(FMC_E_ALIGN, "groupnorm_bwd: dy / addend must be 16-byte aligned");
     GnGeom g = gn_geom(HW, C);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(g.split, N), block(g.block);
@@ -891,15 +901,21 @@ extern "C" int fmc_groupnorm_silu_bwd(const void* dy, const void* x, void* dx, c
         hipLaunchKernelGGL((gn_partial_kernel<bf16_t, 1>), grid, block, lds, st, (const bf16_t*)x, (const bf16_t*)dy,
                            gamma, beta, stats, part, HW, C, G, g.tpr, g.rpi, g.rows_per_split, act);
         hipLaunchKernelGGL((gn_apply_bwd_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)x,
-                           (bf16_t*)dx, gamma, beta, stats, part, HW, C, G, g.tpr, g.rpi, g.rows_per_split, act);
+                           (bf16_t*)dx, gamma, beta, stats, part, HW, C, G, g.tpr, g.rpi, g.rows_per_split, act, (const bf16_t*)addend);
     } else {
         hipLaunchKernelGGL((gn_partial_kernel<float, 1>), grid, block, lds, st, (const float*)x, (const float*)dy, gamma,
                            beta, stats, part, HW, C, G, g.tpr, g.rpi, g.rows_per_split, act);
         hipLaunchKernelGGL((gn_apply_bwd_kernel<float>), grid, block, 0, st, (const float*)dy, (const float*)x,
-                           (float*)dx, gamma, beta, stats, part, HW, C, G, g.tpr, g.rpi, g.rows_per_split, act);
+                           (float*)dx, gamma, beta, stats, part, HW, C, G, g.tpr, g.rpi, g.rows_per_split, act, (const float*)addend);
     }
     FMC_CHECK_LAUNCH("fmc_groupnorm_silu_bwd");
     return 0;
+}
+
+extern "C" int fmc_groupnorm_silu_bwd(const void* dy, const void* x, void* dx, const float* gamma, const float* beta,
+                                      const float* stats, void* workspace, int N, int HW, int C, int G, int act,
+                                      int dtype, void* stream) {
+    return fmc_groupnorm_silu_bwd_add(dy, x, dx, gamma, beta, stats, workspace, N, HW, C, G, act, nullptr, dtype, stream);
 }
 
 template <typename T, int NCH, int R>
@@ -969,7 +985,7 @@ extern "C" int fmc_geglu_fwd(const void* x, void* y, int64_t M, int Cff, int dty
 
 template <typename T>
 static void launch_ln_bwd(const void* dy, const void* x, const float* gamma, void* dx, float* dgamma, float* dbeta,
-                          int64_t M, int C, float eps, hipStream_t st) {
+                          int64_t M, int C, float eps, hipStream_t st, const void* addend = nullptr) {
     const int wpb = 4;
     int64_t blocks = (M + wpb - 1) / wpb;
     if (blocks > 2048) blocks = 2048;            // grid-stride: every wave owns many rows -> few dgamma/dbeta atomics
@@ -977,7 +993,7 @@ static void launch_ln_bwd(const void* dy, const void* x, const float* gamma, voi
 #define LNB_CASE(K)                                                                                                   \
     case K:                                                                                                           \
         hipLaunchKernelGGL((layernorm_bwd_kernel<T, K>), grid, block, 0, st, (const T*)dy, (const T*)x, gamma, (T*)dx, \
-                           dgamma, dbeta, M, C, eps);                                                                 \
+                           dgamma, dbeta, M, C, eps, (const T*)addend);                                               \
         break;
     switch ((C / 8 + 63) / 64) {
         LNB_CASE(1) LNB_CASE(2) LNB_CASE(3) LNB_CASE(4) LNB_CASE(5)
@@ -986,18 +1002,24 @@ static void launch_ln_bwd(const void* dy, const void* x, const float* gamma, voi
 #undef LNB_CASE
 }
 
-extern "C" int fmc_layernorm_bwd(const void* dy, const void* x, const float* gamma, void* dx, float* dgamma,
-                                 float* dbeta, int64_t M, int C, float eps, int dtype, void* stream) {
+extern "C" int fmc_layernorm_bwd_add(const void* dy, const void* x, const float* gamma, void* dx, float* dgamma,
+                                     float* dbeta, const void* addend, int64_t M, int C, float eps, int dtype, void* stream) {
     if (!dy || !x || !gamma || !dx) FMC_FAIL(FMC_E_NULL, "layernorm_bwd: NULL argument");
+    if (addend && !fmc_aligned16(addend)) FMC_FAIL(FMC_E_ALIGN, "layernorm_bwd: addend must be 16-byte aligned");
     if ((dgamma == nullptr) != (dbeta == nullptr)) FMC_FAIL(FMC_E_NULL, "layernorm_bwd: pass both dgamma and dbeta or neither");
     if (M <= 0 || C <= 0 || C % 8 || C > 8 * 64 * 5) FMC_FAIL(FMC_E_SHAPE, "layernorm_bwd: need C%%8==0 and C<=2560 (C=%d)", C);
     if (!fmc_aligned16(dy) || !fmc_aligned16(x) || !fmc_aligned16(dx)) FMC_FAIL(FMC_E_ALIGN, "layernorm_bwd: tensors must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == FMC_BF16) launch_ln_bwd<bf16_t>(dy, x, gamma, dx, dgamma, dbeta, M, C, eps, st);
-    else if (dtype == FMC_F32) launch_ln_bwd<float>(dy, x, gamma, dx, dgamma, dbeta, M, C, eps, st);
+    if (dtype == FMC_BF16) launch_ln_bwd<bf16_t>(dy, x, gamma, dx, dgamma, dbeta, M, C, eps, st, addend);
+    else if (dtype == FMC_F32) launch_ln_bwd<float>(dy, x, gamma, dx, dgamma, dbeta, M, C, eps, st, addend);
     else FMC_FAIL(FMC_E_DTYPE, "layernorm_bwd: dtype %d", dtype);
     FMC_CHECK_LAUNCH("fmc_layernorm_bwd");
     return 0;
+}
+
+extern "C" int fmc_layernorm_bwd(const void* dy, const void* x, const float* gamma, void* dx, float* dgamma,
+                                 float* dbeta, int64_t M, int C, float eps, int dtype, void* stream) {
+    return fmc_layernorm_bwd_add(dy, x, gamma, dx, dgamma, dbeta, nullptr, M, C, eps, dtype, stream);
 }
 
 extern "C" int fmc_geglu_bwd(const void* dy, const void* x, void* dx, int64_t M, int Cff, int dtype, void* stream) {

@@ -142,6 +142,51 @@ class _GroupNormSiLU(torch.autograd.Function):
         return dx, None, None, None, None, None
 
 
+def _gn_backward(ctx, dy, addend):
+    x, gamma, beta, stats = ctx.saved_tensors
+    if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+        raise NotImplementedError("fmc_groupnorm_silu_bwd computes dX only (gamma/beta are frozen on the FMC path)")
+    dy = dy.contiguous()
+    N, S, C = x.shape
+    lib = _lib.load()
+    dx = torch.empty_like(x)
+    ws = _workspace(x.device, lib.fmc_groupnorm_workspace_bytes(N, C, ctx.groups))
+    _lib.check(lib.fmc_groupnorm_silu_bwd_add(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats.data_ptr(),
+                                              ws.data_ptr(), N, S, C, ctx.groups, int(ctx.act), _p(addend), _dt(x), _stream()),
+               "fmc_groupnorm_silu_bwd_add")
+    return dx
+
+
+class _GroupNormSiLUSkip(torch.autograd.Function):
+    """`(h, GroupNorm(h))` as ONE autograd node for `h + f(norm(h))`: the backward receives the gradient along the skip and the one through
+    the norm together and returns `d_skip + dX(norm)` from the norm's backward kernel (`fmc_groupnorm_silu_bwd_add`) -- autograd would
+    otherwise sum the two with an elementwise launch per residual connection (303 per OMC-stage step)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, act):
+        y, stats = groupnorm_silu_raw(x, gamma, beta, groups, eps, act)
+        ctx.save_for_backward(x, gamma, beta, stats)
+        ctx.groups, ctx.act = groups, act
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, d_skip, dy):
+        if dy is None:
+            return d_skip, None, None, None, None, None
+        add = None
+        if d_skip is not None:
+            add = d_skip if d_skip.is_contiguous() else d_skip.contiguous()
+        return _gn_backward(ctx, dy, add), None, None, None, None, None
+
+
+def groupnorm_silu_skip(x, gamma, beta, groups: int, eps: float, act: bool):
+    """(x for the skip connection, GroupNorm(+SiLU)(x)) -- one autograd node when x needs a gradient, the plain pair otherwise."""
+    if torch.is_grad_enabled() and x.requires_grad and x.is_cuda and x.is_contiguous():
+        return _GroupNormSiLUSkip.apply(x, gamma, beta, groups, eps, act)
+    return x, groupnorm_silu(x, gamma, beta, groups, eps, act)
+
+
 def groupnorm_silu(x, gamma, beta, groups: int, eps: float, act: bool, x2=None, gn_tag=None) -> torch.Tensor:
     """GroupNorm over `[N, S, C]` tokens (statistics per sample and group over S x C/G) + optional SiLU.
     gamma/beta: fp32 `[C]`.  `x2`: second channel block (the result normalises `cat([x, x2], -1)` without building it).
@@ -181,6 +226,49 @@ class _LayerNorm(torch.autograd.Function):
         _lib.check(_lib.load().fmc_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), dx.data_ptr(), _p(dg),
                                                  _p(db), M, C, float(ctx.eps), _dt(x), _stream()), "fmc_layernorm_bwd")
         return dx, dg, db, None, None, None, None
+
+
+def _ln_backward(ctx, dy, addend):
+    x, gamma = ctx.saved_tensors
+    dy = dy.contiguous()
+    C = x.shape[-1]
+    M = x.numel() // C
+    dx = torch.empty_like(x)
+    want_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+    dg = torch.zeros(C, dtype=torch.float32, device=x.device) if want_p else None
+    db = torch.zeros(C, dtype=torch.float32, device=x.device) if want_p else None
+    _lib.check(_lib.load().fmc_layernorm_bwd_add(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), dx.data_ptr(), _p(dg), _p(db), _p(addend), M, C,
+                                                 float(ctx.eps), _dt(x), _stream()), "fmc_layernorm_bwd_add")
+    return dx, dg, db
+
+
+class _LayerNormSkip(torch.autograd.Function):
+    """`(h, LayerNorm(h) [+ pe])` as ONE autograd node (see _GroupNormSiLUSkip): backward = `d_skip + dX(norm)` in `fmc_layernorm_bwd_add`."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, pe, pe_inner, pe_frames):
+        ctx.save_for_backward(x, gamma)
+        ctx.eps = eps
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), _layernorm_raw(x, gamma, beta, eps, pe, pe_inner, pe_frames)
+
+    @staticmethod
+    def backward(ctx, d_skip, dy):
+        if dy is None:
+            return d_skip, None, None, None, None, None, None
+        add = None
+        if d_skip is not None:
+            add = d_skip if d_skip.is_contiguous() else d_skip.contiguous()
+        dx, dg, db = _ln_backward(ctx, dy, add)
+        return dx, dg, db, None, None, None, None
+
+
+def layernorm_skip(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
+                   pe: Optional[torch.Tensor] = None, pe_inner: int = 1, pe_frames: int = 1):
+    """(x for the skip connection, LayerNorm(x)) -- one autograd node when x needs a gradient."""
+    if torch.is_grad_enabled() and x.requires_grad and x.is_cuda and x.is_contiguous():
+        return _LayerNormSkip.apply(x, gamma, beta, eps, pe, pe_inner, pe_frames)
+    return x, layernorm(x, gamma, beta, eps, pe, pe_inner, pe_frames)
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
@@ -1315,11 +1403,11 @@ def _time_ms(fn, reps=8):
     return ms
 
 
-def _pick(key, hip_fn, lib_fn, static_hip: bool, extra_arms=(), k320: bool = False) -> int:
+def _pick(key, hip_fn, lib_fn, static_hip: bool, extra_arms=(), k320: bool = False, own_only: bool = False) -> int:
     """0 = vendor library arm, 1..6 = fused gfx950 kernel with that tile geometry (`hip_fn(tile)`)."""
     if not _cache_state["loaded"]:
         load_autotune_table()
-    no_lib = DETERMINISTIC and key[0] == "conv"
+    no_lib = (DETERMINISTIC and key[0] == "conv") or own_only
     if no_lib:
         key = key + ("det",)
     use = _choice.get(key)
@@ -1426,9 +1514,9 @@ def geglu_linear(x: torch.Tensor, weight: torch.Tensor, bias, weight_il: torch.T
 
 
 def conv3x3(x_nchw: torch.Tensor, weight_cl: torch.Tensor, bias, temb=None, residual_nchw=None, stride=(1, 1),
-            padding=(1, 1), temb_div: int = 1, upsample: bool = False, emit_gn: bool = False) -> torch.Tensor:
+            padding=(1, 1), temb_div: int = 1, upsample: bool = False, emit_gn: bool = False, own_only: bool = False) -> torch.Tensor:
     """3x3 conv on a logical NCHW / physical channels-last tensor with `+ temb[:, :, None, None]` and `+ residual`.
-    Returns a logical NCHW view over channels-last storage."""
+    Returns a logical NCHW view over channels-last storage.  `own_only`: the vendor library is not a candidate arm."""
     import torch.nn.functional as F
 
     def lib():
@@ -1475,7 +1563,7 @@ def conv3x3(x_nchw: torch.Tensor, weight_cl: torch.Tensor, bias, temb=None, resi
     hip = lambda tile: conv3x3_bf16(x, weight_cl, bias, temb, r, tile=tile, temb_div=temb_div,
                                     upsample=upsample, stride2=stride2).permute(0, 3, 1, 2)
     tiles = ((n * h * w + 127) // 128) * ((cout + 127) // 128)
-    use = _pick(key, hip, lib, tiles >= 256, split_arms(n * h * w, cout, 9 * cin))
+    use = _pick(key, hip, lib, tiles >= 256, split_arms(n * h * w, cout, 9 * cin), own_only=own_only)
     return lib() if use == 0 else hip(max(use, 0))
 
 

@@ -12,6 +12,8 @@ their state-dict keys) and logical tensor shapes as the re
 """
 from __future__ import annotations
 
+import os
+
 import math
 from typing import Optional
 
@@ -66,8 +68,27 @@ class GroupNorm(nn.GroupNorm):
                              self.eps, act, None if x2 is None else to_tokens(x2), gn_tag=getattr(x, "_fmc_gn", None))
         return from_tokens(y, h, w)
 
+    def skip(self, x: torch.Tensor, act: bool = False):
+        """`(x for the residual connection, norm(x))` on a `[N, C, h, w]` tensor: one autograd node under a gradient (LayerNorm.skip)."""
+        if NORM_SKIP and torch.is_grad_enabled() and x.requires_grad and x.is_cuda and x.dtype in (torch.bfloat16, torch.float32):
+            n, c, h, w = x.shape
+            xs, y = K.groupnorm_silu_skip(to_tokens(x), f32_param(self, "weight"), f32_param(self, "bias"), self.num_groups, self.eps, act)
+            return from_tokens(xs, h, w), from_tokens(y, h, w)
+        return x, self(x, act=act)
+
+
+NORM_SKIP = os.environ.get("FMC_NORM_SKIP", "1") != "0"          # A/B switch: norm + skip connection as one autograd node (training)
+
 
 class LayerNorm(nn.LayerNorm):
+    def skip(self, x: torch.Tensor, pe: Optional[torch.Tensor] = None, pe_inner: int = 1, pe_frames: int = 1, defer: bool = False):
+        """`(x for the residual connection, norm(x))`.  Under autograd the pair is ONE node whose backward adds the skip gradient inside
+        the LayerNorm backward kernel (hip_ops.layernorm_skip); without a gradient it is `(x, self(x))`."""
+        if NORM_SKIP and torch.is_grad_enabled() and x.requires_grad and x.is_cuda and x.dtype in (torch.bfloat16, torch.float32):
+            return K.layernorm_skip(x if x.is_contiguous() else x.contiguous(), f32_param(self, "weight"), f32_param(self, "bias"), self.eps,
+                                    pe, pe_inner, pe_frames)
+        return x, self(x, pe, pe_inner, pe_frames, defer=defer)
+
     def ln_spec(self, pe: Optional[torch.Tensor] = None, pe_inner: int = 1, pe_frames: int = 1, stats_only: bool = False):
         """What a producing GEMM needs to write this norm's output (or, `stats_only`, its rows' mean / rstd for a consumer GEMM that
         applies the norm itself) from its own epilogue (`hip_ops.linear(..., ln=...)`)."""
@@ -92,6 +113,9 @@ class LayerNorm(nn.LayerNorm):
         if not x.is_contiguous():
             x = x.contiguous()
         return K.layernorm(x, f32_param(self, "weight"), f32_param(self, "bias"), self.eps, pe, pe_inner, pe_frames)
+
+
+PADDED_EDGE_CONVS = os.environ.get("FMC_PADDED_EDGE_CONVS", "1") != "0"      # A/B switch: conv_in / conv_out on the own kernel (else MIOpen)
 
 
 class Conv2d(nn.Conv2d):
@@ -128,6 +152,10 @@ class Conv2d(nn.Conv2d):
                 and self.weight.requires_grad):
             # trainable filter under bf16 autocast (OMC Adapter / camera encoder): forward + backward-data on the gfx950 kernel
             return K.conv3x3_trainable(x, self.weight, self.bias)
+        if (self.kernel_size == (3, 3) and self.dilation == (1, 1) and self.groups == 1 and x.is_cuda and not needs_grad
+                and self.stride == (1, 1) and self.padding == (1, 1) and x.dtype == torch.bfloat16 and self.weight.dtype == torch.bfloat16
+                and (self.in_channels % 64 or self.out_channels % 8) and temb is None and residual is None and not upsample and PADDED_EDGE_CONVS):
+            return self.padded_conv3x3(x)
         if self.kernel_size == (3, 3) and self.dilation == (1, 1) and self.groups == 1 and x.is_cuda and not needs_grad:
             return K.conv3x3(x, self._weight_cl(), self.bias, temb, residual, self.stride, self.padding, temb_div,
                              upsample, emit_gn=emit_gn)
@@ -139,6 +167,30 @@ class Conv2d(nn.Conv2d):
         if residual is not None:
             y = y + residual
         return y
+
+    def padded_conv3x3(self, x: torch.Tensor) -> torch.Tensor:
+        """The edge convolutions (U-Net conv_in 4 -> 320 / conv_out 320 -> 4, VAE conv_in / conv_out) on the hand-written implicit-GEMM kernel:
+        input channels zero-padded to a multiple of 64, output channels to a multiple of 8 (zero filters), the result sliced back -- no
+        MIOpen kernel anywhere in the denoising step or the decoder.  (`unet.py:284-285,155-156` of the reference: plain nn.Conv2d.)"""
+        cout, cin = self.weight.shape[:2]
+        cin_p, cout_p = (cin + 63) // 64 * 64, (cout + 7) // 8 * 8
+        key = (self.weight.data_ptr(), self.weight._version, None if self.bias is None else (self.bias.data_ptr(), self.bias._version))
+        hit = self.__dict__.get("_padded")
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                w = torch.zeros(cout_p, cin_p, 3, 3, dtype=self.weight.dtype, device=self.weight.device)
+                w[:cout, :cin] = self.weight
+                b = torch.zeros(cout_p, dtype=self.weight.dtype, device=self.weight.device)
+                if self.bias is not None:
+                    b[:cout] = self.bias
+                hit = (key, w.contiguous(memory_format=torch.channels_last), b)
+            self.__dict__["_padded"] = hit
+        if cin_p != cin:
+            xp = torch.zeros(x.shape[0], cin_p, x.shape[2], x.shape[3], dtype=x.dtype, device=x.device).contiguous(memory_format=torch.channels_last)
+            xp[:, :cin] = x
+            x = xp
+        y = K.conv3x3(x.contiguous(memory_format=torch.channels_last), hit[1], hit[2], own_only=True)
+        return y[:, :cout]
 
     def _weight_cl(self) -> torch.Tensor:
         """The filter in channels-last memory format.  ATen's MIOpen path otherwise re-lays-out the (up to 29 MB)
@@ -275,8 +327,16 @@ class ResnetBlock2D(nn.Module):
                 t = t[: input_tensor.shape[0] // div]
         elif self.time_emb_proj is not None and temb is not None:
             t = self.time_emb_proj(F.silu(temb))                       # [N, Cout], rides in conv1's epilogue
-        if skip is not None and self.conv_shortcut is None:
-            input_tensor, skip = torch.cat([input_tensor, skip], dim=1), None
+        if skip is not None and (self.conv_shortcut is None or (torch.is_grad_enabled() and (input_tensor.requires_grad or skip.requires_grad))):
+            input_tensor, skip = torch.cat([input_tensor, skip], dim=1), None          # (under autograd: ONE tensor for norm1 and the shortcut)
+        if skip is None and torch.is_grad_enabled() and input_tensor.requires_grad:
+            # norm1 and the residual / shortcut use of the input as one autograd node: the skip gradient enters the GroupNorm backward kernel
+            input_tensor, n1 = self.norm1.skip(input_tensor, act=True)
+            h = self.conv1(n1, temb=t, temb_div=div)
+            if self.conv_shortcut is not None:
+                input_tensor = self.conv_shortcut(input_tensor)
+            out = self.conv2(self.norm2(h, act=True), residual=input_tensor)
+            return out if self.output_scale_factor == 1.0 else out / self.output_scale_factor
         # both convolutions feed a GroupNorm (norm2 here, the next module's norm behind conv2): where that norm would read its input
         # twice (the 40x64 level) the conv's epilogue emits its statistics (`emit_gn`, hip_ops.gn_emit_ok)
         h = self.conv1(self.norm1(input_tensor, act=True, x2=skip), temb=t, temb_div=div, emit_gn=True)
@@ -491,14 +551,17 @@ class BasicTransformerBlock(nn.Module):
         if self.attn2 is not None:
             self.attn2.__dict__["_next_ln"] = None if torch.is_grad_enabled() else self.norm3.ln_spec(stats_only=True)
         # `attn(...) + hidden_states` / `ff(...) + hidden_states`: the residual rides in the output projection's epilogue
-        hidden_states = self.attn1(self.norm1(hidden_states, defer=True), encoder_hidden_states=None,
-                                   attention_mask=attention_mask, _residual=hidden_states, **kw)
+        # (`norm.skip`: under autograd, the norm and the residual use of its input are one node -- hip_ops.layernorm_skip)
+        hidden_states, n = self.norm1.skip(hidden_states, defer=True)
+        hidden_states = self.attn1(n, encoder_hidden_states=None, attention_mask=attention_mask, _residual=hidden_states, **kw)
         if cfg_expand:          # shared classifier-free-guidance prefix ends here: the text cross-attention is the first op that tells the halves apart
             hidden_states = torch.cat([hidden_states, hidden_states], dim=0)
         if self.attn2 is not None:
-            hidden_states = self.attn2(self.norm2(hidden_states, defer=True), encoder_hidden_states=encoder_hidden_states,
-                                       attention_mask=encoder_attention_mask, _residual=hidden_states, **kw)
-        return self.ff(self.norm3(hidden_states, defer=True), residual=hidden_states)
+            hidden_states, n = self.norm2.skip(hidden_states, defer=True)
+            hidden_states = self.attn2(n, encoder_hidden_states=encoder_hidden_states, attention_mask=encoder_attention_mask,
+                                       _residual=hidden_states, **kw)
+        hidden_states, n = self.norm3.skip(hidden_states, defer=True)
+        return self.ff(n, residual=hidden_states)
 
 
 class Transformer2DModelOutput:
@@ -535,8 +598,13 @@ class Transformer2DModel(nn.Module):
         up to and including the self-attention runs once, the output covers both halves (see UNet3DConditionModel.cfg_shared_input)."""
         n, c, h, w = hidden_states.shape
         residual = to_tokens(hidden_states)
-        x = K.groupnorm_silu(residual, f32_param(self.norm, "weight"), f32_param(self.norm, "bias"),
-                             self.norm.num_groups, self.norm.eps, False, gn_tag=getattr(hidden_states, "_fmc_gn", None))
+        if NORM_SKIP and torch.is_grad_enabled() and residual.requires_grad and residual.is_cuda:
+            # the norm and the `+ residual` of proj_out as one autograd node (hip_ops.groupnorm_silu_skip)
+            residual, x = K.groupnorm_silu_skip(residual if residual.is_contiguous() else residual.contiguous(), f32_param(self.norm, "weight"),
+                                                f32_param(self.norm, "bias"), self.norm.num_groups, self.norm.eps, False)
+        else:
+            x = K.groupnorm_silu(residual, f32_param(self.norm, "weight"), f32_param(self.norm, "bias"),
+                                 self.norm.num_groups, self.norm.eps, False, gn_tag=getattr(hidden_states, "_fmc_gn", None))
         x = linear_op(x, self.proj_in.weight.view(self.proj_in.out_channels, c), self.proj_in.bias,
                       ln=None if torch.is_grad_enabled() else self.transformer_blocks[0].norm1.ln_spec(stats_only=True))
         for bi, blk in enumerate(self.transformer_blocks):

@@ -159,12 +159,13 @@ class TemporalTransformerBlock(nn.Module):
         for attention_block, norm in zip(self.attention_blocks, self.norms):
             pe = attention_block.pos_encoder
             if pe is not None:       # LayerNorm and `pos_encoder(norm(x))` in one pass (motion_module.py:288,355)
-                n = norm(hidden_states, pe=pe.table(), pe_inner=inner, pe_frames=frames)
+                hidden_states, n = norm.skip(hidden_states, pe=pe.table(), pe_inner=inner, pe_frames=frames)
             else:
-                n = norm(hidden_states)
+                hidden_states, n = norm.skip(hidden_states)
             hidden_states = attention_block(n, encoder_hidden_states=None, attention_mask=attention_mask,
                                             _pe_applied=True, _residual=hidden_states, **cross_attention_kwargs)
-        return self.ff(self.ff_norm(hidden_states, defer=True), residual=hidden_states)
+        hidden_states, n = self.ff_norm.skip(hidden_states, defer=True)
+        return self.ff(n, residual=hidden_states)
 
 
 class TemporalTransformer3DModel(nn.Module):
@@ -204,8 +205,14 @@ class TemporalTransformer3DModel(nn.Module):
         if not t.is_contiguous():
             t = t.contiguous()
         residual = t.view(b * f, h * w, c)
-        x = K.groupnorm_silu(residual, f32_param(self.norm, "weight"), f32_param(self.norm, "bias"),
-                             self.norm.num_groups, self.norm.eps, False, gn_tag=getattr(hidden_states, "_fmc_gn", None))
+        from .layers import NORM_SKIP
+        if NORM_SKIP and torch.is_grad_enabled() and residual.requires_grad and residual.is_cuda:
+            # the norm and the `+ residual` of proj_out as one autograd node (hip_ops.groupnorm_silu_skip)
+            residual, x = K.groupnorm_silu_skip(residual, f32_param(self.norm, "weight"), f32_param(self.norm, "bias"),
+                                                self.norm.num_groups, self.norm.eps, False)
+        else:
+            x = K.groupnorm_silu(residual, f32_param(self.norm, "weight"), f32_param(self.norm, "bias"),
+                                 self.norm.num_groups, self.norm.eps, False, gn_tag=getattr(hidden_states, "_fmc_gn", None))
         blk0 = self.transformer_blocks[0]
         ln0 = None
         if not torch.is_grad_enabled():                  # the first block's first norm (+ PE) leaves proj_in's epilogue

@@ -22,30 +22,10 @@ from .layers import Conv2d, GroupNorm, Linear, ResnetBlock2D, Upsample2D, from_t
 
 
 def _padded_conv3x3(conv: Conv2d, x: torch.Tensor, act_dtype_ok: bool = True) -> torch.Tensor:
-    """The two edge convolutions (conv_in 4 -> C, conv_out C -> 3) on the hand-written implicit-GEMM kernel: input channels are zero-padded
-    to 64 and output channels to 8 (zero filters), the result is sliced back -- MIOpen is not involved anywhere in the decoder."""
-    from .. import hip_ops as K
+    """The two edge convolutions (conv_in 4 -> C, conv_out C -> 3) on the hand-written implicit-GEMM kernel (`Conv2d.padded_conv3x3`)."""
     if not x.is_cuda or torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
         return F.conv2d(x, conv.weight, conv.bias, 1, 1)
-    cout, cin = conv.weight.shape[:2]
-    cin_p, cout_p = (cin + 63) // 64 * 64, (cout + 7) // 8 * 8
-    key = (conv.weight.data_ptr(), conv.weight._version)
-    hit = conv.__dict__.get("_padded")
-    if hit is None or hit[0] != key:
-        with torch.no_grad():
-            w = torch.zeros(cout_p, cin_p, 3, 3, dtype=conv.weight.dtype, device=conv.weight.device)
-            w[:cout, :cin] = conv.weight
-            b = torch.zeros(cout_p, dtype=conv.weight.dtype, device=conv.weight.device)
-            if conv.bias is not None:
-                b[:cout] = conv.bias
-            hit = (key, w.contiguous(memory_format=torch.channels_last), b)
-        conv.__dict__["_padded"] = hit
-    if cin_p != cin:
-        xp = torch.zeros(x.shape[0], cin_p, x.shape[2], x.shape[3], dtype=x.dtype, device=x.device).contiguous(memory_format=torch.channels_last)
-        xp[:, :cin] = x
-        x = xp
-    y = K.conv3x3(x.contiguous(memory_format=torch.channels_last), hit[1], hit[2])
-    return y[:, :cout]
+    return conv.padded_conv3x3(x)
 
 
 class DecoderOutput:

@@ -1497,3 +1497,45 @@ def test_layernorm_applied_in_the_consuming_gemm(K):
     got = K.linear(pend, qd, None)
     assert K.ln_epilogue_calls.get("materialised", 0) == before + 1
     assert torch.equal(got, K.linear(K.layernorm(h, gamma, beta, 1e-5), qd, None))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_norm_with_skip_is_one_autograd_node(K, dtype):
+    """`layernorm_skip` / `groupnorm_silu_skip`: `(h, norm(h))` as one node whose backward adds the skip gradient inside the norm's backward
+    kernel (`fmc_layernorm_bwd_add` / `fmc_groupnorm_silu_bwd_add`).  Gradients of `sum(w1 * h_skip) + sum(w2 * norm(h))` against plain
+    PyTorch autograd in fp64, and the cases where only one of the two outputs is used."""
+    g = torch.Generator().manual_seed(21)
+    tol = 2e-5 if dtype == torch.float32 else 1.5e-2
+    # LayerNorm (+ positional encoding)
+    x0 = torch.randn(2, 16, 40, 320, generator=g)
+    gamma, beta = 1.0 + 0.2 * torch.randn(320, generator=g), 0.1 * torch.randn(320, generator=g)
+    pe = torch.randn(16, 320, generator=g)
+    w1, w2 = torch.randn(x0.shape, generator=g), torch.randn(x0.shape, generator=g)
+    xr = x0.to(dtype).double().requires_grad_(True)
+    ref_y = F.layer_norm(xr, (320,), gamma.double(), beta.double(), 1e-5) + pe.double()[None, :, None, :]
+    (w1.double() * xr).sum().add((w2.double() * ref_y).sum()).backward()
+    for use in ("both", "norm", "skip"):
+        x = x0.to("cuda", dtype).requires_grad_(True)
+        xs, y = K.layernorm_skip(x, gamma.cuda(), beta.cuda(), 1e-5, pe.cuda(), 40, 16)
+        assert rel_inf(y, ref_y) < (1e-5 if dtype == torch.float32 else 1e-2) and torch.equal(xs, x)
+        loss = 0.0
+        if use in ("both", "skip"):
+            loss = loss + (w1.cuda().to(dtype) * xs).float().sum()
+        if use in ("both", "norm"):
+            loss = loss + (w2.cuda().to(dtype) * y).float().sum()
+        loss.backward()
+        if use == "both":
+            assert rel_inf(x.grad, xr.grad) < tol
+        elif use == "skip":
+            assert rel_inf(x.grad, w1.to(dtype).double()) < tol
+    # GroupNorm + SiLU
+    x0 = torch.randn(3, 640, 320, generator=g)
+    w1, w2 = torch.randn(x0.shape, generator=g), torch.randn(x0.shape, generator=g)
+    xr = x0.to(dtype).double().requires_grad_(True)
+    ref_y = F.silu(F.group_norm(xr.transpose(1, 2), 32, gamma.double(), beta.double(), 1e-6)).transpose(1, 2)
+    (w1.double() * xr).sum().add((w2.double() * ref_y).sum()).backward()
+    x = x0.to("cuda", dtype).requires_grad_(True)
+    xs, y = K.groupnorm_silu_skip(x, gamma.cuda(), beta.cuda(), 32, 1e-6, True)
+    assert rel_inf(y, ref_y) < (1e-5 if dtype == torch.float32 else 1e-2)
+    ((w1.cuda().to(dtype) * xs).float().sum() + (w2.cuda().to(dtype) * y).float().sum()).backward()
+    assert rel_inf(x.grad, xr.grad) < tol
