@@ -597,7 +597,13 @@ def train_main(args):
             if dev_us <= 0:
                 continue
             frames = [f for f in (ev.stack or []) if "synfmc_amd" in f or "bench.py" in f][:3]
-            key = (ev.name, " <- ".join(fr.split("/")[-1] for fr in frames))
+            where = " <- ".join(fr.split("/")[-1] for fr in frames)
+            if not where:                                    # backward: no Python stack -- name the autograd node the op ran under
+                root = ev
+                while root.cpu_parent is not None:
+                    root = root.cpu_parent
+                where = root.name
+            key = (ev.name, where)
             agg[key][0] += dev_us
             agg[key][1] += 1
         with open(args.torch_profile, "w") as f:

@@ -546,18 +546,24 @@ class BasicTransformerBlock(nn.Module):
         # the LayerNorm behind each attention leaves its output projection's epilogue where the tile holds whole rows (hip_ops.linear_ln)
         # ... as its rows' statistics only: every norm of this block feeds a GEMM (QKV / to_q / the GEGLU projection), which applies it in its
         # own epilogue on gamma-scaled weights (hip_ops.linear_lnc, `defer=True` below) -- LayerNorm(x) is neither written nor read.
-        nxt = self.norm2 if self.attn2 is not None else self.norm3
-        self.attn1.__dict__["_next_ln"] = None if (cfg_expand or torch.is_grad_enabled()) else nxt.ln_spec(stats_only=True)
+        from .attention_processor import AttnProcessor, LoRAAttnProcessor
+
+        def plain(attn):            # only these processors hand the normed tokens to `linear_op` and nowhere else (a pose merge also uses
+            return type(attn.processor) in (AttnProcessor, LoRAAttnProcessor)      # them as a residual: it needs the materialised norm)
+        d1, d2 = plain(self.attn1), self.attn2 is not None and plain(self.attn2)
         if self.attn2 is not None:
+            self.attn1.__dict__["_next_ln"] = None if (cfg_expand or torch.is_grad_enabled()) else self.norm2.ln_spec(stats_only=d2)
             self.attn2.__dict__["_next_ln"] = None if torch.is_grad_enabled() else self.norm3.ln_spec(stats_only=True)
+        else:
+            self.attn1.__dict__["_next_ln"] = None if (cfg_expand or torch.is_grad_enabled()) else self.norm3.ln_spec(stats_only=True)
         # `attn(...) + hidden_states` / `ff(...) + hidden_states`: the residual rides in the output projection's epilogue
         # (`norm.skip`: under autograd, the norm and the residual use of its input are one node -- hip_ops.layernorm_skip)
-        hidden_states, n = self.norm1.skip(hidden_states, defer=True)
+        hidden_states, n = self.norm1.skip(hidden_states, defer=d1)
         hidden_states = self.attn1(n, encoder_hidden_states=None, attention_mask=attention_mask, _residual=hidden_states, **kw)
         if cfg_expand:          # shared classifier-free-guidance prefix ends here: the text cross-attention is the first op that tells the halves apart
             hidden_states = torch.cat([hidden_states, hidden_states], dim=0)
         if self.attn2 is not None:
-            hidden_states, n = self.norm2.skip(hidden_states, defer=True)
+            hidden_states, n = self.norm2.skip(hidden_states, defer=d2)
             hidden_states = self.attn2(n, encoder_hidden_states=encoder_hidden_states, attention_mask=encoder_attention_mask,
                                        _residual=hidden_states, **kw)
         hidden_states, n = self.norm3.skip(hidden_states, defer=True)
@@ -606,7 +612,8 @@ class Transformer2DModel(nn.Module):
             x = K.groupnorm_silu(residual, f32_param(self.norm, "weight"), f32_param(self.norm, "bias"),
                                  self.norm.num_groups, self.norm.eps, False, gn_tag=getattr(hidden_states, "_fmc_gn", None))
         x = linear_op(x, self.proj_in.weight.view(self.proj_in.out_channels, c), self.proj_in.bias,
-                      ln=None if torch.is_grad_enabled() else self.transformer_blocks[0].norm1.ln_spec(stats_only=True))
+                      ln=None if torch.is_grad_enabled() else self.transformer_blocks[0].norm1.ln_spec(
+                          stats_only=type(self.transformer_blocks[0].attn1.processor).__name__ in ("AttnProcessor", "LoRAAttnProcessor")))
         for bi, blk in enumerate(self.transformer_blocks):
             x = blk(x, attention_mask=attention_mask, encoder_hidden_states=encoder_hidden_states,
                     encoder_attention_mask=encoder_attention_mask, timestep=timestep,
