@@ -221,6 +221,38 @@ def measure_conv_roofline(device, dtype, iters=20):
     return out
 
 
+def measure_proj_roofline(device, dtype, iters=20):
+    """One launch of the token-projection kernel family that holds the largest share of the step (round 3: the 160x320 kernels): the
+    GEGLU feed-forward projection of the 20x32 level as the U-Net issues it (`[2F * 640 tokens, 640] x [5120, 640]^T`, gated to 2560
+    columns), through the autotuned front-end, timed like the other roofline launches."""
+    from synfmc_amd import hip_ops as K
+    from synfmc_amd.models.layers import interleave_geglu
+    M, Kd, N = 2 * FRAMES * (HEIGHT // 16) * (WIDTH // 16), WIDTHS[1], 8 * WIDTHS[1]
+    x = torch.randn(M, Kd, device=device, dtype=dtype)
+    w = torch.randn(N, Kd, device=device, dtype=dtype) * Kd ** -0.5
+    b = torch.randn(N, device=device, dtype=dtype)
+    w32, b32 = interleave_geglu(w, b)
+    w8, b8 = interleave_geglu(w, b, 8)
+    for _ in range(3):
+        K.geglu_linear(x, w, b, w32, b32, w8, b8)
+    arm = K._choice.get(("geglu", M, N, Kd))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        K.geglu_linear(x, w, b, w32, b32, w8, b8)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * M * N * Kd
+    achieved = flops / (ms * 1e-3) / 1e12
+    names = {0: "vendor library + geglu_kernel", 3: "gemm_kernel<256x256,16 waves,GEGLU>", 13: "gemm8_kernel<256x256,8-phase,GEGLU>",
+             512: "gemm160p_kernel<160x320 persistent,GEGLU>"}
+    return {"bound": "mfma", "kernel": f"{names.get(arm, f'fmc_linear_bf16 arm {arm}')} [{M}x{N}x{Kd}]", "autotuned_arm": arm,
+            "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+            "avg_launch_ms": round(ms, 4), "flops_per_launch": flops, "traffic_algorithmic": 2.0 * (M * Kd + N * Kd + M * N // 2),
+            "traffic": None, "traffic_note": "no counter pass for this launch"}
+
+
 def unet_flops(batch, h, w, executed=False, config="obj"):
     """Analytic forward FLOPs from a meta-device trace of the oracle.  `executed=False`: the reference graph (LoRA as
     separate `up(down(x))` GEMMs, text K/V projected once per FRAME).  `executed=True`: what the product launches --
@@ -810,6 +842,7 @@ def main():
         roof = measure_attention_roofline(device, dtype) if bf else None
         roof_conv = measure_conv_roofline(device, dtype) if bf else None
         roof_temp = measure_temporal_roofline(device, dtype) if bf else None
+        roof_proj = measure_proj_roofline(device, dtype) if bf else None
         f_ref = unet_flops(2, HEIGHT // 8, WIDTH // 8, config=cfg)
         f_exec = unet_flops(2, HEIGHT // 8, WIDTH // 8, executed=True, config=cfg)
         if unet.cfg_shared_input:                       # one clip's worth of conv_in, ResNet block 0, proj_in, QKV, self-attention, out-projection
@@ -836,7 +869,7 @@ def main():
             "unet_tflop_per_step_reference_graph": round(f_ref / 1e12, 3),
             "executed_tflops_per_gpu": round(f_exec / 1e12 / (ms * 1e-3), 1),
             "conditioning_once_per_clip_ms": round(cond_ms, 2),
-            "roofline": roof, "roofline_conv": roof_conv, "roofline_temporal": roof_temp, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_conv": roof_conv, "roofline_temporal": roof_temp, "roofline_proj": roof_proj, "cpu_baseline": cpu,
         }
         if loop50_s is not None:
             out["ddim_50_step_loop_s"] = round(loop50_s, 3)
