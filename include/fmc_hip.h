@@ -78,6 +78,11 @@ int fmc_groupnorm_silu_bwd(const void* dy, const void* x, void* dx, const float*
  * pe_inner = hw, pe_frames = F).   gamma/beta/pe: fp32. */
 int fmc_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, const float* pe,
                       int64_t M, int C, float eps, int pe_inner, int pe_frames, int dtype, void* stream);
+/* The same with the residual add in front: sum_out = x + addend (rounded to the storage type), y = LayerNorm(sum_out) (+ pe).  For
+ * `h = attn(...) + h` followed by the next norm (diffusers BasicTransformerBlock, fmc/models/motion_module.py:282-300) where the
+ * projection ran on the vendor-library arm and would leave the add to an elementwise launch.  C in {320, 640, 1280}. */
+int fmc_layernorm_add_fwd(const void* x, const void* addend, void* sum_out, void* y, const float* gamma, const float* beta,
+                          const float* pe, int64_t M, int C, float eps, int pe_inner, int pe_frames, int dtype, void* stream);
 
 /* GEGLU gate of diffusers' FeedForward (`a * gelu_erf(g)` with a,g = chunk(proj(x), 2);
  * fmc/models/motion_module.py:284 and BasicTransformerBlock.ff):  x [M, 2*Cff] -> y [M, Cff]. */

@@ -25,6 +25,8 @@ SIGNATURES = {
                                        c_int, c_float, c_int, c_int, c_void_p, c_int, c_void_p]),
     "fmc_groupnorm_silu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                        c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fmc_layernorm_add_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int,
+                                      c_int, c_int, c_void_p]),
     "fmc_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int,
                                   c_int, c_int, c_void_p]),
     "fmc_geglu_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),

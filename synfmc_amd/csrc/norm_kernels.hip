@@ -573,11 +573,24 @@ template <int LPR> __device__ __forceinline__ float group_sum(float v) {   // su
     return v;
 }
 
+template <typename T> __device__ __forceinline__ void round_as_stored(float (&v)[8]);
+template <> __device__ __forceinline__ void round_as_stored<float>(float (&)[8]) {}
+template <> __device__ __forceinline__ void round_as_stored<bf16_t>(float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned r = pack_bf2(v[2 * i], v[2 * i + 1]);
+        v[2 * i] = __uint_as_float(r << 16);
+        v[2 * i + 1] = __uint_as_float(r & 0xffff0000u);
+    }
+}
+
 template <typename T, int LPR, int U>   // 5 eight-element chunks per lane, U rows per lane group
 __global__ __launch_bounds__(256) void layernorm_g_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ pe, int64_t M, float eps, int pe_inner,
-                                                          int pe_frames) {
+                                                          int pe_frames, const T* __restrict__ addend = nullptr, T* __restrict__ sum_out = nullptr) {
+    // addend / sum_out (both or neither): the rows normalised are h = round_T(x + addend) and h is written to sum_out -- the residual add
+    // that a vendor-library projection leaves to a separate elementwise launch, done where its result is consumed (fmc_layernorm_add_fwd)
     constexpr int NCH = 5, C = LPR * NCH * 8, RPW = 64 / LPR;
     // gamma / beta through LDS: requested together with the rows (read from global memory behind the statistics they were a second
     // memory round trip in the life of every wave, which is one load burst, a reduction and one store burst long)
@@ -605,8 +618,17 @@ __global__ __launch_bounds__(256) void layernorm_g_kernel(const T* __restrict__ 
         const int64_t row = row0 + RPW * u;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
-            if (row < M) Vec8<T>::load(x + row * C + (j * LPR + t) * 8, v[u][j]);
-            else {
+            if (row < M) {
+                Vec8<T>::load(x + row * C + (j * LPR + t) * 8, v[u][j]);
+                if (addend) {
+                    float a8[8];
+                    Vec8<T>::load(addend + row * C + (j * LPR + t) * 8, a8);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[u][j][i] += a8[i];
+                    Vec8<T>::store(sum_out + row * C + (j * LPR + t) * 8, v[u][j]);
+                    round_as_stored<T>(v[u][j]);             // the norm sees the stored (rounded) sum, as a separate pass would
+                }
+            } else {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[u][j][i] = 0.f;
             }
@@ -655,22 +677,22 @@ __global__ __launch_bounds__(256) void layernorm_g_kernel(const T* __restrict__ 
 
 template <typename T, int LPR, int U>
 static void launch_ln_g(const void* x, void* y, const float* gamma, const float* beta, const float* pe, int64_t M, float eps,
-                        int pe_inner, int pe_frames, hipStream_t st) {
+                        int pe_inner, int pe_frames, hipStream_t st, const void* addend = nullptr, void* sum_out = nullptr) {
     const int64_t rpw = (64 / LPR) * U, waves = (M + rpw - 1) / rpw;
     hipLaunchKernelGGL((layernorm_g_kernel<T, LPR, U>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, (const T*)x,
-                       (T*)y, gamma, beta, pe, M, eps, pe_inner, pe_frames);
+                       (T*)y, gamma, beta, pe, M, eps, pe_inner, pe_frames, (const T*)addend, (T*)sum_out);
 }
 
 template <typename T>
 static bool try_launch_ln16(const void* x, void* y, const float* gamma, const float* beta, const float* pe, int64_t M, int C,
-                            float eps, int pe_inner, int pe_frames, hipStream_t st) {
+                            float eps, int pe_inner, int pe_frames, hipStream_t st, const void* addend = nullptr, void* sum_out = nullptr) {
     const bool many = M >= 32768;                            // two rows per lane group when there are plenty of rows
     switch (C) {
-        case 320: many ? launch_ln_g<T, 8, 2>(x, y, gamma, beta, pe, M, eps, pe_inner, pe_frames, st)
-                       : launch_ln_g<T, 8, 1>(x, y, gamma, beta, pe, M, eps, pe_inner, pe_frames, st); return true;
-        case 640: many ? launch_ln_g<T, 16, 2>(x, y, gamma, beta, pe, M, eps, pe_inner, pe_frames, st)
-                       : launch_ln_g<T, 16, 1>(x, y, gamma, beta, pe, M, eps, pe_inner, pe_frames, st); return true;
-        case 1280: launch_ln_g<T, 32, 1>(x, y, gamma, beta, pe, M, eps, pe_inner, pe_frames, st); return true;
+        case 320: many ? launch_ln_g<T, 8, 2>(x, y, gamma, beta, pe, M, eps, pe_inner, pe_frames, st, addend, sum_out)
+                       : launch_ln_g<T, 8, 1>(x, y, gamma, beta, pe, M, eps, pe_inner, pe_frames, st, addend, sum_out); return true;
+        case 640: many ? launch_ln_g<T, 16, 2>(x, y, gamma, beta, pe, M, eps, pe_inner, pe_frames, st, addend, sum_out)
+                       : launch_ln_g<T, 16, 1>(x, y, gamma, beta, pe, M, eps, pe_inner, pe_frames, st, addend, sum_out); return true;
+        case 1280: launch_ln_g<T, 32, 1>(x, y, gamma, beta, pe, M, eps, pe_inner, pe_frames, st, addend, sum_out); return true;
         default: return false;
     }
 }
@@ -950,6 +972,24 @@ static void launch_ln(const void* x, void* y, const float* gamma, const float* b
         case 5: launch_ln_n<T, 5>(x, y, gamma, beta, pe, M, C, eps, pe_inner, pe_frames, st); break;
         default: break;
     }
+}
+
+extern "C" int fmc_layernorm_add_fwd(const void* x, const void* addend, void* sum_out, void* y, const float* gamma, const float* beta,
+                                     const float* pe, int64_t M, int C, float eps, int pe_inner, int pe_frames, int dtype, void* stream) {
+    if (!x || !addend || !sum_out || !y || !gamma || !beta) FMC_FAIL(FMC_E_NULL, "layernorm_add: NULL argument");
+    if (M <= 0 || (C != 320 && C != 640 && C != 1280)) FMC_FAIL(FMC_E_SHAPE, "layernorm_add: C must be 320, 640 or 1280 (C=%d)", C);
+    if (pe && (pe_inner <= 0 || pe_frames <= 0)) FMC_FAIL(FMC_E_SHAPE, "layernorm_add: pe_inner/pe_frames must be > 0");
+    if (!fmc_aligned16(x) || !fmc_aligned16(y) || !fmc_aligned16(addend) || !fmc_aligned16(sum_out))
+        FMC_FAIL(FMC_E_ALIGN, "layernorm_add: tensors must be 16-byte aligned");
+    if (!pe) { pe_inner = 1; pe_frames = 1; }
+    hipStream_t st = (hipStream_t)stream;
+    bool ok = false;
+    if (dtype == FMC_BF16) ok = try_launch_ln16<bf16_t>(x, y, gamma, beta, pe, M, C, eps, pe_inner, pe_frames, st, addend, sum_out);
+    else if (dtype == FMC_F32) ok = try_launch_ln16<float>(x, y, gamma, beta, pe, M, C, eps, pe_inner, pe_frames, st, addend, sum_out);
+    else FMC_FAIL(FMC_E_DTYPE, "layernorm_add: dtype %d", dtype);
+    if (!ok) FMC_FAIL(FMC_E_SHAPE, "layernorm_add: unsupported width %d", C);
+    FMC_CHECK_LAUNCH("fmc_layernorm_add_fwd");
+    return 0;
 }
 
 extern "C" int fmc_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, const float* pe,

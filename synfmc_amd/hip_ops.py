@@ -271,6 +271,28 @@ def layernorm_skip(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps
     return x, layernorm(x, gamma, beta, eps, pe, pe_inner, pe_frames)
 
 
+LAZY_RESIDUAL = os.environ.get("FMC_LAZY_RESIDUAL", "1") != "0"    # A/B switch: the residual add behind a vendor-arm projection rides in the next LayerNorm
+
+
+def layernorm_add(x: torch.Tensor, addend: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
+                  pe: Optional[torch.Tensor] = None, pe_inner: int = 1, pe_frames: int = 1):
+    """`h = x + addend` (rounded to the storage type, as a separate add would) and `LayerNorm(h) (+ pe)` in one pass: returns (h, y)."""
+    _dev(x, addend, gamma, beta, pe)
+    assert x.is_contiguous() and addend.is_contiguous() and x.shape == addend.shape and x.dtype == addend.dtype
+    C = x.shape[-1]
+    M = x.numel() // C
+    h, y = torch.empty_like(x), torch.empty_like(x)
+    _lib.check(_lib.load().fmc_layernorm_add_fwd(x.data_ptr(), addend.data_ptr(), h.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                 _p(pe), M, C, float(eps), int(pe_inner), int(pe_frames), _dt(x), _stream()), "fmc_layernorm_add_fwd")
+    return h, y
+
+
+def resolve_pending_add(x: torch.Tensor) -> torch.Tensor:
+    """A projection output whose residual add was left to its consumer (`linear(..., lazy_residual=True)` on the vendor arm): the sum."""
+    r = getattr(x, "_fmc_pending_add", None)
+    return x if r is None else torch.add(r, x)
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
               pe: Optional[torch.Tensor] = None, pe_inner: int = 1, pe_frames: int = 1) -> torch.Tensor:
     """LayerNorm over the last dim of contiguous tokens; optionally adds `pe[(row // pe_inner) % pe_frames]`
@@ -1428,7 +1450,8 @@ def _pick(key, hip_fn, lib_fn, static_hip: bool, extra_arms=(), k320: bool = Fal
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
            residual: Optional[torch.Tensor] = None, alpha: float = 1.0, x2: Optional[torch.Tensor] = None,
-           residual2: Optional[torch.Tensor] = None, gn_hw: int = 0, ln: Optional["LnSpec"] = None) -> torch.Tensor:
+           residual2: Optional[torch.Tensor] = None, gn_hw: int = 0, ln: Optional["LnSpec"] = None,
+           lazy_residual: bool = False) -> torch.Tensor:
     """`alpha * (x @ weight^T + bias) + residual [+ residual2]` for bf16 device tensors (see `linear_bf16`).  With `x2`
     the input is the concat `[x, x2]` along the last dim; the fused kernel reads the two tensors in place."""
     import torch.nn.functional as F
@@ -1475,6 +1498,12 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     hip = lambda tile: linear_bf16(x, weight, bias, residual, alpha, tile=tile, x2=x2, residual2=residual2)
     use = _pick(key, hip, lib, Kd <= 640 and N <= 1024 and M >= 16384, split_arms(M, N, Kd),
                 k320=(Kd == 320 and N % 320 == 0 and M % 64 == 0 and x2 is None and residual2 is None))
+    if (use == 0 and lazy_residual and LAZY_RESIDUAL and residual is not None and residual2 is None and alpha == 1.0 and x2 is None
+            and N in (320, 640, 1280) and residual.is_contiguous() and not torch.is_grad_enabled()):
+        # vendor arm: the caller's next op is a LayerNorm of `y + residual` (LayerNorm.skip): it does the add in its own pass
+        y = F.linear(x, weight, bias)
+        y._fmc_pending_add = residual
+        return y
     return lib() if use == 0 else hip(max(use, 0))
 
 

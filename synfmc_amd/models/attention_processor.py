@@ -58,7 +58,8 @@ def _attention_core(attn, q_in: torch.Tensor, kv_in: Optional[torch.Tensor], tem
         kv = linear_op(kv_in, w_b)
         o = K.cross_attention_q_kv(q, kv, heads, attn.scale)
     # (`_next_ln`: the LayerNorm the block applies to `attn(x) + x` -- set by the block, consumed by hip_ops.linear when the tile holds whole rows)
-    return linear_op(o, w_o, attn.to_out[0].bias, residual, ln=attn.__dict__.get("_next_ln") if residual is not None else None)
+    return linear_op(o, w_o, attn.to_out[0].bias, residual, ln=attn.__dict__.get("_next_ln") if residual is not None else None,
+                     lazy_residual=residual is not None and bool(attn.__dict__.get("_lazy_res")))
 
 
 def _fusable(attn, residual, shape4):

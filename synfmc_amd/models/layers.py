@@ -87,6 +87,11 @@ class LayerNorm(nn.LayerNorm):
         if NORM_SKIP and torch.is_grad_enabled() and x.requires_grad and x.is_cuda and x.dtype in (torch.bfloat16, torch.float32):
             return K.layernorm_skip(x if x.is_contiguous() else x.contiguous(), f32_param(self, "weight"), f32_param(self, "bias"), self.eps,
                                     pe, pe_inner, pe_frames)
+        r = getattr(x, "_fmc_pending_add", None)
+        if r is not None:                                # x = a vendor-arm projection whose `+ residual` was left to this norm (hip_ops.linear)
+            if x.is_contiguous() and x.shape[-1] in (320, 640, 1280) and x.dtype == r.dtype:
+                return K.layernorm_add(x, r, f32_param(self, "weight"), f32_param(self, "bias"), self.eps, pe, pe_inner, pe_frames)
+            x = K.resolve_pending_add(x)
         return x, self(x, pe, pe_inner, pe_frames, defer=defer)
 
     def ln_spec(self, pe: Optional[torch.Tensor] = None, pe_inner: int = 1, pe_frames: int = 1, stats_only: bool = False):
@@ -102,6 +107,7 @@ class LayerNorm(nn.LayerNorm):
                 pe_frames: int = 1, defer: bool = False) -> torch.Tensor:
         """`defer`: the caller hands the result straight to `linear_op` / the GEGLU projection; when x's producer left the rows' statistics,
         x comes back marked "norm pending" and that GEMM applies it in its epilogue -- LayerNorm(x) is never written."""
+        x = K.resolve_pending_add(x)                                   # (a lazily-added residual reaches a norm through `skip`; never dropped here)
         key = self._ln_key(pe, pe_inner, pe_frames)
         if defer and pe is None:
             stats = K.take_ln_stats(x, key)
@@ -206,16 +212,19 @@ class Conv2d(nn.Conv2d):
         return hit[1]
 
 
-def linear_op(x, weight, bias=None, residual=None, alpha: float = 1.0, x2=None, gn_hw: int = 0, ln=None):
+def linear_op(x, weight, bias=None, residual=None, alpha: float = 1.0, x2=None, gn_hw: int = 0, ln=None, lazy_residual: bool = False):
     """`alpha * (x @ W^T + b) + residual`: fused gfx950 GEMM or hipBLASLt + epilogue passes (`hip_ops.linear`) for
     frozen bf16 weights on the GPU, plain autograd ops otherwise."""
+    x = K.resolve_pending_add(x)
+    if residual is not None:
+        residual = K.resolve_pending_add(residual)
     if getattr(x, "_fmc_pending_ln", None) is not None and not (x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and not torch.is_grad_enabled()):
         x = K.resolve_pending_ln(x)                     # (never on the paths that defer a norm; kept so that a pending norm cannot be dropped)
     if x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16:
         grad = torch.is_grad_enabled()
         if not (grad and (x.requires_grad or weight.requires_grad or (residual is not None and residual.requires_grad)
                           or (x2 is not None and x2.requires_grad))):
-            return K.linear(x, weight, bias, residual, alpha, x2, gn_hw=gn_hw, ln=ln)
+            return K.linear(x, weight, bias, residual, alpha, x2, gn_hw=gn_hw, ln=ln, lazy_residual=lazy_residual)
         if x2 is not None:
             x, x2 = torch.cat([x, x2], dim=-1), None
         if not weight.requires_grad and (bias is None or not bias.requires_grad):   # frozen layer, activation gradient only
@@ -551,6 +560,11 @@ class BasicTransformerBlock(nn.Module):
         def plain(attn):            # only these processors hand the normed tokens to `linear_op` and nowhere else (a pose merge also uses
             return type(attn.processor) in (AttnProcessor, LoRAAttnProcessor)      # them as a residual: it needs the materialised norm)
         d1, d2 = plain(self.attn1), self.attn2 is not None and plain(self.attn2)
+        # (`_lazy_res`: the output projection's `+ residual` may be left to the next norm's pass when the projection runs on the vendor arm;
+        #  true exactly where the very next consumer is `norm.skip` below)
+        self.attn1.__dict__["_lazy_res"] = not cfg_expand and not torch.is_grad_enabled()
+        if self.attn2 is not None:
+            self.attn2.__dict__["_lazy_res"] = not torch.is_grad_enabled()
         if self.attn2 is not None:
             self.attn1.__dict__["_next_ln"] = None if (cfg_expand or torch.is_grad_enabled()) else self.norm2.ln_spec(stats_only=d2)
             self.attn2.__dict__["_next_ln"] = None if torch.is_grad_enabled() else self.norm3.ln_spec(stats_only=True)

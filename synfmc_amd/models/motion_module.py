@@ -156,6 +156,7 @@ class TemporalTransformerBlock(nn.Module):
             return self.norms[i].ln_spec() if enc is None else self.norms[i].ln_spec(enc.table(), inner, frames)
         for i, attention_block in enumerate(self.attention_blocks):
             attention_block.__dict__["_next_ln"] = spec(i + 1)
+            attention_block.__dict__["_lazy_res"] = not torch.is_grad_enabled()      # (the next consumer is `norm.skip` / `ff_norm.skip` below)
         for attention_block, norm in zip(self.attention_blocks, self.norms):
             pe = attention_block.pos_encoder
             if pe is not None:       # LayerNorm and `pos_encoder(norm(x))` in one pass (motion_module.py:288,355)

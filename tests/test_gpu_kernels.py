@@ -1539,3 +1539,27 @@ def test_norm_with_skip_is_one_autograd_node(K, dtype):
     assert rel_inf(y, ref_y) < (1e-5 if dtype == torch.float32 else 1e-2)
     ((w1.cuda().to(dtype) * xs).float().sum() + (w2.cuda().to(dtype) * y).float().sum()).backward()
     assert rel_inf(x.grad, xr.grad) < tol
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [320, 640, 1280])
+def test_layernorm_with_the_residual_add_in_front(K, dtype, C):
+    """`fmc_layernorm_add_fwd`: `h = x + addend` rounded to the storage type, `y = LayerNorm(h) (+ pe)` -- bit-identical to the separate
+    `torch.add` + `fmc_layernorm_fwd` pair it replaces; and the front-end's lazy residual (`linear(..., lazy_residual=True)` on the vendor
+    arm + `resolve_pending_add`)."""
+    g = torch.Generator().manual_seed(31)
+    M = 2 * 16 * 40
+    x = torch.randn(2, 16, 40, C, generator=g).to("cuda", dtype)
+    r = torch.randn(2, 16, 40, C, generator=g).to("cuda", dtype)
+    gamma, beta = (1.0 + 0.2 * torch.randn(C, generator=g)).cuda(), (0.1 * torch.randn(C, generator=g)).cuda()
+    pe = torch.randn(16, C, generator=g).cuda()
+    for use_pe in (False, True):
+        args = (pe, 40, 16) if use_pe else (None, 1, 1)
+        h, y = K.layernorm_add(x, r, gamma, beta, 1e-5, *args)
+        h_ref = torch.add(r, x)
+        assert torch.equal(h, h_ref)
+        assert torch.equal(y, K.layernorm(h_ref, gamma, beta, 1e-5, *args))
+    t = x.view(x.shape)
+    t._fmc_pending_add = r
+    assert torch.equal(K.resolve_pending_add(t), torch.add(r, x)) and K.resolve_pending_add(x) is x
