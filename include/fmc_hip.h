@@ -281,6 +281,15 @@ int fmc_linear_bf16_ln(const void* x, const void* w, const void* bias, const voi
  *   the motion module's ff_norm (fmc/models/motion_module.py:295-299).  Needs bf16, N % 320 == 0, M % 160 == 0, more 160 x 320 tiles than CUs. */
 int fmc_linear_bf16_lnc(const void* x, const void* w_gamma, void* out, int64_t M, int N, int K, int64_t ldx, int64_t ldo, int epilogue,
                         const float* ln_stats, const float* ln_c, const float* ln_bias, void* stream);
+/* The feed-forward's intermediate in TILE-MAJOR order (diffusers FeedForward: GEGLU projection -> Linear, fmc call sites as for
+ * fmc_linear_bf16): `[M / 160][C / 32][160 rows][32]` instead of `[M][C]`.  The GEGLU projection (epilogue 1, out_blocked = 1) writes its
+ * gated 160 x 160 tile as five contiguous 10-KiB blocks, and the second GEMM (epilogue 0, x_blocked = 1) requests each 32-deep A sub-tile as
+ * ONE contiguous block: linear 1-KiB LDS-DMA requests and whole DRAM pages instead of 160 row segments of 64 bytes.  The tensor is private to
+ * the pair; results are bit-identical to the row-major path.  Tile 16's persistent form only (M % 160 == 0, N % 320 == 0, more tiles than CUs);
+ * ln_stats / ln_c / ln_bias != NULL: the GEGLU projection also applies its input's LayerNorm (fmc_linear_bf16_lnc; bias must be NULL then). */
+int fmc_linear_bf16_ffblk(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int N, int K,
+                          int64_t ldres, float alpha, int epilogue, int x_blocked, int out_blocked, const float* ln_stats, const float* ln_c,
+                          const float* ln_bias, void* stream);
 int fmc_conv3x3_bf16_gn(const void* x, const void* w, const void* bias, const void* temb, const void* residual, void* out, int n_img,
                         int H, int W, int Cin, int Cout, int64_t temb_row_stride, int temb_img_div, int upsample2x,
                         float* gn_partials, void* stream);

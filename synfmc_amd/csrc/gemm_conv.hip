@@ -72,6 +72,9 @@ struct GemmParams {
     bf16_t* ln_out;                   // gemm160p_kernel, plain epilogue, N == 320: ALSO write LayerNorm(out rows) * gamma + beta (+ pe row) here
     const float* ln_gamma; const float* ln_beta; const float* ln_pe;   //   (the consumer's norm: the tile holds whole rows, x is not read again);
     float ln_eps; int ln_pe_inner, ln_pe_frames;                        //   pe row of output row m = ((m / ln_pe_inner) % ln_pe_frames), ln_pe_inner % 160 == 0
+    int a_blocked;                    // gemm160p_kernel: the A operand is stored tile-major, [M / 160][K / 32][160 rows][32] -- the sub-tile a workgroup requests is
+                                      //   ONE contiguous 10-KiB block (what the GEGLU epilogue writes with out_blocked for the feed-forward's second GEMM)
+    int out_blocked;                  // gemm160p_kernel, GEGLU epilogue: write the gated output in that layout (K of the consumer = N / 2)
     float* ln_stats;                  // ... or only the rows' (mean, rstd) -> ln_stats[M][2], for a consumer GEMM that applies the LayerNorm itself:
     const float* lnc_stats; const float* lnc_c; const float* lnc_bias;  // gemm160p_kernel as that consumer (W pre-scaled by gamma): out = rstd[m] (acc -
                                       //   mean[m] c[n]) + lnc_bias[n], c[n] = sum_k W'[n, k], lnc_bias = W beta + bias (fp32 [N]); alpha 1, no bf16 bias
@@ -1457,7 +1460,8 @@ void gemm160_kernel(const GemmParams P) {
             const int64_t m = m0 + lr;
             const bool ok = m < P.M;
             if (MODE == 0) {
-                e_vo[e] = ok ? (unsigned)((m * P.lda + psrc * 8) * 2) : OOB;
+                e_vo[e] = ok ? (P.a_blocked ? (unsigned)((((int64_t)tile_m * (P.K / BK)) * (BM * BK) + lr * BK + psrc * 8) * 2)     // tile-major A: GemmParams
+                                            : (unsigned)((m * P.lda + psrc * 8) * 2)) : OOB;
             } else {
                 const int64_t mm = ok ? m : 0;
                 const int pix = (int)(mm % P.hw);
@@ -1518,7 +1522,7 @@ void gemm160_kernel(const GemmParams P) {
             for (int e = 0; e < 4; ++e) {
                 bf16_t* dst = e_lds[e] == NBUF * SUB_ELEMS ? smem + NBUF * SUB_ELEMS : stage + e_lds[e];
                 if (MODE == 0) {
-                    dma(rsA, e_vo[e], it_s * BK * 2, dst);
+                    dma(rsA, e_vo[e], P.a_blocked ? it_s * (BM * BK * 2) : it_s * BK * 2, dst);
                 } else {
                     unsigned vo;
                     if (P.ups == 1) {
@@ -1839,13 +1843,14 @@ void gemm160p_kernel(const GemmParams P) {
                 vo = (unsigned)(((int64_t)n * P.K + psrc * 8) * 2);
             } else if (live && i < 20 + BM / 16) {
                 const int64_t m = (int64_t)tm * BM + 16 * (i - 20) + prow;
-                vo = (unsigned)((m * P.lda + psrc * 8) * 2);
+                vo = P.a_blocked ? (unsigned)((((int64_t)tm * nks) * (BM * BK) + (16 * (i - 20) + prow) * BK + psrc * 8) * 2)
+                                 : (unsigned)((m * P.lda + psrc * 8) * 2);
             }
             e_vo[e] = vo;
         }
     };
     auto issue = [&]() {
-        const int soff = it_s * BK * 2;
+        const int soff = (!w_wave && P.a_blocked) ? it_s * (BM * BK * 2) : it_s * BK * 2;     // (blocked A: the next sub-tile is the next 10-KiB block)
 #pragma unroll
         for (int e = 0; e < NE; ++e) {                // (LDS destinations as wave-uniform 32-bit offsets: they travel through M0)
             const int dst = e_lds[e] == NBUF * SUB_ELEMS ? NBUF * SUB_ELEMS : it_buf * SUB_ELEMS + e_lds[e];
@@ -1999,8 +2004,15 @@ void gemm160p_kernel(const GemmParams P) {
                 for (int it = 0; it < S_EPI; ++it) {                     // 160 rows x 20 chunks = 3200 = 6.25 per thread: the 7th repeats the 6th
                     int c = tid + it * NT;
                     if (c >= BM * 20) c -= NT;
-                    const int r = c / 20, ch = c - r * 20;
-                    *reinterpret_cast<u32x4*>(P.out + (m0 + r) * P.ldo + n0 / 2 + ch * 8) = *reinterpret_cast<const u32x4*>(Os + r * 168 + ch * 8);
+                    // row-major: chunk c = (row, 8-column chunk).  out_blocked (tile-major output for the feed-forward's second GEMM): my
+                    // 160 x 160 tile = 5 blocks [160 rows][32] of 10 KiB, block kb of the whole tensor at (m0 / 160) (N / 64) + n0 / 64 + kb;
+                    // chunk c = (kb, row, 8-column quarter) in storage order.  One store either way (offsets selected, no divergent code).
+                    const int kb = c / 640, rem = c - kb * 640;
+                    const int rB = rem >> 2, r = P.out_blocked ? rB : c / 20;
+                    const int col = P.out_blocked ? kb * 32 + (rem & 3) * 8 : (c - (c / 20) * 20) * 8;
+                    const int64_t off = P.out_blocked ? (((m0 / BM) * (int64_t)(P.N / 64) + n0 / 64 + kb) * BM + rB) * 32 + (rem & 3) * 8
+                                                      : (m0 + r) * P.ldo + n0 / 2 + col;
+                    *reinterpret_cast<u32x4*>(P.out + off) = *reinterpret_cast<const u32x4*>(Os + r * 168 + col);
                 }
                 __syncthreads();                                         // Os is free again
             } else {
@@ -2803,7 +2815,8 @@ static int linear_impl(const void* x, const void* w, const void* bias, const voi
                        int k_split, const void* residual2, void* stream, int f32io, void* gn_partials = nullptr, int gn_hw = 0,
                        void* ln_out = nullptr, const float* ln_gamma = nullptr, const float* ln_beta = nullptr, float ln_eps = 0.f,
                        const float* ln_pe = nullptr, int ln_pe_inner = 1, int ln_pe_frames = 1, float* ln_stats = nullptr,
-                       const float* lnc_stats = nullptr, const float* lnc_c = nullptr, const float* lnc_bias = nullptr) {
+                       const float* lnc_stats = nullptr, const float* lnc_c = nullptr, const float* lnc_bias = nullptr, int a_blocked = 0,
+                       int out_blocked = 0) {
     if (!x || !w || !out) FMC_FAIL(FMC_E_NULL, "linear_bf16: NULL tensor");
     if (M <= 0 || N <= 0 || K <= 0 || K % BK_MAX || N % 8 || ldx % 8 || ldo % (f32io ? 4 : 8) || (residual && ldres % (f32io ? 4 : 8)))
         FMC_FAIL(FMC_E_SHAPE, "linear_bf16: need K%%64==0, N%%8==0 and strides %%8==0 (M=%lld N=%d K=%d)", (long long)M, N, K);
@@ -2835,6 +2848,16 @@ static int linear_impl(const void* x, const void* w, const void* bias, const voi
                                   "residual, alpha 1)");
     }
     P.lnc_stats = lnc_stats; P.lnc_c = lnc_c; P.lnc_bias = lnc_bias;
+    if (a_blocked || out_blocked) {                           // tile-major intermediate of the feed-forward: persistent form of tile 16 only
+        const int cus = fmc_cu_count() & ~7;
+        if (f32io || tile != 16 || split_k != 1 || gn_partials || x2 || N % 320 || M % 160 || cus < 8 ||
+            (out_blocked && (M / 160) * (N / 320) <= cus) ||                      // (the GEGLU epilogue that writes tile-major is the persistent form's)
+            (a_blocked && (epilogue != 0 || ldx != K || K % 32)) || (out_blocked && (epilogue != 1 || ldo != N / 2 || (N / 2) % 32)) ||
+            (int64_t)M * (a_blocked ? K : N / 2) * 2 >= ((int64_t)1 << 31) || (getenv("FMC_G160_PERSIST") && atoi(getenv("FMC_G160_PERSIST")) == 0))
+            FMC_FAIL(FMC_E_SHAPE, "linear_bf16: the tile-major feed-forward intermediate needs tile 16's persistent form (M %% 160 == 0, N %% 320 == 0, "
+                                  "more tiles than CUs, dense rows)");
+    }
+    P.a_blocked = a_blocked; P.out_blocked = out_blocked;
     if (ln_out || ln_stats) {
         const int cus = fmc_cu_count() & ~7;
         if ((ln_out != nullptr) == (ln_stats != nullptr)) FMC_FAIL(FMC_E_NULL, "linear_bf16_ln: exactly one of ln_out / ln_stats");
@@ -2889,6 +2912,15 @@ extern "C" int fmc_linear_bf16_lnc(const void* x, const void* w_gamma, void* out
     if (!ln_stats || !ln_c || !ln_bias) FMC_FAIL(FMC_E_NULL, "linear_bf16_lnc: NULL ln_stats / ln_c / ln_bias");
     return linear_impl(x, w_gamma, nullptr, nullptr, out, M, N, K, ldx, 0, ldo, 1.f, epilogue, 16, 1, nullptr, 0, nullptr, 0, 0, nullptr, stream, 0,
                        nullptr, 0, nullptr, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr, ln_stats, ln_c, ln_bias);
+}
+
+extern "C" int fmc_linear_bf16_ffblk(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int N, int K,
+                                     int64_t ldres, float alpha, int epilogue, int x_blocked, int out_blocked, const float* ln_stats,
+                                     const float* ln_c, const float* ln_bias, void* stream) {
+    if (!x_blocked && !out_blocked) FMC_FAIL(FMC_E_SHAPE, "linear_bf16_ffblk: neither operand is tile-major (use fmc_linear_bf16)");
+    const int n_out = epilogue == 1 ? N / 2 : N;
+    return linear_impl(x, w, bias, residual, out, M, N, K, K, ldres, n_out, alpha, epilogue, 16, 1, nullptr, 0, nullptr, 0, 0, nullptr, stream, 0,
+                       nullptr, 0, nullptr, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr, ln_stats, ln_c, ln_bias, x_blocked, out_blocked);
 }
 
 extern "C" int fmc_linear_x3_f32(const void* x3, const void* w3, const float* bias, const float* residual, float* out, int64_t M,

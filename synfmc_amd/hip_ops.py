@@ -1137,6 +1137,55 @@ def linear_ln(x: torch.Tensor, weight: torch.Tensor, bias, residual, alpha: floa
     return out
 
 
+FF_BLOCKED = os.environ.get("FMC_FF_BLOCKED", "1") != "0"        # A/B switch: tile-major intermediate between the two GEMMs of a feed-forward
+
+
+def ff_blocked_ok(x: torch.Tensor, w1_il160: Optional[torch.Tensor], w2: torch.Tensor, residual) -> bool:
+    """Both GEMMs of the feed-forward on tile 16 with the `[M / 160][Cff / 32][160][32]` intermediate (`fmc_linear_bf16_ffblk`)?"""
+    if not FF_BLOCKED or w1_il160 is None or torch.is_grad_enabled():
+        return False
+    N1, Kd = w1_il160.shape
+    N2, Cff = w2.shape
+    M = x.numel() // x.shape[-1]
+    return (x.is_cuda and x.dtype == torch.bfloat16 and w1_il160.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16 and x.is_contiguous()
+            and w1_il160.is_contiguous() and w2.is_contiguous() and N1 == 2 * Cff and Cff % 160 == 0 and N2 % 320 == 0 and Kd % 64 == 0
+            and M % 160 == 0 and M >= 16384 and (M // 160) * (N1 // 320) > _cus(x.device) and M * Cff * 2 < (1 << 31)
+            and (residual is None or (residual.is_contiguous() and residual.dtype == x.dtype))
+            and os.environ.get("FMC_G160_PERSIST", "1") != "0")
+
+
+def geglu_linear_blocked(x: torch.Tensor, weight_il160: torch.Tensor, bias_il160) -> torch.Tensor:
+    """GEGLU projection whose gated output is written tile-major (private to the feed-forward's second GEMM, `linear_from_blocked`).
+    A pending LayerNorm on x (LayerNorm.forward(defer=True)) is applied in the epilogue as in `linear_lnc`."""
+    pend = getattr(x, "_fmc_pending_ln", None)
+    N, Kd = weight_il160.shape
+    M = x.numel() // Kd
+    out = torch.empty(*x.shape[:-1], N // 2, dtype=x.dtype, device=x.device)
+    if pend is not None:
+        stats, gamma, beta, _ = pend
+        wg, c, b = _ln_folded_weight(weight_il160, bias_il160, gamma, beta)
+        _dev(x, wg, c, b, stats)
+        ln_epilogue_calls["consumed"] += 1
+        args = (wg.data_ptr(), None, None, out.data_ptr(), M, N, Kd, 0, 1.0, 1, 0, 1, stats.data_ptr(), c.data_ptr(), b.data_ptr())
+    else:
+        _dev(x, weight_il160, bias_il160)
+        args = (weight_il160.data_ptr(), _p(bias_il160), None, out.data_ptr(), M, N, Kd, 0, 1.0, 1, 0, 1, None, None, None)
+    _lib.check(_lib.load().fmc_linear_bf16_ffblk(x.data_ptr(), *args, _stream()), "fmc_linear_bf16_ffblk")
+    return out
+
+
+def linear_from_blocked(xb: torch.Tensor, weight: torch.Tensor, bias, residual, alpha: float = 1.0) -> torch.Tensor:
+    """`alpha * (x @ weight^T + bias) + residual` for an x in the tile-major layout of `geglu_linear_blocked`."""
+    _dev(xb, weight, bias, residual)
+    N, Kd = weight.shape
+    M = xb.numel() // Kd
+    out = torch.empty(*xb.shape[:-1], N, dtype=xb.dtype, device=xb.device)
+    _lib.check(_lib.load().fmc_linear_bf16_ffblk(xb.data_ptr(), weight.data_ptr(), _p(bias), _p(residual), out.data_ptr(), M, N, Kd,
+                                                 0 if residual is None else N, float(alpha), 0, 1, 0, None, None, None, _stream()),
+               "fmc_linear_bf16_ffblk")
+    return out
+
+
 def linear_gn(x: torch.Tensor, weight: torch.Tensor, bias, residual, alpha: float, residual2, hw: int):
     """`linear_bf16` on the 160 x 320 kernel + the GroupNorm partial sums of the output: (out, partials [M / hw, hw / 160, 32, 2])."""
     _dev(x, weight, bias, residual)

@@ -497,20 +497,26 @@ class GEGLU(nn.Module):
         super().__init__()
         self.proj = Linear(dim_in, dim_out * 2)
 
+    def interleaved(self):
+        """(W, b in 32-row value / gate blocks, W, b in [8 value | 8 gate] blocks or None, None): the row orders the fused kernels want, cached."""
+        w = self.proj.weight
+        key = (w.data_ptr(), w._version)
+        hit = self.__dict__.get("_il")
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                b = None if self.proj.bias is None else self.proj.bias.detach()
+                il160 = interleave_geglu(w.detach(), b, 8) if (w.shape[0] // 2) % 160 == 0 else (None, None)
+                hit = (key, interleave_geglu(w.detach(), b) + il160)
+            self.__dict__["_il"] = hit
+        return hit[1]
+
     def forward(self, hidden_states, scale: float = 1.0):
         w = self.proj.weight
         if hidden_states.is_cuda and (hidden_states.dtype == torch.bfloat16 or (hidden_states.dtype == torch.float32 and K.F32_GEMM)) \
                 and hidden_states.dtype == w.dtype and w.shape[0] % 256 == 0 \
                 and not (torch.is_grad_enabled() and (w.requires_grad or hidden_states.requires_grad)):
-            key = (w.data_ptr(), w._version)
-            hit = self.__dict__.get("_il")
-            if hit is None or hit[0] != key:
-                with torch.no_grad():
-                    b = None if self.proj.bias is None else self.proj.bias.detach()
-                    il160 = interleave_geglu(w.detach(), b, 8) if (w.shape[0] // 2) % 160 == 0 else (None, None)
-                    hit = (key, interleave_geglu(w.detach(), b) + il160)
-                self.__dict__["_il"] = hit
-            return K.geglu_linear(hidden_states, w, self.proj.bias, hit[1][0], hit[1][1], hit[1][2], hit[1][3])
+            il = self.interleaved()
+            return K.geglu_linear(hidden_states, w, self.proj.bias, il[0], il[1], il[2], il[3])
         return K.geglu(self.proj(K.resolve_pending_ln(hidden_states)))
 
 
@@ -524,7 +530,13 @@ class FeedForward(nn.Module):
                                   Linear(inner, dim if dim_out is None else dim_out)])
 
     def forward(self, hidden_states, scale: float = 1.0, residual: Optional[torch.Tensor] = None):
-        return self.net[2](self.net[0](hidden_states), residual=residual)
+        proj, out = self.net[0], self.net[2]
+        il = proj.interleaved() if (hidden_states.is_cuda and hidden_states.dtype == torch.bfloat16 and not torch.is_grad_enabled()) else None
+        if il is not None and K.ff_blocked_ok(hidden_states, il[2], out.weight, residual):
+            # the [M, 4C] intermediate stays tile-major between the two GEMMs: contiguous 10-KiB operand blocks for the second one
+            mid = K.geglu_linear_blocked(hidden_states, il[2], il[3])
+            return K.linear_from_blocked(mid, out.weight, out.bias, residual)
+        return out(proj(hidden_states), residual=residual)
 
 
 class BasicTransformerBlock(nn.Module):

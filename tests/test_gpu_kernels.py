@@ -1563,3 +1563,45 @@ def test_layernorm_with_the_residual_add_in_front(K, dtype, C):
     t = x.view(x.shape)
     t._fmc_pending_add = r
     assert torch.equal(K.resolve_pending_add(t), torch.add(r, x)) and K.resolve_pending_add(x) is x
+
+
+@torch.no_grad()
+def test_feed_forward_with_a_tile_major_intermediate(K):
+    """`fmc_linear_bf16_ffblk`: the GEGLU projection writes its gated output as `[M / 160][Cff / 32][160][32]`, the second GEMM requests each
+    32-deep A sub-tile as one contiguous block.  The intermediate is the row-major one permuted, the pair's result is BIT-IDENTICAL to the
+    row-major path on tile 16 (same products, same order) -- persistent and plain-grid form of the second GEMM, with and without residual,
+    with the GEGLU projection also applying its input's LayerNorm; several launches on fresh data."""
+    dtype = torch.bfloat16
+    from synfmc_amd.models.layers import interleave_geglu
+    for (M, C) in [(81920, 320), (20480, 640)]:
+        Cff = 4 * C
+        w1o, w1d = rnd((2 * Cff, C), 42, dtype, scale=C ** -0.5)
+        b1o, b1d = rnd((2 * Cff,), 40, dtype)
+        w2o, w2d = rnd((C, Cff), 43, dtype, scale=Cff ** -0.5)
+        b2o, b2d = rnd((C,), 44, dtype)
+        wi8, bi8 = interleave_geglu(w1d, b1d, 8)
+        for it in range(2):
+            xo, xd = rnd((M, C), 760 + it, dtype)
+            ro, rd = rnd((M, C), 860 + it, dtype)
+            assert K.ff_blocked_ok(xd, wi8, w2d, rd)
+            mid_rm = K.linear_bf16(xd, wi8, bi8, geglu=True, tile=512)
+            mid_tm = K.geglu_linear_blocked(xd, wi8, bi8)
+            assert torch.equal(mid_tm.view(M // 160, Cff // 32, 160, 32).permute(0, 2, 1, 3).reshape(M, Cff), mid_rm)
+            for res in (rd, None):
+                got = K.linear_from_blocked(mid_tm, w2d, b2d, res)
+                assert torch.equal(got, K.linear_bf16(mid_rm, w2d, b2d, res, 1.0, tile=512)), f"ff blocked {(M, C)} it {it} res {res is not None}"
+    # with the input's LayerNorm applied by the GEGLU projection (deferred norm3 / ff_norm)
+    g = torch.Generator().manual_seed(8)
+    gamma, beta = (1.0 + 0.3 * torch.randn(320, generator=g)).cuda(), (0.2 * torch.randn(320, generator=g)).cuda()
+    M, C, Cff = 81920, 320, 1280
+    w1o, w1d = rnd((2 * Cff, C), 52, dtype, scale=C ** -0.5)
+    b1o, b1d = rnd((2 * Cff,), 50, dtype)
+    wi8, bi8 = interleave_geglu(w1d, b1d, 8)
+    wi32, bi32 = interleave_geglu(w1d, b1d)
+    xo, xd = rnd((M, C), 770, dtype)
+    wo, wd = rnd((320, 320), 45, dtype, scale=320 ** -0.5)
+    h = K.linear(xd, wd, None, None, 1.0, ln=K.LnSpec(gamma, beta, 1e-5, None, 1, 1, ("ff",), stats_only=True))
+    pend = K.pending_ln(h, K.take_ln_stats(h, ("ff",)), gamma, beta, 1e-5)
+    mid_rm = K.geglu_linear(pend, w1d, b1d, wi32, bi32, wi8, bi8)
+    mid_tm = K.geglu_linear_blocked(pend, wi8, bi8)
+    assert torch.equal(mid_tm.view(M // 160, Cff // 32, 160, 32).permute(0, 2, 1, 3).reshape(M, Cff), mid_rm)
