@@ -205,6 +205,11 @@ int fmc_cfg_ddim_step(const void* eps_uc, const float* x, float* x_out, int64_t 
  *   16 = 160 x 320 tiles (8 waves of 80 x 80 on the 16x16x32 MFMA, 32-deep sub-tiles in a 5-buffer LDS-DMA ring, one phase per sub-tile;
  *   N % 320 == 0, otherwise falls back to 13; token projections with more tiles than CUs and M % 160 == 0 run its persistent form, in which
  *   the next tile's operands stream in under the epilogue; GEGLU wants weight rows ordered [8 value | 8 gate] per 16);
+ *   18 = tile 16 on a weight the caller PRE-PACKED tile-major in the kernel's own sub-tile order -- projections `[N / 320][K / 32][320][32]`,
+ *   3x3 filters `[Cout / 320][Cin / 64][9 taps][2][320][32]` (sub-tile = (64-channel chunk, tap, 32-channel half)): every W piece of a sub-tile is
+ *   one contiguous KiB; linear LDS-DMA requests move 30-50 % more bytes per CU than 16 rows x 64 B (tools/ubench/dma_mfma); bit-identical
+ *   results, -1 .. -5 % per launch.  No fall-back exists for such a weight: N % 320 != 0, a two-source operand or stream-K are FMC_E_SHAPE.  The
+ *   `w_tilemajor` flag of the tile-16-only entry points below (fmc_*_gn, fmc_linear_bf16_ln / _lnc / _ffblk) says the same about their weight.
  *   17 = the persistent form on 256 x 320 tiles (5 operand requests per 40 MFMAs and wave instead of 4 per 25), GEGLU epilogue only,
  *   M % 256 == 0 and more tiles than CUs -- anything else falls back to 16; same weight row order and bit-identical results.
  *   Every arm computes the same function -- bit for bit among the plain-grid arms of one k-tile depth
@@ -260,7 +265,7 @@ int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, const void*
  * ------------------------------------------------------------------------------------------- */
 int fmc_linear_bf16_gn(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int N, int K,
                        int64_t ldx, int64_t ldres, int64_t ldo, float alpha, const void* residual2, float* gn_partials, int gn_hw,
-                       void* stream);
+                       int w_tilemajor, void* stream);
 /* fmc_linear_bf16_ln = fmc_linear_bf16 (epilogue 0, tile 16, persistent form) for N == 320 that ALSO writes the CONSUMER's LayerNorm of the
  *   rows it produces (diffusers BasicTransformerBlock norm1 / norm2 / norm3 behind proj_in / attn1 / attn2, and the motion module's norms
  *   behind proj_in / the attention blocks: fmc/models/motion_module.py:282-288,355): a 160 x 320 tile holds whole rows, so
@@ -270,7 +275,8 @@ int fmc_linear_bf16_gn(const void* x, const void* w, const void* bias, const voi
  *   gamma / beta / pe fp32.  Anything else is FMC_E_SHAPE (callers fall back to fmc_linear_bf16 + fmc_layernorm_fwd). */
 int fmc_linear_bf16_ln(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int N, int K,
                        int64_t ldx, int64_t ldres, int64_t ldo, float alpha, const void* residual2, void* ln_out, const float* ln_gamma,
-                       const float* ln_beta, float ln_eps, const float* ln_pe, int ln_pe_inner, int ln_pe_frames, float* ln_stats, void* stream);
+                       const float* ln_beta, float ln_eps, const float* ln_pe, int ln_pe_inner, int ln_pe_frames, float* ln_stats, int w_tilemajor,
+                       void* stream);
 /* ... or, with ln_out == NULL and ln_stats != NULL, only the rows' statistics: ln_stats[M][2] = (mean, rstd) fp32 -- for a consumer that is a
  * GEMM and applies the LayerNorm itself:
  * fmc_linear_bf16_lnc = LayerNorm(x) @ w^T + b computed WITHOUT materialising LayerNorm(x): with w_gamma = w diag(gamma) (bf16),
@@ -280,7 +286,7 @@ int fmc_linear_bf16_ln(const void* x, const void* w, const void* bias, const voi
  *   bf16.  Call sites: attn1 / attn2.to_q / the GEGLU projection behind norm1 / norm2 / norm3 of diffusers' BasicTransformerBlock and behind
  *   the motion module's ff_norm (fmc/models/motion_module.py:295-299).  Needs bf16, N % 320 == 0, M % 160 == 0, more 160 x 320 tiles than CUs. */
 int fmc_linear_bf16_lnc(const void* x, const void* w_gamma, void* out, int64_t M, int N, int K, int64_t ldx, int64_t ldo, int epilogue,
-                        const float* ln_stats, const float* ln_c, const float* ln_bias, void* stream);
+                        const float* ln_stats, const float* ln_c, const float* ln_bias, int w_tilemajor, void* stream);
 /* The feed-forward's intermediate in TILE-MAJOR order (diffusers FeedForward: GEGLU projection -> Linear, fmc call sites as for
  * fmc_linear_bf16): `[M / 160][C / 32][160 rows][32]` instead of `[M][C]`.  The GEGLU projection (epilogue 1, out_blocked = 1) writes its
  * gated 160 x 160 tile as five contiguous 10-KiB blocks, and the second GEMM (epilogue 0, x_blocked = 1) requests each 32-deep A sub-tile as
@@ -289,10 +295,10 @@ int fmc_linear_bf16_lnc(const void* x, const void* w_gamma, void* out, int64_t M
  * ln_stats / ln_c / ln_bias != NULL: the GEGLU projection also applies its input's LayerNorm (fmc_linear_bf16_lnc; bias must be NULL then). */
 int fmc_linear_bf16_ffblk(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int N, int K,
                           int64_t ldres, float alpha, int epilogue, int x_blocked, int out_blocked, const float* ln_stats, const float* ln_c,
-                          const float* ln_bias, void* stream);
+                          const float* ln_bias, int w_tilemajor, void* stream);
 int fmc_conv3x3_bf16_gn(const void* x, const void* w, const void* bias, const void* temb, const void* residual, void* out, int n_img,
                         int H, int W, int Cin, int Cout, int64_t temb_row_stride, int temb_img_div, int upsample2x,
-                        float* gn_partials, void* stream);
+                        float* gn_partials, int w_tilemajor, void* stream);
 int fmc_groupnorm_apply_fwd(const void* x, void* y, const float* gamma, const float* beta, float* stats, const float* partials,
                             int part_splits, int N, int HW, int C, int G, float eps, int act, int dtype, void* stream);
 

@@ -48,15 +48,15 @@ SIGNATURES = {
                                 c_int64, c_int64, c_float, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int,
                                 c_void_p, c_void_p]),
     "fmc_linear_bf16_gn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_int64,
-                                   c_float, c_void_p, c_void_p, c_int, c_void_p]),
+                                   c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fmc_linear_bf16_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_int64,
-                                   c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+                                   c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "fmc_linear_bf16_lnc": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p,
-                                    c_void_p]),
+                                    c_int, c_void_p]),
     "fmc_linear_bf16_ffblk": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_float, c_int, c_int, c_int,
-                                      c_void_p, c_void_p, c_void_p, c_void_p]),
+                                      c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "fmc_conv3x3_bf16_gn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                    c_int64, c_int, c_int, c_void_p, c_void_p]),
+                                    c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
     "fmc_groupnorm_apply_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                         c_float, c_int, c_int, c_void_p]),
     "fmc_split_bf16x3": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),

@@ -72,6 +72,9 @@ struct GemmParams {
     bf16_t* ln_out;                   // gemm160p_kernel, plain epilogue, N == 320: ALSO write LayerNorm(out rows) * gamma + beta (+ pe row) here
     const float* ln_gamma; const float* ln_beta; const float* ln_pe;   //   (the consumer's norm: the tile holds whole rows, x is not read again);
     float ln_eps; int ln_pe_inner, ln_pe_frames;                        //   pe row of output row m = ((m / ln_pe_inner) % ln_pe_frames), ln_pe_inner % 160 == 0
+    int w_blocked;                    // gemm160 kernels: the W operand is PRE-PACKED tile-major in the kernel's own sub-tile order,
+                                      //   [N / 320][K / 32][320 rows][32] (conv: sub-tile s = (64-channel chunk, tap, 32-channel half)): a W piece is a
+                                      //   contiguous KiB (fmc_pack_weight_tilemajor) -- linear requests move 30-50 % more bytes per CU than 16 rows x 64 B
     int a_blocked;                    // gemm160p_kernel: the A operand is stored tile-major, [M / 160][K / 32][160 rows][32] -- the sub-tile a workgroup requests is
                                       //   ONE contiguous 10-KiB block (what the GEGLU epilogue writes with out_blocked for the feed-forward's second GEMM)
     int out_blocked;                  // gemm160p_kernel, GEGLU epilogue: write the gated output in that layout (K of the consumer = N / 2)
@@ -1453,7 +1456,8 @@ void gemm160_kernel(const GemmParams P) {
         if (i < 20) {
             const int lw = 16 * i + prow, n = n0 + lw;
             e_lds[e] = (BM + 16 * i) * BK;
-            e_vo[e] = n < P.N ? (unsigned)(((int64_t)n * P.K + psrc * 8) * 2) : OOB;
+            e_vo[e] = n >= P.N ? OOB : (P.w_blocked ? (unsigned)((((int64_t)tile_n * (P.K / BK)) * (BN * BK) + lw * BK + psrc * 8) * 2)
+                                                     : (unsigned)(((int64_t)n * P.K + psrc * 8) * 2));
         } else if (i < 30) {
             const int lr = 16 * (i - 20) + prow;
             e_lds[e] = 16 * (i - 20) * BK;
@@ -1512,7 +1516,8 @@ void gemm160_kernel(const GemmParams P) {
     };
     auto issue = [&]() {
         bf16_t* stage = smem + it_buf * SUB_ELEMS;
-        const int kw = (MODE == 1 ? it_tap * P.cin + it_ci0 + it_half * 32 : it_s * BK) * 2;     // byte offset inside a W row
+        const int kw = P.w_blocked ? it_s * (BN * BK * 2)                                            // the next 20-KiB block of my column tile
+                                   : (MODE == 1 ? it_tap * P.cin + it_ci0 + it_half * 32 : it_s * BK) * 2;     // byte offset inside a W row
         if (w_wave) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) dma(rsW, e_vo[e], kw, stage + e_lds[e]);
@@ -1840,7 +1845,8 @@ void gemm160p_kernel(const GemmParams P) {
             unsigned vo = OOB;
             if (live && i < 20) {
                 const int n = tn * BN + 16 * i + prow;
-                vo = (unsigned)(((int64_t)n * P.K + psrc * 8) * 2);
+                vo = P.w_blocked ? (unsigned)((((int64_t)tn * nks) * (BN * BK) + (16 * i + prow) * BK + psrc * 8) * 2)
+                                 : (unsigned)(((int64_t)n * P.K + psrc * 8) * 2);
             } else if (live && i < 20 + BM / 16) {
                 const int64_t m = (int64_t)tm * BM + 16 * (i - 20) + prow;
                 vo = P.a_blocked ? (unsigned)((((int64_t)tm * nks) * (BM * BK) + (16 * (i - 20) + prow) * BK + psrc * 8) * 2)
@@ -1850,7 +1856,8 @@ void gemm160p_kernel(const GemmParams P) {
         }
     };
     auto issue = [&]() {
-        const int soff = (!w_wave && P.a_blocked) ? it_s * (BM * BK * 2) : it_s * BK * 2;     // (blocked A: the next sub-tile is the next 10-KiB block)
+        const int soff = w_wave ? (P.w_blocked ? it_s * (BN * BK * 2) : it_s * BK * 2)          // (tile-major operands: the next sub-tile is the next block)
+                                : (P.a_blocked ? it_s * (BM * BK * 2) : it_s * BK * 2);
 #pragma unroll
         for (int e = 0; e < NE; ++e) {                // (LDS destinations as wave-uniform 32-bit offsets: they travel through M0)
             const int dst = e_lds[e] == NBUF * SUB_ELEMS ? NBUF * SUB_ELEMS : it_buf * SUB_ELEMS + e_lds[e];
@@ -2727,7 +2734,7 @@ bool gemm8_ok(GemmParams& P) {
 }
 
 // tile arms (fmc_hip.h): geometry x k-tile depth x ring depth
-constexpr int GEMM_TILE_MAX = 17;
+constexpr int GEMM_TILE_MAX = 18;
 
 // geometry: the largest tile that still gives every CU work and does not waste more than ~20 % of N
 template <int MODE, int EPI>
@@ -2816,8 +2823,9 @@ static int linear_impl(const void* x, const void* w, const void* bias, const voi
                        void* ln_out = nullptr, const float* ln_gamma = nullptr, const float* ln_beta = nullptr, float ln_eps = 0.f,
                        const float* ln_pe = nullptr, int ln_pe_inner = 1, int ln_pe_frames = 1, float* ln_stats = nullptr,
                        const float* lnc_stats = nullptr, const float* lnc_c = nullptr, const float* lnc_bias = nullptr, int a_blocked = 0,
-                       int out_blocked = 0) {
+                       int out_blocked = 0, int w_tilemajor = 0) {
     if (!x || !w || !out) FMC_FAIL(FMC_E_NULL, "linear_bf16: NULL tensor");
+    if (tile == 18) { tile = 16; w_tilemajor = 1; }           // tile 18 = tile 16 on a weight pre-packed tile-major (fmc_hip.h)
     if (M <= 0 || N <= 0 || K <= 0 || K % BK_MAX || N % 8 || ldx % 8 || ldo % (f32io ? 4 : 8) || (residual && ldres % (f32io ? 4 : 8)))
         FMC_FAIL(FMC_E_SHAPE, "linear_bf16: need K%%64==0, N%%8==0 and strides %%8==0 (M=%lld N=%d K=%d)", (long long)M, N, K);
     if (f32io && (x2 || split_k < 0)) FMC_FAIL(FMC_E_SHAPE, "linear_x3_f32: no two-source operand (split it into one buffer) and no stream-K");
@@ -2875,6 +2883,12 @@ static int linear_impl(const void* x, const void* w, const void* bias, const voi
     P.a2 = (const bf16_t*)x2; P.lda2 = ldx2; P.ksplit = x2 ? k_split : 0;
     hipStream_t st = (hipStream_t)stream;
     if (tile < 0 || tile > GEMM_TILE_MAX) FMC_FAIL(FMC_E_SHAPE, "linear_bf16: tile %d", tile);
+    P.w_blocked = 0;
+    if (w_tilemajor) {                                        // no other kernel can read that weight: everything that would leave tile 16 is an error
+        if (tile != 16 || f32io || N % 320 || x2 || split_k < 1 || ((M - 1) * ldx + K) * 2 >= ((int64_t)1 << 31) || (int64_t)N * K * 2 >= ((int64_t)1 << 31))
+            FMC_FAIL(FMC_E_SHAPE, "linear_bf16: a tile-major weight (tile 18) needs bf16, N %% 320 == 0, no two-source operand, no stream-K, operands < 2 GiB");
+        P.w_blocked = 1;
+    }
     if (int rc = set_split_k(P, split_k, workspace, workspace_bytes, epilogue == 0, "linear_bf16")) return rc;
     if (epilogue == 0) launch_gemm<0, 0>(P, tile, st); else launch_gemm<0, 1>(P, tile, st);
     FMC_CHECK_LAUNCH("fmc_linear_bf16");
@@ -2891,36 +2905,36 @@ extern "C" int fmc_linear_bf16(const void* x, const void* w, const void* bias, c
 
 extern "C" int fmc_linear_bf16_gn(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,
                                   int N, int K, int64_t ldx, int64_t ldres, int64_t ldo, float alpha, const void* residual2,
-                                  float* gn_partials, int gn_hw, void* stream) {
+                                  float* gn_partials, int gn_hw, int w_tilemajor, void* stream) {
     if (!gn_partials) FMC_FAIL(FMC_E_NULL, "linear_bf16_gn: NULL gn_partials");
     return linear_impl(x, w, bias, residual, out, M, N, K, ldx, ldres, ldo, alpha, 0, 16, 1, nullptr, 0, nullptr, 0, 0, residual2, stream, 0,
-                       gn_partials, gn_hw);
+                       gn_partials, gn_hw, nullptr, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr, nullptr, nullptr, nullptr, 0, 0, w_tilemajor);
 }
 
 extern "C" int fmc_linear_bf16_ln(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,
                                   int N, int K, int64_t ldx, int64_t ldres, int64_t ldo, float alpha, const void* residual2,
                                   void* ln_out, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* ln_pe,
-                                  int ln_pe_inner, int ln_pe_frames, float* ln_stats, void* stream) {
+                                  int ln_pe_inner, int ln_pe_frames, float* ln_stats, int w_tilemajor, void* stream) {
     if (!ln_out && !ln_stats) FMC_FAIL(FMC_E_NULL, "linear_bf16_ln: NULL ln_out and ln_stats");
     if (ln_out && (!ln_gamma || !ln_beta)) FMC_FAIL(FMC_E_NULL, "linear_bf16_ln: NULL gamma / beta");
     return linear_impl(x, w, bias, residual, out, M, N, K, ldx, ldres, ldo, alpha, 0, 16, 1, nullptr, 0, nullptr, 0, 0, residual2, stream, 0,
-                       nullptr, 0, ln_out, ln_gamma, ln_beta, ln_eps, ln_pe, ln_pe_inner, ln_pe_frames, ln_stats);
+                       nullptr, 0, ln_out, ln_gamma, ln_beta, ln_eps, ln_pe, ln_pe_inner, ln_pe_frames, ln_stats, nullptr, nullptr, nullptr, 0, 0, w_tilemajor);
 }
 
 extern "C" int fmc_linear_bf16_lnc(const void* x, const void* w_gamma, void* out, int64_t M, int N, int K, int64_t ldx, int64_t ldo, int epilogue,
-                                   const float* ln_stats, const float* ln_c, const float* ln_bias, void* stream) {
+                                   const float* ln_stats, const float* ln_c, const float* ln_bias, int w_tilemajor, void* stream) {
     if (!ln_stats || !ln_c || !ln_bias) FMC_FAIL(FMC_E_NULL, "linear_bf16_lnc: NULL ln_stats / ln_c / ln_bias");
     return linear_impl(x, w_gamma, nullptr, nullptr, out, M, N, K, ldx, 0, ldo, 1.f, epilogue, 16, 1, nullptr, 0, nullptr, 0, 0, nullptr, stream, 0,
-                       nullptr, 0, nullptr, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr, ln_stats, ln_c, ln_bias);
+                       nullptr, 0, nullptr, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr, ln_stats, ln_c, ln_bias, 0, 0, w_tilemajor);
 }
 
 extern "C" int fmc_linear_bf16_ffblk(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int N, int K,
                                      int64_t ldres, float alpha, int epilogue, int x_blocked, int out_blocked, const float* ln_stats,
-                                     const float* ln_c, const float* ln_bias, void* stream) {
+                                     const float* ln_c, const float* ln_bias, int w_tilemajor, void* stream) {
     if (!x_blocked && !out_blocked) FMC_FAIL(FMC_E_SHAPE, "linear_bf16_ffblk: neither operand is tile-major (use fmc_linear_bf16)");
     const int n_out = epilogue == 1 ? N / 2 : N;
     return linear_impl(x, w, bias, residual, out, M, N, K, K, ldres, n_out, alpha, epilogue, 16, 1, nullptr, 0, nullptr, 0, 0, nullptr, stream, 0,
-                       nullptr, 0, nullptr, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr, ln_stats, ln_c, ln_bias, x_blocked, out_blocked);
+                       nullptr, 0, nullptr, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr, ln_stats, ln_c, ln_bias, x_blocked, out_blocked, w_tilemajor);
 }
 
 extern "C" int fmc_linear_x3_f32(const void* x3, const void* w3, const float* bias, const float* residual, float* out, int64_t M,
@@ -2934,8 +2948,9 @@ extern "C" int fmc_linear_x3_f32(const void* x3, const void* w3, const float* bi
 static int conv3x3_impl(const void* x, const void* w, const void* bias, const void* temb, const void* residual,
                         void* out, int n_img, int H, int W, int Cin, int Cout, int64_t temb_row_stride,
                         int temb_img_div, int upsample2x, int tile, int split_k,
-                        void* workspace, int64_t workspace_bytes, void* stream, int f32io, void* gn_partials = nullptr) {
+                        void* workspace, int64_t workspace_bytes, void* stream, int f32io, void* gn_partials = nullptr, int w_tilemajor = 0) {
     if (!x || !w || !out) FMC_FAIL(FMC_E_NULL, "conv3x3_bf16: NULL tensor");
+    if (tile == 18) { tile = 16; w_tilemajor = 1; }           // tile 18 = tile 16 on a filter pre-packed tile-major (fmc_hip.h)
     if (n_img <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % BK_MAX || Cout % 8)
         FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: need Cin%%64==0 and Cout%%8==0 (Cin=%d Cout=%d)", Cin, Cout);
     if (!fmc_aligned16(x) || !fmc_aligned16(w) || !fmc_aligned16(out) || (residual && !fmc_aligned16(residual)) ||
@@ -2959,6 +2974,13 @@ static int conv3x3_impl(const void* x, const void* w, const void* bias, const vo
     if (upsample2x == 1 && ((H | W) & 1)) FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: upsample2x needs even H, W (the OUTPUT size)");
     P.ups = upsample2x;
     if (tile < 0 || tile > GEMM_TILE_MAX) FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: tile %d", tile);
+    P.w_blocked = 0;
+    if (w_tilemajor) {                                        // the filter is packed in the kernel's (chunk, tap, half) sub-tile order
+        if (tile != 16 || f32io || Cout % 320 || Cin % 64 || split_k < 1 || (int64_t)Cout * 9 * Cin * 2 >= ((int64_t)1 << 31) ||
+            (int64_t)n_img * H * W * Cin * 2 * (upsample2x == 2 ? 4 : 1) >= ((int64_t)1 << 31))
+            FMC_FAIL(FMC_E_SHAPE, "conv3x3_bf16: tile 18 (tile-major filter) needs bf16, Cout %% 320 == 0, Cin %% 64 == 0, no stream-K, operands < 2 GiB");
+        P.w_blocked = 1;
+    }
     if (int rc = set_split_k(P, split_k, workspace, workspace_bytes, true, "conv3x3_bf16")) return rc;
     launch_gemm<1, 0>(P, tile, (hipStream_t)stream);
     FMC_CHECK_LAUNCH("fmc_conv3x3_bf16");
@@ -2975,10 +2997,10 @@ extern "C" int fmc_conv3x3_bf16(const void* x, const void* w, const void* bias, 
 
 extern "C" int fmc_conv3x3_bf16_gn(const void* x, const void* w, const void* bias, const void* temb, const void* residual,
                                    void* out, int n_img, int H, int W, int Cin, int Cout, int64_t temb_row_stride,
-                                   int temb_img_div, int upsample2x, float* gn_partials, void* stream) {
+                                   int temb_img_div, int upsample2x, float* gn_partials, int w_tilemajor, void* stream) {
     if (!gn_partials) FMC_FAIL(FMC_E_NULL, "conv3x3_bf16_gn: NULL gn_partials");
     return conv3x3_impl(x, w, bias, temb, residual, out, n_img, H, W, Cin, Cout, temb_row_stride, temb_img_div, upsample2x, 16, 1,
-                        nullptr, 0, stream, 0, gn_partials);
+                        nullptr, 0, stream, 0, gn_partials, w_tilemajor);
 }
 
 extern "C" int fmc_conv3x3_x3_f32(const void* x3, const void* w3, const float* bias, const float* temb, const float* residual,

@@ -835,6 +835,7 @@ def cfg_ddim_step(eps: torch.Tensor, x: torch.Tensor, guidance: float, alpha_t: 
 # --------------------------------------------------------------------------------------------
 ARM_160 = 512
 ARM_256 = 528                       # C-ABI tile 17: persistent 256 x 320 tiles, GEGLU projections only (falls back to tile 16)
+ARM_160B = 544                      # C-ABI tile 18: tile 16 reading the weight pre-packed tile-major (`_w_tilemajor`): linear 1-KiB operand requests
 
 
 def _decode_arm(tile: int, split_k: int):
@@ -842,6 +843,8 @@ def _decode_arm(tile: int, split_k: int):
     hybrid; ARM_160 (512) is the C-ABI tile 16, the 160 x 320 kernel."""
     if tile == ARM_256:
         return 17, 1
+    if tile == ARM_160B:
+        return 18, 1
     if ARM_160 <= tile < ARM_160 + 5:                  # 512 + log2(split): the 160 x 320 kernel, split-K 1 / 2 / 4 / 8 / 16
         return 16, 1 << (tile - ARM_160)
     if tile >= 256:
@@ -908,6 +911,50 @@ def split_arms(M: int, N: int, Kd: int):
     return tuple(arms)
 
 
+W_TILEMAJOR = os.environ.get("FMC_W_TILEMAJOR", "1") != "0"      # A/B switch: the 160 x 320 kernels read weights pre-packed tile-major (tile 18)
+
+
+def _owner_cache(t: torch.Tensor, name: str) -> dict:
+    """A dict living on the tensor that owns t's storage (dies with it), reset when that tensor's version changes."""
+    owner = t._base if t._base is not None else t
+    cache = getattr(owner, name, None)
+    if cache is None or cache[0] != owner._version:
+        cache = (owner._version, {})
+        try:
+            setattr(owner, name, cache)
+        except Exception:
+            pass
+    return cache[1]
+
+
+def _w_tilemajor(weight: torch.Tensor) -> torch.Tensor:
+    """`[N, K]` projection weight -> `[N / 320][K / 32][320][32]`: what tile 18 reads (a W piece of a sub-tile = one contiguous KiB)."""
+    cache = _owner_cache(weight, "_fmc_wtm")
+    key = ("lin", weight.storage_offset(), tuple(weight.shape), tuple(weight.stride()), weight._version)
+    hit = cache.get(key)
+    if hit is None:
+        N, Kd = weight.shape
+        with torch.no_grad():
+            hit = weight.detach().reshape(N // 320, 320, Kd // 32, 32).permute(0, 2, 1, 3).contiguous()
+        cache[key] = hit
+    return hit
+
+
+def _w_tilemajor_conv(weight_cl: torch.Tensor) -> torch.Tensor:
+    """Channels-last 3x3 filter (physically `[Cout][3][3][Cin]`) -> `[Cout / 320][Cin / 64][9 taps][2 halves][320][32]`: the conv kernel's own
+    sub-tile order (64-channel chunk, tap, 32-channel half)."""
+    cache = _owner_cache(weight_cl, "_fmc_wtm")
+    key = ("conv", weight_cl.storage_offset(), tuple(weight_cl.shape), tuple(weight_cl.stride()), weight_cl._version)
+    hit = cache.get(key)
+    if hit is None:
+        cout, cin = weight_cl.shape[:2]
+        with torch.no_grad():
+            w = weight_cl.detach().permute(0, 2, 3, 1).reshape(cout // 320, 320, 9, cin // 64, 2, 32)      # [nt][row][tap][chunk][half][32]
+            hit = w.permute(0, 3, 2, 4, 1, 5).contiguous()                                                 # [nt][chunk][tap][half][row][32]
+        cache[key] = hit
+    return hit
+
+
 def linear_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
     return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.stride(-1) == 1
             and weight.shape[1] % 64 == 0 and weight.shape[0] % 8 == 0 and weight.is_contiguous())
@@ -933,6 +980,12 @@ def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     tile, split_k = _decode_arm(tile, split_k)
     _dev(x, weight, bias, residual, x2)
     N, Kd = weight.shape
+    if tile == 18:
+        M0 = x.numel() // x.shape[-1]
+        if x2 is not None or N % 320 or split_k < 1 or M0 * max(Kd, N) * 2 >= (1 << 31) or N * Kd * 2 >= (1 << 31):
+            tile = 16                                   # (not a case tile 16 takes on a packed weight: row-major, with tile 16's own fall-backs)
+        else:
+            weight = _w_tilemajor(weight)
     M, ldx = _rows2d(x)
     ldx2, k_split = 0, 0
     if x2 is not None:
@@ -982,6 +1035,11 @@ def conv3x3_bf16(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias: Optional[t
     assert residual_nhwc is None or (residual_nhwc.is_contiguous() and residual_nhwc.shape == (n, h, w, cout))
     out = torch.empty(n, h, w, cout, dtype=x_nhwc.dtype, device=x_nhwc.device)
     tile, split_k = _decode_arm(tile, split_k)
+    if tile == 18:
+        if cout % 320 or cin % 64 or split_k < 1 or x_nhwc.numel() * 2 >= (1 << 31) or weight_cl.numel() * 2 >= (1 << 31):
+            tile = 16
+        else:
+            weight_cl = _w_tilemajor_conv(weight_cl)
     ws, ws_bytes = _splitk_workspace(x_nhwc.device, split_k, n * h * w, cout)
     _lib.check(_lib.load().fmc_conv3x3_bf16(x_nhwc.data_ptr(), weight_cl.data_ptr(), _p(bias), _p(temb),
                                             _p(residual_nhwc), out.data_ptr(), n, h, w, cin, cout,
@@ -1112,8 +1170,9 @@ def linear_lnc(x: torch.Tensor, weight: torch.Tensor, bias, pend, geglu: bool = 
     n_out = N // 2 if geglu else N
     out = torch.empty(*x.shape[:-1], n_out, dtype=x.dtype, device=x.device)
     ln_epilogue_calls["consumed"] += 1
-    _lib.check(_lib.load().fmc_linear_bf16_lnc(x.data_ptr(), wg.data_ptr(), out.data_ptr(), M, N, Kd, ldx, n_out, int(geglu), stats.data_ptr(),
-                                               c.data_ptr(), b.data_ptr(), _stream()), "fmc_linear_bf16_lnc")
+    wt = _w_tilemajor(wg) if W_TILEMAJOR else wg
+    _lib.check(_lib.load().fmc_linear_bf16_lnc(x.data_ptr(), wt.data_ptr(), out.data_ptr(), M, N, Kd, ldx, n_out, int(geglu), stats.data_ptr(),
+                                               c.data_ptr(), b.data_ptr(), int(W_TILEMAJOR), _stream()), "fmc_linear_bf16_lnc")
     return out
 
 
@@ -1130,9 +1189,11 @@ def linear_ln(x: torch.Tensor, weight: torch.Tensor, bias, residual, alpha: floa
         ln_out = None
     else:
         stats, ln_out = None, torch.empty_like(out)
-    _lib.check(_lib.load().fmc_linear_bf16_ln(x.data_ptr(), weight.data_ptr(), _p(bias), _p(residual), out.data_ptr(), M, N, Kd, ldx, ldres, N,
+    wt = _w_tilemajor(weight) if W_TILEMAJOR else weight
+    _lib.check(_lib.load().fmc_linear_bf16_ln(x.data_ptr(), wt.data_ptr(), _p(bias), _p(residual), out.data_ptr(), M, N, Kd, ldx, ldres, N,
                                               float(alpha), _p(residual2), _p(ln_out), ln.gamma.data_ptr(), ln.beta.data_ptr(), float(ln.eps),
-                                              _p(ln.pe), int(ln.pe_inner), int(ln.pe_frames), _p(stats), _stream()), "fmc_linear_bf16_ln")
+                                              _p(ln.pe), int(ln.pe_inner), int(ln.pe_frames), _p(stats), int(W_TILEMAJOR), _stream()),
+               "fmc_linear_bf16_ln")
     out._fmc_ln = (stats, ln.key, True) if ln.stats_only else (ln_out, ln.key, False)
     return out
 
@@ -1166,10 +1227,12 @@ def geglu_linear_blocked(x: torch.Tensor, weight_il160: torch.Tensor, bias_il160
         wg, c, b = _ln_folded_weight(weight_il160, bias_il160, gamma, beta)
         _dev(x, wg, c, b, stats)
         ln_epilogue_calls["consumed"] += 1
-        args = (wg.data_ptr(), None, None, out.data_ptr(), M, N, Kd, 0, 1.0, 1, 0, 1, stats.data_ptr(), c.data_ptr(), b.data_ptr())
+        wt = _w_tilemajor(wg) if W_TILEMAJOR else wg
+        args = (wt.data_ptr(), None, None, out.data_ptr(), M, N, Kd, 0, 1.0, 1, 0, 1, stats.data_ptr(), c.data_ptr(), b.data_ptr(), int(W_TILEMAJOR))
     else:
         _dev(x, weight_il160, bias_il160)
-        args = (weight_il160.data_ptr(), _p(bias_il160), None, out.data_ptr(), M, N, Kd, 0, 1.0, 1, 0, 1, None, None, None)
+        wt = _w_tilemajor(weight_il160) if W_TILEMAJOR else weight_il160
+        args = (wt.data_ptr(), _p(bias_il160), None, out.data_ptr(), M, N, Kd, 0, 1.0, 1, 0, 1, None, None, None, int(W_TILEMAJOR))
     _lib.check(_lib.load().fmc_linear_bf16_ffblk(x.data_ptr(), *args, _stream()), "fmc_linear_bf16_ffblk")
     return out
 
@@ -1180,8 +1243,9 @@ def linear_from_blocked(xb: torch.Tensor, weight: torch.Tensor, bias, residual, 
     N, Kd = weight.shape
     M = xb.numel() // Kd
     out = torch.empty(*xb.shape[:-1], N, dtype=xb.dtype, device=xb.device)
-    _lib.check(_lib.load().fmc_linear_bf16_ffblk(xb.data_ptr(), weight.data_ptr(), _p(bias), _p(residual), out.data_ptr(), M, N, Kd,
-                                                 0 if residual is None else N, float(alpha), 0, 1, 0, None, None, None, _stream()),
+    wt = _w_tilemajor(weight) if W_TILEMAJOR else weight
+    _lib.check(_lib.load().fmc_linear_bf16_ffblk(xb.data_ptr(), wt.data_ptr(), _p(bias), _p(residual), out.data_ptr(), M, N, Kd,
+                                                 0 if residual is None else N, float(alpha), 0, 1, 0, None, None, None, int(W_TILEMAJOR), _stream()),
                "fmc_linear_bf16_ffblk")
     return out
 
@@ -1195,8 +1259,9 @@ def linear_gn(x: torch.Tensor, weight: torch.Tensor, bias, residual, alpha: floa
     part = torch.empty(M // hw, hw // 160, 32, 2, dtype=torch.float32, device=x.device)
     ldres = 0 if residual is None else _rows2d(residual)[1]
     gn_epilogue_calls["emitted"] += 1
-    _lib.check(_lib.load().fmc_linear_bf16_gn(x.data_ptr(), weight.data_ptr(), _p(bias), _p(residual), out.data_ptr(), M, N, Kd, ldx, ldres, N,
-                                              float(alpha), _p(residual2), part.data_ptr(), int(hw), _stream()), "fmc_linear_bf16_gn")
+    wt = _w_tilemajor(weight) if W_TILEMAJOR else weight
+    _lib.check(_lib.load().fmc_linear_bf16_gn(x.data_ptr(), wt.data_ptr(), _p(bias), _p(residual), out.data_ptr(), M, N, Kd, ldx, ldres, N,
+                                              float(alpha), _p(residual2), part.data_ptr(), int(hw), int(W_TILEMAJOR), _stream()), "fmc_linear_bf16_gn")
     out._fmc_gn = (part, N)
     return out
 
@@ -1211,9 +1276,10 @@ def conv3x3_gn(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias, temb, residu
     out = torch.empty(n, h, w, cout, dtype=x_nhwc.dtype, device=x_nhwc.device)
     part = torch.empty(n, (h * w) // 160, 32, 2, dtype=torch.float32, device=x_nhwc.device)
     gn_epilogue_calls["emitted"] += 1
-    _lib.check(_lib.load().fmc_conv3x3_bf16_gn(x_nhwc.data_ptr(), weight_cl.data_ptr(), _p(bias), _p(temb), _p(residual_nhwc), out.data_ptr(),
+    wt = _w_tilemajor_conv(weight_cl) if W_TILEMAJOR else weight_cl
+    _lib.check(_lib.load().fmc_conv3x3_bf16_gn(x_nhwc.data_ptr(), wt.data_ptr(), _p(bias), _p(temb), _p(residual_nhwc), out.data_ptr(),
                                                n, h, w, cin, cout, 0 if temb is None else temb.stride(0), int(temb_div),
-                                               2 if stride2 else int(upsample), part.data_ptr(), _stream()), "fmc_conv3x3_bf16_gn")
+                                               2 if stride2 else int(upsample), part.data_ptr(), int(W_TILEMAJOR), _stream()), "fmc_conv3x3_bf16_gn")
     return out, (part, cout)
 
 
@@ -1266,7 +1332,7 @@ def _f32_arm(key_bf16, tile: int) -> int:
         use -= 256
     elif use >= 128:
         use -= 128
-    return use if (1 <= use <= 14 or use == ARM_160) else 0
+    return ARM_160 if use == ARM_160B else (use if (1 <= use <= 14 or use == ARM_160) else 0)
 
 
 def linear_f32(x: torch.Tensor, weight: torch.Tensor, bias=None, residual=None, alpha: float = 1.0, geglu: bool = False,
@@ -1426,7 +1492,8 @@ atexit.register(_save_at_exit)
 GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 11,     # 8..10, 12 (4-stage rings) exist but never won on the FMC shapes
               13,                            # the 8-phase 256x256 kernel (staggered wave rows, half-tile DMA, counted vmcnt)
               15,                            # K = 320 token projections: persistent, weights resident in registers (falls back to 5 elsewhere)
-              ARM_160,                       # 160 x 320 tiles on the 8-phase schedule: whole rounds / no padded columns for N = 320 k (falls back to 13)
+              ARM_160B if W_TILEMAJOR else ARM_160,   # 160 x 320 tiles (whole rounds / no padded columns for N = 320 k; falls back to 13 elsewhere), reading the weight
+                                             # pre-packed tile-major (bit-identical to ARM_160, -1 .. -5 % per launch: tools/probe_wtm.py)
               128 + 2, 128 + 3,              # stream-K (persistent workgroups) on the two 1-per-CU geometries
               128 + 13,                      # stream-K on the 8-phase kernel: persistent partial pass + one finishing workgroup per tile
               256 + 13)                      # the same for the LAST PARTIAL ROUND of tiles only, the whole rounds on the plain grid
@@ -1489,7 +1556,7 @@ def _pick(key, hip_fn, lib_fn, static_hip: bool, extra_arms=(), k320: bool = Fal
             return 0 if not (static_hip or no_lib) else -1          # -1: kernel's own geometry heuristic
         times = ([] if no_lib else [(_time_ms(lib_fn), 0)]) + [(_time_ms(lambda t=t: hip_fn(t)), t) for t in GEMM_TILES + tuple(extra_arms)
                                                                 if (t != 15 or k320)    # (arm 15 exists for the K = 320 token projections only,
-                                                                and (not (ARM_160 <= t < ARM_160 + 5 or t == ARM_256) or n320)]  #  arm 16 for outputs whose width is a multiple of 320)
+                                                                and (not (ARM_160 <= t < ARM_160 + 5 or t in (ARM_256, ARM_160B)) or n320)]  #  arm 16 for outputs whose width is a multiple of 320)
         use = min(times)[1]
         _choice[key] = use
         _tune_log[key] = {arm: round(ms, 4) for ms, arm in times}
@@ -1572,9 +1639,9 @@ def geglu_linear(x: torch.Tensor, weight: torch.Tensor, bias, weight_il: torch.T
             and weight_il.shape[1] % 64 == 0 and x.is_contiguous()):
         N, Kd = weight.shape
         arm = _f32_arm(("geglu", x.numel() // Kd, N, Kd), 0)
-        if arm == ARM_160 and weight_il160 is not None:
+        if arm in (ARM_160, ARM_160B) and weight_il160 is not None:
             return linear_f32(x, weight_il160, bias_il160, geglu=True, tile=ARM_160)
-        return linear_f32(x, weight_il, bias_il, geglu=True, tile=0 if arm == ARM_160 else arm)
+        return linear_f32(x, weight_il, bias_il, geglu=True, tile=0 if arm in (ARM_160, ARM_160B) else arm)
     if not linear_supported(x, weight_il) or weight_il.shape[0] % 64 or (x.ndim > 2 and not x.is_contiguous()):
         return lib()
     N, Kd = weight.shape
@@ -1582,7 +1649,7 @@ def geglu_linear(x: torch.Tensor, weight: torch.Tensor, bias, weight_il: torch.T
     has160 = weight_il160 is not None and N % 320 == 0
 
     def hip(tile):
-        if tile in (ARM_160, ARM_256):                  # (without the 160-block order these arms would silently pair wrong rows: route them to 13)
+        if tile in (ARM_160, ARM_256, ARM_160B):        # (without the 160-block order these arms would silently pair wrong rows: route them to 13)
             return linear_bf16(x, weight_il160, bias_il160, geglu=True, tile=tile) if has160 else linear_bf16(x, weight_il, bias_il, geglu=True, tile=13)
         return linear_bf16(x, weight_il, bias_il, geglu=True, tile=tile)
     # (ARM_256, the persistent 256 x 320 form, is selectable but not a candidate: measured 235 / 153 / 134 us against ARM_160's 203 / 153 / 130 us on

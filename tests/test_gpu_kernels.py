@@ -1605,3 +1605,47 @@ def test_feed_forward_with_a_tile_major_intermediate(K):
     mid_rm = K.geglu_linear(pend, w1d, b1d, wi32, bi32, wi8, bi8)
     mid_tm = K.geglu_linear_blocked(pend, wi8, bi8)
     assert torch.equal(mid_tm.view(M // 160, Cff // 32, 160, 32).permute(0, 2, 1, 3).reshape(M, Cff), mid_rm)
+
+
+@torch.no_grad()
+def test_tile_major_weights_are_bit_identical(K):
+    """Tile 18 (arm 544) = tile 16 on a weight pre-packed `[N / 320][K / 32][320][32]` (filters: `[Cout / 320][Cin / 64][9][2][320][32]`, the conv
+    kernel's own sub-tile order): same products in the same order, so every output is bit-identical to tile 16 -- plain and persistent form,
+    bias / residual / GEGLU, conv with temb / residual / upsample / stride 2, the GroupNorm- and LayerNorm-emitting entry points; shapes tile 16
+    does not take on a packed weight fall back to the row-major path."""
+    dtype = torch.bfloat16
+    from synfmc_amd.models.layers import interleave_geglu
+    for (M, N, Kd) in [(81920, 320, 320), (20480, 640, 640), (4100, 960, 1280), (5120, 1280, 5120)]:
+        xo, xd = rnd((M, Kd), 780, dtype)
+        wo, wd = rnd((N, Kd), 45, dtype, scale=Kd ** -0.5)
+        bo, bd = rnd((N,), 46, dtype)
+        ro, rd = rnd((M, N), 880, dtype)
+        assert torch.equal(K.linear_bf16(xd, wd, bd, rd, 0.5, tile=K.ARM_160B), K.linear_bf16(xd, wd, bd, rd, 0.5, tile=K.ARM_160)), (M, N, Kd)
+        assert torch.equal(K.linear_bf16(xd, wd, None, None, 1.0, tile=K.ARM_160B), K.linear_bf16(xd, wd, None, None, 1.0, tile=K.ARM_160))
+    go, gd = rnd((2560, 320), 42, dtype, scale=320 ** -0.5)
+    gbo, gbd = rnd((2560,), 40, dtype)
+    w8, b8 = interleave_geglu(gd, gbd, 8)
+    for M in (48000, 4100):
+        xo, xd = rnd((M, 320), 781, dtype)
+        assert torch.equal(K.linear_bf16(xd, w8, b8, geglu=True, tile=K.ARM_160B), K.linear_bf16(xd, w8, b8, geglu=True, tile=K.ARM_160))
+    co, cd = rnd((4, 36, 30, 320), 47, dtype)
+    fo, fd = rnd((640, 320, 3, 3), 44, dtype, scale=(9 * 320) ** -0.5)
+    f_cl = fd.contiguous(memory_format=torch.channels_last)
+    to, td = rnd((4, 640), 43, dtype)
+    ro, rd = rnd((4, 36, 30, 640), 48, dtype)
+    for kw in ({}, {"upsample": True}, {"stride2": True}):
+        assert torch.equal(K.conv3x3_bf16(cd, f_cl, None, None, None, tile=K.ARM_160B, **kw), K.conv3x3_bf16(cd, f_cl, None, None, None, tile=K.ARM_160, **kw)), kw
+    assert torch.equal(K.conv3x3_bf16(cd, f_cl, None, td, rd, tile=K.ARM_160B), K.conv3x3_bf16(cd, f_cl, None, td, rd, tile=K.ARM_160))
+    # not taken on a packed weight: N % 320 != 0, two-source operand -> the row-major path, same function as before
+    xo, xd = rnd((700, 320), 41, dtype)
+    wo, wd = rnd((328, 320), 42, dtype, scale=320 ** -0.5)
+    assert torch.equal(K.linear_bf16(xd, wd, None, None, 1.0, tile=K.ARM_160B), K.linear_bf16(xd, wd, None, None, 1.0, tile=13))
+    x1o, x1d = rnd((700, 128), 51, dtype)
+    x2o, x2d = rnd((700, 192), 52, dtype)
+    w3o, w3d = rnd((320, 320), 53, dtype, scale=320 ** -0.5)
+    assert torch.equal(K.linear_bf16(x1d, w3d, None, None, 1.0, tile=K.ARM_160B, x2=x2d), K.linear_bf16(x1d, w3d, None, None, 1.0, tile=13, x2=x2d))
+    # the flag of the tile-16-only entry points (GroupNorm partials here; the LayerNorm ones are covered by their own tests, which run with it on)
+    assert K.W_TILEMAJOR
+    xo, xd = rnd((2, 2560, 320), 54, dtype)
+    y = K.linear(xd, w3d, None, None, 1.0, gn_hw=2560)
+    assert getattr(y, "_fmc_gn", None) is not None and torch.equal(y, K.linear_bf16(xd, w3d, None, None, 1.0, tile=K.ARM_160))

@@ -1,6 +1,6 @@
 # final GPU call of the round: full GPU suite, default bench line, steady-state kernel trace, roofline counters, training line
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r03f; mkdir -p $O
+O=gpurun_out/r03g; mkdir -p $O
 export FMC_AUTOTUNE_CACHE=$PWD/$O/autotune_cache.json
 timeout 1800 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -4 $O/pytest.log
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -c 1500 $O/bench.json

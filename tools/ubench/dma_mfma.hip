@@ -13,13 +13,13 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
 template <int LDS, int M>
-__global__ __launch_bounds__(1024) void k(const unsigned char* base, int shape, int D, int iters, float* sink, int depth, int inter) {
+__global__ __launch_bounds__(1024) void k(const unsigned char* base, int shape, int D, int iters, float* sink, int depth, int inter, int row_bytes_arg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long region = 65536;
+    const long region = 65536 * 8;
     const unsigned char* mine = base + (long)blockIdx.x * region;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)mine, 0, (int)region, 0x00020000);
-    const int row_bytes = 1280;
+    const int row_bytes = row_bytes_arg;
     unsigned voff;
     int step;                                            // byte advance between consecutive pieces of a wave
     if (shape == 0) { voff = (lane >> 2) * row_bytes + (lane & 3) * 16; step = 64; }
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(1024) void k(const unsigned char* base, int shape, 
             else { u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, soff, 0); v[0] ^= t[0]; }
             soff += step;
             if (shape != 2 && (soff % row_bytes) + step > row_bytes) soff += (shape == 0 ? 16 : shape == 1 ? 8 : 4) * row_bytes - (soff % row_bytes);
-            if (soff > region - 24 * 1280) soff = wave * 4096 % 1024;
+            if (soff > region - 24 * row_bytes) soff = wave * 4096 % 1024;
         };
         if (inter) {                                     // 4 requests, each followed by a quarter of the MFMAs
 #pragma unroll
@@ -83,15 +83,16 @@ int main(int argc, char** argv) {
     const int waves = argc > 5 ? atoi(argv[5]) : 8;
     const int wgs = argc > 6 ? atoi(argv[6]) : 256;
     const int use_lds = argc > 7 ? atoi(argv[7]) : 1;
+    const int row_bytes = argc > 10 ? atoi(argv[10]) : 1280;   // pitch of the operand rows (K * 2 bytes)
     const int inter = argc > 9 ? atoi(argv[9]) : 0;   // 1: 4 x {request, M/4 MFMAs} per iteration; 2: the same with s_setprio around the MFMAs
     const int depth = argc > 8 ? atoi(argv[8]) : 2;   // s_waitcnt vmcnt(0 / 4 / 8 / 16 / 32) after each group of D requests
     unsigned char* buf;
-    hipMalloc(&buf, (size_t)wgs * 65536 + 4096);
-    hipMemset(buf, 1, (size_t)wgs * 65536);
+    hipMalloc(&buf, (size_t)wgs * 65536 * 8 + 4096);
+    hipMemset(buf, 1, (size_t)wgs * 65536 * 8);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     auto launch = [&]() {
-#define L(LD, MM) hipLaunchKernelGGL((k<LD, MM>), dim3(wgs), dim3(64 * waves), waves * 8192, 0, buf, shape, D, iters, nullptr, depth, inter)
+#define L(LD, MM) hipLaunchKernelGGL((k<LD, MM>), dim3(wgs), dim3(64 * waves), waves * 8192, 0, buf, shape, D, iters, nullptr, depth, inter, row_bytes)
         if (use_lds) { if (M == 0) L(1, 0); else if (M == 25) L(1, 25); else L(1, 50); }
         else { if (M == 0) L(0, 0); else if (M == 25) L(0, 25); else L(0, 50); }
     };
@@ -105,7 +106,7 @@ int main(int argc, char** argv) {
     hipEventElapsedTime(&ms, e0, e1);
     ms /= 3;
     const double ns_iter = ms * 1e6 / iters;
-    printf("inter %d depth %d shape %d lds %d  D %2d M %3d waves %d wgs %3d: %7.1f ns / iteration   %6.1f GB/s per CU   %6.1f ns per request and CU   MFMA %5.1f %% of 16-cycle issue at 2.4 GHz\n", inter, depth, shape, use_lds, D, M,
+    printf("pitch %5d inter %d depth %d shape %d lds %d  D %2d M %3d waves %d wgs %3d: %7.1f ns / iteration   %6.1f GB/s per CU   %6.1f ns per request and CU   MFMA %5.1f %% of 16-cycle issue at 2.4 GHz\n", row_bytes, inter, depth, shape, use_lds, D, M,
            waves, wgs, ns_iter, D * waves * 1024.0 / ns_iter, D ? ns_iter / (D * waves) : 0.0, M ? 100.0 * (M * (waves / 4.0) * 16 / 2.4) / ns_iter : 0.0);
     return 0;
 }

@@ -1,15 +1,11 @@
 cd $GRAFT_REPO_ROOT/tools/ubench
-O=../../gpurun_out/dma_mfma3.txt; : > $O
-for sh in 0 2; do
-for w in 4 8; do
-  ./dma_mfma $sh 4 0 2000 $w 256 1 2 0 >> $O
-  ./dma_mfma $sh 0 25 2000 $w 256 1 2 0 >> $O
-  ./dma_mfma $sh 4 25 2000 $w 256 1 2 0 >> $O
-  ./dma_mfma $sh 4 25 2000 $w 256 1 2 1 >> $O
-  ./dma_mfma $sh 4 25 2000 $w 256 1 2 2 >> $O
-  ./dma_mfma $sh 4 50 2000 $w 256 1 2 0 >> $O
-  ./dma_mfma $sh 4 50 2000 $w 256 1 2 1 >> $O
-  ./dma_mfma $sh 4 50 2000 $w 256 1 2 2 >> $O
+O=../../gpurun_out/dma_mfma4.txt; : > $O
+for p in 640 1280 2560 5120 5760 11520 23040 704 1408 2688; do
+  ./dma_mfma 0 4 0 1000 8 256 1 2 0 $p >> $O
 done
+./dma_mfma 2 4 0 1000 8 256 1 2 0 1280 >> $O
+for p in 640 1280 2560 5760 11520; do
+  ./dma_mfma 0 4 25 1000 8 256 1 2 0 $p >> $O
 done
-cat $O | cut -c1-170
+./dma_mfma 2 4 25 1000 8 256 1 2 0 1280 >> $O
+cat $O | cut -c1-150
