@@ -843,8 +843,8 @@ def _decode_arm(tile: int, split_k: int):
     hybrid; ARM_160 (512) is the C-ABI tile 16, the 160 x 320 kernel."""
     if tile == ARM_256:
         return 17, 1
-    if tile == ARM_160B:
-        return 18, 1
+    if ARM_160B <= tile < ARM_160B + 5:                # 544 + log2(split): the same on the tile-major weight copy
+        return 18, 1 << (tile - ARM_160B)
     if ARM_160 <= tile < ARM_160 + 5:                  # 512 + log2(split): the 160 x 320 kernel, split-K 1 / 2 / 4 / 8 / 16
         return 16, 1 << (tile - ARM_160)
     if tile >= 256:
@@ -907,7 +907,7 @@ def split_arms(M: int, N: int, Kd: int):
         arms += [1 + 16 * 3, 9 + 16 * 3]
     if N % 320 == 0:                                    # 160 x 320 tiles with split-K: as many workgroups as CUs, whole rounds
         t160 = ((M + 159) // 160) * (N // 320)
-        arms += [ARM_160 + si for si in (1, 2, 3, 4) if 128 <= t160 * (1 << si) <= 512 and Kd // 32 >= 8 * (1 << si)]
+        arms += [(ARM_160B if W_TILEMAJOR else ARM_160) + si for si in (1, 2, 3, 4) if 128 <= t160 * (1 << si) <= 512 and Kd // 32 >= 8 * (1 << si)]
     return tuple(arms)
 
 
@@ -1332,7 +1332,7 @@ def _f32_arm(key_bf16, tile: int) -> int:
         use -= 256
     elif use >= 128:
         use -= 128
-    return ARM_160 if use == ARM_160B else (use if (1 <= use <= 14 or use == ARM_160) else 0)
+    return ARM_160 if ARM_160B <= use < ARM_160B + 5 else (use if (1 <= use <= 14 or use == ARM_160) else 0)
 
 
 def linear_f32(x: torch.Tensor, weight: torch.Tensor, bias=None, residual=None, alpha: float = 1.0, geglu: bool = False,
@@ -1556,7 +1556,7 @@ def _pick(key, hip_fn, lib_fn, static_hip: bool, extra_arms=(), k320: bool = Fal
             return 0 if not (static_hip or no_lib) else -1          # -1: kernel's own geometry heuristic
         times = ([] if no_lib else [(_time_ms(lib_fn), 0)]) + [(_time_ms(lambda t=t: hip_fn(t)), t) for t in GEMM_TILES + tuple(extra_arms)
                                                                 if (t != 15 or k320)    # (arm 15 exists for the K = 320 token projections only,
-                                                                and (not (ARM_160 <= t < ARM_160 + 5 or t in (ARM_256, ARM_160B)) or n320)]  #  arm 16 for outputs whose width is a multiple of 320)
+                                                                and (not (ARM_160 <= t < ARM_160 + 5 or ARM_160B <= t < ARM_160B + 5 or t == ARM_256) or n320)]  #  arm 16 for outputs whose width is a multiple of 320)
         use = min(times)[1]
         _choice[key] = use
         _tune_log[key] = {arm: round(ms, 4) for ms, arm in times}

@@ -1256,7 +1256,7 @@ def test_gemm_160x320_persistent_form(K):
                 assert_bf16_close(outg, a * F.gelu(g), F.gelu(g).abs() * ma + 1.13 * a.abs() * mg + 1e-3, f"persistent geglu {(M, N, Kd)}")
 
 
-@pytest.mark.parametrize("tile", [513, 514, 515])
+@pytest.mark.parametrize("tile", [513, 514, 515, 545, 546, 547])
 def test_gemm_160x320_split_k(K, tile):
     """Arm 512 + log2(split): the 160 x 320 kernel writes fp32 partial sums of 2 / 4 / 8 k ranges, splitk_reduce_kernel finishes (the
     5x8-level shapes: 32 tiles cannot fill 256 CUs)."""
