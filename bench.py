@@ -780,9 +780,9 @@ def main():
     x_shape = (2,) + tuple(latents.shape[1:])
     parity, cpu, parity_tol = None, None, (4e-2 if dtype == torch.bfloat16 else 1e-3)
     # every step feeds the U-Net cat([latents, latents]) (as the reference pipeline does): the prefix the two halves share runs once
-    unet.cfg_shared_input = not args.no_cfg_shared
+    cfg_shared = not args.no_cfg_shared
     with torch.no_grad():
-        runner = _GraphedUNet(unet, x_shape, text2, pose_feats, traj_feats, dtype)
+        runner = _GraphedUNet(unet, x_shape, text2, pose_feats, traj_feats, dtype, cfg_shared_input=cfg_shared)
         if args.no_graph:
             def unet_step(x, t):
                 kw = {}
@@ -790,7 +790,7 @@ def main():
                     kw["pose_embedding_features"] = pose_feats
                     if cfg == "obj":
                         kw["traj_features"] = traj_feats
-                return unet(x, torch.tensor(int(t), device=device), encoder_hidden_states=text2, **kw).sample
+                return unet(x, torch.tensor(int(t), device=device), encoder_hidden_states=text2, **({'cfg_shared_input': True} if cfg_shared else {}), **kw).sample
         else:
             runner.capture()
             unet_step = runner
@@ -845,7 +845,7 @@ def main():
         roof_proj = measure_proj_roofline(device, dtype) if bf else None
         f_ref = unet_flops(2, HEIGHT // 8, WIDTH // 8, config=cfg)
         f_exec = unet_flops(2, HEIGHT // 8, WIDTH // 8, executed=True, config=cfg)
-        if unet.cfg_shared_input:                       # one clip's worth of conv_in, ResNet block 0, proj_in, QKV, self-attention, out-projection
+        if cfg_shared:                                  # one clip's worth of conv_in, ResNet block 0, proj_in, QKV, self-attention, out-projection
             toks, c0 = FRAMES * (HEIGHT // 8) * (WIDTH // 8), WIDTHS[0]
             f_exec -= 2.0 * toks * (9 * 4 * c0 + 2 * 9 * c0 * c0 + c0 * c0 + 3 * c0 * c0 + c0 * c0) + 4.0 * FRAMES * ((HEIGHT // 8) * (WIDTH // 8)) ** 2 * c0
         ms = elapsed / args.steps * 1e3
@@ -857,7 +857,7 @@ def main():
             "config": {"workload": CONFIGS[cfg]["workload"], "baseline_config": cfg,
                        "frames": FRAMES, "height": HEIGHT, "width": WIDTH, "guidance_scale": args.guidance,
                        "hip_graph": not args.no_graph, "fp8_temporal_attention": args.fp8_temporal,
-                       "cfg_shared_prefix": bool(unet.cfg_shared_input),
+                       "cfg_shared_prefix": bool(cfg_shared),
                        "parallelism": f"dp{world} (independent clips, no collective)"},
             "parity_rel_inf": parity, "parity_gate": parity_tol if parity is not None else None,
             "parity_note": ("max|eps_gpu - eps_oracle| / max|eps_oracle| for one CFG-batch-2 step (t = 801) of the benchmarked "

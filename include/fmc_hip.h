@@ -218,6 +218,12 @@ int fmc_cfg_ddim_step(const void* eps_uc, const float* x, float* x_out, int64_t 
  *   split_k > 1 (epilogue 0 only): the k-tiles of every output tile are dealt to split_k workgroups that write fp32
  *   partial sums to `workspace` (>= split_k * M * N * 4 bytes, 16-byte aligned, caller-owned scratch); a second kernel
  *   sums them in a fixed order and applies the epilogue.  For M*N too small to fill 256 CUs (the 5x8 level).
+ *   split_k == -3 / split_k <= -16 (arms 13 / 14 only; other arms treat it as -1): the K-LOCKSTEP split.  Every tile's reduction is cut into
+ *   S chunks (S = -split_k - 16, or chosen by a cost model for -3); unit (chunk, tile) u runs on workgroup (u mod CUs) of a persistent pass in
+ *   such an order that the CUs of one XCD work on the same k-chunk of the same filter column block at the same time (the weight leaves the
+ *   Infinity Cache once per XCD and round, not once per tile: 775 -> ~90 MB per launch on the 10x16-level convolutions); fp32 partials in
+ *   accumulator layout, one slot per unit (workspace >= 4096 + tiles * S * 256 KiB), summed in chunk order by a bandwidth-shaped finishing
+ *   kernel that applies the plain epilogue (GEGLU: by the 8-phase kernel's own finishing launch).  Deterministic; same workspace as -1.
  *   split_k == -2 (arms 13 / 14 only; other arms treat it as -1): the tiles of the whole rounds (tiles / CUs * CUs of them) run on the
  *   plain grid and only the last partial round goes through the two stream-K launches below -- same workspace, same results as -1.
  *   split_k == -1: stream-K.  (On the 8-phase arms 13 / 14: TWO launches -- a persistent pass, one workgroup per CU, every

@@ -64,6 +64,10 @@ struct GemmParams {
     int sk_whole;                     // 8-phase stream-K: 1 = the persistent pass (ROLE 3) finished the whole tiles itself
     int sk_t0;                        // 8-phase hybrid: tiles [0, sk_t0) (launch order) run on the plain grid, only the rest is stream-K'd
     int sk_hybrid;                    // split_k == -2 was asked for
+    int sk_lock, sk_lock_len;         // split_k == -3, 8-phase kernel: K-LOCKSTEP split -- every tile's reduction is cut into sk_lock chunks of sk_lock_len
+                                      //   k-tiles; unit u = chunk * T + tile (tiles n-outer / m-inner), workgroup b runs units (b & 7) * (sk / 8) + (b >> 3)
+                                      //   + round * sk: the 32 CUs of an XCD work on the SAME k-chunk of (at most two) filter column blocks at the same
+                                      //   time, so a weight byte leaves the Infinity Cache once per XCD and round instead of once per tile
     int64_t a_bytes;                  // 8-phase kernel: size of the A operand in bytes (buffer descriptor range)
     const float* q8_inv;              // EPI 2 (fp8 e4m3 output, three equal column blocks q | k | v): 1 / scale per block (device)
     unsigned* q8_amax;                // EPI 2: running max |value| per block as float bits (device, atomicMax), may be NULL
@@ -817,7 +821,10 @@ void gemm8_kernel(const GemmParams P) {
     constexpr bool SK = ROLE == 1 || ROLE == 3;
     int64_t sk_it = 0, sk_end = 0, sk_gbase = 0, sk_I = 0;
     int sk_r = 0, sk_per = 1, sk_first = 0;
-    if (SK) {
+    int lk_u = 0;                                     // k-lockstep form: my next unit
+    if (SK && P.sk_lock) {
+        lk_u = (int)(blockIdx.x & 7) * (P.sk >> 3) + (int)(blockIdx.x >> 3);
+    } else if (SK) {
         const int T = P.tiles_m * P.tiles_n - P.sk_t0, x = blockIdx.x & 7, q = blockIdx.x >> 3;
         sk_per = P.sk >> 3;
         const int tg0 = (int)((int64_t)T * x / 8), tg1 = (int)((int64_t)T * (x + 1) / 8);
@@ -838,7 +845,17 @@ void gemm8_kernel(const GemmParams P) {
     const int l31 = lane & 31, half = lane >> 5;
     const int prow = lane >> 3, pch = lane & 7;      // my row / 16-byte chunk inside a 1-KiB DMA piece (8 rows x 128 B)
     int tile_m, tile_n, kt0 = 0, nk = nkt, sk_slot = 0;
-    if (SK) {
+    if (SK && P.sk_lock) {
+        const int T = P.tiles_m * P.tiles_n;
+        if (lk_u >= T * P.sk_lock) break;
+        const int c = lk_u / T, t = lk_u - c * T;
+        tile_n = t / P.tiles_m;
+        tile_m = t - tile_n * P.tiles_m;
+        kt0 = c * P.sk_lock_len;
+        nk = min(nkt, kt0 + P.sk_lock_len);
+        sk_slot = lk_u;
+        lk_u += P.sk;
+    } else if (SK) {
         if (sk_it >= sk_end) break;
         const int lin = (int)(sk_it / nkt);
         kt0 = (int)(sk_it - (int64_t)lin * nkt);
@@ -852,7 +869,37 @@ void gemm8_kernel(const GemmParams P) {
         const int id = blockIdx.x, q = total >> 3, r = total & 7, x = id & 7;
         const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);   // XCD x owns a contiguous range
         lin_to_tile(ROLE == 2 ? lin + P.sk_t0 : lin, P, tile_m, tile_n);
-        if (ROLE == 2) {
+        if (ROLE == 2 && P.sk_lock) {                 // k-lockstep pass: chunk c of tile t left its accumulators in slot c * T + t
+#pragma unroll
+            for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                for (int b2 = 0; b2 < 4; ++b2)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[a2][b2][e] = 0.f;
+            const int T = P.tiles_m * P.tiles_n, t = tile_n * P.tiles_m + tile_m;
+#pragma unroll 1
+            for (int c = 0; c < P.sk_lock; ++c) {
+                const int slot = c * T + t;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) {
+                        u32x4 t4[4];
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            const int quad = (wave * 8 + ni * 4 + mi) * 4 + gq;
+                            t4[gq] = __builtin_amdgcn_raw_buffer_load_b128(rsP, (int)(((int64_t)slot * (BM * BN / 4) + quad * 64 + lane) * 16), 0, 0);
+                        }
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            union { u32x4 u; f32x4 f; } cv;
+                            cv.u = t4[gq];
+                            acc[ni][mi][4 * gq] += cv.f[0]; acc[ni][mi][4 * gq + 1] += cv.f[1];
+                            acc[ni][mi][4 * gq + 2] += cv.f[2]; acc[ni][mi][4 * gq + 3] += cv.f[3];
+                        }
+                    }
+            }
+        } else if (ROLE == 2) {
             // the segments of ROLE 1 that cover tile `lin`: XCD group g holds tiles [T g / 8, T (g + 1) / 8); inside it range r of
             // `per` covers iterations [I r / per, I (r + 1) / per) and was run by block (per - 1 - r) * 8 + g
             const int T = total, per = P.sk >> 3;
@@ -2263,6 +2310,58 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams P) 
     Vec8<bf16_t>::store(P.out + m * P.ldo + n, v);
 }
 
+// finishing pass of the k-lockstep split (split_k == -3 / <= -16) on the 8-phase kernel: out = epilogue(sum over the sk_lock chunk slots of a tile).
+// The slots are in ACCUMULATOR layout (gemm8_kernel: slot[wave][ni * 4 + mi][gq][lane] x 16 B); a 256-thread block owns one 32 x 32 block (wave, ni, mi) of
+// one tile, thread = (l31, gq, half) with (gq, half) fastest: a wave's 16-byte loads cover eight whole 128-byte lines of every slot, its 8-byte stores
+// eight 64-byte row segments.  One launch of tiles x 64 small blocks instead of one 512-thread workgroup per tile (100 of 256 CUs on the 10x16-level
+// convolutions, each walking 1.3 MB of partials on its own): the pass is a plain bandwidth kernel.  Summation order: chunk 0, 1, ... (fixed).
+template <int MODE>
+__global__ __launch_bounds__(256) void sk_finish_kernel(const GemmParams P) {
+    const int blk = blockIdx.x & 63, t = blockIdx.x >> 6;
+    const int T = P.tiles_m * P.tiles_n;
+    const int tile_n = t / P.tiles_m, tile_m = t - tile_n * P.tiles_m;
+    const int wave = blk >> 3, ni = (blk >> 2) & 1, mi = blk & 3;
+    const int tid = threadIdx.x, half = tid & 1, gq = (tid >> 1) & 3, l31 = tid >> 3;
+    const int quad = (wave * 8 + ni * 4 + mi) * 4 + gq;
+    const float* src = P.ws + ((int64_t)t * (256 * 256 / 4) + quad * 64 + half * 32 + l31) * 4;
+    const int64_t cstride = (int64_t)T * 256 * 256;
+    f32x4 v = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll 4
+    for (int c = 1; c < P.sk_lock; ++c) v += *reinterpret_cast<const f32x4*>(src + c * cstride);
+    const int64_t m = (int64_t)tile_m * 256 + (wave >> 2) * 128 + mi * 32 + l31;
+    const int n = tile_n * 256 + (wave & 3) * 64 + ni * 32 + 8 * gq + 4 * half;
+    if (m >= P.M || n >= P.N) return;
+    auto up4 = [](const bf16_t* p, float (&o)[4]) {
+        const u32x2 w = *reinterpret_cast<const u32x2*>(p);
+        o[0] = __uint_as_float(w[0] << 16); o[1] = __uint_as_float(w[0] & 0xffff0000u);
+        o[2] = __uint_as_float(w[1] << 16); o[3] = __uint_as_float(w[1] & 0xffff0000u);
+    };
+    float o[4] = {v[0], v[1], v[2], v[3]}, a[4];
+    if (P.bias) {
+        up4(P.bias + n, a);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] += a[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] *= P.alpha;
+    if (MODE == 1 && P.temb) {
+        up4(P.temb + ((m / P.hw) / P.temb_div) * P.temb_ld + n, a);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] += a[j];
+    }
+    if (P.res) {
+        up4(P.res + m * P.ldres + n, a);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] += a[j];
+        if (P.res2) {
+            up4(P.res2 + m * P.ldres + n, a);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += a[j];
+        }
+    }
+    *reinterpret_cast<u32x2*>(P.out + m * P.ldo + n) = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+}
+
 template <int MODE, int EPI, int WM, int WN, int MI, int BK, int STAGES, bool SK>
 void launch_gemm_k(GemmParams& P, unsigned grid, size_t lds, hipStream_t st) {
     static size_t raised = 0;                            // (the LDS size of one instantiation depends on the epilogue variant)
@@ -2364,7 +2463,7 @@ void launch_gemm8(GemmParams& P, hipStream_t st) {
     }
     const int tiles = P.tiles_m * P.tiles_n;
     P.sk_t0 = 0;
-    if (P.sk && P.sk_hybrid) {
+    if (P.sk && P.sk_hybrid && !P.sk_lock) {
         // hybrid: the whole rounds on the plain grid, only the last partial round through stream-K -- the partial traffic (2 x 256 KiB per
         // segment) and the finishing launch then cover tiles % CUs tiles instead of all of them
         const int g = fmc_cu_count() & ~7;
@@ -2383,6 +2482,35 @@ void launch_gemm8(GemmParams& P, hipStream_t st) {
             return;
         }
         if (rem == 0) P.sk = 0;                           // whole rounds only: the plain grid (else: fewer tiles than CUs -> full stream-K below)
+    }
+    if (P.sk && P.sk_lock) {
+        // k-lockstep split: S chunks per tile, unit = (chunk, tile); S = the caller's (split_k <= -16) or the cheapest by a small model:
+        // rounds x (chunk length x 1.9 us per 64-deep k-tile + 4 us of prologue / partial store) + 0.06 us of finishing traffic per unit
+        // (constants fitted to tools/r04/probe_lock.py: profiles/r04_probe_lock.txt)
+        const int g = fmc_cu_count() & ~7, nkt = P.K / 64;
+        int S = P.sk_lock > 1 ? P.sk_lock : 0;
+        if (!S) {
+            double best = 1e30;
+            for (int s2 = 2; s2 <= 16 && s2 <= nkt / 4; ++s2) {
+                const int L = (nkt + s2 - 1) / s2;
+                if ((s2 - 1) * L >= nkt) continue;
+                const int rounds = (tiles * s2 + g - 1) / (g > 0 ? g : 1);
+                const double cost = rounds * (L * 1.9 + 4.0) + tiles * s2 * 0.06;
+                if (cost < best) { best = cost; S = s2; }
+            }
+        }
+        const int L = S ? (nkt + S - 1) / S : 0;
+        const int64_t need = (int64_t)tiles * S * 256 * 256 * (int64_t)sizeof(float) + 4096;
+        if (g >= 8 && S >= 2 && (S - 1) * L < nkt && P.sk_ws_bytes >= need && need < ((int64_t)1 << 31)) {
+            P.sk = g;
+            P.sk_lock = S;
+            P.sk_lock_len = L;
+            hipLaunchKernelGGL((gemm8_kernel<MODE, EPI, PF, 1>), dim3((unsigned)g), dim3(512), lds, st, P);
+            if constexpr (EPI == 0) hipLaunchKernelGGL((sk_finish_kernel<MODE>), dim3((unsigned)tiles * 64), dim3(256), 0, st, P);
+            else hipLaunchKernelGGL((gemm8_kernel<MODE, EPI, PF, 2>), dim3((unsigned)tiles), dim3(512), lds, st, P);
+            return;
+        }
+        P.sk_lock = 0;                                    // too little work / workspace: plain stream-K rules below
     }
     if (P.sk) {
         // stream-K = persistent main kernel (one 128-KiB workgroup per CU, partials only) + one finishing workgroup per tile
@@ -2795,7 +2923,10 @@ int set_split_k(GemmParams& P, int split_k, void* workspace, int64_t workspace_b
     P.sk_flags = nullptr;
     P.sk_ws_bytes = 0;
     P.sk_hybrid = split_k == -2;
-    if (split_k == -1 || split_k == -2) {                // stream-K: [4096 B of flags (zero on entry and on return) | partials]
+    P.sk_lock = split_k == -3 ? 1 : (split_k <= -16 ? -split_k - 16 : 0);      // k-lockstep split on the 8-phase arms (other arms: plain stream-K)
+    P.sk_lock_len = 0;
+    if (split_k <= -16 && (P.sk_lock < 2 || P.sk_lock > 64)) FMC_FAIL(FMC_E_SHAPE, "%s: split_k %d (k-lockstep chunks = -split_k - 16 in 2..64)", who, split_k);
+    if (split_k == -1 || split_k == -2 || split_k == -3 || split_k <= -16) {                // stream-K: [4096 B of flags (zero on entry and on return) | partials]
         if (!workspace || !fmc_aligned16(workspace) || workspace_bytes < 8192)
             FMC_FAIL(FMC_E_NULL, "%s: stream-K needs a 16-byte aligned, zero-initialised workspace", who);
         P.sk = 1;

@@ -847,6 +847,8 @@ def _decode_arm(tile: int, split_k: int):
         return 18, 1 << (tile - ARM_160B)
     if ARM_160 <= tile < ARM_160 + 5:                  # 512 + log2(split): the 160 x 320 kernel, split-K 1 / 2 / 4 / 8 / 16
         return 16, 1 << (tile - ARM_160)
+    if tile >= 384:
+        return tile - 384, -3                           # k-lockstep split on the 8-phase arms (round 4): chunks of every tile's reduction, an XCD's CUs on the same chunk
     if tile >= 256:
         return tile - 256, -2                           # whole rounds on the plain grid, the last partial round stream-K (8-phase arms)
     if tile >= 128:
@@ -889,7 +891,7 @@ def release_streamk_workspace(stream) -> None:
 
 
 def _splitk_workspace(device, split_k: int, M: int, N: int):
-    if split_k in (-1, -2):
+    if split_k < 0:                                     # -1 / -2 / -3 / <= -16: the stream-K forms
         return _streamk_workspace(device)
     if split_k <= 1:
         return None, 0
@@ -1327,12 +1329,24 @@ def _f32_arm(key_bf16, tile: int) -> int:
     code is the timed code); stream-K forms map to their plain geometry, the vendor arm / arm 15 to the kernel's own rule."""
     if tile:
         return tile
-    use = _choice.get(key_bf16, 0)
-    if use >= 256:
+    return _f32_arm_of(_choice.get(key_bf16, 0))
+
+
+def _f32_arm_of(use: int) -> int:
+    """bf16 autotune arm id -> the arm parity mode runs.  The 160 x 320 family (512.. / 544.., with or without split-K; 528 = its 256-row GEGLU
+    form) maps to ARM_160 -- the same kernel on the row-major split-bf16 weight -- BEFORE the stream-K offsets are peeled (all of them are >= 256);
+    128+ / 256+ / 384+ stream-K forms map to their plain geometry."""
+    if ARM_160 <= use < ARM_160 + 5 or ARM_160B <= use < ARM_160B + 5 or use == ARM_256:
+        return ARM_160
+    if use >= 384:
+        use -= 384
+    elif use >= 256:
         use -= 256
     elif use >= 128:
         use -= 128
-    return ARM_160 if ARM_160B <= use < ARM_160B + 5 else (use if (1 <= use <= 14 or use == ARM_160) else 0)
+    if 16 <= use < 128:                                 # split-K ids (geometry + 16 log2(split)): the geometry
+        use &= 15
+    return use if 1 <= use <= 14 else 0
 
 
 def linear_f32(x: torch.Tensor, weight: torch.Tensor, bias=None, residual=None, alpha: float = 1.0, geglu: bool = False,
@@ -1496,7 +1510,8 @@ GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 11,     # 8..10, 12 (4-stage rings) exist but
                                              # pre-packed tile-major (bit-identical to ARM_160, -1 .. -5 % per launch: tools/probe_wtm.py)
               128 + 2, 128 + 3,              # stream-K (persistent workgroups) on the two 1-per-CU geometries
               128 + 13,                      # stream-K on the 8-phase kernel: persistent partial pass + one finishing workgroup per tile
-              256 + 13)                      # the same for the LAST PARTIAL ROUND of tiles only, the whole rounds on the plain grid
+              256 + 13,                      # the same for the LAST PARTIAL ROUND of tiles only, the whole rounds on the plain grid
+              384 + 13)                      # k-lockstep split on the 8-phase kernel (round 4): the filter is read once per XCD, lean finishing pass
 if os.environ.get("FMC_GEMM_ARMS"):              # A/B switch: the arm list the autotuner may choose from, e.g. "1,2,3,11"
     GEMM_TILES = tuple(int(a) for a in os.environ["FMC_GEMM_ARMS"].split(","))
 # fmc_linear_bf16 / fmc_conv3x3_bf16 `tile` arms tried per shape (14 = arm 13 with a deeper prefetch measured no better anywhere,

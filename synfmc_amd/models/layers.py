@@ -627,7 +627,7 @@ class Transformer2DModel(nn.Module):
                 cross_attention_kwargs=None, attention_mask=None, encoder_attention_mask=None,
                 return_dict: bool = True, cfg_expand: bool = False):
         """`cfg_expand`: `hidden_states` holds ONE copy of the two identical halves of a classifier-free-guidance batch; everything
-        up to and including the self-attention runs once, the output covers both halves (see UNet3DConditionModel.cfg_shared_input)."""
+        up to and including the self-attention runs once, the output covers both halves (see the `cfg_shared_input` keyword of UNet3DConditionModel.forward)."""
         n, c, h, w = hidden_states.shape
         residual = to_tokens(hidden_states)
         if NORM_SKIP and torch.is_grad_enabled() and residual.requires_grad and residual.is_cuda:

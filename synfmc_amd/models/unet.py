@@ -297,7 +297,7 @@ class UNet3DConditionModel(nn.Module):
         return self.time_embedding(self.time_proj(timesteps).to(dtype=self.dtype))
 
     def _run(self, sample, timestep, encoder_hidden_states, attention_mask, cross_attention_kwargs,
-             pose_embedding_features, traj_features, use_pose, return_dict):
+             pose_embedding_features, traj_features, use_pose, return_dict, cfg_shared_input: bool = False):
         if attention_mask is not None:
             raise NotImplementedError("attention masks are never passed on the FMC path")
         if use_pose and cross_attention_kwargs is not None:
@@ -313,10 +313,12 @@ class UNet3DConditionModel(nn.Module):
         try:
             return self._run_blocks(sample, emb, encoder_hidden_states, attention_mask, cross_attention_kwargs,
                                     pose_embedding_features, traj_features, use_pose, return_dict, upsample_size,
-                                    forward_upsample_size)
+                                    forward_upsample_size, bool(cfg_shared_input))
         finally:
             for r in self._resnets_with_temb():
                 r._t_pre = None
+            if len(self.down_blocks):                    # (the one-shot hint of `_run_blocks`; normally consumed by the block -- not after an exception)
+                self.down_blocks[0].__dict__.pop("_cfg_half_input", None)
 
     def _resnets_with_temb(self):
         rs = getattr(self, "_temb_resnets", None)
@@ -350,17 +352,19 @@ class UNet3DConditionModel(nn.Module):
 
     def _run_blocks(self, sample, emb, encoder_hidden_states, attention_mask, cross_attention_kwargs,
                     pose_embedding_features, traj_features, use_pose, return_dict, upsample_size,
-                    forward_upsample_size):
+                    forward_upsample_size, cfg_shared_input: bool = False):
         if sample.dtype != self.dtype:
             sample = sample.to(self.dtype)
         if encoder_hidden_states.dtype != self.dtype:
             encoder_hidden_states = encoder_hidden_states.to(self.dtype)
         # text stays [B, 77, C]: the cross-attention kernel shares it across the F frames of a clip
-        # Shared classifier-free-guidance prefix (`cfg_shared_input`, set by the pipelines, which build the batch as `cat([latents] * 2)`,
+        # Shared classifier-free-guidance prefix (`cfg_shared_input=True`, a PER-CALL keyword of `forward` passed by the pipelines, which build the batch as `cat([latents] * 2)`,
         # pipeline_animation_cm_om.py:704): until the first text cross-attention the two halves of the batch are the same numbers through
         # the same layers (same timestep, same camera features), so conv_in, the first ResNet block and the first self-attention run
         # ONCE on one half and their outputs are duplicated -- identical results, 0.5 ms less per 16x320x512 step.
-        shared = (getattr(self, "cfg_shared_input", False) and not torch.is_grad_enabled() and sample.shape[0] % 2 == 0
+        # The caller vouches that the two halves of `sample` (and of the timestep / camera features) are identical; nothing sticky is kept on the
+        # module: a call without the keyword always takes the plain path.
+        shared = (cfg_shared_input and not torch.is_grad_enabled() and sample.shape[0] % 2 == 0
                   and len(self.down_blocks[0].resnets) > 0)
         if shared:
             sample = sample[: sample.shape[0] // 2]
@@ -420,14 +424,16 @@ class UNet3DConditionModel(nn.Module):
         return UNet3DConditionOutput(sample=sample)
 
     _pass_traj_none = False
+    _accepts_cfg_shared_input = True     # `forward(..., cfg_shared_input=True)`: see `_run_blocks`
 
     def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, attention_mask=None,
                 cross_attention_kwargs=None, return_dict: bool = True, down_block_additional_residuals=None,
-                mid_block_additional_residual=None, motion_module_alphas=1.0, debug: bool = False):
+                mid_block_additional_residual=None, motion_module_alphas=1.0, debug: bool = False,
+                cfg_shared_input: bool = False):
         if down_block_additional_residuals is not None or mid_block_additional_residual is not None:
             raise NotImplementedError("ControlNet residuals are unused by FMC")
         return self._run(sample, timestep, encoder_hidden_states, attention_mask, cross_attention_kwargs, None, None,
-                         False, return_dict)
+                         False, return_dict, cfg_shared_input)
 
 
 class UNet3DConditionModelPoseCond(UNet3DConditionModel):
@@ -485,11 +491,11 @@ class UNet3DConditionModelPoseCond(UNet3DConditionModel):
     def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, attention_mask=None,
                 cross_attention_kwargs=None, pose_embedding_features: List[torch.Tensor] = None,
                 return_dict: bool = True, down_block_additional_residuals=None, mid_block_additional_residual=None,
-                motion_module_alphas=1.0, debug: bool = False):
+                motion_module_alphas=1.0, debug: bool = False, cfg_shared_input: bool = False):
         if down_block_additional_residuals is not None or mid_block_additional_residual is not None:
             raise NotImplementedError("ControlNet residuals are unused by FMC")
         return self._run(sample, timestep, encoder_hidden_states, attention_mask, cross_attention_kwargs,
-                         pose_embedding_features, None, pose_embedding_features is not None, return_dict)
+                         pose_embedding_features, None, pose_embedding_features is not None, return_dict, cfg_shared_input)
 
 
 class UNet3DConditionModelCamObjCond(UNet3DConditionModelPoseCond):
@@ -504,10 +510,10 @@ class UNet3DConditionModelCamObjCond(UNet3DConditionModelPoseCond):
                 cross_attention_kwargs=None, pose_embedding_features: List[torch.Tensor] = None,
                 traj_features: List[torch.Tensor] = None, return_dict: bool = True,
                 down_block_additional_residuals=None, mid_block_additional_residual=None, motion_module_alphas=1.0,
-                debug: bool = False):
+                debug: bool = False, cfg_shared_input: bool = False):
         if down_block_additional_residuals is not None or mid_block_additional_residual is not None:
             raise NotImplementedError("ControlNet residuals are unused by FMC")
         if pose_embedding_features is None:
             raise TypeError("pose_embedding_features is required (the reference zips over it, unet_cam_obj.py:1211)")
         return self._run(sample, timestep, encoder_hidden_states, attention_mask, cross_attention_kwargs,
-                         pose_embedding_features, traj_features, True, return_dict)
+                         pose_embedding_features, traj_features, True, return_dict, cfg_shared_input)

@@ -40,8 +40,9 @@ class _GraphedUNet:
     """Captures `unet(x, t, text[, pose_feats, traj])` into a HIP graph whose inputs are static buffers owned here;
     `set_conditioning` refills them for a new clip, `__call__` replays with new latents / timestep."""
 
-    def __init__(self, unet, latents_shape, text, pose_feats, traj_feats, dtype):
+    def __init__(self, unet, latents_shape, text, pose_feats, traj_feats, dtype, cfg_shared_input: bool = False):
         self.unet = unet
+        self.cfg_shared_input = bool(cfg_shared_input)      # the caller feeds `cat([latents] * 2)`: the U-Net may compute the shared prefix once
         dev = text.device
         self.x = torch.zeros(latents_shape, dtype=dtype, device=dev)
         self.t = torch.zeros((), dtype=torch.int64, device=dev)
@@ -59,6 +60,8 @@ class _GraphedUNet:
             kw = dict(pose_embedding_features=self.pose)
             if self.traj is not None or getattr(self.unet, "_pass_traj_none", False):   # (the CMC-only model takes no traj_features)
                 kw["traj_features"] = self.traj
+        if self.cfg_shared_input:
+            kw["cfg_shared_input"] = True
         return self.unet(self.x, self.t, encoder_hidden_states=self.text, **kw).sample
 
     def capture(self):
@@ -215,8 +218,9 @@ class AnimationPipeline:
         self.check_inputs(prompt, height, width, callback_steps)
         do_cfg = guidance_scale > 1.0
         # the loops below feed the U-Net `cat([latents] * 2)` under classifier-free guidance: its two halves are identical until the
-        # first text cross-attention, and the U-Net may compute that prefix once (UNet3DConditionModel.cfg_shared_input; FMC_CFG_SHARED=0: A/B)
-        unet.cfg_shared_input = bool(do_cfg) and os.environ.get("FMC_CFG_SHARED", "1") != "0"
+        # first text cross-attention, and the U-Net may compute that prefix once (the `cfg_shared_input` keyword of its forward, passed per call:
+        # nothing sticky on the module; FMC_CFG_SHARED=0: A/B)
+        self._cfg_shared = bool(do_cfg) and os.environ.get("FMC_CFG_SHARED", "1") != "0"
         batch_size = 1
         if latents is not None:
             batch_size = latents.shape[0]
@@ -233,6 +237,8 @@ class AnimationPipeline:
     def _runner(self, x_shape, text, pose_feats, traj, use_graph):
         """The U-Net step as a callable `(x, t) -> eps`: a cached HIP graph (refilled with this clip's conditioning) or eager."""
         unet = self.unet
+        shared = bool(getattr(self, "_cfg_shared", False)) and getattr(unet, "_accepts_cfg_shared_input", False)   # (a foreign U-Net never sees the keyword)
+        skw = {"cfg_shared_input": True} if shared else {}
         if not use_graph:
             def eager(x, t):
                 kw = {}
@@ -240,15 +246,15 @@ class AnimationPipeline:
                     kw["pose_embedding_features"] = pose_feats
                     if traj is not None or getattr(unet, "_pass_traj_none", False):    # (UNet3DConditionModelPoseCond takes no traj_features)
                         kw["traj_features"] = traj
-                return unet(x, torch.tensor(int(t), device=x.device), encoder_hidden_states=text, **kw).sample
+                return unet(x, torch.tensor(int(t), device=x.device), encoder_hidden_states=text, **skw, **kw).sample
             return eager
         key = (tuple(x_shape), tuple(text.shape), unet.dtype, pose_feats is not None, traj is not None,
-               bool(getattr(unet, "cfg_shared_input", False)), _weights_version(unet))
+               shared, _weights_version(unet))
         r = self._runners.get(key)
         if r is None:
             for k in [k for k in self._runners if k[:-1] == key[:-1]]:      # same shapes, stale weights: drop the graph
                 del self._runners[k]
-            r = _GraphedUNet(unet, x_shape, text, pose_feats, traj, unet.dtype)
+            r = _GraphedUNet(unet, x_shape, text, pose_feats, traj, unet.dtype, cfg_shared_input=shared)
             r.capture()
             self._runners[key] = r
         else:
@@ -256,7 +262,6 @@ class AnimationPipeline:
         return r
 
     def _finish(self, latents, output_type, return_dict):
-        self.unet.cfg_shared_input = False                 # (a direct `unet(...)` call by the user gets the plain path)
         if output_type == "latent":
             video = latents
         else:

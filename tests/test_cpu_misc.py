@@ -435,3 +435,17 @@ def test_bench_entry_spawns_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True,
                          text=True, env=dict(env, WORLD_SIZE="3", RANK="0"), timeout=120, cwd="/tmp")
     assert bad.returncode != 0 and "WORLD_SIZE=3" in (bad.stderr + bad.stdout)
+
+
+def test_parity_mode_arm_decoding_reaches_the_160x320_kernels():
+    """`_f32_arm` peeled the stream-K offsets (>= 256) before it looked for the 160 x 320 family (512.. / 528 / 544..), so fp32
+    parity mode never ran the kernels the bf16 path autotunes to.  The family (any split) maps to ARM_160; stream-K / hybrid / k-lockstep forms
+    map to their plain geometry; split-K ids to their geometry; the vendor arm and arm 15 to the kernel's own rule (0)."""
+    from synfmc_amd import hip_ops as K
+    for arm in list(range(K.ARM_160, K.ARM_160 + 5)) + list(range(K.ARM_160B, K.ARM_160B + 5)) + [K.ARM_256]:
+        assert K._f32_arm_of(arm) == K.ARM_160, arm
+    assert K._f32_arm_of(128 + 13) == 13 and K._f32_arm_of(256 + 13) == 13 and K._f32_arm_of(384 + 13) == 13 and K._f32_arm_of(128 + 3) == 3
+    assert K._f32_arm_of(2 + 16 * 2) == 2 and K._f32_arm_of(9 + 16) == 9
+    assert K._f32_arm_of(0) == 0 and K._f32_arm_of(15) == 0 and K._f32_arm_of(11) == 11
+    # what the decoder hands the C ABI for the arms of this round
+    assert K._decode_arm(384 + 13, 1) == (13, -3) and K._decode_arm(256 + 13, 1) == (13, -2) and K._decode_arm(K.ARM_160B + 2, 1) == (18, 4)

@@ -723,7 +723,7 @@ def test_gemm_k320_weight_stationary_arm(K):
     assert rel_inf(K.linear_bf16(xd6, wd6, None, None, 1.0, tile=15).float(), F.linear(xo6, wo6)) < 1e-2           # K != 320
 
 
-@pytest.mark.parametrize("tile", [13, 14, 128 + 13, 128 + 14, 256 + 13])
+@pytest.mark.parametrize("tile", [13, 14, 128 + 13, 128 + 14, 256 + 13, 384 + 13])
 def test_gemm_8phase_arms(K, tile):
     """The 8-phase 256x256 kernel (staggered wave rows, half-tile DMA with counted vmcnt): ragged M / N (partial tiles),
     K from one k-tile up, every epilogue (bias, alpha, one / two residuals, GEGLU, two-source A operand), the conv loader
@@ -802,6 +802,55 @@ def test_gemm_8phase_arms(K, tile):
             assert torch.equal(got, K.linear_bf16(xd, wd, None, rd, 1.0, tile=tile))                          # deterministic
         ws = K._sk_ws[(torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)]
         assert int(ws[:1024].view(torch.int32).abs().sum()) == 0
+
+
+@pytest.mark.parametrize("chunks", [2, 3, 5, 7, 16])
+def test_gemm_8phase_k_lockstep_split(K, chunks):
+    """`split_k = -(16 + S)` on the 8-phase kernel: every tile's reduction cut into S chunks, unit (chunk, tile) -> workgroup so that the CUs of an
+    XCD work on the same k-chunk (the filter leaves the Infinity Cache once per XCD), fp32 partials in accumulator layout, `sk_finish_kernel`
+    sums them in chunk order and applies the epilogue.  Ragged M / N, chunk lengths that do not divide K / 64 (the last chunk is shorter), more
+    units than CUs (several rounds), bias / alpha / temb / one and two residuals, conv loader (plain, upsample, stride 2), the GEGLU form (finished
+    by the 8-phase kernel's own epilogue), determinism, repeated launches on fresh data."""
+    dtype = torch.bfloat16
+    sk = -(16 + chunks)
+    for (M, N, Kd) in [(4100, 1032, 1280), (1280, 1280, 5120), (700, 320, 1088), (5120, 1280, 2304)]:
+        wo, wd = rnd((N, Kd), 45, dtype, scale=Kd ** -0.5)
+        bo, bd = rnd((N,), 46, dtype)
+        for it in range(3):
+            xo, xd = rnd((M, Kd), 200 + it, dtype)
+            ro, rd = rnd((M, N), 300 + it, dtype)
+            r2o, r2d = rnd((M, N), 400 + it, dtype)
+            got = K.linear_bf16(xd, wd, bd, rd, 0.5, tile=13, split_k=sk)
+            assert rel_inf(got.float(), 0.5 * F.linear(xo, wo, bo) + ro) < 1e-2, (M, N, Kd, it)
+            assert rel_inf(got.float(), K.linear_bf16(xd, wd, bd, rd, 0.5, tile=13).float()) < 8e-3
+            if it == 0:
+                assert torch.equal(got, K.linear_bf16(xd, wd, bd, rd, 0.5, tile=13, split_k=sk))                   # deterministic
+                got2 = K.linear_bf16(xd, wd, None, rd, 1.0, tile=13, split_k=sk, residual2=r2d)
+                assert rel_inf(got2.float(), F.linear(xo, wo) + ro + r2o) < 1e-2
+                assert rel_inf(K.linear_bf16(xd, wd, None, None, 1.0, tile=13, split_k=sk).float(), F.linear(xo, wo)) < 1e-2
+    from synfmc_amd.models.layers import interleave_geglu
+    go, gd = rnd((2048, 1280), 42, dtype, scale=1280 ** -0.5)
+    gbo, gbd = rnd((2048,), 40, dtype)
+    xo, xd = rnd((1100, 1280), 41, dtype)
+    wi, bi = interleave_geglu(gd, gbd)
+    a, g = F.linear(xo, go, gbo).chunk(2, dim=-1)
+    assert rel_inf(K.linear_bf16(xd, wi, bi, geglu=True, tile=13, split_k=sk).float(), a * F.gelu(g)) < 1e-2
+    # conv loader: the 5x8 / 10x16-level shapes the arm is for (reduced image count), temb + residual, upsample, stride 2
+    for (n, h, w, cin, cout) in [(4, 5, 8, 1280, 1280), (2, 10, 16, 640, 1288), (3, 10, 16, 1920, 328)]:
+        co, cd = rnd((n, cin, h, w), 47, dtype)
+        fo, fd = rnd((cout, cin, 3, 3), 44, dtype, scale=(9 * cin) ** -0.5)
+        bo, bd = rnd((cout,), 49, dtype)
+        to, td = rnd((n, cout), 43, dtype)
+        ro, rd = rnd((n, cout, h, w), 48, dtype)
+        x_nhwc, f_cl = cd.permute(0, 2, 3, 1).contiguous(), fd.contiguous(memory_format=torch.channels_last)
+        refc = F.conv2d(co, fo, bo, 1, 1)
+        outc = K.conv3x3_bf16(x_nhwc, f_cl, bd, td, rd.permute(0, 2, 3, 1).contiguous(), tile=13, split_k=sk)
+        assert rel_inf(outc.permute(0, 3, 1, 2).float(), refc + to[:, :, None, None] + ro) < 1e-2, (n, h, w, cin, cout)
+        outu = K.conv3x3_bf16(x_nhwc, f_cl, None, None, None, tile=13, split_k=sk, upsample=True)
+        assert rel_inf(outu.permute(0, 3, 1, 2).float(), F.conv2d(F.interpolate(co, scale_factor=2.0, mode="nearest"), fo, None, 1, 1)) < 1e-2
+        if h % 2 == 0:
+            outs = K.conv3x3_bf16(x_nhwc, f_cl, None, None, None, tile=13, split_k=sk, stride2=True)
+            assert rel_inf(outs.permute(0, 3, 1, 2).float(), F.conv2d(co, fo, None, 2, 1)) < 1e-2
 
 
 @pytest.mark.parametrize("n,H,W,cin,cout", [(4, 12, 20, 64, 128), (16, 4, 6, 320, 320), (2, 32, 48, 320, 64), (3, 7, 9, 128, 72)])

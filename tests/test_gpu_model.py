@@ -453,7 +453,7 @@ def test_fp8_temporal_attention_frames32_forward_and_training():
 
 
 def test_cfg_shared_prefix_equals_the_plain_path(stack):
-    """`unet.cfg_shared_input`: with the two halves of the batch identical (the pipelines' `cat([latents] * 2)`), computing conv_in, the
+    """`unet(..., cfg_shared_input=True)`: with the two halves of the batch identical (the pipelines' `cat([latents] * 2)`), computing conv_in, the
     first ResNet block and the first self-attention once and duplicating gives the plain path's output -- fp32 to round-off, bf16 to the
     arm-dependent summation order of two differently shaped launches."""
     clip = stack["clip"]
@@ -467,9 +467,11 @@ def test_cfg_shared_prefix_equals_the_plain_path(stack):
         traj = [dev(t) for t in stack["traj"]]                                  # conditioned half only: feature_add skips the first
         with torch.no_grad():
             plain = pu(x2, torch.tensor(801, device="cuda"), dev(text2), pose_embedding_features=pose2, traj_features=traj).sample
-            pu.cfg_shared_input = True
-            shared = pu(x2, torch.tensor(801, device="cuda"), dev(text2), pose_embedding_features=pose2, traj_features=traj).sample
-            pu.cfg_shared_input = False
+            shared = pu(x2, torch.tensor(801, device="cuda"), dev(text2), pose_embedding_features=pose2, traj_features=traj,
+                        cfg_shared_input=True).sample
+            again = pu(x2, torch.tensor(801, device="cuda"), dev(text2), pose_embedding_features=pose2, traj_features=traj).sample
+            assert torch.equal(again, plain)                                    # the hint is per call: nothing sticky stays on the module
+            assert "_cfg_half_input" not in pu.down_blocks[0].__dict__
         assert shared.shape == plain.shape and rel_inf(shared, plain) < tol
         assert rel_inf(plain[0], plain[1]) > 1e-3                               # (the halves do differ downstream)
 

@@ -1,0 +1,14 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04a; mkdir -p $O
+export FMC_AUTOTUNE_CACHE=$PWD/$O/autotune_cache.json
+timeout 900 python bench.py --autotune-log $O/autotune.log > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -c 1500 $O/bench.json
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format csv -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $O/trace.log 2>&1
+T=$(find $O/trace -name "*kernel_trace.csv" | head -1)
+python tools/summarize_trace.py $T > $O/kernel_summary.md 2>&1
+python -c "
+import sys; sys.path.insert(0,'tools')
+import summarize_trace as s
+s.by_grid('$T')" > $O/by_grid.md 2>&1
+cp $(find $O/trace -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
+find $O/trace -name "*.csv" -size +1M -delete
+head -22 $O/kernel_summary.md | cut -c1-160
