@@ -417,6 +417,31 @@ int fmc_temporal_attn_fp8_bwd(const void* q, const void* k, const void* v, const
 int fmc_nhwc_to_cmajor_padded(const void* src, void* dst, int n_img, int H, int W, int C, int64_t row_len, int guard,
                               int shifts, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * The fused temporal attention block of the motion modules at the 40x64 level (round 4; csrc/temporal_block.hip).
+ * Replaces, for one attention block of `TemporalTransformerBlock.forward` (fmc/models/motion_module.py:287-300) as driven by
+ * `TemporalSelfAttention.forward` (:349-389) and `PoseAdaptorAttnProcessor.forward` / `AttnProcessor.__call__`
+ * (fmc/models/attention_processor.py:202-293 / :20-82):
+ *     n = LayerNorm(h) + pe[frame];   m = merge_scale * (n W_m^T) + pose_term + n   (only with w_merge_tm);   q | k | v = m W_qkv^T;
+ *     o = softmax(q k^T * scale) v per (pixel, head) over the frames;   out = o W_out^T + b_out + h
+ * in ONE launch: a 160-row tile (10 pixels x 16 frames) stays in LDS from h to out, q / k / v / scores / o live in registers.
+ *   h, out, pose_term: bf16 [n_clips, frames, hw, channels] (channels-last video tokens; out may not alias h);
+ *   ln_gamma fp32 [C]; ln_bpe fp32 [frames][C] = LayerNorm beta + positional-encoding row (pe zero when the block has none);
+ *   w_merge_tm / w_out_tm: the [C, C] weights tile-major [C / 32][C][32] (`hip_ops._w_tilemajor`); pose_term = merge_scale * (W_m pose + b_m);
+ *   w_qkv_packed: the fused [3 C, C] projection in MFMA-fragment order per head (`hip_ops.pack_temporal_qkv`);
+ *   ln_stats (optional): fp32 [rows][2] = (mean, rstd) of every out row with eps ln_stats_eps, for a consumer GEMM that applies the next
+ *   LayerNorm itself (fmc_linear_bf16_lnc).
+ * Shapes: frames == 16, channels == 320, heads == 8, hw % 10 == 0 (the 40x64 level of the 16x320x512 configurations); anything else is
+ * FMC_E_SHAPE -- callers keep the un-fused chain there.  bf16 only.  MFMA bound: 2 rows C (C [merge] + 4 C) + 4 rows F C flops.
+ * ------------------------------------------------------------------------------------------- */
+int fmc_temporal_block_bf16(const void* h, void* out, const float* ln_gamma, const float* ln_bpe, float ln_eps, const void* w_merge_tm,
+                            const void* pose_term, float merge_scale, const void* w_qkv_packed, const void* w_out_tm, const void* b_out,
+                            float* ln_stats, float ln_stats_eps, int n_clips, int frames, int hw, int channels, int heads, float scale,
+                            void* stream);
+/* Diagnostic: `buf` = device buffer of [workgroups][4][8] int64 that receives s_memrealtime stamps (100 MHz) of wave 0 at the phase boundaries of
+ * its first four tiles (tools/r04/probe_tb.py); NULL switches the stamps off (default). */
+int fmc_temporal_block_set_debug(void* buf);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,6 +78,9 @@ SIGNATURES = {
     "fmc_temporal_attn_fp8_fwd": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_int64] * 6 + [c_float, c_void_p]),
     "fmc_temporal_attn_fp8_bwd": (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_int64] * 9 + [c_float, c_void_p]),
     "fmc_nhwc_to_cmajor_padded": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p]),
+    "fmc_temporal_block_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_float, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "fmc_temporal_block_set_debug": (c_int, [c_void_p]),
     "fmc_conv3x3_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                  c_int, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
 }

@@ -957,6 +957,52 @@ def _w_tilemajor_conv(weight_cl: torch.Tensor) -> torch.Tensor:
     return hit
 
 
+def pack_temporal_qkv(w_qkv: torch.Tensor, heads: int = 8) -> torch.Tensor:
+    """Fused temporal `[3 C, C]` projection (rows q | k | v, heads contiguous inside each) -> the MFMA-fragment order of `fmc_temporal_block_bf16`
+    (C = 320, d = 40): per head [q: blocks q[0:16], q[16:32], tail = (q[32:40] | k[32:40])][k: k[0:16], k[16:32]][v: v[0:16], v[16:32], (v[32:40] | 0)],
+    every part as [k-step C / 32][block][lane = 16 * (k chunk of 8) + row][8]: the fragment of one 16-row block and k-step is one contiguous KiB,
+    a head's 30 (part, k-step) steps one contiguous 80-KiB stream."""
+    C3, C = w_qkv.shape
+    assert C3 == 3 * C and C == 320 and heads == 8, "the fused temporal block exists for C = 320, 8 heads"
+    d = C // heads
+    w = w_qkv.detach()
+    q, k, v = w[:C].view(heads, d, C), w[C:2 * C].view(heads, d, C), w[2 * C:].view(heads, d, C)
+    z = torch.zeros(heads, 8, C, dtype=w.dtype, device=w.device)
+    parts = [torch.stack([q[:, 0:16], q[:, 16:32], torch.cat([q[:, 32:40], k[:, 32:40]], 1)], 1),        # [H, 3, 16, C]
+             torch.stack([k[:, 0:16], k[:, 16:32]], 1),
+             torch.stack([v[:, 0:16], v[:, 16:32], torch.cat([v[:, 32:40], z], 1)], 1)]
+    out = []
+    for blk in parts:                                   # [H, nb, 16 rows, C] -> [H, ks, nb, kq, row, 8]
+        nb = blk.shape[1]
+        out.append(blk.reshape(heads, nb, 16, C // 32, 4, 8).permute(0, 3, 1, 4, 2, 5).reshape(heads, -1))
+    return torch.cat(out, 1).contiguous().view(-1)
+
+
+def temporal_block_supported(h: torch.Tensor, heads: int) -> bool:
+    """`[B, F, hw, C]` bf16 tokens the fused block takes: F = 16, C = 320, 8 heads, hw % 10 == 0, inference."""
+    return (h.is_cuda and h.dtype == torch.bfloat16 and h.ndim == 4 and h.is_contiguous() and h.shape[1] == 16 and h.shape[3] == 320 and heads == 8
+            and h.shape[2] % 10 == 0 and h.numel() * 2 < (1 << 31) and not torch.is_grad_enabled())
+
+
+def temporal_block(h: torch.Tensor, ln_gamma: torch.Tensor, ln_bpe: torch.Tensor, ln_eps: float, w_qkv_packed: torch.Tensor,
+                   w_out_tm: torch.Tensor, b_out: Optional[torch.Tensor], scale: float, w_merge_tm: Optional[torch.Tensor] = None,
+                   pose_term: Optional[torch.Tensor] = None, merge_scale: float = 1.0, stats_eps: Optional[float] = None):
+    """One attention block of the temporal transformer in one launch (`fmc_temporal_block_bf16`): LayerNorm (+ pe) -> [Camera-Adapter merge] ->
+    q | k | v -> attention over the frames -> out-projection + bias + h.  Returns `out` or `(out, ln_stats)` when `stats_eps` is given."""
+    _dev(h, ln_gamma, ln_bpe, w_qkv_packed, w_out_tm, b_out, w_merge_tm, pose_term)
+    B, F, hw, C = h.shape
+    assert h.is_contiguous() and ln_gamma.dtype == torch.float32 and ln_bpe.dtype == torch.float32 and tuple(ln_bpe.shape) == (F, C) and ln_bpe.is_contiguous()
+    assert (w_merge_tm is None) == (pose_term is None)
+    assert pose_term is None or (pose_term.shape == h.shape and pose_term.is_contiguous() and pose_term.dtype == h.dtype)
+    out = torch.empty_like(h)
+    stats = torch.empty(B * F * hw, 2, dtype=torch.float32, device=h.device) if stats_eps is not None else None
+    _lib.check(_lib.load().fmc_temporal_block_bf16(h.data_ptr(), out.data_ptr(), ln_gamma.data_ptr(), ln_bpe.data_ptr(), float(ln_eps), _p(w_merge_tm),
+                                                   _p(pose_term), float(merge_scale), w_qkv_packed.data_ptr(), w_out_tm.data_ptr(), _p(b_out),
+                                                   _p(stats), float(stats_eps or 0.0), B, F, hw, C, 8, float(scale), _stream()),
+               "fmc_temporal_block_bf16")
+    return out if stats is None else (out, stats)
+
+
 def linear_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
     return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.stride(-1) == 1
             and weight.shape[1] % 64 == 0 and weight.shape[0] % 8 == 0 and weight.is_contiguous())

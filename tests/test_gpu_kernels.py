@@ -1698,3 +1698,81 @@ def test_tile_major_weights_are_bit_identical(K):
     xo, xd = rnd((2, 2560, 320), 54, dtype)
     y = K.linear(xd, w3d, None, None, 1.0, gn_hw=2560)
     assert getattr(y, "_fmc_gn", None) is not None and torch.equal(y, K.linear_bf16(xd, w3d, None, None, 1.0, tile=K.ARM_160))
+
+
+def _temporal_block_reference(h, gamma, beta, pe, eps, wqkv, wout, bout, heads, wm=None, bm=None, pose=None, s=1.0, round_bf16=True):
+    """fp32 restatement of one attention block of the temporal transformer (fmc/models/motion_module.py:287-300, 349-389;
+    fmc/models/attention_processor.py:202-293): h `[B, F, hw, C]`.  With `round_bf16` the tensors the fused kernel keeps in bf16 (x, the pose
+    term, m, q / k / v, the probabilities, o) are rounded where the kernel rounds them, so that the comparison isolates the arithmetic."""
+    r = (lambda t: t.bfloat16().float()) if round_bf16 else (lambda t: t)
+    B, Fr, hw, C = h.shape
+    d = C // heads
+    x = r(F.layer_norm(h, (C,), gamma, beta, eps) + pe[None, :Fr, None, :])
+    m = x
+    if wm is not None:
+        pt = r(s * F.linear(pose, wm, bm))
+        m = r(s * F.linear(x, wm) + pt + x)
+    qkv = r(F.linear(m, wqkv))
+    q, k, v = (t.reshape(B, Fr, hw, heads, d).permute(0, 2, 3, 1, 4) for t in qkv.chunk(3, dim=-1))      # [B, hw, H, F, d]
+    p = r(torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, dim=-1))
+    o = r(p @ v).permute(0, 3, 1, 2, 4).reshape(B, Fr, hw, C)
+    return F.linear(o, wout, bout) + h
+
+
+@pytest.mark.parametrize("merge", [True, False])
+@pytest.mark.parametrize("B,hw", [(1, 10), (2, 2560), (3, 70)])
+def test_temporal_block_fused(K, merge, B, hw):
+    """`fmc_temporal_block_bf16`: LayerNorm + pe -> [Camera-Adapter merge + pose term] -> q | k | v -> attention over the 16 frames ->
+    out-projection + bias + residual, one launch, a 160-row tile resident in LDS.  Against the fp32 restatement with the kernel's bf16
+    rounding points (element-wise bf16 bound on the output) and against the plain fp32 chain (max norm); one tile, the bench size (2 clips x
+    2560 pixels = 512 tiles on 256 CUs: two per workgroup), an odd tile count; the row statistics for the next LayerNorm; repeated launches."""
+    dtype = torch.bfloat16
+    C, H, Fr = 320, 8, 16
+    ho, hd = rnd((B, Fr, hw, C), 1, dtype, scale=1.5, shift=0.2)
+    go, _ = rnd((C,), 2, torch.float32, scale=0.3, shift=1.0)
+    bo, _ = rnd((C,), 3, torch.float32, scale=0.2)
+    peo, _ = rnd((32, C), 4, torch.float32, scale=0.7)
+    wqo, wqd = rnd((3 * C, C), 5, dtype, scale=C ** -0.5 * 1.5)
+    woo, wod = rnd((C, C), 6, dtype, scale=C ** -0.5)
+    boo, bod = rnd((C,), 7, dtype, scale=0.3)
+    wmo, wmd = rnd((C, C), 8, dtype, scale=C ** -0.5)
+    bmo, bmd = rnd((C,), 9, dtype, scale=0.3)
+    poo, pod = rnd((B, Fr, hw, C), 10, dtype)
+    s = 0.7
+    bpe = (bo[None] + peo[:Fr]).cuda().contiguous()
+    pt = K.linear_bf16(pod.view(-1, C), wmd, bmd, None, s).view(B, Fr, hw, C) if merge else None
+    kw = dict(w_merge_tm=K._w_tilemajor(wmd), pose_term=pt, merge_scale=s) if merge else {}
+    out, stats = K.temporal_block(hd, go.cuda(), bpe, 1e-5, K.pack_temporal_qkv(wqd), K._w_tilemajor(wod), bod, 40 ** -0.5, stats_eps=1e-5, **kw)
+    rk = dict(wm=wmo, bm=bmo, pose=poo, s=s) if merge else {}
+    if merge:                                            # the pose term the kernel reads is the GEMM's own rounding of s (W pose + b)
+        rk["pose"] = None
+    ref_args = (ho, go, bo, peo, 1e-5, wqo, woo, boo, H)
+
+    def reference(round_bf16):
+        if not merge:
+            return _temporal_block_reference(*ref_args, round_bf16=round_bf16)
+        r = (lambda t: t.bfloat16().float()) if round_bf16 else (lambda t: t)
+        # (restated here with the device's own pose term so that its rounding is not compared)
+        x = r(F.layer_norm(ho, (C,), go, bo, 1e-5) + peo[None, :Fr, None, :])
+        m = r(s * F.linear(x, wmo) + pt.float().cpu() + x)
+        qkv = r(F.linear(m, wqo))
+        q, k, v = (t.reshape(B, Fr, hw, H, 40).permute(0, 2, 3, 1, 4) for t in qkv.chunk(3, dim=-1))
+        p = r(torch.softmax(q @ k.transpose(-1, -2) * 40 ** -0.5, dim=-1))
+        o = r(p @ v).permute(0, 3, 1, 2, 4).reshape(B, Fr, hw, C)
+        return F.linear(o, woo, boo) + ho
+    ref_r, ref_f = reference(True), reference(False)
+    assert rel_inf(out.float(), ref_f) < 2e-2, (merge, B, hw)
+    # element-wise: the kernel's bf16 intermediates can round the other way on ties / accumulation order: bound = bf16 output rounding + the
+    # out-projection's amplification of a 2^-8 error in o (|W_out| row sums ~ 14 x C^-1/2 x |o|)
+    err = (out.float().cpu() - ref_r).abs()
+    bound = 2.0 ** -8 * ref_r.abs() + 0.08
+    assert not bool((err > bound).any()), f"{int((err > bound).sum())} / {err.numel()} beyond the bound, worst {float((err - bound).max()):.3e} at {int((err - bound).flatten().argmax())}"
+    # row statistics of the rounded output
+    mu = out.float().mean(-1).view(-1)
+    rstd = (out.float().var(-1, unbiased=False) + 1e-5).rsqrt().view(-1)
+    assert rel_inf(stats[:, 0], mu) < 1e-4 and rel_inf(stats[:, 1], rstd) < 1e-4
+    for it in range(3):                                  # deterministic, no state between launches
+        again = K.temporal_block(hd, go.cuda(), bpe, 1e-5, K.pack_temporal_qkv(wqd), K._w_tilemajor(wod), bod, 40 ** -0.5, **kw)
+        assert torch.equal(again, out)
+    with pytest.raises(ValueError):                      # shapes outside the fused block's domain are refused (callers keep the un-fused chain)
+        K.temporal_block(hd[:, :, :hw - 1].contiguous(), go.cuda(), bpe, 1e-5, K.pack_temporal_qkv(wqd), K._w_tilemajor(wod), bod, 40 ** -0.5)

@@ -470,7 +470,8 @@ def test_cfg_shared_prefix_equals_the_plain_path(stack):
             shared = pu(x2, torch.tensor(801, device="cuda"), dev(text2), pose_embedding_features=pose2, traj_features=traj,
                         cfg_shared_input=True).sample
             again = pu(x2, torch.tensor(801, device="cuda"), dev(text2), pose_embedding_features=pose2, traj_features=traj).sample
-            assert torch.equal(again, plain)                                    # the hint is per call: nothing sticky stays on the module
+            assert rel_inf(again, plain) < (1e-6 if dtype == torch.float32 else tol)   # the hint is per call: nothing sticky stays on the module
+            assert not hasattr(pu, "cfg_shared_input")                          # (bf16: the first call of a shape autotunes, later calls may run another arm)
             assert "_cfg_half_input" not in pu.down_blocks[0].__dict__
         assert shared.shape == plain.shape and rel_inf(shared, plain) < tol
         assert rel_inf(plain[0], plain[1]) > 1e-3                               # (the halves do differ downstream)
