@@ -67,6 +67,16 @@ __device__ __forceinline__ void unpack4(const u32x2& w, float (&o)[4]) {
     o[0] = __uint_as_float(w[0] << 16); o[1] = __uint_as_float(w[0] & 0xffff0000u);
     o[2] = __uint_as_float(w[1] << 16); o[3] = __uint_as_float(w[1] & 0xffff0000u);
 }
+// MFMA results are consumed by VALU code only behind TB_SETTLE(): a scheduling fence + 32 idle issue cycles.  hipcc (ROCm 7.2) interleaves the
+// consumers of a k-loop's accumulators (v_cvt_pk, the score MFMAs) into the loop's last step with the wait states ITS tables give the gfx950
+// v_mfma_f32_16x16x32_bf16 -- observed: deterministic garbage in the pixel whose accumulators were read first, moving from pixel to pixel with
+// the register allocation of the build (q right, probabilities wrong); with the fence every build since has been right.  ~0.1 % of a tile.
+#define TB_SETTLE()                                                                                                      \
+    do {                                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+    } while (0)
 #define TB_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define TB_STAMP(i)                                                                                                      \
     do {                                                                                                                 \
@@ -91,8 +101,6 @@ void temporal_block_kernel(const TBParams P) {
     const __amdgpu_buffer_rsrc_t rsPT = __builtin_amdgcn_make_buffer_rsrc((void*)(HAS_MERGE ? P.pose_term : P.h), 0, (int)(total_elems * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsWM = __builtin_amdgcn_make_buffer_rsrc((void*)(HAS_MERGE ? P.w_merge : P.w_out), 0, 320 * 320 * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsWO = __builtin_amdgcn_make_buffer_rsrc((void*)P.w_out, 0, 320 * 320 * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsQKV = __builtin_amdgcn_make_buffer_rsrc((void*)P.w_qkv, 0, 8 * TB_QKV_HEAD * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsBPE = __builtin_amdgcn_make_buffer_rsrc((void*)P.ln_bpe, 0, 16 * 320 * 4, 0x00020000);
 
     // ---- weight sub-tile requests (gemm160's image): piece i = 4 wave + e covers rows 16 i .. 16 i + 15 of the sub-tile ---------------------
     const int prow = lane >> 2, pch = lane & 3, psrc = pch ^ (3 * ((prow >> 3) & 1));
@@ -117,14 +125,20 @@ void temporal_block_kernel(const TBParams P) {
     // `mid(g)` runs in LOAD(g) right after the requests (prefetch hooks).  On entry: sub-tiles 0, 1 requested into buffers 0, 1 and
     // `vm_first` leaves everything younger than sub-tile 0 outstanding.  VM_MID = loads `mid` issues at g == 2 (per lane).
     auto read_frags = [&](int g, int buf) {
-        const bf16_t* Ws = RING + buf * TB_SUB + wfrag;
+        // (the per-lane fragment offsets are recomputed here from an opaque copy: left visible as loop invariants of the persistent tile loop,
+        //  hipcc materialises the addresses of all 20 + 30 unrolled steps up front, spills them and reloads them inside the main loops -- and
+        //  every scratch reload carries an `s_waitcnt vmcnt(0)` that drains the weight stream)
+        int wfrag_o = wfrag, xrow_o = (wr * 80 + l15) * TB_C, kqx = kq ^ xsw;
+        asm volatile("" : "+v"(wfrag_o), "+v"(xrow_o), "+v"(kqx));
+        const bf16_t* Ws = RING + buf * TB_SUB + wfrag_o;
 #pragma unroll
         for (int nb = 0; nb < 5; ++nb) {
             union { bf16x8 v; u32x4 u; } t;
             t.u = *reinterpret_cast<const u32x4*>(Ws + nb * 16 * 32);
             wf[nb] = t.v;
         }
-        const bf16_t* As = X + (wr * 80 + l15) * TB_C + (((4 * g + kq) ^ xsw)) * 8;
+        // chunk (4 g + kq) ^ xsw = 8 (g >> 1) + ((4 (g & 1) + kq) ^ xsw) = 8 (g >> 1) + ((4 (g & 1)) ^ (kq ^ xsw))   (kq < 4, xsw < 8)
+        const bf16_t* As = X + xrow_o + ((g >> 1) * 8 + (((g & 1) * 4) ^ kqx)) * 8;
 #pragma unroll
         for (int mb = 0; mb < 5; ++mb) {
             union { bf16x8 v; u32x4 u; } t;
@@ -152,6 +166,26 @@ void temporal_block_kernel(const TBParams P) {
     u32x2 side[5][5];
     const int n_tiles_per_clip = P.hw / TB_PIX;
 
+    // h rows of a tile -> X by LDS-DMA: 6400 16-byte chunks = 100 pieces; piece q = wave + 8 j; LDS chunk idx = 64 q + lane -> row idx / 40,
+    // physical chunk idx % 40 (the source address carries the swizzle)
+    auto issue_h = [&](int t) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                  // (per-tile address arithmetic must not be hoisted out of the persistent loop: 40 live registers)
+        const int clip = t / n_tiles_per_clip, p0 = (t - clip * n_tiles_per_clip) * TB_PIX;
+        const unsigned row0 = (unsigned)(((int64_t)clip * TB_F * P.hw + p0) * TB_C), fstride = (unsigned)(P.hw * TB_C);
+#pragma unroll
+        for (int j = 0; j < 13; ++j) {
+            const int q = wave + 8 * j;
+            if (q < 100) {
+                const int idx = 64 * q + ln, r = idx / 40, pc = idx - r * 40, c = pc ^ ((r >> 1) & 7);
+                const unsigned src = (row0 + (unsigned)(r & 15) * fstride + (unsigned)(r >> 4) * TB_C + (unsigned)c * 8) * 2;
+                tb_dma(rsH, src, 0, X + 64 * q * 8);
+            }
+        }
+    };
+    if ((int)blockIdx.x < P.tiles) issue_h(blockIdx.x);
+    float* stats = reinterpret_cast<float*>(smem_raw + TB_X_ELEMS * 2 + 53248);      // (mean, rstd) x 160 rows: behind the epilogue's staging rows in the ring region
+
     int tslot = -1;
     for (int tile = blockIdx.x; tile < P.tiles; tile += gridDim.x) {
         ++tslot;
@@ -170,85 +204,87 @@ void temporal_block_kernel(const TBParams P) {
                     side[mb][nb] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(base + (unsigned)(mb * TB_C + nb * 16) * 2), 0, 0));
         };
 
-        // ================= phase A: h rows -> X (LDS-DMA), beta + pe table -> ring buffer 2, LayerNorm in place =================
-        // 6400 16-byte chunks = 100 pieces; piece q = wave + 8 j; LDS chunk idx = 64 q + lane -> row idx / 40, physical chunk idx % 40
+        // ================= phase A: LayerNorm (+ pe) of the h rows in X, in place =================
+        // (the rows were requested under the previous tile's epilogue; the merge's first two weight sub-tiles go out behind the norm's constants)
+        // normalising thread = (logical chunk c, row group rg): rows rg, rg + 12, ...; frame of row r = r & 15 -> only the four frames
+        // (rg + 12 j) & 15 occur: gamma and the four (beta + pe) rows of its 8 columns live in registers for the tile
+        int tid_t = tid;
+        asm volatile("" : "+v"(tid_t));               // (as above: gamma / beta + pe are re-read per tile -- L1 / L2 resident -- rather than kept live across it)
+        const int nc = tid_t % 40, nrg = tid_t / 40;
+        f32x4 ng0, ng1, nb0[4], nb1[4];
+        if (tid < 480) {
+            ng0 = *reinterpret_cast<const f32x4*>(P.ln_gamma + nc * 8);
+            ng1 = *reinterpret_cast<const f32x4*>(P.ln_gamma + nc * 8 + 4);
 #pragma unroll
-        for (int j = 0; j < 13; ++j) {
-            const int q = wave + 8 * j;
-            if (q < 100) {
-                const int idx = 64 * q + lane, r = idx / 40, pc = idx - r * 40, c = pc ^ ((r >> 1) & 7);
-                const unsigned src = (row0 + (unsigned)(r & 15) * fstride + (unsigned)(r >> 4) * TB_C + (unsigned)c * 8) * 2;
-                tb_dma(rsH, src, 0, X + 64 * q * 8);
+            for (int j = 0; j < 4; ++j) {
+                const float* bp = P.ln_bpe + ((nrg + 12 * j) & 15) * 320 + nc * 8;
+                nb0[j] = *reinterpret_cast<const f32x4*>(bp);
+                nb1[j] = *reinterpret_cast<const f32x4*>(bp + 4);
             }
         }
-        // beta + pe: 16 x 320 fp32 = 20 KiB = 20 pieces, linear, into ring buffer 2
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int q = wave + 8 * j;
-            if (q < 20) tb_dma(rsBPE, (unsigned)((64 * q + lane) * 16), 0, RING + 2 * TB_SUB + 64 * q * 8);
+        __builtin_amdgcn_sched_barrier(0);
+        if (HAS_MERGE) {
+            issue_w(rsWM, 0, 0);
+            issue_w(rsWM, 1, 1);
         }
-        TB_VMCNT(0);
+        if (HAS_MERGE && w_wave) TB_VMCNT(8); else TB_VMCNT(0);   // the h rows (and gamma / beta + pe) have landed; the two weight sub-tiles may still be in flight
         __syncthreads();
         TB_STAMP(1);
-        float* stats = reinterpret_cast<float*>(RING + TB_SUB);                  // (mean, rstd) x 160 rows, in ring buffer 1
-        const float* bpe = reinterpret_cast<const float*>(RING + 2 * TB_SUB);    // [16][320]
         {
-            // statistics: 4 lanes per row, centred variance (two passes over the LDS rows)
+            // statistics: 4 lanes per row, the row's 40 chunks in registers, centred variance
 #pragma unroll 1
             for (int r = tid >> 2; r < TB_ROWS; r += 128) {
                 const int q = tid & 3;
                 const bf16_t* xr = X + r * TB_C;
+                u32x4 x4[10];
                 float s1 = 0.f;
 #pragma unroll
                 for (int i = 0; i < 10; ++i) {
-                    const u32x4 x4 = *reinterpret_cast<const u32x4*>(xr + (q + 4 * i) * 8);
+                    x4[i] = *reinterpret_cast<const u32x4*>(xr + (q + 4 * i) * 8);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) s1 += __uint_as_float(x4[j] << 16) + __uint_as_float(x4[j] & 0xffff0000u);
+                    for (int j = 0; j < 4; ++j) s1 += __uint_as_float(x4[i][j] << 16) + __uint_as_float(x4[i][j] & 0xffff0000u);
                 }
                 s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2);
                 const float mean = s1 * (1.f / 320.f);
                 float s2 = 0.f;
 #pragma unroll
-                for (int i = 0; i < 10; ++i) {
-                    const u32x4 x4 = *reinterpret_cast<const u32x4*>(xr + (q + 4 * i) * 8);
+                for (int i = 0; i < 10; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float a = __uint_as_float(x4[j] << 16) - mean, b = __uint_as_float(x4[j] & 0xffff0000u) - mean;
+                        const float a = __uint_as_float(x4[i][j] << 16) - mean, b = __uint_as_float(x4[i][j] & 0xffff0000u) - mean;
                         s2 += a * a + b * b;
                     }
-                }
                 s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2);
                 if (q == 0) *reinterpret_cast<f32x2_t*>(stats + 2 * r) = f32x2_t{mean, rsqrtf(s2 * (1.f / 320.f) + P.ln_eps)};
             }
         }
         __syncthreads();
         if (tid < 480) {
-            // normalise in place: thread = (logical chunk c, row group); gamma of its 8 columns in registers
-            const int c = tid % 40, rg = tid / 40;
-            const f32x4 g0 = *reinterpret_cast<const f32x4*>(P.ln_gamma + c * 8), g1 = *reinterpret_cast<const f32x4*>(P.ln_gamma + c * 8 + 4);
-#pragma unroll 2
-            for (int r = rg; r < TB_ROWS; r += 12) {
-                u32x4* px = reinterpret_cast<u32x4*>(X + r * TB_C + (c ^ ((r >> 1) & 7)) * 8);
-                const u32x4 x4 = *px;
-                const f32x2_t st = *reinterpret_cast<const f32x2_t*>(stats + 2 * r);
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bpe + (r & 15) * 320 + c * 8), b1 = *reinterpret_cast<const f32x4*>(bpe + (r & 15) * 320 + c * 8 + 4);
-                const float m = st[0], rs = st[1];
-                u32x4 o4;
-                o4[0] = pack_bf2((__uint_as_float(x4[0] << 16) - m) * rs * g0[0] + b0[0], (__uint_as_float(x4[0] & 0xffff0000u) - m) * rs * g0[1] + b0[1]);
-                o4[1] = pack_bf2((__uint_as_float(x4[1] << 16) - m) * rs * g0[2] + b0[2], (__uint_as_float(x4[1] & 0xffff0000u) - m) * rs * g0[3] + b0[3]);
-                o4[2] = pack_bf2((__uint_as_float(x4[2] << 16) - m) * rs * g1[0] + b1[0], (__uint_as_float(x4[2] & 0xffff0000u) - m) * rs * g1[1] + b1[1]);
-                o4[3] = pack_bf2((__uint_as_float(x4[3] << 16) - m) * rs * g1[2] + b1[2], (__uint_as_float(x4[3] & 0xffff0000u) - m) * rs * g1[3] + b1[3]);
-                *px = o4;
-            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = nrg + 12 * (4 * kk + j);
+                    if (r < TB_ROWS) {
+                        u32x4* px = reinterpret_cast<u32x4*>(X + r * TB_C + (nc ^ ((r >> 1) & 7)) * 8);
+                        const u32x4 x4 = *px;
+                        const f32x2_t st = *reinterpret_cast<const f32x2_t*>(stats + 2 * r);
+                        const float m = st[0], rs = st[1];
+                        u32x4 o4;
+                        o4[0] = pack_bf2((__uint_as_float(x4[0] << 16) - m) * rs * ng0[0] + nb0[j][0], (__uint_as_float(x4[0] & 0xffff0000u) - m) * rs * ng0[1] + nb0[j][1]);
+                        o4[1] = pack_bf2((__uint_as_float(x4[1] << 16) - m) * rs * ng0[2] + nb0[j][2], (__uint_as_float(x4[1] & 0xffff0000u) - m) * rs * ng0[3] + nb0[j][3]);
+                        o4[2] = pack_bf2((__uint_as_float(x4[2] << 16) - m) * rs * ng1[0] + nb1[j][0], (__uint_as_float(x4[2] & 0xffff0000u) - m) * rs * ng1[1] + nb1[j][1]);
+                        o4[3] = pack_bf2((__uint_as_float(x4[3] << 16) - m) * rs * ng1[2] + nb1[j][2], (__uint_as_float(x4[3] & 0xffff0000u) - m) * rs * ng1[3] + nb1[j][3]);
+                        *px = o4;
+                    }
+                }
         }
-        __syncthreads();                                          // X = x = LayerNorm(h) + pe; the ring is free
+        __syncthreads();                                          // X = x = LayerNorm(h) + pe
         TB_STAMP(2);
 
         // ================= phase B: m = s x W_m^T + pose_term + x (in place) =================
         if (HAS_MERGE) {
-            issue_w(rsWM, 0, 0);
-            issue_w(rsWM, 1, 1);
-            TB_VMCNT(4);
+            TB_VMCNT(4);                                          // sub-tile 0 (requested at the head of the tile)
             __builtin_amdgcn_s_barrier();
             if (wr == 1) __builtin_amdgcn_s_barrier();            // wave row 1 runs one barrier behind wave row 0
             __builtin_amdgcn_sched_barrier(0);
@@ -261,13 +297,12 @@ void temporal_block_kernel(const TBParams P) {
             for (int g = 0; g < 10; ++g) {
                 read_frags(g, g % 3);
                 if (g + 2 < 10) issue_w(rsWM, g + 2, (g + 2) % 3);
-                if (g == 2) side_load(rsPT);
-                // queue (a requesting wave): g <= 1: [W g+1, W g+2]; g == 2: [W3, W4, side x 25]; g == 3: [W4, side, W5]; then [W g+1, W g+2]; g >= 8: tail
-                if (g == 2 || g == 3) TB_VMCNT(29);
-                else if (g < 8) TB_VMCNT(4);
-                else TB_VMCNT(0);
+                if (g < 8) TB_VMCNT(4); else TB_VMCNT(0);         // retires sub-tile g + 1, the one just requested stays in flight
                 TB_MMA();
             }
+            // the pose term in accumulator layout (25 eight-byte loads per lane).  Requested HERE, not under the main loop: 50 more live registers
+            // next to the 100 accumulators + 40 fragment registers spill, and every scratch reload is an `s_waitcnt vmcnt(0)` that drains the ring
+            side_load(rsPT);
             if (wr == 0) __builtin_amdgcn_s_barrier();            // the wave rows meet again: every fragment read of x is done
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -294,7 +329,11 @@ void temporal_block_kernel(const TBParams P) {
         issue_w(rsWO, 1, 1);
         u32x2 o_pk[10][3];                                        // o of my head: (row 16 m + l15, channels 16 nb + 4 kq ..) as 4 bf16
         {
-            const unsigned qkv_base = (unsigned)(wave * TB_QKV_HEAD * 2) + (unsigned)lane * 16;
+            // my head's 80-KiB stream through its own descriptor: the step offsets below are then compile-time constants (soffset literals),
+            // not 80 precomputed scalar registers
+            const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(P.w_qkv + (size_t)wave * TB_QKV_HEAD), 0, TB_QKV_HEAD * 2, 0x00020000);
+            int qkv_lane = lane * 16;
+            asm volatile("" : "+v"(qkv_lane));
             // weight fragment stream of the head: step s = 0 .. 29 -> (part = s / 10, k-step = s % 10); bytes before step s:
             //   part 0 (q0 q1 tail): 3 KiB per step; part 1 (k0 k1): 2 KiB; part 2 (v0 v1 v2): 3 KiB
             auto step_off = [](int s) { return s < 10 ? s * 3072 : (s < 20 ? 30720 + (s - 10) * 2048 : 51200 + (s - 20) * 3072); };
@@ -303,7 +342,7 @@ void temporal_block_kernel(const TBParams P) {
                 const int nbk = (s >= 10 && s < 20) ? 2 : 3;
 #pragma unroll
                 for (int b = 0; b < 3; ++b)
-                    if (b < nbk) wq[s % 3][b] = __builtin_amdgcn_raw_buffer_load_b128(rsQKV, (int)(qkv_base + (unsigned)(step_off(s) + b * 1024)), 0, 0);
+                    if (b < nbk) wq[s % 3][b] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, qkv_lane, step_off(s) + b * 1024, 0);
             };
             load_step(0);
             load_step(1);
@@ -311,7 +350,6 @@ void temporal_block_kernel(const TBParams P) {
             bf16x8 q8[10];
             u32x2 t4[10];                                         // tail block: lanes kq < 2: q channels 32 + 4 kq ..; kq >= 2: k channels 32 + 4 (kq - 2) ..
             u32x2 p_pk[10];                                       // softmax probabilities P^T (keys 4 kq .. of query l15), bf16
-            const bf16_t* Xa = X + l15 * TB_C;
             // (every step is instantiated with compile-time (part, k-step): the 30-step loop nest is beyond the unroller's size limit, and left
             // rolled it indexes the fragment ring dynamically -> scratch)
             auto zero_pacc = [&]() {
@@ -323,12 +361,14 @@ void temporal_block_kernel(const TBParams P) {
             auto step = [&](auto part_c, auto ks_c) {
                 constexpr int part = decltype(part_c)::value, ks = decltype(ks_c)::value, s = part * 10 + ks;
                 if constexpr (s + 2 < 30) load_step(s + 2);
-                const int xo = ((4 * ks + kq) ^ xsw) * 8;
+                int kqx = kq ^ xsw, xrow_o = l15 * TB_C;
+                asm volatile("" : "+v"(kqx), "+v"(xrow_o));        // (see read_frags: no address of a later step may be computed ahead and spilled)
+                const int xo = xrow_o + ((ks >> 1) * 8 + (((ks & 1) * 4) ^ kqx)) * 8;
                 __builtin_amdgcn_sched_barrier(0);                // (keeps later k-steps' fragment reads from being hoisted over this one: registers)
 #pragma unroll
                 for (int m = 0; m < 10; ++m) {
                     union { bf16x8 v; u32x4 u; } a;
-                    a.u = *reinterpret_cast<const u32x4*>(Xa + m * 16 * TB_C + xo);
+                    a.u = *reinterpret_cast<const u32x4*>(X + m * 16 * TB_C + xo);
 #pragma unroll
                     for (int b = 0; b < (part == 1 ? 2 : 3); ++b) {
                         union { bf16x8 v; u32x4 u; } w;
@@ -345,6 +385,7 @@ void temporal_block_kernel(const TBParams P) {
             // ---- q (+ the shared tail block) ----
             zero_pacc();
             TB_PART(0);
+            TB_SETTLE();
 #pragma unroll
             for (int m = 0; m < 10; ++m) {
                 union { bf16x8 v; u32x4 u; } t;
@@ -356,13 +397,14 @@ void temporal_block_kernel(const TBParams P) {
             // ---- k, scores, softmax ----
             zero_pacc();
             TB_PART(1);
+            TB_SETTLE();
 #pragma unroll
             for (int m = 0; m < 10; ++m) {
                 union { bf16x8 v; u32x4 u; } k8;
                 k8.u = u32x4{pack_bf2(pacc[m][0][0], pacc[m][0][1]), pack_bf2(pacc[m][0][2], pacc[m][0][3]),
                              pack_bf2(pacc[m][1][0], pacc[m][1][1]), pack_bf2(pacc[m][1][2], pacc[m][1][3])};
                 // S^T[key][query] = K Q^T: A = k rows, B = q rows (both index the reduction by the same channel permutation)
-                f32x4 sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k8.v, q8[m], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                const f32x4 sc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k8.v, q8[m], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                 // tails: q channels 32..39 sit in lanes kq < 2 of t4, k channels 32..39 in lanes kq >= 2 -> bring those down by a half-wave swap
                 union { u32x2 u; s16x4 s; } qt, kt;
                 const unsigned keep = kq < 2 ? 0xffffffffu : 0u;
@@ -370,7 +412,9 @@ void temporal_block_kernel(const TBParams P) {
                 const auto s0 = __builtin_amdgcn_permlane32_swap(t4[m][0], t4[m][0], false, false);
                 const auto s1 = __builtin_amdgcn_permlane32_swap(t4[m][1], t4[m][1], false, false);
                 kt.u = u32x2{(unsigned)s0[1] & keep, (unsigned)s1[1] & keep};       // [1]: lanes 0-31 see the upper half's value of lane + 32
-                sc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt.s, qt.s, sc, 0, 0, 0);
+                const f32x4 sc2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt.s, qt.s, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                TB_SETTLE();
+                const f32x4 sc = sc1 + sc2;
                 // softmax over the 16 keys of query l15: 4 in-lane values x 4 lanes (kq)
                 float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])) * P.scale_log2;
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -386,17 +430,21 @@ void temporal_block_kernel(const TBParams P) {
             // ---- v, o = P V ----
             zero_pacc();
             TB_PART(2);
+            TB_SETTLE();
 #pragma unroll
             for (int m = 0; m < 10; ++m) {
                 union { u32x2 u; s16x4 s; } pb;
                 pb.u = p_pk[m];
+                f32x4 o[3];
 #pragma unroll
                 for (int b = 0; b < 3; ++b) {
                     union { u32x2 u; s16x4 s; } vt;                  // V^T: (channel 16 b + l15, keys 4 kq ..)
                     vt.u = u32x2{pack_bf2(pacc[m][b][0], pacc[m][b][1]), pack_bf2(pacc[m][b][2], pacc[m][b][3])};
-                    const f32x4 o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt.s, pb.s, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);   // (query l15, channels 16 b + 4 kq ..)
-                    o_pk[m][b] = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+                    o[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt.s, pb.s, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);   // (query l15, channels 16 b + 4 kq ..)
                 }
+                TB_SETTLE();
+#pragma unroll
+                for (int b = 0; b < 3; ++b) o_pk[m][b] = u32x2{pack_bf2(o[b][0], o[b][1]), pack_bf2(o[b][2], o[b][3])};
             }
 #undef TB_PART
 #undef TB_STEP
@@ -404,16 +452,20 @@ void temporal_block_kernel(const TBParams P) {
         TB_STAMP(4);
         __syncthreads();                                          // every head is done with m: o may overwrite it
         TB_STAMP(5);
-#pragma unroll
-        for (int m = 0; m < 10; ++m)
+        {
+            int orow = l15 * TB_C, okq = kq, oxs = xsw;
+            asm volatile("" : "+v"(orow), "+v"(okq), "+v"(oxs));   // (addresses computed here, not ahead of phase D: see read_frags)
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
-                const int ch = 16 * b + 4 * kq;                  // channel inside the head
+                const int ch = 16 * b + 4 * okq;                 // channel inside the head
+                const int col = 40 * wave + ch;
+                const int off = orow + (((col >> 3) ^ oxs) << 3) + (col & 7);
                 if (ch < 40) {
-                    const int r = 16 * m + l15, col = 40 * wave + ch;
-                    *reinterpret_cast<u32x2*>(X + r * TB_C + (((col >> 3) ^ xsw) << 3) + (col & 7)) = o_pk[m][b];
+#pragma unroll
+                    for (int m = 0; m < 10; ++m) *reinterpret_cast<u32x2*>(X + m * 16 * TB_C + off) = o_pk[m][b];
                 }
             }
+        }
         // ================= phase E: h' = o W_out^T + b + h =================
         TB_VMCNT(0);                                              // (sub-tiles 0, 1 of W_out have long landed)
         __syncthreads();                                          // X = o; ring buffers 0, 1 published
@@ -428,13 +480,10 @@ void temporal_block_kernel(const TBParams P) {
         for (int g = 0; g < 10; ++g) {
             read_frags(g, g % 3);
             if (g + 2 < 10) issue_w(rsWO, g + 2, (g + 2) % 3);
-            if (g == 2) side_load(rsH);
-            if (g == 0 || g == 1) TB_VMCNT(4);                    // (nothing older than sub-tile g + 1 is pending)
-            else if (g == 2 || g == 3) TB_VMCNT(29);
-            else if (g < 8) TB_VMCNT(4);
-            else TB_VMCNT(0);
+            if (g < 8) TB_VMCNT(4); else TB_VMCNT(0);
             TB_MMA();
         }
+        side_load(rsH);                                           // the residual rows in accumulator layout (see phase B)
         if (wr == 0) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         TB_STAMP(6);
@@ -454,6 +503,9 @@ void temporal_block_kernel(const TBParams P) {
                     for (int j = 0; j < 4; ++j) acc[mb][nb][j] += b4[j] + hv[j];
                 }
             }
+            // X (= o) is dead since the main loop: the NEXT tile's h rows stream in under the staging passes and stores below
+            __builtin_amdgcn_sched_barrier(0);
+            if (tile + (int)gridDim.x < P.tiles) issue_h(tile + gridDim.x);
 #pragma unroll 1
             for (int pass = 0; pass < 2; ++pass) {
                 if (wr == pass) {
