@@ -162,27 +162,27 @@ void temporal_block_kernel(const TBParams P) {
         __builtin_amdgcn_sched_barrier(0);                                                                               \
     } while (0)
 
-    // the side operand of an epilogue (pose term / residual h) in accumulator layout: 25 eight-byte loads per lane, issued under the main loop
-    u32x2 side[5][5];
     const int n_tiles_per_clip = P.hw / TB_PIX;
 
-    // h rows of a tile -> X by LDS-DMA: 6400 16-byte chunks = 100 pieces; piece q = wave + 8 j; LDS chunk idx = 64 q + lane -> row idx / 40,
-    // physical chunk idx % 40 (the source address carries the swizzle)
-    auto issue_h = [&](int t) {
+    // rows [r0, r0 + nr) of a tile of `rs` (h or the pose term) -> LDS at `dst` by LDS-DMA, row-major with X's chunk swizzle (16-byte chunk c of tile
+    // row r at chunk c ^ ((r >> 1) & 7): the source address carries it).  nr * 40 chunks = pieces of 64; piece q = wave + 8 j.
+    auto issue_rows = [&](const __amdgpu_buffer_rsrc_t& rs, int t, int r0, int nr, bf16_t* dst) {
         int ln = lane;
         asm volatile("" : "+v"(ln));                  // (per-tile address arithmetic must not be hoisted out of the persistent loop: 40 live registers)
         const int clip = t / n_tiles_per_clip, p0 = (t - clip * n_tiles_per_clip) * TB_PIX;
         const unsigned row0 = (unsigned)(((int64_t)clip * TB_F * P.hw + p0) * TB_C), fstride = (unsigned)(P.hw * TB_C);
+        const int pieces = nr * 40 / 64;
 #pragma unroll
         for (int j = 0; j < 13; ++j) {
             const int q = wave + 8 * j;
-            if (q < 100) {
-                const int idx = 64 * q + ln, r = idx / 40, pc = idx - r * 40, c = pc ^ ((r >> 1) & 7);
+            if (q < pieces) {
+                const int idx = 64 * q + ln, rl = idx / 40, pc = idx - rl * 40, r = r0 + rl, c = pc ^ ((r >> 1) & 7);
                 const unsigned src = (row0 + (unsigned)(r & 15) * fstride + (unsigned)(r >> 4) * TB_C + (unsigned)c * 8) * 2;
-                tb_dma(rsH, src, 0, X + 64 * q * 8);
+                tb_dma(rs, src, 0, dst + 64 * q * 8);
             }
         }
     };
+    auto issue_h = [&](int t) { issue_rows(rsH, t, 0, TB_ROWS, X); };
     if ((int)blockIdx.x < P.tiles) issue_h(blockIdx.x);
     float* stats = reinterpret_cast<float*>(smem_raw + TB_X_ELEMS * 2 + 53248);      // (mean, rstd) x 160 rows: behind the epilogue's staging rows in the ring region
 
@@ -194,40 +194,14 @@ void temporal_block_kernel(const TBParams P) {
         // global element offset of tile row (pixel p, frame f): ((clip * 16 + f) * hw + p0 + p) * 320
         const unsigned row0 = (unsigned)(((int64_t)clip * TB_F * P.hw + p0) * TB_C);         // (pixel 0, frame 0)
         const unsigned fstride = (unsigned)(P.hw * TB_C);
-        auto side_load = [&](const __amdgpu_buffer_rsrc_t& rs) {
-            // my rows: pixel 5 wr + mb, frame l15
-            const unsigned base = (row0 + (unsigned)l15 * fstride + (unsigned)(5 * wr) * TB_C + (unsigned)ecol) * 2;
-#pragma unroll
-            for (int mb = 0; mb < 5; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < 5; ++nb)
-                    side[mb][nb] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(base + (unsigned)(mb * TB_C + nb * 16) * 2), 0, 0));
-        };
-
         // ================= phase A: LayerNorm (+ pe) of the h rows in X, in place =================
         // (the rows were requested under the previous tile's epilogue; the merge's first two weight sub-tiles go out behind the norm's constants)
-        // normalising thread = (logical chunk c, row group rg): rows rg, rg + 12, ...; frame of row r = r & 15 -> only the four frames
-        // (rg + 12 j) & 15 occur: gamma and the four (beta + pe) rows of its 8 columns live in registers for the tile
-        int tid_t = tid;
-        asm volatile("" : "+v"(tid_t));               // (as above: gamma / beta + pe are re-read per tile -- L1 / L2 resident -- rather than kept live across it)
-        const int nc = tid_t % 40, nrg = tid_t / 40;
-        f32x4 ng0, ng1, nb0[4], nb1[4];
-        if (tid < 480) {
-            ng0 = *reinterpret_cast<const f32x4*>(P.ln_gamma + nc * 8);
-            ng1 = *reinterpret_cast<const f32x4*>(P.ln_gamma + nc * 8 + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float* bp = P.ln_bpe + ((nrg + 12 * j) & 15) * 320 + nc * 8;
-                nb0[j] = *reinterpret_cast<const f32x4*>(bp);
-                nb1[j] = *reinterpret_cast<const f32x4*>(bp + 4);
-            }
-        }
         __builtin_amdgcn_sched_barrier(0);
         if (HAS_MERGE) {
             issue_w(rsWM, 0, 0);
             issue_w(rsWM, 1, 1);
         }
-        if (HAS_MERGE && w_wave) TB_VMCNT(8); else TB_VMCNT(0);   // the h rows (and gamma / beta + pe) have landed; the two weight sub-tiles may still be in flight
+        if (HAS_MERGE && w_wave) TB_VMCNT(8); else TB_VMCNT(0);   // the h rows have landed; the two weight sub-tiles may still be in flight
         __syncthreads();
         TB_STAMP(1);
         {
@@ -258,12 +232,33 @@ void temporal_block_kernel(const TBParams P) {
                 if (q == 0) *reinterpret_cast<f32x2_t*>(stats + 2 * r) = f32x2_t{mean, rsqrtf(s2 * (1.f / 320.f) + P.ln_eps)};
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // normalising thread = (logical chunk c, row group rg): rows rg, rg + 12, ...; frame of row r = r & 15 -> only the four frames (rg + 12 j) & 15
+        // occur.  gamma of its 8 columns stays in registers; the (beta + pe) row of frame class j is fetched (L1 / L2 resident) while class
+        // j - 1 is normalised -- all four at once were spilled by the register allocator the moment they arrived (two scratch round trips per row)
+        int tid_t = tid;
+        asm volatile("" : "+v"(tid_t));
+        const int nc = tid_t % 40, nrg = tid_t / 40;
+        f32x4 ng0 = f32x4{0.f, 0.f, 0.f, 0.f}, ng1 = ng0, cb0 = ng0, cb1 = ng0;
+        if (tid < 480) {
+            ng0 = *reinterpret_cast<const f32x4*>(P.ln_gamma + nc * 8);
+            ng1 = *reinterpret_cast<const f32x4*>(P.ln_gamma + nc * 8 + 4);
+            const float* bp = P.ln_bpe + (nrg & 15) * 320 + nc * 8;
+            cb0 = *reinterpret_cast<const f32x4*>(bp);
+            cb1 = *reinterpret_cast<const f32x4*>(bp + 4);
+        }
         __syncthreads();
         if (tid < 480) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
+            for (int j = 0; j < 4; ++j) {
+                f32x4 nx0 = cb0, nx1 = cb1;
+                if (j < 3) {
+                    const float* bp = P.ln_bpe + ((nrg + 12 * (j + 1)) & 15) * 320 + nc * 8;
+                    nx0 = *reinterpret_cast<const f32x4*>(bp);
+                    nx1 = *reinterpret_cast<const f32x4*>(bp + 4);
+                }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int kk = 0; kk < 4; ++kk) {
                     const int r = nrg + 12 * (4 * kk + j);
                     if (r < TB_ROWS) {
                         u32x4* px = reinterpret_cast<u32x4*>(X + r * TB_C + (nc ^ ((r >> 1) & 7)) * 8);
@@ -271,13 +266,15 @@ void temporal_block_kernel(const TBParams P) {
                         const f32x2_t st = *reinterpret_cast<const f32x2_t*>(stats + 2 * r);
                         const float m = st[0], rs = st[1];
                         u32x4 o4;
-                        o4[0] = pack_bf2((__uint_as_float(x4[0] << 16) - m) * rs * ng0[0] + nb0[j][0], (__uint_as_float(x4[0] & 0xffff0000u) - m) * rs * ng0[1] + nb0[j][1]);
-                        o4[1] = pack_bf2((__uint_as_float(x4[1] << 16) - m) * rs * ng0[2] + nb0[j][2], (__uint_as_float(x4[1] & 0xffff0000u) - m) * rs * ng0[3] + nb0[j][3]);
-                        o4[2] = pack_bf2((__uint_as_float(x4[2] << 16) - m) * rs * ng1[0] + nb1[j][0], (__uint_as_float(x4[2] & 0xffff0000u) - m) * rs * ng1[1] + nb1[j][1]);
-                        o4[3] = pack_bf2((__uint_as_float(x4[3] << 16) - m) * rs * ng1[2] + nb1[j][2], (__uint_as_float(x4[3] & 0xffff0000u) - m) * rs * ng1[3] + nb1[j][3]);
+                        o4[0] = pack_bf2((__uint_as_float(x4[0] << 16) - m) * rs * ng0[0] + cb0[0], (__uint_as_float(x4[0] & 0xffff0000u) - m) * rs * ng0[1] + cb0[1]);
+                        o4[1] = pack_bf2((__uint_as_float(x4[1] << 16) - m) * rs * ng0[2] + cb0[2], (__uint_as_float(x4[1] & 0xffff0000u) - m) * rs * ng0[3] + cb0[3]);
+                        o4[2] = pack_bf2((__uint_as_float(x4[2] << 16) - m) * rs * ng1[0] + cb1[0], (__uint_as_float(x4[2] & 0xffff0000u) - m) * rs * ng1[1] + cb1[1]);
+                        o4[3] = pack_bf2((__uint_as_float(x4[3] << 16) - m) * rs * ng1[2] + cb1[2], (__uint_as_float(x4[3] & 0xffff0000u) - m) * rs * ng1[3] + cb1[3]);
                         *px = o4;
                     }
                 }
+                cb0 = nx0; cb1 = nx1;
+            }
         }
         __syncthreads();                                          // X = x = LayerNorm(h) + pe
         TB_STAMP(2);
@@ -300,26 +297,34 @@ void temporal_block_kernel(const TBParams P) {
                 if (g < 8) TB_VMCNT(4); else TB_VMCNT(0);         // retires sub-tile g + 1, the one just requested stays in flight
                 TB_MMA();
             }
-            // the pose term in accumulator layout (25 eight-byte loads per lane).  Requested HERE, not under the main loop: 50 more live registers
-            // next to the 100 accumulators + 40 fragment registers spill, and every scratch reload is an `s_waitcnt vmcnt(0)` that drains the ring
-            side_load(rsPT);
-            if (wr == 0) __builtin_amdgcn_s_barrier();            // the wave rows meet again: every fragment read of x is done
+            if (wr == 0) __builtin_amdgcn_s_barrier();            // the wave rows meet again: every fragment read of x is done, the ring is free
             __builtin_amdgcn_sched_barrier(0);
+            // m = s acc + pose term + x, in place.  The pose-term rows of one wave row at a time arrive in the ring by LDS-DMA (whole 640-byte rows,
+            // X's swizzle) and are picked up in accumulator layout from there: as 25 eight-byte global loads per lane they cost the texture
+            // path 16 quarter-lines per instruction (3 us of an epilogue of 6.7) -- or, requested under the main loop, 50 live registers that spill
+#pragma unroll 1
+            for (int pass = 0; pass < 2; ++pass) {
+                issue_rows(rsPT, tile, 80 * pass, 80, RING);
+                TB_VMCNT(0);
+                __syncthreads();
+                if (wr == pass) {
 #pragma unroll
-            for (int mb = 0; mb < 5; ++mb) {
-                const int r = wr * 80 + mb * 16 + l15;
+                    for (int mb = 0; mb < 5; ++mb) {
+                        const int rl = mb * 16 + l15;             // row inside the wave row; tile row = 80 pass + rl (same swizzle: 80 / 2 = 0 mod 8)
 #pragma unroll
-                for (int nb = 0; nb < 5; ++nb) {
-                    const int col = ecol + nb * 16;
-                    u32x2* px = reinterpret_cast<u32x2*>(X + r * TB_C + (((col >> 3) ^ xsw) << 3) + (col & 7));
-                    float xv[4], pv[4];
-                    unpack4(*px, xv);
-                    unpack4(side[mb][nb], pv);
-                    *px = u32x2{pack_bf2(acc[mb][nb][0] * P.merge_scale + pv[0] + xv[0], acc[mb][nb][1] * P.merge_scale + pv[1] + xv[1]),
-                                pack_bf2(acc[mb][nb][2] * P.merge_scale + pv[2] + xv[2], acc[mb][nb][3] * P.merge_scale + pv[3] + xv[3])};
+                        for (int nb = 0; nb < 5; ++nb) {
+                            const int col = ecol + nb * 16, off = rl * TB_C + (((col >> 3) ^ xsw) << 3) + (col & 7);
+                            u32x2* px = reinterpret_cast<u32x2*>(X + pass * 80 * TB_C + off);
+                            float xv[4], pv[4];
+                            unpack4(*px, xv);
+                            unpack4(*reinterpret_cast<const u32x2*>(RING + off), pv);
+                            *px = u32x2{pack_bf2(acc[mb][nb][0] * P.merge_scale + pv[0] + xv[0], acc[mb][nb][1] * P.merge_scale + pv[1] + xv[1]),
+                                        pack_bf2(acc[mb][nb][2] * P.merge_scale + pv[2] + xv[2], acc[mb][nb][3] * P.merge_scale + pv[3] + xv[3])};
+                        }
+                    }
                 }
+                __syncthreads();                                  // (pass 0: the ring rows may be overwritten; pass 1: X = m)
             }
-            __syncthreads();                                      // X = m
         }
 
         TB_STAMP(3);
@@ -483,10 +488,10 @@ void temporal_block_kernel(const TBParams P) {
             if (g < 8) TB_VMCNT(4); else TB_VMCNT(0);
             TB_MMA();
         }
-        side_load(rsH);                                           // the residual rows in accumulator layout (see phase B)
         if (wr == 0) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         TB_STAMP(6);
+        issue_h(tile);                                            // X (= o) is dead: this tile's h rows come back for the residual add (see phase B)
         {
             // epilogue: wave row `pass` stages its 80 rows (bf16, pitch 328) in the ring region; whole-row stores
             constexpr int OP = 328, CPR = 40;
@@ -496,14 +501,26 @@ void temporal_block_kernel(const TBParams P) {
                 float b4[4] = {0.f, 0.f, 0.f, 0.f};
                 if (P.b_out) unpack4(*reinterpret_cast<const u32x2*>(P.b_out + ecol + nb * 16), b4);
 #pragma unroll
-                for (int mb = 0; mb < 5; ++mb) {
-                    float hv[4];
-                    unpack4(side[mb][nb], hv);
+                for (int mb = 0; mb < 5; ++mb)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[mb][nb][j] += b4[j] + hv[j];
+                    for (int j = 0; j < 4; ++j) acc[mb][nb][j] += b4[j];
+            }
+            TB_VMCNT(0);
+            __syncthreads();
+#pragma unroll
+            for (int mb = 0; mb < 5; ++mb) {
+                const int r = wr * 80 + mb * 16 + l15;
+#pragma unroll
+                for (int nb = 0; nb < 5; ++nb) {
+                    const int col = ecol + nb * 16;
+                    float hv[4];
+                    unpack4(*reinterpret_cast<const u32x2*>(X + r * TB_C + (((col >> 3) ^ xsw) << 3) + (col & 7)), hv);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[mb][nb][j] += hv[j];
                 }
             }
-            // X (= o) is dead since the main loop: the NEXT tile's h rows stream in under the staging passes and stores below
+            __syncthreads();
+            // the NEXT tile's h rows stream into X under the staging passes and stores below
             __builtin_amdgcn_sched_barrier(0);
             if (tile + (int)gridDim.x < P.tiles) issue_h(tile + gridDim.x);
 #pragma unroll 1
