@@ -10,6 +10,7 @@ walks the frame axis with a stride.  The reference's 3-D `(b h w) f c` token lay
 from __future__ import annotations
 
 import math
+import os
 from typing import Any, Dict, Optional
 
 import torch
@@ -17,7 +18,8 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import hip_ops as K
-from .attention_processor import PoseAdaptorAttnProcessor
+from .attention_processor import (AttnProcessor, LORAPoseAdaptorAttnProcessor, LoRAAttnProcessor, PoseAdaptorAttnProcessor,
+                                  _pose_tokens)
 from .layers import Attention, FeedForward, LayerNorm, f32_param, linear_op
 from .resnet import InflatedGroupNorm
 
@@ -54,6 +56,9 @@ def get_motion_module(in_channels, motion_module_type: str, motion_module_kwargs
     if motion_module_type == "Vanilla":
         return VanillaTemporalModule(in_channels=in_channels, **motion_module_kwargs)
     raise ValueError
+
+
+TEMPORAL_FUSED = os.environ.get("FMC_TEMPORAL_FUSED", "1") != "0"     # A/B switch: the fused temporal attention block kernel (40x64 level)
 
 
 class PositionalEncoding(nn.Module):
@@ -141,8 +146,90 @@ class TemporalTransformerBlock(nn.Module):
         self.ff = FeedForward(dim, dropout=dropout, activation_fn=activation_fn)
         self.ff_norm = LayerNorm(dim)
 
+    # ---- the fused attention block (`fmc_temporal_block_bf16`, round 4) -------------------------------------------------------------------
+    def fused_blocks_ok(self, hidden_states, attention_mask, cross_attention_kwargs) -> bool:
+        """Every attention block of this transformer block can run as ONE launch each (LayerNorm + pe -> [Camera-Adapter merge] -> q | k | v ->
+        attention over the frames -> out-projection + residual): inference, bf16 `[B, 16, P, 320]` tokens with P % 10 == 0, 8 heads, plain /
+        Camera-Adapter / frozen-LoRA processors, nothing applied after the output projection.  Anything else keeps the un-fused chain."""
+        if not TEMPORAL_FUSED or attention_mask is not None or hidden_states.ndim != 4:
+            return False
+        for blk in self.attention_blocks:
+            proc = blk.processor
+            if not isinstance(proc, (AttnProcessor, LoRAAttnProcessor, PoseAdaptorAttnProcessor, LORAPoseAdaptorAttnProcessor)):
+                return False
+            if not K.temporal_block_supported(hidden_states, blk.heads) or blk.inner_dim != hidden_states.shape[-1]:
+                return False
+            if (blk.residual_connection or blk.rescale_output_factor != 1.0 or blk.__dict__.get("_fp8_scales") is not None
+                    or blk.to_q.weight.dtype != torch.bfloat16 or getattr(blk, "is_cross", False)):
+                return False
+            if isinstance(proc, (PoseAdaptorAttnProcessor, LORAPoseAdaptorAttnProcessor)):
+                pf = cross_attention_kwargs.get("pose_feature")
+                if pf is None or not (proc.query_condition and proc.key_value_condition) or proc.qkv_merge.weight.dtype != torch.bfloat16:
+                    return False
+        return True
+
+    def _fused_constants(self, i, frames):
+        """(gamma fp32, beta + pe rows fp32 `[frames, C]`) of attention block i, cached on the block."""
+        norm, enc = self.norms[i], self.attention_blocks[i].pos_encoder
+        g, b = f32_param(norm, "weight"), f32_param(norm, "bias")
+        pe = None if enc is None else enc.table()
+        key = (g.data_ptr(), g._version, b.data_ptr(), b._version, None if pe is None else (pe.data_ptr(), pe._version), frames)
+        hit = self.__dict__.setdefault("_fused_c", {}).get(i)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                bpe = b[None, :].expand(frames, -1) if pe is None else b[None, :] + pe[:frames]
+                hit = (key, g.contiguous(), bpe.float().contiguous())
+            self.__dict__["_fused_c"][i] = hit
+        return hit[1], hit[2]
+
+    def _fused_weights(self, i, lora, lora_scale):
+        attn = self.attention_blocks[i]
+        w_qkv, _, w_o = attn.fused_weights(lora, lora_scale)
+        key = (w_qkv.data_ptr(), w_qkv._version, w_o.data_ptr(), w_o._version)
+        hit = attn.__dict__.get("_fused_tb")
+        if hit is None or hit[0] != key:
+            hit = (key, K.pack_temporal_qkv(w_qkv, attn.heads), K._w_tilemajor(w_o))
+            attn.__dict__["_fused_tb"] = hit
+        return hit[1], hit[2]
+
+    def _forward_fused(self, hidden_states, cross_attention_kwargs):
+        frames = hidden_states.shape[1]
+        h = hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()
+        n_blocks = len(self.attention_blocks)
+        stats = None
+        for i, attn in enumerate(self.attention_blocks):
+            proc = attn.processor
+            lora = proc if isinstance(proc, (LoRAAttnProcessor, LORAPoseAdaptorAttnProcessor)) else None
+            lora_scale = 1.0
+            if lora is not None:
+                from .attention_processor import _require_frozen
+                _require_frozen(proc)
+                s_kw = cross_attention_kwargs.get("scale")
+                lora_scale = proc.lora_scale if s_kw is None else s_kw
+            gamma, bpe = self._fused_constants(i, frames)
+            w_qkv, w_o = self._fused_weights(i, lora, lora_scale)
+            kw = {}
+            if isinstance(proc, (PoseAdaptorAttnProcessor, LORAPoseAdaptorAttnProcessor)):
+                # `merge(h + pose) * s + h` (attention_processor.py:256-258): the pose part s (W pose + b) once per clip, the rest in the kernel
+                s = proc.scale if isinstance(proc, LORAPoseAdaptorAttnProcessor) else (cross_attention_kwargs.get("scale") or proc.scale)
+                pose = _pose_tokens(cross_attention_kwargs["pose_feature"], h)
+                assert pose.shape == h.shape, "pose_feature does not match the hidden states"
+                wm, bm = proc.qkv_merge.weight, proc.qkv_merge.bias
+                kw = dict(w_merge_tm=K._w_tilemajor(wm), pose_term=proc._pose_term(pose, wm, bm, s), merge_scale=s)
+            last = i == n_blocks - 1
+            out = K.temporal_block(h, gamma, bpe, self.norms[i].eps, w_qkv, w_o, attn.to_out[0].bias, attn.scale,
+                                   stats_eps=self.ff_norm.eps if last else None, **kw)
+            h, stats = out if last else (out, None)
+        # the feed-forward's norm is applied by its GEGLU projection from the row statistics the last block left
+        K.ln_epilogue_calls["emitted"] += 1
+        h._fmc_ln = (stats, self.ff_norm._ln_key(None, 1, 1), True)
+        hidden_states, n = self.ff_norm.skip(h, defer=True)
+        return self.ff(n, residual=hidden_states)
+
     def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None,
                 cross_attention_kwargs: Dict[str, Any] = {}):
+        if not torch.is_grad_enabled() and self.fused_blocks_ok(hidden_states, attention_mask, cross_attention_kwargs):
+            return self._forward_fused(hidden_states, cross_attention_kwargs)
         if hidden_states.ndim == 4:
             frames, inner = hidden_states.shape[1], hidden_states.shape[2]
         else:
@@ -216,7 +303,11 @@ class TemporalTransformer3DModel(nn.Module):
                                  self.norm.num_groups, self.norm.eps, False, gn_tag=getattr(hidden_states, "_fmc_gn", None))
         blk0 = self.transformer_blocks[0]
         ln0 = None
-        if not torch.is_grad_enabled():                  # the first block's first norm (+ PE) leaves proj_in's epilogue
+        # (the fused attention blocks normalise their input themselves: proj_in then has no LayerNorm to emit; x stands in for its output here --
+        #  same shape / dtype / device when the inner width equals the channel count, the only case the fused block takes)
+        will_fuse = (not torch.is_grad_enabled() and c == self.proj_in.out_features and x.is_contiguous()
+                     and blk0.fused_blocks_ok(x.view(b, f, h * w, c), attention_mask, cross_attention_kwargs))
+        if not torch.is_grad_enabled() and not will_fuse:   # the first block's first norm (+ PE) leaves proj_in's epilogue
             enc0 = blk0.attention_blocks[0].pos_encoder
             ln0 = blk0.norms[0].ln_spec() if enc0 is None else blk0.norms[0].ln_spec(enc0.table(), h * w, f)
         x = linear_op(x, self.proj_in.weight, self.proj_in.bias, ln=ln0)

@@ -559,3 +559,54 @@ def test_pipeline_end_to_end_with_text_encoder_and_vae(stack):
     assert rel_inf(torch.from_numpy(by_hand), video) < 1e-5
     other = pipe("two dogs", stack["pose_emb"].cuda(), output_type="latent", **common).videos
     assert rel_inf(other, lat) > 1e-3                         # the prompt reaches the U-Net
+
+
+@pytest.mark.gpu
+def test_temporal_transformer_block_fused_kernel_equals_the_unfused_chain():
+    """The motion module's transformer block at the 40x64-level width (C = 320, 8 heads, 16 frames, pixels % 10 == 0) runs its two attention blocks
+    as one `fmc_temporal_block_bf16` launch each (motion_module.TEMPORAL_FUSED); the result must match the un-fused chain (LayerNorm epilogue /
+    merge GEMM / fused QKV GEMM / temporal attention kernel / out-projection) on the same weights -- Camera-Adapter block with a non-zero
+    `qkv_merge` and pose feature, plain second block, feed-forward fed from the row statistics the last fused block leaves -- and the fp32
+    restatement of the reference block (oracle/fmc_modules.py)."""
+    from synfmc_amd.models import motion_module as MM
+    from synfmc_amd.models.attention_processor import AttnProcessor, PoseAdaptorAttnProcessor
+    torch.manual_seed(3)
+    C, H, Fr, P, B = 320, 8, 16, 40, 2
+    blk = MM.TemporalTransformerBlock(dim=C, num_attention_heads=H, attention_head_dim=C // H, attention_block_types=("Temporal_Self", "Temporal_Self"),
+                                      temporal_position_encoding=True, temporal_position_encoding_max_len=32)
+    blk.attention_blocks[0].set_processor(PoseAdaptorAttnProcessor(hidden_size=C, pose_feature_dim=C, query_condition=True, key_value_condition=True,
+                                                                   scale=0.8))
+    blk.attention_blocks[1].set_processor(AttnProcessor())
+    with torch.no_grad():
+        for p in blk.parameters():
+            if p.ndim >= 2:
+                p.normal_(0, p.shape[-1] ** -0.5)
+            else:
+                p.normal_(0, 0.2)
+        for n in list(blk.norms) + [blk.ff_norm]:
+            n.weight.add_(1.0)
+    blk = blk.to("cuda", torch.bfloat16).eval()
+    x = (torch.randn(B, Fr, P, C) * 1.2).to("cuda", torch.bfloat16)
+    pose = torch.randn(B, Fr, P, C).to("cuda", torch.bfloat16)
+    kw = {"pose_feature": pose}
+    with torch.no_grad():
+        assert blk.fused_blocks_ok(x, None, kw)
+        calls = []
+        real = MM.K.temporal_block
+        MM.K.temporal_block = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        try:
+            fused = blk(x, cross_attention_kwargs=kw)
+        finally:
+            MM.K.temporal_block = real
+        assert len(calls) == 2                                           # both attention blocks took the fused kernel
+        MM.TEMPORAL_FUSED = False
+        try:
+            plain = blk(x, cross_attention_kwargs=kw)
+        finally:
+            MM.TEMPORAL_FUSED = True
+        # fp32 reference of the same block (un-fused chain of this package in fp32 storage = the split-bf16 parity mode, checked against the oracle elsewhere)
+        ref = blk.float()(x.float(), cross_attention_kwargs={"pose_feature": pose.float()})
+    assert rel_inf(fused, plain) < 2e-2
+    e_f, e_p = rel_inf(fused, ref), rel_inf(plain, ref)
+    assert e_f < 2e-2 and e_f < 2.0 * e_p + 2e-3, (e_f, e_p)               # the fused kernel is as close to fp32 as the chain it replaces
+    assert not blk.fused_blocks_ok(x[:, :, :39].contiguous(), None, kw)      # pixels % 10 != 0: the un-fused chain
