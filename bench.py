@@ -29,6 +29,9 @@ The JSON line also carries
                   events on the launch stream; peak = 2.5 PFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md);
   roofline_temporal -- the level-0 temporal attention kernel (HBM-bound): algorithmic bytes 4*N*F*H*D*2 / launch time
                   against 8 TB/s;
+  roofline_temporal_block -- the FUSED temporal attention block of a 40x64-level motion module (LayerNorm + Camera-Adapter merge +
+                  q | k | v + attention over the frames + out-projection in one launch): (merge + QKV + core + out) flops / launch time
+                  against the 2.5 PFLOP/s dense bf16 MFMA peak -- the north-star's "MFMA utilisation on temporal attention";
   cpu_baseline -- the oracle (fp32 PyTorch restatement; the reference itself needs diffusers, not installable)
                   timed on this node's host cores on ONE real step of the metric's configuration (no extrapolation).
 """
@@ -251,6 +254,44 @@ def measure_proj_roofline(device, dtype, iters=20):
             "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
             "avg_launch_ms": round(ms, 4), "flops_per_launch": flops, "traffic_algorithmic": 2.0 * (M * Kd + N * Kd + M * N // 2),
             "traffic": None, "traffic_note": "no counter pass for this launch"}
+
+
+def measure_temporal_block_roofline(device, dtype, iters=20):
+    """The north-star's temporal-attention target ("MFMA utilisation on temporal attention"): one launch of the FUSED attention block of a
+    40x64-level motion module exactly as the U-Net issues it (`fmc_temporal_block_bf16`: LayerNorm + pe -> Camera-Adapter merge + pose term ->
+    q | k | v -> attention over the 16 frames -> out-projection + residual; CFG batch 2 x 2560 pixels x 16 frames = 81920 rows, C = 320).
+    Algorithmic flops = 2 M C (C + 3 C + C) [merge, q | k | v, out] + 4 M F C [scores + PV]; HBM-side bytes h + pose term + out."""
+    from synfmc_amd import hip_ops as K
+    B, Fr, hw, C, H = 2, FRAMES, (HEIGHT // 8) * (WIDTH // 8), WIDTHS[0], 8
+    if not (Fr == 16 and C == 320 and hw % 10 == 0):
+        return None
+    h = torch.randn(B, Fr, hw, C, device=device, dtype=dtype)
+    pt = torch.randn(B, Fr, hw, C, device=device, dtype=dtype)
+    g = torch.randn(C, device=device) * 0.2 + 1
+    bpe = torch.randn(Fr, C, device=device)
+    wq = torch.randn(3 * C, C, device=device, dtype=dtype) * C ** -0.5
+    wo = torch.randn(C, C, device=device, dtype=dtype) * C ** -0.5
+    wm = torch.randn(C, C, device=device, dtype=dtype) * C ** -0.5
+    bo = torch.randn(C, device=device, dtype=dtype)
+    wqp, wot, wmt = K.pack_temporal_qkv(wq, H), K._w_tilemajor(wo), K._w_tilemajor(wm)
+    run = lambda: K.temporal_block(h, g, bpe, 1e-5, wqp, wot, bo, (C // H) ** -0.5, w_merge_tm=wmt, pose_term=pt, merge_scale=1.0)
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    M = B * Fr * hw
+    flops = 2.0 * M * C * 5 * C + 4.0 * M * Fr * C
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": f"temporal_block_kernel<merge> (fused LN + merge + qkv + attention + out-projection, bf16) [{B}x{Fr}x{hw}x{C}]",
+            "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+            "avg_launch_ms": round(ms, 4), "flops_per_launch": flops, "traffic_algorithmic": 3.0 * M * C * 2,
+            "traffic": None, "traffic_note": "no counter pass for this launch yet",
+            "replaces": "LayerNorm epilogue + merge GEMM + fused QKV GEMM + temporal_attn_kernel + out-projection GEMM (4 launches, ~790 MB of HBM traffic)"}
 
 
 def unet_flops(batch, h, w, executed=False, config="obj"):
@@ -843,6 +884,7 @@ def main():
         roof_conv = measure_conv_roofline(device, dtype) if bf else None
         roof_temp = measure_temporal_roofline(device, dtype) if bf else None
         roof_proj = measure_proj_roofline(device, dtype) if bf else None
+        roof_tb = measure_temporal_block_roofline(device, dtype) if bf else None
         f_ref = unet_flops(2, HEIGHT // 8, WIDTH // 8, config=cfg)
         f_exec = unet_flops(2, HEIGHT // 8, WIDTH // 8, executed=True, config=cfg)
         if cfg_shared:                                  # one clip's worth of conv_in, ResNet block 0, proj_in, QKV, self-attention, out-projection
@@ -869,7 +911,8 @@ def main():
             "unet_tflop_per_step_reference_graph": round(f_ref / 1e12, 3),
             "executed_tflops_per_gpu": round(f_exec / 1e12 / (ms * 1e-3), 1),
             "conditioning_once_per_clip_ms": round(cond_ms, 2),
-            "roofline": roof, "roofline_conv": roof_conv, "roofline_temporal": roof_temp, "roofline_proj": roof_proj, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_conv": roof_conv, "roofline_temporal": roof_temp, "roofline_temporal_block": roof_tb, "roofline_proj": roof_proj,
+            "cpu_baseline": cpu,
         }
         if loop50_s is not None:
             out["ddim_50_step_loop_s"] = round(loop50_s, 3)

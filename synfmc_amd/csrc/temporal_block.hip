@@ -183,6 +183,27 @@ void temporal_block_kernel(const TBParams P) {
         }
     };
     auto issue_h = [&](int t) { issue_rows(rsH, t, 0, TB_ROWS, X); };
+    // epilogue side operand (pose term) of pass p = the rows of accumulator block mb = p of BOTH wave rows (tile rows 16 p .. and 80 + 16 p ..): 32 rows
+    // = one 20-KiB ring buffer, rows 0-15 / 16-31, X's swizzle.  20 one-KiB pieces: 3 from waves 0-3, 2 from waves 4-7.
+    auto issue_pass = [&](const __amdgpu_buffer_rsrc_t& rs, int t, int pss, int buf) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int clip = t / n_tiles_per_clip, p0 = (t - clip * n_tiles_per_clip) * TB_PIX;
+        const unsigned row0 = (unsigned)(((int64_t)clip * TB_F * P.hw + p0) * TB_C), fstride = (unsigned)(P.hw * TB_C);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int q = wave + 8 * j;
+            if (q < 20) {
+                const int idx = 64 * q + ln, rl = idx / 40, pc = idx - rl * 40, r = (rl < 16 ? 16 * pss + rl : 64 + 16 * pss + rl), c = pc ^ ((r >> 1) & 7);
+                const unsigned src = (row0 + (unsigned)(r & 15) * fstride + (unsigned)(r >> 4) * TB_C + (unsigned)c * 8) * 2;
+                tb_dma(rs, src, 0, RING + buf * TB_SUB + 64 * q * 8);
+            }
+        }
+    };
+#define TB_VMCNT2(a, b)                                                                                                  \
+    do {                                                                                                                 \
+        if (wave < 4) TB_VMCNT(a); else TB_VMCNT(b);                                                                     \
+    } while (0)
     if ((int)blockIdx.x < P.tiles) issue_h(blockIdx.x);
     float* stats = reinterpret_cast<float*>(smem_raw + TB_X_ELEMS * 2 + 53248);      // (mean, rstd) x 160 rows: behind the epilogue's staging rows in the ring region
 
@@ -294,37 +315,44 @@ void temporal_block_kernel(const TBParams P) {
             for (int g = 0; g < 10; ++g) {
                 read_frags(g, g % 3);
                 if (g + 2 < 10) issue_w(rsWM, g + 2, (g + 2) % 3);
-                if (g < 8) TB_VMCNT(4); else TB_VMCNT(0);         // retires sub-tile g + 1, the one just requested stays in flight
+                // the ring buffers the weight stream no longer needs take the first pose-term passes (same rule as the stream: the buffer read at LOAD(g - 1))
+                if (g == 8) issue_pass(rsPT, tile, 0, 1);
+                if (g == 9) issue_pass(rsPT, tile, 1, 2);
+                if (g < 8) TB_VMCNT(4);                           // retires sub-tile g + 1, the one just requested stays in flight
+                else if (g == 8) TB_VMCNT2(3, 2);                 // sub-tile 9; my pieces of pass 0 stay in flight
                 TB_MMA();
             }
             if (wr == 0) __builtin_amdgcn_s_barrier();            // the wave rows meet again: every fragment read of x is done, the ring is free
             __builtin_amdgcn_sched_barrier(0);
-            // m = s acc + pose term + x, in place.  The pose-term rows of one wave row at a time arrive in the ring by LDS-DMA (whole 640-byte rows,
-            // X's swizzle) and are picked up in accumulator layout from there: as 25 eight-byte global loads per lane they cost the texture
-            // path 16 quarter-lines per instruction (3 us of an epilogue of 6.7) -- or, requested under the main loop, 50 live registers that spill
-#pragma unroll 1
-            for (int pass = 0; pass < 2; ++pass) {
-                issue_rows(rsPT, tile, 80 * pass, 80, RING);
-                TB_VMCNT(0);
-                __syncthreads();
-                if (wr == pass) {
+            issue_pass(rsPT, tile, 2, 0);
+            // m = s acc + pose term + x, in place, accumulator block row by block row (pass p = block mb = p of both wave rows).  The pose-term rows
+            // arrive in the ring by LDS-DMA (whole 640-byte rows) three passes ahead and are picked up in accumulator layout: as 25 eight-byte
+            // global loads per lane they cost the texture path 16 quarter-lines per instruction (3 us of the epilogue), requested under the main
+            // loop 50 live registers that spill; as two 80-row passes behind the loop their latency was exposed twice (epilogue 9 us).
 #pragma unroll
-                    for (int mb = 0; mb < 5; ++mb) {
-                        const int rl = mb * 16 + l15;             // row inside the wave row; tile row = 80 pass + rl (same swizzle: 80 / 2 = 0 mod 8)
+            for (int pss = 0; pss < 5; ++pss) {
+                // queue (oldest first): pass pss, pss + 1, pss + 2 (where they exist)
+                if (pss == 0) TB_VMCNT2(6, 4);
+                else if (pss < 4) TB_VMCNT2(3, 2);
+                else TB_VMCNT(0);
+                __syncthreads();                                  // pass pss published; everybody is done with pass pss - 1
+                if (pss >= 1 && pss + 2 < 5) issue_pass(rsPT, tile, pss + 2, (pss + 3) % 3);      // into the buffer pass pss - 1 has just left
+                {
+                    const bf16_t* Pt = RING + ((pss + 1) % 3) * TB_SUB + (wr * 16 + l15) * TB_C;
+                    bf16_t* Xr = X + (wr * 80 + pss * 16 + l15) * TB_C;
 #pragma unroll
-                        for (int nb = 0; nb < 5; ++nb) {
-                            const int col = ecol + nb * 16, off = rl * TB_C + (((col >> 3) ^ xsw) << 3) + (col & 7);
-                            u32x2* px = reinterpret_cast<u32x2*>(X + pass * 80 * TB_C + off);
-                            float xv[4], pv[4];
-                            unpack4(*px, xv);
-                            unpack4(*reinterpret_cast<const u32x2*>(RING + off), pv);
-                            *px = u32x2{pack_bf2(acc[mb][nb][0] * P.merge_scale + pv[0] + xv[0], acc[mb][nb][1] * P.merge_scale + pv[1] + xv[1]),
-                                        pack_bf2(acc[mb][nb][2] * P.merge_scale + pv[2] + xv[2], acc[mb][nb][3] * P.merge_scale + pv[3] + xv[3])};
-                        }
+                    for (int nb = 0; nb < 5; ++nb) {
+                        const int col = ecol + nb * 16, off = (((col >> 3) ^ xsw) << 3) + (col & 7);
+                        u32x2* px = reinterpret_cast<u32x2*>(Xr + off);
+                        float xv[4], pv[4];
+                        unpack4(*px, xv);
+                        unpack4(*reinterpret_cast<const u32x2*>(Pt + off), pv);
+                        *px = u32x2{pack_bf2(acc[pss][nb][0] * P.merge_scale + pv[0] + xv[0], acc[pss][nb][1] * P.merge_scale + pv[1] + xv[1]),
+                                    pack_bf2(acc[pss][nb][2] * P.merge_scale + pv[2] + xv[2], acc[pss][nb][3] * P.merge_scale + pv[3] + xv[3])};
                     }
                 }
-                __syncthreads();                                  // (pass 0: the ring rows may be overwritten; pass 1: X = m)
             }
+            __syncthreads();                                      // X = m
         }
 
         TB_STAMP(3);
@@ -370,17 +398,28 @@ void temporal_block_kernel(const TBParams P) {
                 asm volatile("" : "+v"(kqx), "+v"(xrow_o));        // (see read_frags: no address of a later step may be computed ahead and spilled)
                 const int xo = xrow_o + ((ks >> 1) * 8 + (((ks & 1) * 4) ^ kqx)) * 8;
                 __builtin_amdgcn_sched_barrier(0);                // (keeps later k-steps' fragment reads from being hoisted over this one: registers)
+                // the pixel blocks' A fragments through a 3-register-set pipeline: the read of block m + 2 is issued in front of the MFMAs of block m
+                // (left to itself hipcc reads one fragment, waits lgkmcnt(0), issues its 3 MFMAs, reads the next: the LDS latency of every block exposed)
+                constexpr int NBK = part == 1 ? 2 : 3;
+                u32x4 af3[3];
+                af3[0] = *reinterpret_cast<const u32x4*>(X + 0 * 16 * TB_C + xo);
+                af3[1] = *reinterpret_cast<const u32x4*>(X + 1 * 16 * TB_C + xo);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // (the two leading reads first)
 #pragma unroll
                 for (int m = 0; m < 10; ++m) {
+                    if (m + 2 < 10) af3[(m + 2) % 3] = *reinterpret_cast<const u32x4*>(X + (m + 2) * 16 * TB_C + xo);
                     union { bf16x8 v; u32x4 u; } a;
-                    a.u = *reinterpret_cast<const u32x4*>(X + m * 16 * TB_C + xo);
+                    a.u = af3[m % 3];
 #pragma unroll
-                    for (int b = 0; b < (part == 1 ? 2 : 3); ++b) {
+                    for (int b = 0; b < NBK; ++b) {
                         union { bf16x8 v; u32x4 u; } w;
                         w.u = wq[s % 3][b];
                         if constexpr (part < 2) pacc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, a.v, pacc[m][b], 0, 0, 0);   // (frame l15, 4 channels)
                         else pacc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, w.v, pacc[m][b], 0, 0, 0);                     // (channel l15, 4 frames)
                     }
+                    // one LDS read, then this block's MFMAs: pins the interleave (mask 0x100 = DS read, 0x008 = MFMA)
+                    if (m + 2 < 10) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, NBK, 0);
                 }
             };
 #define TB_STEP(PART, KS) step(std::integral_constant<int, PART>{}, std::integral_constant<int, KS>{})
