@@ -5,7 +5,7 @@ is pinned by the reference at `environment.yaml:13` but is not vendored, not
 installed in this image and cannot be fetched; the reference holds no tests or
 golden vectors for it.  Every class below restates the *published* 0.24.0
 behaviour in plain fp32 PyTorch and cites the reference
-call site that relies on it.  `tests/test_oracle_primitives.py` cross-checks
+call site that relies on it.  `tests/test_cpu_misc.py` (`test_attention_matches_sdpa` .. `test_positional_encoding_added_after_layernorm`) cross-checks
 them against torch built-ins (`F.scaled_dot_product_attention`, `F.group_norm`,
 `F.gelu`, closed-form DDIM).
 
