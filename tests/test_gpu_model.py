@@ -169,7 +169,7 @@ def test_camera_ctrl_pipeline_cmc_only(stack, use_graph):
     assert rel_inf(out, ref) < 1e-2
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-3), (torch.bfloat16, 1.5e-1)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 6e-2)])     # (2x / 5x the measured 2.9e-2 / 2.0e-5: gpurun_out/r04f/grad.log)
 def test_stage3_training_gradients(stack, dtype, tol):
     """OMC-stage training step: Adapter gradients through the frozen U-Net.  Exercises every backward kernel
     (GroupNorm+SiLU, LayerNorm, GEGLU, spatial self/cross attention, temporal attention, mask modulate, feature add)
@@ -188,6 +188,7 @@ def test_stage3_training_gradients(stack, dtype, tol):
         l_got, g_got = TC.product_grads(pu, pe, pa, clip, stack["pose_emb"], t, noise, "cuda", dtype)
     assert abs(float(l_ref) - float(l_got)) < (1e-4 if dtype == torch.float32 else 2e-2) * abs(float(l_ref))
     err, scale = TC.compare(g_ref, g_got)
+    print(f"gradient rel-inf vs the oracle's autograd ({dtype}): {err:.3e} (tolerance {tol})")
     assert scale > 0 and err < tol
 
 
@@ -213,6 +214,7 @@ def test_stage2_training_gradients(stack, dtype, tol):
     assert enc and mrg
     for part in (enc, mrg):
         err, scale = TC.compare(part, g_got)
+        print(f"stage-2 gradient rel-inf vs the oracle's autograd ({dtype}, {next(iter(part))[:5]}..): {err:.3e} (tolerance {tol})")
         assert scale > 0 and err < tol
 
 
@@ -248,6 +250,7 @@ def test_frames32_forward_and_training(dtype, tol, gtol):
         l_got, g_got = TC.product_grads(pu, pe, pa, clip, pose_emb, t, noise, "cuda", dtype)
     assert abs(float(l_ref) - float(l_got)) < (1e-4 if dtype == torch.float32 else 2e-2) * abs(float(l_ref))
     err, scale = TC.compare(g_ref, g_got)
+    print(f"gradient rel-inf vs the oracle's autograd ({dtype}): {err:.3e} (tolerance {gtol})")
     assert scale > 0 and err < gtol
 
 
@@ -403,6 +406,7 @@ def test_lora_pose_adaptor_processor_forward_and_gradients(stack, dtype, tol, gt
         l_got, g_got = TC.product_grads(pu, pe, pa, clip, stack["pose_emb"], t, noise, "cuda", dtype)
     assert abs(float(l_ref) - float(l_got)) < (1e-4 if dtype == torch.float32 else 2e-2) * abs(float(l_ref))
     err, scale = TC.compare(g_ref, g_got)
+    print(f"gradient rel-inf vs the oracle's autograd ({dtype}): {err:.3e} (tolerance {gtol})")
     assert scale > 0 and err < gtol
 
 
