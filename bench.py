@@ -97,7 +97,7 @@ def build_models(device, dtype, config="obj"):
     from synfmc_amd.models.pose_adaptor import CameraPoseEncoder
     from synfmc_amd.models.unet import UNet3DConditionModel, UNet3DConditionModelCamObjCond, UNet3DConditionModelPoseCond
     from synfmc_amd.modified_modules import patch_unet_for_omc
-    from tests import common_models as CM
+    from synfmc_amd import configs as CM
     enc = ada = None
     with torch.device(device):
         if config == "lora":
@@ -120,7 +120,7 @@ def build_models(device, dtype, config="obj"):
 
 
 def synthetic_inputs(rank, device):
-    from tests import common_models as CM
+    from synfmc_amd import configs as CM
     clip = CM.synthetic_clip(B=1, Fr=FRAMES, H=HEIGHT, W=WIDTH, n_obj=3, cross_dim=CROSS_DIM, seed=1234 + rank)
     g = torch.Generator().manual_seed(99 + rank)
     uncond = torch.randn(1, 77, CROSS_DIM, generator=g)
@@ -300,7 +300,7 @@ def unet_flops(batch, h, w, executed=False, config="obj"):
     LoRA merged into the projection weights, text K/V projected once per CLIP."""
     from torch.utils.flop_counter import FlopCounterMode
     from oracle import fmc_modules as OM
-    from tests import common_models as CM
+    from synfmc_amd import configs as CM
     with torch.device("meta"):
         u = OM.UNet3DConditionModelCamObjCond(**CM.unet_kwargs(WIDTHS, CROSS_DIM))
         u.set_all_attn_processor(**CM.processor_kwargs(WIDTHS, lora=not executed, temporal=config != "lora"))
@@ -376,7 +376,7 @@ def oracle_step(unet, enc, ada, clip, text2, latents, t, want_config1=True, conf
     from einops import rearrange
     from oracle import conditioning as OC
     from oracle import fmc_modules as OM
-    from tests import common_models as CM
+    from synfmc_amd import configs as CM
     # oneDNN / OpenMP scaling collapses far below the 256 hardware threads of the GPU node (same 16x128x192 sample: 2.3 s on
     # 8 threads, 1.6 s on 16, 2.6 s on 32, 5.6 s on 64, 427 s on 256), so the port runs on a fixed, stated number of threads
     cores = min(os.cpu_count() or 1, int(os.environ.get("FMC_CPU_BASELINE_THREADS", "16")))
@@ -546,7 +546,7 @@ def train_main(args):
     from synfmc_amd.util import stack_object_inputs
     from synfmc_amd import hip_ops as K
     from synfmc_amd.models.pose_adaptor import features_to_video
-    from tests import training_common as TC
+    from synfmc_amd import configs as TC
     unet, enc, ada = build_models(device, dtype)
     ada = ada.float().requires_grad_(True)                  # fp32 master weights for the trainable Adapter
     if args.fp8_temporal:

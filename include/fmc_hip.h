@@ -439,7 +439,7 @@ int fmc_temporal_block_bf16(const void* h, void* out, const float* ln_gamma, con
                             float* ln_stats, float ln_stats_eps, int n_clips, int frames, int hw, int channels, int heads, float scale,
                             void* stream);
 /* Diagnostic: `buf` = device buffer of [workgroups][4][8] int64 that receives s_memrealtime stamps (100 MHz) of wave 0 at the phase boundaries of
- * its first four tiles (tools/r04/probe_tb.py); NULL switches the stamps off (default). */
+ * its first four tiles (tools/scratch/r04/probe_tb.py); NULL switches the stamps off (default). */
 int fmc_temporal_block_set_debug(void* buf);
 
 #ifdef __cplusplus

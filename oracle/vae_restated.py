@@ -100,3 +100,59 @@ class AutoencoderKLDecoderOnly(nn.Module):
 
     def decode(self, z):
         return self.decoder(self.post_quant_conv(z))
+
+
+# ---- encoder half (round 4): diffusers models/vae.py `Encoder(double_z=True)`, models/unet_2d_blocks.py `DownEncoderBlock2D`, models/resnet.py
+# `Downsample2D(use_conv=True, padding=0)` (pads (0, 1, 0, 1), then 3x3 stride 2), `DiagonalGaussianDistribution`; reached from
+# `train_cam_obj_ctrl.py:786` / `train_cam_ctrl.py:544` (`vae.encode(pixel_values).latent_dist.sample() * 0.18215`).  PARITY UNPINNED like the decoder.
+class Down(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, stride=2, padding=0)
+
+    def forward(self, x):
+        return self.conv(F.pad(x, (0, 1, 0, 1), mode="constant", value=0))
+
+
+class DownBlock(nn.Module):
+    def __init__(self, cin, cout, layers, down, groups):
+        super().__init__()
+        self.resnets = nn.ModuleList([Resnet(cin if i == 0 else cout, cout, groups) for i in range(layers)])
+        self.downsamplers = nn.ModuleList([Down(cout)]) if down else None
+
+    def forward(self, x):
+        for r in self.resnets:
+            x = r(x)
+        return x if self.downsamplers is None else self.downsamplers[0](x)
+
+
+class Encoder(nn.Module):
+    def __init__(self, cin=3, latent=4, widths=(128, 256, 512, 512), layers_per_block=2, groups=32):
+        super().__init__()
+        self.conv_in = nn.Conv2d(cin, widths[0], 3, padding=1)
+        blocks, prev = [], widths[0]
+        for i, c in enumerate(widths):
+            blocks.append(DownBlock(prev, c, layers_per_block, i != len(widths) - 1, groups))
+            prev = c
+        self.down_blocks = nn.ModuleList(blocks)
+        self.mid_block = Mid(prev, groups)
+        self.conv_norm_out = nn.GroupNorm(groups, prev, eps=1e-6)
+        self.conv_out = nn.Conv2d(prev, 2 * latent, 3, padding=1)
+
+    def forward(self, x):
+        x = self.conv_in(x)
+        for b in self.down_blocks:
+            x = b(x)
+        return self.conv_out(F.silu(self.conv_norm_out(self.mid_block(x))))
+
+
+class AutoencoderKLFull(AutoencoderKLDecoderOnly):
+    def __init__(self, widths=(128, 256, 512, 512), layers_per_block=2, groups=32, latent_channels=4):
+        super().__init__(widths, layers_per_block, groups, latent_channels)
+        self.encoder = Encoder(3, latent_channels, widths, layers_per_block, groups)
+        self.quant_conv = nn.Conv2d(2 * latent_channels, 2 * latent_channels, 1)
+
+    def encode_moments(self, x):
+        """(mean, logvar clamped to [-30, 20]) of the posterior."""
+        mean, logvar = self.quant_conv(self.encoder(x)).chunk(2, dim=1)
+        return mean, logvar.clamp(-30.0, 20.0)

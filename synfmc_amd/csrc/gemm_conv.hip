@@ -1434,7 +1434,7 @@ __device__ __forceinline__ void gn_tile_finish(const GemmParams& P, float* red, 
 // both wave rows (WAR safe with a phase to spare); `vmcnt(8)` at the end of LOAD(g) retires sub-tile g + 1, the barrier publishes it,
 // LOAD(g + 1) reads it (a wave reads DMA'd data one phase after the wait that retired it).  Past the end of K the stream wraps to
 // valid addresses so the count stays exact.
-// What bounds the loop (measured, tools/probe_g160_dbg*.py + tools/ubench/cu_bw): the DMA instruction stream.  With the 32 DMA
+// What bounds the loop (measured, tools/scratch/probe_g160_dbg*.py + tools/ubench/cu_bw): the DMA instruction stream.  With the 32 DMA
 // instructions per sub-tile and CU taken out, the conv 32x20x32 640->640 launch drops from 222 to 113 us; with them in but pointed out of
 // range (no memory traffic at all) it stays at 194; the stream alone (no MFMA, no ds_read, no barrier, no wait) takes 221 us on 8
 // workgroups and on 256.  So it is neither HBM / Infinity Cache / L2 bandwidth nor latency, but ~15 ns per `buffer_load ... lds` wave
@@ -2486,7 +2486,7 @@ void launch_gemm8(GemmParams& P, hipStream_t st) {
     if (P.sk && P.sk_lock) {
         // k-lockstep split: S chunks per tile, unit = (chunk, tile); S = the caller's (split_k <= -16) or the cheapest by a small model:
         // rounds x (chunk length x 1.9 us per 64-deep k-tile + 4 us of prologue / partial store) + 0.06 us of finishing traffic per unit
-        // (constants fitted to tools/r04/probe_lock.py: profiles/r04_probe_lock.txt)
+        // (constants fitted to tools/scratch/r04/probe_lock.py: profiles/r04_probe_lock.txt)
         const int g = fmc_cu_count() & ~7, nkt = P.K / 64;
         int S = P.sk_lock > 1 ? P.sk_lock : 0;
         if (!S) {

@@ -1553,7 +1553,7 @@ GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 11,     # 8..10, 12 (4-stage rings) exist but
               13,                            # the 8-phase 256x256 kernel (staggered wave rows, half-tile DMA, counted vmcnt)
               15,                            # K = 320 token projections: persistent, weights resident in registers (falls back to 5 elsewhere)
               ARM_160B if W_TILEMAJOR else ARM_160,   # 160 x 320 tiles (whole rounds / no padded columns for N = 320 k; falls back to 13 elsewhere), reading the weight
-                                             # pre-packed tile-major (bit-identical to ARM_160, -1 .. -5 % per launch: tools/probe_wtm.py)
+                                             # pre-packed tile-major (bit-identical to ARM_160, -1 .. -5 % per launch: tools/scratch/probe_wtm.py)
               128 + 2, 128 + 3,              # stream-K (persistent workgroups) on the two 1-per-CU geometries
               128 + 13,                      # stream-K on the 8-phase kernel: persistent partial pass + one finishing workgroup per tile
               256 + 13,                      # the same for the LAST PARTIAL ROUND of tiles only, the whole rounds on the plain grid
@@ -1561,7 +1561,7 @@ GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 11,     # 8..10, 12 (4-stage rings) exist but
 if os.environ.get("FMC_GEMM_ARMS"):              # A/B switch: the arm list the autotuner may choose from, e.g. "1,2,3,11"
     GEMM_TILES = tuple(int(a) for a in os.environ["FMC_GEMM_ARMS"].split(","))
 # fmc_linear_bf16 / fmc_conv3x3_bf16 `tile` arms tried per shape (14 = arm 13 with a deeper prefetch measured no better anywhere,
-# tools/probe_g8.py)
+# tools/scratch/probe_g8.py)
 
 
 def autotune_report():
@@ -1714,7 +1714,7 @@ def geglu_linear(x: torch.Tensor, weight: torch.Tensor, bias, weight_il: torch.T
             return linear_bf16(x, weight_il160, bias_il160, geglu=True, tile=tile) if has160 else linear_bf16(x, weight_il, bias_il, geglu=True, tile=13)
         return linear_bf16(x, weight_il, bias_il, geglu=True, tile=tile)
     # (ARM_256, the persistent 256 x 320 form, is selectable but not a candidate: measured 235 / 153 / 134 us against ARM_160's 203 / 153 / 130 us on
-    #  the three U-Net levels, tools/probe_g256.py -- DESIGN.md section 6, round 3.  FMC_GEMM_ARMS=...,528 offers it.)
+    #  the three U-Net levels, tools/scratch/probe_g256.py -- DESIGN.md section 6, round 3.  FMC_GEMM_ARMS=...,528 offers it.)
     use = _pick(("geglu", M, N, Kd), hip, lib, M >= 65536)
     return lib() if use == 0 else hip(max(use, 0))
 

@@ -8,39 +8,7 @@ import torch
 from oracle import conditioning as OC
 from oracle import fmc_modules as OM
 
-MMK = dict(num_attention_heads=8, num_transformer_block=1, attention_block_types=["Temporal_Self", "Temporal_Self"],
-           temporal_position_encoding=True, temporal_position_encoding_max_len=32, temporal_attention_dim_div=1,
-           zero_initialize=False)
-
-
-def unet_kwargs(widths=(64, 128, 256, 256), cross_dim=64, motion=True):
-    cfg = dict(OM.SD15_UNET_CONFIG)
-    cfg.update(block_out_channels=tuple(widths), cross_attention_dim=cross_dim, sample_size=16)
-    cfg.update(use_motion_module=motion, motion_module_resolutions=[1, 2, 4, 8], motion_module_mid_block=False,
-               motion_module_type="Vanilla", motion_module_kwargs=copy.deepcopy(MMK))
-    return cfg
-
-
-def processor_kwargs(widths, lora=True, temporal=True, motion_lora=False):
-    """configs/obj.yaml / cam.yaml processor layout.  `temporal=False`: the Domain-LoRA-only model of BASELINE
-    configs[1] (LoRA on attn1 / attn2, plain temporal attention).  `motion_lora=True`: `LORAPoseAdaptorAttnProcessor`
-    (Camera Adapter + LoRA, rank C/4) on the temporal attention."""
-    return dict(add_spatial=False, spatial_attn_names="attn1", add_temporal=temporal, temporal_attn_names="0",
-                add_spatial_lora=lora, add_motion_lora=motion_lora,
-                lora_kwargs={"lora_rank": 2, "lora_scale": 1.0},
-                motion_lora_kwargs={"lora_rank": 4 if motion_lora else -1, "lora_scale": 1.0},
-                pose_feature_dimensions=list(widths), query_condition=True, key_value_condition=True, scale=1.0)
-
-
-def encoder_kwargs(widths, max_len=16):
-    return dict(downscale_factor=8, channels=list(widths), nums_rb=2, cin=384, ksize=1, sk=True, use_conv=False,
-                compression_factor=1, temporal_attention_nhead=8, attention_block_types=["Temporal_Self"],
-                temporal_position_encoding=True, temporal_position_encoding_max_len=max_len)
-
-
-def adapter_kwargs(widths):
-    return dict(channels=list(widths), nums_rb=2, cin=832, sk=True, use_conv=False, use_pre_zero_conv=True,
-                use_post_zero_conv=True)
+from synfmc_amd.configs import (MMK, adapter_kwargs, encoder_kwargs, processor_kwargs, synthetic_clip, unet_kwargs)  # noqa: E402,F401
 
 
 def reseed(module, seed, std=0.05, fan_in_gain=None):
@@ -111,43 +79,6 @@ def build_product(oracle_unet, oracle_enc, oracle_ada, widths=(64, 128, 256, 256
         ada.load_state_dict(oracle_ada.state_dict(), strict=True)
         ada = ada.to(device=device, dtype=dtype).eval().requires_grad_(False)
     return unet, enc, ada
-
-
-def synthetic_clip(B=1, Fr=16, H=128, W=128, n_obj=3, cross_dim=64, seed=100):
-    """SURVEY.md section 8d synthetic inputs: latents, text, smooth relative camera trajectory, intrinsics,
-    per-object relative poses and Gaussian circle masks."""
-    g = torch.Generator().manual_seed(seed)
-    rng = np.random.default_rng(seed)
-    latents = torch.randn(B, 4, Fr, H // 8, W // 8, generator=g)
-    text = torch.randn(B, 77, cross_dim, generator=g)
-    c2w = np.zeros((B, Fr, 3, 4), dtype=np.float32)
-    for b in range(B):
-        ang, t = np.zeros(3), np.zeros(3)
-        for f in range(Fr):
-            if f:
-                ang += rng.normal(0, 0.02, 3)
-                t += rng.normal(0, 0.03, 3)
-            cx, cy, cz = np.cos(ang)
-            sx, sy, sz = np.sin(ang)
-            Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
-            Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
-            Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
-            c2w[b, f, :, :3] = Rz @ Ry @ Rx
-            c2w[b, f, :, 3] = t
-    K = torch.tensor([float(W), float(W), W / 2.0, H / 2.0]).view(1, 1, 4).repeat(B, Fr, 1)
-    infos, masks = [], []
-    for b in range(B):
-        ctr = rng.uniform([W * 0.25, H * 0.25], [W * 0.75, H * 0.75], size=(n_obj, 2))
-        rad = rng.uniform(min(H, W) * 0.12, min(H, W) * 0.3, size=n_obj)
-        fi, fm = [], []
-        for f in range(Fr):
-            ctr = ctr + rng.normal(0, 1.5, size=ctr.shape)
-            fm.append(torch.from_numpy(np.stack(
-                [OC.gaussian_circle_mask(H, W, ctr[o], rad[o])[None] for o in range(n_obj)])).float())
-            fi.append(rng.normal(0, 0.5, size=(n_obj, 12)))
-        infos.append(fi)
-        masks.append(fm)
-    return dict(latents=latents, text=text, c2w=torch.from_numpy(c2w), K=K, infos=infos, masks=masks)
 
 
 class bf16_rounding:

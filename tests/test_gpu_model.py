@@ -501,6 +501,33 @@ def test_vae_decoder_matches_restatement(dtype, tol):
     assert got.shape == (3, 3, 128, 192) and rel_inf(got, want) < tol
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
+def test_vae_encoder_matches_restatement(dtype, tol):
+    """`AutoencoderKL.encode(x).latent_dist` (train_cam_obj_ctrl.py:786) against the plain-PyTorch restatement of diffusers' encoder: the
+    posterior's mean / clamped logvar, `sample()` = mean + std * noise of the given generator, `mode()`; the asymmetric-pad stride-2
+    downsamplers run on the implicit-GEMM kernel's stride-2 mode over a shifted copy (vae._Downsample); full state dict loads strictly."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import vae_restated as OV
+    from synfmc_amd.models.vae import AutoencoderKL
+    widths = (64, 128, 128, 128)
+    ref = CM.reseed(OV.AutoencoderKLFull(widths), 73, fan_in_gain=1.0).eval()
+    vae = AutoencoderKL(block_out_channels=widths)
+    vae.load_state_dict(ref.state_dict(), strict=True)
+    vae = vae.to("cuda", dtype).eval().requires_grad_(False)
+    x = torch.rand(2, 3, 128, 192, generator=torch.Generator().manual_seed(74)) * 2 - 1
+    with torch.no_grad():
+        mean, logvar = ref.encode_moments(x)
+        dist = vae.encode(x.cuda()).latent_dist
+    assert dist.mean.shape == (2, 4, 16, 24)
+    assert rel_inf(dist.mean, mean) < tol and rel_inf(dist.logvar, logvar) < tol
+    g = torch.Generator(device="cuda").manual_seed(5)
+    smp = dist.sample(g)
+    noise = torch.randn(dist.mean.shape, generator=torch.Generator(device="cuda").manual_seed(5), device="cuda", dtype=torch.float32)
+    assert rel_inf(smp.float(), dist.mean + dist.std * noise) < (1e-6 if dtype == torch.float32 else 1e-2)
+    assert torch.equal(dist.mode().float(), dist.mean.to(dtype).float())
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 4e-2)])
 def test_clip_text_encoder_matches_transformers(dtype, tol):
     """`CLIPTextModel` against the real `transformers.CLIPTextModel` (random init, state dict copied over)."""

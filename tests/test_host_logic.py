@@ -395,8 +395,8 @@ def test_pipeline_without_classifier_free_guidance(stack, fake):
 
 def test_vae_and_clip_state_dict_keys():
     """f4: `synfmc_amd.models.clip_text.CLIPTextModel` carries exactly `transformers.CLIPTextModel`'s keys (and accepts the `text_model.`-prefixed
-    form of older checkpoints); `synfmc_amd.models.vae.AutoencoderKL` carries the decoder-side keys of diffusers' AutoencoderKL as the restated
-    oracle lists them, and drops the encoder half of a full checkpoint."""
+    form of older checkpoints); `synfmc_amd.models.vae.AutoencoderKL` carries the keys of diffusers' AutoencoderKL as the restated
+    oracle lists them (encoder, quant_conv, post_quant_conv, decoder); `load_decoder_state_dict` reads only the decoder half."""
     import transformers
     from oracle import vae_restated as OV
     from synfmc_amd.models.clip_text import CLIPTextConfig, CLIPTextModel
@@ -411,13 +411,19 @@ def test_vae_and_clip_state_dict_keys():
     real = CLIPTextModel(CLIPTextConfig(**kw))
     real.load_state_dict({"text_model." + k: v for k, v in real.state_dict().items()}, strict=True)      # transformers-4.x style keys
     widths = (64, 64, 128, 128)
-    ov = OV.AutoencoderKLDecoderOnly(widths)
+    ov = OV.AutoencoderKLFull(widths)
     vae = AutoencoderKL(block_out_channels=widths)
     assert {k: tuple(v.shape) for k, v in vae.state_dict().items()} == {k: tuple(v.shape) for k, v in ov.state_dict().items()}
-    full = dict(ov.state_dict())
-    full["encoder.conv_in.weight"] = torch.zeros(1)
+    vae.load_state_dict(ov.state_dict(), strict=True)                       # a full checkpoint loads key for key
+    dec_only = {k: v for k, v in OV.AutoencoderKLDecoderOnly(widths).state_dict().items()}
+    assert all(k.startswith(("decoder.", "post_quant_conv.")) for k in dec_only)
+    vae.load_decoder_state_dict(dec_only, strict=True)                      # a decoder-only checkpoint leaves the encoder half as it is
+    full = dict(dec_only)
+    full["encoder.conv_in.weight"] = torch.zeros(1)                         # encoder keys of a full checkpoint are ignored by this loader
     full["quant_conv.weight"] = torch.zeros(1)
     vae.load_decoder_state_dict(full, strict=True)
+    for k in ("encoder.down_blocks.0.downsamplers.0.conv.weight", "encoder.mid_block.attentions.0.to_q.weight", "quant_conv.bias"):
+        assert k in vae.state_dict()
     for k in ("decoder.mid_block.attentions.0.to_q.weight", "decoder.up_blocks.2.resnets.0.conv_shortcut.weight",
               "decoder.up_blocks.0.upsamplers.0.conv.weight", "decoder.conv_norm_out.weight", "post_quant_conv.bias"):
         assert k in vae.state_dict()

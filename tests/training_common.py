@@ -10,8 +10,7 @@ SCHED = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_
              clip_sample=False)
 
 
-def union_masks(clip, thr=0.5):
-    return torch.stack([torch.stack([(m[:, 0] > thr).any(dim=0) for m in clip["masks"][b]]) for b in range(len(clip["masks"]))])
+from synfmc_amd.configs import union_masks  # noqa: E402,F401
 
 
 def oracle_grads(ou, oe, oa, clip, pose_emb, t, noise):

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/pmc_attn
 for C in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "TCC_HIT_sum TCC_MISS_sum"; do
   D=gpurun_out/pmc_attn/$(echo $C | tr ' ' '_')
-  timeout 300 rocprofv3 --pmc $C --kernel-trace -d $D -o p --output-format csv -- python tools/probe_attn.py > $D.log 2>&1
+  timeout 300 rocprofv3 --pmc $C --kernel-trace -d $D -o p --output-format csv -- python tools/scratch/probe_attn.py > $D.log 2>&1
   F=$(find $D -name "*counter_collection.csv" | head -1)
   python - "$F" <<'PY'
 import csv, sys, collections

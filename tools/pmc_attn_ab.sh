@@ -6,10 +6,10 @@ for MODE in 1 2; do
   export FMC_SA_XCD=$MODE
   [ $MODE = 2 ] && unset FMC_SA_XCD
   echo "== xcd map $MODE"
-  python tools/probe_attn.py 2>&1 | grep "self\|cross" | head -4
+  python tools/scratch/probe_attn.py 2>&1 | grep "self\|cross" | head -4
   for C in FETCH_SIZE WRITE_SIZE; do
     D=gpurun_out/pmc_attn_ab/m${MODE}_$C
-    timeout 300 rocprofv3 --pmc $C --kernel-trace -d $D -o p --output-format csv -- python tools/probe_attn.py > $D.log 2>&1
+    timeout 300 rocprofv3 --pmc $C --kernel-trace -d $D -o p --output-format csv -- python tools/scratch/probe_attn.py > $D.log 2>&1
     F=$(find $D -name "*counter_collection.csv" | head -1)
     python - "$F" <<'PY'
 import csv, sys, collections

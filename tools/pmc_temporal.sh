@@ -4,9 +4,9 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/pmc_temporal; mkdir -p $O
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $C --kernel-trace -d $O/$C -o p --output-format csv -- python tools/probe_temporal.py > $O/$C.log 2>&1
+  timeout 300 rocprofv3 --pmc $C --kernel-trace -d $O/$C -o p --output-format csv -- python tools/scratch/probe_temporal.py > $O/$C.log 2>&1
 done
-timeout 300 rocprofv3 --kernel-trace -d $O/trace -o t --output-format csv -- python tools/probe_temporal.py > $O/trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace -d $O/trace -o t --output-format csv -- python tools/scratch/probe_temporal.py > $O/trace.log 2>&1
 python - <<'PY' > gpurun_out/pmc_temporal/summary.md
 import csv, glob, collections
 def table(path, col):

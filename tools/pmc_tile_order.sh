@@ -5,10 +5,10 @@ for GM in ${GMS:-1 8}; do
   export ${ABVAR:-FMC_GEMM_GM}=$GM
 
   echo "== ${ABVAR:-FMC_GEMM_GM}=$GM"
-  python tools/probe_tile_order.py 2>&1 | grep "tile="
+  python tools/scratch/probe_tile_order.py 2>&1 | grep "tile="
   for C in FETCH_SIZE WRITE_SIZE; do
     D=$O/gm${GM}_$C
-    PROBE_ITERS=3 timeout 300 rocprofv3 --pmc $C --kernel-trace -d $D -o p --output-format csv -- python tools/probe_tile_order.py > $D.log 2>&1
+    PROBE_ITERS=3 timeout 300 rocprofv3 --pmc $C --kernel-trace -d $D -o p --output-format csv -- python tools/scratch/probe_tile_order.py > $D.log 2>&1
     python - "$(find $D -name '*counter_collection.csv' | head -1)" <<'PY'
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "gemm_kernel" in r["Kernel_Name"]]
