@@ -192,7 +192,7 @@ def test_stage3_training_gradients(stack, dtype, tol):
     assert scale > 0 and err < tol
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-3), (torch.bfloat16, 1.5e-1)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])     # measured on MI355X: 2.3e-6 / 9.4e-3; bound = measured x 2 (fp32: x 40, still 30 x below the old bound)
 def test_stage2_training_gradients(stack, dtype, tol):
     """CMC-stage training step (train_cam_ctrl.py:540-665): gradients of the camera encoder (through its own temporal
     transformer blocks and 3x3 convs) and of the `qkv_merge` layers inside the frozen U-Net, background-weighted loss,
@@ -218,7 +218,7 @@ def test_stage2_training_gradients(stack, dtype, tol):
         assert scale > 0 and err < tol
 
 
-@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 1e-3, 3e-3), (torch.bfloat16, 6e-2, 1.5e-1)])
+@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 1e-3, 1e-4), (torch.bfloat16, 6e-2, 2.5e-2)])     # gradients measured: 4.3e-6 / 1.26e-2; bf16 bound = measured x 2
 def test_frames32_forward_and_training(dtype, tol, gtol):
     """BASELINE.json config 5 shape class: 32-frame clips (temporal attention over F = 32, positional-encoding length 32)
     through the CMC + OMC U-Net -- forward parity and stage-3 gradients against the oracle on the reduced stack."""
@@ -369,7 +369,7 @@ def test_pipeline_graph_reuse_across_clips(stack, monkeypatch):
 
 
 # ---- a11: LORAPoseAdaptorAttnProcessor (attention_processor.py:296-420) ------------------------------------------------
-@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 1e-3, 3e-3), (torch.bfloat16, 6e-2, 1.5e-1)])
+@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 1e-3, 1e-4), (torch.bfloat16, 6e-2, 2.5e-2)])     # gradients measured: 4.3e-6 / 1.26e-2; bf16 bound = measured x 2
 def test_lora_pose_adaptor_processor_forward_and_gradients(stack, dtype, tol, gtol):
     """`add_motion_lora=True`: every temporal attention carries the Camera-Adapter merge AND a LoRA (rank C/4) on its four
     projections.  Forward parity and stage-3 (Adapter) gradient parity against the oracle's un-merged `W x + s up(down x)`."""
@@ -415,7 +415,7 @@ def test_fp8_temporal_attention_frames32_forward_and_training():
     """BASELINE.json configs[4] shape class on the reduced stack: 32-frame clip, CMC + OMC, every temporal attention (U-Net
     motion modules and camera encoder) on the fp8 path -- e4m3 q | k | v out of the QKV projection epilogue with per-tensor
     delayed scaling, QK^T on the fp8 MFMA.  Forward and stage-3 (Adapter) gradients against the fp32 oracle.  Stated
-    bounds: forward 6e-2, gradients 1e-1 rel-inf (measured 2.3e-2 / 1.0e-2; e4m3 carries 3 mantissa bits, 6 % per element on
+    bounds: measured x 2, written next to the asserts (measured 2.0e-2 / 1.4e-2; e4m3 carries 3 mantissa bits, 6 % per element on
     q, k and v of 48 attention layers, next to the bf16 path's measured 1.6e-2 / 1.2e-2 on the same case)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
@@ -451,8 +451,9 @@ def test_fp8_temporal_attention_frames32_forward_and_training():
         res[fp8] = (rel_inf(out.float(), ref), err_g, abs(float(l_ref) - float(l_got)) / abs(float(l_ref)))
         print(f"fp8 temporal attention {'ON ' if fp8 else 'off'}: forward rel-inf {res[fp8][0]:.3e}, Adapter-gradient rel-inf "
               f"{res[fp8][1]:.3e}, loss rel {res[fp8][2]:.3e}")
-    assert res[True][0] < 6e-2 and res[True][1] < 1e-1 and res[True][2] < 1e-2
-    assert res[False][0] < 6e-2 and res[False][1] < 1.5e-1
+    # measured: bf16 1.56e-2 / 1.10e-2, fp8 2.03e-2 / 1.45e-2 (forward / Adapter gradients); bounds = measured x 2
+    assert res[True][0] < 4.1e-2 and res[True][1] < 2.9e-2 and res[True][2] < 1e-2
+    assert res[False][0] < 3.2e-2 and res[False][1] < 2.2e-2
     assert any(m.__dict__.get("_fp8_scales") is not None and m.__dict__["_fp8_scales"].calibrated for m in pu.modules())
 
 
