@@ -132,7 +132,9 @@ def synthetic_inputs(rank, device):
 # in this tree -- it cannot silently go stale with the next kernel change.
 _KERNEL_SOURCES = {"sa40d": ("spatial_attn.hip", "attn_common.h", "common.h"),
                    "temporal": ("temporal_attn.hip", "attn_common.h", "common.h"),
-                   "conv": ("gemm_conv.hip", "common.h")}
+                   "conv": ("gemm_conv.hip", "common.h"),
+                   "proj": ("gemm_conv.hip", "common.h"),
+                   "tblock": ("temporal_block.hip", "common.h")}
 
 
 def kernel_source_sha(kernel: str) -> str:
@@ -250,10 +252,11 @@ def measure_proj_roofline(device, dtype, iters=20):
     achieved = flops / (ms * 1e-3) / 1e12
     names = {0: "vendor library + geglu_kernel", 3: "gemm_kernel<256x256,16 waves,GEGLU>", 13: "gemm8_kernel<256x256,8-phase,GEGLU>",
              512: "gemm160p_kernel<160x320 persistent,GEGLU>"}
-    return {"bound": "mfma", "kernel": f"{names.get(arm, f'fmc_linear_bf16 arm {arm}')} [{M}x{N}x{Kd}]", "autotuned_arm": arm,
-            "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-            "avg_launch_ms": round(ms, 4), "flops_per_launch": flops, "traffic_algorithmic": 2.0 * (M * Kd + N * Kd + M * N // 2),
-            "traffic": None, "traffic_note": "no counter pass for this launch"}
+    out = {"bound": "mfma", "kernel": f"{names.get(arm, f'fmc_linear_bf16 arm {arm}')} [{M}x{N}x{Kd}]", "autotuned_arm": arm,
+           "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+           "avg_launch_ms": round(ms, 4), "flops_per_launch": flops, "traffic_algorithmic": 2.0 * (M * Kd + N * Kd + M * N // 2)}
+    out.update(recorded_counters("proj"))
+    return out
 
 
 def measure_temporal_block_roofline(device, dtype, iters=20):
@@ -287,11 +290,12 @@ def measure_temporal_block_roofline(device, dtype, iters=20):
     M = B * Fr * hw
     flops = 2.0 * M * C * 5 * C + 4.0 * M * Fr * C
     achieved = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": f"temporal_block_kernel<merge> (fused LN + merge + qkv + attention + out-projection, bf16) [{B}x{Fr}x{hw}x{C}]",
-            "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-            "avg_launch_ms": round(ms, 4), "flops_per_launch": flops, "traffic_algorithmic": 3.0 * M * C * 2,
-            "traffic": None, "traffic_note": "no counter pass for this launch yet",
-            "replaces": "LayerNorm epilogue + merge GEMM + fused QKV GEMM + temporal_attn_kernel + out-projection GEMM (4 launches, ~790 MB of HBM traffic)"}
+    out = {"bound": "mfma", "kernel": f"temporal_block_kernel<merge> (fused LN + merge + qkv + attention + out-projection, bf16) [{B}x{Fr}x{hw}x{C}]",
+           "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+           "avg_launch_ms": round(ms, 4), "flops_per_launch": flops, "traffic_algorithmic": 3.0 * M * C * 2,
+           "replaces": "LayerNorm epilogue + merge GEMM + fused QKV GEMM + temporal_attn_kernel + out-projection GEMM (4 launches, ~790 MB of HBM traffic)"}
+    out.update(recorded_counters("tblock"))
+    return out
 
 
 def unet_flops(batch, h, w, executed=False, config="obj"):

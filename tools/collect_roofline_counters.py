@@ -21,7 +21,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "gpurun_out", "roofline_pmc")
 GROUPS = ["FETCH_SIZE", "WRITE_SIZE", "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE"]
-KERNELS = {"sa40d": "sa40d_kernel", "temporal": "temporal_attn_kernel", "conv": "gemm"}     # (the conv probe is the only gemm*/conv launch with MODE 1)
+KERNELS = {"sa40d": "sa40d_kernel", "temporal": "temporal_attn_kernel", "conv": "gemm", "proj": "gemm160p", "tblock": "temporal_block_kernel"}
+# (the conv probe is the only gemm* launch with MODE 1, the GEGLU projection probe the only one with MODE 0)
 
 
 def which(name):
@@ -29,8 +30,12 @@ def which(name):
         return "sa40d"
     if "temporal_attn_kernel" in name:
         return "temporal"
-    if "gemm8_kernel<1" in name or "gemm_kernel<1" in name:
+    if "temporal_block_kernel" in name:
+        return "tblock"
+    if "gemm8_kernel<1" in name or "gemm_kernel<1" in name or "gemm160_kernel<1" in name:
         return "conv"
+    if "gemm160p_kernel" in name or "gemm160_kernel<0" in name or "gemm8_kernel<0" in name or "gemm_kernel<0" in name:
+        return "proj"
     return None
 
 
@@ -38,7 +43,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp", FMC_AUTOTUNE_CACHE=os.environ.get("FMC_AUTOTUNE_CACHE", ""))
     vals = collections.defaultdict(lambda: collections.defaultdict(list))
-    dur = collections.defaultdict(list)
+    dur = collections.defaultdict(list)            # (class, exact kernel name) -> durations
     for i, grp in enumerate(GROUPS):
         d = os.path.join(OUT, f"p{i}")
         cmd = ["rocprofv3", "--pmc", *grp.split(), "--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--",
@@ -49,25 +54,33 @@ def main():
             for r in csv.DictReader(open(f)):
                 k = which(r["Kernel_Name"])
                 if k:
-                    vals[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    vals[k][(r["Counter_Name"], r["Kernel_Name"])].append(float(r["Counter_Value"]))
         for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
                 k = which(r["Kernel_Name"])
                 if k and i == 2:
-                    dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                    dur[k, r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
             if os.path.getsize(f) > (1 << 20):
                 os.remove(f)
     import bench
-    mean = lambda v: sum(v[4:]) / max(1, len(v[4:]))          # skip warm-up / autotune launches
+    mean = lambda v: sum(v[-12:]) / max(1, len(v[-12:]))      # the timed loop's 12 launches (what precedes them is warm-up / autotune)
     out = {"method": "rocprofv3 --pmc <one group per pass> --kernel-trace; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024", "kernels": {}}
     for k in KERNELS:
-        c = {n: mean(v) for n, v in vals[k].items()}
+        # a class can match several instantiations while the autotuner tries its arms: the probe's own launch is the most frequent one
+        names = collections.Counter()
+        for (cn, kn), v in vals[k].items():
+            names[kn] += len(v)
+        if not names:
+            continue
+        kn = names.most_common(1)[0][0]
+        c = {cn: mean(v) for (cn, kn2), v in vals[k].items() if kn2 == kn}
         if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
             continue
         e = {"source_sha16": bench.kernel_source_sha(k), "traffic_bytes": round((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024),
              "fetch_size_kb": round(c["FETCH_SIZE"]), "write_size_kb": round(c["WRITE_SIZE"])}
-        if c.get("GRBM_GUI_ACTIVE") and dur[k]:
-            ns = mean(dur[k])
+        e["kernel_name"] = kn[:80]
+        if c.get("GRBM_GUI_ACTIVE") and dur.get((k, kn)):
+            ns = mean(dur[k, kn])
             e["matrix_pipe_busy"] = round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024 * c["GRBM_GUI_ACTIVE"] / 8), 3)
             e["shader_clock_ghz_under_counters"] = round(c["GRBM_GUI_ACTIVE"] / 8 / ns, 3)
             e["avg_launch_us_under_counters"] = round(ns / 1e3, 1)
