@@ -511,86 +511,81 @@ void temporal_block_kernel(const TBParams P) {
             }
         }
         // ================= phase E: h' = o W_out^T + b + h =================
-        // (the accumulators start from the bias: its 5 eight-byte loads retire with the wait below, nothing in the epilogue touches global memory
-        //  outside the counted queue)
-        u32x2 bo2[5];
-#pragma unroll
-        for (int nb = 0; nb < 5; ++nb) bo2[nb] = P.b_out ? *reinterpret_cast<const u32x2*>(P.b_out + ecol + nb * 16) : u32x2{0u, 0u};
         TB_VMCNT(0);                                              // (sub-tiles 0, 1 of W_out have long landed)
         __syncthreads();                                          // X = o; ring buffers 0, 1 published
         if (wr == 1) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int b = 0; b < 5; ++b) {
-            float b4[4];
-            unpack4(bo2[b], b4);
+        for (int a = 0; a < 5; ++a)
 #pragma unroll
-            for (int a = 0; a < 5; ++a) acc[a][b] = f32x4{b4[0], b4[1], b4[2], b4[3]};
-        }
+            for (int b = 0; b < 5; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 10; ++g) {
             read_frags(g, g % 3);
             if (g + 2 < 10) issue_w(rsWO, g + 2, (g + 2) % 3);
-            // the residual rows (h of this tile) come back in five 32-row passes through the ring, the first two into the buffers the weight
-            // stream has left (as the pose term in phase B)
-            if (g == 8) issue_pass(rsH, tile, 0, 1);
-            if (g == 9) issue_pass(rsH, tile, 1, 2);
-            if (g < 8) TB_VMCNT(4);
-            else if (g == 8) TB_VMCNT2(3, 2);
+            if (g < 8) TB_VMCNT(4); else TB_VMCNT(0);
             TB_MMA();
         }
-        if (wr == 0) __builtin_amdgcn_s_barrier();                // every fragment read of X (= o) is done: X and the ring are free
+        if (wr == 0) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         TB_STAMP(6);
+        issue_h(tile);                                            // X (= o) is dead: this tile's h rows come back for the residual add (see phase B)
         {
-            // epilogue.  Queue of this lane's vector-memory operations, oldest first (waves 0-3 / waves 4-7 issue 3 / 2 per pass P and store S,
-            // 13 / 12 for the next tile's rows H):  P0 P1 | P2 H | S0 P3 | S1 P4 | S2 | S3 | S4.   Pass p: wait for P_p (counted: the smaller of the
-            // two wave classes' younger-operation counts, so the other class waits for a few operations more than it needs), barrier, h' = acc + h in
-            // place in the ring buffer, barrier, whole-row 16-byte stores straight from the ring buffer, barrier, the buffer takes pass p + 3.
-            // The next tile's h rows stream into X under all of it.
-            const bool has_next = tile + (int)gridDim.x < P.tiles;
-            issue_pass(rsH, tile, 2, 0);
-            if (has_next) issue_h(tile + gridDim.x);
+            // epilogue: wave row `pass` stages its 80 rows (bf16, pitch 328) in the ring region; whole-row stores
+            constexpr int OP = 328, CPR = 40;
+            bf16_t* Os = RING;
 #pragma unroll
-            for (int pss = 0; pss < 5; ++pss) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (pss == 0) { if (has_next) TB_VMCNT(16); else TB_VMCNT(4); }          // younger than P0: P1 P2 [H]
-                else if (pss == 1) { if (has_next) TB_VMCNT(18); else TB_VMCNT(6); }     // P2 [H] S0 P3
-                else if (pss == 2) { if (has_next) TB_VMCNT(20); else TB_VMCNT(8); }     // [H] S0 P3 S1 P4
-                else if (pss == 3) TB_VMCNT(6);                                          // S1 P4 S2
-                else TB_VMCNT(4);                                                        // S2 S3
-                __syncthreads();                                  // pass pss published
-                bf16_t* Hs = RING + ((pss + 1) % 3) * TB_SUB;
-                {
-                    bf16_t* Hr = Hs + (wr * 16 + l15) * TB_C;
+            for (int nb = 0; nb < 5; ++nb) {
+                float b4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (P.b_out) unpack4(*reinterpret_cast<const u32x2*>(P.b_out + ecol + nb * 16), b4);
 #pragma unroll
-                    for (int nb = 0; nb < 5; ++nb) {
-                        const int col = ecol + nb * 16, off = (((col >> 3) ^ xsw) << 3) + (col & 7);
-                        u32x2* ph = reinterpret_cast<u32x2*>(Hr + off);
-                        float hv[4];
-                        unpack4(*ph, hv);
-                        *ph = u32x2{pack_bf2(acc[pss][nb][0] + hv[0], acc[pss][nb][1] + hv[1]), pack_bf2(acc[pss][nb][2] + hv[2], acc[pss][nb][3] + hv[3])};
-                    }
+                for (int mb = 0; mb < 5; ++mb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[mb][nb][j] += b4[j];
+            }
+            TB_VMCNT(0);
+            __syncthreads();
+#pragma unroll
+            for (int mb = 0; mb < 5; ++mb) {
+                const int r = wr * 80 + mb * 16 + l15;
+#pragma unroll
+                for (int nb = 0; nb < 5; ++nb) {
+                    const int col = ecol + nb * 16;
+                    float hv[4];
+                    unpack4(*reinterpret_cast<const u32x2*>(X + r * TB_C + (((col >> 3) ^ xsw) << 3) + (col & 7)), hv);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[mb][nb][j] += hv[j];
                 }
-                __syncthreads();                                  // the 32 finished rows are in the ring buffer
-                // buffer row rl = tile row (rl < 16 ? 16 pss + rl : 64 + 16 pss + rl) = (pixel, frame); physical chunk pc holds logical chunk pc ^ swizzle
+            }
+            __syncthreads();
+            // the NEXT tile's h rows stream into X under the staging passes and stores below
+            __builtin_amdgcn_sched_barrier(0);
+            if (tile + (int)gridDim.x < P.tiles) issue_h(tile + gridDim.x);
+#pragma unroll 1
+            for (int pass = 0; pass < 2; ++pass) {
+                if (wr == pass) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int c = tid + 512 * j;
-                    if (c < 32 * 40) {
-                        const int rl = c / 40, pc = c - rl * 40, r = (rl < 16 ? 16 * pss + rl : 64 + 16 * pss + rl), lc = pc ^ ((r >> 1) & 7);
-                        const unsigned dst = row0 + (unsigned)(r & 15) * fstride + (unsigned)(r >> 4) * TB_C + (unsigned)lc * 8;
-                        *reinterpret_cast<u32x4*>(P.out + dst) = *reinterpret_cast<const u32x4*>(Hs + c * 8);
-                    }
+                    for (int mb = 0; mb < 5; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < 5; ++nb)
+                            *reinterpret_cast<u32x2*>(Os + (mb * 16 + l15) * OP + ecol + nb * 16) =
+                                u32x2{pack_bf2(acc[mb][nb][0], acc[mb][nb][1]), pack_bf2(acc[mb][nb][2], acc[mb][nb][3])};
                 }
-                if (STATS && tid < 128) {
-                    const int rl = tid >> 2, q = tid & 3, r = (rl < 16 ? 16 * pss + rl : 64 + 16 * pss + rl);
+                __syncthreads();
+                // staged row rr (0..79) = tile row 80 pass + rr = (pixel 5 pass + rr / 16, frame rr % 16)
+                for (int c = tid; c < 80 * CPR; c += 512) {
+                    const int rr = c / CPR, ch = c - rr * CPR;
+                    const unsigned dst = row0 + (unsigned)(rr & 15) * fstride + (unsigned)(5 * pass + (rr >> 4)) * TB_C + (unsigned)ch * 8;
+                    *reinterpret_cast<u32x4*>(P.out + dst) = *reinterpret_cast<const u32x4*>(Os + rr * OP + ch * 8);
+                }
+                if (STATS && tid < 320) {
+                    const int rr = tid >> 2, q = tid & 3;
                     float s1 = 0.f;
                     u32x4 x4[10];
 #pragma unroll
                     for (int i = 0; i < 10; ++i) {
-                        x4[i] = *reinterpret_cast<const u32x4*>(Hs + rl * TB_C + (q + 4 * i) * 8);
+                        x4[i] = *reinterpret_cast<const u32x4*>(Os + rr * OP + (q + 4 * i) * 8);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) s1 += __uint_as_float(x4[i][j] << 16) + __uint_as_float(x4[i][j] & 0xffff0000u);
                     }
@@ -606,14 +601,11 @@ void temporal_block_kernel(const TBParams P) {
                         }
                     s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2);
                     if (q == 0) {
-                        const int64_t grow = ((int64_t)clip * TB_F + (r & 15)) * P.hw + p0 + (r >> 4);
+                        const int64_t grow = ((int64_t)clip * TB_F + (rr & 15)) * P.hw + p0 + 5 * pass + (rr >> 4);
                         *reinterpret_cast<f32x2_t*>(P.ln_stats + grow * 2) = f32x2_t{mean, rsqrtf(s2 * (1.f / 320.f) + P.ln_stats_eps)};
                     }
                 }
-                if (pss + 3 < 5) {
-                    __syncthreads();                              // everybody has read the buffer: it takes pass pss + 3
-                    issue_pass(rsH, tile, pss + 3, (pss + 1) % 3);
-                }
+                __syncthreads();
             }
         }
         TB_STAMP(7);
