@@ -2165,21 +2165,30 @@ void gemm160p_kernel(const GemmParams P) {
                     // (1) statistics of the 80 staged (rounded) rows: 4 lanes per row, 16-byte reads, one pass (sum, sum of squares), two shuffles
                     if (tid < 320) {
                         const int r = tid >> 2, q = tid & 3;
+                        // (centred variance, as the stand-alone LayerNorm kernel and torch compute it: E[x^2] - mean^2 loses the variance of rows with
+                        //  |mean| >> std, and which path a row takes depends on the autotuned arm.  The row is read from the staging tile twice: held in
+                        //  registers between the passes it costs 40 VGPRs next to the other wave row's live accumulators -- 375 spilled registers.)
                         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                         for (int i = 0; i < 10; ++i) {
                             const u32x4 x4 = *reinterpret_cast<const u32x4*>(Os + r * OP + (q + 4 * i) * 8);
 #pragma unroll
+                            for (int j = 0; j < 4; ++j) s1 += __uint_as_float(x4[j] << 16) + __uint_as_float(x4[j] & 0xffff0000u);
+                        }
+                        s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2);
+                        const float mean = s1 * (1.f / 320.f);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < 10; ++i) {
+                            const u32x4 x4 = *reinterpret_cast<const u32x4*>(Os + r * OP + (q + 4 * i) * 8);
+#pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                const float lo = __uint_as_float(x4[j] << 16), hi = __uint_as_float(x4[j] & 0xffff0000u);
-                                s1 += lo + hi;
+                                const float lo = __uint_as_float(x4[j] << 16) - mean, hi = __uint_as_float(x4[j] & 0xffff0000u) - mean;
                                 s2 += lo * lo + hi * hi;
                             }
                         }
-                        s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2);
                         s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2);
-                        const float mean = s1 * (1.f / 320.f);
-                        if (q == 0) *reinterpret_cast<f32x2_t*>(lnS + 640 + 2 * r) = f32x2_t{mean, rsqrtf(fmaxf(s2 * (1.f / 320.f) - mean * mean, 0.f) + P.ln_eps)};
+                        if (q == 0) *reinterpret_cast<f32x2_t*>(lnS + 640 + 2 * r) = f32x2_t{mean, rsqrtf(s2 * (1.f / 320.f) + P.ln_eps)};
                     }
                     __syncthreads();                                     // (also: every thread's copy of the rows to `out` has left the staging tile)
                     if (LN == 2) {                                       // the consumer GEMM normalises: it only needs (mean, rstd) per row; one store per thread

@@ -887,7 +887,8 @@ def prepare_streamk_workspace(stream) -> None:
 
 def release_streamk_workspace(stream) -> None:
     """Drop the workspace of a stream that is going away (a discarded graph runner): 486 MB per key otherwise stay allocated."""
-    _sk_ws.pop((torch.cuda.current_device(), stream.cuda_stream), None)
+    dev = getattr(getattr(stream, "device", None), "index", None)          # the stream's own device, not whichever is current when a runner dies
+    _sk_ws.pop((torch.cuda.current_device() if dev is None else dev, stream.cuda_stream), None)
 
 
 def _splitk_workspace(device, split_k: int, M: int, N: int):

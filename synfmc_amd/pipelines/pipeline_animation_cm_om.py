@@ -72,6 +72,9 @@ class _GraphedUNet:
             for _ in range(2):
                 self._call()
         torch.cuda.current_stream().wait_stream(side)
+        if getattr(self, "_cap_stream", None) is not None:     # re-capture (`set_conditioning` on a non-refillable runner): the old graph dies
+            self.graph = None                                  # with its stream's stream-K workspace (~0.5 GB), not only the last one in __del__
+            K.release_streamk_workspace(self._cap_stream)
         self._cap_stream = torch.cuda.Stream()
         K.prepare_streamk_workspace(self._cap_stream)      # allocated and zeroed eagerly, not inside the capture
         self.graph = torch.cuda.CUDAGraph()
