@@ -2801,7 +2801,8 @@ void launch_gemm160(GemmParams& P, hipStream_t st) {
         // more tiles than CUs on a token projection: the persistent form (the next tile's operands stream in under this tile's epilogue)
         static const int persist = getenv("FMC_G160_PERSIST") ? atoi(getenv("FMC_G160_PERSIST")) : 1;
         const int cus = fmc_cu_count() & ~7;
-        if (persist && !P.f32io && P.M % 160 == 0 && P.tiles_m * P.tiles_n > cus && cus >= 8) {
+        // (FMC_G160_PERSIST=2: also launches of exactly one round -- tiles == CUs, the level-1 N = 640 projections -- A/B switch)
+        if (persist && !P.f32io && P.M % 160 == 0 && (persist == 2 ? P.tiles_m * P.tiles_n >= cus : P.tiles_m * P.tiles_n > cus) && cus >= 8) {
             constexpr size_t ldsp = (size_t)3 * (160 + 320) * 32 * sizeof(bf16_t) + 1024 + (EPI == 1 ? (size_t)160 * 168 * 2 + 4096 : (size_t)80 * 328 * 2 + 5120);
             static bool raisedp = false;
             if (!raisedp) {

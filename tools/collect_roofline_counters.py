@@ -54,25 +54,33 @@ def main():
             for r in csv.DictReader(open(f)):
                 k = which(r["Kernel_Name"])
                 if k:
-                    vals[k][(r["Counter_Name"], r["Kernel_Name"])].append(float(r["Counter_Value"]))
+                    vals[k][(r["Counter_Name"], r["Kernel_Name"])].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
         for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
                 k = which(r["Kernel_Name"])
                 if k and i == 2:
-                    dur[k, r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                    dur[k, r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
             if os.path.getsize(f) > (1 << 20):
                 os.remove(f)
     import bench
-    mean = lambda v: sum(v[-12:]) / max(1, len(v[-12:]))      # the timed loop's 12 launches (what precedes them is warm-up / autotune)
+    def mean(v):                                              # the timed loop's 12 launches = the last 12 dispatches (what precedes them is warm-up / autotune)
+        w = [x for _, x in sorted(v)][-12:]
+        return sum(w) / max(1, len(w))
     out = {"method": "rocprofv3 --pmc <one group per pass> --kernel-trace; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024", "kernels": {}}
     for k in KERNELS:
-        # a class can match several instantiations while the autotuner tries its arms: the probe's own launch is the most frequent one
-        names = collections.Counter()
+        # a class matches several instantiations while the autotuner tries its arms: the probe's own launch is the one dispatched LAST, in every pass
+        last = {}
         for (cn, kn), v in vals[k].items():
-            names[kn] += len(v)
-        if not names:
+            d = max(x for x, _ in v)
+            if cn not in last or d > last[cn][0]:
+                last[cn] = (d, kn)
+        names = {kn for _, kn in last.values()}
+        if not last:
             continue
-        kn = names.most_common(1)[0][0]
+        if len(names) != 1:
+            print(f"{k}: the passes ended on different kernels {names}: skipped", file=sys.stderr)
+            continue
+        kn = names.pop()
         c = {cn: mean(v) for (cn, kn2), v in vals[k].items() if kn2 == kn}
         if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
             continue
