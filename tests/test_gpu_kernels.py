@@ -723,6 +723,26 @@ def test_gemm_k320_weight_stationary_arm(K):
     assert rel_inf(K.linear_bf16(xd6, wd6, None, None, 1.0, tile=15).float(), F.linear(xo6, wo6)) < 1e-2           # K != 320
 
 
+@pytest.mark.parametrize("arm", [600, 601])
+def test_gemm_small_m_tiles(K, arm):
+    """The 64 x 128 tiles of the ring kernel (a wave = 32 x 64; C-ABI tiles 19 / 20, autotune arms 600 / 601: offered for M <= 2560 projections, where
+    128 x 128 tiles leave more than half of the 256 CUs idle): ragged M / N, bias / alpha / residual, bit-identical to the 128 x 128 kernel (same
+    products in the same order), deterministic; two residuals and split-K fall back to tile 1."""
+    dtype = torch.bfloat16
+    for (M, N, Kd) in [(1280, 1280, 1280), (640, 3840, 1280), (2560, 1280, 5120), (1000, 328, 320), (70, 136, 64)]:
+        wo, wd = rnd((N, Kd), 45, dtype, scale=Kd ** -0.5)
+        bo, bd = rnd((N,), 46, dtype)
+        xo, xd = rnd((M, Kd), 47, dtype)
+        ro, rd = rnd((M, N), 48, dtype)
+        r2o, r2d = rnd((M, N), 49, dtype)
+        got = K.linear_bf16(xd, wd, bd, rd, 0.5, tile=arm)
+        assert rel_inf(got.float(), 0.5 * F.linear(xo, wo, bo) + ro) < 1e-2, (M, N, Kd)
+        assert torch.equal(got, K.linear_bf16(xd, wd, bd, rd, 0.5, tile=arm))
+        assert torch.equal(got, K.linear_bf16(xd, wd, bd, rd, 0.5, tile=1 if arm == 600 else 4))          # (tile 1: 64-deep k-tiles, tile 4: 32-deep)
+        assert rel_inf(K.linear_bf16(xd, wd, bd, None, 1.0, tile=arm).float(), F.linear(xo, wo, bo)) < 1e-2
+        assert rel_inf(K.linear_bf16(xd, wd, None, rd, 1.0, tile=arm, residual2=r2d).float(), F.linear(xo, wo) + ro + r2o) < 1e-2
+
+
 @pytest.mark.parametrize("tile", [13, 14, 128 + 13, 128 + 14, 256 + 13, 384 + 13])
 def test_gemm_8phase_arms(K, tile):
     """The 8-phase 256x256 kernel (staggered wave rows, half-tile DMA with counted vmcnt): ragged M / N (partial tiles),
