@@ -213,6 +213,7 @@ int fmc_cfg_ddim_step(const void* eps_uc, const float* x, float* x_out, int64_t 
  *   17 = the persistent form on 256 x 320 tiles (5 operand requests per 40 MFMAs and wave instead of 4 per 25), GEGLU epilogue only,
  *   M % 256 == 0 and more tiles than CUs -- anything else falls back to 16; same weight row order and bit-identical results.
  *   19 / 20 = 64 x 128 tiles of the ring kernel for small M (a wave = 32 x 64; 64-deep k-tiles in a 3-stage ring / 32-deep in a 4-stage ring: 2 / 3 workgroups per CU),
+ *   21 / 22 = 128 x 128 / 64 x 256 on 8 such waves (two workgroups = 16 waves per CU);
  *   fmc_linear_bf16 without GEGLU only, bit-identical to tiles 1 / 4; split-K, stream-K, two residuals and fp32 storage fall back to tile 1.
  *   Every arm computes the same function -- bit for bit among the plain-grid arms of one k-tile depth
  *   (the 32-deep arms, split-K and stream-K add the same products in another order) -- so callers may time them and keep

@@ -2872,7 +2872,7 @@ bool gemm8_ok(GemmParams& P) {
 }
 
 // tile arms (fmc_hip.h): geometry x k-tile depth x ring depth
-constexpr int GEMM_TILE_MAX = 20;
+constexpr int GEMM_TILE_MAX = 22;
 
 // geometry: the largest tile that still gives every CU work and does not waste more than ~20 % of N
 template <int MODE, int EPI>
@@ -2908,9 +2908,11 @@ void launch_gemm(GemmParams& P, int tile, hipStream_t st) {
         g = 5;
     }
     if constexpr (MODE == 0 && EPI == 0) {                // small-M experiment (round 4): 64 x 128 tiles, a wave = 32 x 64; in-register epilogue only
-        if ((g == 19 || g == 20) && (P.split_k != 1 || P.res2 || P.sk || P.f32io)) g = 1;
+        if (g >= 19 && g <= 22 && (P.split_k != 1 || P.res2 || P.sk || P.f32io)) g = 1;
         if (g == 19) { launch_gemm_g<0, 0, 2, 2, 64, 3, 1>(P, st); return; }      // 3-stage ring of 24-KiB k-tiles: 2 workgroups per CU
         if (g == 20) { launch_gemm_g<0, 0, 2, 2, 32, 4, 1>(P, st); return; }      // 32-deep k-tiles, 4-stage ring (48 KiB): 3 per CU
+        if (g == 21) { launch_gemm_g<0, 0, 4, 2, 64, 2, 1>(P, st); return; }      // 128 x 128 as 8 waves of 32 x 64: 64 KiB, two workgroups = 16 waves per CU
+        if (g == 22) { launch_gemm_g<0, 0, 2, 4, 64, 2, 1>(P, st); return; }      // 64 x 256, 8 waves: 80 KiB, two per CU
     }
     switch (g) {
         case 14: launch_gemm8<MODE, EPI, 5>(P, st); break;              // 8-phase 256x256, 5 half-tiles ahead

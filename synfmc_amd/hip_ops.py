@@ -835,14 +835,14 @@ def cfg_ddim_step(eps: torch.Tensor, x: torch.Tensor, guidance: float, alpha_t: 
 # --------------------------------------------------------------------------------------------
 ARM_160 = 512
 ARM_256 = 528                       # C-ABI tile 17: persistent 256 x 320 tiles, GEGLU projections only (falls back to tile 16)
-ARM_SMALLM = 600                    # C-ABI tiles 19 / 20: 64 x 128 tiles for M <= 5120 projections (experiment, round 4)
+ARM_SMALLM = 600                    # C-ABI tiles 19 .. 22: 64 x 128 (4 waves, 64- / 32-deep k-tiles), 128 x 128 and 64 x 256 (8 waves) with 32 x 64 per wave, for M <= 2560 (round 4)
 ARM_160B = 544                      # C-ABI tile 18: tile 16 reading the weight pre-packed tile-major (`_w_tilemajor`): linear 1-KiB operand requests
 
 
 def _decode_arm(tile: int, split_k: int):
     """autotune arm id -> (C-ABI tile id, split_k).  Ids 16..127 encode split-K (geometry + 16 log2(split)), 128+ / 256+ stream-K and its
     hybrid; ARM_160 (512) is the C-ABI tile 16, the 160 x 320 kernel."""
-    if tile in (ARM_SMALLM, ARM_SMALLM + 1):           # 600 / 601: the 64 x 128 small-M tiles (C-ABI tile 19 / 20)
+    if ARM_SMALLM <= tile < ARM_SMALLM + 4:            # 600 .. 603: the small-M tiles of 32 x 64 per wave (C-ABI tiles 19 .. 22)
         return 19 + tile - ARM_SMALLM, 1
     if tile == ARM_256:
         return 17, 1
@@ -1680,7 +1680,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     key = ("lin", M, N, Kd, bias is not None, (residual is not None) + (residual2 is not None),
            0 if x2 is None else x.shape[-1])
     hip = lambda tile: linear_bf16(x, weight, bias, residual, alpha, tile=tile, x2=x2, residual2=residual2)
-    small = (ARM_SMALLM,) if (M <= 2560 and x2 is None and residual2 is None) else ()      # 64 x 128 tiles: 200-400 workgroups where 128 x 128 gives 100-200
+    small = (ARM_SMALLM, ARM_SMALLM + 2) if (M <= 2560 and x2 is None and residual2 is None) else ()      # 64 x 128 tiles: 200-400 workgroups where 128 x 128 gives 100-200
     use = _pick(key, hip, lib, Kd <= 640 and N <= 1024 and M >= 16384, split_arms(M, N, Kd) + small,
                 k320=(Kd == 320 and N % 320 == 0 and M % 64 == 0 and x2 is None and residual2 is None))
     if (use == 0 and lazy_residual and LAZY_RESIDUAL and residual is not None and residual2 is None and alpha == 1.0 and x2 is None

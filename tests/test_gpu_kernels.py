@@ -723,9 +723,9 @@ def test_gemm_k320_weight_stationary_arm(K):
     assert rel_inf(K.linear_bf16(xd6, wd6, None, None, 1.0, tile=15).float(), F.linear(xo6, wo6)) < 1e-2           # K != 320
 
 
-@pytest.mark.parametrize("arm", [600, 601])
+@pytest.mark.parametrize("arm", [600, 601, 602, 603])
 def test_gemm_small_m_tiles(K, arm):
-    """The 64 x 128 tiles of the ring kernel (a wave = 32 x 64; C-ABI tiles 19 / 20, autotune arms 600 / 601: offered for M <= 2560 projections, where
+    """The 64 x 128 tiles of the ring kernel (a wave = 32 x 64; C-ABI tiles 19 .. 22, autotune arms 600 .. 603 -- 64 x 128 on 4 waves, 128 x 128 and 64 x 256 on 8: offered for M <= 2560 projections, where
     128 x 128 tiles leave more than half of the 256 CUs idle): ragged M / N, bias / alpha / residual, bit-identical to the 128 x 128 kernel (same
     products in the same order), deterministic; two residuals and split-K fall back to tile 1."""
     dtype = torch.bfloat16
@@ -738,7 +738,7 @@ def test_gemm_small_m_tiles(K, arm):
         got = K.linear_bf16(xd, wd, bd, rd, 0.5, tile=arm)
         assert rel_inf(got.float(), 0.5 * F.linear(xo, wo, bo) + ro) < 1e-2, (M, N, Kd)
         assert torch.equal(got, K.linear_bf16(xd, wd, bd, rd, 0.5, tile=arm))
-        assert torch.equal(got, K.linear_bf16(xd, wd, bd, rd, 0.5, tile=1 if arm == 600 else 4))          # (tile 1: 64-deep k-tiles, tile 4: 32-deep)
+        assert torch.equal(got, K.linear_bf16(xd, wd, bd, rd, 0.5, tile=4 if arm == 601 else 1))          # (tile 1: 64-deep k-tiles, tile 4: 32-deep)
         assert rel_inf(K.linear_bf16(xd, wd, bd, None, 1.0, tile=arm).float(), F.linear(xo, wo, bo)) < 1e-2
         assert rel_inf(K.linear_bf16(xd, wd, None, rd, 1.0, tile=arm, residual2=r2d).float(), F.linear(xo, wo) + ro + r2o) < 1e-2
 

@@ -16,7 +16,7 @@ for (M, N, Kd, res) in [(1280, 1280, 1280, True), (1280, 3840, 1280, False), (12
     out = {}
     lib = (lambda: torch.add(r, F.linear(x, w, b))) if res else (lambda: F.linear(x, w, b))
     out["vendor"] = (K._time_ms(lib, reps=20), 0.0)
-    for arm in (1, 2, 13, 33, 397, 600, 601):
+    for arm in (1, 2, 13, 600, 602, 603):
         try:
             y = K.linear_bf16(x, w, b, r, 1.0, tile=arm)
             e = ((y.float() - ref).abs().max() / ref.abs().max()).item()
