@@ -686,13 +686,16 @@ static void launch_ln_g(const void* x, void* y, const float* gamma, const float*
 template <typename T>
 static bool try_launch_ln16(const void* x, void* y, const float* gamma, const float* beta, const float* pe, int64_t M, int C,
                             float eps, int pe_inner, int pe_frames, hipStream_t st, const void* addend = nullptr, void* sum_out = nullptr) {
-    const bool many = M >= 32768;                            // two rows per lane group when there are plenty of rows
+    static const int force_u = getenv("FMC_LN_U") ? atoi(getenv("FMC_LN_U")) : 0;      // A/B switch: 1 / 2 rows per lane group whatever M
+    // (one row per lane group everywhere: two measured 7-35 % slower at every FMC shape, also at M = 81920 -- tools/scratch/r04/probe_ln.py)
+    const bool many = force_u == 2;
     switch (C) {
         case 320: many ? launch_ln_g<T, 8, 2>(x, y, gamma, beta, pe, M, eps, pe_inner, pe_frames, st, addend, sum_out)
                        : launch_ln_g<T, 8, 1>(x, y, gamma, beta, pe, M, eps, pe_inner, pe_frames, st, addend, sum_out); return true;
         case 640: many ? launch_ln_g<T, 16, 2>(x, y, gamma, beta, pe, M, eps, pe_inner, pe_frames, st, addend, sum_out)
                        : launch_ln_g<T, 16, 1>(x, y, gamma, beta, pe, M, eps, pe_inner, pe_frames, st, addend, sum_out); return true;
-        case 1280: launch_ln_g<T, 32, 1>(x, y, gamma, beta, pe, M, eps, pe_inner, pe_frames, st, addend, sum_out); return true;
+        case 1280: force_u == 2 ? launch_ln_g<T, 32, 2>(x, y, gamma, beta, pe, M, eps, pe_inner, pe_frames, st, addend, sum_out)
+                                : launch_ln_g<T, 32, 1>(x, y, gamma, beta, pe, M, eps, pe_inner, pe_frames, st, addend, sum_out); return true;
         default: return false;
     }
 }
