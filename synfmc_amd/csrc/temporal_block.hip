@@ -622,11 +622,25 @@ extern "C" int fmc_temporal_block_set_debug(void* buf) {
     return 0;
 }
 
+int fmc_temporal_block640_launch(const void* h, void* out, const float* ln_gamma, const float* ln_bpe, float ln_eps, const void* w_merge_frag,
+                                 const void* pose_term, float merge_scale, const void* w_qkv_packed, const void* w_out_frag, const void* b_out,
+                                 int n_clips, int hw, float scale, hipStream_t st);      // temporal_block640.hip
+
 extern "C" int fmc_temporal_block_bf16(const void* h, void* out, const float* ln_gamma, const float* ln_bpe, float ln_eps, const void* w_merge_tm,
                                        const void* pose_term, float merge_scale, const void* w_qkv_packed, const void* w_out_tm, const void* b_out,
                                        float* ln_stats, float ln_stats_eps, int n_clips, int frames, int hw, int channels, int heads, float scale,
                                        void* stream) {
     if (!h || !out || !ln_gamma || !ln_bpe || !w_qkv_packed || !w_out_tm) FMC_FAIL(FMC_E_NULL, "temporal_block_bf16: NULL tensor");
+    if (channels == 640 && frames == 16 && heads == 8 && hw > 0 && n_clips > 0) {     // the 20x32 level: its own kernel and weight formats (see fmc_hip.h)
+        if ((w_merge_tm != nullptr) != (pose_term != nullptr)) FMC_FAIL(FMC_E_NULL, "temporal_block_bf16: w_merge and pose_term come together");
+        if (ln_stats) FMC_FAIL(FMC_E_SHAPE, "temporal_block_bf16: no row statistics at C = 640");
+        if ((int64_t)n_clips * frames * hw * channels * 2 >= ((int64_t)1 << 31)) FMC_FAIL(FMC_E_SHAPE, "temporal_block_bf16: tensor of 2 GiB or more");
+        if (!fmc_aligned16(h) || !fmc_aligned16(out) || !fmc_aligned16(w_qkv_packed) || !fmc_aligned16(w_out_tm) || !fmc_aligned16(ln_gamma) || !fmc_aligned16(ln_bpe) ||
+            (w_merge_tm && (!fmc_aligned16(w_merge_tm) || !fmc_aligned16(pose_term))) || (b_out && !fmc_aligned16(b_out)))
+            FMC_FAIL(FMC_E_ALIGN, "temporal_block_bf16: tensors must be 16-byte aligned");
+        return fmc_temporal_block640_launch(h, out, ln_gamma, ln_bpe, ln_eps, w_merge_tm, pose_term, merge_scale, w_qkv_packed, w_out_tm, b_out, n_clips, hw, scale,
+                                            (hipStream_t)stream);
+    }
     if (frames != 16 || channels != 320 || heads != 8 || hw <= 0 || hw % 10 || n_clips <= 0)
         FMC_FAIL(FMC_E_SHAPE, "temporal_block_bf16: the fused block exists for F = 16, C = 320, 8 heads, pixels %% 10 == 0 (got F=%d C=%d H=%d hw=%d)", frames,
                  channels, heads, hw);

@@ -1,0 +1,444 @@
+// The fused temporal attention block of the motion modules at the 20x32 level (C = 640, 8 heads x 80, F = 16 frames), gfx950.
+//
+// Same chain as temporal_block.hip (fmc/models/motion_module.py:287-300, fmc/models/attention_processor.py:255-291):
+//     n = LayerNorm_i(h) + pe;  m = s qkv_merge(n + pose) + n (block 0);  q | k | v = to_q / to_k / to_v (m);  o = softmax(q k^T d^-1/2) v over the frames;
+//     h' = to_out(o) + b + h
+// which at this level ran as a LayerNorm launch + three GEMM launches + the temporal attention launch (~160 us per block, 10 blocks per step).
+//
+// C = 640 changes the geometry of temporal_block.hip, not the idea.  A tile is 5 pixels x 16 frames = 80 rows (M = 20480 = 256 tiles: one per CU); X, the
+// resident 80 x 640 bf16 tile, takes 100 KiB, so a 32-deep sub-tile of a 640-row weight (40 KiB) cannot be double-buffered in what is left.  The weights
+// therefore never touch LDS: the 8 waves sit side by side along N (a wave = 80 rows x 80 columns = 5 x 5 v_mfma_f32_16x16x32_bf16 accumulators, as in
+// every 160x320 kernel of this library), so a wave's W rows are its own, and it reads them straight into registers from a copy PRE-PACKED IN FRAGMENT
+// ORDER (one contiguous KiB per 16-row block and k-step, `hip_ops.pack_w_frag80`), three k-steps ahead -- the scheme of phase D of temporal_block.hip,
+// here for all four projections.  No ring, no counted vmcnt and no barrier inside a main loop: X is read-only while a projection runs.
+//   A  h rows -> X by LDS-DMA (row = 16 pixel + frame; 16-byte chunks XOR-swizzled through the source address: conflict-free ds_read_b128),
+//      LayerNorm + (beta + pe[frame]) in place.
+//   B  (block 0) m = s x W_m^T + pose_term + x, in place; the pose-term rows arrive in three 16-row pass buffers (60 KiB) under the main loop.
+//   D  wave = head: q | k | v of the head for the 80 rows in registers (swapped product for q, k; un-swapped for v), scores = two 16x16x32 + one
+//      16x16x16 MFMA per pixel (d = 80 = 32 + 32 + 16: no padding), softmax across 4 lanes, PV = five 16x16x16; o parked in registers, then written over m.
+//   E  h' = o W_out^T + b + h: the residual rows come back through the pass buffers, h' is formed in place there and leaves with whole-row stores.
+// Roofline: MFMA.  Algorithmic flops = 2 M C (C [merge] + 3 C + C) + 4 M F C = 132 GF (block 0) / 106 GF (block 1) at M = 20480; HBM-side bytes 79 / 52 MB.
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+constexpr int T6_C = 640, T6_ROWS = 80, T6_PIX = 5, T6_F = 16, T6_CPR = 80;   // CPR: 16-byte chunks per row
+constexpr int T6_X_ELEMS = T6_ROWS * T6_C;                 // 51200 bf16 = 100 KiB
+constexpr int T6_PASS = 16 * T6_C;                         // one pass buffer: 16 rows (20 KiB)
+constexpr int T6_LDS = (T6_X_ELEMS + 3 * T6_PASS) * 2;     // 163840 B
+constexpr int T6_WAVE_W = 20 * 5 * 512;                    // bf16 elements of one wave's packed 80 x 640 weight slice (100 KiB)
+
+struct T6Params {
+    const bf16_t* h; bf16_t* out;                          // [clips, 16, hw, 640] channels-last video tokens
+    const float* ln_gamma;                                 // [640]
+    const float* ln_bpe;                                   // [16][640]: LayerNorm beta + positional-encoding row of frame f
+    float ln_eps;
+    const bf16_t* w_merge;                                 // fragment order [8 waves][20 k-steps][5 blocks][lane][8], or NULL
+    const bf16_t* pose_term;                               // s (W_m pose + b_m), layout of h (read when w_merge)
+    float merge_scale;
+    const bf16_t* w_qkv;                                   // [8 heads][q | k | v][20 k-steps][5 blocks][lane][8]
+    const bf16_t* w_out;                                   // fragment order as w_merge
+    const bf16_t* b_out;                                   // [640] or NULL
+    int n_clips, hw, tpc;
+    float scale_log2;
+};
+
+__device__ __forceinline__ void t6_dma(const __amdgpu_buffer_rsrc_t& rs, unsigned voff, void* lds) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, (int)voff, 0, 0, 0);
+}
+__device__ __forceinline__ void t6_unpack4(const u32x2& w, float (&o)[4]) {
+    o[0] = __uint_as_float(w[0] << 16); o[1] = __uint_as_float(w[0] & 0xffff0000u);
+    o[2] = __uint_as_float(w[1] << 16); o[3] = __uint_as_float(w[1] & 0xffff0000u);
+}
+// (see TB_SETTLE in temporal_block.hip: MFMA results are handed to VALU code only behind a scheduling fence + idle issue cycles)
+#define T6_SETTLE()                                                                                                      \
+    do {                                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+    } while (0)
+#define T6_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+template <bool HAS_MERGE>
+__global__ __launch_bounds__(512, 2)
+void temporal_block640_kernel(const T6Params P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* X = reinterpret_cast<bf16_t*>(smem_raw);             // [80][640], chunk c of row r at chunk c ^ ((r >> 1) & 7)
+    bf16_t* PB = X + T6_X_ELEMS;                                 // 3 pass buffers [16][640], X's swizzle
+    float* stats = reinterpret_cast<float*>(PB + 2 * T6_PASS);   // phase A only: (mean, rstd) x 80 rows, in pass buffer 2
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int xsw = (l15 >> 1) & 7;                              // chunk swizzle of my fragment rows (row = 16 mb + l15)
+    const int ecol = wave * 80 + 4 * kq;                         // my accumulator columns in phases B, E: ecol + 16 nb + j
+
+    const int tile = blockIdx.x;
+    const int clip = tile / P.tpc, p0 = (tile - clip * P.tpc) * T6_PIX;
+    const unsigned row0 = (unsigned)(((int64_t)clip * T6_F * P.hw + p0) * T6_C);      // (pixel 0, frame 0)
+    const unsigned fstride = (unsigned)(P.hw * T6_C);
+    const int64_t total_elems = (int64_t)P.n_clips * T6_F * P.hw * T6_C;
+    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)P.h, 0, (int)(total_elems * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsPT = __builtin_amdgcn_make_buffer_rsrc((void*)(HAS_MERGE ? P.pose_term : P.h), 0, (int)(total_elems * 2), 0x00020000);
+
+    // rows [r0, r0 + nr) of the tile of `rs` -> LDS at `dst`, row-major with X's chunk swizzle; nr * 80 chunks = pieces of 64, piece q = wave + 8 j
+    auto issue_rows = [&](const __amdgpu_buffer_rsrc_t& rs, int r0, int nr, bf16_t* dst) {
+        const int pieces = nr * T6_CPR / 64;
+#pragma unroll
+        for (int j = 0; j < 13; ++j) {
+            const int q = wave + 8 * j;
+            if (q < pieces) {
+                const int idx = 64 * q + lane, rl = idx / T6_CPR, pc = idx - rl * T6_CPR, r = r0 + rl, c = pc ^ ((r >> 1) & 7);
+                const unsigned src = (row0 + (unsigned)(r & 15) * fstride + (unsigned)(r >> 4) * T6_C + (unsigned)c * 8) * 2;
+                t6_dma(rs, src, dst + 64 * q * 8);
+            }
+        }
+    };
+    auto issue_pass = [&](const __amdgpu_buffer_rsrc_t& rs, int pss) { issue_rows(rs, 16 * pss, 16, PB + (pss % 3) * T6_PASS); };
+
+    // ================= phase A: h -> X, LayerNorm (+ pe) in place =================
+    issue_rows(rsH, 0, T6_ROWS, X);
+    T6_VMCNT0();
+    __syncthreads();
+    {
+        // statistics: 8 lanes per row, 10 chunks each, centred variance
+#pragma unroll 1
+        for (int r = tid >> 3; r < T6_ROWS; r += 64) {
+            const int q = tid & 7;
+            const bf16_t* xr = X + r * T6_C;
+            u32x4 x4[10];
+            float s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                x4[i] = *reinterpret_cast<const u32x4*>(xr + (q + 8 * i) * 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s1 += __uint_as_float(x4[i][j] << 16) + __uint_as_float(x4[i][j] & 0xffff0000u);
+            }
+            s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
+            const float mean = s1 * (1.f / 640.f);
+            float s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 10; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = __uint_as_float(x4[i][j] << 16) - mean, b = __uint_as_float(x4[i][j] & 0xffff0000u) - mean;
+                    s2 += a * a + b * b;
+                }
+            s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4);
+            if (q == 0) *reinterpret_cast<f32x2_t*>(stats + 2 * r) = f32x2_t{mean, rsqrtf(s2 * (1.f / 640.f) + P.ln_eps)};
+        }
+    }
+    __syncthreads();
+    if (tid < 480) {
+        // normalising thread = (logical chunk nc of 80, row group nrg of 6): rows nrg, nrg + 6, ...; (beta + pe) of the row's frame from the L1-resident table
+        const int nc = tid % 80, nrg = tid / 80;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(P.ln_gamma + nc * 8), g1 = *reinterpret_cast<const f32x4*>(P.ln_gamma + nc * 8 + 4);
+#pragma unroll 2
+        for (int r = nrg; r < T6_ROWS; r += 6) {
+            const float* bp = P.ln_bpe + (r & 15) * T6_C + nc * 8;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+            u32x4* px = reinterpret_cast<u32x4*>(X + r * T6_C + (nc ^ ((r >> 1) & 7)) * 8);
+            const u32x4 x4 = *px;
+            const f32x2_t st = *reinterpret_cast<const f32x2_t*>(stats + 2 * r);
+            const float m = st[0], rs = st[1];
+            u32x4 o4;
+            o4[0] = pack_bf2((__uint_as_float(x4[0] << 16) - m) * rs * g0[0] + b0[0], (__uint_as_float(x4[0] & 0xffff0000u) - m) * rs * g0[1] + b0[1]);
+            o4[1] = pack_bf2((__uint_as_float(x4[1] << 16) - m) * rs * g0[2] + b0[2], (__uint_as_float(x4[1] & 0xffff0000u) - m) * rs * g0[3] + b0[3]);
+            o4[2] = pack_bf2((__uint_as_float(x4[2] << 16) - m) * rs * g1[0] + b1[0], (__uint_as_float(x4[2] & 0xffff0000u) - m) * rs * g1[1] + b1[1]);
+            o4[3] = pack_bf2((__uint_as_float(x4[3] << 16) - m) * rs * g1[2] + b1[2], (__uint_as_float(x4[3] & 0xffff0000u) - m) * rs * g1[3] + b1[3]);
+            *px = o4;
+        }
+    }
+    __syncthreads();                                              // X = x = LayerNorm(h) + pe; the pass buffers are free
+
+    // ---- one 80 x 640 x 640 projection with the A operand resident in X and MY 80 weight rows streamed from `wbase` (fragment order) -----------------
+    f32x4 acc[5][5];
+    auto project = [&](const bf16_t* wbase) {
+        const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(wbase + (size_t)wave * T6_WAVE_W), 0, T6_WAVE_W * 2, 0x00020000);
+        int wl = lane * 16;
+        asm volatile("" : "+v"(wl));
+        u32x4 wfr[3][5];
+        auto load_w = [&](int g) {
+#pragma unroll
+            for (int nb = 0; nb < 5; ++nb) wfr[g % 3][nb] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wl, (g * 5 + nb) * 1024, 0);
+        };
+        load_w(0);
+        load_w(1);
+        auto step = [&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g + 2 < 20) load_w(g + 2);
+            int kqx = kq ^ xsw, xrow_o = l15 * T6_C;
+            asm volatile("" : "+v"(kqx), "+v"(xrow_o));
+            const int xo = xrow_o + ((g >> 1) * 8 + (((g & 1) * 4) ^ kqx)) * 8;
+            __builtin_amdgcn_sched_barrier(0);
+            u32x4 af3[3];
+            af3[0] = *reinterpret_cast<const u32x4*>(X + 0 * 16 * T6_C + xo);
+            af3[1] = *reinterpret_cast<const u32x4*>(X + 1 * 16 * T6_C + xo);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+            for (int mb = 0; mb < 5; ++mb) {
+                if (mb + 2 < 5) af3[(mb + 2) % 3] = *reinterpret_cast<const u32x4*>(X + (mb + 2) * 16 * T6_C + xo);
+                union { bf16x8 v; u32x4 u; } a;
+                a.u = af3[mb % 3];
+#pragma unroll
+                for (int nb = 0; nb < 5; ++nb) {
+                    union { bf16x8 v; u32x4 u; } w;
+                    w.u = wfr[g % 3][nb];
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, a.v, acc[mb][nb], 0, 0, 0);
+                }
+                if (mb + 2 < 5) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+            }
+        };
+#define T6_G(G) step(std::integral_constant<int, G>{})
+        T6_G(0); T6_G(1); T6_G(2); T6_G(3); T6_G(4); T6_G(5); T6_G(6); T6_G(7); T6_G(8); T6_G(9);
+        T6_G(10); T6_G(11); T6_G(12); T6_G(13); T6_G(14); T6_G(15); T6_G(16); T6_G(17); T6_G(18); T6_G(19);
+#undef T6_G
+        T6_SETTLE();
+    };
+
+    // ================= phase B: m = s x W_m^T + pose_term + x (in place) =================
+    if (HAS_MERGE) {
+        issue_pass(rsPT, 0);
+        issue_pass(rsPT, 1);
+        issue_pass(rsPT, 2);
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+#pragma unroll
+            for (int b = 0; b < 5; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        project(P.w_merge);
+        T6_VMCNT0();
+        __syncthreads();                                          // every wave is done reading x; passes 0-2 have landed
+#pragma unroll
+        for (int pss = 0; pss < 5; ++pss) {
+            if (pss >= 3) {
+                T6_VMCNT0();
+                __syncthreads();
+            }
+            {
+                const bf16_t* Pt = PB + (pss % 3) * T6_PASS + l15 * T6_C;
+                bf16_t* Xr = X + (pss * 16 + l15) * T6_C;
+#pragma unroll
+                for (int nb = 0; nb < 5; ++nb) {
+                    const int col = ecol + nb * 16, off = (((col >> 3) ^ xsw) << 3) + (col & 7);
+                    u32x2* px = reinterpret_cast<u32x2*>(Xr + off);
+                    float xv[4], pv[4];
+                    t6_unpack4(*px, xv);
+                    t6_unpack4(*reinterpret_cast<const u32x2*>(Pt + off), pv);
+                    *px = u32x2{pack_bf2(acc[pss][nb][0] * P.merge_scale + pv[0] + xv[0], acc[pss][nb][1] * P.merge_scale + pv[1] + xv[1]),
+                                pack_bf2(acc[pss][nb][2] * P.merge_scale + pv[2] + xv[2], acc[pss][nb][3] * P.merge_scale + pv[3] + xv[3])};
+                }
+            }
+            if (pss + 3 < 5) {
+                __syncthreads();                                  // everybody has read pass pss: its buffer takes pass pss + 3
+                issue_pass(rsPT, pss + 3);
+            }
+        }
+        __syncthreads();                                          // X = m
+    }
+
+    // ================= phase D: wave = head.  q | k | v projections + attention, all in registers =================
+    u32x2 o_pk[5][5];                                             // o of my head: (row 16 m + l15, channels 16 b + 4 kq ..) as 4 bf16
+    {
+        const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(P.w_qkv + (size_t)wave * (3 * T6_WAVE_W)), 0, 3 * T6_WAVE_W * 2, 0x00020000);
+        int qkv_lane = lane * 16;
+        asm volatile("" : "+v"(qkv_lane));
+        u32x4 wq[3][5];                                           // [stage][block]
+        auto load_step = [&](int s) {
+#pragma unroll
+            for (int b = 0; b < 5; ++b) wq[s % 3][b] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, qkv_lane, (s * 5 + b) * 1024, 0);
+        };
+        load_step(0);
+        load_step(1);
+        f32x4 pacc[5][5];
+        bf16x8 q8a[5], q8b[5];
+        s16x4 q4[5];
+        u32x2 p_pk[5];
+        auto zero_pacc = [&]() {
+#pragma unroll
+            for (int m = 0; m < 5; ++m)
+#pragma unroll
+                for (int b = 0; b < 5; ++b) pacc[m][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        };
+        auto step = [&](auto part_c, auto ks_c) {
+            constexpr int part = decltype(part_c)::value, ks = decltype(ks_c)::value, s = part * 20 + ks;
+            if constexpr (s + 2 < 60) load_step(s + 2);
+            int kqx = kq ^ xsw, xrow_o = l15 * T6_C;
+            asm volatile("" : "+v"(kqx), "+v"(xrow_o));
+            const int xo = xrow_o + ((ks >> 1) * 8 + (((ks & 1) * 4) ^ kqx)) * 8;
+            __builtin_amdgcn_sched_barrier(0);
+            u32x4 af3[3];
+            af3[0] = *reinterpret_cast<const u32x4*>(X + 0 * 16 * T6_C + xo);
+            af3[1] = *reinterpret_cast<const u32x4*>(X + 1 * 16 * T6_C + xo);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+            for (int m = 0; m < 5; ++m) {
+                if (m + 2 < 5) af3[(m + 2) % 3] = *reinterpret_cast<const u32x4*>(X + (m + 2) * 16 * T6_C + xo);
+                union { bf16x8 v; u32x4 u; } a;
+                a.u = af3[m % 3];
+#pragma unroll
+                for (int b = 0; b < 5; ++b) {
+                    union { bf16x8 v; u32x4 u; } w;
+                    w.u = wq[s % 3][b];
+                    if constexpr (part < 2) pacc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, a.v, pacc[m][b], 0, 0, 0);   // (frame l15, 4 channels)
+                    else pacc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, w.v, pacc[m][b], 0, 0, 0);                     // (channel l15, 4 frames)
+                }
+                if (m + 2 < 5) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+            }
+        };
+#define T6_STEP(PART, KS) step(std::integral_constant<int, PART>{}, std::integral_constant<int, KS>{})
+#define T6_PART(PART)                                                                                                    \
+    T6_STEP(PART, 0); T6_STEP(PART, 1); T6_STEP(PART, 2); T6_STEP(PART, 3); T6_STEP(PART, 4);                            \
+    T6_STEP(PART, 5); T6_STEP(PART, 6); T6_STEP(PART, 7); T6_STEP(PART, 8); T6_STEP(PART, 9);                            \
+    T6_STEP(PART, 10); T6_STEP(PART, 11); T6_STEP(PART, 12); T6_STEP(PART, 13); T6_STEP(PART, 14);                       \
+    T6_STEP(PART, 15); T6_STEP(PART, 16); T6_STEP(PART, 17); T6_STEP(PART, 18); T6_STEP(PART, 19)
+        auto pack8 = [](const f32x4& x, const f32x4& y) {
+            union { bf16x8 v; u32x4 u; } t;
+            t.u = u32x4{pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
+            return t.v;
+        };
+        auto pack4 = [](const f32x4& x) {
+            union { u32x2 u; s16x4 s; } t;
+            t.u = u32x2{pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3])};
+            return t.s;
+        };
+        // ---- q ----
+        zero_pacc();
+        T6_PART(0);
+        T6_SETTLE();
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            q8a[m] = pack8(pacc[m][0], pacc[m][1]);
+            q8b[m] = pack8(pacc[m][2], pacc[m][3]);
+            q4[m] = pack4(pacc[m][4]);
+        }
+        // ---- k, scores, softmax ----
+        zero_pacc();
+        T6_PART(1);
+        T6_SETTLE();
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            // S^T[key][query] = K Q^T: A = k rows, B = q rows (both index the reduction by the same channel permutation)
+            const bf16x8 k8a = pack8(pacc[m][0], pacc[m][1]), k8b = pack8(pacc[m][2], pacc[m][3]);
+            const s16x4 k4 = pack4(pacc[m][4]);
+            const f32x4 sc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k8a, q8a[m], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const f32x4 sc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k8b, q8b[m], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const f32x4 sc3 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(k4, q4[m], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            T6_SETTLE();
+            const f32x4 sc = sc1 + sc2 + sc3;
+            float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])) * P.scale_log2;
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float e[4], sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { e[j] = __builtin_amdgcn_exp2f(sc[j] * P.scale_log2 - mx); sum += e[j]; }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.f / sum;
+            p_pk[m] = u32x2{pack_bf2(e[0] * inv, e[1] * inv), pack_bf2(e[2] * inv, e[3] * inv)};
+        }
+        // ---- v, o = P V ----
+        zero_pacc();
+        T6_PART(2);
+        T6_SETTLE();
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            union { u32x2 u; s16x4 s; } pb;
+            pb.u = p_pk[m];
+            f32x4 o[5];
+#pragma unroll
+            for (int b = 0; b < 5; ++b) o[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pack4(pacc[m][b]), pb.s, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);   // (query l15, channels 16 b + 4 kq ..)
+            T6_SETTLE();
+#pragma unroll
+            for (int b = 0; b < 5; ++b) o_pk[m][b] = u32x2{pack_bf2(o[b][0], o[b][1]), pack_bf2(o[b][2], o[b][3])};
+        }
+#undef T6_PART
+#undef T6_STEP
+    }
+    __syncthreads();                                              // every head is done with m: o may overwrite it
+    {
+        int orow = l15 * T6_C, okq = kq, oxs = xsw;
+        asm volatile("" : "+v"(orow), "+v"(okq), "+v"(oxs));
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+            const int col = 80 * wave + 16 * b + 4 * okq;
+            const int off = orow + (((col >> 3) ^ oxs) << 3) + (col & 7);
+#pragma unroll
+            for (int m = 0; m < 5; ++m) *reinterpret_cast<u32x2*>(X + m * 16 * T6_C + off) = o_pk[m][b];
+        }
+    }
+    // the residual rows (h of this tile) come back through the pass buffers under the out-projection
+    issue_pass(rsH, 0);
+    issue_pass(rsH, 1);
+    issue_pass(rsH, 2);
+    __syncthreads();                                              // X = o
+
+    // ================= phase E: h' = o W_out^T + b + h =================
+#pragma unroll
+    for (int nb = 0; nb < 5; ++nb) {
+        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (P.b_out) t6_unpack4(*reinterpret_cast<const u32x2*>(P.b_out + ecol + nb * 16), b4);
+#pragma unroll
+        for (int mb = 0; mb < 5; ++mb) acc[mb][nb] = f32x4{b4[0], b4[1], b4[2], b4[3]};
+    }
+    project(P.w_out);
+#pragma unroll
+    for (int pss = 0; pss < 5; ++pss) {
+        T6_VMCNT0();
+        __syncthreads();                                          // pass pss has landed (all waves' pieces)
+        bf16_t* Hs = PB + (pss % 3) * T6_PASS;
+        {
+            bf16_t* Hr = Hs + l15 * T6_C;
+#pragma unroll
+            for (int nb = 0; nb < 5; ++nb) {
+                const int col = ecol + nb * 16, off = (((col >> 3) ^ xsw) << 3) + (col & 7);
+                u32x2* ph = reinterpret_cast<u32x2*>(Hr + off);
+                float hv[4];
+                t6_unpack4(*ph, hv);
+                *ph = u32x2{pack_bf2(acc[pss][nb][0] + hv[0], acc[pss][nb][1] + hv[1]), pack_bf2(acc[pss][nb][2] + hv[2], acc[pss][nb][3] + hv[3])};
+            }
+        }
+        __syncthreads();                                          // the 16 finished rows (pixel pss, frames 0-15) are in the pass buffer
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int c = tid + 512 * j;
+            if (j < 2 || tid < 256) {                             // 16 rows x 80 chunks = 2.5 x 512
+                const int rl = c / T6_CPR, pc = c - rl * T6_CPR, r = 16 * pss + rl, lc = pc ^ ((r >> 1) & 7);
+                const unsigned dst = row0 + (unsigned)(r & 15) * fstride + (unsigned)(r >> 4) * T6_C + (unsigned)lc * 8;
+                *reinterpret_cast<u32x4*>(P.out + dst) = *reinterpret_cast<const u32x4*>(Hs + c * 8);
+            }
+        }
+        if (pss + 3 < 5) {
+            __syncthreads();                                      // everybody has read the buffer: it takes pass pss + 3
+            issue_pass(rsH, pss + 3);
+        }
+    }
+}
+
+}  // namespace
+
+// called by fmc_temporal_block_bf16 (temporal_block.hip) for channels == 640; the arguments are already checked for NULL / alignment there
+int fmc_temporal_block640_launch(const void* h, void* out, const float* ln_gamma, const float* ln_bpe, float ln_eps, const void* w_merge_frag,
+                                 const void* pose_term, float merge_scale, const void* w_qkv_packed, const void* w_out_frag, const void* b_out,
+                                 int n_clips, int hw, float scale, hipStream_t st) {
+    if (hw % 5) FMC_FAIL(FMC_E_SHAPE, "temporal_block_bf16: C = 640 wants pixels %% 5 == 0 (got %d)", hw);
+    T6Params P{};
+    P.h = (const bf16_t*)h; P.out = (bf16_t*)out; P.ln_gamma = ln_gamma; P.ln_bpe = ln_bpe; P.ln_eps = ln_eps;
+    P.w_merge = (const bf16_t*)w_merge_frag; P.pose_term = (const bf16_t*)pose_term; P.merge_scale = merge_scale;
+    P.w_qkv = (const bf16_t*)w_qkv_packed; P.w_out = (const bf16_t*)w_out_frag; P.b_out = (const bf16_t*)b_out;
+    P.n_clips = n_clips; P.hw = hw; P.tpc = hw / 5;
+    P.scale_log2 = scale * 1.4426950408889634f;
+    const unsigned grid = (unsigned)(n_clips * P.tpc);
+    static bool raised = false;
+    if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block640_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, T6_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block640_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, T6_LDS);
+        raised = true;
+    }
+    if (w_merge_frag) hipLaunchKernelGGL((temporal_block640_kernel<true>), dim3(grid), dim3(512), T6_LDS, st, P);
+    else hipLaunchKernelGGL((temporal_block640_kernel<false>), dim3(grid), dim3(512), T6_LDS, st, P);
+    FMC_CHECK_LAUNCH("fmc_temporal_block_bf16 (C = 640)");
+    return 0;
+}

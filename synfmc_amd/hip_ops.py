@@ -982,17 +982,41 @@ def pack_temporal_qkv(w_qkv: torch.Tensor, heads: int = 8) -> torch.Tensor:
     return torch.cat(out, 1).contiguous().view(-1)
 
 
+def pack_w_frag80(w: torch.Tensor) -> torch.Tensor:
+    """`[640, 640]` projection weight -> the MFMA-fragment order of the C = 640 fused temporal block (`temporal_block640.hip`): wave w owns output columns
+    80 w .. 80 w + 79; per wave [k-step K / 32][block of 16 rows][lane = 16 * (k chunk of 8) + row][8]: the fragment of one block and k-step is one contiguous
+    KiB, a wave's 100 (k-step, block) fragments one contiguous 100-KiB stream that never passes through LDS."""
+    N, Kd = w.shape
+    assert N == 640 and Kd == 640, "the C = 640 fused temporal block"
+    return w.detach().reshape(8, 5, 16, Kd // 32, 4, 8).permute(0, 3, 1, 4, 2, 5).contiguous().view(-1)
+
+
+def pack_temporal_qkv80(w_qkv: torch.Tensor, heads: int = 8) -> torch.Tensor:
+    """Fused temporal `[3 C, C]` projection at C = 640 (d = 80 = five whole 16-row blocks per head and part, no padding): per head [q | k | v], every part
+    as [k-step][block][lane][8] like `pack_w_frag80`."""
+    C3, C = w_qkv.shape
+    assert C3 == 3 * C and C == 640 and heads == 8, "the C = 640 fused temporal block: 8 heads x 80"
+    w = w_qkv.detach()
+    parts = [w[i * C:(i + 1) * C].reshape(heads, 5, 16, C // 32, 4, 8).permute(0, 3, 1, 4, 2, 5).reshape(heads, -1) for i in range(3)]
+    return torch.cat(parts, 1).contiguous().view(-1)
+
+
 def temporal_block_supported(h: torch.Tensor, heads: int) -> bool:
-    """`[B, F, hw, C]` bf16 tokens the fused block takes: F = 16, C = 320, 8 heads, hw % 10 == 0, inference."""
-    return (h.is_cuda and h.dtype == torch.bfloat16 and h.ndim == 4 and h.is_contiguous() and h.shape[1] == 16 and h.shape[3] == 320 and heads == 8
-            and h.shape[2] % 10 == 0 and h.numel() * 2 < (1 << 31) and not torch.is_grad_enabled())
+    """`[B, F, hw, C]` bf16 tokens the fused block takes: F = 16, 8 heads, C = 320 with hw % 10 == 0 or C = 640 with hw % 5 == 0, inference."""
+    return (h.is_cuda and h.dtype == torch.bfloat16 and h.ndim == 4 and h.is_contiguous() and h.shape[1] == 16 and heads == 8
+            and ((h.shape[3] == 320 and h.shape[2] % 10 == 0) or (h.shape[3] == 640 and h.shape[2] % 5 == 0 and TEMPORAL_FUSED_640))
+            and h.numel() * 2 < (1 << 31) and not torch.is_grad_enabled())
+
+
+TEMPORAL_FUSED_640 = os.environ.get("FMC_TEMPORAL_FUSED_640", "1") != "0"      # A/B switch: the 20x32-level blocks on the un-fused chain
 
 
 def temporal_block(h: torch.Tensor, ln_gamma: torch.Tensor, ln_bpe: torch.Tensor, ln_eps: float, w_qkv_packed: torch.Tensor,
                    w_out_tm: torch.Tensor, b_out: Optional[torch.Tensor], scale: float, w_merge_tm: Optional[torch.Tensor] = None,
                    pose_term: Optional[torch.Tensor] = None, merge_scale: float = 1.0, stats_eps: Optional[float] = None):
     """One attention block of the temporal transformer in one launch (`fmc_temporal_block_bf16`): LayerNorm (+ pe) -> [Camera-Adapter merge] ->
-    q | k | v -> attention over the frames -> out-projection + bias + h.  Returns `out` or `(out, ln_stats)` when `stats_eps` is given."""
+    q | k | v -> attention over the frames -> out-projection + bias + h.  Returns `out` or `(out, ln_stats)` when `stats_eps` is given.
+    C = 320: `w_qkv_packed = pack_temporal_qkv(..)`, `w_out_tm` / `w_merge_tm` = `_w_tilemajor(..)`.  C = 640: `pack_temporal_qkv80`, `pack_w_frag80`, no statistics."""
     _dev(h, ln_gamma, ln_bpe, w_qkv_packed, w_out_tm, b_out, w_merge_tm, pose_term)
     B, F, hw, C = h.shape
     assert h.is_contiguous() and ln_gamma.dtype == torch.float32 and ln_bpe.dtype == torch.float32 and tuple(ln_bpe.shape) == (F, C) and ln_bpe.is_contiguous()

@@ -149,7 +149,7 @@ class TemporalTransformerBlock(nn.Module):
     # ---- the fused attention block (`fmc_temporal_block_bf16`, round 4) -------------------------------------------------------------------
     def fused_blocks_ok(self, hidden_states, attention_mask, cross_attention_kwargs) -> bool:
         """Every attention block of this transformer block can run as ONE launch each (LayerNorm + pe -> [Camera-Adapter merge] -> q | k | v ->
-        attention over the frames -> out-projection + residual): inference, bf16 `[B, 16, P, 320]` tokens with P % 10 == 0, 8 heads, plain /
+        attention over the frames -> out-projection + residual): inference, bf16 `[B, 16, P, 320]` tokens with P % 10 == 0 or `[B, 16, P, 640]` with P % 5 == 0, 8 heads, plain /
         Camera-Adapter / frozen-LoRA processors, nothing applied after the output projection.  Anything else keeps the un-fused chain."""
         if not TEMPORAL_FUSED or attention_mask is not None or hidden_states.ndim != 4:
             return False
@@ -188,9 +188,23 @@ class TemporalTransformerBlock(nn.Module):
         key = (w_qkv.data_ptr(), w_qkv._version, w_o.data_ptr(), w_o._version)
         hit = attn.__dict__.get("_fused_tb")
         if hit is None or hit[0] != key:
-            hit = (key, K.pack_temporal_qkv(w_qkv, attn.heads), K._w_tilemajor(w_o))
+            if w_o.shape[0] == 640:                      # the 20x32 level: weights in MFMA-fragment order (temporal_block640.hip)
+                hit = (key, K.pack_temporal_qkv80(w_qkv, attn.heads), K.pack_w_frag80(w_o))
+            else:
+                hit = (key, K.pack_temporal_qkv(w_qkv, attn.heads), K._w_tilemajor(w_o))
             attn.__dict__["_fused_tb"] = hit
         return hit[1], hit[2]
+
+    @staticmethod
+    def _merge_packed(proc, wm):
+        if wm.shape[0] != 640:
+            return K._w_tilemajor(wm)
+        key = (wm.data_ptr(), wm._version)
+        hit = proc.__dict__.get("_fused_wm")
+        if hit is None or hit[0] != key:
+            hit = (key, K.pack_w_frag80(wm))
+            proc.__dict__["_fused_wm"] = hit
+        return hit[1]
 
     def _forward_fused(self, hidden_states, cross_attention_kwargs):
         frames = hidden_states.shape[1]
@@ -215,14 +229,15 @@ class TemporalTransformerBlock(nn.Module):
                 pose = _pose_tokens(cross_attention_kwargs["pose_feature"], h)
                 assert pose.shape == h.shape, "pose_feature does not match the hidden states"
                 wm, bm = proc.qkv_merge.weight, proc.qkv_merge.bias
-                kw = dict(w_merge_tm=K._w_tilemajor(wm), pose_term=proc._pose_term(pose, wm, bm, s), merge_scale=s)
-            last = i == n_blocks - 1
+                kw = dict(w_merge_tm=self._merge_packed(proc, wm), pose_term=proc._pose_term(pose, wm, bm, s), merge_scale=s)
+            last = i == n_blocks - 1 and h.shape[-1] == 320     # (row statistics for the feed-forward's LayerNorm-in-GEMM: the 40x64 level only)
             out = K.temporal_block(h, gamma, bpe, self.norms[i].eps, w_qkv, w_o, attn.to_out[0].bias, attn.scale,
                                    stats_eps=self.ff_norm.eps if last else None, **kw)
             h, stats = out if last else (out, None)
-        # the feed-forward's norm is applied by its GEGLU projection from the row statistics the last block left
-        K.ln_epilogue_calls["emitted"] += 1
-        h._fmc_ln = (stats, self.ff_norm._ln_key(None, 1, 1), True)
+        if stats is not None:
+            # the feed-forward's norm is applied by its GEGLU projection from the row statistics the last block left
+            K.ln_epilogue_calls["emitted"] += 1
+            h._fmc_ln = (stats, self.ff_norm._ln_key(None, 1, 1), True)
         hidden_states, n = self.ff_norm.skip(h, defer=True)
         return self.ff(n, residual=hidden_states)
 

@@ -1740,6 +1740,51 @@ def _temporal_block_reference(h, gamma, beta, pe, eps, wqkv, wout, bout, heads, 
 
 
 @pytest.mark.parametrize("merge", [True, False])
+@pytest.mark.parametrize("B,hw", [(1, 5), (2, 640), (3, 35)])
+def test_temporal_block_fused_640(K, merge, B, hw):
+    """The same block at the 20x32 level (C = 640, 8 heads x 80; `temporal_block640.hip`: 80-row tiles, weights streamed in fragment order straight into
+    registers): one tile, the bench size (2 x 640 pixels = 256 tiles), an odd tile count; element-wise bf16 bound against the restatement with the
+    kernel's rounding points, max norm against the plain fp32 chain; deterministic."""
+    dtype = torch.bfloat16
+    C, H, Fr, d = 640, 8, 16, 80
+    ho, hd = rnd((B, Fr, hw, C), 1, dtype, scale=1.5, shift=0.2)
+    go, _ = rnd((C,), 2, torch.float32, scale=0.3, shift=1.0)
+    bo, _ = rnd((C,), 3, torch.float32, scale=0.2)
+    peo, _ = rnd((32, C), 4, torch.float32, scale=0.7)
+    wqo, wqd = rnd((3 * C, C), 5, dtype, scale=C ** -0.5 * 1.5)
+    woo, wod = rnd((C, C), 6, dtype, scale=C ** -0.5)
+    boo, bod = rnd((C,), 7, dtype, scale=0.3)
+    wmo, wmd = rnd((C, C), 8, dtype, scale=C ** -0.5)
+    bmo, bmd = rnd((C,), 9, dtype, scale=0.3)
+    poo, pod = rnd((B, Fr, hw, C), 10, dtype)
+    s = 0.7
+    bpe = (bo[None] + peo[:Fr]).cuda().contiguous()
+    pt = K.linear_bf16(pod.view(-1, C), wmd, bmd, None, s).view(B, Fr, hw, C) if merge else None
+    kw = dict(w_merge_tm=K.pack_w_frag80(wmd), pose_term=pt, merge_scale=s) if merge else {}
+    run = lambda: K.temporal_block(hd, go.cuda(), bpe, 1e-5, K.pack_temporal_qkv80(wqd), K.pack_w_frag80(wod), bod, d ** -0.5, **kw)
+    out = run()
+
+    def reference(round_bf16):
+        r = (lambda t: t.bfloat16().float()) if round_bf16 else (lambda t: t)
+        x = r(F.layer_norm(ho, (C,), go, bo, 1e-5) + peo[None, :Fr, None, :])
+        m = r(s * F.linear(x, wmo) + pt.float().cpu() + x) if merge else x
+        qkv = r(F.linear(m, wqo))
+        q, k, v = (t.reshape(B, Fr, hw, H, d).permute(0, 2, 3, 1, 4) for t in qkv.chunk(3, dim=-1))
+        p = r(torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, dim=-1))
+        o = r(p @ v).permute(0, 3, 1, 2, 4).reshape(B, Fr, hw, C)
+        return F.linear(o, woo, boo) + ho
+    ref_r, ref_f = reference(True), reference(False)
+    assert rel_inf(out.float(), ref_f) < 2e-2, (merge, B, hw)
+    err = (out.float().cpu() - ref_r).abs()
+    bound = 2.0 ** -8 * ref_r.abs() + 0.08
+    assert not bool((err > bound).any()), f"{int((err > bound).sum())} / {err.numel()} beyond the bound, worst {float((err - bound).max()):.3e} at {int((err - bound).flatten().argmax())}"
+    for it in range(3):
+        assert torch.equal(run(), out)
+    with pytest.raises(ValueError):
+        K.temporal_block(hd[:, :, :hw - 1].contiguous(), go.cuda(), bpe, 1e-5, K.pack_temporal_qkv80(wqd), K.pack_w_frag80(wod), bod, d ** -0.5)
+
+
+@pytest.mark.parametrize("merge", [True, False])
 @pytest.mark.parametrize("B,hw", [(1, 10), (2, 2560), (3, 70)])
 def test_temporal_block_fused(K, merge, B, hw):
     """`fmc_temporal_block_bf16`: LayerNorm + pe -> [Camera-Adapter merge + pose term] -> q | k | v -> attention over the 16 frames ->

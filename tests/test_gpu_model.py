@@ -594,8 +594,10 @@ def test_pipeline_end_to_end_with_text_encoder_and_vae(stack):
 
 
 @pytest.mark.gpu
-def test_temporal_transformer_block_fused_kernel_equals_the_unfused_chain():
-    """The motion module's transformer block at the 40x64-level width (C = 320, 8 heads, 16 frames, pixels % 10 == 0) runs its two attention blocks
+@pytest.mark.parametrize("C,P", [(320, 40), (640, 35)])
+def test_temporal_transformer_block_fused_kernel_equals_the_unfused_chain(C, P):
+    """The motion module's transformer block at the 40x64-level width (C = 320, 8 heads, 16 frames, pixels % 10 == 0) and at the 20x32-level width
+    (C = 640, pixels % 5 == 0: `temporal_block640.hip`) runs its two attention blocks
     as one `fmc_temporal_block_bf16` launch each (motion_module.TEMPORAL_FUSED); the result must match the un-fused chain (LayerNorm epilogue /
     merge GEMM / fused QKV GEMM / temporal attention kernel / out-projection) on the same weights -- Camera-Adapter block with a non-zero
     `qkv_merge` and pose feature, plain second block, feed-forward fed from the row statistics the last fused block leaves -- and the fp32
@@ -603,7 +605,7 @@ def test_temporal_transformer_block_fused_kernel_equals_the_unfused_chain():
     from synfmc_amd.models import motion_module as MM
     from synfmc_amd.models.attention_processor import AttnProcessor, PoseAdaptorAttnProcessor
     torch.manual_seed(3)
-    C, H, Fr, P, B = 320, 8, 16, 40, 2
+    H, Fr, B = 8, 16, 2
     blk = MM.TemporalTransformerBlock(dim=C, num_attention_heads=H, attention_head_dim=C // H, attention_block_types=("Temporal_Self", "Temporal_Self"),
                                       temporal_position_encoding=True, temporal_position_encoding_max_len=32)
     blk.attention_blocks[0].set_processor(PoseAdaptorAttnProcessor(hidden_size=C, pose_feature_dim=C, query_condition=True, key_value_condition=True,
@@ -641,4 +643,4 @@ def test_temporal_transformer_block_fused_kernel_equals_the_unfused_chain():
     assert rel_inf(fused, plain) < 2e-2
     e_f, e_p = rel_inf(fused, ref), rel_inf(plain, ref)
     assert e_f < 2e-2 and e_f < 2.0 * e_p + 2e-3, (e_f, e_p)               # the fused kernel is as close to fp32 as the chain it replaces
-    assert not blk.fused_blocks_ok(x[:, :, :39].contiguous(), None, kw)      # pixels % 10 != 0: the un-fused chain
+    assert not blk.fused_blocks_ok(x[:, :, :P - 1].contiguous(), None, kw)   # pixels % 10 (% 5 at C = 640) != 0: the un-fused chain
