@@ -32,6 +32,7 @@ The JSON line also carries
   roofline_temporal_block -- the FUSED temporal attention block of a 40x64-level motion module (LayerNorm + Camera-Adapter merge +
                   q | k | v + attention over the frames + out-projection in one launch): (merge + QKV + core + out) flops / launch time
                   against the 2.5 PFLOP/s dense bf16 MFMA peak -- the north-star's "MFMA utilisation on temporal attention";
+  roofline_temporal_block_l1 -- the same block at the 20x32 level (C = 640, 8 heads x 80: its own kernel, temporal_block640.hip);
   cpu_baseline -- the oracle (fp32 PyTorch restatement; the reference itself needs diffusers, not installable)
                   timed on this node's host cores on ONE real step of the metric's configuration (no extrapolation).
 """
@@ -134,7 +135,8 @@ _KERNEL_SOURCES = {"sa40d": ("spatial_attn.hip", "attn_common.h", "common.h"),
                    "temporal": ("temporal_attn.hip", "attn_common.h", "common.h"),
                    "conv": ("gemm_conv.hip", "common.h"),
                    "proj": ("gemm_conv.hip", "common.h"),
-                   "tblock": ("temporal_block.hip", "common.h")}
+                   "tblock": ("temporal_block.hip", "common.h"),
+                   "tblock640": ("temporal_block640.hip", "common.h")}
 
 
 def kernel_source_sha(kernel: str) -> str:
@@ -256,6 +258,43 @@ def measure_proj_roofline(device, dtype, iters=20):
            "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
            "avg_launch_ms": round(ms, 4), "flops_per_launch": flops, "traffic_algorithmic": 2.0 * (M * Kd + N * Kd + M * N // 2)}
     out.update(recorded_counters("proj"))
+    return out
+
+
+def measure_temporal_block_l1_roofline(device, dtype, iters=20):
+    """The same fused block at the 20x32 level (C = 640, 8 heads x 80; `temporal_block640.hip`: 80-row tiles, weights streamed in fragment order into
+    registers), as the U-Net issues it: CFG batch 2 x 640 pixels x 16 frames = 20480 rows = 256 tiles, one per CU."""
+    from synfmc_amd import hip_ops as K
+    B, Fr, hw, C, H = 2, FRAMES, (HEIGHT // 16) * (WIDTH // 16), WIDTHS[1], 8
+    if not (Fr == 16 and C == 640 and hw % 5 == 0):
+        return None
+    h = torch.randn(B, Fr, hw, C, device=device, dtype=dtype)
+    pt = torch.randn(B, Fr, hw, C, device=device, dtype=dtype)
+    g = torch.randn(C, device=device) * 0.2 + 1
+    bpe = torch.randn(Fr, C, device=device)
+    wq = torch.randn(3 * C, C, device=device, dtype=dtype) * C ** -0.5
+    wo = torch.randn(C, C, device=device, dtype=dtype) * C ** -0.5
+    wm = torch.randn(C, C, device=device, dtype=dtype) * C ** -0.5
+    bo = torch.randn(C, device=device, dtype=dtype)
+    wqp, wot, wmt = K.pack_temporal_qkv80(wq, H), K.pack_w_frag80(wo), K.pack_w_frag80(wm)
+    run = lambda: K.temporal_block(h, g, bpe, 1e-5, wqp, wot, bo, (C // H) ** -0.5, w_merge_tm=wmt, pose_term=pt, merge_scale=1.0)
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    M = B * Fr * hw
+    flops = 2.0 * M * C * 5 * C + 4.0 * M * Fr * C
+    achieved = flops / (ms * 1e-3) / 1e12
+    out = {"bound": "mfma", "kernel": f"temporal_block640_kernel<merge> (fused LN + merge + qkv + attention + out-projection, bf16) [{B}x{Fr}x{hw}x{C}]",
+           "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+           "avg_launch_ms": round(ms, 4), "flops_per_launch": flops, "traffic_algorithmic": 3.0 * M * C * 2,
+           "replaces": "LayerNorm + merge GEMM + fused QKV GEMM + temporal_attn_kernel + out-projection GEMM (5 launches, ~160 us)"}
+    out.update(recorded_counters("tblock640"))
     return out
 
 
@@ -889,6 +928,7 @@ def main():
         roof_temp = measure_temporal_roofline(device, dtype) if bf else None
         roof_proj = measure_proj_roofline(device, dtype) if bf else None
         roof_tb = measure_temporal_block_roofline(device, dtype) if bf else None
+        roof_tb1 = measure_temporal_block_l1_roofline(device, dtype) if bf else None
         f_ref = unet_flops(2, HEIGHT // 8, WIDTH // 8, config=cfg)
         f_exec = unet_flops(2, HEIGHT // 8, WIDTH // 8, executed=True, config=cfg)
         if cfg_shared:                                  # one clip's worth of conv_in, ResNet block 0, proj_in, QKV, self-attention, out-projection
@@ -915,7 +955,7 @@ def main():
             "unet_tflop_per_step_reference_graph": round(f_ref / 1e12, 3),
             "executed_tflops_per_gpu": round(f_exec / 1e12 / (ms * 1e-3), 1),
             "conditioning_once_per_clip_ms": round(cond_ms, 2),
-            "roofline": roof, "roofline_conv": roof_conv, "roofline_temporal": roof_temp, "roofline_temporal_block": roof_tb, "roofline_proj": roof_proj,
+            "roofline": roof, "roofline_conv": roof_conv, "roofline_temporal": roof_temp, "roofline_temporal_block": roof_tb, "roofline_temporal_block_l1": roof_tb1, "roofline_proj": roof_proj,
             "cpu_baseline": cpu,
         }
         if loop50_s is not None:

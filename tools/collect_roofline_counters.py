@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "gpurun_out", "roofline_pmc")
 GROUPS = ["FETCH_SIZE", "WRITE_SIZE", "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE"]
-KERNELS = {"sa40d": "sa40d_kernel", "temporal": "temporal_attn_kernel", "conv": "gemm", "proj": "gemm160p", "tblock": "temporal_block_kernel"}
+KERNELS = {"sa40d": "sa40d_kernel", "temporal": "temporal_attn_kernel", "conv": "gemm", "proj": "gemm160p", "tblock": "temporal_block_kernel", "tblock640": "temporal_block640_kernel"}
 # (the conv probe is the only gemm* launch with MODE 1, the GEGLU projection probe the only one with MODE 0)
 
 
@@ -30,6 +30,8 @@ def which(name):
         return "sa40d"
     if "temporal_attn_kernel" in name:
         return "temporal"
+    if "temporal_block640_kernel" in name:
+        return "tblock640"
     if "temporal_block_kernel" in name:
         return "tblock"
     if "gemm8_kernel<1" in name or "gemm_kernel<1" in name or "gemm160_kernel<1" in name:
