@@ -441,6 +441,20 @@ int fmc_temporal_block_bf16(const void* h, void* out, const float* ln_gamma, con
                             const void* pose_term, float merge_scale, const void* w_qkv_packed, const void* w_out_tm, const void* b_out,
                             float* ln_stats, float ln_stats_eps, int n_clips, int frames, int hw, int channels, int heads, float scale,
                             void* stream);
+/* ---- fused text cross-attention block of the spatial transformer at the 20x32 level (round 4) ----------------------------------------------------
+ * Replaces, for `attn2` of diffusers' BasicTransformerBlock as the reference U-Net builds it (fmc/models/unet_blocks.py:323-333; Attention /
+ * AttnProcessor: fmc/models/attention_processor.py:20-82, :148-154 with LoRA):
+ *     out = to_out(softmax(to_q(LayerNorm(h)) k^T * scale) v) + b_out + h        (k | v = the text's fused to_k / to_v projection)
+ * in ONE launch (was LayerNorm + to_q GEMM + cross-attention kernel + to_out GEMM): the skeleton of the C = 640 temporal block (80-row tiles resident
+ * in LDS, weights in fragment order straight into registers, wave = head), k / v fragments of the <= 80 text tokens held in registers.
+ *   h, out: bf16 [n_images][hw][640] tokens, hw % 80 == 0; ln_gamma fp32 [640]; ln_bpe fp32 [16][640], every row = the LayerNorm beta;
+ *   w_q_packed / w_out_frag: `hip_ops.pack_w_frag80` of the [640, 640] weights; kvfrag: fmc_xattn_pack_kv of the text k | v (one per text row);
+ *   images_per_text: images that share a text row (frames of a clip).
+ * fmc_xattn_pack_kv: kv bf16 [batch][S <= 80][1280] (batch stride ld_batch elements) -> bf16 [batch][8 heads][12800] MFMA fragments. */
+int fmc_xattn_block640_bf16(const void* h, void* out, const float* ln_gamma, const float* ln_bpe, float ln_eps, const void* w_q_packed,
+                            const void* kvfrag, const void* w_out_frag, const void* b_out, int n_images, int hw, int n_keys, int images_per_text,
+                            float scale, void* stream);
+int fmc_xattn_pack_kv(const void* kv, void* out, int batch, int S, int64_t ld_batch, void* stream);
 /* Diagnostic: `buf` = device buffer of [workgroups][4][8] int64 that receives s_memrealtime stamps (100 MHz) of wave 0 at the phase boundaries of
  * its first four tiles (tools/scratch/r04/probe_tb.py); NULL switches the stamps off (default). */
 int fmc_temporal_block_set_debug(void* buf);

@@ -43,6 +43,10 @@ struct T6Params {
     const bf16_t* b_out;                                   // [640] or NULL
     int n_clips, hw, tpc;
     float scale_log2;
+    // XATT (the text cross-attention block of the spatial transformer at this level, same skeleton): tokens [images][hw][640], a tile = 80 consecutive rows
+    const bf16_t* kvfrag;                                  // [batch][8 heads][K: 5 key blocks x (512 + 512 + 256) | V^T: 5 x 5 x 256] (fmc_xattn_pack_kv)
+    int n_keys, frames_per_batch;                          // text tokens (<= 80); images per text row (kv_batch_div)
+    int64_t total_rows;
 };
 
 __device__ __forceinline__ void t6_dma(const __amdgpu_buffer_rsrc_t& rs, unsigned voff, void* lds) {
@@ -61,7 +65,7 @@ __device__ __forceinline__ void t6_unpack4(const u32x2& w, float (&o)[4]) {
     } while (0)
 #define T6_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
-template <bool HAS_MERGE>
+template <bool HAS_MERGE, bool XATT>
 __global__ __launch_bounds__(512, 2)
 void temporal_block640_kernel(const T6Params P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -76,9 +80,11 @@ void temporal_block640_kernel(const T6Params P) {
 
     const int tile = blockIdx.x;
     const int clip = tile / P.tpc, p0 = (tile - clip * P.tpc) * T6_PIX;
-    const unsigned row0 = (unsigned)(((int64_t)clip * T6_F * P.hw + p0) * T6_C);      // (pixel 0, frame 0)
-    const unsigned fstride = (unsigned)(P.hw * T6_C);
-    const int64_t total_elems = (int64_t)P.n_clips * T6_F * P.hw * T6_C;
+    // tile row r = 16 hi + lo lives at element row0 + lo * fstride + hi * pstride: temporal = (frame lo, pixel hi) of the clip; XATT = row 80 tile + r
+    const unsigned row0 = XATT ? (unsigned)((int64_t)tile * T6_ROWS * T6_C) : (unsigned)(((int64_t)clip * T6_F * P.hw + p0) * T6_C);
+    const unsigned fstride = XATT ? (unsigned)T6_C : (unsigned)(P.hw * T6_C);
+    const unsigned pstride = XATT ? (unsigned)(16 * T6_C) : (unsigned)T6_C;
+    const int64_t total_elems = P.total_rows * T6_C;
     const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)P.h, 0, (int)(total_elems * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsPT = __builtin_amdgcn_make_buffer_rsrc((void*)(HAS_MERGE ? P.pose_term : P.h), 0, (int)(total_elems * 2), 0x00020000);
 
@@ -90,7 +96,7 @@ void temporal_block640_kernel(const T6Params P) {
             const int q = wave + 8 * j;
             if (q < pieces) {
                 const int idx = 64 * q + lane, rl = idx / T6_CPR, pc = idx - rl * T6_CPR, r = r0 + rl, c = pc ^ ((r >> 1) & 7);
-                const unsigned src = (row0 + (unsigned)(r & 15) * fstride + (unsigned)(r >> 4) * T6_C + (unsigned)c * 8) * 2;
+                const unsigned src = (row0 + (unsigned)(r & 15) * fstride + (unsigned)(r >> 4) * pstride + (unsigned)c * 8) * 2;
                 t6_dma(rs, src, dst + 64 * q * 8);
             }
         }
@@ -241,7 +247,8 @@ void temporal_block640_kernel(const T6Params P) {
     // ================= phase D: wave = head.  q | k | v projections + attention, all in registers =================
     u32x2 o_pk[5][5];                                             // o of my head: (row 16 m + l15, channels 16 b + 4 kq ..) as 4 bf16
     {
-        const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(P.w_qkv + (size_t)wave * (3 * T6_WAVE_W)), 0, 3 * T6_WAVE_W * 2, 0x00020000);
+        constexpr int NPARTS = XATT ? 1 : 3;                      // XATT: only to_q (k | v come from the text, packed per step by fmc_xattn_pack_kv)
+        const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(P.w_qkv + (size_t)wave * (NPARTS * T6_WAVE_W)), 0, NPARTS * T6_WAVE_W * 2, 0x00020000);
         int qkv_lane = lane * 16;
         asm volatile("" : "+v"(qkv_lane));
         u32x4 wq[3][5];                                           // [stage][block]
@@ -263,7 +270,7 @@ void temporal_block640_kernel(const T6Params P) {
         };
         auto step = [&](auto part_c, auto ks_c) {
             constexpr int part = decltype(part_c)::value, ks = decltype(ks_c)::value, s = part * 20 + ks;
-            if constexpr (s + 2 < 60) load_step(s + 2);
+            if constexpr (s + 2 < 20 * NPARTS) load_step(s + 2);
             int kqx = kq ^ xsw, xrow_o = l15 * T6_C;
             asm volatile("" : "+v"(kqx), "+v"(xrow_o));
             const int xo = xrow_o + ((ks >> 1) * 8 + (((ks & 1) * 4) ^ kqx)) * 8;
@@ -314,6 +321,82 @@ void temporal_block640_kernel(const T6Params P) {
             q8b[m] = pack8(pacc[m][2], pacc[m][3]);
             q4[m] = pack4(pacc[m][4]);
         }
+        if constexpr (XATT) {
+            // ---- scores against the text keys (5 blocks of 16, keys >= n_keys masked), softmax, o = P V: K and V^T fragments straight from the packed copy ----
+            const int batch = (int)(((int64_t)tile * T6_ROWS / P.hw) / P.frames_per_batch);
+            const bf16_t* KF = P.kvfrag + ((size_t)batch * 8 + wave) * 12800;
+            u32x2 pp[5][5];                                       // probabilities P^T: [query block m][key block]: keys 4 kq .. of query l15
+            {
+                bf16x8 ka[5], kbb[5];
+                s16x4 k4[5];
+#pragma unroll
+                for (int kb = 0; kb < 5; ++kb) {
+                    ka[kb] = *reinterpret_cast<const bf16x8*>(KF + kb * 1280 + lane * 8);
+                    kbb[kb] = *reinterpret_cast<const bf16x8*>(KF + kb * 1280 + 512 + lane * 8);
+                    k4[kb] = *reinterpret_cast<const s16x4*>(KF + kb * 1280 + 1024 + lane * 4);
+                }
+#pragma unroll
+                for (int m = 0; m < 5; ++m) {
+                    f32x4 sc[5];
+                    // (an accumulator is touched again only four MFMAs later, the order is pinned: back-to-back dependent MFMAs gave wrong scores for the
+                    //  middle pixel blocks -- the hazard class of TB_SETTLE in temporal_block.hip)
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kb = 0; kb < 5; ++kb) sc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[kb], q8a[m], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kb = 0; kb < 5; ++kb) sc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kbb[kb], q8b[m], sc[kb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kb = 0; kb < 5; ++kb) sc[kb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(k4[kb], q4[m], sc[kb], 0, 0, 0);
+                    T6_SETTLE();
+                    float mx = -3.0e38f;
+#pragma unroll
+                    for (int kb = 0; kb < 5; ++kb)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            sc[kb][j] = (16 * kb + 4 * kq + j < P.n_keys) ? sc[kb][j] * P.scale_log2 : -3.0e38f;
+                            mx = fmaxf(mx, sc[kb][j]);
+                        }
+                    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    float sum = 0.f;
+#pragma unroll
+                    for (int kb = 0; kb < 5; ++kb)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { sc[kb][j] = __builtin_amdgcn_exp2f(sc[kb][j] - mx); sum += sc[kb][j]; }
+                    sum += __shfl_xor(sum, 16, 64);
+                    sum += __shfl_xor(sum, 32, 64);
+                    const float inv = 1.f / sum;
+#pragma unroll
+                    for (int kb = 0; kb < 5; ++kb) pp[m][kb] = u32x2{pack_bf2(sc[kb][0] * inv, sc[kb][1] * inv), pack_bf2(sc[kb][2] * inv, sc[kb][3] * inv)};
+                }
+            }
+            {
+                s16x4 vf[5][5];                                   // V^T: [channel block][key block]: (channel 16 b + l15, keys 16 kb + 4 kq ..)
+#pragma unroll
+                for (int b = 0; b < 5; ++b)
+#pragma unroll
+                    for (int kb = 0; kb < 5; ++kb) vf[b][kb] = *reinterpret_cast<const s16x4*>(KF + 6400 + ((b * 5 + kb) * 64 + lane) * 4);
+#pragma unroll
+                for (int m = 0; m < 5; ++m) {
+                    f32x4 o[5];
+#pragma unroll
+                    for (int b = 0; b < 5; ++b) o[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kb = 0; kb < 5; ++kb) {              // (key block outer: the five accumulators take turns)
+                        union { u32x2 u; s16x4 s; } pb;
+                        pb.u = pp[m][kb];
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int b = 0; b < 5; ++b) o[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf[b][kb], pb.s, o[b], 0, 0, 0);
+                    }
+                    T6_SETTLE();
+#pragma unroll
+                    for (int b = 0; b < 5; ++b) o_pk[m][b] = u32x2{pack_bf2(o[b][0], o[b][1]), pack_bf2(o[b][2], o[b][3])};
+                }
+            }
+        } else {
         // ---- k, scores, softmax ----
         zero_pacc();
         T6_PART(1);
@@ -354,6 +437,7 @@ void temporal_block640_kernel(const T6Params P) {
 #pragma unroll
             for (int b = 0; b < 5; ++b) o_pk[m][b] = u32x2{pack_bf2(o[b][0], o[b][1]), pack_bf2(o[b][2], o[b][3])};
         }
+        }  // (!XATT)
 #undef T6_PART
 #undef T6_STEP
     }
@@ -406,7 +490,7 @@ void temporal_block640_kernel(const T6Params P) {
             const int c = tid + 512 * j;
             if (j < 2 || tid < 256) {                             // 16 rows x 80 chunks = 2.5 x 512
                 const int rl = c / T6_CPR, pc = c - rl * T6_CPR, r = 16 * pss + rl, lc = pc ^ ((r >> 1) & 7);
-                const unsigned dst = row0 + (unsigned)(r & 15) * fstride + (unsigned)(r >> 4) * T6_C + (unsigned)lc * 8;
+                const unsigned dst = row0 + (unsigned)(r & 15) * fstride + (unsigned)(r >> 4) * pstride + (unsigned)lc * 8;
                 *reinterpret_cast<u32x4*>(P.out + dst) = *reinterpret_cast<const u32x4*>(Hs + c * 8);
             }
         }
@@ -414,6 +498,42 @@ void temporal_block640_kernel(const T6Params P) {
             __syncthreads();                                      // everybody has read the buffer: it takes pass pss + 3
             issue_pass(rsH, pss + 3);
         }
+    }
+}
+
+// text k | v `[batch][S][2 C]` (C = 640, 8 heads x 80) -> the MFMA fragments phase D of the XATT block reads: per (batch, head)
+//   K: 5 key blocks x [a: lane x 8 | b: lane x 8 | tail: lane x 4]: lane (l15 = key in block, kq) holds channels {4 kq .. + 3, 16 + 4 kq .. + 3} (+ 32 for b),
+//      64 + 4 kq .. + 3 for the tail -- the channel permutation q comes out of the swapped product in;
+//   V^T: [channel block 5][key block 5][lane][4]: lane (l15 = channel in block, kq) holds keys 16 kb + 4 kq .. + 3.   Keys >= S are zero.
+__global__ __launch_bounds__(256) void xattn_pack_kv_kernel(const bf16_t* __restrict__ kv, bf16_t* __restrict__ out, int S, int64_t ldb) {
+    const int bh = blockIdx.x, b = bh >> 3, h = bh & 7;
+    const bf16_t* kb_ = kv + (int64_t)b * ldb + h * 80;            // k of (b, h): row stride 1280
+    const bf16_t* vb_ = kb_ + 640;
+    bf16_t* o = out + (size_t)bh * 12800;
+    for (int g = threadIdx.x; g < 3200; g += 256) {               // groups of 4 output elements
+        u32x2 val = u32x2{0u, 0u};
+        if (g < 1600) {                                           // K: key block kb = g / 320; inside: a (128 groups), b (128), tail (64)
+            const int kb = g / 320, r = g - kb * 320;
+            int lane, ch;
+            if (r < 256) {
+                const int part = r >> 7, q = r & 127;
+                lane = q >> 1;
+                ch = 32 * part + 16 * (q & 1) + 4 * (lane >> 4);
+            } else {
+                lane = r - 256;
+                ch = 64 + 4 * (lane >> 4);
+            }
+            const int key = 16 * kb + (lane & 15);
+            if (key < S) val = *reinterpret_cast<const u32x2*>(kb_ + (int64_t)key * 1280 + ch);
+        } else {                                                  // V^T: (cb, kb, lane)
+            const int q = g - 1600, lane = q & 63, kb = (q >> 6) % 5, cb = (q >> 6) / 5;
+            const int ch = 16 * cb + (lane & 15), key0 = 16 * kb + 4 * (lane >> 4);
+            unsigned short e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = key0 + j < S ? vb_[(int64_t)(key0 + j) * 1280 + ch] : (unsigned short)0;
+            val = u32x2{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16)};
+        }
+        *reinterpret_cast<u32x2*>(o + g * 4) = val;
     }
 }
 
@@ -429,16 +549,60 @@ int fmc_temporal_block640_launch(const void* h, void* out, const float* ln_gamma
     P.w_merge = (const bf16_t*)w_merge_frag; P.pose_term = (const bf16_t*)pose_term; P.merge_scale = merge_scale;
     P.w_qkv = (const bf16_t*)w_qkv_packed; P.w_out = (const bf16_t*)w_out_frag; P.b_out = (const bf16_t*)b_out;
     P.n_clips = n_clips; P.hw = hw; P.tpc = hw / 5;
+    P.total_rows = (int64_t)n_clips * T6_F * hw;
     P.scale_log2 = scale * 1.4426950408889634f;
     const unsigned grid = (unsigned)(n_clips * P.tpc);
     static bool raised = false;
     if (!raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block640_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, T6_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block640_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, T6_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block640_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T6_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block640_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T6_LDS);
         raised = true;
     }
-    if (w_merge_frag) hipLaunchKernelGGL((temporal_block640_kernel<true>), dim3(grid), dim3(512), T6_LDS, st, P);
-    else hipLaunchKernelGGL((temporal_block640_kernel<false>), dim3(grid), dim3(512), T6_LDS, st, P);
+    if (w_merge_frag) hipLaunchKernelGGL((temporal_block640_kernel<true, false>), dim3(grid), dim3(512), T6_LDS, st, P);
+    else hipLaunchKernelGGL((temporal_block640_kernel<false, false>), dim3(grid), dim3(512), T6_LDS, st, P);
     FMC_CHECK_LAUNCH("fmc_temporal_block_bf16 (C = 640)");
+    return 0;
+}
+
+// The text cross-attention block of the spatial transformer at the 20x32 level in one launch (BasicTransformerBlock, diffusers 0.24 as driven by
+// fmc/models/unet_blocks.py:323-333 / fmc/models/attention_processor.py:50-69,148-154):   out = to_out(softmax(to_q(LayerNorm(h)) k^T d^-1/2) v) + b + h
+// for tokens h [images][hw][640] (hw % 80 == 0), 8 heads x 80, text k | v packed by fmc_xattn_pack_kv.  Replaces LayerNorm + to_q GEMM + cross-attention
+// kernel + to_out GEMM.  ln_bpe: fp32 [16][640] rows all equal to the LayerNorm beta (the kernel shares phase A with the temporal block).
+extern "C" int fmc_xattn_block640_bf16(const void* h, void* out, const float* ln_gamma, const float* ln_bpe, float ln_eps, const void* w_q_packed,
+                                       const void* kvfrag, const void* w_out_frag, const void* b_out, int n_images, int hw, int n_keys, int images_per_text,
+                                       float scale, void* stream) {
+    if (!h || !out || !ln_gamma || !ln_bpe || !w_q_packed || !kvfrag || !w_out_frag) FMC_FAIL(FMC_E_NULL, "xattn_block640_bf16: NULL tensor");
+    if (n_images <= 0 || hw <= 0 || hw % 80 || n_keys <= 0 || n_keys > 80 || images_per_text <= 0 || n_images % images_per_text)
+        FMC_FAIL(FMC_E_SHAPE, "xattn_block640_bf16: hw %% 80 == 0, 1 <= keys <= 80, images %% images_per_text == 0 (got hw=%d keys=%d images=%d / %d)", hw, n_keys,
+                 n_images, images_per_text);
+    if ((int64_t)n_images * hw * 640 * 2 >= ((int64_t)1 << 31)) FMC_FAIL(FMC_E_SHAPE, "xattn_block640_bf16: tensor of 2 GiB or more");
+    if (!fmc_aligned16(h) || !fmc_aligned16(out) || !fmc_aligned16(w_q_packed) || !fmc_aligned16(kvfrag) || !fmc_aligned16(w_out_frag) || !fmc_aligned16(ln_gamma) ||
+        !fmc_aligned16(ln_bpe) || (b_out && !fmc_aligned16(b_out)))
+        FMC_FAIL(FMC_E_ALIGN, "xattn_block640_bf16: tensors must be 16-byte aligned");
+    T6Params P{};
+    P.h = (const bf16_t*)h; P.out = (bf16_t*)out; P.ln_gamma = ln_gamma; P.ln_bpe = ln_bpe; P.ln_eps = ln_eps;
+    P.w_qkv = (const bf16_t*)w_q_packed; P.w_out = (const bf16_t*)w_out_frag; P.b_out = (const bf16_t*)b_out;
+    P.kvfrag = (const bf16_t*)kvfrag; P.n_keys = n_keys; P.frames_per_batch = images_per_text;
+    P.n_clips = 1; P.hw = hw; P.tpc = 1;
+    P.total_rows = (int64_t)n_images * hw;
+    P.scale_log2 = scale * 1.4426950408889634f;
+    const unsigned grid = (unsigned)(P.total_rows / T6_ROWS);
+    static bool raised = false;
+    if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block640_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T6_LDS);
+        raised = true;
+    }
+    hipLaunchKernelGGL((temporal_block640_kernel<false, true>), dim3(grid), dim3(512), T6_LDS, (hipStream_t)stream, P);
+    FMC_CHECK_LAUNCH("fmc_xattn_block640_bf16");
+    return 0;
+}
+
+// kv: bf16 [batch][S][1280] (k | v of the fused to_k / to_v projection, rows `ld_batch` elements apart per batch entry) -> out: bf16 [batch][8][12800]
+extern "C" int fmc_xattn_pack_kv(const void* kv, void* out, int batch, int S, int64_t ld_batch, void* stream) {
+    if (!kv || !out) FMC_FAIL(FMC_E_NULL, "xattn_pack_kv: NULL tensor");
+    if (batch <= 0 || S <= 0 || S > 80 || ld_batch < (int64_t)S * 1280) FMC_FAIL(FMC_E_SHAPE, "xattn_pack_kv: 1 <= S <= 80 text tokens of 2 x 640 channels");
+    if (((uintptr_t)kv & 7) || !fmc_aligned16(out)) FMC_FAIL(FMC_E_ALIGN, "xattn_pack_kv: alignment");
+    hipLaunchKernelGGL(xattn_pack_kv_kernel, dim3((unsigned)(batch * 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)kv, (bf16_t*)out, S, ld_batch);
+    FMC_CHECK_LAUNCH("fmc_xattn_pack_kv");
     return 0;
 }

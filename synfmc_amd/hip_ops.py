@@ -1031,6 +1031,32 @@ def temporal_block(h: torch.Tensor, ln_gamma: torch.Tensor, ln_bpe: torch.Tensor
     return out if stats is None else (out, stats)
 
 
+XATTN_FUSED_640 = os.environ.get("FMC_XATTN_FUSED_640", "1") != "0"      # A/B switch: the 20x32-level text cross-attention as one launch
+
+
+def xattn_block640_supported(h: torch.Tensor, kv_tokens: int, heads: int) -> bool:
+    """`[images, hw, 640]` bf16 tokens the fused cross-attention block takes: 8 heads, hw % 80 == 0, at most 80 text tokens, inference."""
+    return (XATTN_FUSED_640 and h.is_cuda and h.dtype == torch.bfloat16 and h.ndim == 3 and h.is_contiguous() and h.shape[2] == 640 and heads == 8
+            and h.shape[1] % 80 == 0 and 0 < kv_tokens <= 80 and h.numel() * 2 < (1 << 31) and not torch.is_grad_enabled())
+
+
+def xattn_block640(h: torch.Tensor, ln_gamma: torch.Tensor, ln_btab: torch.Tensor, ln_eps: float, w_q_packed: torch.Tensor, kv: torch.Tensor,
+                   w_out_frag: torch.Tensor, b_out: Optional[torch.Tensor], scale: float, images_per_text: int) -> torch.Tensor:
+    """`to_out(softmax(to_q(LayerNorm(h)) k^T scale) v) + b + h` in one launch (`fmc_xattn_block640_bf16`); `kv [B, S, 1280]` = the text's fused
+    k | v projection (packed into MFMA fragments by one tiny launch, `fmc_xattn_pack_kv`); `ln_btab [16, 640]` fp32 rows = the LayerNorm beta."""
+    _dev(h, ln_gamma, ln_btab, w_q_packed, kv, w_out_frag, b_out)
+    N, hw, C = h.shape
+    B, S, C2 = kv.shape
+    assert C == 640 and C2 == 1280 and kv.stride(2) == 1 and kv.stride(1) == C2 and N % images_per_text == 0 and N // images_per_text == B
+    frag = torch.empty(B * 8 * 12800, dtype=h.dtype, device=h.device)
+    _lib.check(_lib.load().fmc_xattn_pack_kv(kv.data_ptr(), frag.data_ptr(), B, S, kv.stride(0), _stream()), "fmc_xattn_pack_kv")
+    out = torch.empty_like(h)
+    _lib.check(_lib.load().fmc_xattn_block640_bf16(h.data_ptr(), out.data_ptr(), ln_gamma.data_ptr(), ln_btab.data_ptr(), float(ln_eps), w_q_packed.data_ptr(),
+                                                   frag.data_ptr(), w_out_frag.data_ptr(), _p(b_out), N, hw, S, images_per_text, float(scale), _stream()),
+               "fmc_xattn_block640_bf16")
+    return out
+
+
 def linear_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
     return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.stride(-1) == 1
             and weight.shape[1] % 64 == 0 and weight.shape[0] % 8 == 0 and weight.is_contiguous())

@@ -559,6 +559,34 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = LayerNorm(dim, elementwise_affine=norm_elementwise_affine, eps=norm_eps)
         self.ff = FeedForward(dim, dropout=dropout, activation_fn=activation_fn, final_dropout=final_dropout)
 
+    def _xattn_fused(self, hidden_states, encoder_hidden_states, kw):
+        """`attn2(norm2(h), text) + h` as one launch (+ the text's k | v projection and its fragment pack)."""
+        from .attention_processor import LoRAAttnProcessor, _require_frozen
+        attn, proc = self.attn2, self.attn2.processor
+        lora, lora_scale = None, 1.0
+        if isinstance(proc, LoRAAttnProcessor):
+            _require_frozen(proc)
+            lora = proc
+            s_kw = kw.get("scale")
+            lora_scale = proc.lora_scale if s_kw is None else s_kw
+        w_q, w_kv, w_o = attn.fused_weights(lora, lora_scale)
+        key = (w_q.data_ptr(), w_q._version, w_o.data_ptr(), w_o._version)
+        hit = attn.__dict__.get("_fused_xb")
+        if hit is None or hit[0] != key:
+            hit = (key, K.pack_w_frag80(w_q), K.pack_w_frag80(w_o))
+            attn.__dict__["_fused_xb"] = hit
+        g, b = f32_param(self.norm2, "weight"), f32_param(self.norm2, "bias")
+        ck = (g.data_ptr(), g._version, b.data_ptr(), b._version)
+        c = self.__dict__.get("_fused_xc")
+        if c is None or c[0] != ck:
+            with torch.no_grad():
+                c = (ck, g.contiguous(), b[None, :].expand(16, -1).float().contiguous())
+            self.__dict__["_fused_xc"] = c
+        h = hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()
+        kv = linear_op(encoder_hidden_states, w_kv)
+        return K.xattn_block640(h, c[1], c[2], self.norm2.eps, hit[1], kv, hit[2], attn.to_out[0].bias, attn.scale,
+                                h.shape[0] // encoder_hidden_states.shape[0])
+
     def forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, timestep=None, cross_attention_kwargs=None, class_labels=None,
                 cfg_expand: bool = False):
@@ -572,12 +600,22 @@ class BasicTransformerBlock(nn.Module):
         def plain(attn):            # only these processors hand the normed tokens to `linear_op` and nowhere else (a pose merge also uses
             return type(attn.processor) in (AttnProcessor, LoRAAttnProcessor)      # them as a residual: it needs the materialised norm)
         d1, d2 = plain(self.attn1), self.attn2 is not None and plain(self.attn2)
+        # the text cross-attention block of the 20x32 level as ONE launch (LayerNorm + to_q + attention over the text tokens + to_out + residual:
+        # hip_ops.xattn_block640): plain / frozen-LoRA processor, 8 heads x 80, tokens [images, hw, 640] with hw % 80 == 0, no mask
+        fuse2 = (d2 and not cfg_expand and encoder_hidden_states is not None and encoder_attention_mask is None and hidden_states.ndim == 3
+                 and encoder_hidden_states.ndim == 3 and hidden_states.shape[0] % encoder_hidden_states.shape[0] == 0
+                 and K.xattn_block640_supported(hidden_states, encoder_hidden_states.shape[1], self.attn2.heads)
+                 and self.attn2.inner_dim == 640 and not self.attn2.residual_connection and self.attn2.rescale_output_factor == 1.0
+                 and self.attn2.to_q.weight.dtype == torch.bfloat16 and encoder_hidden_states.dtype == torch.bfloat16)
         # (`_lazy_res`: the output projection's `+ residual` may be left to the next norm's pass when the projection runs on the vendor arm;
         #  true exactly where the very next consumer is `norm.skip` below)
         self.attn1.__dict__["_lazy_res"] = not cfg_expand and not torch.is_grad_enabled()
         if self.attn2 is not None:
             self.attn2.__dict__["_lazy_res"] = not torch.is_grad_enabled()
-        if self.attn2 is not None:
+        if fuse2:                                   # (the fused block normalises its input itself and wants it materialised)
+            self.attn1.__dict__["_lazy_res"] = False
+            self.attn1.__dict__["_next_ln"] = None
+        elif self.attn2 is not None:
             self.attn1.__dict__["_next_ln"] = None if (cfg_expand or torch.is_grad_enabled()) else self.norm2.ln_spec(stats_only=d2)
             self.attn2.__dict__["_next_ln"] = None if torch.is_grad_enabled() else self.norm3.ln_spec(stats_only=True)
         else:
@@ -588,7 +626,9 @@ class BasicTransformerBlock(nn.Module):
         hidden_states = self.attn1(n, encoder_hidden_states=None, attention_mask=attention_mask, _residual=hidden_states, **kw)
         if cfg_expand:          # shared classifier-free-guidance prefix ends here: the text cross-attention is the first op that tells the halves apart
             hidden_states = torch.cat([hidden_states, hidden_states], dim=0)
-        if self.attn2 is not None:
+        if fuse2:
+            hidden_states = self._xattn_fused(hidden_states, encoder_hidden_states, kw)
+        elif self.attn2 is not None:
             hidden_states, n = self.norm2.skip(hidden_states, defer=d2)
             hidden_states = self.attn2(n, encoder_hidden_states=encoder_hidden_states, attention_mask=encoder_attention_mask,
                                        _residual=hidden_states, **kw)
