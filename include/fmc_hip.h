@@ -455,6 +455,13 @@ int fmc_xattn_block640_bf16(const void* h, void* out, const float* ln_gamma, con
                             const void* kvfrag, const void* w_out_frag, const void* b_out, int n_images, int hw, int n_keys, int images_per_text,
                             float scale, void* stream);
 int fmc_xattn_pack_kv(const void* kv, void* out, int batch, int S, int64_t ld_batch, void* stream);
+/* The same block at the 40x64 level (C = 320, 8 heads x 40) on the skeleton of fmc_temporal_block_bf16 (160-row tiles, persistent): hw % 160 == 0;
+ * w_q_packed = `hip_ops.pack_xattn_q40` (per head [10 k-steps][q0 | q1 | (q tail, zeros)][lane][8]), w_out_tm tile-major (`_w_tilemajor`),
+ * kvfrag = fmc_xattn_pack_kv40 (kv bf16 [batch][S <= 80][640] -> [batch][8][7680]); ln_stats (optional): (mean, rstd) of every out row. */
+int fmc_xattn_block320_bf16(const void* h, void* out, const float* ln_gamma, const float* ln_bpe, float ln_eps, const void* w_q_packed,
+                            const void* kvfrag, const void* w_out_tm, const void* b_out, float* ln_stats, float ln_stats_eps, int n_images, int hw,
+                            int n_keys, int images_per_text, float scale, void* stream);
+int fmc_xattn_pack_kv40(const void* kv, void* out, int batch, int S, int64_t ld_batch, void* stream);
 /* Diagnostic: `buf` = device buffer of [workgroups][4][8] int64 that receives s_memrealtime stamps (100 MHz) of wave 0 at the phase boundaries of
  * its first four tiles (tools/scratch/r04/probe_tb.py); NULL switches the stamps off (default). */
 int fmc_temporal_block_set_debug(void* buf);

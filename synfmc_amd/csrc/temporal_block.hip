@@ -58,6 +58,10 @@ struct TBParams {
     int n_clips, hw, tiles;
     float scale_log2;                                  // d^-1/2 * log2(e)
     long long* dbg_times;                              // diagnostic (fmc_temporal_block_set_debug): [workgroup][tile slot 0..3][8] s_memrealtime stamps of wave 0
+    // XATT (the text cross-attention block of the spatial transformer at this level on the same skeleton): tokens [images][hw][320], a tile = 160 consecutive rows
+    const bf16_t* kvfrag;                              // [batch][8 heads][K: 5 key blocks x (512 + 256) | V^T: 3 x 5 x 256] (fmc_xattn_pack_kv, C = 320)
+    int n_keys, images_per_text;
+    int64_t total_rows;
 };
 
 __device__ __forceinline__ void tb_dma(const __amdgpu_buffer_rsrc_t& rs, unsigned voff, int soff, void* lds) {
@@ -84,7 +88,7 @@ __device__ __forceinline__ void unpack4(const u32x2& w, float (&o)[4]) {
     } while (0)
 
 // HAS_MERGE: attention block 0 (Camera Adapter); STATS: also emit the (mean, rstd) of the output rows
-template <bool HAS_MERGE, bool STATS>
+template <bool HAS_MERGE, bool STATS, bool XATT = false>
 __global__ __launch_bounds__(512, 2)
 void temporal_block_kernel(const TBParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -96,7 +100,7 @@ void temporal_block_kernel(const TBParams P) {
     const int l15 = lane & 15, kq = lane >> 4;
     const bool w_wave = wave < 5;                                // waves 0-4 request the weight sub-tiles (4 one-KiB pieces each)
 
-    const int64_t total_elems = (int64_t)P.n_clips * TB_F * P.hw * TB_C;
+    const int64_t total_elems = P.total_rows * TB_C;
     const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)P.h, 0, (int)(total_elems * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsPT = __builtin_amdgcn_make_buffer_rsrc((void*)(HAS_MERGE ? P.pose_term : P.h), 0, (int)(total_elems * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsWM = __builtin_amdgcn_make_buffer_rsrc((void*)(HAS_MERGE ? P.w_merge : P.w_out), 0, 320 * 320 * 2, 0x00020000);
@@ -163,21 +167,27 @@ void temporal_block_kernel(const TBParams P) {
     } while (0)
 
     const int n_tiles_per_clip = P.hw / TB_PIX;
+    // tile row r = 16 hi + lo lives at element row0 + lo * fstride + hi * pstride: temporal = (frame lo, pixel hi) of the clip; XATT = row 160 tile + r
+    const unsigned fstride = XATT ? (unsigned)TB_C : (unsigned)(P.hw * TB_C), pstride = XATT ? (unsigned)(16 * TB_C) : (unsigned)TB_C;
+    auto tile_row0 = [&](int t) {
+        if (XATT) return (unsigned)((int64_t)t * TB_ROWS * TB_C);
+        const int clip = t / n_tiles_per_clip, p0 = (t - clip * n_tiles_per_clip) * TB_PIX;
+        return (unsigned)(((int64_t)clip * TB_F * P.hw + p0) * TB_C);
+    };
 
     // rows [r0, r0 + nr) of a tile of `rs` (h or the pose term) -> LDS at `dst` by LDS-DMA, row-major with X's chunk swizzle (16-byte chunk c of tile
     // row r at chunk c ^ ((r >> 1) & 7): the source address carries it).  nr * 40 chunks = pieces of 64; piece q = wave + 8 j.
     auto issue_rows = [&](const __amdgpu_buffer_rsrc_t& rs, int t, int r0, int nr, bf16_t* dst) {
         int ln = lane;
         asm volatile("" : "+v"(ln));                  // (per-tile address arithmetic must not be hoisted out of the persistent loop: 40 live registers)
-        const int clip = t / n_tiles_per_clip, p0 = (t - clip * n_tiles_per_clip) * TB_PIX;
-        const unsigned row0 = (unsigned)(((int64_t)clip * TB_F * P.hw + p0) * TB_C), fstride = (unsigned)(P.hw * TB_C);
+        const unsigned row0 = tile_row0(t);
         const int pieces = nr * 40 / 64;
 #pragma unroll
         for (int j = 0; j < 13; ++j) {
             const int q = wave + 8 * j;
             if (q < pieces) {
                 const int idx = 64 * q + ln, rl = idx / 40, pc = idx - rl * 40, r = r0 + rl, c = pc ^ ((r >> 1) & 7);
-                const unsigned src = (row0 + (unsigned)(r & 15) * fstride + (unsigned)(r >> 4) * TB_C + (unsigned)c * 8) * 2;
+                const unsigned src = (row0 + (unsigned)(r & 15) * fstride + (unsigned)(r >> 4) * pstride + (unsigned)c * 8) * 2;
                 tb_dma(rs, src, 0, dst + 64 * q * 8);
             }
         }
@@ -188,14 +198,13 @@ void temporal_block_kernel(const TBParams P) {
     auto issue_pass = [&](const __amdgpu_buffer_rsrc_t& rs, int t, int pss, int buf) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        const int clip = t / n_tiles_per_clip, p0 = (t - clip * n_tiles_per_clip) * TB_PIX;
-        const unsigned row0 = (unsigned)(((int64_t)clip * TB_F * P.hw + p0) * TB_C), fstride = (unsigned)(P.hw * TB_C);
+        const unsigned row0 = tile_row0(t);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int q = wave + 8 * j;
             if (q < 20) {
                 const int idx = 64 * q + ln, rl = idx / 40, pc = idx - rl * 40, r = (rl < 16 ? 16 * pss + rl : 64 + 16 * pss + rl), c = pc ^ ((r >> 1) & 7);
-                const unsigned src = (row0 + (unsigned)(r & 15) * fstride + (unsigned)(r >> 4) * TB_C + (unsigned)c * 8) * 2;
+                const unsigned src = (row0 + (unsigned)(r & 15) * fstride + (unsigned)(r >> 4) * pstride + (unsigned)c * 8) * 2;
                 tb_dma(rs, src, 0, RING + buf * TB_SUB + 64 * q * 8);
             }
         }
@@ -213,8 +222,7 @@ void temporal_block_kernel(const TBParams P) {
         TB_STAMP(0);
         const int clip = tile / n_tiles_per_clip, p0 = (tile - clip * n_tiles_per_clip) * TB_PIX;
         // global element offset of tile row (pixel p, frame f): ((clip * 16 + f) * hw + p0 + p) * 320
-        const unsigned row0 = (unsigned)(((int64_t)clip * TB_F * P.hw + p0) * TB_C);         // (pixel 0, frame 0)
-        const unsigned fstride = (unsigned)(P.hw * TB_C);
+        const unsigned row0 = tile_row0(tile);                                          // (pixel 0, frame 0)
         // ================= phase A: LayerNorm (+ pe) of the h rows in X, in place =================
         // (the rows were requested under the previous tile's epilogue; the merge's first two weight sub-tiles go out behind the norm's constants)
         __builtin_amdgcn_sched_barrier(0);
@@ -364,7 +372,8 @@ void temporal_block_kernel(const TBParams P) {
         {
             // my head's 80-KiB stream through its own descriptor: the step offsets below are then compile-time constants (soffset literals),
             // not 80 precomputed scalar registers
-            const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(P.w_qkv + (size_t)wave * TB_QKV_HEAD), 0, TB_QKV_HEAD * 2, 0x00020000);
+            constexpr int QKV_STREAM = XATT ? 10 * 3 * 512 : TB_QKV_HEAD;      // XATT: the head's to_q only ([q0 | q1 | (q tail, zeros)] per k-step)
+            const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(P.w_qkv + (size_t)wave * QKV_STREAM), 0, QKV_STREAM * 2, 0x00020000);
             int qkv_lane = lane * 16;
             asm volatile("" : "+v"(qkv_lane));
             // weight fragment stream of the head: step s = 0 .. 29 -> (part = s / 10, k-step = s % 10); bytes before step s:
@@ -393,7 +402,7 @@ void temporal_block_kernel(const TBParams P) {
             };
             auto step = [&](auto part_c, auto ks_c) {
                 constexpr int part = decltype(part_c)::value, ks = decltype(ks_c)::value, s = part * 10 + ks;
-                if constexpr (s + 2 < 30) load_step(s + 2);
+                if constexpr (s + 2 < (XATT ? 10 : 30)) load_step(s + 2);
                 int kqx = kq ^ xsw, xrow_o = l15 * TB_C;
                 asm volatile("" : "+v"(kqx), "+v"(xrow_o));        // (see read_frags: no address of a later step may be computed ahead and spilled)
                 const int xo = xrow_o + ((ks >> 1) * 8 + (((ks & 1) * 4) ^ kqx)) * 8;
@@ -438,6 +447,70 @@ void temporal_block_kernel(const TBParams P) {
                 q8[m] = t.v;
                 t4[m] = u32x2{pack_bf2(pacc[m][2][0], pacc[m][2][1]), pack_bf2(pacc[m][2][2], pacc[m][2][3])};
             }
+            if constexpr (XATT) {
+                // ---- scores against the text keys (5 blocks of 16, keys >= n_keys masked), softmax and o = P V block by block; K and V^T fragments from the packed copy ----
+                const int batch = (int)(((int64_t)tile * TB_ROWS / P.hw) / P.images_per_text);
+                const bf16_t* KF = P.kvfrag + ((size_t)batch * 8 + wave) * 7680;
+                bf16x8 ka[5];
+                s16x4 kt[5], vf[3][5];
+#pragma unroll
+                for (int kb = 0; kb < 5; ++kb) {
+                    ka[kb] = *reinterpret_cast<const bf16x8*>(KF + kb * 768 + lane * 8);
+                    kt[kb] = *reinterpret_cast<const s16x4*>(KF + kb * 768 + 512 + lane * 4);
+                }
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+#pragma unroll
+                    for (int kb = 0; kb < 5; ++kb) vf[b][kb] = *reinterpret_cast<const s16x4*>(KF + 3840 + ((b * 5 + kb) * 64 + lane) * 4);
+#pragma unroll
+                for (int m = 0; m < 10; ++m) {
+                    union { u32x2 u; s16x4 s; } qt;
+                    const unsigned keep = kq < 2 ? 0xffffffffu : 0u;
+                    qt.u = u32x2{t4[m][0] & keep, t4[m][1] & keep};
+                    f32x4 sc[5];
+                    // (an accumulator is touched again only four MFMAs later, the order pinned: see temporal_block640.hip)
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kb = 0; kb < 5; ++kb) sc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[kb], q8[m], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kb = 0; kb < 5; ++kb) sc[kb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt[kb], qt.s, sc[kb], 0, 0, 0);
+                    TB_SETTLE();
+                    float mx = -3.0e38f;
+#pragma unroll
+                    for (int kb = 0; kb < 5; ++kb)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            sc[kb][j] = (16 * kb + 4 * kq + j < P.n_keys) ? sc[kb][j] * P.scale_log2 : -3.0e38f;
+                            mx = fmaxf(mx, sc[kb][j]);
+                        }
+                    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    float sum = 0.f;
+#pragma unroll
+                    for (int kb = 0; kb < 5; ++kb)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { sc[kb][j] = __builtin_amdgcn_exp2f(sc[kb][j] - mx); sum += sc[kb][j]; }
+                    sum += __shfl_xor(sum, 16, 64);
+                    sum += __shfl_xor(sum, 32, 64);
+                    const float inv = 1.f / sum;
+                    f32x4 o[3];
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) o[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kb = 0; kb < 5; ++kb) {
+                        union { u32x2 u; s16x4 s; } pb;
+                        pb.u = u32x2{pack_bf2(sc[kb][0] * inv, sc[kb][1] * inv), pack_bf2(sc[kb][2] * inv, sc[kb][3] * inv)};
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int b = 0; b < 3; ++b) o[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf[b][kb], pb.s, o[b], 0, 0, 0);
+                        if (kb & 1) asm volatile("s_nop 7" ::: "memory");   // (three accumulators take turns: spacing for the dependent ones)
+                    }
+                    TB_SETTLE();
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) o_pk[m][b] = u32x2{pack_bf2(o[b][0], o[b][1]), pack_bf2(o[b][2], o[b][3])};
+                }
+            } else {
             // ---- k, scores, softmax ----
             zero_pacc();
             TB_PART(1);
@@ -490,6 +563,7 @@ void temporal_block_kernel(const TBParams P) {
 #pragma unroll
                 for (int b = 0; b < 3; ++b) o_pk[m][b] = u32x2{pack_bf2(o[b][0], o[b][1]), pack_bf2(o[b][2], o[b][3])};
             }
+            }  // (!XATT)
 #undef TB_PART
 #undef TB_STEP
         }
@@ -576,7 +650,7 @@ void temporal_block_kernel(const TBParams P) {
                 // staged row rr (0..79) = tile row 80 pass + rr = (pixel 5 pass + rr / 16, frame rr % 16)
                 for (int c = tid; c < 80 * CPR; c += 512) {
                     const int rr = c / CPR, ch = c - rr * CPR;
-                    const unsigned dst = row0 + (unsigned)(rr & 15) * fstride + (unsigned)(5 * pass + (rr >> 4)) * TB_C + (unsigned)ch * 8;
+                    const unsigned dst = row0 + (unsigned)(rr & 15) * fstride + (unsigned)(5 * pass + (rr >> 4)) * pstride + (unsigned)ch * 8;
                     *reinterpret_cast<u32x4*>(P.out + dst) = *reinterpret_cast<const u32x4*>(Os + rr * OP + ch * 8);
                 }
                 if (STATS && tid < 320) {
@@ -601,7 +675,7 @@ void temporal_block_kernel(const TBParams P) {
                         }
                     s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2);
                     if (q == 0) {
-                        const int64_t grow = ((int64_t)clip * TB_F + (rr & 15)) * P.hw + p0 + 5 * pass + (rr >> 4);
+                        const int64_t grow = XATT ? (int64_t)tile * TB_ROWS + 80 * pass + rr : ((int64_t)clip * TB_F + (rr & 15)) * P.hw + p0 + 5 * pass + (rr >> 4);
                         *reinterpret_cast<f32x2_t*>(P.ln_stats + grow * 2) = f32x2_t{mean, rsqrtf(s2 * (1.f / 320.f) + P.ln_stats_eps)};
                     }
                 }
@@ -614,6 +688,82 @@ void temporal_block_kernel(const TBParams P) {
 }
 
 }  // namespace
+
+// text k | v `[batch][S][2 C]` (C = 320, 8 heads x 40) -> the MFMA fragments phase D of the XATT block reads: per (batch, head) 7680 bf16:
+//   K: 5 key blocks x [a: lane x 8 = channels {4 kq .. + 3, 16 + 4 kq .. + 3} | tail: lane x 4 = channels 32 + 4 kq .. + 3 for kq < 2, zeros beyond];
+//   V^T: [channel block 3][key block 5][lane][4]: lane (l15 = channel 16 cb + l15 < 40, kq) holds keys 16 kb + 4 kq .. + 3.   Keys >= S are zero.
+__global__ __launch_bounds__(256) void xattn_pack_kv40_kernel(const bf16_t* __restrict__ kv, bf16_t* __restrict__ out, int S, int64_t ldb) {
+    const int bh = blockIdx.x, b = bh >> 3, h = bh & 7;
+    const bf16_t* kb_ = kv + (int64_t)b * ldb + h * 40;            // k of (b, h): row stride 640
+    const bf16_t* vb_ = kb_ + 320;
+    bf16_t* o = out + (size_t)bh * 7680;
+    for (int g = threadIdx.x; g < 1920; g += 256) {               // groups of 4 output elements
+        u32x2 val = u32x2{0u, 0u};
+        if (g < 960) {                                            // K: key block kb = g / 192; inside: a (128 groups), tail (64)
+            const int kb = g / 192, r = g - kb * 192;
+            int lane, ch;
+            if (r < 128) { lane = r >> 1; ch = 16 * (r & 1) + 4 * (lane >> 4); }
+            else { lane = r - 128; ch = (lane >> 4) < 2 ? 32 + 4 * (lane >> 4) : -1; }
+            const int key = 16 * kb + (lane & 15);
+            if (key < S && ch >= 0) val = *reinterpret_cast<const u32x2*>(kb_ + (int64_t)key * 640 + ch);
+        } else {                                                  // V^T: (cb, kb, lane)
+            const int q = g - 960, lane = q & 63, kb = (q >> 6) % 5, cb = (q >> 6) / 5;
+            const int ch = 16 * cb + (lane & 15), key0 = 16 * kb + 4 * (lane >> 4);
+            unsigned short e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = (key0 + j < S && ch < 40) ? vb_[(int64_t)(key0 + j) * 640 + ch] : (unsigned short)0;
+            val = u32x2{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16)};
+        }
+        *reinterpret_cast<u32x2*>(o + g * 4) = val;
+    }
+}
+
+extern "C" int fmc_xattn_pack_kv40(const void* kv, void* out, int batch, int S, int64_t ld_batch, void* stream) {
+    if (!kv || !out) FMC_FAIL(FMC_E_NULL, "xattn_pack_kv40: NULL tensor");
+    if (batch <= 0 || S <= 0 || S > 80 || ld_batch < (int64_t)S * 640) FMC_FAIL(FMC_E_SHAPE, "xattn_pack_kv40: 1 <= S <= 80 text tokens of 2 x 320 channels");
+    if (((uintptr_t)kv & 7) || !fmc_aligned16(out)) FMC_FAIL(FMC_E_ALIGN, "xattn_pack_kv40: alignment");
+    hipLaunchKernelGGL(xattn_pack_kv40_kernel, dim3((unsigned)(batch * 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)kv, (bf16_t*)out, S, ld_batch);
+    FMC_CHECK_LAUNCH("fmc_xattn_pack_kv40");
+    return 0;
+}
+
+// The text cross-attention block of the spatial transformer at the 40x64 level in one launch (see fmc_xattn_block640_bf16): tokens h [images][hw][320],
+// hw % 160 == 0, 8 heads x 40; w_q_packed = hip_ops.pack_xattn_q40, w_out_tm = hip_ops._w_tilemajor, kvfrag = fmc_xattn_pack_kv40; optional row statistics.
+extern "C" int fmc_xattn_block320_bf16(const void* h, void* out, const float* ln_gamma, const float* ln_bpe, float ln_eps, const void* w_q_packed,
+                                       const void* kvfrag, const void* w_out_tm, const void* b_out, float* ln_stats, float ln_stats_eps, int n_images, int hw,
+                                       int n_keys, int images_per_text, float scale, void* stream) {
+    if (!h || !out || !ln_gamma || !ln_bpe || !w_q_packed || !kvfrag || !w_out_tm) FMC_FAIL(FMC_E_NULL, "xattn_block320_bf16: NULL tensor");
+    if (n_images <= 0 || hw <= 0 || hw % 160 || n_keys <= 0 || n_keys > 80 || images_per_text <= 0 || n_images % images_per_text)
+        FMC_FAIL(FMC_E_SHAPE, "xattn_block320_bf16: hw %% 160 == 0, 1 <= keys <= 80, images %% images_per_text == 0 (got hw=%d keys=%d images=%d / %d)", hw, n_keys,
+                 n_images, images_per_text);
+    if ((int64_t)n_images * hw * 320 * 2 >= ((int64_t)1 << 31)) FMC_FAIL(FMC_E_SHAPE, "xattn_block320_bf16: tensor of 2 GiB or more");
+    if (!fmc_aligned16(h) || !fmc_aligned16(out) || !fmc_aligned16(w_q_packed) || !fmc_aligned16(kvfrag) || !fmc_aligned16(w_out_tm) || !fmc_aligned16(ln_gamma) ||
+        !fmc_aligned16(ln_bpe) || (b_out && !fmc_aligned16(b_out)) || (ln_stats && ((uintptr_t)ln_stats & 7)))
+        FMC_FAIL(FMC_E_ALIGN, "xattn_block320_bf16: tensors must be 16-byte aligned");
+    TBParams P{};
+    P.h = (const bf16_t*)h; P.out = (bf16_t*)out; P.ln_gamma = ln_gamma; P.ln_bpe = ln_bpe; P.ln_eps = ln_eps;
+    P.w_qkv = (const bf16_t*)w_q_packed; P.w_out = (const bf16_t*)w_out_tm; P.b_out = (const bf16_t*)b_out;
+    P.ln_stats = ln_stats; P.ln_stats_eps = ln_stats_eps;
+    P.kvfrag = (const bf16_t*)kvfrag; P.n_keys = n_keys; P.images_per_text = images_per_text;
+    P.n_clips = 1; P.hw = hw; P.total_rows = (int64_t)n_images * hw;
+    P.tiles = (int)(P.total_rows / TB_ROWS);
+    P.scale_log2 = scale * 1.4426950408889634f;
+    P.dbg_times = nullptr;
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    const unsigned grid = (unsigned)(P.tiles < cus ? P.tiles : cus);
+    static bool raised = false;
+    if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block_kernel<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS);
+        raised = true;
+    }
+    if (ln_stats) hipLaunchKernelGGL((temporal_block_kernel<false, true, true>), dim3(grid), dim3(512), TB_LDS, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL((temporal_block_kernel<false, false, true>), dim3(grid), dim3(512), TB_LDS, (hipStream_t)stream, P);
+    FMC_CHECK_LAUNCH("fmc_xattn_block320_bf16");
+    return 0;
+}
 
 static long long* g_tb_dbg = nullptr;
 // diagnostic: device buffer of [workgroups][4][8] int64 that receives s_memrealtime stamps (100 MHz) of wave 0 at the phase boundaries; NULL = off
@@ -655,6 +805,7 @@ extern "C" int fmc_temporal_block_bf16(const void* h, void* out, const float* ln
     P.w_qkv = (const bf16_t*)w_qkv_packed; P.w_out = (const bf16_t*)w_out_tm; P.b_out = (const bf16_t*)b_out;
     P.ln_stats = ln_stats; P.ln_stats_eps = ln_stats_eps;
     P.n_clips = n_clips; P.hw = hw; P.tiles = n_clips * (hw / 10);
+    P.total_rows = (int64_t)n_clips * frames * hw;
     P.scale_log2 = scale * 1.4426950408889634f;
     P.dbg_times = g_tb_dbg;
     int dev = 0, cus = 256;

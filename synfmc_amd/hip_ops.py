@@ -1032,29 +1032,61 @@ def temporal_block(h: torch.Tensor, ln_gamma: torch.Tensor, ln_bpe: torch.Tensor
 
 
 XATTN_FUSED_640 = os.environ.get("FMC_XATTN_FUSED_640", "1") != "0"      # A/B switch: the 20x32-level text cross-attention as one launch
+XATTN_FUSED_320 = os.environ.get("FMC_XATTN_FUSED_320", "1") != "0"      # ... and the 40x64-level one
 
 
-def xattn_block640_supported(h: torch.Tensor, kv_tokens: int, heads: int) -> bool:
-    """`[images, hw, 640]` bf16 tokens the fused cross-attention block takes: 8 heads, hw % 80 == 0, at most 80 text tokens, inference."""
-    return (XATTN_FUSED_640 and h.is_cuda and h.dtype == torch.bfloat16 and h.ndim == 3 and h.is_contiguous() and h.shape[2] == 640 and heads == 8
-            and h.shape[1] % 80 == 0 and 0 < kv_tokens <= 80 and h.numel() * 2 < (1 << 31) and not torch.is_grad_enabled())
+def pack_xattn_q40(w_q: torch.Tensor, heads: int = 8) -> torch.Tensor:
+    """`to_q [320, 320]` of a text cross-attention (8 heads x 40) -> the fragment order phase D of the fused block reads: per head [10 k-steps][3 blocks =
+    q[0:16], q[16:32], (q[32:40] | 8 zero rows)][lane = 16 * (k chunk of 8) + row][8] (the q part of `pack_temporal_qkv`, the shared tail block's k half empty)."""
+    C, Ci = w_q.shape
+    assert C == 320 and Ci == 320 and heads == 8
+    q = w_q.detach().view(heads, 40, Ci)
+    z = torch.zeros(heads, 8, Ci, dtype=q.dtype, device=q.device)
+    blk = torch.stack([q[:, 0:16], q[:, 16:32], torch.cat([q[:, 32:40], z], 1)], 1)            # [H, 3, 16, C]
+    return blk.reshape(heads, 3, 16, Ci // 32, 4, 8).permute(0, 3, 1, 4, 2, 5).contiguous().view(-1)
 
 
-def xattn_block640(h: torch.Tensor, ln_gamma: torch.Tensor, ln_btab: torch.Tensor, ln_eps: float, w_q_packed: torch.Tensor, kv: torch.Tensor,
-                   w_out_frag: torch.Tensor, b_out: Optional[torch.Tensor], scale: float, images_per_text: int) -> torch.Tensor:
-    """`to_out(softmax(to_q(LayerNorm(h)) k^T scale) v) + b + h` in one launch (`fmc_xattn_block640_bf16`); `kv [B, S, 1280]` = the text's fused
-    k | v projection (packed into MFMA fragments by one tiny launch, `fmc_xattn_pack_kv`); `ln_btab [16, 640]` fp32 rows = the LayerNorm beta."""
-    _dev(h, ln_gamma, ln_btab, w_q_packed, kv, w_out_frag, b_out)
+def xattn_block_supported(h: torch.Tensor, kv_tokens: int, heads: int) -> bool:
+    """`[images, hw, C]` bf16 tokens the fused text cross-attention block takes: 8 heads, at most 80 text tokens, inference; C = 640 with hw % 80 == 0
+    or C = 320 with hw % 160 == 0."""
+    if not (h.is_cuda and h.dtype == torch.bfloat16 and h.ndim == 3 and h.is_contiguous() and heads == 8 and 0 < kv_tokens <= 80
+            and h.numel() * 2 < (1 << 31) and not torch.is_grad_enabled()):
+        return False
+    return (XATTN_FUSED_640 and h.shape[2] == 640 and h.shape[1] % 80 == 0) or (XATTN_FUSED_320 and h.shape[2] == 320 and h.shape[1] % 160 == 0)
+
+
+xattn_block640_supported = xattn_block_supported
+
+
+def xattn_block(h: torch.Tensor, ln_gamma: torch.Tensor, ln_btab: torch.Tensor, ln_eps: float, w_q_packed: torch.Tensor, kv: torch.Tensor,
+                w_out_packed: torch.Tensor, b_out: Optional[torch.Tensor], scale: float, images_per_text: int, stats_eps: Optional[float] = None):
+    """`to_out(softmax(to_q(LayerNorm(h)) k^T scale) v) + b + h` in one launch; `kv [B, S, 2 C]` = the text's fused k | v projection (packed into MFMA
+    fragments by one tiny launch); `ln_btab [16, C]` fp32 rows = the LayerNorm beta.  C = 640: `fmc_xattn_block640_bf16`, weights `pack_w_frag80`;
+    C = 320: `fmc_xattn_block320_bf16`, `pack_xattn_q40` / `_w_tilemajor`, and `stats_eps` adds the (mean, rstd) of the output rows: `(out, stats)`."""
+    _dev(h, ln_gamma, ln_btab, w_q_packed, kv, w_out_packed, b_out)
     N, hw, C = h.shape
     B, S, C2 = kv.shape
-    assert C == 640 and C2 == 1280 and kv.stride(2) == 1 and kv.stride(1) == C2 and N % images_per_text == 0 and N // images_per_text == B
-    frag = torch.empty(B * 8 * 12800, dtype=h.dtype, device=h.device)
-    _lib.check(_lib.load().fmc_xattn_pack_kv(kv.data_ptr(), frag.data_ptr(), B, S, kv.stride(0), _stream()), "fmc_xattn_pack_kv")
+    assert C in (320, 640) and C2 == 2 * C and kv.stride(2) == 1 and kv.stride(1) == C2 and N % images_per_text == 0 and N // images_per_text == B
     out = torch.empty_like(h)
-    _lib.check(_lib.load().fmc_xattn_block640_bf16(h.data_ptr(), out.data_ptr(), ln_gamma.data_ptr(), ln_btab.data_ptr(), float(ln_eps), w_q_packed.data_ptr(),
-                                                   frag.data_ptr(), w_out_frag.data_ptr(), _p(b_out), N, hw, S, images_per_text, float(scale), _stream()),
-               "fmc_xattn_block640_bf16")
-    return out
+    L = _lib.load()
+    if C == 640:
+        assert stats_eps is None
+        frag = torch.empty(B * 8 * 12800, dtype=h.dtype, device=h.device)
+        _lib.check(L.fmc_xattn_pack_kv(kv.data_ptr(), frag.data_ptr(), B, S, kv.stride(0), _stream()), "fmc_xattn_pack_kv")
+        _lib.check(L.fmc_xattn_block640_bf16(h.data_ptr(), out.data_ptr(), ln_gamma.data_ptr(), ln_btab.data_ptr(), float(ln_eps), w_q_packed.data_ptr(),
+                                             frag.data_ptr(), w_out_packed.data_ptr(), _p(b_out), N, hw, S, images_per_text, float(scale), _stream()),
+                   "fmc_xattn_block640_bf16")
+        return out
+    frag = torch.empty(B * 8 * 7680, dtype=h.dtype, device=h.device)
+    stats = torch.empty(N * hw, 2, dtype=torch.float32, device=h.device) if stats_eps is not None else None
+    _lib.check(L.fmc_xattn_pack_kv40(kv.data_ptr(), frag.data_ptr(), B, S, kv.stride(0), _stream()), "fmc_xattn_pack_kv40")
+    _lib.check(L.fmc_xattn_block320_bf16(h.data_ptr(), out.data_ptr(), ln_gamma.data_ptr(), ln_btab.data_ptr(), float(ln_eps), w_q_packed.data_ptr(),
+                                         frag.data_ptr(), w_out_packed.data_ptr(), _p(b_out), _p(stats), float(stats_eps or 0.0), N, hw, S, images_per_text,
+                                         float(scale), _stream()), "fmc_xattn_block320_bf16")
+    return out if stats is None else (out, stats)
+
+
+xattn_block640 = xattn_block
 
 
 def linear_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:

@@ -573,7 +573,7 @@ class BasicTransformerBlock(nn.Module):
         key = (w_q.data_ptr(), w_q._version, w_o.data_ptr(), w_o._version)
         hit = attn.__dict__.get("_fused_xb")
         if hit is None or hit[0] != key:
-            hit = (key, K.pack_w_frag80(w_q), K.pack_w_frag80(w_o))
+            hit = (key, K.pack_w_frag80(w_q), K.pack_w_frag80(w_o)) if w_q.shape[0] == 640 else (key, K.pack_xattn_q40(w_q, attn.heads), K._w_tilemajor(w_o))
             attn.__dict__["_fused_xb"] = hit
         g, b = f32_param(self.norm2, "weight"), f32_param(self.norm2, "bias")
         ck = (g.data_ptr(), g._version, b.data_ptr(), b._version)
@@ -584,8 +584,14 @@ class BasicTransformerBlock(nn.Module):
             self.__dict__["_fused_xc"] = c
         h = hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()
         kv = linear_op(encoder_hidden_states, w_kv)
-        return K.xattn_block640(h, c[1], c[2], self.norm2.eps, hit[1], kv, hit[2], attn.to_out[0].bias, attn.scale,
-                                h.shape[0] // encoder_hidden_states.shape[0])
+        per_text = h.shape[0] // encoder_hidden_states.shape[0]
+        if h.shape[2] == 640:
+            return K.xattn_block(h, c[1], c[2], self.norm2.eps, hit[1], kv, hit[2], attn.to_out[0].bias, attn.scale, per_text)
+        # the 40x64 level: the feed-forward's norm3 is applied by its GEGLU projection from the row statistics this launch leaves
+        out, stats = K.xattn_block(h, c[1], c[2], self.norm2.eps, hit[1], kv, hit[2], attn.to_out[0].bias, attn.scale, per_text, stats_eps=self.norm3.eps)
+        K.ln_epilogue_calls["emitted"] += 1
+        out._fmc_ln = (stats, self.norm3._ln_key(None, 1, 1), True)
+        return out
 
     def forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, timestep=None, cross_attention_kwargs=None, class_labels=None,
@@ -600,12 +606,12 @@ class BasicTransformerBlock(nn.Module):
         def plain(attn):            # only these processors hand the normed tokens to `linear_op` and nowhere else (a pose merge also uses
             return type(attn.processor) in (AttnProcessor, LoRAAttnProcessor)      # them as a residual: it needs the materialised norm)
         d1, d2 = plain(self.attn1), self.attn2 is not None and plain(self.attn2)
-        # the text cross-attention block of the 20x32 level as ONE launch (LayerNorm + to_q + attention over the text tokens + to_out + residual:
-        # hip_ops.xattn_block640): plain / frozen-LoRA processor, 8 heads x 80, tokens [images, hw, 640] with hw % 80 == 0, no mask
+        # the text cross-attention block of the 40x64 / 20x32 levels as ONE launch (LayerNorm + to_q + attention over the text tokens + to_out + residual:
+        # hip_ops.xattn_block): plain / frozen-LoRA processor, 8 heads, tokens [images, hw, 320 | 640] with hw % 160 | 80 == 0, no mask
         fuse2 = (d2 and not cfg_expand and encoder_hidden_states is not None and encoder_attention_mask is None and hidden_states.ndim == 3
                  and encoder_hidden_states.ndim == 3 and hidden_states.shape[0] % encoder_hidden_states.shape[0] == 0
-                 and K.xattn_block640_supported(hidden_states, encoder_hidden_states.shape[1], self.attn2.heads)
-                 and self.attn2.inner_dim == 640 and not self.attn2.residual_connection and self.attn2.rescale_output_factor == 1.0
+                 and K.xattn_block_supported(hidden_states, encoder_hidden_states.shape[1], self.attn2.heads)
+                 and self.attn2.inner_dim == hidden_states.shape[2] and not self.attn2.residual_connection and self.attn2.rescale_output_factor == 1.0
                  and self.attn2.to_q.weight.dtype == torch.bfloat16 and encoder_hidden_states.dtype == torch.bfloat16)
         # (`_lazy_res`: the output projection's `+ residual` may be left to the next norm's pass when the projection runs on the vendor arm;
         #  true exactly where the very next consumer is `norm.skip` below)

@@ -1739,6 +1739,46 @@ def _temporal_block_reference(h, gamma, beta, pe, eps, wqkv, wout, bout, heads, 
     return F.linear(o, wout, bout) + h
 
 
+@pytest.mark.parametrize("B,Fr,hw,S", [(1, 1, 160, 77), (2, 16, 2560, 77), (3, 2, 320, 80), (2, 3, 160, 5)])
+def test_xattn_block_fused_320(K, B, Fr, hw, S):
+    """`fmc_xattn_block320_bf16` + `fmc_xattn_pack_kv40`: the text cross-attention block at the 40x64 level (C = 320, 8 heads x 40) on the 160-row
+    persistent skeleton of the temporal block, with the row statistics for the next LayerNorm; same checks as at C = 640."""
+    dtype = torch.bfloat16
+    C, H, d = 320, 8, 40
+    N = B * Fr
+    ho, hd = rnd((N, hw, C), 1, dtype, scale=1.5, shift=0.2)
+    go, _ = rnd((C,), 2, torch.float32, scale=0.3, shift=1.0)
+    bo, _ = rnd((C,), 3, torch.float32, scale=0.2)
+    wqo, wqd = rnd((C, C), 5, dtype, scale=C ** -0.5 * 1.5)
+    woo, wod = rnd((C, C), 6, dtype, scale=C ** -0.5)
+    boo, bod = rnd((C,), 7, dtype, scale=0.3)
+    kvo, kvd = rnd((B, S, 2 * C), 8, dtype, scale=1.2)
+    btab = bo[None].expand(16, C).contiguous().cuda()
+    run = lambda **k: K.xattn_block(hd, go.cuda(), btab, 1e-5, K.pack_xattn_q40(wqd), kvd, K._w_tilemajor(wod), bod, d ** -0.5, Fr, **k)
+    out, stats = run(stats_eps=1e-5)
+
+    def reference(round_bf16):
+        r = (lambda t: t.bfloat16().float()) if round_bf16 else (lambda t: t)
+        x = r(F.layer_norm(ho, (C,), go, bo, 1e-5))
+        q = r(F.linear(x, wqo)).reshape(B, Fr * hw, H, d).permute(0, 2, 1, 3)
+        k = kvo[..., :C].reshape(B, S, H, d).permute(0, 2, 1, 3)
+        v = kvo[..., C:].reshape(B, S, H, d).permute(0, 2, 1, 3)
+        p = r(torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, dim=-1))
+        o = r(p @ v).permute(0, 2, 1, 3).reshape(N, hw, C)
+        return F.linear(o, woo, boo) + ho
+    ref_r, ref_f = reference(True), reference(False)
+    assert rel_inf(out.float(), ref_f) < 2e-2, (B, Fr, hw, S)
+    err = (out.float().cpu() - ref_r).abs()
+    bound = 2.0 ** -8 * ref_r.abs() + 0.08
+    assert not bool((err > bound).any()), f"{int((err > bound).sum())} / {err.numel()} beyond the bound, worst {float((err - bound).max()):.3e}"
+    mu = out.float().mean(-1).view(-1)
+    rstd = (out.float().var(-1, unbiased=False) + 1e-5).rsqrt().view(-1)
+    assert rel_inf(stats[:, 0], mu) < 1e-4 and rel_inf(stats[:, 1], rstd) < 1e-4
+    assert torch.equal(run(), out)
+    with pytest.raises(ValueError):
+        K.xattn_block(hd[:, :hw - 16].contiguous(), go.cuda(), btab, 1e-5, K.pack_xattn_q40(wqd), kvd, K._w_tilemajor(wod), bod, d ** -0.5, Fr)
+
+
 @pytest.mark.parametrize("B,Fr,hw,S", [(1, 1, 80, 77), (2, 16, 640, 77), (3, 2, 160, 80), (2, 3, 80, 5)])
 def test_xattn_block_fused_640(K, B, Fr, hw, S):
     """`fmc_xattn_block640_bf16` + `fmc_xattn_pack_kv`: LayerNorm -> to_q -> attention over the text tokens (k | v of a `[B, S, 1280]` projection shared by

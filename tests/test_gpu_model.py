@@ -594,13 +594,14 @@ def test_pipeline_end_to_end_with_text_encoder_and_vae(stack):
 
 
 @pytest.mark.gpu
-def test_basic_transformer_block_fused_text_cross_attention_equals_the_unfused_chain():
-    """diffusers' BasicTransformerBlock at the 20x32-level width (C = 640, 8 heads x 80, hw % 80 == 0) runs `attn2(norm2(h), text) + h` as one
-    `fmc_xattn_block640_bf16` launch (hip_ops.XATTN_FUSED_640); the block's output must match the un-fused chain (LayerNorm / to_q GEMM /
+@pytest.mark.parametrize("C,hw", [(640, 160), (320, 320)])
+def test_basic_transformer_block_fused_text_cross_attention_equals_the_unfused_chain(C, hw):
+    """diffusers' BasicTransformerBlock at the 20x32-level width (C = 640, 8 heads x 80, hw % 80 == 0) and the 40x64-level one (C = 320, hw % 160 == 0) runs
+    `attn2(norm2(h), text) + h` as one `fmc_xattn_block640_bf16` / `fmc_xattn_block320_bf16` launch (hip_ops.XATTN_FUSED_640 / _320); the block's output must match the un-fused chain (LayerNorm / to_q GEMM /
     cross-attention kernel / to_out GEMM) on the same weights, and both the fp32 run of the same module."""
     from synfmc_amd.models import layers as L
     torch.manual_seed(5)
-    C, H, hw, B, Fr, S = 640, 8, 160, 2, 3, 77
+    H, B, Fr, S = 8, 2, 3, 77
     blk = L.BasicTransformerBlock(C, H, C // H, cross_attention_dim=768)
     with torch.no_grad():
         for p in blk.parameters():
@@ -615,18 +616,18 @@ def test_basic_transformer_block_fused_text_cross_attention_equals_the_unfused_c
     text = torch.randn(B, S, 768).to("cuda", torch.bfloat16)
     with torch.no_grad():
         calls = []
-        real = L.K.xattn_block640
-        L.K.xattn_block640 = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        real = L.K.xattn_block
+        L.K.xattn_block = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
         try:
             fused = blk(x, encoder_hidden_states=text)
         finally:
-            L.K.xattn_block640 = real
+            L.K.xattn_block = real
         assert len(calls) == 1
-        L.K.XATTN_FUSED_640 = False
+        L.K.XATTN_FUSED_640 = L.K.XATTN_FUSED_320 = False
         try:
             plain = blk(x, encoder_hidden_states=text)
         finally:
-            L.K.XATTN_FUSED_640 = True
+            L.K.XATTN_FUSED_640 = L.K.XATTN_FUSED_320 = True
         ref = blk.float()(x.float(), encoder_hidden_states=text.float())
     assert rel_inf(fused, plain) < 2e-2
     e_f, e_p = rel_inf(fused, ref), rel_inf(plain, ref)
