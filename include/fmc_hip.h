@@ -462,6 +462,13 @@ int fmc_xattn_block320_bf16(const void* h, void* out, const float* ln_gamma, con
                             const void* kvfrag, const void* w_out_tm, const void* b_out, float* ln_stats, float ln_stats_eps, int n_images, int hw,
                             int n_keys, int images_per_text, float scale, void* stream);
 int fmc_xattn_pack_kv40(const void* kv, void* out, int batch, int S, int64_t ld_batch, void* stream);
+/* ---- LayerNorm + GEGLU projection of a feed-forward at the 20x32 level, A operand resident (round 4) ----------------------------------------------
+ * out[M][cff] = (n W_v^T + b_v) * gelu(n W_g^T + b_g), n = LayerNorm(h): `GEGLU.forward` of diffusers' FeedForward behind norm3 / ff_norm
+ * (fmc/models/motion_module.py:295-299; BasicTransformerBlock).  A workgroup keeps its 80 normalised rows in LDS and walks the cff / 320 column chunks
+ * with the chunk's weight rows streamed in MFMA-fragment order (`hip_ops.pack_geglu_frag80`) -- replaces fmc_layernorm_fwd + fmc_linear_bf16(GEGLU).
+ *   h bf16 [M][640], M % 80 == 0; out bf16 [M][cff] row-major, cff % 320 == 0; bias bf16 [2 cff] (value | gate) or NULL. */
+int fmc_geglu640_ln_bf16(const void* h, void* out, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* w_packed, const void* bias,
+                         int64_t M, int cff, void* stream);
 /* Diagnostic: `buf` = device buffer of [workgroups][4][8] int64 that receives s_memrealtime stamps (100 MHz) of wave 0 at the phase boundaries of
  * its first four tiles (tools/scratch/r04/probe_tb.py); NULL switches the stamps off (default). */
 int fmc_temporal_block_set_debug(void* buf);

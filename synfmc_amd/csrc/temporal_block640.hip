@@ -501,6 +501,201 @@ void temporal_block640_kernel(const T6Params P) {
     }
 }
 
+// ---- LayerNorm + GEGLU projection of a feed-forward at the 20x32 level with the A operand RESIDENT (round 4) ------------------------------------------
+// out[M][Cff] = (n W_v^T + b_v) * gelu(n W_g^T + b_g), n = LayerNorm(h): diffusers FeedForward(GEGLU) as BasicTransformerBlock / TemporalTransformerBlock
+// call it (fmc/models/motion_module.py:295-299; diffusers 0.24 attention.py).  The 160x320 kernel re-requests the A tile for every one of its 16 n-tiles and
+// spends 7 of 19.75 us per tile in its epilogue; here a workgroup keeps its 80 normalised rows in LDS (100 KiB), walks the Cff / 320 column chunks, and
+// streams each chunk's 640 weight rows in fragment order straight into registers (the projections of temporal_block640_kernel).  Weight rows are
+// permuted per wave to [v 0-15 | v 16-31 | v 32-39, g 32-39 | g 0-15 | g 16-31] (hip_ops.pack_geglu_frag80): value and gate of a column meet in one lane
+// for four of the five 16-row blocks, one v_permlane32_swap serves the fifth.
+__device__ __forceinline__ float t6_gelu_erf(float g) {       // Abramowitz & Stegun 7.1.26 (|error| < 1.5e-7), as gemm_conv.hip
+    const float x = fabsf(g) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = 1.f - p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);
+    return 0.5f * g + 0.5f * fabsf(g) * e;
+}
+
+struct G6Params {
+    const bf16_t* h; bf16_t* out;                          // h [M][640]; out [M][Cff] row-major
+    const float* ln_gamma; const float* ln_beta; float ln_eps;
+    const bf16_t* w;                                       // [Cff / 320 chunks][8 waves][20 k-steps][5 blocks][lane][8]
+    const bf16_t* bias;                                    // [2 Cff] (value | gate) or NULL
+    int64_t M; int cff;
+};
+
+__global__ __launch_bounds__(512, 2)
+void geglu640_kernel(const G6Params P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* X = reinterpret_cast<bf16_t*>(smem_raw);             // [80][640], chunk c of row r at chunk c ^ ((r >> 1) & 7)
+    bf16_t* S = X + T6_X_ELEMS;                                  // staging [80][328] (52.5 KiB); phase A: (mean, rstd) x 80 rows
+    float* stats = reinterpret_cast<float*>(S);
+    constexpr int SP = 328;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int xsw = (l15 >> 1) & 7;
+    const int64_t m0 = (int64_t)blockIdx.x * T6_ROWS;
+    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)P.h, 0, (int)(P.M * T6_C * 2), 0x00020000);
+    // ---- phase A: rows -> X, LayerNorm in place ----
+#pragma unroll
+    for (int j = 0; j < 13; ++j) {
+        const int q = wave + 8 * j;
+        if (q < 100) {
+            const int idx = 64 * q + lane, r = idx / T6_CPR, pc = idx - r * T6_CPR, c = pc ^ ((r >> 1) & 7);
+            t6_dma(rsH, (unsigned)(((m0 + r) * T6_C + c * 8) * 2), X + 64 * q * 8);
+        }
+    }
+    T6_VMCNT0();
+    __syncthreads();
+#pragma unroll 1
+    for (int r = tid >> 3; r < T6_ROWS; r += 64) {
+        const int q = tid & 7;
+        const bf16_t* xr = X + r * T6_C;
+        u32x4 x4[10];
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            x4[i] = *reinterpret_cast<const u32x4*>(xr + (q + 8 * i) * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s1 += __uint_as_float(x4[i][j] << 16) + __uint_as_float(x4[i][j] & 0xffff0000u);
+        }
+        s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
+        const float mean = s1 * (1.f / 640.f);
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 10; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = __uint_as_float(x4[i][j] << 16) - mean, b = __uint_as_float(x4[i][j] & 0xffff0000u) - mean;
+                s2 += a * a + b * b;
+            }
+        s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4);
+        if (q == 0) *reinterpret_cast<f32x2_t*>(stats + 2 * r) = f32x2_t{mean, rsqrtf(s2 * (1.f / 640.f) + P.ln_eps)};
+    }
+    __syncthreads();
+    if (tid < 480) {
+        const int nc = tid % 80, nrg = tid / 80;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(P.ln_gamma + nc * 8), g1 = *reinterpret_cast<const f32x4*>(P.ln_gamma + nc * 8 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(P.ln_beta + nc * 8), b1 = *reinterpret_cast<const f32x4*>(P.ln_beta + nc * 8 + 4);
+#pragma unroll 2
+        for (int r = nrg; r < T6_ROWS; r += 6) {
+            u32x4* px = reinterpret_cast<u32x4*>(X + r * T6_C + (nc ^ ((r >> 1) & 7)) * 8);
+            const u32x4 x4 = *px;
+            const f32x2_t st = *reinterpret_cast<const f32x2_t*>(stats + 2 * r);
+            const float m = st[0], rs = st[1];
+            u32x4 o4;
+            o4[0] = pack_bf2((__uint_as_float(x4[0] << 16) - m) * rs * g0[0] + b0[0], (__uint_as_float(x4[0] & 0xffff0000u) - m) * rs * g0[1] + b0[1]);
+            o4[1] = pack_bf2((__uint_as_float(x4[1] << 16) - m) * rs * g0[2] + b0[2], (__uint_as_float(x4[1] & 0xffff0000u) - m) * rs * g0[3] + b0[3]);
+            o4[2] = pack_bf2((__uint_as_float(x4[2] << 16) - m) * rs * g1[0] + b1[0], (__uint_as_float(x4[2] & 0xffff0000u) - m) * rs * g1[1] + b1[1]);
+            o4[3] = pack_bf2((__uint_as_float(x4[3] << 16) - m) * rs * g1[2] + b1[2], (__uint_as_float(x4[3] & 0xffff0000u) - m) * rs * g1[3] + b1[3]);
+            *px = o4;
+        }
+    }
+    __syncthreads();                                              // X = LayerNorm(h); the staging region is free
+
+    f32x4 acc[5][5];
+    const int nchunks = P.cff / 320;
+#pragma unroll 1
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(P.w + ((size_t)ch * 8 + wave) * T6_WAVE_W), 0, T6_WAVE_W * 2, 0x00020000);
+        int wl = lane * 16;
+        asm volatile("" : "+v"(wl));
+        u32x4 wfr[3][5];
+        auto load_w = [&](int g) {
+#pragma unroll
+            for (int nb = 0; nb < 5; ++nb) wfr[g % 3][nb] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wl, (g * 5 + nb) * 1024, 0);
+        };
+        load_w(0);
+        load_w(1);
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+#pragma unroll
+            for (int b = 0; b < 5; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto step = [&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g + 2 < 20) load_w(g + 2);
+            int kqx = kq ^ xsw, xrow_o = l15 * T6_C;
+            asm volatile("" : "+v"(kqx), "+v"(xrow_o));
+            const int xo = xrow_o + ((g >> 1) * 8 + (((g & 1) * 4) ^ kqx)) * 8;
+            __builtin_amdgcn_sched_barrier(0);
+            u32x4 af3[3];
+            af3[0] = *reinterpret_cast<const u32x4*>(X + 0 * 16 * T6_C + xo);
+            af3[1] = *reinterpret_cast<const u32x4*>(X + 1 * 16 * T6_C + xo);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+            for (int mb = 0; mb < 5; ++mb) {
+                if (mb + 2 < 5) af3[(mb + 2) % 3] = *reinterpret_cast<const u32x4*>(X + (mb + 2) * 16 * T6_C + xo);
+                union { bf16x8 v; u32x4 u; } a;
+                a.u = af3[mb % 3];
+#pragma unroll
+                for (int nb = 0; nb < 5; ++nb) {
+                    union { bf16x8 v; u32x4 u; } w;
+                    w.u = wfr[g % 3][nb];
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, a.v, acc[mb][nb], 0, 0, 0);
+                }
+                if (mb + 2 < 5) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+            }
+        };
+#define G6_G(G) step(std::integral_constant<int, G>{})
+        G6_G(0); G6_G(1); G6_G(2); G6_G(3); G6_G(4); G6_G(5); G6_G(6); G6_G(7); G6_G(8); G6_G(9);
+        G6_G(10); G6_G(11); G6_G(12); G6_G(13); G6_G(14); G6_G(15); G6_G(16); G6_G(17); G6_G(18); G6_G(19);
+#undef G6_G
+        T6_SETTLE();
+        // ---- gate: my 40 gated columns gc0 .. gc0 + 39 of this chunk ----
+        const int gc0 = ch * 320 + wave * 40;
+        float bv[3][4], bg[3][4];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int c0 = gc0 + 16 * p + 4 * (p == 2 ? (kq & 1) : kq);
+            if (P.bias) {
+                t6_unpack4(*reinterpret_cast<const u32x2*>(P.bias + c0), bv[p]);
+                t6_unpack4(*reinterpret_cast<const u32x2*>(P.bias + P.cff + c0), bg[p]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[p][j] = bg[p][j] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int mb = 0; mb < 5; ++mb) {
+            bf16_t* Sr = S + (mb * 16 + l15) * SP + wave * 40;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {                          // blocks (0, 3) and (1, 4): value and gate in the same lane
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (acc[mb][p][j] + bv[p][j]) * t6_gelu_erf(acc[mb][3 + p][j] + bg[p][j]);
+                *reinterpret_cast<u32x2*>(Sr + 16 * p + 4 * kq) = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+            }
+            {                                                     // block 2: lanes kq < 2 hold value columns 32 + 4 kq .., lanes kq >= 2 their gates
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned own = __float_as_uint(acc[mb][2][j]);
+                    const auto sw = __builtin_amdgcn_permlane32_swap(own, own, false, false);
+                    const float gate = __uint_as_float((unsigned)sw[1]);          // (lanes 0-31 see lane + 32's value)
+                    o[j] = (acc[mb][2][j] + bv[2][j]) * t6_gelu_erf(gate + bg[2][j]);
+                }
+                if (kq < 2) *reinterpret_cast<u32x2*>(Sr + 32 + 4 * kq) = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+            }
+        }
+        __syncthreads();
+        // ---- whole-row stores: 80 rows x 40 sixteen-byte chunks = 6.25 per thread ----
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {
+            const int c = tid + 512 * it;
+            if (it < 6 || tid < 128) {
+                const int r = c / 40, cc = c - r * 40;
+                *reinterpret_cast<u32x4*>(P.out + (m0 + r) * (int64_t)P.cff + ch * 320 + cc * 8) = *reinterpret_cast<const u32x4*>(S + r * SP + cc * 8);
+            }
+        }
+        __syncthreads();                                          // the staging region is free again
+    }
+}
+
 // text k | v `[batch][S][2 C]` (C = 640, 8 heads x 80) -> the MFMA fragments phase D of the XATT block reads: per (batch, head)
 //   K: 5 key blocks x [a: lane x 8 | b: lane x 8 | tail: lane x 4]: lane (l15 = key in block, kq) holds channels {4 kq .. + 3, 16 + 4 kq .. + 3} (+ 32 for b),
 //      64 + 4 kq .. + 3 for the tail -- the channel permutation q comes out of the swapped product in;
@@ -604,5 +799,27 @@ extern "C" int fmc_xattn_pack_kv(const void* kv, void* out, int batch, int S, in
     if (((uintptr_t)kv & 7) || !fmc_aligned16(out)) FMC_FAIL(FMC_E_ALIGN, "xattn_pack_kv: alignment");
     hipLaunchKernelGGL(xattn_pack_kv_kernel, dim3((unsigned)(batch * 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)kv, (bf16_t*)out, S, ld_batch);
     FMC_CHECK_LAUNCH("fmc_xattn_pack_kv");
+    return 0;
+}
+
+// LayerNorm + GEGLU projection with the A operand resident (see geglu640_kernel): h bf16 [M][640] (M % 80 == 0), out bf16 [M][cff] row-major,
+// w_packed = hip_ops.pack_geglu_frag80 of the [2 cff, 640] projection (cff % 320 == 0), bias bf16 [2 cff] or NULL, ln_gamma / ln_beta fp32 [640].
+extern "C" int fmc_geglu640_ln_bf16(const void* h, void* out, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* w_packed, const void* bias,
+                                    int64_t M, int cff, void* stream) {
+    if (!h || !out || !ln_gamma || !ln_beta || !w_packed) FMC_FAIL(FMC_E_NULL, "geglu640_ln_bf16: NULL tensor");
+    if (M <= 0 || M % 80 || cff <= 0 || cff % 320 || M * 640 * 2 >= ((int64_t)1 << 31) || M * cff * 2 >= ((int64_t)1 << 40))
+        FMC_FAIL(FMC_E_SHAPE, "geglu640_ln_bf16: M %% 80 == 0, cff %% 320 == 0 (got M=%lld cff=%d)", (long long)M, cff);
+    if (!fmc_aligned16(h) || !fmc_aligned16(out) || !fmc_aligned16(w_packed) || !fmc_aligned16(ln_gamma) || !fmc_aligned16(ln_beta) || (bias && ((uintptr_t)bias & 7)))
+        FMC_FAIL(FMC_E_ALIGN, "geglu640_ln_bf16: tensors must be 16-byte aligned");
+    G6Params P{};
+    P.h = (const bf16_t*)h; P.out = (bf16_t*)out; P.ln_gamma = ln_gamma; P.ln_beta = ln_beta; P.ln_eps = ln_eps;
+    P.w = (const bf16_t*)w_packed; P.bias = (const bf16_t*)bias; P.M = M; P.cff = cff;
+    static bool raised = false;
+    if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&geglu640_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, T6_LDS);
+        raised = true;
+    }
+    hipLaunchKernelGGL(geglu640_kernel, dim3((unsigned)(M / 80)), dim3(512), T6_LDS, (hipStream_t)stream, P);
+    FMC_CHECK_LAUNCH("fmc_geglu640_ln_bf16");
     return 0;
 }

@@ -529,6 +529,20 @@ class FeedForward(nn.Module):
         self.net = nn.ModuleList([GEGLU(dim, inner), nn.Dropout(dropout),
                                   Linear(inner, dim if dim_out is None else dim_out)])
 
+    def forward_ln(self, h, norm, residual):
+        """`ff(norm(h)) + residual` with LayerNorm + GEGLU projection as one launch where `hip_ops.geglu_ln_direct` exists (the 20x32 level), else None."""
+        proj, out = self.net[0], self.net[2]
+        w = proj.proj.weight
+        if not K.geglu_ln_direct_ok(h, w) or getattr(h, "_fmc_pending_add", None) is not None or getattr(h, "_fmc_ln", None) is not None:
+            return None
+        key = (w.data_ptr(), w._version)
+        hit = self.__dict__.get("_geglu_frag")
+        if hit is None or hit[0] != key:
+            hit = (key, K.pack_geglu_frag80(w))
+            self.__dict__["_geglu_frag"] = hit
+        mid = K.geglu_ln_direct(h, f32_param(norm, "weight"), f32_param(norm, "bias"), norm.eps, hit[1], proj.proj.bias, w.shape[0] // 2)
+        return out(mid, residual=residual)
+
     def forward(self, hidden_states, scale: float = 1.0, residual: Optional[torch.Tensor] = None):
         proj, out = self.net[0], self.net[2]
         il = proj.interleaved() if (hidden_states.is_cuda and hidden_states.dtype == torch.bfloat16 and not torch.is_grad_enabled()) else None
@@ -638,6 +652,10 @@ class BasicTransformerBlock(nn.Module):
             hidden_states, n = self.norm2.skip(hidden_states, defer=d2)
             hidden_states = self.attn2(n, encoder_hidden_states=encoder_hidden_states, attention_mask=encoder_attention_mask,
                                        _residual=hidden_states, **kw)
+        if not torch.is_grad_enabled():
+            y = self.ff.forward_ln(hidden_states, self.norm3, hidden_states)
+            if y is not None:
+                return y
         hidden_states, n = self.norm3.skip(hidden_states, defer=True)
         return self.ff(n, residual=hidden_states)
 

@@ -238,6 +238,10 @@ class TemporalTransformerBlock(nn.Module):
             # the feed-forward's norm is applied by its GEGLU projection from the row statistics the last block left
             K.ln_epilogue_calls["emitted"] += 1
             h._fmc_ln = (stats, self.ff_norm._ln_key(None, 1, 1), True)
+        if stats is None:
+            y = self.ff.forward_ln(h, self.ff_norm, h)       # (the 20x32 level: LayerNorm + GEGLU projection as one launch)
+            if y is not None:
+                return y
         hidden_states, n = self.ff_norm.skip(h, defer=True)
         return self.ff(n, residual=hidden_states)
 

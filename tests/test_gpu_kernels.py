@@ -1739,6 +1739,35 @@ def _temporal_block_reference(h, gamma, beta, pe, eps, wqkv, wout, bout, heads, 
     return F.linear(o, wout, bout) + h
 
 
+@pytest.mark.parametrize("M,cff", [(80, 320), (20480, 2560), (240, 640)])
+def test_geglu_ln_direct_640(K, M, cff):
+    """`fmc_geglu640_ln_bf16`: LayerNorm + GEGLU projection with the A operand resident in LDS and the (value / gate row-permuted) weight streamed in
+    fragment order; against fp32 (max norm), the same with the kernel's rounding points (element-wise bf16 bound), and deterministic."""
+    dtype = torch.bfloat16
+    C = 640
+    ho, hd = rnd((M, C), 1, dtype, scale=1.5, shift=0.2)
+    go, _ = rnd((C,), 2, torch.float32, scale=0.3, shift=1.0)
+    bo, _ = rnd((C,), 3, torch.float32, scale=0.2)
+    wo, wd = rnd((2 * cff, C), 4, dtype, scale=C ** -0.5)
+    bio, bid = rnd((2 * cff,), 5, dtype, scale=0.3)
+    out = K.geglu_ln_direct(hd, go.cuda(), bo.cuda(), 1e-5, K.pack_geglu_frag80(wd), bid, cff)
+
+    def reference(round_bf16):
+        r = (lambda t: t.bfloat16().float()) if round_bf16 else (lambda t: t)
+        n = r(F.layer_norm(ho, (C,), go, bo, 1e-5))
+        y = F.linear(n, wo, bio)
+        return y[:, :cff] * F.gelu(y[:, cff:])
+    ref_r, ref_f = reference(True), reference(False)
+    assert rel_inf(out.float(), ref_f) < 2e-2
+    err = (out.float().cpu() - ref_r).abs()                # (a bf16 flip of a normalised element moves a product by 2^-8 |n w|: absolute slack next to the relative bound)
+    bound = 2.0 ** -8 * ref_r.abs() + 0.02
+    assert not bool((err > bound).any()), f"{int((err > bound).sum())} / {err.numel()} beyond the bound, worst {float((err - bound).max()):.3e}"
+    assert torch.equal(out, K.geglu_ln_direct(hd, go.cuda(), bo.cuda(), 1e-5, K.pack_geglu_frag80(wd), bid, cff))
+    out_nb = K.geglu_ln_direct(hd, go.cuda(), bo.cuda(), 1e-5, K.pack_geglu_frag80(wd), None, cff)
+    y = F.linear(F.layer_norm(ho, (C,), go, bo, 1e-5), wo)
+    assert rel_inf(out_nb.float(), y[:, :cff] * F.gelu(y[:, cff:])) < 2e-2
+
+
 @pytest.mark.parametrize("B,Fr,hw,S", [(1, 1, 160, 77), (2, 16, 2560, 77), (3, 2, 320, 80), (2, 3, 160, 5)])
 def test_xattn_block_fused_320(K, B, Fr, hw, S):
     """`fmc_xattn_block320_bf16` + `fmc_xattn_pack_kv40`: the text cross-attention block at the 40x64 level (C = 320, 8 heads x 40) on the 160-row
