@@ -469,6 +469,9 @@ int fmc_xattn_pack_kv40(const void* kv, void* out, int batch, int S, int64_t ld_
  *   h bf16 [M][640], M % 80 == 0; out bf16 [M][cff] row-major, cff % 320 == 0; bias bf16 [2 cff] (value | gate) or NULL. */
 int fmc_geglu640_ln_bf16(const void* h, void* out, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* w_packed, const void* bias,
                          int64_t M, int cff, void* stream);
+/* The same at the 40x64 level: h bf16 [M][320], cff % 160 == 0; 4 waves and 77 KiB of LDS per workgroup, two workgroups per CU. */
+int fmc_geglu320_ln_bf16(const void* h, void* out, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* w_packed, const void* bias,
+                         int64_t M, int cff, void* stream);
 /* Diagnostic: `buf` = device buffer of [workgroups][4][8] int64 that receives s_memrealtime stamps (100 MHz) of wave 0 at the phase boundaries of
  * its first four tiles (tools/scratch/r04/probe_tb.py); NULL switches the stamps off (default). */
 int fmc_temporal_block_set_debug(void* buf);

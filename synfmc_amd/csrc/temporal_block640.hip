@@ -527,44 +527,47 @@ struct G6Params {
     int64_t M; int cff;
 };
 
-__global__ __launch_bounds__(512, 2)
-void geglu640_kernel(const G6Params P) {
+template <int GC_>                                          // GC_ = 640 (8 waves, one tile per CU) | 320 (4 waves, 80 KiB: two workgroups per CU)
+__global__ __launch_bounds__(GC_ / 80 * 64, 2)
+void geglu_direct_kernel(const G6Params P) {
+    constexpr int C = GC_, NW = C / 80, NT = 64 * NW, CPR = C / 8, KS = C / 32, GCOLS = 40 * NW, LPR = CPR / 10, WAVE_W = KS * 5 * 512;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* X = reinterpret_cast<bf16_t*>(smem_raw);             // [80][640], chunk c of row r at chunk c ^ ((r >> 1) & 7)
-    bf16_t* S = X + T6_X_ELEMS;                                  // staging [80][328] (52.5 KiB); phase A: (mean, rstd) x 80 rows
+    bf16_t* S = X + T6_ROWS * C;                                 // staging [80][GCOLS + 8]; phase A: (mean, rstd) x 80 rows
     float* stats = reinterpret_cast<float*>(S);
-    constexpr int SP = 328;
+    constexpr int SP = GCOLS + 8;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
     const int xsw = (l15 >> 1) & 7;
     const int64_t m0 = (int64_t)blockIdx.x * T6_ROWS;
-    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)P.h, 0, (int)(P.M * T6_C * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)P.h, 0, (int)(P.M * C * 2), 0x00020000);
     // ---- phase A: rows -> X, LayerNorm in place ----
 #pragma unroll
     for (int j = 0; j < 13; ++j) {
-        const int q = wave + 8 * j;
-        if (q < 100) {
-            const int idx = 64 * q + lane, r = idx / T6_CPR, pc = idx - r * T6_CPR, c = pc ^ ((r >> 1) & 7);
-            t6_dma(rsH, (unsigned)(((m0 + r) * T6_C + c * 8) * 2), X + 64 * q * 8);
+        const int q = wave + NW * j;
+        if (q < T6_ROWS * CPR / 64) {
+            const int idx = 64 * q + lane, r = idx / CPR, pc = idx - r * CPR, c = pc ^ ((r >> 1) & 7);
+            t6_dma(rsH, (unsigned)(((m0 + r) * C + c * 8) * 2), X + 64 * q * 8);
         }
     }
     T6_VMCNT0();
     __syncthreads();
 #pragma unroll 1
-    for (int r = tid >> 3; r < T6_ROWS; r += 64) {
-        const int q = tid & 7;
-        const bf16_t* xr = X + r * T6_C;
+    for (int r = tid / LPR; r < T6_ROWS; r += 64) {
+        const int q = tid % LPR;
+        const bf16_t* xr = X + r * C;
         u32x4 x4[10];
         float s1 = 0.f;
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
-            x4[i] = *reinterpret_cast<const u32x4*>(xr + (q + 8 * i) * 8);
+            x4[i] = *reinterpret_cast<const u32x4*>(xr + (q + LPR * i) * 8);
 #pragma unroll
             for (int j = 0; j < 4; ++j) s1 += __uint_as_float(x4[i][j] << 16) + __uint_as_float(x4[i][j] & 0xffff0000u);
         }
-        s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
-        const float mean = s1 * (1.f / 640.f);
+        s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2);
+        if (LPR == 8) s1 += __shfl_xor(s1, 4);
+        const float mean = s1 * (1.f / C);
         float s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < 10; ++i)
@@ -573,17 +576,18 @@ void geglu640_kernel(const G6Params P) {
                 const float a = __uint_as_float(x4[i][j] << 16) - mean, b = __uint_as_float(x4[i][j] & 0xffff0000u) - mean;
                 s2 += a * a + b * b;
             }
-        s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4);
-        if (q == 0) *reinterpret_cast<f32x2_t*>(stats + 2 * r) = f32x2_t{mean, rsqrtf(s2 * (1.f / 640.f) + P.ln_eps)};
+        s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2);
+        if (LPR == 8) s2 += __shfl_xor(s2, 4);
+        if (q == 0) *reinterpret_cast<f32x2_t*>(stats + 2 * r) = f32x2_t{mean, rsqrtf(s2 * (1.f / C) + P.ln_eps)};
     }
     __syncthreads();
-    if (tid < 480) {
-        const int nc = tid % 80, nrg = tid / 80;
+    if (tid < CPR * 6) {
+        const int nc = tid % CPR, nrg = tid / CPR;
         const f32x4 g0 = *reinterpret_cast<const f32x4*>(P.ln_gamma + nc * 8), g1 = *reinterpret_cast<const f32x4*>(P.ln_gamma + nc * 8 + 4);
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(P.ln_beta + nc * 8), b1 = *reinterpret_cast<const f32x4*>(P.ln_beta + nc * 8 + 4);
 #pragma unroll 2
         for (int r = nrg; r < T6_ROWS; r += 6) {
-            u32x4* px = reinterpret_cast<u32x4*>(X + r * T6_C + (nc ^ ((r >> 1) & 7)) * 8);
+            u32x4* px = reinterpret_cast<u32x4*>(X + r * C + (nc ^ ((r >> 1) & 7)) * 8);
             const u32x4 x4 = *px;
             const f32x2_t st = *reinterpret_cast<const f32x2_t*>(stats + 2 * r);
             const float m = st[0], rs = st[1];
@@ -598,10 +602,10 @@ void geglu640_kernel(const G6Params P) {
     __syncthreads();                                              // X = LayerNorm(h); the staging region is free
 
     f32x4 acc[5][5];
-    const int nchunks = P.cff / 320;
+    const int nchunks = P.cff / GCOLS;
 #pragma unroll 1
     for (int ch = 0; ch < nchunks; ++ch) {
-        const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(P.w + ((size_t)ch * 8 + wave) * T6_WAVE_W), 0, T6_WAVE_W * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(P.w + ((size_t)ch * NW + wave) * WAVE_W), 0, WAVE_W * 2, 0x00020000);
         int wl = lane * 16;
         asm volatile("" : "+v"(wl));
         u32x4 wfr[3][5];
@@ -617,18 +621,18 @@ void geglu640_kernel(const G6Params P) {
             for (int b = 0; b < 5; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
         auto step = [&](auto gc) {
             constexpr int g = decltype(gc)::value;
-            if constexpr (g + 2 < 20) load_w(g + 2);
-            int kqx = kq ^ xsw, xrow_o = l15 * T6_C;
+            if constexpr (g + 2 < KS) load_w(g + 2);
+            int kqx = kq ^ xsw, xrow_o = l15 * C;
             asm volatile("" : "+v"(kqx), "+v"(xrow_o));
             const int xo = xrow_o + ((g >> 1) * 8 + (((g & 1) * 4) ^ kqx)) * 8;
             __builtin_amdgcn_sched_barrier(0);
             u32x4 af3[3];
-            af3[0] = *reinterpret_cast<const u32x4*>(X + 0 * 16 * T6_C + xo);
-            af3[1] = *reinterpret_cast<const u32x4*>(X + 1 * 16 * T6_C + xo);
+            af3[0] = *reinterpret_cast<const u32x4*>(X + 0 * 16 * C + xo);
+            af3[1] = *reinterpret_cast<const u32x4*>(X + 1 * 16 * C + xo);
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
             for (int mb = 0; mb < 5; ++mb) {
-                if (mb + 2 < 5) af3[(mb + 2) % 3] = *reinterpret_cast<const u32x4*>(X + (mb + 2) * 16 * T6_C + xo);
+                if (mb + 2 < 5) af3[(mb + 2) % 3] = *reinterpret_cast<const u32x4*>(X + (mb + 2) * 16 * C + xo);
                 union { bf16x8 v; u32x4 u; } a;
                 a.u = af3[mb % 3];
 #pragma unroll
@@ -643,11 +647,11 @@ void geglu640_kernel(const G6Params P) {
         };
 #define G6_G(G) step(std::integral_constant<int, G>{})
         G6_G(0); G6_G(1); G6_G(2); G6_G(3); G6_G(4); G6_G(5); G6_G(6); G6_G(7); G6_G(8); G6_G(9);
-        G6_G(10); G6_G(11); G6_G(12); G6_G(13); G6_G(14); G6_G(15); G6_G(16); G6_G(17); G6_G(18); G6_G(19);
+        if constexpr (KS == 20) { G6_G(10); G6_G(11); G6_G(12); G6_G(13); G6_G(14); G6_G(15); G6_G(16); G6_G(17); G6_G(18); G6_G(19); }
 #undef G6_G
         T6_SETTLE();
         // ---- gate: my 40 gated columns gc0 .. gc0 + 39 of this chunk ----
-        const int gc0 = ch * 320 + wave * 40;
+        const int gc0 = ch * GCOLS + wave * 40;
         float bv[3][4], bg[3][4];
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
@@ -683,13 +687,13 @@ void geglu640_kernel(const G6Params P) {
             }
         }
         __syncthreads();
-        // ---- whole-row stores: 80 rows x 40 sixteen-byte chunks = 6.25 per thread ----
+        // ---- whole-row stores: 80 rows x GCOLS / 8 sixteen-byte chunks = 6.25 per thread ----
 #pragma unroll
         for (int it = 0; it < 7; ++it) {
-            const int c = tid + 512 * it;
-            if (it < 6 || tid < 128) {
-                const int r = c / 40, cc = c - r * 40;
-                *reinterpret_cast<u32x4*>(P.out + (m0 + r) * (int64_t)P.cff + ch * 320 + cc * 8) = *reinterpret_cast<const u32x4*>(S + r * SP + cc * 8);
+            const int c = tid + NT * it;
+            if (it < 6 || tid < NT / 4) {
+                const int r = c / (GCOLS / 8), cc = c - r * (GCOLS / 8);
+                *reinterpret_cast<u32x4*>(P.out + (m0 + r) * (int64_t)P.cff + ch * GCOLS + cc * 8) = *reinterpret_cast<const u32x4*>(S + r * SP + cc * 8);
             }
         }
         __syncthreads();                                          // the staging region is free again
@@ -816,10 +820,33 @@ extern "C" int fmc_geglu640_ln_bf16(const void* h, void* out, const float* ln_ga
     P.w = (const bf16_t*)w_packed; P.bias = (const bf16_t*)bias; P.M = M; P.cff = cff;
     static bool raised = false;
     if (!raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&geglu640_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, T6_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&geglu_direct_kernel<640>), hipFuncAttributeMaxDynamicSharedMemorySize, T6_LDS);
         raised = true;
     }
-    hipLaunchKernelGGL(geglu640_kernel, dim3((unsigned)(M / 80)), dim3(512), T6_LDS, (hipStream_t)stream, P);
+    hipLaunchKernelGGL(geglu_direct_kernel<640>, dim3((unsigned)(M / 80)), dim3(512), T6_LDS, (hipStream_t)stream, P);
     FMC_CHECK_LAUNCH("fmc_geglu640_ln_bf16");
+    return 0;
+}
+
+// the same at the 40x64 level: h bf16 [M][320], w_packed = hip_ops.pack_geglu_frag80 of the [2 cff, 320] projection, cff % 160 == 0; 4 waves and 77 KiB of
+// LDS per workgroup, two workgroups per CU
+extern "C" int fmc_geglu320_ln_bf16(const void* h, void* out, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* w_packed, const void* bias,
+                                    int64_t M, int cff, void* stream) {
+    if (!h || !out || !ln_gamma || !ln_beta || !w_packed) FMC_FAIL(FMC_E_NULL, "geglu320_ln_bf16: NULL tensor");
+    if (M <= 0 || M % 80 || cff <= 0 || cff % 160 || M * 320 * 2 >= ((int64_t)1 << 31))
+        FMC_FAIL(FMC_E_SHAPE, "geglu320_ln_bf16: M %% 80 == 0, cff %% 160 == 0 (got M=%lld cff=%d)", (long long)M, cff);
+    if (!fmc_aligned16(h) || !fmc_aligned16(out) || !fmc_aligned16(w_packed) || !fmc_aligned16(ln_gamma) || !fmc_aligned16(ln_beta) || (bias && ((uintptr_t)bias & 7)))
+        FMC_FAIL(FMC_E_ALIGN, "geglu320_ln_bf16: tensors must be 16-byte aligned");
+    G6Params P{};
+    P.h = (const bf16_t*)h; P.out = (bf16_t*)out; P.ln_gamma = ln_gamma; P.ln_beta = ln_beta; P.ln_eps = ln_eps;
+    P.w = (const bf16_t*)w_packed; P.bias = (const bf16_t*)bias; P.M = M; P.cff = cff;
+    constexpr int lds = (80 * 320 + 80 * 168) * 2;
+    static bool raised = false;
+    if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&geglu_direct_kernel<320>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        raised = true;
+    }
+    hipLaunchKernelGGL(geglu_direct_kernel<320>, dim3((unsigned)(M / 80)), dim3(256), lds, (hipStream_t)stream, P);
+    FMC_CHECK_LAUNCH("fmc_geglu320_ln_bf16");
     return 0;
 }

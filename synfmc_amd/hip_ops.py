@@ -1090,36 +1090,42 @@ xattn_block640 = xattn_block
 
 
 GEGLU_DIRECT_640 = os.environ.get("FMC_GEGLU_DIRECT_640", "1") != "0"      # A/B switch: LayerNorm + GEGLU projection of the 20x32 level with the A operand resident
+GEGLU_DIRECT_320 = os.environ.get("FMC_GEGLU_DIRECT_320", "1") != "0"      # ... and of the 40x64 level
 
 
 def pack_geglu_frag80(w: torch.Tensor) -> torch.Tensor:
-    """GEGLU projection `[2 Cff, 640]` (value rows, then gate rows) -> `fmc_geglu640_ln_bf16`'s fragment order: [Cff / 320 chunks][8 waves][20 k-steps]
-    [5 blocks][lane][8]; wave w of chunk c owns gated columns 320 c + 40 w .. + 39, its 80 weight rows ordered [v 0-15 | v 16-31 | v 32-39, g 32-39 |
-    g 0-15 | g 16-31] so that value and gate of a column share a lane in four of the five blocks."""
+    """GEGLU projection `[2 Cff, C]` (value rows, then gate rows; C = 640 | 320) -> `fmc_geglu640_ln_bf16` / `fmc_geglu320_ln_bf16`'s fragment order:
+    [Cff / (40 NW) chunks][NW = C / 80 waves][C / 32 k-steps][5 blocks][lane][8]; wave w of chunk c owns gated columns 40 NW c + 40 w .. + 39, its 80 weight
+    rows ordered [v 0-15 | v 16-31 | v 32-39, g 32-39 | g 0-15 | g 16-31] so that value and gate of a column share a lane in four of the five blocks."""
     two_cff, Kd = w.shape
-    cff = two_cff // 2
-    assert Kd == 640 and cff % 320 == 0
-    base = (torch.arange(cff // 320, device=w.device)[:, None] * 320 + torch.arange(8, device=w.device)[None, :] * 40)[..., None]      # [nc, 8, 1]
+    cff, nw = two_cff // 2, Kd // 80
+    assert Kd in (320, 640) and cff % (40 * nw) == 0
+    nc = cff // (40 * nw)
+    base = (torch.arange(nc, device=w.device)[:, None] * (40 * nw) + torch.arange(nw, device=w.device)[None, :] * 40)[..., None]      # [nc, nw, 1]
     r = torch.arange(16, device=w.device)
-    idx = torch.cat([base + r, base + 16 + r, base + 32 + r[:8], cff + base + 32 + r[:8], cff + base + r, cff + base + 16 + r], -1)    # [nc, 8, 80]
-    wp = w.detach()[idx.reshape(-1)].reshape(cff // 320, 8, 5, 16, Kd // 32, 4, 8)
+    idx = torch.cat([base + r, base + 16 + r, base + 32 + r[:8], cff + base + 32 + r[:8], cff + base + r, cff + base + 16 + r], -1)    # [nc, nw, 80]
+    wp = w.detach()[idx.reshape(-1)].reshape(nc, nw, 5, 16, Kd // 32, 4, 8)
     return wp.permute(0, 1, 4, 2, 5, 3, 6).contiguous().view(-1)
 
 
 def geglu_ln_direct_ok(h: torch.Tensor, weight: torch.Tensor) -> bool:
-    return (GEGLU_DIRECT_640 and h.is_cuda and h.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and h.is_contiguous() and h.shape[-1] == 640
-            and weight.shape[1] == 640 and (weight.shape[0] // 2) % 320 == 0 and (h.numel() // 640) % 80 == 0 and h.numel() * 2 < (1 << 31)
-            and not torch.is_grad_enabled())
+    C = h.shape[-1]
+    if not (h.is_cuda and h.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and h.is_contiguous() and weight.shape[1] == C
+            and (h.numel() // C) % 80 == 0 and h.numel() * 2 < (1 << 31) and not torch.is_grad_enabled()):
+        return False
+    return (GEGLU_DIRECT_640 and C == 640 and (weight.shape[0] // 2) % 320 == 0) or (GEGLU_DIRECT_320 and C == 320 and (weight.shape[0] // 2) % 160 == 0)
 
 
 def geglu_ln_direct(h: torch.Tensor, ln_gamma: torch.Tensor, ln_beta: torch.Tensor, ln_eps: float, w_packed: torch.Tensor, bias: Optional[torch.Tensor],
                     cff: int) -> torch.Tensor:
-    """`GEGLU(LayerNorm(h))` in one launch (`fmc_geglu640_ln_bf16`): `[..., 640] -> [..., cff]`."""
+    """`GEGLU(LayerNorm(h))` in one launch (`fmc_geglu640_ln_bf16` / `fmc_geglu320_ln_bf16`): `[..., C] -> [..., cff]`."""
     _dev(h, ln_gamma, ln_beta, w_packed, bias)
-    M = h.numel() // 640
+    C = h.shape[-1]
+    M = h.numel() // C
     out = torch.empty(*h.shape[:-1], cff, dtype=h.dtype, device=h.device)
-    _lib.check(_lib.load().fmc_geglu640_ln_bf16(h.data_ptr(), out.data_ptr(), ln_gamma.data_ptr(), ln_beta.data_ptr(), float(ln_eps), w_packed.data_ptr(),
-                                                _p(bias), M, cff, _stream()), "fmc_geglu640_ln_bf16")
+    fn = _lib.load().fmc_geglu640_ln_bf16 if C == 640 else _lib.load().fmc_geglu320_ln_bf16
+    _lib.check(fn(h.data_ptr(), out.data_ptr(), ln_gamma.data_ptr(), ln_beta.data_ptr(), float(ln_eps), w_packed.data_ptr(), _p(bias), M, cff, _stream()),
+               "fmc_geglu_ln_bf16")
     return out
 
 

@@ -533,7 +533,8 @@ class FeedForward(nn.Module):
         """`ff(norm(h)) + residual` with LayerNorm + GEGLU projection as one launch where `hip_ops.geglu_ln_direct` exists (the 20x32 level), else None."""
         proj, out = self.net[0], self.net[2]
         w = proj.proj.weight
-        if not K.geglu_ln_direct_ok(h, w) or getattr(h, "_fmc_pending_add", None) is not None or getattr(h, "_fmc_ln", None) is not None:
+        if not K.geglu_ln_direct_ok(h, w) or getattr(h, "_fmc_pending_add", None) is not None or getattr(h, "_fmc_ln", None) is not None \
+                or getattr(h, "_fmc_pending_ln", None) is not None:
             return None
         key = (w.data_ptr(), w._version)
         hit = self.__dict__.get("_geglu_frag")
@@ -602,6 +603,8 @@ class BasicTransformerBlock(nn.Module):
         if h.shape[2] == 640:
             return K.xattn_block(h, c[1], c[2], self.norm2.eps, hit[1], kv, hit[2], attn.to_out[0].bias, attn.scale, per_text)
         # the 40x64 level: the feed-forward's norm3 is applied by its GEGLU projection from the row statistics this launch leaves
+        if K.geglu_ln_direct_ok(h, self.ff.net[0].proj.weight):          # (the feed-forward normalises its input itself: no statistics to leave)
+            return K.xattn_block(h, c[1], c[2], self.norm2.eps, hit[1], kv, hit[2], attn.to_out[0].bias, attn.scale, per_text)
         out, stats = K.xattn_block(h, c[1], c[2], self.norm2.eps, hit[1], kv, hit[2], attn.to_out[0].bias, attn.scale, per_text, stats_eps=self.norm3.eps)
         K.ln_epilogue_calls["emitted"] += 1
         out._fmc_ln = (stats, self.norm3._ln_key(None, 1, 1), True)
@@ -635,11 +638,16 @@ class BasicTransformerBlock(nn.Module):
         if fuse2:                                   # (the fused block normalises its input itself and wants it materialised)
             self.attn1.__dict__["_lazy_res"] = False
             self.attn1.__dict__["_next_ln"] = None
+        ff_direct = not torch.is_grad_enabled() and hidden_states.ndim == 3 and K.geglu_ln_direct_ok(hidden_states, self.ff.net[0].proj.weight)
+        if fuse2:
+            pass
         elif self.attn2 is not None:
             self.attn1.__dict__["_next_ln"] = None if (cfg_expand or torch.is_grad_enabled()) else self.norm2.ln_spec(stats_only=d2)
-            self.attn2.__dict__["_next_ln"] = None if torch.is_grad_enabled() else self.norm3.ln_spec(stats_only=True)
+            self.attn2.__dict__["_next_ln"] = None if (torch.is_grad_enabled() or ff_direct) else self.norm3.ln_spec(stats_only=True)
+            if ff_direct:
+                self.attn2.__dict__["_lazy_res"] = False
         else:
-            self.attn1.__dict__["_next_ln"] = None if (cfg_expand or torch.is_grad_enabled()) else self.norm3.ln_spec(stats_only=True)
+            self.attn1.__dict__["_next_ln"] = None if (cfg_expand or torch.is_grad_enabled() or ff_direct) else self.norm3.ln_spec(stats_only=True)
         # `attn(...) + hidden_states` / `ff(...) + hidden_states`: the residual rides in the output projection's epilogue
         # (`norm.skip`: under autograd, the norm and the residual use of its input are one node -- hip_ops.layernorm_skip)
         hidden_states, n = self.norm1.skip(hidden_states, defer=d1)

@@ -230,7 +230,8 @@ class TemporalTransformerBlock(nn.Module):
                 assert pose.shape == h.shape, "pose_feature does not match the hidden states"
                 wm, bm = proc.qkv_merge.weight, proc.qkv_merge.bias
                 kw = dict(w_merge_tm=self._merge_packed(proc, wm), pose_term=proc._pose_term(pose, wm, bm, s), merge_scale=s)
-            last = i == n_blocks - 1 and h.shape[-1] == 320     # (row statistics for the feed-forward's LayerNorm-in-GEMM: the 40x64 level only)
+            # (row statistics for the feed-forward's LayerNorm-in-GEMM: the 40x64 level, and only while the feed-forward does not normalise its input itself)
+            last = i == n_blocks - 1 and h.shape[-1] == 320 and not K.geglu_ln_direct_ok(h, self.ff.net[0].proj.weight)
             out = K.temporal_block(h, gamma, bpe, self.norms[i].eps, w_qkv, w_o, attn.to_out[0].bias, attn.scale,
                                    stats_eps=self.ff_norm.eps if last else None, **kw)
             h, stats = out if last else (out, None)

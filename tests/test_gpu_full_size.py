@@ -86,7 +86,9 @@ def test_bench_step_16x320x512_bf16_vs_reference_golden(g6, monkeypatch):
     used_ln = {k: K.ln_epilogue_calls[k] - before_ln[k] for k in before_ln}
     print(f"GroupNorm statistics from producing epilogues: {used}; LayerNorms written by producing epilogues: {used_ln}")
     assert used["consumed"] >= 3 * 15                                        # (3 eager forwards; the 40x64-level single-source GroupNorms)
-    assert used_ln["consumed"] >= 3 * 25 and used_ln["consumed"] == used_ln["emitted"]   # (the 40x64-level LayerNorms; none written in vain)
+    # (the 40x64-level LayerNorms a GEMM epilogue still produces or applies: 10 per forward since the fused temporal / cross-attention blocks and the
+    #  resident-operand GEGLU normalise their own input -- it was 25+ in round 3; none written in vain)
+    assert used_ln["consumed"] >= 3 * 8 and used_ln["consumed"] == used_ln["emitted"]
     assert used_ln.get("materialised", 0) == 0                                             # (no deferred norm had to be materialised after all)
     ref = g6["eps"]
     e = rel_inf(eager, ref)

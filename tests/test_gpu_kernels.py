@@ -1739,12 +1739,11 @@ def _temporal_block_reference(h, gamma, beta, pe, eps, wqkv, wout, bout, heads, 
     return F.linear(o, wout, bout) + h
 
 
-@pytest.mark.parametrize("M,cff", [(80, 320), (20480, 2560), (240, 640)])
-def test_geglu_ln_direct_640(K, M, cff):
-    """`fmc_geglu640_ln_bf16`: LayerNorm + GEGLU projection with the A operand resident in LDS and the (value / gate row-permuted) weight streamed in
+@pytest.mark.parametrize("M,cff,C", [(80, 320, 640), (20480, 2560, 640), (240, 640, 640), (80, 160, 320), (81920, 1280, 320), (400, 480, 320)])
+def test_geglu_ln_direct(K, M, cff, C):
+    """`fmc_geglu640_ln_bf16` / `fmc_geglu320_ln_bf16`: LayerNorm + GEGLU projection with the A operand resident in LDS and the (value / gate row-permuted) weight streamed in
     fragment order; against fp32 (max norm), the same with the kernel's rounding points (element-wise bf16 bound), and deterministic."""
     dtype = torch.bfloat16
-    C = 640
     ho, hd = rnd((M, C), 1, dtype, scale=1.5, shift=0.2)
     go, _ = rnd((C,), 2, torch.float32, scale=0.3, shift=1.0)
     bo, _ = rnd((C,), 3, torch.float32, scale=0.2)
