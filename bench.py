@@ -134,7 +134,7 @@ def synthetic_inputs(rank, device):
 _KERNEL_SOURCES = {"sa40d": ("spatial_attn.hip", "attn_common.h", "common.h"),
                    "temporal": ("temporal_attn.hip", "attn_common.h", "common.h"),
                    "conv": ("gemm_conv.hip", "common.h"),
-                   "proj": ("gemm_conv.hip", "common.h"),
+                   "proj": ("temporal_block640.hip", "gemm_conv.hip", "common.h"),
                    "tblock": ("temporal_block.hip", "common.h"),
                    "tblock640": ("temporal_block640.hip", "common.h")}
 
@@ -229,31 +229,42 @@ def measure_conv_roofline(device, dtype, iters=20):
 
 
 def measure_proj_roofline(device, dtype, iters=20):
-    """One launch of the token-projection kernel family that holds the largest share of the step (round 3: the 160x320 kernels): the
-    GEGLU feed-forward projection of the 20x32 level as the U-Net issues it (`[2F * 640 tokens, 640] x [5120, 640]^T`, gated to 2560
-    columns), through the autotuned front-end, timed like the other roofline launches."""
+    """One launch of the feed-forward input projection of the 20x32 level as the U-Net issues it since round 4: LayerNorm + GEGLU projection
+    `[2F * 640 tokens, 640] x [5120, 640]^T` gated to 2560 columns with the A operand resident (`fmc_geglu640_ln_bf16`); where that kernel does not apply
+    (other widths) the 160x320 GEGLU kernel through the autotuned front-end.  Timed like the other roofline launches."""
     from synfmc_amd import hip_ops as K
     from synfmc_amd.models.layers import interleave_geglu
     M, Kd, N = 2 * FRAMES * (HEIGHT // 16) * (WIDTH // 16), WIDTHS[1], 8 * WIDTHS[1]
     x = torch.randn(M, Kd, device=device, dtype=dtype)
     w = torch.randn(N, Kd, device=device, dtype=dtype) * Kd ** -0.5
     b = torch.randn(N, device=device, dtype=dtype)
-    w32, b32 = interleave_geglu(w, b)
-    w8, b8 = interleave_geglu(w, b, 8)
+    with torch.no_grad():
+        direct = K.geglu_ln_direct_ok(x, w)
+    if direct:
+        g, beta, wp = torch.randn(Kd, device=device) * 0.2 + 1, torch.randn(Kd, device=device), K.pack_geglu_frag80(w)
+        def run():
+            with torch.no_grad():
+                return K.geglu_ln_direct(x, g, beta, 1e-5, wp, b, N // 2)
+        arm = "direct"
+    else:
+        w32, b32 = interleave_geglu(w, b)
+        w8, b8 = interleave_geglu(w, b, 8)
+        run = lambda: K.geglu_linear(x, w, b, w32, b32, w8, b8)
     for _ in range(3):
-        K.geglu_linear(x, w, b, w32, b32, w8, b8)
-    arm = K._choice.get(("geglu", M, N, Kd))
+        run()
+    if not direct:
+        arm = K._choice.get(("geglu", M, N, Kd))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        K.geglu_linear(x, w, b, w32, b32, w8, b8)
+        run()
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * M * N * Kd
     achieved = flops / (ms * 1e-3) / 1e12
-    names = {0: "vendor library + geglu_kernel", 3: "gemm_kernel<256x256,16 waves,GEGLU>", 13: "gemm8_kernel<256x256,8-phase,GEGLU>",
-             512: "gemm160p_kernel<160x320 persistent,GEGLU>"}
+    names = {"direct": "geglu_direct_kernel<640> (LayerNorm + GEGLU projection, A resident, weights in fragment order)", 0: "vendor library + geglu_kernel",
+             3: "gemm_kernel<256x256,16 waves,GEGLU>", 13: "gemm8_kernel<256x256,8-phase,GEGLU>", 512: "gemm160p_kernel<160x320 persistent,GEGLU>"}
     out = {"bound": "mfma", "kernel": f"{names.get(arm, f'fmc_linear_bf16 arm {arm}')} [{M}x{N}x{Kd}]", "autotuned_arm": arm,
            "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
            "avg_launch_ms": round(ms, 4), "flops_per_launch": flops, "traffic_algorithmic": 2.0 * (M * Kd + N * Kd + M * N // 2)}

@@ -36,7 +36,7 @@ def which(name):
         return "tblock"
     if "gemm8_kernel<1" in name or "gemm_kernel<1" in name or "gemm160_kernel<1" in name:
         return "conv"
-    if "gemm160p_kernel" in name or "gemm160_kernel<0" in name or "gemm8_kernel<0" in name or "gemm_kernel<0" in name:
+    if "geglu_direct_kernel" in name or "gemm160p_kernel" in name or "gemm160_kernel<0" in name or "gemm8_kernel<0" in name or "gemm_kernel<0" in name:
         return "proj"
     return None
 
