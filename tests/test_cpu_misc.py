@@ -517,3 +517,47 @@ def test_two_rank_gloo_step_orderings_agree(tmp_path):
     o = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert o["ranks_equal"] and len(set(o["digests"])) == 1, o
     assert o["n_unused"] == [2, 2, 2]
+
+
+def test_fragment_order_weight_packers():
+    """Host logic of the fused kernels' weight formats (no GPU): every packed element sits where the kernel's fragment addressing reads it.
+    A fragment = one 16-row block x one 32-deep k-step = [lane = 16 * (k chunk of 8) + row][8]; streams are [wave | head][k-step][block]."""
+    import torch
+    from synfmc_amd import hip_ops as K
+    g = torch.Generator().manual_seed(0)
+
+    def frag(packed, off, lane, e):               # element e of lane's 16 bytes in the fragment starting at element offset `off`
+        return packed[off + lane * 8 + e]
+
+    # pack_w_frag80: wave w owns rows 80 w ..; fragment (w, g, nb) at ((w * KS + g) * 5 + nb) * 512
+    for C in (640,):
+        w = torch.randn(C, C, generator=g)
+        p = K.pack_w_frag80(w)
+        KS = C // 32
+        for (wv, ks, nb, lane, e) in [(0, 0, 0, 0, 0), (C // 80 - 1, KS - 1, 4, 63, 7), (1, 3, 2, 37, 5)]:
+            row, kq = lane & 15, lane >> 4
+            assert frag(p, ((wv * KS + ks) * 5 + nb) * 512, lane, e) == w[80 * wv + 16 * nb + row, 32 * ks + 8 * kq + e]
+    # pack_temporal_qkv80: head h, part (q | k | v), k-step, block
+    w = torch.randn(3 * 640, 640, generator=g)
+    p = K.pack_temporal_qkv80(w)
+    for (h, part, ks, nb, lane, e) in [(0, 0, 0, 0, 0, 0), (7, 2, 19, 4, 63, 7), (3, 1, 5, 2, 21, 3)]:
+        row, kq = lane & 15, lane >> 4
+        off = h * 3 * 51200 + part * 51200 + (ks * 5 + nb) * 512
+        assert frag(p, off, lane, e) == w[part * 640 + 80 * h + 16 * nb + row, 32 * ks + 8 * kq + e]
+    # pack_xattn_q40: per head [10 k-steps][q0 | q1 | (q tail, zeros)]
+    w = torch.randn(320, 320, generator=g)
+    p = K.pack_xattn_q40(w)
+    for (h, ks, nb, lane, e) in [(0, 0, 0, 0, 0), (7, 9, 1, 63, 7), (2, 4, 2, 5, 6), (2, 4, 2, 13, 6)]:
+        row, kq = lane & 15, lane >> 4
+        want = w[40 * h + 16 * nb + row, 32 * ks + 8 * kq + e] if 16 * nb + row < 40 else 0.0
+        assert frag(p, h * 15360 + (ks * 3 + nb) * 512, lane, e) == want
+    # pack_geglu_frag80: chunk c, wave wv: rows [v 0-15 | v 16-31 | v 32-39, g 32-39 | g 0-15 | g 16-31] of gated columns 40 NW c + 40 wv ..
+    for C, cff in ((640, 640), (320, 320)):
+        w = torch.randn(2 * cff, C, generator=g)
+        p = K.pack_geglu_frag80(w)
+        NW, KS = C // 80, C // 32
+        for (c, wv, ks, nb, lane, e) in [(0, 0, 0, 0, 0, 0), (cff // (40 * NW) - 1, NW - 1, KS - 1, 4, 63, 7), (1, 1, 2, 2, 3, 1), (1, 1, 2, 2, 11, 1), (0, 2, 1, 3, 40, 2)]:
+            row, kq = lane & 15, lane >> 4
+            base = 40 * NW * c + 40 * wv
+            src = [base + row, base + 16 + row, (base + 32 + row) if row < 8 else (cff + base + 32 + row - 8), cff + base + row, cff + base + 16 + row][nb]
+            assert frag(p, (((c * NW + wv) * KS + ks) * 5 + nb) * 512, lane, e) == w[src, 32 * ks + 8 * kq + e]
