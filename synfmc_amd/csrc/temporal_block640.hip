@@ -603,18 +603,25 @@ void geglu_direct_kernel(const G6Params P) {
 
     f32x4 acc[5][5];
     const int nchunks = P.cff / GCOLS;
+    // one descriptor over the whole packed weight; the chunk's first two k-steps are requested BEFORE the previous chunk's gating / staging / stores
+    // (the fragment registers are idle there: requested at the head of a chunk their L2 round trip was exposed once per chunk)
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)P.w, 0, (int)((int64_t)2 * P.cff * C * 2), 0x00020000);
+    u32x4 wfr[3][5];
+    int wl = 0;
+    auto load_w = [&](int g) {
+#pragma unroll
+        for (int nb = 0; nb < 5; ++nb) wfr[g % 3][nb] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wl, (g * 5 + nb) * 1024, 0);
+    };
+    auto chunk_base = [&](int ch) {
+        int v = lane * 16 + (ch * NW + wave) * (WAVE_W * 2);
+        asm volatile("" : "+v"(v));
+        return v;
+    };
+    wl = chunk_base(0);
+    load_w(0);
+    load_w(1);
 #pragma unroll 1
     for (int ch = 0; ch < nchunks; ++ch) {
-        const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(P.w + ((size_t)ch * NW + wave) * WAVE_W), 0, WAVE_W * 2, 0x00020000);
-        int wl = lane * 16;
-        asm volatile("" : "+v"(wl));
-        u32x4 wfr[3][5];
-        auto load_w = [&](int g) {
-#pragma unroll
-            for (int nb = 0; nb < 5; ++nb) wfr[g % 3][nb] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wl, (g * 5 + nb) * 1024, 0);
-        };
-        load_w(0);
-        load_w(1);
 #pragma unroll
         for (int a = 0; a < 5; ++a)
 #pragma unroll
@@ -650,7 +657,8 @@ void geglu_direct_kernel(const G6Params P) {
         if constexpr (KS == 20) { G6_G(10); G6_G(11); G6_G(12); G6_G(13); G6_G(14); G6_G(15); G6_G(16); G6_G(17); G6_G(18); G6_G(19); }
 #undef G6_G
         T6_SETTLE();
-        // ---- gate: my 40 gated columns gc0 .. gc0 + 39 of this chunk ----
+        // ---- gate: my 40 gated columns gc0 .. gc0 + 39 of this chunk (the bias first: its loads must be OLDER than the weight prefetch below, or waiting
+        //      for them waits for the prefetch too) ----
         const int gc0 = ch * GCOLS + wave * 40;
         float bv[3][4], bg[3][4];
 #pragma unroll
@@ -664,6 +672,13 @@ void geglu_direct_kernel(const G6Params P) {
                 for (int j = 0; j < 4; ++j) bv[p][j] = bg[p][j] = 0.f;
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ch + 1 < nchunks) {                                   // the next chunk's first two k-steps (stages 0, 1: the loop's last steps have left them)
+            wl = chunk_base(ch + 1);
+            load_w(0);
+            load_w(1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mb = 0; mb < 5; ++mb) {
             bf16_t* Sr = S + (mb * 16 + l15) * SP + wave * 40;
