@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04f2; mkdir -p $O
+O=gpurun_out/r04f5; mkdir -p $O
 export FMC_AUTOTUNE_CACHE=$PWD/$O/autotune_cache.json
 timeout 2400 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -4 $O/pytest.log
 timeout 1500 python tools/collect_roofline_counters.py > $O/counters.log 2>&1; cp gpurun_out/roofline_counters.json profiles/roofline_counters.json; cp gpurun_out/roofline_counters.json $O/
