@@ -22,6 +22,16 @@ void fmc_set_error(const char* fmt, ...);
         if (e__ != hipSuccess) FMC_FAIL(FMC_E_LAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
     } while (0)
 
+// ---- per-device host state -------------------------------------------------------------------------
+// A process may drive several GPUs: the CU count and the "dynamic-LDS attribute raised" flags are kept per device id.
+int fmc_device();                 // the calling thread's current device (0 when the runtime cannot say)
+int fmc_cu_count();               // compute units of that device, looked up once per device
+struct FmcPerDeviceFlag {         // `static FmcPerDeviceFlag raised; if (!raised) { ...; raised = true; }` -- once per device, not per process
+    unsigned long long mask = 0;
+    bool operator!() const { return !((mask >> (fmc_device() & 63)) & 1ull); }
+    FmcPerDeviceFlag& operator=(bool v) { if (v) mask |= 1ull << (fmc_device() & 63); return *this; }
+};
+
 static inline bool fmc_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- vector / fragment types ---------------------------------------------------------------------

@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <hip/hip_runtime.h>
+
 #include "../../include/fmc_hip.h"
 
 static thread_local char g_err[512] = "";
@@ -15,3 +17,19 @@ void fmc_set_error(const char* fmt, ...) {
 
 extern "C" int fmc_version(void) { return FMC_VERSION; }
 extern "C" const char* fmc_last_error(void) { return g_err; }
+
+int fmc_device() {
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess && dev >= 0 ? dev : 0;
+}
+
+int fmc_cu_count() {
+    static int n[64] = {0};
+    const int dev = fmc_device() & 63;
+    if (!n[dev]) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        n[dev] = cus;
+    }
+    return n[dev];
+}

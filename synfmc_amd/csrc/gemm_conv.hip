@@ -2238,17 +2238,6 @@ void gemm160p_kernel(const GemmParams P) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the requests past my last tile: out of range, zeros into the scratch KiB / dead buffers)
 }
 
-int fmc_cu_count() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
-
 int gemm_geometry_override() {   // FMC_GEMM_TILE = 0 (caller's choice) | 1..10: see fmc_hip.h
     static int v = -1;
     if (v < 0) {
@@ -2460,7 +2449,7 @@ void launch_gemm8(GemmParams& P, hipStream_t st) {
     constexpr size_t ring = (size_t)2 * 512 * 64 * sizeof(bf16_t) + 1024;
     constexpr size_t staged = (size_t)256 * ((EPI != 0 ? 128 : 256) + 8) * sizeof(bf16_t);
     constexpr size_t lds = staged > ring ? staged : ring;
-    static bool raised = false;
+    static FmcPerDeviceFlag raised;
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_kernel<MODE, EPI, PF, 0>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2747,7 +2736,7 @@ void launch_gemm_k320_c(GemmParams& P, hipStream_t st) {
     const int per_cu = MI * NI == 1 ? 3 : (MI * NI == 2 ? 2 : 1);
     const int tiles = (int)(P.M / (32 * MI)), slots = fmc_cu_count() * per_cu;
     dim3 grid((unsigned)(tiles < slots ? tiles : slots), (unsigned)(P.N / (160 * NI)));
-    static bool raised = false;
+    static FmcPerDeviceFlag raised;
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_k320_kernel<MI, NI, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_k320_kernel<MI, NI, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2784,7 +2773,7 @@ void launch_gemm160(GemmParams& P, hipStream_t st) {
     }
     constexpr size_t lds = (size_t)5 * (160 + 320) * 32 * sizeof(bf16_t) + 1024;          // five sub-tile buffers + the dummies' KiB
     static_assert(lds >= (size_t)160 * 328 * 2 && lds >= (size_t)160 * 164 * 4, "epilogue staging fits the operand buffers");
-    static bool raised = false;
+    static FmcPerDeviceFlag raised;
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm160_kernel<MODE, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         raised = true;
@@ -2804,7 +2793,7 @@ void launch_gemm160(GemmParams& P, hipStream_t st) {
         // (FMC_G160_PERSIST=2: also launches of exactly one round -- tiles == CUs, the level-1 N = 640 projections -- A/B switch)
         if (persist && !P.f32io && P.M % 160 == 0 && (persist == 2 ? P.tiles_m * P.tiles_n >= cus : P.tiles_m * P.tiles_n > cus) && cus >= 8) {
             constexpr size_t ldsp = (size_t)3 * (160 + 320) * 32 * sizeof(bf16_t) + 1024 + (EPI == 1 ? (size_t)160 * 168 * 2 + 4096 : (size_t)80 * 328 * 2 + 5120);
-            static bool raisedp = false;
+            static FmcPerDeviceFlag raisedp;
             if (!raisedp) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm160p_kernel<EPI, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm160p_kernel<EPI, 5, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
@@ -2855,7 +2844,7 @@ void launch_gemm256p(GemmParams& P, hipStream_t st) {
     }
     constexpr size_t ldsp = (size_t)3 * (256 + 320) * 32 * sizeof(bf16_t) + 1024 + (size_t)128 * 168 * 2;
     static_assert(ldsp <= 160 * 1024, "ring + staging fit the LDS");
-    static bool raised = false;
+    static FmcPerDeviceFlag raised;
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm160p_kernel<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
         raised = true;

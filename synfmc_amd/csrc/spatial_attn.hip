@@ -1058,7 +1058,7 @@ inline void launch_xattn40(const SAParams& P, hipStream_t st) {
     if (per < 1) per = 1;
     if (per > units) per = units;
     const size_t lds = (size_t)8 * 96 * XA_VP * 2;
-    static bool raised = false;
+    static FmcPerDeviceFlag raised;
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn40_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         raised = true;
@@ -1105,7 +1105,7 @@ void launch_sa_v(const SAParams& Pin, hipStream_t st) {
     const size_t lds = sizeof(T) * ((size_t)SA_BK * (NKS * 16 + 8) + (VR ? (size_t)SA_BK * sa_vr_pitch<NDT>() : (size_t)NDT * 32 * (SA_BK + 4)));
     dim3 grid((unsigned)(P.B * P.H * P.nqblk)), block(64 * SA_WAVES);
     if (lds > 64 * 1024) {  // gfx950 has 160 KiB of LDS per CU; opting in is needed above 64 KiB
-        static bool raised = false;
+        static FmcPerDeviceFlag raised;
         if (!raised) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_attn_kernel<T, NKS, SHORT_KV, PF, NQ, MK, VR>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

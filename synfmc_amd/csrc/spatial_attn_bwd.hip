@@ -323,7 +323,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_dkdv_kernel(const SABwdParams
 }
 
 template <typename K>
-void raise_lds(K kernel, size_t lds, bool& raised) {
+void raise_lds(K kernel, size_t lds, FmcPerDeviceFlag& raised) {
     if (lds > 64 * 1024 && !raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         raised = true;
@@ -344,7 +344,7 @@ void launch_bwd(SABwdParams P, hipStream_t st) {
     }
     {
         const size_t lds = sizeof(T) * ((size_t)2 * BK2 * KP + (size_t)NDT * 32 * VP);
-        static bool raised = false;
+        static FmcPerDeviceFlag raised;
         raise_lds(&attn_dq_kernel<T, NKS>, lds, raised);
         P.nblk = (P.Sq + 127) / 128;
         P.xcd = (P.B % 8 == 0 && !getenv("FMC_SAB_XCD0")) ? 1 : 0;
@@ -354,7 +354,7 @@ void launch_bwd(SABwdParams P, hipStream_t st) {
         constexpr int BKV = 32 * WAVES;
         const size_t lds = sizeof(T) * ((size_t)2 * BKV * KP + (size_t)2 * BQ * KP + (size_t)2 * NDT * 32 * (BQ + 4)) +
                            2 * BQ * sizeof(float);
-        static bool raised = false;
+        static FmcPerDeviceFlag raised;
         raise_lds(&attn_dkdv_kernel<T, NKS, WAVES, BQ>, lds, raised);
         P.nblk = (P.Skv + BKV - 1) / BKV;
         const int bkv = P.B / P.kv_batch_div;

@@ -694,7 +694,7 @@ void launch_ta_bwd(const TABwdParams& P, hipStream_t st) {
     const int CW = P.GH * P.D;
     const size_t lds = sizeof(T) * 7 * (size_t)(FT * 16) * (CW + 8);
     if (lds > 64 * 1024) {
-        static bool raised = false;
+        static FmcPerDeviceFlag raised;
         if (!raised) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_attn_bwd_kernel<T, FT, NK32>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -727,7 +727,7 @@ void launch_ta(const TAParams& P, hipStream_t st) {
     auto go = [&](auto nw) {                                          // the waves of a workgroup split the unit's heads
         constexpr int NW = decltype(nw)::value;
         if (lds > 64 * 1024) {
-            static bool raised = false;
+            static FmcPerDeviceFlag raised;
             if (!raised) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_attn_kernel<T, FT, NK32, NW>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -842,7 +842,7 @@ void launch_ta8(const TA8Params& P, hipStream_t st) {
     const int CW = P.GH * P.D;
     const size_t lds = 3 * (size_t)(FT * 16) * (CW + 16) + sizeof(bf16_t) * (size_t)(FT * 16) * (CW + 8);
     if (lds > 64 * 1024) {
-        static bool raised = false;
+        static FmcPerDeviceFlag raised;
         if (!raised) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_attn_fp8_kernel<FT, NK32>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

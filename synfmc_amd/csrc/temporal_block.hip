@@ -749,11 +749,9 @@ extern "C" int fmc_xattn_block320_bf16(const void* h, void* out, const float* ln
     P.tiles = (int)(P.total_rows / TB_ROWS);
     P.scale_log2 = scale * 1.4426950408889634f;
     P.dbg_times = nullptr;
-    int dev = 0, cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    const int cus = fmc_cu_count();
     const unsigned grid = (unsigned)(P.tiles < cus ? P.tiles : cus);
-    static bool raised = false;
+    static FmcPerDeviceFlag raised;
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block_kernel<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS);
@@ -808,12 +806,10 @@ extern "C" int fmc_temporal_block_bf16(const void* h, void* out, const float* ln
     P.total_rows = (int64_t)n_clips * frames * hw;
     P.scale_log2 = scale * 1.4426950408889634f;
     P.dbg_times = g_tb_dbg;
-    int dev = 0, cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    const int cus = fmc_cu_count();
     const unsigned grid = (unsigned)(P.tiles < cus ? P.tiles : cus);
     hipStream_t st = (hipStream_t)stream;
-    static bool raised = false;
+    static FmcPerDeviceFlag raised;
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS);

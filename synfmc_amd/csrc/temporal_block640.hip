@@ -766,7 +766,7 @@ int fmc_temporal_block640_launch(const void* h, void* out, const float* ln_gamma
     P.total_rows = (int64_t)n_clips * T6_F * hw;
     P.scale_log2 = scale * 1.4426950408889634f;
     const unsigned grid = (unsigned)(n_clips * P.tpc);
-    static bool raised = false;
+    static FmcPerDeviceFlag raised;
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block640_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T6_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block640_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T6_LDS);
@@ -801,7 +801,7 @@ extern "C" int fmc_xattn_block640_bf16(const void* h, void* out, const float* ln
     P.total_rows = (int64_t)n_images * hw;
     P.scale_log2 = scale * 1.4426950408889634f;
     const unsigned grid = (unsigned)(P.total_rows / T6_ROWS);
-    static bool raised = false;
+    static FmcPerDeviceFlag raised;
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block640_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T6_LDS);
         raised = true;
@@ -833,7 +833,7 @@ extern "C" int fmc_geglu640_ln_bf16(const void* h, void* out, const float* ln_ga
     G6Params P{};
     P.h = (const bf16_t*)h; P.out = (bf16_t*)out; P.ln_gamma = ln_gamma; P.ln_beta = ln_beta; P.ln_eps = ln_eps;
     P.w = (const bf16_t*)w_packed; P.bias = (const bf16_t*)bias; P.M = M; P.cff = cff;
-    static bool raised = false;
+    static FmcPerDeviceFlag raised;
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&geglu_direct_kernel<640>), hipFuncAttributeMaxDynamicSharedMemorySize, T6_LDS);
         raised = true;
@@ -856,7 +856,7 @@ extern "C" int fmc_geglu320_ln_bf16(const void* h, void* out, const float* ln_ga
     P.h = (const bf16_t*)h; P.out = (bf16_t*)out; P.ln_gamma = ln_gamma; P.ln_beta = ln_beta; P.ln_eps = ln_eps;
     P.w = (const bf16_t*)w_packed; P.bias = (const bf16_t*)bias; P.M = M; P.cff = cff;
     constexpr int lds = (80 * 320 + 80 * 168) * 2;
-    static bool raised = false;
+    static FmcPerDeviceFlag raised;
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&geglu_direct_kernel<320>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         raised = true;

@@ -111,12 +111,25 @@ class LoRAAttnProcessor(nn.Module):
                  pose_feature=None, scale=None, temporal: bool = False, _residual=None):
         _require_frozen(self)
         attn.prepare_attention_mask(attention_mask, 0, 0)
-        s = self.lora_scale if scale is None else scale
+        s = resolve_lora_scale(self, scale)
         shape4 = hidden_states.shape if (hidden_states.ndim == 4 and not temporal) else None
         x = _tok(hidden_states) if not temporal else hidden_states
         out = _attention_core(attn, x, encoder_hidden_states, temporal, lora=self, lora_scale=s,
                               residual=_fusable(attn, _residual, shape4))
         return _finish(attn, out, hidden_states, shape4)
+
+
+_NO_SCALE = object()
+
+
+def resolve_lora_scale(proc, scale=_NO_SCALE) -> float:
+    """The LoRA scale a processor call resolves to -- ONE rule for the un-fused chain and the fused temporal block.
+    `LoRAAttnProcessor.__call__(..., scale=None)` (reference :108-116): `lora_scale` unless a scale is passed;
+    `LORAPoseAdaptorAttnProcessor.__call__(..., scale=1.0)` (reference :337-347): 1.0 unless a scale is passed, `lora_scale` only for an
+    explicit `scale=None`."""
+    if scale is _NO_SCALE:
+        return 1.0 if isinstance(proc, LORAPoseAdaptorAttnProcessor) else proc.lora_scale
+    return proc.lora_scale if scale is None else scale
 
 
 def _require_frozen(proc: nn.Module) -> None:
@@ -235,7 +248,7 @@ class LORAPoseAdaptorAttnProcessor(nn.Module, _PoseMerge):
                  pose_feature=None, temporal: bool = False, _residual=None):
         assert pose_feature is not None
         _require_frozen(self)
-        ls = self.lora_scale if scale is None else scale
+        ls = resolve_lora_scale(self, scale)
         attn.prepare_attention_mask(attention_mask, 0, 0)
         shape4 = hidden_states.shape if (hidden_states.ndim == 4 and not temporal) else None
         x = hidden_states if temporal else _tok(hidden_states)

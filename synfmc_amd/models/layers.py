@@ -430,7 +430,10 @@ class Attention(nn.Module):
                 and not isinstance(processor, nn.Module):
             self._modules.pop("processor")
         self.processor = processor
-        self.__dict__.pop("_fused", None)
+        # the merged projection weights and everything packed from them belong to the old processor (a freed merged tensor's address can come
+        # back with version 0 under the caching allocator: the packed caches also hold their sources alive, see `_fused_tb` / `_fused_xb`)
+        for name in ("_fused", "_fused_tb", "_fused_xb"):
+            self.__dict__.pop(name, None)
 
     def set_use_memory_efficient_attention_xformers(self, *a, **k):
         pass
@@ -582,13 +585,15 @@ class BasicTransformerBlock(nn.Module):
         if isinstance(proc, LoRAAttnProcessor):
             _require_frozen(proc)
             lora = proc
-            s_kw = kw.get("scale")
-            lora_scale = proc.lora_scale if s_kw is None else s_kw
+            from .attention_processor import resolve_lora_scale
+            lora_scale = resolve_lora_scale(proc, kw["scale"]) if "scale" in kw else resolve_lora_scale(proc)
         w_q, w_kv, w_o = attn.fused_weights(lora, lora_scale)
         key = (w_q.data_ptr(), w_q._version, w_o.data_ptr(), w_o._version)
         hit = attn.__dict__.get("_fused_xb")
         if hit is None or hit[0] != key:
-            hit = (key, K.pack_w_frag80(w_q), K.pack_w_frag80(w_o)) if w_q.shape[0] == 640 else (key, K.pack_xattn_q40(w_q, attn.heads), K._w_tilemajor(w_o))
+            # (the entry keeps w_q / w_o alive: an equal data pointer then means the same storage, not a recycled address)
+            hit = ((key, K.pack_w_frag80(w_q), K.pack_w_frag80(w_o), (w_q, w_o)) if w_q.shape[0] == 640
+                   else (key, K.pack_xattn_q40(w_q, attn.heads), K._w_tilemajor(w_o), (w_q, w_o)))
             attn.__dict__["_fused_xb"] = hit
         g, b = f32_param(self.norm2, "weight"), f32_param(self.norm2, "bias")
         ck = (g.data_ptr(), g._version, b.data_ptr(), b._version)

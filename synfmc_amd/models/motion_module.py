@@ -166,6 +166,15 @@ class TemporalTransformerBlock(nn.Module):
                 pf = cross_attention_kwargs.get("pose_feature")
                 if pf is None or not (proc.query_condition and proc.key_value_condition) or proc.qkv_merge.weight.dtype != torch.bfloat16:
                     return False
+                # (what the un-fused `_merge` falls back on -- a pose feature of another dtype or shape -- must fall back here too)
+                if pf.dtype != torch.bfloat16 or not pf.is_cuda:
+                    return False
+                if pf.ndim == 5:
+                    b, c, f, hh, ww = pf.shape
+                    if (b, f, hh * ww, c) != tuple(hidden_states.shape):
+                        return False
+                elif tuple(pf.shape) != tuple(hidden_states.shape):
+                    return False
         return True
 
     def _fused_constants(self, i, frames):
@@ -188,10 +197,12 @@ class TemporalTransformerBlock(nn.Module):
         key = (w_qkv.data_ptr(), w_qkv._version, w_o.data_ptr(), w_o._version)
         hit = attn.__dict__.get("_fused_tb")
         if hit is None or hit[0] != key:
+            # (the entry keeps w_qkv / w_o alive: an equal data pointer then means the same storage, not an address the caching allocator
+            #  handed to the NEXT processor's merged weights; `Attention.set_processor` drops the entry as well)
             if w_o.shape[0] == 640:                      # the 20x32 level: weights in MFMA-fragment order (temporal_block640.hip)
-                hit = (key, K.pack_temporal_qkv80(w_qkv, attn.heads), K.pack_w_frag80(w_o))
+                hit = (key, K.pack_temporal_qkv80(w_qkv, attn.heads), K.pack_w_frag80(w_o), (w_qkv, w_o))
             else:
-                hit = (key, K.pack_temporal_qkv(w_qkv, attn.heads), K._w_tilemajor(w_o))
+                hit = (key, K.pack_temporal_qkv(w_qkv, attn.heads), K._w_tilemajor(w_o), (w_qkv, w_o))
             attn.__dict__["_fused_tb"] = hit
         return hit[1], hit[2]
 
@@ -202,7 +213,7 @@ class TemporalTransformerBlock(nn.Module):
         key = (wm.data_ptr(), wm._version)
         hit = proc.__dict__.get("_fused_wm")
         if hit is None or hit[0] != key:
-            hit = (key, K.pack_w_frag80(wm))
+            hit = (key, K.pack_w_frag80(wm), wm)
             proc.__dict__["_fused_wm"] = hit
         return hit[1]
 
@@ -216,10 +227,11 @@ class TemporalTransformerBlock(nn.Module):
             lora = proc if isinstance(proc, (LoRAAttnProcessor, LORAPoseAdaptorAttnProcessor)) else None
             lora_scale = 1.0
             if lora is not None:
-                from .attention_processor import _require_frozen
+                from .attention_processor import _require_frozen, resolve_lora_scale
                 _require_frozen(proc)
-                s_kw = cross_attention_kwargs.get("scale")
-                lora_scale = proc.lora_scale if s_kw is None else s_kw
+                # the same rule as the un-fused processors' `scale` defaults (a missing kwarg is NOT `lora_scale` for the LoRA + pose processor)
+                lora_scale = (resolve_lora_scale(proc, cross_attention_kwargs["scale"]) if "scale" in cross_attention_kwargs
+                              else resolve_lora_scale(proc))
             gamma, bpe = self._fused_constants(i, frames)
             w_qkv, w_o = self._fused_weights(i, lora, lora_scale)
             kw = {}

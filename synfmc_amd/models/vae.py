@@ -169,17 +169,38 @@ class Encoder(nn.Module):
 class DiagonalGaussianDistribution:
     """diffusers `DiagonalGaussianDistribution(moments)`: mean | logvar along the channel axis, logvar clamped to [-30, 20]."""
 
-    def __init__(self, parameters: torch.Tensor):
+    def __init__(self, parameters: torch.Tensor, deterministic: bool = False):
         self.parameters = parameters
+        self.deterministic = deterministic
         self.mean, logvar = torch.chunk(parameters.float(), 2, dim=1)
         self.logvar = torch.clamp(logvar, -30.0, 20.0)
         self.std = torch.exp(0.5 * self.logvar)
         self.var = torch.exp(self.logvar)
+        if deterministic:
+            self.var = self.std = torch.zeros_like(self.mean)
 
     def sample(self, generator: Optional[torch.Generator] = None) -> torch.Tensor:
-        noise = torch.randn(self.mean.shape, generator=generator, device=self.mean.device if generator is None else generator.device,
-                            dtype=torch.float32).to(self.mean.device)
-        return (self.mean + self.std * noise).to(self.parameters.dtype)
+        """The random stream is diffusers' `randn_tensor(shape, generator, device=parameters.device, dtype=parameters.dtype)`: drawn in the
+        PARAMETERS' dtype (a bf16 model draws bf16 noise), on the generator's device when that is the CPU and the parameters live on the GPU."""
+        p = self.parameters
+        gen_dev = p.device if generator is None else generator.device
+        draw_dev = gen_dev if (gen_dev.type == "cpu" and p.device.type != "cpu") else p.device
+        noise = torch.randn(self.mean.shape, generator=generator, device=draw_dev, dtype=p.dtype).to(p.device)
+        return (self.mean + self.std * noise.float()).to(p.dtype)
+
+    def kl(self, other: "Optional[DiagonalGaussianDistribution]" = None) -> torch.Tensor:
+        if self.deterministic:
+            return torch.zeros(1, device=self.parameters.device)
+        if other is None:
+            return 0.5 * torch.sum(self.mean.pow(2) + self.var - 1.0 - self.logvar, dim=[1, 2, 3])
+        return 0.5 * torch.sum((self.mean - other.mean).pow(2) / other.var + self.var / other.var - 1.0 - self.logvar + other.logvar,
+                               dim=[1, 2, 3])
+
+    def nll(self, sample: torch.Tensor, dims=(1, 2, 3)) -> torch.Tensor:
+        if self.deterministic:
+            return torch.zeros(1, device=self.parameters.device)
+        log2pi = 1.8378770664093453
+        return 0.5 * torch.sum(log2pi + self.logvar + (sample.float() - self.mean).pow(2) / self.var, dim=list(dims))
 
     def mode(self) -> torch.Tensor:
         return self.mean.to(self.parameters.dtype)

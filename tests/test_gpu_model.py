@@ -524,9 +524,15 @@ def test_vae_encoder_matches_restatement(dtype, tol):
     assert rel_inf(dist.mean, mean) < tol and rel_inf(dist.logvar, logvar) < tol
     g = torch.Generator(device="cuda").manual_seed(5)
     smp = dist.sample(g)
-    noise = torch.randn(dist.mean.shape, generator=torch.Generator(device="cuda").manual_seed(5), device="cuda", dtype=torch.float32)
+    # diffusers draws `randn_tensor(..., device=parameters.device, dtype=parameters.dtype)`: the noise stream is the PARAMETERS' dtype
+    noise = torch.randn(dist.mean.shape, generator=torch.Generator(device="cuda").manual_seed(5), device="cuda", dtype=dtype).float()
     assert rel_inf(smp.float(), dist.mean + dist.std * noise) < (1e-6 if dtype == torch.float32 else 1e-2)
     assert torch.equal(dist.mode().float(), dist.mean.to(dtype).float())
+    # a CPU generator with GPU parameters draws on the CPU and moves (randn_tensor's rule)
+    smp_c = dist.sample(torch.Generator().manual_seed(6))
+    noise_c = torch.randn(dist.mean.shape, generator=torch.Generator().manual_seed(6), dtype=dtype).float().cuda()
+    assert rel_inf(smp_c.float(), dist.mean + dist.std * noise_c) < (1e-6 if dtype == torch.float32 else 1e-2)
+    assert dist.kl().shape == (2,) and dist.nll(smp).shape == (2,)
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 4e-2)])
