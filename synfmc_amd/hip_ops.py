@@ -1058,8 +1058,26 @@ def xattn_block_supported(h: torch.Tensor, kv_tokens: int, heads: int) -> bool:
 xattn_block640_supported = xattn_block_supported
 
 
+def xattn_pack_kv(kv: torch.Tensor) -> torch.Tensor:
+    """`kv [B, S, 2 C]` (the text's fused k | v projection, C = 320 | 640, S <= 80) -> the K / V^T MFMA fragments the fused text cross-attention block
+    reads (`fmc_xattn_pack_kv40` / `fmc_xattn_pack_kv`).  Constant over the denoising steps of a clip: packed once per clip (`Attention.text_kv`)."""
+    _dev(kv)
+    B, S, C2 = kv.shape
+    C = C2 // 2
+    assert C in (320, 640) and kv.stride(2) == 1 and kv.stride(1) == C2 and S <= 80
+    L = _lib.load()
+    if C == 640:
+        frag = torch.empty(B * 8 * 12800, dtype=kv.dtype, device=kv.device)
+        _lib.check(L.fmc_xattn_pack_kv(kv.data_ptr(), frag.data_ptr(), B, S, kv.stride(0), _stream()), "fmc_xattn_pack_kv")
+    else:
+        frag = torch.empty(B * 8 * 7680, dtype=kv.dtype, device=kv.device)
+        _lib.check(L.fmc_xattn_pack_kv40(kv.data_ptr(), frag.data_ptr(), B, S, kv.stride(0), _stream()), "fmc_xattn_pack_kv40")
+    return frag
+
+
 def xattn_block(h: torch.Tensor, ln_gamma: torch.Tensor, ln_btab: torch.Tensor, ln_eps: float, w_q_packed: torch.Tensor, kv: torch.Tensor,
-                w_out_packed: torch.Tensor, b_out: Optional[torch.Tensor], scale: float, images_per_text: int, stats_eps: Optional[float] = None):
+                w_out_packed: torch.Tensor, b_out: Optional[torch.Tensor], scale: float, images_per_text: int, stats_eps: Optional[float] = None,
+                frag: Optional[torch.Tensor] = None):
     """`to_out(softmax(to_q(LayerNorm(h)) k^T scale) v) + b + h` in one launch; `kv [B, S, 2 C]` = the text's fused k | v projection (packed into MFMA
     fragments by one tiny launch); `ln_btab [16, C]` fp32 rows = the LayerNorm beta.  C = 640: `fmc_xattn_block640_bf16`, weights `pack_w_frag80`;
     C = 320: `fmc_xattn_block320_bf16`, `pack_xattn_q40` / `_w_tilemajor`, and `stats_eps` adds the (mean, rstd) of the output rows: `(out, stats)`."""
@@ -1069,17 +1087,16 @@ def xattn_block(h: torch.Tensor, ln_gamma: torch.Tensor, ln_btab: torch.Tensor, 
     assert C in (320, 640) and C2 == 2 * C and kv.stride(2) == 1 and kv.stride(1) == C2 and N % images_per_text == 0 and N // images_per_text == B
     out = torch.empty_like(h)
     L = _lib.load()
+    if frag is None:
+        frag = xattn_pack_kv(kv)
+    assert frag.numel() == B * 8 * (12800 if C == 640 else 7680) and frag.dtype == h.dtype
     if C == 640:
         assert stats_eps is None
-        frag = torch.empty(B * 8 * 12800, dtype=h.dtype, device=h.device)
-        _lib.check(L.fmc_xattn_pack_kv(kv.data_ptr(), frag.data_ptr(), B, S, kv.stride(0), _stream()), "fmc_xattn_pack_kv")
         _lib.check(L.fmc_xattn_block640_bf16(h.data_ptr(), out.data_ptr(), ln_gamma.data_ptr(), ln_btab.data_ptr(), float(ln_eps), w_q_packed.data_ptr(),
                                              frag.data_ptr(), w_out_packed.data_ptr(), _p(b_out), N, hw, S, images_per_text, float(scale), _stream()),
                    "fmc_xattn_block640_bf16")
         return out
-    frag = torch.empty(B * 8 * 7680, dtype=h.dtype, device=h.device)
     stats = torch.empty(N * hw, 2, dtype=torch.float32, device=h.device) if stats_eps is not None else None
-    _lib.check(L.fmc_xattn_pack_kv40(kv.data_ptr(), frag.data_ptr(), B, S, kv.stride(0), _stream()), "fmc_xattn_pack_kv40")
     _lib.check(L.fmc_xattn_block320_bf16(h.data_ptr(), out.data_ptr(), ln_gamma.data_ptr(), ln_btab.data_ptr(), float(ln_eps), w_q_packed.data_ptr(),
                                          frag.data_ptr(), w_out_packed.data_ptr(), _p(b_out), _p(stats), float(stats_eps or 0.0), N, hw, S, images_per_text,
                                          float(scale), _stream()), "fmc_xattn_block320_bf16")

@@ -38,7 +38,7 @@ def _tok(x: torch.Tensor) -> torch.Tensor:
 
 
 def _attention_core(attn, q_in: torch.Tensor, kv_in: Optional[torch.Tensor], temporal: bool, lora=None,
-                    lora_scale: float = 1.0, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    lora_scale: float = 1.0, residual: Optional[torch.Tensor] = None, text_context: bool = False) -> torch.Tensor:
     """Fused projection -> attention kernel -> output projection (bias, dropout p=0) [+ residual]."""
     heads = attn.heads
     w_a, w_b, w_o = attn.fused_weights(lora, lora_scale)
@@ -55,7 +55,8 @@ def _attention_core(attn, q_in: torch.Tensor, kv_in: Optional[torch.Tensor], tem
     else:                                               # cross attention: q GEMM + one [.., 2C] kv GEMM
         assert not temporal
         q = linear_op(q_in, w_a)
-        kv = linear_op(kv_in, w_b)
+        # (text cross attention: k | v of the constant text once per clip -- `Attention.text_kv`; a pose-merged context changes every call)
+        kv = attn.text_kv(kv_in, w_b)[0] if text_context else linear_op(kv_in, w_b)
         o = K.cross_attention_q_kv(q, kv, heads, attn.scale)
     # (`_next_ln`: the LayerNorm the block applies to `attn(x) + x` -- set by the block, consumed by hip_ops.linear when the tile holds whole rows)
     return linear_op(o, w_o, attn.to_out[0].bias, residual, ln=attn.__dict__.get("_next_ln") if residual is not None else None,
@@ -91,7 +92,8 @@ class AttnProcessor:
         attn.prepare_attention_mask(attention_mask, 0, 0)
         shape4 = hidden_states.shape if (hidden_states.ndim == 4 and not temporal) else None
         x = _tok(hidden_states) if not temporal else hidden_states
-        out = _attention_core(attn, x, encoder_hidden_states, temporal, residual=_fusable(attn, _residual, shape4))
+        out = _attention_core(attn, x, encoder_hidden_states, temporal, residual=_fusable(attn, _residual, shape4),
+                              text_context=encoder_hidden_states is not None)
         return _finish(attn, out, hidden_states, shape4)
 
 
@@ -115,7 +117,7 @@ class LoRAAttnProcessor(nn.Module):
         shape4 = hidden_states.shape if (hidden_states.ndim == 4 and not temporal) else None
         x = _tok(hidden_states) if not temporal else hidden_states
         out = _attention_core(attn, x, encoder_hidden_states, temporal, lora=self, lora_scale=s,
-                              residual=_fusable(attn, _residual, shape4))
+                              residual=_fusable(attn, _residual, shape4), text_context=encoder_hidden_states is not None)
         return _finish(attn, out, hidden_states, shape4)
 
 

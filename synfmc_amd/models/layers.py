@@ -395,6 +395,10 @@ class Upsample2D(nn.Module):
 # ----------------------------------------------------------------------------
 # attention (base of TemporalSelfAttention, fmc/models/motion_module.py:324)
 # ----------------------------------------------------------------------------
+TEXT_KV_ONCE = os.environ.get("FMC_TEXT_KV_ONCE", "1") != "0"      # A/B switch: the text's k | v (and fragment pack) once per clip instead of per step
+text_kv_calls = {"computed": 0, "hit": 0}
+
+
 class Attention(nn.Module):
     """Parameter container + helpers the processors use (SURVEY.md section 8b lists the members the reference
     processors touch).  The arithmetic lives in the processors (`synfmc_amd.models.attention_processor`)."""
@@ -432,7 +436,7 @@ class Attention(nn.Module):
         self.processor = processor
         # the merged projection weights and everything packed from them belong to the old processor (a freed merged tensor's address can come
         # back with version 0 under the caching allocator: the packed caches also hold their sources alive, see `_fused_tb` / `_fused_xb`)
-        for name in ("_fused", "_fused_tb", "_fused_xb"):
+        for name in ("_fused", "_fused_tb", "_fused_xb", "_text_kv"):
             self.__dict__.pop(name, None)
 
     def set_use_memory_efficient_attention_xformers(self, *a, **k):
@@ -449,6 +453,48 @@ class Attention(nn.Module):
     def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **cross_attention_kwargs):
         return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states,
                               attention_mask=attention_mask, **cross_attention_kwargs)
+
+    # ---- the text's k | v, once per clip -------------------------------------------------
+    def text_kv(self, text: torch.Tensor, w_kv: torch.Tensor):
+        """`(kv, frag)`: the fused k | v projection of the text embedding and -- where the fused text cross-attention block can run (C = 320 | 640,
+        at most 80 tokens, bf16) -- its MFMA-fragment pack.  The reference projects `attn.to_k / to_v(encoder_hidden_states)` in every denoising step
+        (fmc/models/attention_processor.py:58-59, :145-146); the text and the (frozen) weights are constant over the steps of a clip, so the pair is
+        computed on the first call and kept while `text` and `w_kv` are the same storage at the same version (the entry holds both alive).  Under
+        autograd, or while a stream is being captured, nothing is cached."""
+        def compute():
+            kv = linear_op(text, w_kv)
+            C = w_kv.shape[0] // 2
+            pack = (kv.is_cuda and kv.dtype == torch.bfloat16 and kv.ndim == 3 and C in (320, 640) and kv.shape[1] <= 80 and self.heads == 8
+                    and kv.is_contiguous())
+            return kv, (K.xattn_pack_kv(kv) if pack else None)
+        if not TEXT_KV_ONCE or torch.is_grad_enabled() or not text.is_cuda:
+            return linear_op(text, w_kv), None
+        key = (text.data_ptr(), text._version, tuple(text.shape), text.dtype, w_kv.data_ptr(), w_kv._version)
+        hit = self.__dict__.get("_text_kv")
+        if hit is not None and hit[0] == key:
+            text_kv_calls["hit"] += 1
+            return hit[1], hit[2]
+        kv, frag = compute()
+        text_kv_calls["computed"] += 1
+        if not torch.cuda.is_current_stream_capturing():      # (a capture's allocations belong to the graph's pool: not ours to keep)
+            self.__dict__["_text_kv"] = (key, kv, frag, text, w_kv)
+        return kv, frag
+
+    def refresh_text_kv(self, entry=None):
+        """Recompute an entry of `text_kv` IN PLACE after its text buffer was overwritten with a new clip's embedding (a captured HIP graph reads
+        `kv` / `frag` by address: `_GraphedUNet.set_conditioning`), and make it this module's current entry again."""
+        entry = entry if entry is not None else self.__dict__.get("_text_kv")
+        if entry is None:
+            return None
+        _, kv, frag, text, w_kv = entry
+        with torch.no_grad():
+            kv.copy_(linear_op(text, w_kv))
+            if frag is not None:
+                frag.copy_(K.xattn_pack_kv(kv))
+        key = (text.data_ptr(), text._version, tuple(text.shape), text.dtype, w_kv.data_ptr(), w_kv._version)
+        entry = (key, kv, frag, text, w_kv)
+        self.__dict__["_text_kv"] = entry
+        return entry
 
     # ---- fused projection weights (cached; rebuilt when any source parameter changes) ----------------
     def fused_weights(self, lora=None, lora_scale: float = 1.0):
@@ -577,17 +623,32 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = LayerNorm(dim, elementwise_affine=norm_elementwise_affine, eps=norm_eps)
         self.ff = FeedForward(dim, dropout=dropout, activation_fn=activation_fn, final_dropout=final_dropout)
 
-    def _xattn_fused(self, hidden_states, encoder_hidden_states, kw):
-        """`attn2(norm2(h), text) + h` as one launch (+ the text's k | v projection and its fragment pack)."""
-        from .attention_processor import LoRAAttnProcessor, _require_frozen
+    def _attn2_weights(self, kw):
+        """(W_q, W_kv, W_out) of the text cross-attention with a frozen LoRA merged in at the scale the processor call would resolve."""
+        from .attention_processor import LoRAAttnProcessor, _require_frozen, resolve_lora_scale
         attn, proc = self.attn2, self.attn2.processor
         lora, lora_scale = None, 1.0
         if isinstance(proc, LoRAAttnProcessor):
             _require_frozen(proc)
             lora = proc
-            from .attention_processor import resolve_lora_scale
             lora_scale = resolve_lora_scale(proc, kw["scale"]) if "scale" in kw else resolve_lora_scale(proc)
-        w_q, w_kv, w_o = attn.fused_weights(lora, lora_scale)
+        return attn.fused_weights(lora, lora_scale)
+
+    def prepare_text(self, text: torch.Tensor, cross_attention_kwargs=None) -> bool:
+        """The per-clip part of this block's text cross-attention -- k | v of the text and their fragment pack -- computed now (the pipelines call
+        this before the denoising loop; a step that finds nothing prepared computes and keeps it itself)."""
+        from .attention_processor import AttnProcessor, LoRAAttnProcessor
+        if self.attn2 is None or type(self.attn2.processor) not in (AttnProcessor, LoRAAttnProcessor) or torch.is_grad_enabled():
+            return False
+        kw = dict(cross_attention_kwargs) if cross_attention_kwargs is not None else {}
+        _, w_kv, _ = self._attn2_weights(kw)
+        self.attn2.text_kv(text, w_kv)
+        return True
+
+    def _xattn_fused(self, hidden_states, encoder_hidden_states, kw):
+        """`attn2(norm2(h), text) + h` as one launch (the text's k | v projection and its fragment pack come from `Attention.text_kv`: once per clip)."""
+        attn = self.attn2
+        w_q, w_kv, w_o = self._attn2_weights(kw)
         key = (w_q.data_ptr(), w_q._version, w_o.data_ptr(), w_o._version)
         hit = attn.__dict__.get("_fused_xb")
         if hit is None or hit[0] != key:
@@ -603,14 +664,15 @@ class BasicTransformerBlock(nn.Module):
                 c = (ck, g.contiguous(), b[None, :].expand(16, -1).float().contiguous())
             self.__dict__["_fused_xc"] = c
         h = hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()
-        kv = linear_op(encoder_hidden_states, w_kv)
+        kv, frag = attn.text_kv(encoder_hidden_states, w_kv)           # (once per clip, not per step)
         per_text = h.shape[0] // encoder_hidden_states.shape[0]
         if h.shape[2] == 640:
-            return K.xattn_block(h, c[1], c[2], self.norm2.eps, hit[1], kv, hit[2], attn.to_out[0].bias, attn.scale, per_text)
+            return K.xattn_block(h, c[1], c[2], self.norm2.eps, hit[1], kv, hit[2], attn.to_out[0].bias, attn.scale, per_text, frag=frag)
         # the 40x64 level: the feed-forward's norm3 is applied by its GEGLU projection from the row statistics this launch leaves
         if K.geglu_ln_direct_ok(h, self.ff.net[0].proj.weight):          # (the feed-forward normalises its input itself: no statistics to leave)
-            return K.xattn_block(h, c[1], c[2], self.norm2.eps, hit[1], kv, hit[2], attn.to_out[0].bias, attn.scale, per_text)
-        out, stats = K.xattn_block(h, c[1], c[2], self.norm2.eps, hit[1], kv, hit[2], attn.to_out[0].bias, attn.scale, per_text, stats_eps=self.norm3.eps)
+            return K.xattn_block(h, c[1], c[2], self.norm2.eps, hit[1], kv, hit[2], attn.to_out[0].bias, attn.scale, per_text, frag=frag)
+        out, stats = K.xattn_block(h, c[1], c[2], self.norm2.eps, hit[1], kv, hit[2], attn.to_out[0].bias, attn.scale, per_text, stats_eps=self.norm3.eps,
+                                   frag=frag)
         K.ln_epilogue_calls["emitted"] += 1
         out._fmc_ln = (stats, self.norm3._ln_key(None, 1, 1), True)
         return out

@@ -320,6 +320,35 @@ class UNet3DConditionModel(nn.Module):
             if len(self.down_blocks):                    # (the one-shot hint of `_run_blocks`; normally consumed by the block -- not after an exception)
                 self.down_blocks[0].__dict__.pop("_cfg_half_input", None)
 
+    def _text_in_model_dtype(self, text):
+        """The text embedding in the model's dtype; a converted copy is kept per source tensor (same storage, same version), so that every step of a
+        clip hands the SAME tensor to the cross-attention layers and their once-per-clip k | v (`Attention.text_kv`) stay valid."""
+        if text.dtype == self.dtype:
+            return text
+        if torch.is_grad_enabled() and text.requires_grad:
+            return text.to(self.dtype)
+        key = (text.data_ptr(), text._version, tuple(text.shape), text.dtype, self.dtype)
+        hit = self.__dict__.get("_text_cast")
+        if hit is None or hit[0] != key:
+            hit = (key, text.to(self.dtype), text)
+            if not (text.is_cuda and torch.cuda.is_current_stream_capturing()):
+                self.__dict__["_text_cast"] = hit
+        return hit[1]
+
+    def prepare_text_conditioning(self, encoder_hidden_states, cross_attention_kwargs=None) -> int:
+        """Per-clip text conditioning: k | v of the text tokens for all 16 cross-attention layers and their MFMA-fragment
+        packs, computed ONCE here instead of in every denoising step (the reference re-projects them per step and per frame,
+        fmc/models/attention_processor.py:58-59; pipeline_animation_cm_om.py:679-720 passes the same `text_embeddings` to every step).
+        Returns the number of layers prepared.  Optional: a step that finds nothing prepared does the same on its first call."""
+        from .layers import BasicTransformerBlock
+        n = 0
+        with torch.no_grad():
+            text = self._text_in_model_dtype(encoder_hidden_states)
+            for m in self.modules():
+                if isinstance(m, BasicTransformerBlock):
+                    n += bool(m.prepare_text(text, cross_attention_kwargs))
+        return n
+
     def _resnets_with_temb(self):
         rs = getattr(self, "_temb_resnets", None)
         if rs is None:
@@ -355,8 +384,7 @@ class UNet3DConditionModel(nn.Module):
                     forward_upsample_size, cfg_shared_input: bool = False):
         if sample.dtype != self.dtype:
             sample = sample.to(self.dtype)
-        if encoder_hidden_states.dtype != self.dtype:
-            encoder_hidden_states = encoder_hidden_states.to(self.dtype)
+        encoder_hidden_states = self._text_in_model_dtype(encoder_hidden_states)
         # text stays [B, 77, C]: the cross-attention kernel shares it across the F frames of a clip
         # Shared classifier-free-guidance prefix (`cfg_shared_input=True`, a PER-CALL keyword of `forward` passed by the pipelines, which build the batch as `cat([latents] * 2)`,
         # pipeline_animation_cm_om.py:704): until the first text cross-attention the two halves of the batch are the same numbers through

@@ -47,7 +47,7 @@ class _GraphedUNet:
         self.x = torch.zeros(latents_shape, dtype=dtype, device=dev)
         self.t = torch.zeros((), dtype=torch.int64, device=dev)
         own = lambda v: v.detach().clone(memory_format=torch.preserve_format)
-        self.text = own(text)
+        self.text = own(text if text.dtype == dtype else text.to(dtype))   # (model dtype: the U-Net then hands THIS buffer to its cross-attention layers)
         self.pose = None if pose_feats is None else [own(p) for p in pose_feats]
         self.traj = None if traj_feats is None else [own(p) for p in traj_feats]
         self.graph = None
@@ -86,6 +86,10 @@ class _GraphedUNet:
         # graph reads them by address, so this runner keeps them alive and refreshes them in place for a new clip
         self._pose_terms = [(m, m.__dict__["_pose_term_cache"]) for m in self.unet.modules()
                             if m.__dict__.get("_pose_term_cache") is not None]
+        # ... and the text's k | v projections + fragment packs of the cross-attention layers (`Attention.text_kv`, once per clip): computed by the
+        # warm-up calls from `self.text`, read by the graph by address, refreshed in place by `set_conditioning`
+        self._text_kvs = [(m, m.__dict__["_text_kv"]) for m in self.unet.modules()
+                          if m.__dict__.get("_text_kv") is not None and m.__dict__["_text_kv"][3] is self.text]
         # `set_conditioning` recomputes the pose terms from the `pose_view` tensors: that is only right while they ALIAS this runner's
         # static camera buffers (channels-last storage: the token view is free).  A layout that forced a private copy would replay the
         # next clip with this clip's camera term -- such a runner re-captures instead of refilling.
@@ -113,6 +117,7 @@ class _GraphedUNet:
                 mod.__dict__.pop("_pose_term_cache", None)
             self.capture()
             return
+        self._text_kvs = [(mod, mod.refresh_text_kv(entry)) for mod, entry in getattr(self, "_text_kvs", [])]
         for mod, (key, term, pose_view) in self._pose_terms:
             pf = pose_view if pose_view.is_contiguous() else pose_view.contiguous()
             term.copy_(K.linear(pf, mod.qkv_merge.weight, mod.qkv_merge.bias, None, key[-1]))

@@ -690,3 +690,102 @@ def test_temporal_transformer_block_fused_kernel_equals_the_unfused_chain(C, P):
     e_f, e_p = rel_inf(fused, ref), rel_inf(plain, ref)
     assert e_f < 2e-2 and e_f < 2.0 * e_p + 2e-3, (e_f, e_p)               # the fused kernel is as close to fp32 as the chain it replaces
     assert not blk.fused_blocks_ok(x[:, :, :P - 1].contiguous(), None, kw)   # pixels % 10 (% 5 at C = 640) != 0: the un-fused chain
+
+
+def test_fused_temporal_block_resolves_the_lora_scale_like_the_unfused_processor():
+    """`LORAPoseAdaptorAttnProcessor.__call__(..., scale=1.0)` (reference attention_processor.py:337-347): with no `scale` keyword the LoRA is applied at 1.0,
+    NOT at the processor's `lora_scale` -- and the fused temporal block (full width C = 320, where `fmc_temporal_block_bf16` runs) must resolve it the same
+    way as the un-fused chain.  `lora_scale = 0.35` makes the two rules differ visibly."""
+    from synfmc_amd.models import motion_module as MM
+    from synfmc_amd.models.attention_processor import AttnProcessor, LORAPoseAdaptorAttnProcessor
+    torch.manual_seed(11)
+    C, H, Fr, B, P = 320, 8, 16, 2, 40
+    blk = MM.TemporalTransformerBlock(dim=C, num_attention_heads=H, attention_head_dim=C // H, attention_block_types=("Temporal_Self", "Temporal_Self"),
+                                      temporal_position_encoding=True, temporal_position_encoding_max_len=32)
+    proc = LORAPoseAdaptorAttnProcessor(hidden_size=C, pose_feature_dim=C, query_condition=True, key_value_condition=True, scale=0.8, rank=16,
+                                        lora_scale=0.35)
+    blk.attention_blocks[0].set_processor(proc)
+    blk.attention_blocks[1].set_processor(AttnProcessor())
+    with torch.no_grad():
+        for p in blk.parameters():
+            if p.ndim >= 2:
+                p.normal_(0, p.shape[-1] ** -0.5)
+            else:
+                p.normal_(0, 0.2)
+        for n in list(blk.norms) + [blk.ff_norm]:
+            n.weight.add_(1.0)
+    blk = blk.to("cuda", torch.bfloat16).eval().requires_grad_(False)
+    x = (torch.randn(B, Fr, P, C) * 1.2).to("cuda", torch.bfloat16)
+    kw = {"pose_feature": torch.randn(B, Fr, P, C).to("cuda", torch.bfloat16)}
+
+    def run(fused, **extra):
+        MM.TEMPORAL_FUSED = fused
+        try:
+            with torch.no_grad():
+                return blk(x, cross_attention_kwargs={**kw, **extra})
+        finally:
+            MM.TEMPORAL_FUSED = True
+    assert blk.fused_blocks_ok(x, None, kw)
+    fused, plain = run(True), run(False)
+    assert rel_inf(fused, plain) < 2e-2
+    # the keyword, when given, wins on both paths; and the two scales are distinguishable at this tolerance
+    fused_s, plain_s = run(True, scale=0.35), run(False, scale=0.35)
+    assert rel_inf(fused_s, plain_s) < 2e-2
+    assert rel_inf(plain_s, plain) > 5e-2 and rel_inf(fused_s, fused) > 5e-2
+
+
+@pytest.mark.parametrize("C,hw", [(640, 160), (320, 320), (1280, 40)])
+def test_text_kv_is_projected_once_per_clip(C, hw):
+    """`attn.to_k / to_v(encoder_hidden_states)` (reference attention_processor.py:58-59, every step) and the fragment pack of
+    the fused text cross-attention run ONCE per (text, weights): a second step launches neither; overwriting the text in place (a new clip in
+    the graph runner's static buffer) or swapping the processor recomputes; results equal the per-step path (FMC_TEXT_KV_ONCE=0) bit for bit."""
+    from synfmc_amd.models import layers as L
+    torch.manual_seed(6)
+    H, B, Fr, S = 8, 2, 3, 77
+    blk = L.BasicTransformerBlock(C, H, C // H, cross_attention_dim=768)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.normal_(0, p.shape[-1] ** -0.5) if p.ndim >= 2 else p.normal_(0, 0.2)
+        for n in (blk.norm1, blk.norm2, blk.norm3):
+            n.weight.add_(1.0)
+    blk = blk.to("cuda", torch.bfloat16).eval().requires_grad_(False)
+    x = (torch.randn(B * Fr, hw, C) * 1.2).to("cuda", torch.bfloat16)
+    text = torch.randn(B, S, 768).to("cuda", torch.bfloat16)
+    L.K.DETERMINISTIC, det = True, L.K.DETERMINISTIC
+    try:
+        with torch.no_grad():
+            c0 = dict(L.text_kv_calls)
+            y1 = blk(x, encoder_hidden_states=text)
+            y2 = blk(x, encoder_hidden_states=text)
+            assert L.text_kv_calls["computed"] - c0["computed"] == 1 and L.text_kv_calls["hit"] - c0["hit"] == 1
+            assert torch.equal(y1, y2)
+            entry = blk.attn2.__dict__["_text_kv"]
+            assert (entry[2] is not None) == (C in (320, 640))             # the fragment pack exists exactly where the fused block runs
+            L.TEXT_KV_ONCE = False
+            try:
+                y_step = blk(x, encoder_hidden_states=text)
+            finally:
+                L.TEXT_KV_ONCE = True
+            assert torch.equal(y1, y_step)
+            # a new clip written into the same buffer: the version moves, the pair is recomputed
+            text.copy_(torch.randn(B, S, 768).to("cuda", torch.bfloat16))
+            y3 = blk(x, encoder_hidden_states=text)
+            assert L.text_kv_calls["computed"] - c0["computed"] == 2
+            assert rel_inf(y3, y1) > 1e-2
+            # ... or refreshed in place (what a captured graph needs): same tensors, new content
+            kv_ptr = blk.attn2.__dict__["_text_kv"][1].data_ptr()
+            text.copy_(torch.randn(B, S, 768).to("cuda", torch.bfloat16))
+            blk.attn2.refresh_text_kv()
+            assert blk.attn2.__dict__["_text_kv"][1].data_ptr() == kv_ptr
+            n = L.text_kv_calls["computed"]
+            y4 = blk(x, encoder_hidden_states=text)
+            assert L.text_kv_calls["computed"] == n
+            L.TEXT_KV_ONCE = False
+            try:
+                assert torch.equal(y4, blk(x, encoder_hidden_states=text))
+            finally:
+                L.TEXT_KV_ONCE = True
+            blk.attn2.set_processor(blk.attn2.processor)                   # a processor swap drops the entry
+            assert "_text_kv" not in blk.attn2.__dict__
+    finally:
+        L.K.DETERMINISTIC = det
