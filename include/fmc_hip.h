@@ -312,6 +312,36 @@ int fmc_groupnorm_apply_fwd(const void* x, void* y, const float* gamma, const fl
                             int part_splits, int N, int HW, int C, int G, float eps, int act, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * 3x3 convolution with the input halo tile resident in LDS and GroupNorm + SiLU applied while it is staged (SURVEY.md section 8 f1;
+ * csrc/conv_halo.hip).  Replaces `conv(nonlinearity(norm(x)))` of diffusers' ResnetBlock2D (ctor args fmc/models/unet_blocks.py:306-317:
+ * norm1 -> SiLU -> conv1 (+ time_emb_proj) and norm2 -> SiLU -> conv2 (+ input_tensor)), `InflatedConv3d` / `InflatedGroupNorm`
+ * (fmc/models/resnet.py:16-37) and Upsample2D's conv (unet_blocks.py:625) -- the normalised tensor is never written.
+ *   x [n_img, Hs, Ws, Cin1] (+ x2 [n_img, Hs, Ws, Cin - Cin1] | NULL: the up blocks' `cat([hidden, skip], 1)`, unet_blocks.py:683,798, read in place);
+ *   Hs, Ws = H, W, or H / 2, W / 2 with upsample2x (nearest 2x upsample folded into the halo addressing); H, W = OUTPUT size, W % 32 == 0;
+ *   w_packed = fmc_conv3x3_halo_pack_weight(filter [Cout][3][3][Cin]): Cin (both sources) % 64 == 0, Cout % 160 == 0;
+ *   bias [Cout] | NULL, temb / temb_row_stride / temb_img_div and residual [n_img, H, W, Cout] | NULL as for fmc_conv3x3_bf16;
+ *   gn_coef [n_img, Cin, 2] fp32 | NULL: the operand is act(x * gn_coef[i, c, 0] + gn_coef[i, c, 1]) rounded to bf16 (act = SiLU when gn_act),
+ *     zero outside the image (the reference pads the NORMALISED tensor); produced by fmc_groupnorm_coef;
+ *   gn_partials [n_img, fmc_conv3x3_halo_tiles_per_image(H, W), 32, 2] fp32 | NULL: (sum, sum of squares) of the bf16-rounded outputs per image,
+ *     pixel tile and group of Cout / 32 channels -- the statistics pass of the GroupNorm that consumes `out` (fmc_groupnorm_coef /
+ *     fmc_groupnorm_apply_fwd take them as `partials` with part_splits = tiles per image).
+ * fmc_groupnorm_coef: partial sums [N, part_splits, G, 2] -> coef [N, C, 2] = (rstd gamma_c, beta_c - mean rstd gamma_c) and, when stats != NULL,
+ *   stats [N, G, 2] = (mean, rstd); HW = pixels per image (count per group = HW * C / G); fp64 combination, deterministic. */
+/* The statistics pass of fmc_groupnorm_silu_fwd alone (x read once, nothing written but the sums): partials [N][splits][G][2] fp32 with
+ * splits = fmc_groupnorm_partial_splits(HW, C); x2 / C1: two-source channel concat as for fmc_groupnorm_silu_fwd. */
+int fmc_groupnorm_partial_splits(int HW, int C);
+int fmc_groupnorm_partials(const void* x, const void* x2, int C1, float* partials, int N, int HW, int C, int G, int dtype, void* stream);
+int fmc_conv3x3_halo_supported(int n_img, int H, int W, int Cin, int Cin1, int Cout, int upsample2x);
+int64_t fmc_conv3x3_halo_packed_bytes(int Cin, int Cout);
+int fmc_conv3x3_halo_pack_weight(const void* w, void* dst, int Cin, int Cout, void* stream);
+int fmc_conv3x3_halo_tiles_per_image(int H, int W);
+int fmc_conv3x3_halo_bf16(const void* x, const void* x2, int Cin1, const void* w_packed, const void* bias, const void* temb, const void* residual,
+                          void* out, int n_img, int H, int W, int Cin, int Cout, int64_t temb_row_stride, int temb_img_div, int upsample2x,
+                          const float* gn_coef, int gn_act, float* gn_partials, void* stream);
+int fmc_groupnorm_coef(const float* partials, int part_splits, const float* gamma, const float* beta, float* coef, float* stats, int N, int HW,
+                       int C, int G, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * fp32-storage ("parity") mode of the two GEMMs above: split-bf16 x3 on the SAME kernels.
  * The reference's CPU path is fp32 (north_star: outputs within 1e-3 rel-inf of it); the bf16 product path can only be held
  * to bf16's own rounding against it.  To check the hand-written tile maps, operand loaders (token / implicit 3x3 conv /

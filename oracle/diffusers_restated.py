@@ -468,12 +468,12 @@ class DDIMScheduler:
     def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
                  steps_offset=0, clip_sample=True, set_alpha_to_one=True, prediction_type="epsilon"):
         if beta_schedule == "linear":
-            betas = np.linspace(beta_start, beta_end, num_train_timesteps, dtype=np.float32)
+            betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)      # (diffusers 0.24.0 scheduling_ddim.py: torch.linspace, fp32)
         elif beta_schedule == "scaled_linear":
-            betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=np.float32) ** 2
+            betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
         else:
             raise NotImplementedError(beta_schedule)
-        self.betas = torch.from_numpy(betas)
+        self.betas = betas
         self.alphas = 1.0 - self.betas
         self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
         self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]

@@ -57,6 +57,15 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "fmc_conv3x3_bf16_gn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                     c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "fmc_groupnorm_partial_splits": (c_int, [c_int, c_int]),
+    "fmc_groupnorm_partials": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fmc_conv3x3_halo_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "fmc_conv3x3_halo_packed_bytes": (c_int64, [c_int, c_int]),
+    "fmc_conv3x3_halo_pack_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "fmc_conv3x3_halo_tiles_per_image": (c_int, [c_int, c_int]),
+    "fmc_conv3x3_halo_bf16": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                      c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "fmc_groupnorm_coef": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "fmc_groupnorm_apply_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                         c_float, c_int, c_int, c_void_p]),
     "fmc_split_bf16x3": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),

@@ -892,6 +892,30 @@ extern "C" int fmc_groupnorm_silu_fwd(const void* x, void* y, const float* gamma
     return 0;
 }
 
+// the statistics pass of fmc_groupnorm_silu_fwd alone: per-(sample, split, group) (sum, sum of squares) -> partials [N][splits][G][2], splits =
+// fmc_groupnorm_partial_splits(HW, C); consumed by fmc_groupnorm_coef (conv_halo.hip) or fmc_groupnorm_apply_fwd
+extern "C" int fmc_groupnorm_partial_splits(int HW, int C) { return (HW > 0 && C >= 8 && C <= 8 * 512 && C % 8 == 0) ? gn_geom(HW, C).split : 0; }
+
+extern "C" int fmc_groupnorm_partials(const void* x, const void* x2, int C1, float* partials, int N, int HW, int C, int G, int dtype, void* stream) {
+    if (int rc = gn_check(x, x, N, HW, C, G, dtype)) return rc;
+    if (x2 && (C1 <= 0 || C1 >= C || C1 % 8 || !fmc_aligned16(x2)))
+        FMC_FAIL(FMC_E_SHAPE, "groupnorm_partials: two-source input needs 0 < C1 < C, C1 %% 8 == 0 (C1=%d C=%d)", C1, C);
+    if (!x2) C1 = 0;
+    if (!partials) FMC_FAIL(FMC_E_NULL, "groupnorm_partials: NULL partials");
+    GnGeom g = gn_geom(HW, C);
+    dim3 grid(g.split, N), block(g.block);
+    const size_t lds = (size_t)2 * g.rpi * C * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == FMC_BF16)
+        hipLaunchKernelGGL((gn_partial_kernel<bf16_t, 0>), grid, block, lds, st, (const bf16_t*)x, nullptr, nullptr, nullptr, nullptr, partials, HW, C, G,
+                           g.tpr, g.rpi, g.rows_per_split, 0, (const bf16_t*)x2, C1);
+    else
+        hipLaunchKernelGGL((gn_partial_kernel<float, 0>), grid, block, lds, st, (const float*)x, nullptr, nullptr, nullptr, nullptr, partials, HW, C, G,
+                           g.tpr, g.rpi, g.rows_per_split, 0, (const float*)x2, C1);
+    FMC_CHECK_LAUNCH("fmc_groupnorm_partials");
+    return 0;
+}
+
 extern "C" int fmc_groupnorm_apply_fwd(const void* x, void* y, const float* gamma, const float* beta, float* stats,
                                        const float* partials, int part_splits, int N, int HW, int C, int G, float eps, int act,
                                        int dtype, void* stream) {

@@ -192,7 +192,7 @@ def groupnorm_silu(x, gamma, beta, groups: int, eps: float, act: bool, x2=None, 
     gamma/beta: fp32 `[C]`.  `x2`: second channel block (the result normalises `cat([x, x2], -1)` without building it).
     `gn_tag`: the `_fmc_gn` tag of the tensor x is a view of -- its producer's partial sums replace the statistics pass."""
     if (gn_tag is not None and x2 is None and groups == 32 and gn_tag[1] == x.shape[-1] and gn_tag[0].shape[0] == x.shape[0]
-            and gn_tag[0].shape[1] * 160 == x.shape[1] and not torch.is_grad_enabled()):
+            and gn_tag[0].shape[1] <= 64 and not torch.is_grad_enabled()):       # (any split of the pixels: 160-row tiles, the halo conv's 10 x 32 tiles)
         return groupnorm_apply(x, gamma, beta, groups, eps, act, gn_tag[0])
     if torch.is_grad_enabled() and (x.requires_grad or (x2 is not None and x2.requires_grad)):
         if x2 is not None:
@@ -1475,6 +1475,92 @@ def conv3x3_gn(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias, temb, residu
 
 
 # --------------------------------------------------------------------------------------------
+# 3x3 convolution with the input halo resident in LDS and GroupNorm + SiLU applied while it is staged (csrc/conv_halo.hip; SURVEY.md
+# section 8 f1).  `conv(silu(norm(x)))` of diffusers' ResnetBlock2D as: statistics (out of the producer's epilogue, or one read of x) ->
+# `fmc_groupnorm_coef` (per-(image, channel) scale / shift) -> `fmc_conv3x3_halo_bf16` reading the RAW x.  FMC_CONV_HALO=0: A/B switch.
+# --------------------------------------------------------------------------------------------
+CONV_HALO = os.environ.get("FMC_CONV_HALO", "1") != "0"
+CONV_HALO_MIN_TILES = int(os.environ.get("FMC_CONV_HALO_MIN_TILES", "200"))     # workgroups below which the ring / stream-K arms keep the shape
+CONV_GN_FUSED = os.environ.get("FMC_CONV_GN_FUSED", "0") == "1"   # GroupNorm + SiLU in the conv's operand path instead of a separate apply pass (measured slower)
+conv_halo_calls = {"conv": 0, "gn_fused": 0, "stats_pass": 0, "stats_from_producer": 0}
+
+
+def conv3x3_halo_supported(n: int, h: int, w: int, cin: int, cin1: int, cout: int, upsample: bool) -> bool:
+    return bool(_lib.load().fmc_conv3x3_halo_supported(n, h, w, cin, cin1, cout, int(upsample)))
+
+
+def _w_halo_packed(weight_cl: torch.Tensor) -> torch.Tensor:
+    """Channels-last 3x3 filter (physically `[Cout][3][3][Cin]`) -> the halo kernel's sub-tile order (`fmc_conv3x3_halo_pack_weight`), cached on the weight."""
+    cache = _owner_cache(weight_cl, "_fmc_wtm")
+    key = ("halo", weight_cl.storage_offset(), tuple(weight_cl.shape), tuple(weight_cl.stride()), weight_cl._version)
+    hit = cache.get(key)
+    if hit is None:
+        cout, cin = weight_cl.shape[:2]
+        assert weight_cl.is_contiguous(memory_format=torch.channels_last)
+        hit = torch.empty(cout * 9 * cin, dtype=weight_cl.dtype, device=weight_cl.device)
+        _lib.check(_lib.load().fmc_conv3x3_halo_pack_weight(weight_cl.data_ptr(), hit.data_ptr(), cin, cout, _stream()), "fmc_conv3x3_halo_pack_weight")
+        cache[key] = hit
+    return hit
+
+
+def groupnorm_coef(partials: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, hw: int, C: int, groups: int, eps: float,
+                   want_stats: bool = False):
+    """Partial (sum, sum of squares) `[N, splits, G, 2]` -> per-(image, channel) `(scale, shift)` `[N, C, 2]` of the GroupNorm (+ `[N, G, 2]` mean / rstd)."""
+    _dev(partials, gamma, beta)
+    N, splits, G, _ = partials.shape
+    assert G == groups and partials.dtype == torch.float32 and partials.is_contiguous() and gamma.dtype == torch.float32
+    coef = torch.empty(N, C, 2, dtype=torch.float32, device=partials.device)
+    stats = torch.empty(N, G, 2, dtype=torch.float32, device=partials.device) if want_stats else None
+    _lib.check(_lib.load().fmc_groupnorm_coef(partials.data_ptr(), splits, gamma.data_ptr(), beta.data_ptr(), coef.data_ptr(), _p(stats), N, hw, C,
+                                              groups, float(eps), _stream()), "fmc_groupnorm_coef")
+    return (coef, stats) if want_stats else coef
+
+
+def groupnorm_partials(x: torch.Tensor, groups: int, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The statistics pass of a GroupNorm alone: x `[N, S, C]` (+ `x2 [N, S, C2]`: channel concat read in place) -> partial (sum, sum of squares)
+    `[N, splits, G, 2]` (one read of x, no write)."""
+    _dev(x, x2)
+    N, S, C1 = x.shape
+    C = C1 + (x2.shape[2] if x2 is not None else 0)
+    assert x.is_contiguous() and (x2 is None or (x2.is_contiguous() and x2.shape[:2] == x.shape[:2] and x2.dtype == x.dtype))
+    L = _lib.load()
+    part = torch.empty(N, L.fmc_groupnorm_partial_splits(S, C), groups, 2, dtype=torch.float32, device=x.device)
+    conv_halo_calls["stats_pass"] += 1
+    _lib.check(L.fmc_groupnorm_partials(x.data_ptr(), _p(x2), C1 if x2 is not None else 0, part.data_ptr(), N, S, C, groups, _dt(x), _stream()),
+               "fmc_groupnorm_partials")
+    return part
+
+
+def conv3x3_halo(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias=None, temb=None, residual_nhwc=None, temb_div: int = 1, upsample: bool = False,
+                 x2_nhwc: Optional[torch.Tensor] = None, gn_coef: Optional[torch.Tensor] = None, gn_act: bool = True, emit_gn: bool = False):
+    """`conv3x3(act(x * scale + shift))` on channels-last bf16 images: x `[N, Hs, Ws, C1]` (+ `x2 [N, Hs, Ws, C2]`: channel concat read in place),
+    filter `[Cout, C1 + C2, 3, 3]` channels-last, `gn_coef [N, C1 + C2, 2]` fp32 or None (plain convolution).  Returns out `[N, H, W, Cout]`, or
+    `(out, partials [N, tiles, 32, 2])` with `emit_gn` (statistics of the output for the GroupNorm that consumes it)."""
+    _dev(x_nhwc, weight_cl, bias, temb, residual_nhwc, x2_nhwc, gn_coef)
+    n, hs, ws, c1 = x_nhwc.shape
+    h, w = (2 * hs, 2 * ws) if upsample else (hs, ws)
+    cout, cin = weight_cl.shape[:2]
+    assert x_nhwc.is_contiguous() and x_nhwc.dtype == torch.bfloat16 and weight_cl.dtype == torch.bfloat16
+    if x2_nhwc is not None:
+        assert x2_nhwc.is_contiguous() and x2_nhwc.shape[:3] == x_nhwc.shape[:3] and x2_nhwc.dtype == x_nhwc.dtype and c1 + x2_nhwc.shape[3] == cin
+    else:
+        assert c1 == cin
+    assert temb is None or (temb.stride(1) == 1 and temb.shape == (n // temb_div, cout) and n % temb_div == 0)
+    assert residual_nhwc is None or (residual_nhwc.is_contiguous() and residual_nhwc.shape == (n, h, w, cout))
+    assert gn_coef is None or (gn_coef.shape == (n, cin, 2) and gn_coef.dtype == torch.float32 and gn_coef.is_contiguous())
+    L = _lib.load()
+    wp = _w_halo_packed(weight_cl)
+    out = torch.empty(n, h, w, cout, dtype=x_nhwc.dtype, device=x_nhwc.device)
+    part = torch.empty(n, L.fmc_conv3x3_halo_tiles_per_image(h, w), 32, 2, dtype=torch.float32, device=x_nhwc.device) if emit_gn else None
+    conv_halo_calls["conv"] += 1
+    conv_halo_calls["gn_fused"] += gn_coef is not None
+    _lib.check(L.fmc_conv3x3_halo_bf16(x_nhwc.data_ptr(), _p(x2_nhwc), c1, wp.data_ptr(), _p(bias), _p(temb), _p(residual_nhwc), out.data_ptr(),
+                                       n, h, w, cin, cout, 0 if temb is None else temb.stride(0), int(temb_div), int(upsample), _p(gn_coef),
+                                       int(gn_act), _p(part), _stream()), "fmc_conv3x3_halo_bf16")
+    return (out, part) if emit_gn else out
+
+
+# --------------------------------------------------------------------------------------------
 # fp32-storage ("parity") mode of the two GEMMs: split-bf16 x3 operands on the same gfx950 kernels, fp32 epilogue
 # (include/fmc_hip.h: fmc_split_bf16x3 / fmc_linear_x3_f32 / fmc_conv3x3_x3_f32).  FMC_F32_GEMM=0 sends fp32 projections /
 # convolutions back to the vendor libraries (A/B: which part of a parity figure is the product path's own indexing).
@@ -1907,6 +1993,19 @@ def conv3x3(x_nchw: torch.Tensor, weight_cl: torch.Tensor, bias, temb=None, resi
     stride2 = tuple(stride) == (2, 2)
     if stride2:
         h, w = h // 2, w // 2
+    # the halo-resident kernel (csrc/conv_halo.hip): 1.75 - 1.95 x the ring kernels wherever its 10 x 32 pixel x 160 channel tiles fill the chip
+    # (tools/scratch/r05/bench_halo.py); every such convolution also leaves the statistics of the GroupNorm that consumes its output
+    if (CONV_HALO and not stride2 and (temb is None or temb.stride(1) == 1) and conv3x3_halo_supported(n, h, w, cin, cin, cout, upsample)
+            and n * _lib.load().fmc_conv3x3_halo_tiles_per_image(h, w) * (cout // 160) >= CONV_HALO_MIN_TILES):
+        want = bool(emit_gn and GN_EPILOGUE and cout % 64 == 0 and 160 % (cout // 32) == 0 and not torch.is_grad_enabled())
+        y = conv3x3_halo(x, weight_cl, bias, temb, r, temb_div, upsample, emit_gn=want)
+        if want:
+            y, part = y
+            gn_epilogue_calls["emitted"] += 1
+            y = y.permute(0, 3, 1, 2)
+            y._fmc_gn = (part, cout)
+            return y
+        return y.permute(0, 3, 1, 2)
     if emit_gn and gn_emit_ok(n * h * w, cout, 9 * cin, h * w, x.dtype):
         y, tag = conv3x3_gn(x, weight_cl, bias, temb, r, temb_div, upsample, stride2)
         y = y.permute(0, 3, 1, 2)

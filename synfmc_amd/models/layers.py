@@ -346,6 +346,8 @@ class ResnetBlock2D(nn.Module):
                 input_tensor = self.conv_shortcut(input_tensor)
             out = self.conv2(self.norm2(h, act=True), residual=input_tensor)
             return out if self.output_scale_factor == 1.0 else out / self.output_scale_factor
+        if K.CONV_GN_FUSED and self._gn_fused_ok(input_tensor, skip, t):
+            return self._forward_gn_fused(input_tensor, skip, t, div)
         # both convolutions feed a GroupNorm (norm2 here, the next module's norm behind conv2): where that norm would read its input
         # twice (the 40x64 level) the conv's epilogue emits its statistics (`emit_gn`, hip_ops.gn_emit_ok)
         h = self.conv1(self.norm1(input_tensor, act=True, x2=skip), temb=t, temb_div=div, emit_gn=True)
@@ -353,6 +355,44 @@ class ResnetBlock2D(nn.Module):
             input_tensor = self.conv_shortcut(input_tensor, x2=skip)
         out = self.conv2(self.norm2(h, act=True), residual=input_tensor, emit_gn=True)   # `input + h` rides in conv2's epilogue
         return out if self.output_scale_factor == 1.0 else out / self.output_scale_factor
+
+
+    # ---- GroupNorm + SiLU inside the convolutions' operand path (opt-in: hip_ops.CONV_GN_FUSED) ---------------------------
+    def _gn_fused_ok(self, x, skip, t) -> bool:
+        n, c, h, w = x.shape
+        cin = c + (skip.shape[1] if skip is not None else 0)
+        if not (K.CONV_HALO and x.is_cuda and x.dtype == torch.bfloat16 and self.conv1.weight.dtype == torch.bfloat16 and not torch.is_grad_enabled()
+                and self.output_scale_factor == 1.0 and c % 64 == 0 and cin == self.in_channels
+                and self.out_channels % 64 == 0 and 160 % (self.out_channels // 32) == 0
+                and self.norm1.num_groups == 32 and self.norm2.num_groups == 32 and (t is None or t.stride(1) == 1)):
+            return False
+        return (K.conv3x3_halo_supported(n, h, w, cin, c, self.out_channels, False)
+                and K.conv3x3_halo_supported(n, h, w, self.out_channels, self.out_channels, self.out_channels, False))
+
+    def _forward_gn_fused(self, x, skip, t, div):
+        """`conv2(silu(norm2(conv1(silu(norm1(x))) + temb))) + shortcut(x)` (diffusers ResnetBlock2D.forward) with neither normalised tensor written:
+        statistics of x (the producer's epilogue or one read) -> per-(image, channel) scale / shift -> conv1 reads the RAW x (+ skip, in place) and
+        normalises it while staging its halo, leaves the statistics of its output -> conv2 likewise, `+ input` in its epilogue."""
+        n, c, h, w = x.shape
+        xt = to_tokens(x)
+        st = None if skip is None else to_tokens(skip)
+        tag = getattr(xt, "_fmc_gn", None)
+        if (tag is not None and st is None and tag[1] == c and tag[0].shape[0] == n and tag[0].shape[2] == 32):
+            part1 = tag[0]
+            K.conv_halo_calls["stats_from_producer"] += 1
+        else:
+            part1 = K.groupnorm_partials(xt, 32, st)
+        coef1 = K.groupnorm_coef(part1, f32_param(self.norm1, "weight"), f32_param(self.norm1, "bias"), h * w, self.in_channels, 32, self.norm1.eps)
+        x_nhwc = xt.view(n, h, w, c)
+        s_nhwc = None if st is None else st.view(n, h, w, st.shape[2])
+        hid, part2 = K.conv3x3_halo(x_nhwc, self.conv1._weight_cl(), self.conv1.bias, t, None, div, False, s_nhwc, coef1, True, emit_gn=True)
+        coef2 = K.groupnorm_coef(part2, f32_param(self.norm2, "weight"), f32_param(self.norm2, "bias"), h * w, self.out_channels, 32, self.norm2.eps)
+        res = x if self.conv_shortcut is None else self.conv_shortcut(x, x2=skip)
+        out, part3 = K.conv3x3_halo(hid, self.conv2._weight_cl(), self.conv2.bias, None, to_tokens(res).view(n, h, w, self.out_channels), 1, False,
+                                    None, coef2, True, emit_gn=True)
+        out = out.permute(0, 3, 1, 2)
+        out._fmc_gn = (part3, self.out_channels)
+        return out
 
 
 class Downsample2D(nn.Module):

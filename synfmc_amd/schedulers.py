@@ -25,18 +25,18 @@ class DDIMScheduler:
                  trained_betas=None, clip_sample=True, set_alpha_to_one=True, steps_offset=0,
                  prediction_type="epsilon", thresholding=False, timestep_spacing="leading", **_unused):
         if trained_betas is not None:
-            betas = np.asarray(trained_betas, dtype=np.float32)
+            betas = torch.as_tensor(np.asarray(trained_betas, dtype=np.float32))
         elif beta_schedule == "linear":
-            betas = np.linspace(beta_start, beta_end, num_train_timesteps, dtype=np.float32)
+            betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)      # (diffusers 0.24.0 scheduling_ddim.py: torch.linspace, fp32)
         elif beta_schedule == "scaled_linear":
-            betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=np.float32) ** 2
+            betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
         else:
             raise NotImplementedError(f"{beta_schedule} is not implemented for {self.__class__}")
         if prediction_type != "epsilon":
             raise NotImplementedError("FMC trains epsilon prediction only (train_cam_obj_ctrl.py:870-875)")
         if clip_sample or thresholding or timestep_spacing != "leading":
             raise NotImplementedError("only clip_sample=False / leading spacing (configs/*.yaml) are built")
-        self.betas = torch.from_numpy(betas)
+        self.betas = betas
         self.alphas = 1.0 - self.betas
         self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
         self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]

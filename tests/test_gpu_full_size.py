@@ -180,5 +180,6 @@ def test_train_step_32x512x512_fp8_temporal_attention():
           f"grad rel-inf fp8 vs bf16 {rel_inf(g_f8, g_bf):.3e}")
     assert np.isfinite(loss_bf) and np.isfinite(loss_f8) and torch.isfinite(g_bf).all() and torch.isfinite(g_f8).all()
     assert g_bf.numel() == g_f8.numel() and float(g_bf.norm()) > 0
-    assert abs(loss_f8 - loss_bf) <= 3e-2 * abs(loss_bf)
-    assert rel_inf(g_f8, g_bf) < 3e-2 * 10                    # gradients: the fp8 forward error enters ~60 layers deep (measured 1e-2 at the reduced width)
+    # bounds = measured x 2 (MI355X, two boxes of round 4: loss 3.8e-4 / 8.6e-5 relative, gradients 2.22e-2 / 2.13e-2 rel-inf; gpurun_out/r04f, r04g)
+    assert abs(loss_f8 - loss_bf) <= 8e-4 * abs(loss_bf)
+    assert rel_inf(g_f8, g_bf) < 4.5e-2                       # gradients: the fp8 forward error enters ~60 layers deep
