@@ -131,7 +131,8 @@ def synthetic_inputs(rank, device):
 # Kernel sources whose hash keys the recorded hardware counters (profiles/roofline_counters.json, written by
 # tools/collect_roofline_counters.py on a GPU box): a counter is printed only while the kernel it was collected on is the kernel
 # in this tree -- it cannot silently go stale with the next kernel change.
-_KERNEL_SOURCES = {"sa40d": ("spatial_attn.hip", "attn_common.h", "common.h"),
+_KERNEL_SOURCES = {"conv_halo_l0": ("conv_halo.hip", "common.h"), "conv_halo_l1": ("conv_halo.hip", "common.h"),
+                   "sa40d": ("spatial_attn.hip", "attn_common.h", "common.h"),
                    "temporal": ("temporal_attn.hip", "attn_common.h", "common.h"),
                    "conv": ("gemm_conv.hip", "common.h"),
                    "proj": ("temporal_block640.hip", "gemm_conv.hip", "common.h"),
@@ -194,38 +195,64 @@ def measure_attention_roofline(device, dtype, iters=20, clips=2):
     # tools/collect_roofline_counters.py (separate rocprofv3 --pmc passes) and only quoted for the kernel sources they were taken on
     if (B, S) == (32, 2560):                          # (the counters were collected on the metric's launch shape)
         out.update(recorded_counters("sa40d"))
+    out["_match"] = ("name", "sa40d_kernel")
     return out
 
 
-def measure_conv_roofline(device, dtype, iters=20):
-    """The GEMM / conv kernels are where most of the step goes (78 %): one of their launches exactly as the U-Net issues it
-    (level-1 ResNet conv, CFG batch 2 x 16 frames of 20x32, 640 -> 640) through the same front-end, i.e. on the arm the
-    per-shape autotuner chose for it (reported), for the record next to the attention roofline the north-star asks for."""
-    from synfmc_amd import hip_ops as K
-    n, h, w, ci, co = 2 * FRAMES, HEIGHT // 16, WIDTH // 16, WIDTHS[1], WIDTHS[1]
-    x = torch.randn(n, h, w, ci, device=device, dtype=dtype).permute(0, 3, 1, 2)        # logical NCHW over channels-last storage
-    wt = (torch.randn(co, ci, 3, 3, device=device, dtype=dtype) * 0.02).contiguous(memory_format=torch.channels_last)
-    for _ in range(3):
-        K.conv3x3(x, wt, None)
-    arm = K._choice.get(("conv", n, h, w, ci, co, False, False, False, False))
+def _time_launch(run, iters=20, warm=3):
+    for _ in range(warm):
+        run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        K.conv3x3(x, wt, None)
+        run()
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
+    return e0.elapsed_time(e1) / iters
+
+
+def measure_conv_roofline(device, dtype, level=1, iters=20):
+    """The 3x3 convolutions are the largest block of the step: one of their launches exactly as the U-Net issues it -- `level` 1: ResNet conv of the
+    20x32 level (CFG batch 2 x 16 frames, 640 -> 640), `level` 0: of the 40x64 level (320 -> 320) -- through the same front-end
+    (`hip_ops.conv3x3`), i.e. on the kernel the dispatch picks for it (reported).  Algorithmic flops 2 M Cout 9 Cin; algorithmic bytes x + w + out."""
+    from synfmc_amd import hip_ops as K
+    d = 16 if level == 1 else 8
+    n, h, w, ci, co = 2 * FRAMES, HEIGHT // d, WIDTH // d, WIDTHS[level], WIDTHS[level]
+    x = torch.randn(n, h, w, ci, device=device, dtype=dtype).permute(0, 3, 1, 2)        # logical NCHW over channels-last storage
+    wt = (torch.randn(co, ci, 3, 3, device=device, dtype=dtype) * 0.02).contiguous(memory_format=torch.channels_last)
+    halo0 = K.conv_halo_calls["conv"]
+    ms = _time_launch(lambda: K.conv3x3(x, wt, None), iters)
+    halo = K.conv_halo_calls["conv"] > halo0
+    arm = "halo" if halo else K._choice.get(("conv", n, h, w, ci, co, False, False, False, False))
     flops = 2.0 * n * h * w * 9 * ci * co
     achieved = flops / (ms * 1e-3) / 1e12
-    names = {0: "vendor library", 3: "gemm_kernel<conv3x3,256x256,16 waves>", 13: "gemm8_kernel<conv3x3,256x256,8-phase>",
+    names = {"halo": "conv_halo_kernel<plain> (input halo resident in LDS, W-only LDS-DMA stream, 10x32 pixel x 160 channel tiles)",
+             0: "vendor library", 3: "gemm_kernel<conv3x3,256x256,16 waves>", 13: "gemm8_kernel<conv3x3,256x256,8-phase>",
              141: "gemm8_kernel<conv3x3,8-phase,stream-K>"}
     out = {"bound": "mfma", "kernel": f"{names.get(arm, f'fmc_conv3x3_bf16 arm {arm}')} [{n}x{h}x{w}, {ci}->{co}]",
            "autotuned_arm": arm, "achieved": round(achieved, 2),
            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
            "avg_launch_ms": round(ms, 4), "flops_per_launch": flops,
-           "traffic_algorithmic": 2.0 * (n * h * w * (ci + co) + 9 * ci * co)}
-    out.update(recorded_counters("conv"))
+           "traffic_algorithmic": 2.0 * (n * h * w * (ci + co) + 9 * ci * co),
+           "_match": ("conv_halo", (n, h, w, ci, co, False)) if halo else None}
+    out.update(recorded_counters("conv_halo_l%d" % level if halo else "conv"))
     return out
+
+
+def measure_groupnorm_roofline(device, dtype, iters=30):
+    """GroupNorm(32) + SiLU of the 40x64 level as the step runs it behind a halo convolution: the statistics arrive from the producing conv's
+    epilogue, the launch is the apply pass alone (`fmc_groupnorm_apply_fwd`: read x, write silu(norm(x))).  HBM bound: 2 N HW C e bytes."""
+    from synfmc_amd import hip_ops as K
+    n, hw, C = 2 * FRAMES, (HEIGHT // 8) * (WIDTH // 8), WIDTHS[0]
+    x = torch.randn(n, hw, C, device=device, dtype=dtype)
+    g, b = torch.randn(C, device=device) * 0.2 + 1, torch.randn(C, device=device) * 0.1
+    part = K.groupnorm_partials(x, 32)
+    ms = _time_launch(lambda: K.groupnorm_apply(x, g, b, 32, 1e-5, True, part), iters)
+    nbytes = 2.0 * n * hw * C * 2
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": f"gn_apply_fwd_kernel<bf16> (GroupNorm + SiLU apply pass, statistics from the producer's epilogue) [{n}x{hw}x{C}]",
+            "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "avg_launch_ms": round(ms, 5),
+            "bytes_per_launch": nbytes, "traffic": None, "_match": ("name", "gn_apply_fwd_kernel", n * hw * C)}
 
 
 def measure_proj_roofline(device, dtype, iters=20):
@@ -269,6 +296,7 @@ def measure_proj_roofline(device, dtype, iters=20):
            "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
            "avg_launch_ms": round(ms, 4), "flops_per_launch": flops, "traffic_algorithmic": 2.0 * (M * Kd + N * Kd + M * N // 2)}
     out.update(recorded_counters("proj"))
+    out["_match"] = ("name", "geglu_direct_kernel<640>") if direct else None
     return out
 
 
@@ -306,6 +334,7 @@ def measure_temporal_block_l1_roofline(device, dtype, iters=20):
            "avg_launch_ms": round(ms, 4), "flops_per_launch": flops, "traffic_algorithmic": 3.0 * M * C * 2,
            "replaces": "LayerNorm + merge GEMM + fused QKV GEMM + temporal_attn_kernel + out-projection GEMM (5 launches, ~160 us)"}
     out.update(recorded_counters("tblock640"))
+    out["_match"] = ("name", "temporal_block640_kernel<true, false>")
     return out
 
 
@@ -345,6 +374,118 @@ def measure_temporal_block_roofline(device, dtype, iters=20):
            "avg_launch_ms": round(ms, 4), "flops_per_launch": flops, "traffic_algorithmic": 3.0 * M * C * 2,
            "replaces": "LayerNorm epilogue + merge GEMM + fused QKV GEMM + temporal_attn_kernel + out-projection GEMM (4 launches, ~790 MB of HBM traffic)"}
     out.update(recorded_counters("tblock"))
+    out["_match"] = ("name", "temporal_block_kernel<true, false, false>")
+    return out
+
+
+def in_step_trace(args, cfg, nsteps=4):
+    """Per-launch kernel durations INSIDE the denoising step: this same command (fewer steps, no oracle, no roofline loops) run once more as a
+    child process under `rocprofv3 --kernel-trace`, cut to the window of its last `nsteps` steps (between `cfg_ddim_kernel` dispatches).  The
+    isolated roofline loops above flatter or punish a kernel by up to 20 % (warm weights, DVFS in a back-to-back loop): `frac` of every roofline
+    object is computed from THIS window when it is available.  Returns ([per step: [(kernel name, grid x, workgroup x, us)] in launch order], note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="fmc_in_step_", dir="/tmp")
+    cmd = ["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "t", "--", sys.executable, os.path.abspath(__file__),
+           "--steps", str(nsteps + 2), "--warmup", "2", "--trace-child", "--config", cfg, "--guidance", str(args.guidance), "--dtype", args.dtype]
+    if args.no_cfg_shared:
+        cmd.append("--no-cfg-shared")
+    if args.fp8_temporal:
+        cmd.append("--fp8-temporal")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        files = glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return None, f"trace child failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-300:]}"
+        rows = list(csv.DictReader(open(files[0])))
+    except Exception as e:                                  # the trace is evidence, never a reason to lose the bench line
+        return None, f"trace child: {type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    ends = [int(r["End_Timestamp"]) for r in rows if "cfg_ddim" in r["Kernel_Name"]]
+    if len(ends) < nsteps + 1:
+        return None, f"only {len(ends)} step boundaries in the trace"
+    steps = []
+    for a, b in zip(ends[-nsteps - 1:-1], ends[-nsteps:]):
+        steps.append([(r["Kernel_Name"], int(r.get("Grid_Size_X", 0) or 0), int(r.get("Workgroup_Size_X", 0) or 0),
+                       (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+                      for r in rows if int(r["Start_Timestamp"]) > a and int(r["End_Timestamp"]) <= b])
+    return steps, f"rocprofv3 --kernel-trace of a child run of this command, last {nsteps} steps"
+
+
+def apply_in_step(obj, steps, call_log):
+    """Add `in_step_avg_ms` / `in_step_calls_per_step` to one roofline object and recompute `frac` from it (the isolated loop's figure stays as
+    `frac_isolated`).  `_match`: ("name", substring[, grid x]) = every in-window launch of that kernel, or ("conv_halo", shape) = the launches the
+    recorded call order of one eager step (`call_log`) assigns to that shape."""
+    if obj is None:
+        return None
+    match = obj.pop("_match", None)
+    if steps is None or match is None:
+        obj["in_step_avg_ms"] = None
+        return obj
+    us = []
+    if match[0] == "name":
+        for st in steps:
+            us += [d for name, gx, wx, d in st if match[1] in name]
+    else:
+        order = [shape for fe, shape, _ in call_log if fe == match[0]]
+        for st in steps:
+            ks = [d for name, gx, wx, d in st if "conv_halo_kernel" in name]
+            if len(ks) == len(order):
+                us += [d for d, shape in zip(ks, order) if shape == tuple(match[1])]
+    if not us:
+        obj["in_step_avg_ms"] = None
+        obj["in_step_note"] = "the step does not launch this kernel on this shape (fused away or another arm)"
+        return obj
+    ms = sum(us) / len(us) / 1e3
+    obj["in_step_avg_ms"] = round(ms, 4)
+    obj["in_step_calls_per_step"] = round(len(us) / len(steps), 2)
+    work = obj.get("flops_per_launch", obj.get("bytes_per_launch"))
+    scale = 1e12 if obj["unit"] == "TFLOP/s" else 1e9
+    obj["frac_isolated"] = obj["frac"]
+    obj["achieved_isolated"] = obj["achieved"]
+    obj["achieved"] = round(work / (ms * 1e-3) / scale, 2)
+    obj["frac"] = round(obj["achieved"] / obj["peak"], 4)
+    return obj
+
+
+def step_kernel_families(steps, call_log):
+    """ms per step by kernel family + the halo convolutions' aggregate rate (their shapes from the recorded call order), from the in-step window."""
+    if steps is None:
+        return None
+    fam = (("conv3x3 (conv_halo_kernel)", ("conv_halo_kernel",)), ("conv3x3 / linear (gemm*_kernel, sk_finish)", ("gemm", "sk_finish", "splitk")),
+           ("vendor GEMM (hipBLASLt Cijk_*)", ("Cijk_",)), ("geglu_direct", ("geglu_direct",)), ("spatial attention", ("sa40d", "spatial_attn")),
+           ("temporal block / attention", ("temporal_block", "temporal_attn")), ("text cross-attention block", ("xattn",)),
+           ("groupnorm", ("gn_",)), ("layernorm", ("layernorm",)), ("torch elementwise / copy / cat", ("at::", "elementwise", "CatArray")))
+    tot = {k: 0.0 for k, _ in fam}
+    tot["other"] = 0.0
+    calls = 0
+    for st in steps:
+        for name, gx, wx, d in st:
+            calls += 1
+            for k, subs in fam:
+                if any(x in name for x in subs):
+                    tot[k] += d
+                    break
+            else:
+                tot["other"] += d
+    n = len(steps)
+    out = {"ms_per_step": {k: round(v / n / 1e3, 3) for k, v in tot.items()}, "launches_per_step": round(calls / n, 1)}
+    fl = sum(f for fe, _, f in call_log if fe == "conv_halo")
+    ms = tot["conv3x3 (conv_halo_kernel)"] / n / 1e3
+    if fl and ms:
+        out["conv_halo_all_launches"] = {"launches_per_step": sum(1 for fe, _, _ in call_log if fe == "conv_halo"), "tflop_per_step": round(fl / 1e12, 3),
+                                         "ms_per_step": round(ms, 3), "achieved": round(fl / (ms * 1e-3) / 1e12, 1),
+                                         "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "unit": "TFLOP/s"}
     return out
 
 
@@ -394,6 +535,7 @@ def measure_temporal_roofline(device, dtype, iters=50):
            "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
            "avg_launch_ms": round(ms, 5), "bytes_per_launch": nbytes}
     out.update(recorded_counters("temporal"))
+    out["_match"] = ("name", f"temporal_attn_kernel<unsigned short, 1, {D // 8},")     # (the step launches this kernel only where the block is not fused)
     return out
 
 
@@ -804,6 +946,8 @@ def main():
                          "fp8 temporal attention; = --mode train --clip 32x512x512 --fp8-temporal)")
     ap.add_argument("--no-cfg-shared", action="store_true", help="A/B: compute the CFG batch's identical prefix (conv_in, first ResNet block, "
                     "first self-attention) for both halves instead of once")
+    ap.add_argument("--no-in-step", action="store_true", help="skip the in-step kernel trace (a child run of this command under rocprofv3 --kernel-trace)")
+    ap.add_argument("--trace-child", action="store_true", help="internal: the child run of the in-step trace (no oracle, no roofline loops, no trace)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo stub of the launcher + timing + JSON plumbing (tests)")
     args = ap.parse_args()
     if args.dry_run:
@@ -907,7 +1051,7 @@ def main():
         # does not reproduce the oracle never prints a throughput line; an oracle that throws takes the run down with it.  Runs at
         # N = 1 (where `cpu_baseline` is reported); at N > 1 no rank waits 45 s in a barrier for rank 0's CPU forward -- every rank's
         # kernels are the ones gated at N = 1, and the ranks check their outputs for finiteness.
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.trace_child:
             t_par = 801
             eps_gpu = unet_step(torch.cat([latents, latents]).to(dtype), t_par).float().cpu()
             eps_ref, cpu = oracle_step(unet, enc, ada, clip, text2, clip["latents"].float(), t_par, config=cfg)
@@ -933,7 +1077,7 @@ def main():
         assert torch.isfinite(latents).all(), "non-finite latents"
 
         loop50_s = None
-        if cfg == "lora" and rank == 0:
+        if cfg == "lora" and rank == 0 and not args.trace_child:
             # the configuration's own workload end to end: AnimationPipeline's 50-step DDIM loop on this clip (latents out; VAE / CLIP are
             # outside the path), graphs already warm from a first call
             from synfmc_amd.pipelines.pipeline_animation_cm_om import AnimationPipeline
@@ -948,14 +1092,37 @@ def main():
             loop50_s = time.perf_counter() - t0
             assert torch.isfinite(torch.as_tensor(out50.videos)).all()
 
+    if rank == 0 and args.trace_child:
+        print(json.dumps({"trace_child": True, "ms_per_step": round(elapsed / args.steps * 1e3, 3)}), flush=True)
+        return
     if rank == 0:
         bf = dtype == torch.bfloat16
+        # one EAGER step of exactly what the graph replays: which front-end calls went to an own kernel / the vendor arm / fell through as
+        # ineligible, and the order and shapes of the halo convolutions (to assign the in-step trace's launches to shapes)
+        K.call_log = []
+        d0 = {k: dict(v) for k, v in K.dispatch_calls.items()}
+        with torch.no_grad():
+            if args.no_graph:
+                unet_step(torch.cat([latents, latents]).to(dtype), ts[0])
+            else:
+                runner._call()
+        torch.cuda.synchronize()
+        call_log, K.call_log = K.call_log, None
+        dispatch = {k: {a: K.dispatch_calls[k][a] - d0[k][a] for a in v} for k, v in K.dispatch_calls.items()}
+        K.save_autotune_table()                         # (the trace child reads the arm table this process tuned)
         roof = measure_attention_roofline(device, dtype) if bf else None
-        roof_conv = measure_conv_roofline(device, dtype) if bf else None
+        roof_conv = measure_conv_roofline(device, dtype, 1) if bf else None
+        roof_conv0 = measure_conv_roofline(device, dtype, 0) if bf else None
+        roof_gn = measure_groupnorm_roofline(device, dtype) if bf else None
         roof_temp = measure_temporal_roofline(device, dtype) if bf else None
         roof_proj = measure_proj_roofline(device, dtype) if bf else None
         roof_tb = measure_temporal_block_roofline(device, dtype) if bf else None
         roof_tb1 = measure_temporal_block_l1_roofline(device, dtype) if bf else None
+        steps_tr, tr_note = (None, "skipped (--no-in-step / N > 1 / fp32)") if (args.no_in_step or world > 1 or not bf) else in_step_trace(args, cfg)
+        roofs = [roof, roof_conv, roof_conv0, roof_gn, roof_temp, roof_proj, roof_tb, roof_tb1]
+        for o in roofs:
+            apply_in_step(o, steps_tr, call_log)
+        families = step_kernel_families(steps_tr, call_log)
         f_ref = unet_flops(2, HEIGHT // 8, WIDTH // 8, config=cfg)
         f_exec = unet_flops(2, HEIGHT // 8, WIDTH // 8, executed=True, config=cfg)
         if cfg_shared:                                  # one clip's worth of conv_in, ResNet block 0, proj_in, QKV, self-attention, out-projection
@@ -984,7 +1151,12 @@ def main():
             "conditioning_once_per_clip_ms": round(cond_ms, 2),
             "conditioning_note": (f"Pluecker + camera encoder + OMC rasteriser / adapter + text k | v of {n_text_layers} cross-attention layers "
                                   f"({round(text_ms, 2)} ms); none of it runs inside a step"),
-            "roofline": roof, "roofline_conv": roof_conv, "roofline_temporal": roof_temp, "roofline_temporal_block": roof_tb, "roofline_temporal_block_l1": roof_tb1, "roofline_proj": roof_proj,
+            "roofline": roof, "roofline_conv": roof_conv, "roofline_conv_l0": roof_conv0, "roofline_groupnorm": roof_gn, "roofline_temporal": roof_temp,
+            "roofline_temporal_block": roof_tb, "roofline_temporal_block_l1": roof_tb1, "roofline_proj": roof_proj,
+            "in_step_source": tr_note, "in_step_kernel_families": families,
+            "step_dispatch": {"note": "front-end calls of one step: own kernel / autotuner chose the vendor arm / shape outside the own kernels "
+                                      "(fell through to the vendor library)", **dispatch,
+                              "halo_convs_per_step": sum(1 for fe, _, _ in call_log if fe == "conv_halo")},
             "cpu_baseline": cpu,
         }
         if loop50_s is not None:

@@ -1554,6 +1554,8 @@ def conv3x3_halo(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias=None, temb=
     part = torch.empty(n, L.fmc_conv3x3_halo_tiles_per_image(h, w), 32, 2, dtype=torch.float32, device=x_nhwc.device) if emit_gn else None
     conv_halo_calls["conv"] += 1
     conv_halo_calls["gn_fused"] += gn_coef is not None
+    if call_log is not None:
+        call_log.append(("conv_halo", (n, h, w, cin, cout, bool(upsample)), 2.0 * n * h * w * cout * 9 * cin))
     _lib.check(L.fmc_conv3x3_halo_bf16(x_nhwc.data_ptr(), _p(x2_nhwc), c1, wp.data_ptr(), _p(bias), _p(temb), _p(residual_nhwc), out.data_ptr(),
                                        n, h, w, cin, cout, 0 if temb is None else temb.stride(0), int(temb_div), int(upsample), _p(gn_coef),
                                        int(gn_act), _p(part), _stream()), "fmc_conv3x3_halo_bf16")
@@ -1832,6 +1834,10 @@ def _time_ms(fn, reps=8):
 
 
 NO_VENDOR = os.environ.get("FMC_NO_VENDOR", "0") == "1"      # A/B switch: the vendor library (hipBLASLt / MIOpen) is never a candidate arm
+# where the calls of the three GEMM-shaped front-ends went (bench.py counts one eager step): "own" = a kernel of this library, "vendor" = the
+# autotuner chose the vendor arm, "ineligible" = the shape / dtype / layout is outside the own kernels and the call fell through to the library
+dispatch_calls = {k: {"own": 0, "vendor": 0, "ineligible": 0} for k in ("linear", "geglu", "conv3x3")}
+call_log = None                     # a list while bench.py records one eager step: (front-end, shape tuple, algorithmic flops) per launch
 
 
 def _pick(key, hip_fn, lib_fn, static_hip: bool, extra_arms=(), k320: bool = False, own_only: bool = False) -> int:
@@ -1868,6 +1874,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     if pend is not None:                                # x's LayerNorm is still to be applied (LayerNorm.forward(defer=True))
         if (x2 is None and residual is None and residual2 is None and alpha == 1.0 and not gn_hw and ln is None and weight.is_contiguous()
                 and lnc_ok(x, weight)):
+            dispatch_calls["linear"]["own"] += 1
             return linear_lnc(x, weight, bias, pend)
         x = resolve_pending_ln(x)
 
@@ -1892,15 +1899,18 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     else:
         ok = ok and x.shape[-1] % 64 == 0 and x2.dtype == x.dtype and x2.is_contiguous()
     if not ok or (x.ndim > 2 and not x.is_contiguous()):
+        dispatch_calls["linear"]["ineligible"] += 1
         return lib()
     M = x.numel() // x.shape[-1]
     if ln is not None and x2 is None and not gn_hw and ln_emit_ok(x, weight, residual, residual2, ln):
         # the consumer is a LayerNorm and the 160 x 320 tile holds whole rows (N == 320): it leaves the epilogue too, x is not read again
+        dispatch_calls["linear"]["own"] += 1
         return linear_ln(x, weight, bias, residual, alpha, residual2, ln)
     if (gn_hw and x2 is None and x.is_contiguous() and gn_emit_ok(M, N, Kd, gn_hw, x.dtype)
             and (residual is None or (residual.is_contiguous() and residual.dtype == x.dtype))
             and (residual2 is None or residual2.is_contiguous())):
         # the consumer is a GroupNorm at a level where it would read x twice: the 160 x 320 kernel emits the statistics from its epilogue
+        dispatch_calls["linear"]["own"] += 1
         return linear_gn(x, weight, bias, residual, alpha, residual2, gn_hw)
     key = ("lin", M, N, Kd, bias is not None, (residual is not None) + (residual2 is not None),
            0 if x2 is None else x.shape[-1])
@@ -1911,9 +1921,11 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     if (use == 0 and lazy_residual and LAZY_RESIDUAL and residual is not None and residual2 is None and alpha == 1.0 and x2 is None
             and N in (320, 640, 1280) and residual.is_contiguous() and not torch.is_grad_enabled()):
         # vendor arm: the caller's next op is a LayerNorm of `y + residual` (LayerNorm.skip): it does the add in its own pass
+        dispatch_calls["linear"]["vendor"] += 1
         y = F.linear(x, weight, bias)
         y._fmc_pending_add = residual
         return y
+    dispatch_calls["linear"]["vendor" if use == 0 else "own"] += 1
     return lib() if use == 0 else hip(max(use, 0))
 
 
@@ -1937,6 +1949,7 @@ def geglu_linear(x: torch.Tensor, weight: torch.Tensor, bias, weight_il: torch.T
             return linear_f32(x, weight_il160, bias_il160, geglu=True, tile=ARM_160)
         return linear_f32(x, weight_il, bias_il, geglu=True, tile=0 if arm in (ARM_160, ARM_160B) else arm)
     if not linear_supported(x, weight_il) or weight_il.shape[0] % 64 or (x.ndim > 2 and not x.is_contiguous()):
+        dispatch_calls["geglu"]["ineligible"] += 1
         return lib()
     N, Kd = weight.shape
     M = x.numel() // Kd
@@ -1949,6 +1962,7 @@ def geglu_linear(x: torch.Tensor, weight: torch.Tensor, bias, weight_il: torch.T
     # (ARM_256, the persistent 256 x 320 form, is selectable but not a candidate: measured 235 / 153 / 134 us against ARM_160's 203 / 153 / 130 us on
     #  the three U-Net levels, tools/scratch/probe_g256.py -- DESIGN.md section 6, round 3.  FMC_GEMM_ARMS=...,528 offers it.)
     use = _pick(("geglu", M, N, Kd), hip, lib, M >= 65536)
+    dispatch_calls["geglu"]["vendor" if use == 0 else "own"] += 1
     return lib() if use == 0 else hip(max(use, 0))
 
 
@@ -1981,12 +1995,14 @@ def conv3x3(x_nchw: torch.Tensor, weight_cl: torch.Tensor, bias, temb=None, resi
             return conv3x3_f32(x, weight_cl, bias, temb, r, tile=_f32_arm(key, 0), temb_div=temb_div, upsample=upsample,
                                stride2=s2).permute(0, 3, 1, 2)
     if not conv3x3_supported(x_nchw, weight_cl, stride, padding):
+        dispatch_calls["conv3x3"]["ineligible"] += 1
         return lib()
     n, cin, h, w = x_nchw.shape
     cout = weight_cl.shape[0]
     x = x_nchw.permute(0, 2, 3, 1)
     r = None if residual_nchw is None else residual_nchw.permute(0, 2, 3, 1)
     if not x.is_contiguous() or (r is not None and not r.is_contiguous()):
+        dispatch_calls["conv3x3"]["ineligible"] += 1
         return lib()
     if upsample:
         h, w = 2 * h, 2 * w
@@ -1998,6 +2014,7 @@ def conv3x3(x_nchw: torch.Tensor, weight_cl: torch.Tensor, bias, temb=None, resi
     if (CONV_HALO and not stride2 and (temb is None or temb.stride(1) == 1) and conv3x3_halo_supported(n, h, w, cin, cin, cout, upsample)
             and n * _lib.load().fmc_conv3x3_halo_tiles_per_image(h, w) * (cout // 160) >= CONV_HALO_MIN_TILES):
         want = bool(emit_gn and GN_EPILOGUE and cout % 64 == 0 and 160 % (cout // 32) == 0 and not torch.is_grad_enabled())
+        dispatch_calls["conv3x3"]["own"] += 1
         y = conv3x3_halo(x, weight_cl, bias, temb, r, temb_div, upsample, emit_gn=want)
         if want:
             y, part = y
@@ -2007,6 +2024,7 @@ def conv3x3(x_nchw: torch.Tensor, weight_cl: torch.Tensor, bias, temb=None, resi
             return y
         return y.permute(0, 3, 1, 2)
     if emit_gn and gn_emit_ok(n * h * w, cout, 9 * cin, h * w, x.dtype):
+        dispatch_calls["conv3x3"]["own"] += 1
         y, tag = conv3x3_gn(x, weight_cl, bias, temb, r, temb_div, upsample, stride2)
         y = y.permute(0, 3, 1, 2)
         y._fmc_gn = tag
@@ -2016,6 +2034,7 @@ def conv3x3(x_nchw: torch.Tensor, weight_cl: torch.Tensor, bias, temb=None, resi
                                     upsample=upsample, stride2=stride2).permute(0, 3, 1, 2)
     tiles = ((n * h * w + 127) // 128) * ((cout + 127) // 128)
     use = _pick(key, hip, lib, tiles >= 256, split_arms(n * h * w, cout, 9 * cin), own_only=own_only)
+    dispatch_calls["conv3x3"]["vendor" if use == 0 else "own"] += 1
     return lib() if use == 0 else hip(max(use, 0))
 
 

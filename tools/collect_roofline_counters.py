@@ -21,11 +21,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "gpurun_out", "roofline_pmc")
 GROUPS = ["FETCH_SIZE", "WRITE_SIZE", "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE"]
-KERNELS = {"sa40d": "sa40d_kernel", "temporal": "temporal_attn_kernel", "conv": "gemm", "proj": "gemm160p", "tblock": "temporal_block_kernel", "tblock640": "temporal_block640_kernel"}
+KERNELS = {"sa40d": "sa40d_kernel", "temporal": "temporal_attn_kernel", "conv": "gemm", "conv_halo_l1": "conv_halo_kernel", "conv_halo_l0": "conv_halo_kernel",
+           "proj": "gemm160p", "tblock": "temporal_block_kernel", "tblock640": "temporal_block640_kernel"}
 # (the conv probe is the only gemm* launch with MODE 1, the GEGLU projection probe the only one with MODE 0)
 
 
-def which(name):
+def which(name, row=None):
+    if "conv_halo_kernel" in name:                 # the two probes differ in their grid: 256 workgroups (20x32 level) / 512 (40x64 level) of 512 threads
+        gs = 0
+        for key in ("Grid_Size", "Grid_Size_X"):
+            if row is not None and row.get(key):
+                gs = int(row[key])
+                break
+        return {256 * 512: "conv_halo_l1", 512 * 512: "conv_halo_l0"}.get(gs)
     if "sa40d_kernel" in name:
         return "sa40d"
     if "temporal_attn_kernel" in name:
@@ -54,12 +62,12 @@ def main():
             subprocess.run(cmd, env=env, stdout=log, stderr=subprocess.STDOUT, timeout=900, check=False)
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
-                k = which(r["Kernel_Name"])
+                k = which(r["Kernel_Name"], r)
                 if k:
                     vals[k][(r["Counter_Name"], r["Kernel_Name"])].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
         for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
-                k = which(r["Kernel_Name"])
+                k = which(r["Kernel_Name"], r)
                 if k and i == 2:
                     dur[k, r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
             if os.path.getsize(f) > (1 << 20):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""The six `roofline*` launches of bench.py, exactly as bench.py issues them, 12 times each: the target of the rocprofv3 counter
+"""The `roofline*` launches of bench.py, exactly as bench.py issues them, 12 times each: the target of the rocprofv3 counter
 passes of tools/collect_roofline_counters.py."""
 import os
 import sys
@@ -11,7 +11,9 @@ import bench
 
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
-for fn in (bench.measure_attention_roofline, bench.measure_temporal_roofline, bench.measure_conv_roofline, bench.measure_proj_roofline,
+for fn in (bench.measure_attention_roofline, bench.measure_temporal_roofline, bench.measure_proj_roofline,
            bench.measure_temporal_block_roofline, bench.measure_temporal_block_l1_roofline):
     fn(dev, torch.bfloat16, iters=12)
+bench.measure_conv_roofline(dev, torch.bfloat16, 1, iters=12)
+bench.measure_conv_roofline(dev, torch.bfloat16, 0, iters=12)
 torch.cuda.synchronize()
