@@ -195,7 +195,7 @@ def measure_attention_roofline(device, dtype, iters=20, clips=2):
     # tools/collect_roofline_counters.py (separate rocprofv3 --pmc passes) and only quoted for the kernel sources they were taken on
     if (B, S) == (32, 2560):                          # (the counters were collected on the metric's launch shape)
         out.update(recorded_counters("sa40d"))
-    out["_match"] = ("name", "sa40d_kernel")
+    out["_match"] = ("name", "sa40d_kernel", "maxgrid")
     return out
 
 
@@ -252,7 +252,7 @@ def measure_groupnorm_roofline(device, dtype, iters=30):
     gbs = nbytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": f"gn_apply_fwd_kernel<bf16> (GroupNorm + SiLU apply pass, statistics from the producer's epilogue) [{n}x{hw}x{C}]",
             "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "avg_launch_ms": round(ms, 5),
-            "bytes_per_launch": nbytes, "traffic": None, "_match": ("name", "gn_apply_fwd_kernel", n * hw * C)}
+            "bytes_per_launch": nbytes, "traffic": None, "_match": ("name", "gn_apply_fwd_kernel", "grid", 12960 if (hw, C) == (2560, 320) else -1)}
 
 
 def measure_proj_roofline(device, dtype, iters=20):
@@ -434,8 +434,13 @@ def apply_in_step(obj, steps, call_log):
         return obj
     us = []
     if match[0] == "name":
-        for st in steps:
-            us += [d for name, gx, wx, d in st if match[1] in name]
+        hits = [(gx, d) for st in steps for name, gx, wx, d in st if match[1] in name]
+        if len(match) > 3 and match[2] == "grid":                # one shape of a kernel that serves several: its grid (threads in x)
+            hits = [h for h in hits if h[0] == match[3]]
+        if len(match) > 2 and match[2] == "maxgrid" and hits:    # the launches of the FULL batch (the CFG-shared prefix runs the same kernel on half of it)
+            g = max(gx for gx, _ in hits)
+            hits = [h for h in hits if h[0] == g]
+        us = [d for _, d in hits]
     else:
         order = [shape for fe, shape, _ in call_log if fe == match[0]]
         for st in steps:
@@ -535,7 +540,8 @@ def measure_temporal_roofline(device, dtype, iters=50):
            "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
            "avg_launch_ms": round(ms, 5), "bytes_per_launch": nbytes}
     out.update(recorded_counters("temporal"))
-    out["_match"] = ("name", f"temporal_attn_kernel<unsigned short, 1, {D // 8},")     # (the step launches this kernel only where the block is not fused)
+    out["_match"] = None               # (at this level the step runs the attention inside temporal_block_kernel: `roofline_temporal_block`)
+    out["in_step_note"] = "not launched by the step at this level (fused into temporal_block_kernel); the isolated loop is the only measurement"
     return out
 
 

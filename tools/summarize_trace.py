@@ -41,7 +41,11 @@ def main(path, nsteps=4):
     print(f"window: {nsteps} steps, {(t1 - t0) / 1e6 / nsteps:.3f} ms/step wall, {busy / 1e6 / nsteps:.3f} ms/step kernel-busy\n")
     cat = collections.defaultdict(float)
     for k, (d, c) in agg.items():
-        if "gemm160p_kernel" in k:
+        if "conv_halo_kernel" in k:
+            cat["conv3x3 (fmc conv_halo_kernel, halo resident in LDS)"] += d
+        elif "sk_finish" in k:
+            cat["conv3x3 (fmc sk_finish_kernel, stream-K finishing pass)"] += d
+        elif "gemm160p_kernel" in k:
             cat["linear (fmc gemm160p_kernel, persistent 160x320)"] += d
         elif "gemm160_kernel<1" in k:
             cat["conv3x3 (fmc gemm160_kernel, 160x320)"] += d
