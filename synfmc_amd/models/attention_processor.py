@@ -52,6 +52,15 @@ def _attention_core(attn, q_in: torch.Tensor, kv_in: Optional[torch.Tensor], tem
     elif kv_in is None:                                 # self attention: one [.., 3C] GEMM
         qkv = linear_op(q_in, w_a)
         o = K.self_attention_qkv(qkv, heads, attn.scale, temporal)      # q | k | v stay slices of the fused output
+    elif w_b is None:
+        # a SELF-attention module whose query and key / value inputs differ: the q-only / kv-only Camera-Adapter merge (reference
+        # attention_processor.py:193-200, :259-265 -- `q_merge` / `kv_merge`; un-shipped configurations).  The fused [3C, C] weight is used as its
+        # q rows and its k | v rows on the two inputs; the results are laid side by side so that the fused-QKV attention front-end (and its
+        # backward) serves spatial and temporal tokens alike
+        C = attn.inner_dim
+        assert q_in.shape == kv_in.shape, "q-only / kv-only pose merge: query and key / value tokens must have the same shape"
+        qkv = torch.cat([linear_op(q_in, w_a[:C]), linear_op(kv_in, w_a[C:])], dim=-1)
+        o = K.self_attention_qkv(qkv, heads, attn.scale, temporal)
     else:                                               # cross attention: q GEMM + one [.., 2C] kv GEMM
         assert not temporal
         q = linear_op(q_in, w_a)
@@ -223,9 +232,6 @@ class PoseAdaptorAttnProcessor(nn.Module, _PoseMerge):
             assert encoder_hidden_states is None
         ctx = x if encoder_hidden_states is None else _tok(encoder_hidden_states)
         q_in, kv_in = self._merge(x, ctx, _pose_tokens(pose_feature, x), s)
-        if not (self.query_condition and self.key_value_condition) and encoder_hidden_states is None:
-            raise NotImplementedError("q-only / kv-only pose merge on self attention needs un-fused projections; "
-                                      "the shipped FMC configs use query_condition = key_value_condition = True")
         out = _attention_core(attn, q_in, kv_in, temporal, residual=_fusable(attn, _residual, shape4))
         return _finish(attn, out, hidden_states, shape4)
 

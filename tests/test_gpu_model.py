@@ -790,3 +790,40 @@ def test_text_kv_is_projected_once_per_clip(C, hw):
             assert "_text_kv" not in blk.attn2.__dict__
     finally:
         L.K.DETERMINISTIC = det
+
+
+@pytest.mark.parametrize("which", ["q", "kv"])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
+def test_pose_adaptor_q_only_and_kv_only_merge_on_self_attention(which, dtype, tol):
+    """`PoseAdaptorAttnProcessor(query_condition XOR key_value_condition)` on a temporal SELF attention (reference attention_processor.py:193-200,
+    :259-265: `q_merge` feeds only the query projection, `kv_merge` only key / value): against the reference's arithmetic written out in fp32."""
+    from synfmc_amd.models import motion_module as MM
+    from synfmc_amd.models.attention_processor import PoseAdaptorAttnProcessor
+    torch.manual_seed(21)
+    C, H, Fr, B, P = 320, 8, 16, 2, 20
+    att = MM.TemporalSelfAttention(attention_mode="Temporal_Self", query_dim=C, heads=H, dim_head=C // H, temporal_position_encoding=False)
+    proc = PoseAdaptorAttnProcessor(hidden_size=C, pose_feature_dim=C, query_condition=which == "q", key_value_condition=which == "kv", scale=0.7)
+    att.set_processor(proc)
+    with torch.no_grad():
+        for p in att.parameters():
+            p.normal_(0, p.shape[-1] ** -0.5) if p.ndim >= 2 else p.normal_(0, 0.2)
+    ref = {k: v.detach().clone().float() for k, v in att.state_dict().items()}
+    att = att.to("cuda", dtype).eval().requires_grad_(False)
+    x = torch.randn(B, Fr, P, C).to(dtype)
+    pose = torch.randn(B, Fr, P, C).to(dtype)
+    with torch.no_grad():
+        got = att(x.cuda(), pose_feature=pose.cuda())
+    # the reference's arithmetic (fp32 on the values the device saw)
+    r = (lambda t: t.to(dtype).float())
+    w = {k: r(v) for k, v in ref.items()}
+    xf, pf = x.float(), pose.float()
+    name = "processor.q_merge" if which == "q" else "processor.kv_merge"
+    merged = torch.nn.functional.linear(xf + pf, w[name + ".weight"], w[name + ".bias"]) * 0.7 + xf
+    qh, kvh = (merged, xf) if which == "q" else (xf, merged)
+    lin = torch.nn.functional.linear
+    q, k, v = lin(qh, w["to_q.weight"]), lin(kvh, w["to_k.weight"]), lin(kvh, w["to_v.weight"])
+    sp = lambda t: t.reshape(B, Fr, P, H, C // H).permute(0, 2, 3, 1, 4)                  # [B, P, H, F, d]: attention over the frames
+    pr = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) * (C // H) ** -0.5, dim=-1)
+    o = (pr @ sp(v)).permute(0, 3, 1, 2, 4).reshape(B, Fr, P, C)
+    want = lin(o, w["to_out.0.weight"], w["to_out.0.bias"])
+    assert rel_inf(got, want) < tol
