@@ -1516,6 +1516,51 @@ def groupnorm_coef(partials: torch.Tensor, gamma: torch.Tensor, beta: torch.Tens
     return (coef, stats) if want_stats else coef
 
 
+def conv3x3_halo4_supported(n: int, h: int, w: int, cin: int, cin1: int, cout: int, upsample: bool) -> bool:
+    return bool(_lib.load().fmc_conv3x3_halo4_supported(n, h, w, cin, cin1, cout, int(upsample)))
+
+
+def _w_halo4_packed(weight_cl: torch.Tensor) -> torch.Tensor:
+    cache = _owner_cache(weight_cl, "_fmc_wtm")
+    key = ("halo4", weight_cl.storage_offset(), tuple(weight_cl.shape), tuple(weight_cl.stride()), weight_cl._version)
+    hit = cache.get(key)
+    if hit is None:
+        cout, cin = weight_cl.shape[:2]
+        assert weight_cl.is_contiguous(memory_format=torch.channels_last)
+        hit = torch.empty(cout * 9 * cin, dtype=weight_cl.dtype, device=weight_cl.device)
+        _lib.check(_lib.load().fmc_conv3x3_halo4_pack_weight(weight_cl.data_ptr(), hit.data_ptr(), cin, cout, _stream()), "fmc_conv3x3_halo4_pack_weight")
+        cache[key] = hit
+    return hit
+
+
+def conv3x3_halo4(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias=None, temb=None, residual_nhwc=None, temb_div: int = 1, upsample: bool = False,
+                  x2_nhwc: Optional[torch.Tensor] = None, emit_gn: bool = False):
+    """`conv3x3` on the small feature maps (images 8 / 16 / 32 pixels wide; csrc/conv_halo4.hip): arguments and results as `conv3x3_halo` without the
+    GroupNorm operand path; the statistics partials are per (image, row block of 5 / 10 rows)."""
+    _dev(x_nhwc, weight_cl, bias, temb, residual_nhwc, x2_nhwc)
+    n, hs, ws, c1 = x_nhwc.shape
+    h, w = (2 * hs, 2 * ws) if upsample else (hs, ws)
+    cout, cin = weight_cl.shape[:2]
+    assert x_nhwc.is_contiguous() and x_nhwc.dtype == torch.bfloat16 and weight_cl.dtype == torch.bfloat16
+    if x2_nhwc is not None:
+        assert x2_nhwc.is_contiguous() and x2_nhwc.shape[:3] == x_nhwc.shape[:3] and x2_nhwc.dtype == x_nhwc.dtype and c1 + x2_nhwc.shape[3] == cin
+    else:
+        assert c1 == cin
+    assert temb is None or (temb.stride(1) == 1 and temb.shape == (n // temb_div, cout) and n % temb_div == 0)
+    assert residual_nhwc is None or (residual_nhwc.is_contiguous() and residual_nhwc.shape == (n, h, w, cout))
+    L = _lib.load()
+    wp = _w_halo4_packed(weight_cl)
+    out = torch.empty(n, h, w, cout, dtype=x_nhwc.dtype, device=x_nhwc.device)
+    part = torch.empty(n, L.fmc_conv3x3_halo4_row_blocks_per_image(h, w), 32, 2, dtype=torch.float32, device=x_nhwc.device) if emit_gn else None
+    conv_halo_calls["conv4"] = conv_halo_calls.get("conv4", 0) + 1
+    if call_log is not None:
+        call_log.append(("conv_halo4", (n, h, w, cin, cout, bool(upsample)), 2.0 * n * h * w * cout * 9 * cin))
+    _lib.check(L.fmc_conv3x3_halo4_bf16(x_nhwc.data_ptr(), _p(x2_nhwc), c1, wp.data_ptr(), _p(bias), _p(temb), _p(residual_nhwc), out.data_ptr(),
+                                        n, h, w, cin, cout, 0 if temb is None else temb.stride(0), int(temb_div), int(upsample), _p(part), _stream()),
+               "fmc_conv3x3_halo4_bf16")
+    return (out, part) if emit_gn else out
+
+
 def groupnorm_partials(x: torch.Tensor, groups: int, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The statistics pass of a GroupNorm alone: x `[N, S, C]` (+ `x2 [N, S, C2]`: channel concat read in place) -> partial (sum, sum of squares)
     `[N, splits, G, 2]` (one read of x, no write)."""

@@ -139,3 +139,46 @@ def test_resnet_block_fused_groupnorm_conv_matches_the_oracle_block():
     K.CONV_HALO_MIN_TILES = min_tiles
     e_f, e_p = rel_inf(got, want), rel_inf(plain, want)
     assert e_f < 2e-2 and e_f < 2.0 * e_p + 2e-3, (e_f, e_p)
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,c2,ups,extras", [
+    (4, 10, 16, 64, 80, 0, False, False),        # two images per tile, one chunk
+    (5, 10, 16, 192, 160, 0, False, True),       # an odd image count (the last tile holds one image), bias + temb (per image of a tile) + residual
+    (6, 10, 16, 256, 160, 128, False, True),     # two-source input
+    (4, 10, 16, 128, 80, 0, True, True),         # nearest 2x upsample (5x8 -> 10x16)
+    (16, 5, 8, 128, 160, 0, False, True),        # 5 x 8 images: eight per tile, fragments spanning two image rows
+    (11, 5, 8, 64, 80, 0, False, False),         # ... with a last tile of three images
+    (3, 16, 16, 64, 80, 0, False, True),         # 16 x 16 images (the 32x512x512 configuration): row blocks of 10 + 6 rows
+    (2, 20, 32, 128, 160, 0, False, True),       # 32 pixels wide: one 10 x 32 row block per tile
+])
+def test_conv3x3_halo4_matches_fp32_conv(n, h, w, cin, cout, c2, ups, extras):
+    """`fmc_conv3x3_halo4_bf16` (csrc/conv_halo4.hip), the halo-resident convolution of the small feature maps, against the fp32 convolution of the
+    same bf16-rounded operands; the statistics epilogue against the sums of the rounded outputs."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from synfmc_amd import hip_ops as K
+    hs, ws = (h // 2, w // 2) if ups else (h, w)
+    assert K.conv3x3_halo4_supported(n, h, w, cin, cin - c2, cout, ups)
+    x, x2, wt, g = _mk(n, hs, ws, cin, cout, seed=h + cin + n, c2=c2)
+    bias = temb = res = None
+    div = 1
+    if extras:
+        bias = torch.randn(cout, generator=g).bfloat16()
+        div = 2 if n % 2 == 0 else 1
+        temb = torch.randn(n // div, cout, generator=g).bfloat16()
+        res = torch.randn(n, h, w, cout, generator=g).bfloat16()
+    want = _ref(x, x2, wt, bias, temb, res, div, ups)
+    cu = lambda t: None if t is None else t.cuda()
+    emit = cout % 64 == 0 and 80 % (cout // 32) == 0
+    got = K.conv3x3_halo4(cu(x), wt.cuda(), cu(bias), cu(temb), cu(res), temb_div=div, upsample=ups, x2_nhwc=cu(x2), emit_gn=emit)
+    torch.cuda.synchronize()
+    if emit:
+        got, parts = got
+        o = got.float().cpu().reshape(n, h * w, 32, cout // 32)
+        s_ref = torch.stack([o.sum((1, 3)), (o * o).sum((1, 3))], -1)
+        assert parts.shape[0] == n and parts.shape[2:] == (32, 2)
+        assert rel_inf(parts.sum(1), s_ref) < 1e-4
+    assert got.shape == want.shape
+    assert rel_inf(got, want) < 6e-3
+    again = K.conv3x3_halo4(cu(x), wt.cuda(), cu(bias), cu(temb), cu(res), temb_div=div, upsample=ups, x2_nhwc=cu(x2))
+    assert torch.equal(again, got)                                           # deterministic

@@ -1798,7 +1798,10 @@ def test_xattn_block_fused_320(K, B, Fr, hw, S):
     assert rel_inf(out.float(), ref_f) < 2e-2, (B, Fr, hw, S)
     err = (out.float().cpu() - ref_r).abs()
     print(f"fused block: worst |err| - 2^-8 |ref| = {float((err - 2.0 ** -8 * ref_r.abs()).max()):.4f} (|ref| max {float(ref_r.abs().max()):.2f})")
-    bound = 2.0 ** -8 * ref_r.abs() + 0.08
+    # element-wise bound: one bf16 ulp of the element + 1.5 ulp of the LARGEST output (a flipped rounding of an intermediate -- LayerNorm output, merged
+    # token, q / k / v, probability -- moves an output by a fraction of an ulp of the row's largest terms; measured on MI355X, round 5: worst excess over
+    # 2^-8 |ref| = 0.95 x 2^-8 max|ref| across the four fused-block tests, gpurun_out/r05e/slack.log -- the former flat 0.08 was 1.3 - 3.7 x the measurement)
+    bound = 2.0 ** -8 * ref_r.abs() + 1.5 * 2.0 ** -8 * float(ref_r.abs().max())
     assert not bool((err > bound).any()), f"{int((err > bound).sum())} / {err.numel()} beyond the bound, worst {float((err - bound).max()):.3e}"
     mu = out.float().mean(-1).view(-1)
     rstd = (out.float().var(-1, unbiased=False) + 1e-5).rsqrt().view(-1)
@@ -1840,7 +1843,10 @@ def test_xattn_block_fused_640(K, B, Fr, hw, S):
     assert rel_inf(out.float(), ref_f) < 2e-2, (B, Fr, hw, S)
     err = (out.float().cpu() - ref_r).abs()
     print(f"fused block: worst |err| - 2^-8 |ref| = {float((err - 2.0 ** -8 * ref_r.abs()).max()):.4f} (|ref| max {float(ref_r.abs().max()):.2f})")
-    bound = 2.0 ** -8 * ref_r.abs() + 0.08
+    # element-wise bound: one bf16 ulp of the element + 1.5 ulp of the LARGEST output (a flipped rounding of an intermediate -- LayerNorm output, merged
+    # token, q / k / v, probability -- moves an output by a fraction of an ulp of the row's largest terms; measured on MI355X, round 5: worst excess over
+    # 2^-8 |ref| = 0.95 x 2^-8 max|ref| across the four fused-block tests, gpurun_out/r05e/slack.log -- the former flat 0.08 was 1.3 - 3.7 x the measurement)
+    bound = 2.0 ** -8 * ref_r.abs() + 1.5 * 2.0 ** -8 * float(ref_r.abs().max())
     assert not bool((err > bound).any()), f"{int((err > bound).sum())} / {err.numel()} beyond the bound, worst {float((err - bound).max()):.3e}"
     assert torch.equal(run(), out)
     with pytest.raises(ValueError):
@@ -1890,7 +1896,10 @@ def test_temporal_block_fused_640(K, merge, B, hw):
     assert rel_inf(out.float(), ref_f) < 2e-2, (merge, B, hw)
     err = (out.float().cpu() - ref_r).abs()
     print(f"fused block: worst |err| - 2^-8 |ref| = {float((err - 2.0 ** -8 * ref_r.abs()).max()):.4f} (|ref| max {float(ref_r.abs().max()):.2f})")
-    bound = 2.0 ** -8 * ref_r.abs() + 0.08
+    # element-wise bound: one bf16 ulp of the element + 1.5 ulp of the LARGEST output (a flipped rounding of an intermediate -- LayerNorm output, merged
+    # token, q / k / v, probability -- moves an output by a fraction of an ulp of the row's largest terms; measured on MI355X, round 5: worst excess over
+    # 2^-8 |ref| = 0.95 x 2^-8 max|ref| across the four fused-block tests, gpurun_out/r05e/slack.log -- the former flat 0.08 was 1.3 - 3.7 x the measurement)
+    bound = 2.0 ** -8 * ref_r.abs() + 1.5 * 2.0 ** -8 * float(ref_r.abs().max())
     assert not bool((err > bound).any()), f"{int((err > bound).sum())} / {err.numel()} beyond the bound, worst {float((err - bound).max()):.3e} at {int((err - bound).flatten().argmax())}"
     for it in range(3):
         assert torch.equal(run(), out)
@@ -1948,7 +1957,10 @@ def test_temporal_block_fused(K, merge, B, hw):
     # out-projection's amplification of a 2^-8 error in o (|W_out| row sums ~ 14 x C^-1/2 x |o|)
     err = (out.float().cpu() - ref_r).abs()
     print(f"fused block: worst |err| - 2^-8 |ref| = {float((err - 2.0 ** -8 * ref_r.abs()).max()):.4f} (|ref| max {float(ref_r.abs().max()):.2f})")
-    bound = 2.0 ** -8 * ref_r.abs() + 0.08
+    # element-wise bound: one bf16 ulp of the element + 1.5 ulp of the LARGEST output (a flipped rounding of an intermediate -- LayerNorm output, merged
+    # token, q / k / v, probability -- moves an output by a fraction of an ulp of the row's largest terms; measured on MI355X, round 5: worst excess over
+    # 2^-8 |ref| = 0.95 x 2^-8 max|ref| across the four fused-block tests, gpurun_out/r05e/slack.log -- the former flat 0.08 was 1.3 - 3.7 x the measurement)
+    bound = 2.0 ** -8 * ref_r.abs() + 1.5 * 2.0 ** -8 * float(ref_r.abs().max())
     assert not bool((err > bound).any()), f"{int((err > bound).sum())} / {err.numel()} beyond the bound, worst {float((err - bound).max()):.3e} at {int((err - bound).flatten().argmax())}"
     # row statistics of the rounded output
     mu = out.float().mean(-1).view(-1)
