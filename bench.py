@@ -444,7 +444,7 @@ def apply_in_step(obj, steps, call_log):
     else:
         order = [shape for fe, shape, _ in call_log if fe == match[0]]
         for st in steps:
-            ks = [d for name, gx, wx, d in st if "conv_halo_kernel" in name]
+            ks = [d for name, gx, wx, d in st if "conv_halo_kernel<" in name]
             if len(ks) == len(order):
                 us += [d for d, shape in zip(ks, order) if shape == tuple(match[1])]
     if not us:
@@ -467,7 +467,7 @@ def step_kernel_families(steps, call_log):
     """ms per step by kernel family + the halo convolutions' aggregate rate (their shapes from the recorded call order), from the in-step window."""
     if steps is None:
         return None
-    fam = (("conv3x3 (conv_halo_kernel)", ("conv_halo_kernel",)), ("conv3x3 / linear (gemm*_kernel, sk_finish)", ("gemm", "sk_finish", "splitk")),
+    fam = (("conv3x3 (conv_halo_kernel)", ("conv_halo_kernel", "conv_halo4_kernel", "conv_halo4_finish")), ("conv3x3 / linear (gemm*_kernel, sk_finish)", ("gemm", "sk_finish", "splitk")),
            ("vendor GEMM (hipBLASLt Cijk_*)", ("Cijk_",)), ("geglu_direct", ("geglu_direct",)), ("spatial attention", ("sa40d", "spatial_attn")),
            ("temporal block / attention", ("temporal_block", "temporal_attn")), ("text cross-attention block", ("xattn",)),
            ("groupnorm", ("gn_",)), ("layernorm", ("layernorm",)), ("torch elementwise / copy / cat", ("at::", "elementwise", "CatArray")))
@@ -485,10 +485,10 @@ def step_kernel_families(steps, call_log):
                 tot["other"] += d
     n = len(steps)
     out = {"ms_per_step": {k: round(v / n / 1e3, 3) for k, v in tot.items()}, "launches_per_step": round(calls / n, 1)}
-    fl = sum(f for fe, _, f in call_log if fe == "conv_halo")
+    fl = sum(f for fe, _, f in call_log if fe in ("conv_halo", "conv_halo4"))
     ms = tot["conv3x3 (conv_halo_kernel)"] / n / 1e3
     if fl and ms:
-        out["conv_halo_all_launches"] = {"launches_per_step": sum(1 for fe, _, _ in call_log if fe == "conv_halo"), "tflop_per_step": round(fl / 1e12, 3),
+        out["conv_halo_all_launches"] = {"launches_per_step": sum(1 for fe, _, _ in call_log if fe in ("conv_halo", "conv_halo4")), "tflop_per_step": round(fl / 1e12, 3),
                                          "ms_per_step": round(ms, 3), "achieved": round(fl / (ms * 1e-3) / 1e12, 1),
                                          "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "unit": "TFLOP/s"}
     return out
@@ -1162,7 +1162,8 @@ def main():
             "in_step_source": tr_note, "in_step_kernel_families": families,
             "step_dispatch": {"note": "front-end calls of one step: own kernel / autotuner chose the vendor arm / shape outside the own kernels "
                                       "(fell through to the vendor library)", **dispatch,
-                              "halo_convs_per_step": sum(1 for fe, _, _ in call_log if fe == "conv_halo")},
+                              "halo_convs_per_step": sum(1 for fe, _, _ in call_log if fe == "conv_halo"),
+                              "halo4_convs_per_step": sum(1 for fe, _, _ in call_log if fe == "conv_halo4")},
             "cpu_baseline": cpu,
         }
         if loop50_s is not None:

@@ -21,6 +21,10 @@
 namespace {
 
 constexpr int BM = 320, BN = 80;
+#ifndef FMC_C4_INTERLEAVE
+#define FMC_C4_INTERLEAVE 1
+#endif
+constexpr bool INTERLEAVE = FMC_C4_INTERLEAVE != 0;          // A/B switch (compile time): C - E issued between the MFMAs instead of in front of them
 constexpr int WSUB = BN * 64;                              // one 32-deep W sub-tile: 80 rows x 64 B = 5 KiB
 constexpr unsigned OOB = 0x80000000u;
 
@@ -48,6 +52,8 @@ struct C4Params {
     int64_t temb_ld; int temb_div;
     float* gn_part;                                         // [n_img, tiles_y, 32, 2] partial sums of the rounded outputs (one split per row block), or NULL
     int tiles_y, tiles_p, tiles_n;                          // row blocks per image / pixel tiles / channel tiles
+    int splits; float* ws;                                  // split-K: the 64-channel chunks are dealt to `splits` workgroups per tile, which leave fp32 partial
+                                                            //   sums in ws[split][pixel][Cout]; conv_halo4_finish_kernel adds them (fixed order) and runs the epilogue
     int64_t x_bytes, x2_bytes, w_bytes;
 };
 
@@ -69,16 +75,21 @@ void conv_halo4_kernel(const C4Params P) {
     const bool clsA = wave == 0;                             // wave 0 issues two W pieces per sub-tile (0 and 4), waves 1 .. 3 one
 
     // ---- my tile: XCD x owns a contiguous range; the channel tiles of a pixel tile are neighbours (its halos come from that XCD's L2 once) --------
-    int tile_p, tile_n;
+    int tile_p, tile_n, split;
     {
-        const int total = P.tiles_p * P.tiles_n;
+        const int total = P.tiles_p * P.tiles_n * P.splits;
         const int id = blockIdx.x, q = total >> 3, r = total & 7, xcd = id & 7;
-        const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+        int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+        split = lin % P.splits;                              // (the splits of a tile are neighbours)
+        lin /= P.splits;
         tile_p = lin / P.tiles_n;
         tile_n = lin - tile_p * P.tiles_n;
     }
     const int n0 = tile_n * BN;
-    const int nchunk = P.cin >> 6, nsub = nchunk * 18;
+    const int nchunk_all = P.cin >> 6;
+    const int per = (nchunk_all + P.splits - 1) / P.splits;
+    const int ck0 = split * per, nchunk = max(0, min(nchunk_all, ck0 + per) - ck0);      // my chunks ck0 .. ck0 + nchunk - 1
+    const int nsub = max(nchunk, 1) * 18;
     const int rb0 = tile_p * NB, rb_total = P.n_img * P.tiles_y;     // my row blocks rb0 .. rb0 + NB - 1: (image rb / tiles_y, rows (rb % tiles_y) TH ..)
 
     // ---- halo staging: block b = 4 j + wave holds halo pixels 8 b .. 8 b + 7 x 8 channel groups; lane = 8 g + p takes pixel p, group (p + g) & 7 -----
@@ -101,9 +112,9 @@ void conv_halo4_kernel(const C4Params P) {
     const __amdgpu_buffer_rsrc_t rsX2 = __builtin_amdgcn_make_buffer_rsrc((void*)(P.x2 ? P.x2 : P.x), 0, (int)(P.x2 ? P.x2_bytes : P.x_bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)P.w, 0, (int)P.w_bytes, 0x00020000);
     const int c2 = P.cin - P.c1;
-    auto halo_load = [&](int j, int ch64) -> u32x4 {
-        const int cbeg = ch64 * 64;
-        const bool second = cbeg >= P.c1, past = ch64 >= nchunk;
+    auto halo_load = [&](int j, int crel) -> u32x4 {             // crel: chunk relative to my range
+        const int cbeg = (ck0 + crel) * 64;
+        const bool second = cbeg >= P.c1, past = crel >= nchunk;
         const int pitch = past ? 0 : (second ? c2 : P.c1) * 2;
         const unsigned coff = past ? OOB : (unsigned)(((second ? cbeg - P.c1 : cbeg) + pg * 8) * 2);
         unsigned vo = (unsigned)(h_pix[j] * pitch) + coff;
@@ -118,14 +129,15 @@ void conv_halo4_kernel(const C4Params P) {
 
     // ---- W stream: piece p = KiB p of the 5-KiB sub-tile block; wave w issues piece w, wave 0 also piece 4 --------------------------------------------
     const unsigned w_vo0 = (unsigned)(lane * 16 + wave * 1024);
-    int iss_soff = tile_n * nsub * WSUB, iss_left = nsub, iss_slot = 0;
+    const int w_base = (tile_n * nchunk_all + ck0) * 18 * WSUB;       // my first sub-tile inside the channel tile's block
+    int iss_soff = w_base, iss_left = nsub, iss_slot = 0;
     auto w_issue = [&](auto cls) {
         unsigned char* dst = smem_raw + OFF_W + iss_slot * WSUB + wave * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)dst, 16, (int)w_vo0, iss_soff, 0, 0);
         if constexpr (decltype(cls)::value)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(dst + 4096), 16, (int)w_vo0, iss_soff + 4096, 0, 0);
         iss_soff += WSUB;
-        if (--iss_left == 0) { iss_left = nsub; iss_soff = tile_n * nsub * WSUB; }      // (past the end the stream wraps to valid addresses)
+        if (--iss_left == 0) { iss_left = nsub; iss_soff = w_base; }      // (past the end the stream wraps to valid addresses)
         iss_slot = iss_slot + 1 == NBW ? 0 : iss_slot + 1;
     };
 
@@ -200,15 +212,32 @@ void conv_halo4_kernel(const C4Params P) {
                 if constexpr (nh<NPIECE>(i) >= 1) hreg[i % 3][0] = halo_load(2 * i, c + 1);
                 if constexpr (nh<NPIECE>(i) == 2) hreg[i % 3][1] = halo_load(2 * i + 1, c + 1);
                 w_issue(cls);
-                __builtin_amdgcn_sched_barrier(0);
-                // F. 25 MFMAs of sub-tile s
-                __builtin_amdgcn_s_setprio(1);
+                // F. 25 MFMAs of sub-tile s, with C - E in their issue shadow: a 16x16x32 MFMA occupies the matrix pipe for 16 cycles and the issue
+                //    port for 4 -- the fragment reads, the staging store / loads and the W request (all independent of this sub-tile's operands) go out
+                //    between the matrix instructions instead of in front of them (one wave per SIMD: nobody else would cover that time)
 #pragma unroll
                 for (int mb = 0; mb < 5; ++mb)
 #pragma unroll
                     for (int nb = 0; nb < 5; ++nb)
                         acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i & 1][nb], af[i & 1][mb], acc[mb][nb], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
+                if constexpr (INTERLEAVE) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {                // staging stores first (their data is oldest), one per matrix instruction
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 10; ++k) {               // the 10 fragment reads of sub-tile s + 1
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {                // halo requests and the W request(s)
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             };
             sub(IC<0>{}); sub(IC<1>{}); sub(IC<2>{}); sub(IC<3>{}); sub(IC<4>{}); sub(IC<5>{});
@@ -223,6 +252,21 @@ void conv_halo4_kernel(const C4Params P) {
 
     // ---- epilogue: bias / temb in registers, residual through the staging tile, whole-row 16-byte stores ------------------------------------------------
     // my outputs: acc[mb][nb][j] = (tile pixel 80 wave + 16 mb + l15, tile channel 16 nb + 4 kq + j)
+    if (P.splits > 1) {                                      // raw fp32 partial sums of my chunks: the finishing pass owns the epilogue
+        const int64_t mtot = (int64_t)P.n_img * P.H * P.W;
+#pragma unroll
+        for (int mb = 0; mb < 5; ++mb) {
+            const int r = wave * 80 + mb * 16 + l15;
+            const int blk = r / RB, q = r - blk * RB, ty = q / TW, tx = q - ty * TW;
+            const int rb = rb0 + blk, img = rb / P.tiles_y, y = (rb - img * P.tiles_y) * TH + ty;
+            if (rb < rb_total && y < P.H) {
+                float* dst = P.ws + ((int64_t)split * mtot + ((int64_t)img * P.H + y) * P.W + tx) * P.cout + n0 + 4 * kq;
+#pragma unroll
+                for (int nb = 0; nb < 5; ++nb) *reinterpret_cast<f32x4*>(dst + nb * 16) = acc[mb][nb];
+            }
+        }
+        return;
+    }
     constexpr int OP = BN + 8;                               // bf16 pitch of the staging rows (176 B)
     bf16_t* Os = reinterpret_cast<bf16_t*>(smem_raw);        // [320][OP] = 56,320 B
     constexpr int CPR = BN / 8;                              // 10 sixteen-byte chunks per row
@@ -339,6 +383,40 @@ __global__ __launch_bounds__(256) void conv_halo4_pack_kernel(const bf16_t* __re
     }
 }
 
+// second pass of a split launch: out = sum over the splits (fixed order) + bias + temb + residual, 8 channels of one pixel per thread
+__global__ __launch_bounds__(256) void conv_halo4_finish_kernel(const C4Params P) {
+    const int64_t mtot = (int64_t)P.n_img * P.H * P.W, cpr = P.cout / 8, total = mtot * cpr;
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = id / cpr;
+        const int n = (int)(id - m * cpr) * 8;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < P.splits; ++sp) {
+            const float* src = P.ws + ((int64_t)sp * mtot + m) * P.cout + n;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] += a[k]; v[4 + k] += b[k]; }
+        }
+        float t[8];
+        if (P.bias) {
+            Vec8<bf16_t>::load(P.bias + n, t);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += t[k];
+        }
+        if (P.temb) {
+            const int64_t img = m / ((int64_t)P.H * P.W);
+            Vec8<bf16_t>::load(P.temb + (img / P.temb_div) * P.temb_ld + n, t);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += t[k];
+        }
+        if (P.res) {
+            Vec8<bf16_t>::load(P.res + m * P.cout + n, t);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += t[k];
+        }
+        Vec8<bf16_t>::store(P.out + m * P.cout + n, v);
+    }
+}
+
 template <int TW> int launch_c4(C4Params& P, hipStream_t st) {
     using G = Geo<TW>;
     P.tiles_y = (P.H + G::TH - 1) / G::TH;
@@ -348,7 +426,12 @@ template <int TW> int launch_c4(C4Params& P, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo4_kernel<TW>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
         raised = true;
     }
-    hipLaunchKernelGGL(conv_halo4_kernel<TW>, dim3((unsigned)(P.tiles_p * P.tiles_n)), dim3(256), G::LDS_BYTES, st, P);
+    hipLaunchKernelGGL(conv_halo4_kernel<TW>, dim3((unsigned)(P.tiles_p * P.tiles_n * P.splits)), dim3(256), G::LDS_BYTES, st, P);
+    if (P.splits > 1) {
+        const int64_t chunks = (int64_t)P.n_img * P.H * P.W * (P.cout / 8);
+        const unsigned grid = (unsigned)((chunks + 255) / 256 < 2048 ? (chunks + 255) / 256 : 2048);
+        hipLaunchKernelGGL(conv_halo4_finish_kernel, dim3(grid), dim3(256), 0, st, P);
+    }
     return 0;
 }
 
@@ -384,10 +467,13 @@ extern "C" int fmc_conv3x3_halo4_tiles(int n_img, int H, int W, int Cout) {
 }
 
 /* As fmc_conv3x3_halo_bf16 (fmc_hip.h) without the GroupNorm operand path, for images 8 / 16 / 32 pixels wide; gn_partials
- * [n_img, fmc_conv3x3_halo4_row_blocks_per_image(H, W), 32, 2]; w_packed = fmc_conv3x3_halo4_pack_weight. */
+ * [n_img, fmc_conv3x3_halo4_row_blocks_per_image(H, W), 32, 2]; w_packed = fmc_conv3x3_halo4_pack_weight.  split_k > 1: the 64-channel chunks of the
+ * reduction are dealt to split_k workgroups per tile (5x8-pixel images: 64 tiles on 256 CUs otherwise), fp32 partials in `workspace`
+ * (>= split_k * n_img * H * W * Cout * 4 bytes), summed in a fixed order by a second launch that runs the epilogue; no statistics epilogue then. */
 extern "C" int fmc_conv3x3_halo4_bf16(const void* x, const void* x2, int Cin1, const void* w_packed, const void* bias, const void* temb,
                                       const void* residual, void* out, int n_img, int H, int W, int Cin, int Cout, int64_t temb_row_stride,
-                                      int temb_img_div, int upsample2x, float* gn_partials, void* stream) {
+                                      int temb_img_div, int upsample2x, float* gn_partials, int split_k, void* workspace, int64_t workspace_bytes,
+                                      void* stream) {
     if (!x || !w_packed || !out) FMC_FAIL(FMC_E_NULL, "conv3x3_halo4: NULL x / w / out");
     if (!x2) Cin1 = Cin;
     if (!fmc_conv3x3_halo4_supported(n_img, H, W, Cin, Cin1, Cout, upsample2x))
@@ -399,12 +485,20 @@ extern "C" int fmc_conv3x3_halo4_bf16(const void* x, const void* x2, int Cin1, c
     if (temb && temb_img_div < 1) FMC_FAIL(FMC_E_SHAPE, "conv3x3_halo4: temb_img_div %d", temb_img_div);
     if (gn_partials && (Cout % 64 || BN % (Cout / 32)))
         FMC_FAIL(FMC_E_SHAPE, "conv3x3_halo4: the statistics epilogue needs Cout %% 64 == 0 and 80 %% (Cout / 32) == 0 (Cout=%d)", Cout);
+    if (split_k < 1) split_k = 1;
+    if (split_k > Cin / 64) split_k = Cin / 64;
+    if (split_k > 1) {
+        if (gn_partials) FMC_FAIL(FMC_E_SHAPE, "conv3x3_halo4: the statistics epilogue is not available with split_k > 1");
+        if (!workspace || workspace_bytes < (int64_t)split_k * n_img * H * W * Cout * 4 || !fmc_aligned16(workspace))
+            FMC_FAIL(FMC_E_SHAPE, "conv3x3_halo4: split_k %d needs a 16-byte aligned workspace of %lld bytes", split_k, (long long)split_k * n_img * H * W * Cout * 4);
+    }
     C4Params P;
     P.x = (const bf16_t*)x; P.x2 = (const bf16_t*)x2; P.c1 = Cin1;
     P.w = (const bf16_t*)w_packed; P.bias = (const bf16_t*)bias; P.temb = (const bf16_t*)temb; P.res = (const bf16_t*)residual; P.out = (bf16_t*)out;
     P.n_img = n_img; P.H = H; P.W = W; P.cin = Cin; P.cout = Cout; P.ups = upsample2x ? 1 : 0;
     P.temb_ld = temb_row_stride; P.temb_div = temb ? temb_img_div : 1;
     P.gn_part = gn_partials; P.tiles_n = Cout / BN;
+    P.splits = split_k; P.ws = (float*)workspace;
     const int64_t hs = upsample2x ? H / 2 : H, ws = upsample2x ? W / 2 : W;
     P.x_bytes = (int64_t)n_img * hs * ws * Cin1 * 2; P.x2_bytes = (int64_t)n_img * hs * ws * (Cin - Cin1) * 2;
     P.w_bytes = (int64_t)Cout * 9 * Cin * 2;

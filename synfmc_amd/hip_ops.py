@@ -1481,6 +1481,7 @@ def conv3x3_gn(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias, temb, residu
 # --------------------------------------------------------------------------------------------
 CONV_HALO = os.environ.get("FMC_CONV_HALO", "1") != "0"
 CONV_HALO_MIN_TILES = int(os.environ.get("FMC_CONV_HALO_MIN_TILES", "200"))     # workgroups below which the ring / stream-K arms keep the shape
+CONV_HALO4 = os.environ.get("FMC_CONV_HALO4", "1") != "0"       # A/B switch: the 4-wave form on the 10x16 / 5x8 levels
 CONV_GN_FUSED = os.environ.get("FMC_CONV_GN_FUSED", "0") == "1"   # GroupNorm + SiLU in the conv's operand path instead of a separate apply pass (measured slower)
 conv_halo_calls = {"conv": 0, "gn_fused": 0, "stats_pass": 0, "stats_from_producer": 0}
 
@@ -1533,8 +1534,21 @@ def _w_halo4_packed(weight_cl: torch.Tensor) -> torch.Tensor:
     return hit
 
 
+def conv3x3_halo4_split(n: int, h: int, w: int, cin: int, cout: int, cus: int = 256) -> int:
+    """Workgroups per tile: 1 where the tiles fill the chip, else the divisor of the chunk count that brings the launch closest to one round."""
+    tiles = _lib.load().fmc_conv3x3_halo4_tiles(n, h, w, cout)
+    if tiles >= (3 * cus) // 4:
+        return 1
+    nchunk = cin // 64
+    best = 1
+    for s in range(2, min(nchunk, 16) + 1):
+        if nchunk % s == 0 and tiles * s <= cus + cus // 8:
+            best = s
+    return best
+
+
 def conv3x3_halo4(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias=None, temb=None, residual_nhwc=None, temb_div: int = 1, upsample: bool = False,
-                  x2_nhwc: Optional[torch.Tensor] = None, emit_gn: bool = False):
+                  x2_nhwc: Optional[torch.Tensor] = None, emit_gn: bool = False, split_k: Optional[int] = None):
     """`conv3x3` on the small feature maps (images 8 / 16 / 32 pixels wide; csrc/conv_halo4.hip): arguments and results as `conv3x3_halo` without the
     GroupNorm operand path; the statistics partials are per (image, row block of 5 / 10 rows)."""
     _dev(x_nhwc, weight_cl, bias, temb, residual_nhwc, x2_nhwc)
@@ -1551,13 +1565,16 @@ def conv3x3_halo4(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias=None, temb
     L = _lib.load()
     wp = _w_halo4_packed(weight_cl)
     out = torch.empty(n, h, w, cout, dtype=x_nhwc.dtype, device=x_nhwc.device)
+    if split_k is None:
+        split_k = 1 if emit_gn else conv3x3_halo4_split(n, h, w, cin, cout)
+    ws, ws_bytes = (None, 0) if split_k <= 1 else _splitk_workspace(x_nhwc.device, split_k, n * h * w, cout)
     part = torch.empty(n, L.fmc_conv3x3_halo4_row_blocks_per_image(h, w), 32, 2, dtype=torch.float32, device=x_nhwc.device) if emit_gn else None
     conv_halo_calls["conv4"] = conv_halo_calls.get("conv4", 0) + 1
     if call_log is not None:
         call_log.append(("conv_halo4", (n, h, w, cin, cout, bool(upsample)), 2.0 * n * h * w * cout * 9 * cin))
     _lib.check(L.fmc_conv3x3_halo4_bf16(x_nhwc.data_ptr(), _p(x2_nhwc), c1, wp.data_ptr(), _p(bias), _p(temb), _p(residual_nhwc), out.data_ptr(),
-                                        n, h, w, cin, cout, 0 if temb is None else temb.stride(0), int(temb_div), int(upsample), _p(part), _stream()),
-               "fmc_conv3x3_halo4_bf16")
+                                        n, h, w, cin, cout, 0 if temb is None else temb.stride(0), int(temb_div), int(upsample), _p(part), int(split_k),
+                                        ws, ws_bytes, _stream()), "fmc_conv3x3_halo4_bf16")
     return (out, part) if emit_gn else out
 
 
@@ -2068,6 +2085,13 @@ def conv3x3(x_nchw: torch.Tensor, weight_cl: torch.Tensor, bias, temb=None, resi
             y._fmc_gn = (part, cout)
             return y
         return y.permute(0, 3, 1, 2)
+    # ... and its 4-wave form for the small feature maps (images 8 / 16 pixels wide: the two inner levels; csrc/conv_halo4.hip), split over the
+    # reduction where the tiles alone would leave most of the chip idle (5x8-pixel images: 64 tiles)
+    if (CONV_HALO and CONV_HALO4 and not stride2 and w in (8, 16) and (temb is None or temb.stride(1) == 1)
+            and conv3x3_halo4_supported(n, h, w, cin, cin, cout, upsample)
+            and _lib.load().fmc_conv3x3_halo4_tiles(n, h, w, cout) * conv3x3_halo4_split(n, h, w, cin, cout) >= CONV_HALO_MIN_TILES):
+        dispatch_calls["conv3x3"]["own"] += 1
+        return conv3x3_halo4(x, weight_cl, bias, temb, r, temb_div, upsample).permute(0, 3, 1, 2)
     if emit_gn and gn_emit_ok(n * h * w, cout, 9 * cin, h * w, x.dtype):
         dispatch_calls["conv3x3"]["own"] += 1
         y, tag = conv3x3_gn(x, weight_cl, bias, temb, r, temb_div, upsample, stride2)

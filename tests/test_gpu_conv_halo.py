@@ -170,7 +170,7 @@ def test_conv3x3_halo4_matches_fp32_conv(n, h, w, cin, cout, c2, ups, extras):
     want = _ref(x, x2, wt, bias, temb, res, div, ups)
     cu = lambda t: None if t is None else t.cuda()
     emit = cout % 64 == 0 and 80 % (cout // 32) == 0
-    got = K.conv3x3_halo4(cu(x), wt.cuda(), cu(bias), cu(temb), cu(res), temb_div=div, upsample=ups, x2_nhwc=cu(x2), emit_gn=emit)
+    got = K.conv3x3_halo4(cu(x), wt.cuda(), cu(bias), cu(temb), cu(res), temb_div=div, upsample=ups, x2_nhwc=cu(x2), emit_gn=emit, split_k=1)
     torch.cuda.synchronize()
     if emit:
         got, parts = got
@@ -180,5 +180,12 @@ def test_conv3x3_halo4_matches_fp32_conv(n, h, w, cin, cout, c2, ups, extras):
         assert rel_inf(parts.sum(1), s_ref) < 1e-4
     assert got.shape == want.shape
     assert rel_inf(got, want) < 6e-3
-    again = K.conv3x3_halo4(cu(x), wt.cuda(), cu(bias), cu(temb), cu(res), temb_div=div, upsample=ups, x2_nhwc=cu(x2))
+    again = K.conv3x3_halo4(cu(x), wt.cuda(), cu(bias), cu(temb), cu(res), temb_div=div, upsample=ups, x2_nhwc=cu(x2), split_k=1)
     assert torch.equal(again, got)                                           # deterministic
+    if cin >= 128:                                                           # split-K: the chunks dealt to 2 (and cin / 64) workgroups per tile, fp32 partials + finishing pass
+        for sk in (2, cin // 64):
+            split = K.conv3x3_halo4(cu(x), wt.cuda(), cu(bias), cu(temb), cu(res), temb_div=div, upsample=ups, x2_nhwc=cu(x2), split_k=sk)
+            assert rel_inf(split, want) < 6e-3
+            assert torch.equal(split, K.conv3x3_halo4(cu(x), wt.cuda(), cu(bias), cu(temb), cu(res), temb_div=div, upsample=ups, x2_nhwc=cu(x2), split_k=sk))
+        auto = K.conv3x3_halo4(cu(x), wt.cuda(), cu(bias), cu(temb), cu(res), temb_div=div, upsample=ups, x2_nhwc=cu(x2))     # (the front-end's own choice of split)
+        assert rel_inf(auto, want) < 6e-3

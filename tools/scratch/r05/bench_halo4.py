@@ -28,5 +28,6 @@ for n, h, w, cin, cout, ups in shapes:
     c = t_ms(lambda: K.conv3x3_halo4(x, wt, bias, upsample=ups, emit_gn=True))
     y0 = ref().permute(0, 2, 3, 1).float(); y1 = K.conv3x3_halo4(x, wt, bias, upsample=ups).float()
     err = ((y0 - y1).abs().max() / y0.abs().max()).item()
-    print(f"{n}x{h}x{w} {cin}->{cout} ups={int(ups)}: shipped {a*1e3:7.1f} us ({fl/a/1e9:6.0f} TF/s) | halo4 {b*1e3:7.1f} us ({fl/b/1e9:6.0f} TF/s = {fl/b/1e9/2500:.3f}) | "
+    sk = K.conv3x3_halo4_split(n, h, w, cin, cout)
+    print(f"{n}x{h}x{w} {cin}->{cout} ups={int(ups)} split {sk}: shipped {a*1e3:7.1f} us ({fl/a/1e9:6.0f} TF/s) | halo4 {b*1e3:7.1f} us ({fl/b/1e9:6.0f} TF/s = {fl/b/1e9/2500:.3f}) | "
           f"+stats {c*1e3:7.1f} us | diff vs shipped {err:.2e}", flush=True)

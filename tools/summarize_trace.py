@@ -41,7 +41,9 @@ def main(path, nsteps=4):
     print(f"window: {nsteps} steps, {(t1 - t0) / 1e6 / nsteps:.3f} ms/step wall, {busy / 1e6 / nsteps:.3f} ms/step kernel-busy\n")
     cat = collections.defaultdict(float)
     for k, (d, c) in agg.items():
-        if "conv_halo_kernel" in k:
+        if "conv_halo4" in k:
+            cat["conv3x3 (fmc conv_halo4_kernel + finish, small feature maps)"] += d
+        elif "conv_halo_kernel" in k:
             cat["conv3x3 (fmc conv_halo_kernel, halo resident in LDS)"] += d
         elif "sk_finish" in k:
             cat["conv3x3 (fmc sk_finish_kernel, stream-K finishing pass)"] += d
