@@ -338,8 +338,8 @@ int fmc_conv3x3_halo_tiles_per_image(int H, int W);
 int fmc_conv3x3_halo_bf16(const void* x, const void* x2, int Cin1, const void* w_packed, const void* bias, const void* temb, const void* residual,
                           void* out, int n_img, int H, int W, int Cin, int Cout, int64_t temb_row_stride, int temb_img_div, int upsample2x,
                           const float* gn_coef, int gn_act, float* gn_partials, void* stream);
-/* The same convolution for the SMALL feature maps (csrc/conv_halo4.hip): images 8, 16 or 32 pixels wide (the whole width is one row block of
- * 5 / 10 / 10 rows); a tile is 320 pixels = 8 / 2 / 1 row blocks x 80 output channels, 4 waves with software-pipelined fragment reads.  Arguments as
+/* The same convolution for the SMALL feature maps (csrc/conv_halo4.hip): image width a multiple of 8; the image is cut into row blocks of 10 x 16
+ * pixels (W % 16 == 0) or 5 x 8; a tile is 320 pixels = 2 / 8 row blocks x 80 output channels, 4 waves with software-pipelined fragment reads.  Arguments as
  * fmc_conv3x3_halo_bf16 without the GroupNorm operand path; Cout % 80 == 0; w_packed = fmc_conv3x3_halo4_pack_weight(filter);
  * gn_partials [n_img, fmc_conv3x3_halo4_row_blocks_per_image(H, W), 32, 2].  fmc_conv3x3_halo4_tiles: workgroups an un-split launch has.
  * split_k > 1 (5x8-pixel images: 64 tiles on 256 CUs otherwise): the 64-channel chunks of the reduction are dealt to split_k workgroups per tile, fp32

@@ -4,8 +4,9 @@
 // Why a second geometry.  At 1280 channels those convolutions are 32 images x 160 (or 40) pixels: M = 5120 (1280) rows against K = 11520 .. 23040.
 // conv_halo_kernel's 10 x 32-pixel x 160-channel tiles do not exist there, and the ring kernel's k-lockstep stream-K pass + finishing launch ran them
 // at 0.17 - 0.36 of the MFMA peak (profiles/r05d_kernel_by_grid.md: 27 launches, 3.7 ms of a 28.9 ms step).  Here
-//   * a tile is 320 output pixels = NB whole ROW BLOCKS of TH x TW pixels (TW = 16: two 10 x 16 images; TW = 8: eight 5 x 8 images; TW = 32: one
-//     10 x 32 block as in conv_halo_kernel) x 80 output channels: 256 tiles at the 10x16 level = one per CU, no split, no finishing pass;
+//   * a tile is 320 output pixels = NB ROW BLOCKS of TH x TW pixels (TW = 16 where the image width is a multiple of 16: two 10 x 16 blocks = two
+//     whole images at the 10x16 level; TW = 8 otherwise: eight 5 x 8 blocks = eight images at the 5x8 level; wider / taller images are cut into
+//     such blocks) x 80 output channels: 256 tiles at the 10x16 level = one per CU, no split, no finishing pass;
 //   * the input halos of the tile's row blocks ((TH + 2) x (TW + 2) pixels each, 64 channels at a time) are staged ONCE per chunk through registers
 //     into LDS planes [8 channel groups][pixels] (any tap's fragment read is conflict free for TW >= 16, 2-way for TW = 8) and serve 9 taps x 2
 //     k-halves; only W is streamed by LDS-DMA: 5 one-KiB requests per 32-deep sub-tile and CU;
@@ -51,7 +52,7 @@ struct C4Params {
     int n_img, H, W, cin, cout, ups;
     int64_t temb_ld; int temb_div;
     float* gn_part;                                         // [n_img, tiles_y, 32, 2] partial sums of the rounded outputs (one split per row block), or NULL
-    int tiles_y, tiles_p, tiles_n;                          // row blocks per image / pixel tiles / channel tiles
+    int tiles_y, tiles_x, tiles_p, tiles_n;                 // row blocks per image column / per image row, pixel tiles, channel tiles
     int splits; float* ws;                                  // split-K: the 64-channel chunks are dealt to `splits` workgroups per tile, which leave fp32 partial
                                                             //   sums in ws[split][pixel][Cout]; conv_halo4_finish_kernel adds them (fixed order) and runs the epilogue
     int64_t x_bytes, x2_bytes, w_bytes;
@@ -90,7 +91,8 @@ void conv_halo4_kernel(const C4Params P) {
     const int per = (nchunk_all + P.splits - 1) / P.splits;
     const int ck0 = split * per, nchunk = max(0, min(nchunk_all, ck0 + per) - ck0);      // my chunks ck0 .. ck0 + nchunk - 1
     const int nsub = max(nchunk, 1) * 18;
-    const int rb0 = tile_p * NB, rb_total = P.n_img * P.tiles_y;     // my row blocks rb0 .. rb0 + NB - 1: (image rb / tiles_y, rows (rb % tiles_y) TH ..)
+    const int tpi = P.tiles_y * P.tiles_x;                   // row blocks per image: block rb = (image rb / tpi, rows ((rb % tpi) / tiles_x) TH .., columns ((rb % tpi) % tiles_x) TW ..)
+    const int rb0 = tile_p * NB, rb_total = P.n_img * tpi;   // my row blocks rb0 .. rb0 + NB - 1
 
     // ---- halo staging: block b = 4 j + wave holds halo pixels 8 b .. 8 b + 7 x 8 channel groups; lane = 8 g + p takes pixel p, group (p + g) & 7 -----
     const int Hs = P.ups ? P.H >> 1 : P.H, Ws = P.ups ? P.W >> 1 : P.W;
@@ -102,7 +104,8 @@ void conv_halo4_kernel(const C4Params P) {
         const int blk = px / HB, rem = px - blk * HB;
         const int hy = rem / HW_, hx = rem - hy * HW_;
         const int rb = rb0 + blk;
-        const int img = rb / P.tiles_y, y = (rb - img * P.tiles_y) * TH - 1 + hy, x = hx - 1;
+        const int img = rb / tpi, rin = rb - img * tpi, yb = rin / P.tiles_x, xb = rin - yb * P.tiles_x;
+        const int y = yb * TH - 1 + hy, x = xb * TW - 1 + hx;
         const bool in = px < G::HPIX && rb < rb_total && (unsigned)y < (unsigned)P.H && (unsigned)x < (unsigned)P.W;
         const int ys = P.ups ? y >> 1 : y, xs = P.ups ? x >> 1 : x;
         h_pix[j] = in ? (img * Hs + ys) * Ws + xs : -1;
@@ -258,9 +261,9 @@ void conv_halo4_kernel(const C4Params P) {
         for (int mb = 0; mb < 5; ++mb) {
             const int r = wave * 80 + mb * 16 + l15;
             const int blk = r / RB, q = r - blk * RB, ty = q / TW, tx = q - ty * TW;
-            const int rb = rb0 + blk, img = rb / P.tiles_y, y = (rb - img * P.tiles_y) * TH + ty;
+            const int rb = rb0 + blk, img = rb / tpi, rin = rb - img * tpi, yb = rin / P.tiles_x, xb = rin - yb * P.tiles_x, y = yb * TH + ty;
             if (rb < rb_total && y < P.H) {
-                float* dst = P.ws + ((int64_t)split * mtot + ((int64_t)img * P.H + y) * P.W + tx) * P.cout + n0 + 4 * kq;
+                float* dst = P.ws + ((int64_t)split * mtot + ((int64_t)img * P.H + y) * P.W + xb * TW + tx) * P.cout + n0 + 4 * kq;
 #pragma unroll
                 for (int nb = 0; nb < 5; ++nb) *reinterpret_cast<f32x4*>(dst + nb * 16) = acc[mb][nb];
             }
@@ -272,9 +275,9 @@ void conv_halo4_kernel(const C4Params P) {
     constexpr int CPR = BN / 8;                              // 10 sixteen-byte chunks per row
     auto row_pixel = [&](int r, bool& ok) -> int64_t {       // tile row -> global pixel (rows past the image's last row / past the last image: not stored)
         const int blk = r / RB, q = r - blk * RB, ty = q / TW, tx = q - ty * TW;
-        const int rb = rb0 + blk, img = rb / P.tiles_y, y = (rb - img * P.tiles_y) * TH + ty;
-        ok = rb < rb_total && y < P.H && tx < P.W;
-        return ((int64_t)img * P.H + y) * P.W + tx;
+        const int rb = rb0 + blk, img = rb / tpi, rin = rb - img * tpi, yb = rin / P.tiles_x, xb = rin - yb * P.tiles_x, y = yb * TH + ty;
+        ok = rb < rb_total && y < P.H;
+        return ((int64_t)img * P.H + y) * P.W + xb * TW + tx;
     };
 #pragma unroll
     for (int nb = 0; nb < 5; ++nb) {
@@ -289,7 +292,7 @@ void conv_halo4_kernel(const C4Params P) {
         for (int mb = 0; mb < 5; ++mb) {
             float t4[4] = {0.f, 0.f, 0.f, 0.f};
             if (P.temb) {                                    // (a tile spans several images: the row's own image)
-                const int idx = wave * 80 + mb * 16 + l15, rb = min(rb0 + idx / RB, rb_total - 1), img = rb / P.tiles_y;
+                const int idx = wave * 80 + mb * 16 + l15, rb = min(rb0 + idx / RB, rb_total - 1), img = rb / tpi;
                 const u32x2 t = *reinterpret_cast<const u32x2*>(P.temb + (int64_t)(img / P.temb_div) * P.temb_ld + n);
                 t4[0] = __uint_as_float(t[0] << 16); t4[1] = __uint_as_float(t[0] & 0xffff0000u);
                 t4[2] = __uint_as_float(t[1] << 16); t4[3] = __uint_as_float(t[1] & 0xffff0000u);
@@ -337,8 +340,8 @@ void conv_halo4_kernel(const C4Params P) {
         for (int blk = 0; blk < NB; ++blk) {
             const int rb = rb0 + blk;
             if (rb >= rb_total) break;                       // (uniform)
-            const int img = rb / P.tiles_y, sp = rb - img * P.tiles_y;
-            const int vr = min(TH, P.H - sp * TH) * TW;       // rows of this block inside the image
+            const int img = rb / tpi, sp = rb - img * tpi;
+            const int vr = min(TH, P.H - (sp / P.tiles_x) * TH) * TW;       // rows of this block inside the image
             float gs = 0.f, gss = 0.f;
             for (int r = tid / GT; r < vr; r += RP) {
                 const unsigned* wsrc = reinterpret_cast<const unsigned*>(Os + (blk * RB + r) * OP + gl * cpg);
@@ -355,7 +358,7 @@ void conv_halo4_kernel(const C4Params P) {
             if (tid < GT) {
                 float a = 0.f, b = 0.f;
                 for (int k = 0; k < RP; ++k) { a += red[2 * (tid + k * GT)]; b += red[2 * (tid + k * GT) + 1]; }
-                float* dst = P.gn_part + (((int64_t)img * P.tiles_y + sp) * 32 + (n0 / cpg + tid)) * 2;
+                float* dst = P.gn_part + (((int64_t)img * tpi + sp) * 32 + (n0 / cpg + tid)) * 2;
                 dst[0] = a;
                 dst[1] = b;
             }
@@ -420,7 +423,8 @@ __global__ __launch_bounds__(256) void conv_halo4_finish_kernel(const C4Params P
 template <int TW> int launch_c4(C4Params& P, hipStream_t st) {
     using G = Geo<TW>;
     P.tiles_y = (P.H + G::TH - 1) / G::TH;
-    P.tiles_p = (P.n_img * P.tiles_y + G::NB - 1) / G::NB;
+    P.tiles_x = P.W / TW;
+    P.tiles_p = (P.n_img * P.tiles_y * P.tiles_x + G::NB - 1) / G::NB;
     static FmcPerDeviceFlag raised;
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo4_kernel<TW>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
@@ -448,9 +452,10 @@ extern "C" int fmc_conv3x3_halo4_pack_weight(const void* w, void* dst, int Cin, 
     return 0;
 }
 
-// W must be 8, 16 or 32 (the whole image width is one row block); any H
+// row blocks are 10 x 16 pixels where W % 16 == 0, else 5 x 8 (W % 8 == 0); any H
+static int c4_tw(int W) { return W % 16 == 0 ? 16 : 8; }
 extern "C" int fmc_conv3x3_halo4_supported(int n_img, int H, int W, int Cin, int Cin1, int Cout, int upsample2x) {
-    if (n_img < 1 || H < 1 || (W != 8 && W != 16 && W != 32) || Cin % 64 || Cout % BN) return 0;
+    if (n_img < 1 || H < 1 || W < 8 || W % 8 || Cin % 64 || Cout % BN) return 0;
     if (Cin1 <= 0 || Cin1 > Cin || Cin1 % 64) return 0;
     if (upsample2x && ((H | W) & 1)) return 0;
     const int64_t hs = upsample2x ? H / 2 : H, ws = upsample2x ? W / 2 : W;
@@ -459,10 +464,13 @@ extern "C" int fmc_conv3x3_halo4_supported(int n_img, int H, int W, int Cin, int
     return 1;
 }
 
-extern "C" int fmc_conv3x3_halo4_row_blocks_per_image(int H, int W) { return W == 8 ? (H + 4) / 5 : (H + 9) / 10; }
+extern "C" int fmc_conv3x3_halo4_row_blocks_per_image(int H, int W) {
+    const int tw = c4_tw(W);
+    return (tw == 8 ? (H + 4) / 5 : (H + 9) / 10) * (W / tw);
+}
 
 extern "C" int fmc_conv3x3_halo4_tiles(int n_img, int H, int W, int Cout) {
-    const int nb = W == 8 ? 8 : (W == 16 ? 2 : 1);
+    const int nb = c4_tw(W) == 8 ? 8 : 2;
     return (n_img * fmc_conv3x3_halo4_row_blocks_per_image(H, W) + nb - 1) / nb * (Cout / BN);
 }
 
@@ -477,7 +485,7 @@ extern "C" int fmc_conv3x3_halo4_bf16(const void* x, const void* x2, int Cin1, c
     if (!x || !w_packed || !out) FMC_FAIL(FMC_E_NULL, "conv3x3_halo4: NULL x / w / out");
     if (!x2) Cin1 = Cin;
     if (!fmc_conv3x3_halo4_supported(n_img, H, W, Cin, Cin1, Cout, upsample2x))
-        FMC_FAIL(FMC_E_SHAPE, "conv3x3_halo4: needs W in {8, 16, 32}, Cin %% 64 == 0 (both sources), Cout %% 80 == 0, operands < 2 GiB "
+        FMC_FAIL(FMC_E_SHAPE, "conv3x3_halo4: needs W %% 8 == 0, Cin %% 64 == 0 (both sources), Cout %% 80 == 0, operands < 2 GiB "
                  "(n=%d H=%d W=%d Cin=%d+%d Cout=%d ups=%d)", n_img, H, W, Cin1, Cin - Cin1, Cout, upsample2x);
     if (!fmc_aligned16(x) || !fmc_aligned16(w_packed) || !fmc_aligned16(out) || (x2 && !fmc_aligned16(x2)) || (residual && !fmc_aligned16(residual)) ||
         (bias && (reinterpret_cast<uintptr_t>(bias) & 7)) || (temb && ((reinterpret_cast<uintptr_t>(temb) & 7) || temb_row_stride % 4)))
@@ -503,9 +511,8 @@ extern "C" int fmc_conv3x3_halo4_bf16(const void* x, const void* x2, int Cin1, c
     P.x_bytes = (int64_t)n_img * hs * ws * Cin1 * 2; P.x2_bytes = (int64_t)n_img * hs * ws * (Cin - Cin1) * 2;
     P.w_bytes = (int64_t)Cout * 9 * Cin * 2;
     hipStream_t st = (hipStream_t)stream;
-    if (W == 8) launch_c4<8>(P, st);
-    else if (W == 16) launch_c4<16>(P, st);
-    else launch_c4<32>(P, st);
+    if (c4_tw(W) == 8) launch_c4<8>(P, st);
+    else launch_c4<16>(P, st);
     FMC_CHECK_LAUNCH("fmc_conv3x3_halo4_bf16");
     return 0;
 }

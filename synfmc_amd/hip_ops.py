@@ -2087,7 +2087,7 @@ def conv3x3(x_nchw: torch.Tensor, weight_cl: torch.Tensor, bias, temb=None, resi
         return y.permute(0, 3, 1, 2)
     # ... and its 4-wave form for the small feature maps (images 8 / 16 pixels wide: the two inner levels; csrc/conv_halo4.hip), split over the
     # reduction where the tiles alone would leave most of the chip idle (5x8-pixel images: 64 tiles)
-    if (CONV_HALO and CONV_HALO4 and not stride2 and w in (8, 16) and (temb is None or temb.stride(1) == 1)
+    if (CONV_HALO and CONV_HALO4 and not stride2 and w % 8 == 0 and (temb is None or temb.stride(1) == 1)
             and conv3x3_halo4_supported(n, h, w, cin, cin, cout, upsample)
             and _lib.load().fmc_conv3x3_halo4_tiles(n, h, w, cout) * conv3x3_halo4_split(n, h, w, cin, cout) >= CONV_HALO_MIN_TILES):
         dispatch_calls["conv3x3"]["own"] += 1

@@ -149,7 +149,9 @@ def test_resnet_block_fused_groupnorm_conv_matches_the_oracle_block():
     (16, 5, 8, 128, 160, 0, False, True),        # 5 x 8 images: eight per tile, fragments spanning two image rows
     (11, 5, 8, 64, 80, 0, False, False),         # ... with a last tile of three images
     (3, 16, 16, 64, 80, 0, False, True),         # 16 x 16 images (the 32x512x512 configuration): row blocks of 10 + 6 rows
-    (2, 20, 32, 128, 160, 0, False, True),       # 32 pixels wide: one 10 x 32 row block per tile
+    (2, 20, 32, 128, 160, 0, False, True),       # 32 pixels wide: two 10 x 16 row blocks side by side
+    (2, 32, 48, 64, 80, 0, False, True),         # the reference's training clip (256x384 -> 32 x 48 latents): 4 x 3 row blocks of 10 x 16, rows 30-31 in a short block
+    (3, 16, 24, 128, 160, 64, False, True),      # ... its 16 x 24 level: 5 x 8 row blocks (4 x 3 per image, the last row block one row high), two-source
 ])
 def test_conv3x3_halo4_matches_fp32_conv(n, h, w, cin, cout, c2, ups, extras):
     """`fmc_conv3x3_halo4_bf16` (csrc/conv_halo4.hip), the halo-resident convolution of the small feature maps, against the fp32 convolution of the
