@@ -343,14 +343,16 @@ int fmc_conv3x3_halo_bf16(const void* x, const void* x2, int Cin1, const void* w
  * fmc_conv3x3_halo_bf16 without the GroupNorm operand path; Cout % 80 == 0; w_packed = fmc_conv3x3_halo4_pack_weight(filter);
  * gn_partials [n_img, fmc_conv3x3_halo4_row_blocks_per_image(H, W), 32, 2].  fmc_conv3x3_halo4_tiles: workgroups an un-split launch has.
  * split_k > 1 (5x8-pixel images: 64 tiles on 256 CUs otherwise): the 64-channel chunks of the reduction are dealt to split_k workgroups per tile, fp32
- * partials in `workspace` (>= split_k * n_img * H * W * Cout * 4 bytes), summed in a fixed order by a second launch that runs the epilogue. */
-int fmc_conv3x3_halo4_supported(int n_img, int H, int W, int Cin, int Cin1, int Cout, int upsample2x);
-int fmc_conv3x3_halo4_pack_weight(const void* w, void* dst, int Cin, int Cout, void* stream);
+ * partials in `workspace` (>= split_k * n_img * H * W * Cout * 4 bytes), summed in a fixed order by a second launch that runs the epilogue.
+ * wide != 0 (W % 16 == 0, Cout % 160 == 0; its own packed filter): 8 waves, two per SIMD, 320 pixels x 160 channels per tile -- the same software-pipelined
+ * loop where that many tiles fill the chip (the 40x64 / 20x32 levels). */
+int fmc_conv3x3_halo4_supported(int n_img, int H, int W, int Cin, int Cin1, int Cout, int upsample2x, int wide);
+int fmc_conv3x3_halo4_pack_weight(const void* w, void* dst, int Cin, int Cout, int wide, void* stream);
 int fmc_conv3x3_halo4_row_blocks_per_image(int H, int W);
-int fmc_conv3x3_halo4_tiles(int n_img, int H, int W, int Cout);
+int fmc_conv3x3_halo4_tiles(int n_img, int H, int W, int Cout, int wide);
 int fmc_conv3x3_halo4_bf16(const void* x, const void* x2, int Cin1, const void* w_packed, const void* bias, const void* temb, const void* residual,
                            void* out, int n_img, int H, int W, int Cin, int Cout, int64_t temb_row_stride, int temb_img_div, int upsample2x,
-                           float* gn_partials, int split_k, void* workspace, int64_t workspace_bytes, void* stream);
+                           float* gn_partials, int split_k, void* workspace, int64_t workspace_bytes, int wide, void* stream);
 int fmc_groupnorm_coef(const float* partials, int part_splits, const float* gamma, const float* beta, float* coef, float* stats, int N, int HW,
                        int C, int G, float eps, void* stream);
 

@@ -65,12 +65,12 @@ SIGNATURES = {
     "fmc_conv3x3_halo_tiles_per_image": (c_int, [c_int, c_int]),
     "fmc_conv3x3_halo_bf16": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                       c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
-    "fmc_conv3x3_halo4_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
-    "fmc_conv3x3_halo4_pack_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "fmc_conv3x3_halo4_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "fmc_conv3x3_halo4_pack_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "fmc_conv3x3_halo4_row_blocks_per_image": (c_int, [c_int, c_int]),
-    "fmc_conv3x3_halo4_tiles": (c_int, [c_int, c_int, c_int, c_int]),
+    "fmc_conv3x3_halo4_tiles": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "fmc_conv3x3_halo4_bf16": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                       c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
+                                       c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p]),
     "fmc_groupnorm_coef": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "fmc_groupnorm_apply_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                         c_float, c_int, c_int, c_void_p]),

@@ -21,15 +21,18 @@
 
 namespace {
 
-constexpr int BM = 320, BN = 80;
+constexpr int BM = 320;
 #ifndef FMC_C4_INTERLEAVE
 #define FMC_C4_INTERLEAVE 1
 #endif
 constexpr bool INTERLEAVE = FMC_C4_INTERLEAVE != 0;          // A/B switch (compile time): C - E issued between the MFMAs instead of in front of them
-constexpr int WSUB = BN * 64;                              // one 32-deep W sub-tile: 80 rows x 64 B = 5 KiB
 constexpr unsigned OOB = 0x80000000u;
 
-template <int TW> struct Geo {
+// NWV waves: 4 (one per SIMD, 320 pixels x 80 channels) or 8 (two per SIMD, 320 x 160: wave = pixel block wave % 4, channel block wave / 4)
+template <int TW, int NWV> struct Geo {
+    static constexpr int BN = 20 * NWV, NT = 64 * NWV;
+    static constexpr int WSUB = BN * 64;                   // one 32-deep W sub-tile: BN rows x 64 B (5 / 10 KiB)
+    static constexpr int WPIECES = BN / 16;                // its 1-KiB pieces: 5 / 10; wave w issues piece w, the first WPIECES - NWV waves a second one
     static constexpr int TH = TW == 8 ? 5 : 10;
     static constexpr int RB = TH * TW;                     // pixels per row block
     static constexpr int NB = BM / RB;                     // row blocks per tile: 1 / 2 / 8
@@ -41,7 +44,7 @@ template <int TW> struct Geo {
     static constexpr int DW = NBW - 1;                     // W sub-tile s + DW is requested at LOAD(s), into the slot sub-tile s - 1 was read from
     static constexpr int OFF_W = 2 * HALO;
     static constexpr int LDS_BYTES = OFF_W + NBW * WSUB;
-    static constexpr int NPIECE = (HPIX / 8 + 3) / 4;      // halo pieces (16 B) per thread and chunk: blocks of 8 pixels x 8 channel groups over 4 waves
+    static constexpr int NPIECE = (HPIX / 8 + NWV - 1) / NWV;      // halo pieces (16 B) per thread and chunk: blocks of 8 pixels x 8 channel groups over the waves
     static_assert(HPIX % 8 == 0 && LDS_BYTES <= 163840 && NPIECE <= 18, "geometry");
 };
 
@@ -60,20 +63,26 @@ struct C4Params {
 
 template <int I> using IC = std::integral_constant<int, I>;
 
-// halo pieces requested in sub-tile i of a chunk: two per sub-tile from sub-tile 0 on (requested at LOAD(i), written at LOAD(i + 3))
-template <int NPIECE> constexpr int nh(int i) { return (i >= 0 && 2 * i < NPIECE) ? (2 * i + 1 < NPIECE ? 2 : 1) : 0; }
+// halo pieces requested in sub-tile i of a chunk (requested at LOAD(i), written at LOAD(i + 3)): PPS = 2 per sub-tile where a thread has more than
+// 12 pieces per chunk (4 waves), else one (8 waves: fewer staging registers in flight)
+template <int NPIECE> constexpr int pps() { return NPIECE > 12 ? 2 : 1; }
+template <int NPIECE> constexpr int nh(int i) {
+    return (i >= 0 && pps<NPIECE>() * i < NPIECE) ? (pps<NPIECE>() == 2 && 2 * i + 1 < NPIECE ? 2 : 1) : 0;
+}
 
-template <int TW>
-__global__ __launch_bounds__(256, 1)
+template <int TW, int NWV>
+__global__ __launch_bounds__(64 * NWV, NWV / 4)
 void conv_halo4_kernel(const C4Params P) {
-    using G = Geo<TW>;
+    using G = Geo<TW, NWV>;
+    constexpr int BN = G::BN, NT = G::NT, WSUB = G::WSUB;
     constexpr int TH = G::TH, RB = G::RB, NB = G::NB, HW_ = G::HW_, HB = G::HB, PLANE = G::PLANE, HALO = G::HALO, NBW = G::NBW, OFF_W = G::OFF_W;
     constexpr int NPIECE = G::NPIECE, DW = G::DW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
-    const bool clsA = wave == 0;                             // wave 0 issues two W pieces per sub-tile (0 and 4), waves 1 .. 3 one
+    const int wp = wave & 3, wn = wave >> 2;                 // my 80 pixels / my 80 channels of the tile
+    const bool clsA = wave < G::WPIECES - NWV;               // these waves issue two W pieces per sub-tile (w and NWV + w), the others one
 
     // ---- my tile: XCD x owns a contiguous range; the channel tiles of a pixel tile are neighbours (its halos come from that XCD's L2 once) --------
     int tile_p, tile_n, split;
@@ -100,7 +109,7 @@ void conv_halo4_kernel(const C4Params P) {
     int h_pix[NPIECE];                                       // source pixel index (image-major), or -1
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j) {
-        const int b = 4 * j + wave, px = 8 * b + pp;
+        const int b = NWV * j + wave, px = 8 * b + pp;
         const int blk = px / HB, rem = px - blk * HB;
         const int hy = rem / HW_, hx = rem - hy * HW_;
         const int rb = rb0 + blk;
@@ -110,7 +119,7 @@ void conv_halo4_kernel(const C4Params P) {
         const int ys = P.ups ? y >> 1 : y, xs = P.ups ? x >> 1 : x;
         h_pix[j] = in ? (img * Hs + ys) * Ws + xs : -1;
     }
-    const int h_lds = pg * PLANE + (8 * wave + pp) * 16;     // + j * 512 (+ buffer)
+    const int h_lds = pg * PLANE + (8 * wave + pp) * 16;     // + j * 128 NWV (+ buffer)
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)P.x, 0, (int)P.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsX2 = __builtin_amdgcn_make_buffer_rsrc((void*)(P.x2 ? P.x2 : P.x), 0, (int)(P.x2 ? P.x2_bytes : P.x_bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)P.w, 0, (int)P.w_bytes, 0x00020000);
@@ -126,8 +135,8 @@ void conv_halo4_kernel(const C4Params P) {
         return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)vo, 0, 0));
     };
     auto halo_store = [&](int j, int buf, const u32x4& v) {
-        if (8 * (4 * j + wave) < G::HPIX)                     // (wave-uniform: the last piece index exists for the first waves only)
-            *reinterpret_cast<u32x4*>(smem_raw + buf * HALO + h_lds + j * 512) = v;
+        if (8 * (NWV * j + wave) < G::HPIX)                   // (wave-uniform: the last piece index exists for the first waves only)
+            *reinterpret_cast<u32x4*>(smem_raw + buf * HALO + h_lds + j * (128 * NWV)) = v;
     };
 
     // ---- W stream: piece p = KiB p of the 5-KiB sub-tile block; wave w issues piece w, wave 0 also piece 4 --------------------------------------------
@@ -138,7 +147,7 @@ void conv_halo4_kernel(const C4Params P) {
         unsigned char* dst = smem_raw + OFF_W + iss_slot * WSUB + wave * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)dst, 16, (int)w_vo0, iss_soff, 0, 0);
         if constexpr (decltype(cls)::value)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(dst + 4096), 16, (int)w_vo0, iss_soff + 4096, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(dst + NWV * 1024), 16, (int)w_vo0, iss_soff + NWV * 1024, 0, 0);
         iss_soff += WSUB;
         if (--iss_left == 0) { iss_left = nsub; iss_soff = w_base; }      // (past the end the stream wraps to valid addresses)
         iss_slot = iss_slot + 1 == NBW ? 0 : iss_slot + 1;
@@ -147,11 +156,11 @@ void conv_halo4_kernel(const C4Params P) {
     // ---- fragments: my 80 pixels x all 80 channels ------------------------------------------------------------------------------------------------------
     f32x4 acc[5][5];
     bf16x8 wf[2][5], af[2][5];
-    const int wfrag = OFF_W + (l15 * 32 + (kq ^ (3 * ((l15 >> 3) & 1))) * 8) * 2;      // + slot * WSUB + nb * 1024
+    const int wfrag = OFF_W + ((wn * 80 + l15) * 32 + (kq ^ (3 * ((l15 >> 3) & 1))) * 8) * 2;      // + slot * WSUB + nb * 1024
     int afrag[5];                                            // + buf * HALO + half * 4 * PLANE + (ky * HW_ + kx) * 16
 #pragma unroll
     for (int mb = 0; mb < 5; ++mb) {
-        const int idx = wave * 80 + mb * 16 + l15, blk = idx / RB, r = idx - blk * RB, ty = r / TW, tx = r - ty * TW;
+        const int idx = wp * 80 + mb * 16 + l15, blk = idx / RB, r = idx - blk * RB, ty = r / TW, tx = r - ty * TW;
         afrag[mb] = kq * PLANE + (blk * HB + ty * HW_ + tx) * 16;
     }
 
@@ -167,7 +176,8 @@ void conv_halo4_kernel(const C4Params P) {
 
     auto main_loop = [&](auto cls) {
         constexpr int NW = decltype(cls)::value ? 2 : 1;
-        u32x4 hreg[3][2];                                    // staged pieces in flight: requested at LOAD(i), written at LOAD(i + 3)
+        constexpr int PPS = pps<NPIECE>();
+        u32x4 hreg[3][PPS];                                  // staged pieces in flight: requested at LOAD(i), written at LOAD(i + 3)
         // W sub-tiles 0 .. DW - 1 in flight; sub-tile 0 retired, published, its fragments (and chunk 0's halo) read into set 0
         w_issue(cls); w_issue(cls); w_issue(cls);
         if constexpr (DW == 4) w_issue(cls);
@@ -207,13 +217,13 @@ void conv_halo4_kernel(const C4Params P) {
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 // C. the staged halo pieces requested three sub-tiles ago (retired by wait A) go to the NEXT chunk's buffer
-                if constexpr (nh<NPIECE>(i - 3) >= 1) halo_store(2 * (i - 3), nbuf, hreg[(i - 3) % 3][0]);
-                if constexpr (nh<NPIECE>(i - 3) == 2) halo_store(2 * (i - 3) + 1, nbuf, hreg[(i - 3) % 3][1]);
+                if constexpr (nh<NPIECE>(i - 3) >= 1) halo_store(PPS * (i - 3), nbuf, hreg[(i - 3) % 3][0]);
+                if constexpr (nh<NPIECE>(i - 3) == 2) halo_store(PPS * (i - 3) + 1, nbuf, hreg[(i - 3) % 3][PPS - 1]);
                 // D. sub-tile s + 1's fragments into the other register set (the first sub-tile of the next chunk reads the buffer just filled)
                 read_frags((i + 1) & 1, i == 17 ? nbuf * HALO : abase, aimm1);
                 // E. requests: two halo pieces of the next chunk, then W sub-tile s + DW (into the slot sub-tile s - 1 was read from)
-                if constexpr (nh<NPIECE>(i) >= 1) hreg[i % 3][0] = halo_load(2 * i, c + 1);
-                if constexpr (nh<NPIECE>(i) == 2) hreg[i % 3][1] = halo_load(2 * i + 1, c + 1);
+                if constexpr (nh<NPIECE>(i) >= 1) hreg[i % 3][0] = halo_load(PPS * i, c + 1);
+                if constexpr (nh<NPIECE>(i) == 2) hreg[i % 3][PPS - 1] = halo_load(PPS * i + 1, c + 1);
                 w_issue(cls);
                 // F. 25 MFMAs of sub-tile s, with C - E in their issue shadow: a 16x16x32 MFMA occupies the matrix pipe for 16 cycles and the issue
                 //    port for 4 -- the fragment reads, the staging store / loads and the W request (all independent of this sub-tile's operands) go out
@@ -259,20 +269,20 @@ void conv_halo4_kernel(const C4Params P) {
         const int64_t mtot = (int64_t)P.n_img * P.H * P.W;
 #pragma unroll
         for (int mb = 0; mb < 5; ++mb) {
-            const int r = wave * 80 + mb * 16 + l15;
+            const int r = wp * 80 + mb * 16 + l15;
             const int blk = r / RB, q = r - blk * RB, ty = q / TW, tx = q - ty * TW;
             const int rb = rb0 + blk, img = rb / tpi, rin = rb - img * tpi, yb = rin / P.tiles_x, xb = rin - yb * P.tiles_x, y = yb * TH + ty;
             if (rb < rb_total && y < P.H) {
-                float* dst = P.ws + ((int64_t)split * mtot + ((int64_t)img * P.H + y) * P.W + xb * TW + tx) * P.cout + n0 + 4 * kq;
+                float* dst = P.ws + ((int64_t)split * mtot + ((int64_t)img * P.H + y) * P.W + xb * TW + tx) * P.cout + n0 + wn * 80 + 4 * kq;
 #pragma unroll
                 for (int nb = 0; nb < 5; ++nb) *reinterpret_cast<f32x4*>(dst + nb * 16) = acc[mb][nb];
             }
         }
         return;
     }
-    constexpr int OP = BN + 8;                               // bf16 pitch of the staging rows (176 B)
+    constexpr int OP = BN + 8;                               // bf16 pitch of the staging rows (176 / 336 B)
     bf16_t* Os = reinterpret_cast<bf16_t*>(smem_raw);        // [320][OP] = 56,320 B
-    constexpr int CPR = BN / 8;                              // 10 sixteen-byte chunks per row
+    constexpr int CPR = BN / 8;                              // sixteen-byte chunks per row
     auto row_pixel = [&](int r, bool& ok) -> int64_t {       // tile row -> global pixel (rows past the image's last row / past the last image: not stored)
         const int blk = r / RB, q = r - blk * RB, ty = q / TW, tx = q - ty * TW;
         const int rb = rb0 + blk, img = rb / tpi, rin = rb - img * tpi, yb = rin / P.tiles_x, xb = rin - yb * P.tiles_x, y = yb * TH + ty;
@@ -281,7 +291,7 @@ void conv_halo4_kernel(const C4Params P) {
     };
 #pragma unroll
     for (int nb = 0; nb < 5; ++nb) {
-        const int n = n0 + nb * 16 + 4 * kq;
+        const int n = n0 + wn * 80 + nb * 16 + 4 * kq;
         float b4[4] = {0.f, 0.f, 0.f, 0.f};
         if (P.bias) {
             const u32x2 t = *reinterpret_cast<const u32x2*>(P.bias + n);
@@ -292,7 +302,7 @@ void conv_halo4_kernel(const C4Params P) {
         for (int mb = 0; mb < 5; ++mb) {
             float t4[4] = {0.f, 0.f, 0.f, 0.f};
             if (P.temb) {                                    // (a tile spans several images: the row's own image)
-                const int idx = wave * 80 + mb * 16 + l15, rb = min(rb0 + idx / RB, rb_total - 1), img = rb / tpi;
+                const int idx = wp * 80 + mb * 16 + l15, rb = min(rb0 + idx / RB, rb_total - 1), img = rb / tpi;
                 const u32x2 t = *reinterpret_cast<const u32x2*>(P.temb + (int64_t)(img / P.temb_div) * P.temb_ld + n);
                 t4[0] = __uint_as_float(t[0] << 16); t4[1] = __uint_as_float(t[0] & 0xffff0000u);
                 t4[2] = __uint_as_float(t[1] << 16); t4[3] = __uint_as_float(t[1] & 0xffff0000u);
@@ -302,7 +312,7 @@ void conv_halo4_kernel(const C4Params P) {
         }
     }
     if (P.res) {
-        for (int cidx = tid; cidx < BM * CPR; cidx += 256) {
+        for (int cidx = tid; cidx < BM * CPR; cidx += NT) {
             const int r = cidx / CPR, ch = cidx - r * CPR;
             bool ok;
             const int64_t m = row_pixel(r, ok);
@@ -313,7 +323,7 @@ void conv_halo4_kernel(const C4Params P) {
         for (int mb = 0; mb < 5; ++mb)
 #pragma unroll
             for (int nb = 0; nb < 5; ++nb) {
-                const u32x2 t = *reinterpret_cast<const u32x2*>(Os + (wave * 80 + mb * 16 + l15) * OP + nb * 16 + 4 * kq);
+                const u32x2 t = *reinterpret_cast<const u32x2*>(Os + (wp * 80 + mb * 16 + l15) * OP + wn * 80 + nb * 16 + 4 * kq);
                 acc[mb][nb][0] += __uint_as_float(t[0] << 16); acc[mb][nb][1] += __uint_as_float(t[0] & 0xffff0000u);
                 acc[mb][nb][2] += __uint_as_float(t[1] << 16); acc[mb][nb][3] += __uint_as_float(t[1] & 0xffff0000u);
             }
@@ -323,10 +333,10 @@ void conv_halo4_kernel(const C4Params P) {
     for (int mb = 0; mb < 5; ++mb)
 #pragma unroll
         for (int nb = 0; nb < 5; ++nb)
-            *reinterpret_cast<u32x2*>(Os + (wave * 80 + mb * 16 + l15) * OP + nb * 16 + 4 * kq) =
+            *reinterpret_cast<u32x2*>(Os + (wp * 80 + mb * 16 + l15) * OP + wn * 80 + nb * 16 + 4 * kq) =
                 u32x2{pack_bf2(acc[mb][nb][0], acc[mb][nb][1]), pack_bf2(acc[mb][nb][2], acc[mb][nb][3])};
     __syncthreads();
-    for (int cidx = tid; cidx < BM * CPR; cidx += 256) {
+    for (int cidx = tid; cidx < BM * CPR; cidx += NT) {
         const int r = cidx / CPR, ch = cidx - r * CPR;
         bool ok;
         const int64_t m = row_pixel(r, ok);
@@ -335,7 +345,7 @@ void conv_halo4_kernel(const C4Params P) {
     // GroupNorm statistics of the ROUNDED outputs, one (sum, sum of squares) pair per (image, row block, group): thread t sums group t % GT over
     // rows t / GT, t / GT + RP, ... of one row block at a time; fixed summation order, no atomics
     if (P.gn_part) {
-        const int cpg = P.cout >> 5, GT = BN / cpg, RP = 256 / GT, gl = tid % GT;
+        const int cpg = P.cout >> 5, GT = BN / cpg, RP = NT / GT, gl = tid % GT;
         float* red = reinterpret_cast<float*>(smem_raw + (size_t)BM * OP * 2);
         for (int blk = 0; blk < NB; ++blk) {
             const int rb = rb0 + blk;
@@ -369,7 +379,7 @@ void conv_halo4_kernel(const C4Params P) {
 
 // filter [Cout][3][3][Cin] -> [Cout / 80][Cin / 64][9 taps][2 halves][80 rows][32], 16-byte chunks in their LDS places (chunk p of row r holds
 // logical chunk p ^ (3 * ((r >> 3) & 1)))
-__global__ __launch_bounds__(256) void conv_halo4_pack_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ dst, int cout, int cin) {
+__global__ __launch_bounds__(256) void conv_halo4_pack_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ dst, int cout, int cin, int BN) {
     const int64_t total = (int64_t)cout * 9 * cin / 8;
     for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
         int64_t t = id;
@@ -420,17 +430,17 @@ __global__ __launch_bounds__(256) void conv_halo4_finish_kernel(const C4Params P
     }
 }
 
-template <int TW> int launch_c4(C4Params& P, hipStream_t st) {
-    using G = Geo<TW>;
+template <int TW, int NWV> int launch_c4(C4Params& P, hipStream_t st) {
+    using G = Geo<TW, NWV>;
     P.tiles_y = (P.H + G::TH - 1) / G::TH;
     P.tiles_x = P.W / TW;
     P.tiles_p = (P.n_img * P.tiles_y * P.tiles_x + G::NB - 1) / G::NB;
     static FmcPerDeviceFlag raised;
     if (!raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo4_kernel<TW>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo4_kernel<TW, NWV>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
         raised = true;
     }
-    hipLaunchKernelGGL(conv_halo4_kernel<TW>, dim3((unsigned)(P.tiles_p * P.tiles_n * P.splits)), dim3(256), G::LDS_BYTES, st, P);
+    hipLaunchKernelGGL((conv_halo4_kernel<TW, NWV>), dim3((unsigned)(P.tiles_p * P.tiles_n * P.splits)), dim3(G::NT), G::LDS_BYTES, st, P);
     if (P.splits > 1) {
         const int64_t chunks = (int64_t)P.n_img * P.H * P.W * (P.cout / 8);
         const unsigned grid = (unsigned)((chunks + 255) / 256 < 2048 ? (chunks + 255) / 256 : 2048);
@@ -441,21 +451,23 @@ template <int TW> int launch_c4(C4Params& P, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int fmc_conv3x3_halo4_pack_weight(const void* w, void* dst, int Cin, int Cout, void* stream) {
+// `wide` = 0: 4 waves, 80 output channels per tile; 1: 8 waves, 160 (16-pixel-wide row blocks only).  The packed filter differs between the two.
+extern "C" int fmc_conv3x3_halo4_pack_weight(const void* w, void* dst, int Cin, int Cout, int wide, void* stream) {
+    const int BN = wide ? 160 : 80;
     if (!w || !dst) FMC_FAIL(FMC_E_NULL, "conv3x3_halo4_pack_weight: NULL pointer");
-    if (Cin % 64 || Cout % BN) FMC_FAIL(FMC_E_SHAPE, "conv3x3_halo4_pack_weight: Cin %% 64 / Cout %% 80 (Cin=%d Cout=%d)", Cin, Cout);
+    if (Cin % 64 || Cout % BN) FMC_FAIL(FMC_E_SHAPE, "conv3x3_halo4_pack_weight: Cin %% 64 / Cout %% %d (Cin=%d Cout=%d)", BN, Cin, Cout);
     if (!fmc_aligned16(w) || !fmc_aligned16(dst)) FMC_FAIL(FMC_E_ALIGN, "conv3x3_halo4_pack_weight: pointers must be 16-byte aligned");
     const int64_t chunks = (int64_t)Cout * 9 * Cin / 8;
     const int grid = (int)((chunks + 255) / 256 < 4096 ? (chunks + 255) / 256 : 4096);
-    hipLaunchKernelGGL(conv_halo4_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w, (bf16_t*)dst, Cout, Cin);
+    hipLaunchKernelGGL(conv_halo4_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w, (bf16_t*)dst, Cout, Cin, BN);
     FMC_CHECK_LAUNCH("fmc_conv3x3_halo4_pack_weight");
     return 0;
 }
 
 // row blocks are 10 x 16 pixels where W % 16 == 0, else 5 x 8 (W % 8 == 0); any H
 static int c4_tw(int W) { return W % 16 == 0 ? 16 : 8; }
-extern "C" int fmc_conv3x3_halo4_supported(int n_img, int H, int W, int Cin, int Cin1, int Cout, int upsample2x) {
-    if (n_img < 1 || H < 1 || W < 8 || W % 8 || Cin % 64 || Cout % BN) return 0;
+extern "C" int fmc_conv3x3_halo4_supported(int n_img, int H, int W, int Cin, int Cin1, int Cout, int upsample2x, int wide) {
+    if (n_img < 1 || H < 1 || W < 8 || W % 8 || Cin % 64 || Cout % (wide ? 160 : 80) || (wide && W % 16)) return 0;
     if (Cin1 <= 0 || Cin1 > Cin || Cin1 % 64) return 0;
     if (upsample2x && ((H | W) & 1)) return 0;
     const int64_t hs = upsample2x ? H / 2 : H, ws = upsample2x ? W / 2 : W;
@@ -469,9 +481,9 @@ extern "C" int fmc_conv3x3_halo4_row_blocks_per_image(int H, int W) {
     return (tw == 8 ? (H + 4) / 5 : (H + 9) / 10) * (W / tw);
 }
 
-extern "C" int fmc_conv3x3_halo4_tiles(int n_img, int H, int W, int Cout) {
+extern "C" int fmc_conv3x3_halo4_tiles(int n_img, int H, int W, int Cout, int wide) {
     const int nb = c4_tw(W) == 8 ? 8 : 2;
-    return (n_img * fmc_conv3x3_halo4_row_blocks_per_image(H, W) + nb - 1) / nb * (Cout / BN);
+    return (n_img * fmc_conv3x3_halo4_row_blocks_per_image(H, W) + nb - 1) / nb * (Cout / (wide ? 160 : 80));
 }
 
 /* As fmc_conv3x3_halo_bf16 (fmc_hip.h) without the GroupNorm operand path, for images 8 / 16 / 32 pixels wide; gn_partials
@@ -481,18 +493,19 @@ extern "C" int fmc_conv3x3_halo4_tiles(int n_img, int H, int W, int Cout) {
 extern "C" int fmc_conv3x3_halo4_bf16(const void* x, const void* x2, int Cin1, const void* w_packed, const void* bias, const void* temb,
                                       const void* residual, void* out, int n_img, int H, int W, int Cin, int Cout, int64_t temb_row_stride,
                                       int temb_img_div, int upsample2x, float* gn_partials, int split_k, void* workspace, int64_t workspace_bytes,
-                                      void* stream) {
+                                      int wide, void* stream) {
+    const int BN = wide ? 160 : 80;
     if (!x || !w_packed || !out) FMC_FAIL(FMC_E_NULL, "conv3x3_halo4: NULL x / w / out");
     if (!x2) Cin1 = Cin;
-    if (!fmc_conv3x3_halo4_supported(n_img, H, W, Cin, Cin1, Cout, upsample2x))
-        FMC_FAIL(FMC_E_SHAPE, "conv3x3_halo4: needs W %% 8 == 0, Cin %% 64 == 0 (both sources), Cout %% 80 == 0, operands < 2 GiB "
-                 "(n=%d H=%d W=%d Cin=%d+%d Cout=%d ups=%d)", n_img, H, W, Cin1, Cin - Cin1, Cout, upsample2x);
+    if (!fmc_conv3x3_halo4_supported(n_img, H, W, Cin, Cin1, Cout, upsample2x, wide))
+        FMC_FAIL(FMC_E_SHAPE, "conv3x3_halo4: needs W %% 8 == 0 (wide: %% 16), Cin %% 64 == 0 (both sources), Cout %% %d == 0, operands < 2 GiB "
+                 "(n=%d H=%d W=%d Cin=%d+%d Cout=%d ups=%d)", BN, n_img, H, W, Cin1, Cin - Cin1, Cout, upsample2x);
     if (!fmc_aligned16(x) || !fmc_aligned16(w_packed) || !fmc_aligned16(out) || (x2 && !fmc_aligned16(x2)) || (residual && !fmc_aligned16(residual)) ||
         (bias && (reinterpret_cast<uintptr_t>(bias) & 7)) || (temb && ((reinterpret_cast<uintptr_t>(temb) & 7) || temb_row_stride % 4)))
         FMC_FAIL(FMC_E_ALIGN, "conv3x3_halo4: x / w / out / residual must be 16-byte aligned, bias / temb rows 8-byte aligned");
     if (temb && temb_img_div < 1) FMC_FAIL(FMC_E_SHAPE, "conv3x3_halo4: temb_img_div %d", temb_img_div);
     if (gn_partials && (Cout % 64 || BN % (Cout / 32)))
-        FMC_FAIL(FMC_E_SHAPE, "conv3x3_halo4: the statistics epilogue needs Cout %% 64 == 0 and 80 %% (Cout / 32) == 0 (Cout=%d)", Cout);
+        FMC_FAIL(FMC_E_SHAPE, "conv3x3_halo4: the statistics epilogue needs Cout %% 64 == 0 and %d %% (Cout / 32) == 0 (Cout=%d)", BN, Cout);
     if (split_k < 1) split_k = 1;
     if (split_k > Cin / 64) split_k = Cin / 64;
     if (split_k > 1) {
@@ -511,8 +524,9 @@ extern "C" int fmc_conv3x3_halo4_bf16(const void* x, const void* x2, int Cin1, c
     P.x_bytes = (int64_t)n_img * hs * ws * Cin1 * 2; P.x2_bytes = (int64_t)n_img * hs * ws * (Cin - Cin1) * 2;
     P.w_bytes = (int64_t)Cout * 9 * Cin * 2;
     hipStream_t st = (hipStream_t)stream;
-    if (c4_tw(W) == 8) launch_c4<8>(P, st);
-    else launch_c4<16>(P, st);
+    if (c4_tw(W) == 8) launch_c4<8, 4>(P, st);
+    else if (wide) launch_c4<16, 8>(P, st);
+    else launch_c4<16, 4>(P, st);
     FMC_CHECK_LAUNCH("fmc_conv3x3_halo4_bf16");
     return 0;
 }

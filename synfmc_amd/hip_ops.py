@@ -1517,26 +1517,27 @@ def groupnorm_coef(partials: torch.Tensor, gamma: torch.Tensor, beta: torch.Tens
     return (coef, stats) if want_stats else coef
 
 
-def conv3x3_halo4_supported(n: int, h: int, w: int, cin: int, cin1: int, cout: int, upsample: bool) -> bool:
-    return bool(_lib.load().fmc_conv3x3_halo4_supported(n, h, w, cin, cin1, cout, int(upsample)))
+def conv3x3_halo4_supported(n: int, h: int, w: int, cin: int, cin1: int, cout: int, upsample: bool, wide: bool = False) -> bool:
+    return bool(_lib.load().fmc_conv3x3_halo4_supported(n, h, w, cin, cin1, cout, int(upsample), int(wide)))
 
 
-def _w_halo4_packed(weight_cl: torch.Tensor) -> torch.Tensor:
+def _w_halo4_packed(weight_cl: torch.Tensor, wide: bool = False) -> torch.Tensor:
     cache = _owner_cache(weight_cl, "_fmc_wtm")
-    key = ("halo4", weight_cl.storage_offset(), tuple(weight_cl.shape), tuple(weight_cl.stride()), weight_cl._version)
+    key = ("halo4w" if wide else "halo4", weight_cl.storage_offset(), tuple(weight_cl.shape), tuple(weight_cl.stride()), weight_cl._version)
     hit = cache.get(key)
     if hit is None:
         cout, cin = weight_cl.shape[:2]
         assert weight_cl.is_contiguous(memory_format=torch.channels_last)
         hit = torch.empty(cout * 9 * cin, dtype=weight_cl.dtype, device=weight_cl.device)
-        _lib.check(_lib.load().fmc_conv3x3_halo4_pack_weight(weight_cl.data_ptr(), hit.data_ptr(), cin, cout, _stream()), "fmc_conv3x3_halo4_pack_weight")
+        _lib.check(_lib.load().fmc_conv3x3_halo4_pack_weight(weight_cl.data_ptr(), hit.data_ptr(), cin, cout, int(wide), _stream()),
+                   "fmc_conv3x3_halo4_pack_weight")
         cache[key] = hit
     return hit
 
 
-def conv3x3_halo4_split(n: int, h: int, w: int, cin: int, cout: int, cus: int = 256) -> int:
+def conv3x3_halo4_split(n: int, h: int, w: int, cin: int, cout: int, cus: int = 256, wide: bool = False) -> int:
     """Workgroups per tile: 1 where the tiles fill the chip, else the divisor of the chunk count that brings the launch closest to one round."""
-    tiles = _lib.load().fmc_conv3x3_halo4_tiles(n, h, w, cout)
+    tiles = _lib.load().fmc_conv3x3_halo4_tiles(n, h, w, cout, int(wide))
     if tiles >= (3 * cus) // 4:
         return 1
     nchunk = cin // 64
@@ -1548,7 +1549,7 @@ def conv3x3_halo4_split(n: int, h: int, w: int, cin: int, cout: int, cus: int = 
 
 
 def conv3x3_halo4(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias=None, temb=None, residual_nhwc=None, temb_div: int = 1, upsample: bool = False,
-                  x2_nhwc: Optional[torch.Tensor] = None, emit_gn: bool = False, split_k: Optional[int] = None):
+                  x2_nhwc: Optional[torch.Tensor] = None, emit_gn: bool = False, split_k: Optional[int] = None, wide: bool = False):
     """`conv3x3` on the small feature maps (images 8 / 16 / 32 pixels wide; csrc/conv_halo4.hip): arguments and results as `conv3x3_halo` without the
     GroupNorm operand path; the statistics partials are per (image, row block of 5 / 10 rows)."""
     _dev(x_nhwc, weight_cl, bias, temb, residual_nhwc, x2_nhwc)
@@ -1563,10 +1564,10 @@ def conv3x3_halo4(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias=None, temb
     assert temb is None or (temb.stride(1) == 1 and temb.shape == (n // temb_div, cout) and n % temb_div == 0)
     assert residual_nhwc is None or (residual_nhwc.is_contiguous() and residual_nhwc.shape == (n, h, w, cout))
     L = _lib.load()
-    wp = _w_halo4_packed(weight_cl)
+    wp = _w_halo4_packed(weight_cl, wide)
     out = torch.empty(n, h, w, cout, dtype=x_nhwc.dtype, device=x_nhwc.device)
     if split_k is None:
-        split_k = 1 if emit_gn else conv3x3_halo4_split(n, h, w, cin, cout)
+        split_k = 1 if emit_gn else conv3x3_halo4_split(n, h, w, cin, cout, wide=wide)
     ws, ws_bytes = (None, 0) if split_k <= 1 else _splitk_workspace(x_nhwc.device, split_k, n * h * w, cout)
     part = torch.empty(n, L.fmc_conv3x3_halo4_row_blocks_per_image(h, w), 32, 2, dtype=torch.float32, device=x_nhwc.device) if emit_gn else None
     conv_halo_calls["conv4"] = conv_halo_calls.get("conv4", 0) + 1
@@ -1574,7 +1575,7 @@ def conv3x3_halo4(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias=None, temb
         call_log.append(("conv_halo4", (n, h, w, cin, cout, bool(upsample)), 2.0 * n * h * w * cout * 9 * cin))
     _lib.check(L.fmc_conv3x3_halo4_bf16(x_nhwc.data_ptr(), _p(x2_nhwc), c1, wp.data_ptr(), _p(bias), _p(temb), _p(residual_nhwc), out.data_ptr(),
                                         n, h, w, cin, cout, 0 if temb is None else temb.stride(0), int(temb_div), int(upsample), _p(part), int(split_k),
-                                        ws, ws_bytes, _stream()), "fmc_conv3x3_halo4_bf16")
+                                        ws, ws_bytes, int(wide), _stream()), "fmc_conv3x3_halo4_bf16")
     return (out, part) if emit_gn else out
 
 
@@ -2089,7 +2090,7 @@ def conv3x3(x_nchw: torch.Tensor, weight_cl: torch.Tensor, bias, temb=None, resi
     # reduction where the tiles alone would leave most of the chip idle (5x8-pixel images: 64 tiles)
     if (CONV_HALO and CONV_HALO4 and not stride2 and w % 8 == 0 and (temb is None or temb.stride(1) == 1)
             and conv3x3_halo4_supported(n, h, w, cin, cin, cout, upsample)
-            and _lib.load().fmc_conv3x3_halo4_tiles(n, h, w, cout) * conv3x3_halo4_split(n, h, w, cin, cout) >= CONV_HALO_MIN_TILES):
+            and _lib.load().fmc_conv3x3_halo4_tiles(n, h, w, cout, 0) * conv3x3_halo4_split(n, h, w, cin, cout) >= CONV_HALO_MIN_TILES):
         dispatch_calls["conv3x3"]["own"] += 1
         return conv3x3_halo4(x, weight_cl, bias, temb, r, temb_div, upsample).permute(0, 3, 1, 2)
     if emit_gn and gn_emit_ok(n * h * w, cout, 9 * cin, h * w, x.dtype):

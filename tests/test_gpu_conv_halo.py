@@ -161,6 +161,7 @@ def test_conv3x3_halo4_matches_fp32_conv(n, h, w, cin, cout, c2, ups, extras):
     from synfmc_amd import hip_ops as K
     hs, ws = (h // 2, w // 2) if ups else (h, w)
     assert K.conv3x3_halo4_supported(n, h, w, cin, cin - c2, cout, ups)
+    wide_ok = K.conv3x3_halo4_supported(n, h, w, cin, cin - c2, cout, ups, wide=True)
     x, x2, wt, g = _mk(n, hs, ws, cin, cout, seed=h + cin + n, c2=c2)
     bias = temb = res = None
     div = 1
@@ -191,3 +192,9 @@ def test_conv3x3_halo4_matches_fp32_conv(n, h, w, cin, cout, c2, ups, extras):
             assert torch.equal(split, K.conv3x3_halo4(cu(x), wt.cuda(), cu(bias), cu(temb), cu(res), temb_div=div, upsample=ups, x2_nhwc=cu(x2), split_k=sk))
         auto = K.conv3x3_halo4(cu(x), wt.cuda(), cu(bias), cu(temb), cu(res), temb_div=div, upsample=ups, x2_nhwc=cu(x2))     # (the front-end's own choice of split)
         assert rel_inf(auto, want) < 6e-3
+    if wide_ok:                                                              # the 8-wave form (160 channels per tile): same results as the 4-wave form, bit for bit
+        wide = K.conv3x3_halo4(cu(x), wt.cuda(), cu(bias), cu(temb), cu(res), temb_div=div, upsample=ups, x2_nhwc=cu(x2), split_k=1, wide=True, emit_gn=emit)
+        if emit:
+            wide, wparts = wide
+            assert rel_inf(wparts.sum(1), parts.sum(1)) < 1e-5
+        assert torch.equal(wide, got)

@@ -12,7 +12,8 @@ def t_ms(fn, reps=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 
-shapes = [(32, 10, 16, 1280, 1280, False), (32, 10, 16, 640, 1280, False), (32, 10, 16, 2560, 1280, False), (32, 10, 16, 1920, 1280, False),
+shapes = [(32, 40, 64, 320, 320, False), (32, 40, 64, 960, 320, False), (32, 40, 64, 640, 640, True), (32, 20, 32, 1920, 640, False),
+          (32, 10, 16, 1280, 1280, False), (32, 10, 16, 640, 1280, False), (32, 10, 16, 2560, 1280, False), (32, 10, 16, 1920, 1280, False),
           (32, 10, 16, 1280, 1280, True), (32, 5, 8, 1280, 1280, False), (32, 5, 8, 2560, 1280, False),
           (32, 20, 32, 640, 640, False), (32, 20, 32, 1280, 640, False)]
 for n, h, w, cin, cout, ups in shapes:
@@ -29,5 +30,8 @@ for n, h, w, cin, cout, ups in shapes:
     y0 = ref().permute(0, 2, 3, 1).float(); y1 = K.conv3x3_halo4(x, wt, bias, upsample=ups).float()
     err = ((y0 - y1).abs().max() / y0.abs().max()).item()
     sk = K.conv3x3_halo4_split(n, h, w, cin, cout)
-    print(f"{n}x{h}x{w} {cin}->{cout} ups={int(ups)} split {sk}: shipped {a*1e3:7.1f} us ({fl/a/1e9:6.0f} TF/s) | halo4 {b*1e3:7.1f} us ({fl/b/1e9:6.0f} TF/s = {fl/b/1e9/2500:.3f}) | "
+    wd = float("nan")
+    if K.conv3x3_halo4_supported(n, h, w, cin, cin, cout, ups, wide=True):
+        wd = t_ms(lambda: K.conv3x3_halo4(x, wt, bias, upsample=ups, wide=True))
+    print(f"{n}x{h}x{w} {cin}->{cout} ups={int(ups)} split {sk}: 8-wave {wd*1e3:7.1f} us ({fl/wd/1e9:6.0f} TF/s) | shipped {a*1e3:7.1f} us ({fl/a/1e9:6.0f} TF/s) | halo4 {b*1e3:7.1f} us ({fl/b/1e9:6.0f} TF/s = {fl/b/1e9/2500:.3f}) | "
           f"+stats {c*1e3:7.1f} us | diff vs shipped {err:.2e}", flush=True)
