@@ -1792,20 +1792,25 @@ def _cache_meta():
     return _cache_state["meta"]
 
 
-def load_autotune_table(path: Optional[str] = None) -> int:
-    """Read a persisted arm table (ignored unless it was made by this library build on this device type and with this arm
-    list).  Returns the number of shapes loaded.  Called lazily by the first front-end call."""
+DEFAULT_ARM_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "autotune_default_mi355x.json")
+autotune_sources = {"cache": 0, "defaults": 0}     # shapes taken from the per-build cache / from the tracked default table (bench.py reports them)
+
+
+def _load_table_file(path: str, strict_meta: bool) -> int:
     import ast
     import json
-    _cache_state["loaded"] = True
-    path = path or _cache_path()
     if not path or not os.path.isfile(path):
         return 0
     try:
         with open(path) as f:
             blob = json.load(f)
-        if blob.get("meta") != _cache_meta():
+        meta, mine = blob.get("meta") or {}, _cache_meta()
+        if strict_meta and meta != mine:
             return 0
+        if not strict_meta:                        # the tracked defaults: made for this ARCHITECTURE (device names differ from box to box)
+            arch = torch.cuda.get_device_properties(torch.cuda.current_device()).gcnArchName.split(":")[0]
+            if meta.get("arch") != arch:
+                return 0
         n = 0
         for k, v in blob["choices"].items():
             key = ast.literal_eval(k)
@@ -1814,8 +1819,24 @@ def load_autotune_table(path: Optional[str] = None) -> int:
                 _tune_log[key] = {int(a): ms for a, ms in v.get("ms", {}).items()}
                 n += 1
         return n
-    except Exception:                              # a corrupt cache must never take the run down: re-tune
+    except Exception:                              # a corrupt table must never take the run down: re-tune
         return 0
+
+
+def load_autotune_table(path: Optional[str] = None) -> int:
+    """Read the persisted arm tables.  First the per-build cache next to the library (ignored unless it was made by THIS library build on this
+    device type and with this arm list); then, for shapes it does not hold, the TRACKED default table `autotune_default_mi355x.json` (made on an
+    MI355X by `tools/make_default_arm_table.py` from a bench run; device type must match): a fresh box then runs the arms the table was
+    measured with instead of letting timing noise pick them anew (arm tables differed box to box).  `FMC_AUTOTUNE_DEFAULTS=0`
+    ignores the tracked table.  Returns the number of shapes loaded.  Called lazily by the first front-end call."""
+    _cache_state["loaded"] = True
+    n = _load_table_file(path or _cache_path(), True)
+    autotune_sources["cache"] += n
+    if os.environ.get("FMC_AUTOTUNE_DEFAULTS", "1") != "0" and torch.cuda.is_available():
+        d = _load_table_file(DEFAULT_ARM_TABLE, False)
+        autotune_sources["defaults"] += d
+        n += d
+    return n
 
 
 def save_autotune_table(path: Optional[str] = None) -> Optional[str]:

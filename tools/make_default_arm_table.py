@@ -1,0 +1,28 @@
+#!/usr/bin/env python
+"""Turn the arm table a `bench.py` run persisted on an MI355X (`FMC_AUTOTUNE_CACHE=<file>` / synfmc_amd/lib/autotune_cache.json) into the TRACKED
+default table `synfmc_amd/autotune_default_mi355x.json`: the per-shape choices and their timings, keyed by the GPU architecture only (the per-build cache is
+keyed by the library hash and dies with every rebuild).  Several inputs are merged; where they disagree the arm with the lower measured time wins.
+
+    python tools/make_default_arm_table.py gpurun_out/<run>/autotune_cache.json [more.json ...]
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = {"meta": None, "choices": {}}
+for path in sys.argv[1:]:
+    blob = json.load(open(path))
+    meta = {"arch": "gfx950", "arms": blob["meta"]["arms"], "made_from": []}      # (made on MI355X boxes: the caches carry no architecture field)
+    if out["meta"] is None:
+        out["meta"] = meta
+    out["meta"]["made_from"].append(os.path.relpath(os.path.abspath(path), ROOT))
+    for k, v in blob["choices"].items():
+        old = out["choices"].get(k)
+        t_new = v.get("ms", {}).get(str(v["arm"]), float("inf"))
+        t_old = old.get("ms", {}).get(str(old["arm"]), float("inf")) if old else float("inf")
+        if old is None or t_new < t_old:
+            out["choices"][k] = v
+dst = os.path.join(ROOT, "synfmc_amd", "autotune_default_mi355x.json")
+json.dump(out, open(dst, "w"), indent=0, sort_keys=True)
+print(f"{len(out['choices'])} shapes -> {dst}")
