@@ -2113,7 +2113,18 @@ def conv3x3(x_nchw: torch.Tensor, weight_cl: torch.Tensor, bias, temb=None, resi
             and conv3x3_halo4_supported(n, h, w, cin, cin, cout, upsample)
             and _lib.load().fmc_conv3x3_halo4_tiles(n, h, w, cout, 0) * conv3x3_halo4_split(n, h, w, cin, cout) >= CONV_HALO_MIN_TILES):
         dispatch_calls["conv3x3"]["own"] += 1
-        return conv3x3_halo4(x, weight_cl, bias, temb, r, temb_div, upsample).permute(0, 3, 1, 2)
+        # (statistics for the consuming GroupNorm where it would otherwise read its input twice -- the two-pass norm of the large feature maps -- and
+        #  the launch is not split over the reduction)
+        want = bool(emit_gn and GN_EPILOGUE and h * w >= GN_MIN_HW and cout % 64 == 0 and 80 % (cout // 32) == 0 and not torch.is_grad_enabled()
+                    and conv3x3_halo4_split(n, h, w, cin, cout) == 1)
+        y = conv3x3_halo4(x, weight_cl, bias, temb, r, temb_div, upsample, emit_gn=want)
+        if want:
+            y, part = y
+            gn_epilogue_calls["emitted"] += 1
+            y = y.permute(0, 3, 1, 2)
+            y._fmc_gn = (part, cout)
+            return y
+        return y.permute(0, 3, 1, 2)
     if emit_gn and gn_emit_ok(n * h * w, cout, 9 * cin, h * w, x.dtype):
         dispatch_calls["conv3x3"]["own"] += 1
         y, tag = conv3x3_gn(x, weight_cl, bias, temb, r, temb_div, upsample, stride2)

@@ -1370,9 +1370,11 @@ def test_groupnorm_statistics_from_the_producing_epilogue(K):
     assert torch.equal(y.permute(0, 2, 3, 1), plain)                                      # the emission does not change the output
     tok = y.permute(0, 2, 3, 1).reshape(8, 2560, 320)
     part, C = y._fmc_gn
-    want_s = tok.float().view(8, 16, 160, 32, 10).sum(dim=(2, 4))
-    want_ss = (tok.float() ** 2).view(8, 16, 160, 32, 10).sum(dim=(2, 4))
-    assert rel_inf(part[..., 0], want_s) < 1e-4 and rel_inf(part[..., 1], want_ss) < 1e-5
+    # (how a producer cuts an image into partial sums is its own business -- 160-pixel runs, 10 x 32 tiles, 10 x 16 row blocks: the consumer adds them up)
+    want_s = tok.float().view(8, 2560, 32, 10).sum(dim=(1, 3))
+    want_ss = (tok.float() ** 2).view(8, 2560, 32, 10).sum(dim=(1, 3))
+    assert part.shape[0] == 8 and part.shape[2:] == (32, 2) and part.shape[1] <= 64
+    assert rel_inf(part[..., 0].sum(1), want_s) < 1e-4 and rel_inf(part[..., 1].sum(1), want_ss) < 1e-5
     for act in (True, False):
         got = K.groupnorm_silu(tok, gamma, beta, 32, 1e-5, act, gn_tag=y._fmc_gn)
         two = K.groupnorm_silu(tok, gamma, beta, 32, 1e-5, act)
