@@ -327,6 +327,16 @@ int fmc_groupnorm_apply_fwd(const void* x, void* y, const float* gamma, const fl
  *     fmc_groupnorm_apply_fwd take them as `partials` with part_splits = tiles per image).
  * fmc_groupnorm_coef: partial sums [N, part_splits, G, 2] -> coef [N, C, 2] = (rstd gamma_c, beta_c - mean rstd gamma_c) and, when stats != NULL,
  *   stats [N, G, 2] = (mean, rstd); HW = pixels per image (count per group = HW * C / G); fp64 combination, deterministic. */
+/* ---------------------------------------------------------------------------------------------
+ * Token GEMM for the small-M projections of the 10x16 / 5x8 levels (csrc/gemm4.hip, round 5): nn.Linear of diffusers' Attention / Transformer2D / the
+ * motion module there (fmc/models/attention_processor.py:50-69,255-283, fmc/models/motion_module.py:219,228,284) with what follows it,
+ *   out = alpha * (x W^T + bias) + residual + residual2          (bf16; any of bias / residual / residual2 NULL; residual2 needs residual),
+ * on 160 x 160 tiles, 4 waves, software-pipelined fragment reads and operand requests.  x rows ldx apart, residual(s) ldres, out ldo; W [N, K] row-major.
+ * K % 64 == 0, N % 8 == 0, strides % 8 == 0, operands < 2 GiB; edge tiles are masked.  An arm of `hip_ops.linear`'s per-shape choice (700). */
+int fmc_linear4_supported(int64_t M, int N, int K, int64_t ldx);
+int fmc_linear4_bf16(const void* x, const void* w, const void* bias, const void* residual, const void* residual2, void* out, int64_t M, int N, int K,
+                     int64_t ldx, int64_t ldres, int64_t ldo, float alpha, void* stream);
+
 /* The statistics pass of fmc_groupnorm_silu_fwd alone (x read once, nothing written but the sums): partials [N][splits][G][2] fp32 with
  * splits = fmc_groupnorm_partial_splits(HW, C); x2 / C1: two-source channel concat as for fmc_groupnorm_silu_fwd. */
 int fmc_groupnorm_partial_splits(int HW, int C);

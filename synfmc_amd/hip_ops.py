@@ -836,6 +836,7 @@ def cfg_ddim_step(eps: torch.Tensor, x: torch.Tensor, guidance: float, alpha_t: 
 ARM_160 = 512
 ARM_256 = 528                       # C-ABI tile 17: persistent 256 x 320 tiles, GEGLU projections only (falls back to tile 16)
 ARM_SMALLM = 600                    # C-ABI tiles 19 .. 22: 64 x 128 (4 waves, 64- / 32-deep k-tiles), 128 x 128 and 64 x 256 (8 waves) with 32 x 64 per wave, for M <= 2560 (round 4)
+ARM_G4 = 700                        # `fmc_linear4_bf16` (csrc/gemm4.hip, round 5): 160 x 160 tiles, 4 waves, software-pipelined -- the M <= 5120 projections of the inner levels
 ARM_160B = 544                      # C-ABI tile 18: tile 16 reading the weight pre-packed tile-major (`_w_tilemajor`): linear 1-KiB operand requests
 
 
@@ -1160,6 +1161,26 @@ def _rows2d(t: torch.Tensor):
     return t.shape[0], t.stride(0)
 
 
+def linear4_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+                 alpha: float = 1.0, residual2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`alpha * (x @ weight^T + bias) + residual [+ residual2]` on `fmc_linear4_bf16` (160 x 160 tiles, 4 waves, software-pipelined: the small-M
+    projections of the 10x16 / 5x8 levels).  x `[..., K]` (dense last dim, uniformly strided rows), weight `[N, K]` contiguous."""
+    _dev(x, weight, bias, residual, residual2)
+    N, Kd = weight.shape
+    assert weight.is_contiguous() and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
+    M, ldx = _rows2d(x)
+    out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
+    ldres = 0
+    if residual is not None:
+        assert residual.shape == out.shape
+        _, ldres = _rows2d(residual)
+    if residual2 is not None:
+        assert residual is not None and residual2.shape == out.shape and _rows2d(residual2)[1] == ldres
+    _lib.check(_lib.load().fmc_linear4_bf16(x.data_ptr(), weight.data_ptr(), _p(bias), _p(residual), _p(residual2), out.data_ptr(), M, N, Kd, ldx, ldres,
+                                            N, float(alpha), _stream()), "fmc_linear4_bf16")
+    return out
+
+
 def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
                 residual: Optional[torch.Tensor] = None, alpha: float = 1.0, geglu: bool = False,
                 tile: int = 0, split_k: int = 1, x2: Optional[torch.Tensor] = None,
@@ -1481,6 +1502,7 @@ def conv3x3_gn(x_nhwc: torch.Tensor, weight_cl: torch.Tensor, bias, temb, residu
 # --------------------------------------------------------------------------------------------
 CONV_HALO = os.environ.get("FMC_CONV_HALO", "1") != "0"
 CONV_HALO_MIN_TILES = int(os.environ.get("FMC_CONV_HALO_MIN_TILES", "200"))     # workgroups below which the ring / stream-K arms keep the shape
+LINEAR4 = os.environ.get("FMC_LINEAR4", "1") != "0"            # A/B switch: `fmc_linear4_bf16` is a candidate arm of the projections
 CONV_HALO4 = os.environ.get("FMC_CONV_HALO4", "1") != "0"       # A/B switch: the 4-wave form on the 10x16 / 5x8 levels
 CONV_GN_FUSED = os.environ.get("FMC_CONV_GN_FUSED", "0") == "1"   # GroupNorm + SiLU in the conv's operand path instead of a separate apply pass (measured slower)
 conv_halo_calls = {"conv": 0, "gn_fused": 0, "stats_pass": 0, "stats_from_producer": 0}
@@ -1998,8 +2020,13 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         return linear_gn(x, weight, bias, residual, alpha, residual2, gn_hw)
     key = ("lin", M, N, Kd, bias is not None, (residual is not None) + (residual2 is not None),
            0 if x2 is None else x.shape[-1])
-    hip = lambda tile: linear_bf16(x, weight, bias, residual, alpha, tile=tile, x2=x2, residual2=residual2)
+    hip = lambda tile: (linear4_bf16(x, weight, bias, residual, alpha, residual2) if tile == ARM_G4
+                        else linear_bf16(x, weight, bias, residual, alpha, tile=tile, x2=x2, residual2=residual2))
     small = (ARM_SMALLM, ARM_SMALLM + 2) if (M <= 2560 and x2 is None and residual2 is None) else ()      # 64 x 128 tiles: 200-400 workgroups where 128 x 128 gives 100-200
+    # the software-pipelined 160 x 160 kernel: a candidate wherever its tiles are at most two rounds of the chip (the inner levels' projections)
+    t160 = ((M + 159) // 160) * ((N + 159) // 160)
+    if LINEAR4 and x2 is None and weight.is_contiguous() and 48 <= t160 <= 640 and Kd >= 320:
+        small = small + (ARM_G4,)
     use = _pick(key, hip, lib, Kd <= 640 and N <= 1024 and M >= 16384, split_arms(M, N, Kd) + small,
                 k320=(Kd == 320 and N % 320 == 0 and M % 64 == 0 and x2 is None and residual2 is None))
     if (use == 0 and lazy_residual and LAZY_RESIDUAL and residual is not None and residual2 is None and alpha == 1.0 and x2 is None

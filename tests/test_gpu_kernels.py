@@ -1973,3 +1973,33 @@ def test_temporal_block_fused(K, merge, B, hw):
         assert torch.equal(again, out)
     with pytest.raises(ValueError):                      # shapes outside the fused block's domain are refused (callers keep the un-fused chain)
         K.temporal_block(hd[:, :, :hw - 1].contiguous(), go.cuda(), bpe, 1e-5, K.pack_temporal_qkv(wqd), K._w_tilemajor(wod), bod, 40 ** -0.5)
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("M,N,Kd,extras", [(5120, 1280, 1280, 3), (1280, 1280, 1280, 2), (5120, 3840, 1280, 0), (5120, 1280, 5120, 1),
+                                           (300, 200, 128, 3), (160, 160, 64, 0), (20480, 640, 640, 2)])
+def test_linear4_small_m_projection(K, M, N, Kd, extras):
+    """`fmc_linear4_bf16` (csrc/gemm4.hip): `alpha (x W^T + b) + r + r2` on 160 x 160 software-pipelined tiles -- the M <= 5120 projections of the inner
+    levels (attention_processor.py:50-69,255-283; motion_module.py:219,228,284).  Element-wise bf16 bound against the exact result on the same rounded
+    operands; edge tiles (M, N not multiples of 160), the shortest reduction (two sub-tiles), K = 5120; bit-identical repeats; strided rows."""
+    dtype = torch.bfloat16
+    xo, xd = rnd((M, Kd), 971, dtype)
+    wo, wd = rnd((N, Kd), 972, dtype, scale=Kd ** -0.5)
+    bo, bd = rnd((N,), 973, dtype) if extras >= 1 else (None, None)
+    ro, rd = rnd((M, N), 974, dtype) if extras >= 2 else (None, None)
+    r2o, r2d = rnd((M, N), 975, dtype) if extras >= 3 else (None, None)
+    alpha = 0.7 if extras >= 2 else 1.0
+    got = K.linear4_bf16(xd, wd, bd, rd, alpha, r2d)
+    ref = xo.double() @ wo.double().t()
+    mag = xo.abs().double() @ wo.abs().double().t()
+    if bo is not None:
+        ref, mag = ref + bo.double(), mag + bo.abs().double()
+    ref, mag = alpha * ref, alpha * mag
+    for r in (ro, r2o):
+        if r is not None:
+            ref, mag = ref + r.double(), mag + r.abs().double()
+    assert_bf16_close(got, ref, mag, f"linear4 {(M, N, Kd)}")
+    assert torch.equal(got, K.linear4_bf16(xd, wd, bd, rd, alpha, r2d))
+    if M % 2 == 0:                                                       # rows of a wider matrix (a column slice: ldx > K)
+        wide = torch.cat([xd, xd.flip(0)], dim=1)
+        assert torch.equal(K.linear4_bf16(wide[:, :Kd], wd, bd, rd, alpha, r2d), got)
