@@ -527,26 +527,31 @@ struct G6Params {
     int64_t M; int cff;
 };
 
-template <int GC_>                                          // GC_ = 640 (8 waves, one tile per CU) | 320 (4 waves, 80 KiB: two workgroups per CU)
-__global__ __launch_bounds__(GC_ / 80 * 64, 2)
+// GC_ = 640 (8 waves, one tile per CU) | 320 (4 waves, 80 KiB: two workgroups per CU).  RH = 2 (GC_ = 320 only, round 5): ONE workgroup of 8 waves owns 160
+// rows -- wave w and wave w + 4 run the same columns on the two 80-row halves in step (the per-chunk barriers keep them together), so the two requests for every
+// weight fragment reach the CU's vector cache together instead of from two unrelated workgroups
+template <int GC_, int RH = 1>
+__global__ __launch_bounds__(GC_ / 80 * 64 * RH, 2)
 void geglu_direct_kernel(const G6Params P) {
-    constexpr int C = GC_, NW = C / 80, NT = 64 * NW, CPR = C / 8, KS = C / 32, GCOLS = 40 * NW, LPR = CPR / 10, WAVE_W = KS * 5 * 512;
+    constexpr int C = GC_, NW = C / 80, NT = 64 * NW * RH, ROWS = T6_ROWS * RH, CPR = C / 8, KS = C / 32, GCOLS = 40 * NW, LPR = CPR / 10, WAVE_W = KS * 5 * 512;
+    constexpr int NRG = NT / CPR;                                // row groups of the in-place normalisation pass
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* X = reinterpret_cast<bf16_t*>(smem_raw);             // [80][640], chunk c of row r at chunk c ^ ((r >> 1) & 7)
-    bf16_t* S = X + T6_ROWS * C;                                 // staging [80][GCOLS + 8]; phase A: (mean, rstd) x 80 rows
+    bf16_t* S = X + ROWS * C;                                    // staging [ROWS][GCOLS + 8]; phase A: (mean, rstd) x ROWS rows
     float* stats = reinterpret_cast<float*>(S);
     constexpr int SP = GCOLS + 8;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_all % NW, rh = wave_all / NW;          // my column group / my 80-row half
     const int l15 = lane & 15, kq = lane >> 4;
     const int xsw = (l15 >> 1) & 7;
-    const int64_t m0 = (int64_t)blockIdx.x * T6_ROWS;
+    const int64_t m0 = (int64_t)blockIdx.x * ROWS;
     const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)P.h, 0, (int)(P.M * C * 2), 0x00020000);
     // ---- phase A: rows -> X, LayerNorm in place ----
 #pragma unroll
     for (int j = 0; j < 13; ++j) {
-        const int q = wave + NW * j;
-        if (q < T6_ROWS * CPR / 64) {
+        const int q = wave_all + NW * RH * j;
+        if (q < ROWS * CPR / 64) {
             const int idx = 64 * q + lane, r = idx / CPR, pc = idx - r * CPR, c = pc ^ ((r >> 1) & 7);
             t6_dma(rsH, (unsigned)(((m0 + r) * C + c * 8) * 2), X + 64 * q * 8);
         }
@@ -554,7 +559,7 @@ void geglu_direct_kernel(const G6Params P) {
     T6_VMCNT0();
     __syncthreads();
 #pragma unroll 1
-    for (int r = tid / LPR; r < T6_ROWS; r += 64) {
+    for (int r = tid / LPR; r < ROWS; r += NT / LPR) {
         const int q = tid % LPR;
         const bf16_t* xr = X + r * C;
         u32x4 x4[10];
@@ -581,12 +586,12 @@ void geglu_direct_kernel(const G6Params P) {
         if (q == 0) *reinterpret_cast<f32x2_t*>(stats + 2 * r) = f32x2_t{mean, rsqrtf(s2 * (1.f / C) + P.ln_eps)};
     }
     __syncthreads();
-    if (tid < CPR * 6) {
+    if (tid < CPR * NRG) {
         const int nc = tid % CPR, nrg = tid / CPR;
         const f32x4 g0 = *reinterpret_cast<const f32x4*>(P.ln_gamma + nc * 8), g1 = *reinterpret_cast<const f32x4*>(P.ln_gamma + nc * 8 + 4);
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(P.ln_beta + nc * 8), b1 = *reinterpret_cast<const f32x4*>(P.ln_beta + nc * 8 + 4);
 #pragma unroll 2
-        for (int r = nrg; r < T6_ROWS; r += 6) {
+        for (int r = nrg; r < ROWS; r += NRG) {
             u32x4* px = reinterpret_cast<u32x4*>(X + r * C + (nc ^ ((r >> 1) & 7)) * 8);
             const u32x4 x4 = *px;
             const f32x2_t st = *reinterpret_cast<const f32x2_t*>(stats + 2 * r);
@@ -629,7 +634,7 @@ void geglu_direct_kernel(const G6Params P) {
         auto step = [&](auto gc) {
             constexpr int g = decltype(gc)::value;
             if constexpr (g + 2 < KS) load_w(g + 2);
-            int kqx = kq ^ xsw, xrow_o = l15 * C;
+            int kqx = kq ^ xsw, xrow_o = (rh * T6_ROWS + l15) * C;
             asm volatile("" : "+v"(kqx), "+v"(xrow_o));
             const int xo = xrow_o + ((g >> 1) * 8 + (((g & 1) * 4) ^ kqx)) * 8;
             __builtin_amdgcn_sched_barrier(0);
@@ -681,7 +686,7 @@ void geglu_direct_kernel(const G6Params P) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mb = 0; mb < 5; ++mb) {
-            bf16_t* Sr = S + (mb * 16 + l15) * SP + wave * 40;
+            bf16_t* Sr = S + (rh * T6_ROWS + mb * 16 + l15) * SP + wave * 40;
 #pragma unroll
             for (int p = 0; p < 2; ++p) {                          // blocks (0, 3) and (1, 4): value and gate in the same lane
                 float o[4];
@@ -859,9 +864,14 @@ extern "C" int fmc_geglu320_ln_bf16(const void* h, void* out, const float* ln_ga
     static FmcPerDeviceFlag raised;
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&geglu_direct_kernel<320>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&geglu_direct_kernel<320, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * lds);
         raised = true;
     }
-    hipLaunchKernelGGL(geglu_direct_kernel<320>, dim3((unsigned)(M / 80)), dim3(256), lds, (hipStream_t)stream, P);
+    // A/B switch, default off: measured 215 - 225 us either way on 81920 x 2560 x 320 (gpurun_out/r05n/geglu_ab.txt) -- pairing the two 80-row halves in one
+    // workgroup does not reduce what bounds this launch, so the weight stream's L2 -> CU traffic is not it
+    static const int rows160 = [] { const char* e = getenv("FMC_GEGLU320_ROWS160"); return e ? atoi(e) : 0; }();
+    if (rows160 && M % 160 == 0) hipLaunchKernelGGL((geglu_direct_kernel<320, 2>), dim3((unsigned)(M / 160)), dim3(512), 2 * lds, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL(geglu_direct_kernel<320>, dim3((unsigned)(M / 80)), dim3(256), lds, (hipStream_t)stream, P);
     FMC_CHECK_LAUNCH("fmc_geglu320_ln_bf16");
     return 0;
 }
