@@ -320,7 +320,7 @@ def measure_proj_roofline(device, dtype, iters=20):
            "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
            "avg_launch_ms": round(ms, 4), "flops_per_launch": flops, "traffic_algorithmic": 2.0 * (M * Kd + N * Kd + M * N // 2)}
     out.update(recorded_counters("proj"))
-    out["_match"] = ("name", "geglu_direct_kernel<640>") if direct else None
+    out["_match"] = ("name", "geglu_direct_kernel<640") if direct else None
     return out
 
 
