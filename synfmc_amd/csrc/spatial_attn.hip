@@ -331,6 +331,29 @@ __global__ __launch_bounds__(64 * SA_WAVES, (sizeof(T) == 2) ? (NKS <= 3 && NQ =
 #pragma unroll
     for (int nq = 0; nq < NQ; ++nq) {
         qrow[nq] = (qblk * SA_WAVES + wave) * (32 * NQ) + nq * 32 + l31;
+        if constexpr (sizeof(T) == 2) {
+            // all chunks of the row requested at once from clamped addresses, masked afterwards: a load inside a branch is
+            // followed by its own vmcnt(0) -- NKS dependent round trips at the head of every workgroup
+            const bf16_t* qp = reinterpret_cast<const bf16_t*>(qg) + (int64_t)(qrow[nq] < P.Sq ? qrow[nq] : P.Sq - 1) * P.qrs;
+            u32x4 qraw[NKS];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const int d0 = ks * 16 + half * 8;
+                qraw[ks] = *reinterpret_cast<const u32x4*>(qp + (d0 < D ? d0 : 0));
+            }
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const bool live = qrow[nq] < P.Sq && ks * 16 + half * 8 < D;
+                float qv[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    qv[2 * i] = live ? __uint_as_float(qraw[ks][i] << 16) * P.scale_log2 : 0.f;
+                    qv[2 * i + 1] = live ? __uint_as_float(qraw[ks][i] & 0xffff0000u) * P.scale_log2 : 0.f;
+                }
+                p_frag(qv, qf[nq][ks]);
+            }
+            continue;
+        }
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             const int d0 = ks * 16 + half * 8;
@@ -1066,6 +1089,190 @@ inline void launch_xattn40(const SAParams& P, hipStream_t st) {
     hipLaunchKernelGGL(xattn40_kernel, dim3((unsigned)(per * nkvb)), dim3(512), lds, st, P, nq32, units, nkvb);
 }
 
+// =====================================================================================================================
+// Whole-K/V kernel for the inner levels (bf16, D = 160, S_kv <= 160): the self-attention of the 10x16 and 5x8 feature
+// maps (S = 160 / 40) and the text cross-attention there (S_kv = 77).
+//
+// At these sizes a launch of the tiled kernel above is one wave of workgroups whose time is a chain of round trips
+// (Q, tile 0 -> LDS -> barrier, tile 1 -> ..., three tiles at S = 160: 32 us for 4.2 GF) with every second workgroup
+// of S = 160 holding one busy wave (128 + 32 query rows).  Here a workgroup = 5 waves = 160 query rows takes ALL the keys
+// of its (batch, head) into LDS in one round trip (K row-major, V row-major read through ds_read_b64_tr_b16 as above;
+// 105 KiB at 160 keys), keeps the whole score row in registers (5 x 16 per lane) and does the softmax exactly: the
+// row maximum is known before the first exp, so there is no reference, no rescale and no redo pass.  One barrier.
+// Same fragment mapping and the same rounding points as the tiled kernel (p rounded to bf16 for the PV product, the
+// denominator summed in fp32 from the unrounded p: the even-NKS rule above).
+template <int NB>   // resident 32-key blocks: 3 (S_kv <= 96) or 5 (S_kv <= 160)
+__global__ __launch_bounds__(320, 1) void sa_small160_kernel(const SAParams P) {
+    typedef bf16_t T;
+    constexpr int NKS = 10, NDT = 5, KP = NKS * 16 + 8, VPR = sa_vr_pitch<NDT>(), CH = 20, NKEY = NB * 32, NT = 320;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* Ks = reinterpret_cast<T*>(smem_raw);              // [NKEY][KP]
+    T* Vr = Ks + NKEY * KP;                              // [NKEY][VPR]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int bh = blockIdx.x / P.nqblk, qblk = blockIdx.x - bh * P.nqblk;
+    const int b = bh / P.H, h = bh - b * P.H;
+    const T* qg = (const T*)P.q + (int64_t)b * P.qbs + (int64_t)h * 160;
+    const T* kg = (const T*)P.k + (int64_t)(b / P.kv_batch_div) * P.kbs + (int64_t)h * 160;
+    const T* vg = (const T*)P.v + (int64_t)(b / P.kv_batch_div) * P.kbs + (int64_t)h * 160;
+    T* og = (T*)P.o + (int64_t)b * P.obs + (int64_t)h * 160;
+
+    constexpr int NSLOT = NKEY * CH / NT;                // 16-byte chunks per thread and operand: 10 / 6
+    static_assert(NKEY * CH % NT == 0, "whole chunks per thread");
+    // request order K, Q, V: the loads return in order, so K is in LDS and the scores are under way while V still travels
+    // (a launch moves its ~40 MB of q | k | v in one burst: the V half of it now hides under the QK^T products)
+    u32x4 kreg[NSLOT], vreg[NSLOT];
+    auto gload = [&](const T* base, u32x4 (&reg)[NSLOT]) {
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) {
+            const int c = tid + j * NT, row = c / CH, ch = c - row * CH;
+            // rows past S_kv repeat the last key (no branch, no select behind the load): their scores are masked to -inf
+            // below and their p = 0 multiplies a finite V row
+            reg[j] = *reinterpret_cast<const u32x4*>(base + (int64_t)(row < P.Skv ? row : P.Skv - 1) * P.krs + ch * 8);
+        }
+    };
+    auto lstore = [&](T* dst, int pitch, const u32x4 (&reg)[NSLOT]) {
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) {
+            const int c = tid + j * NT, row = c / CH, ch = c - row * CH;
+            *reinterpret_cast<u32x4*>(dst + row * pitch + ch * 8) = reg[j];
+        }
+    };
+    gload(kg, kreg);
+    const int qrow = (qblk * 5 + wave) * 32 + l31;
+    const bool active = (qblk * 5 + wave) * 32 < P.Sq;   // wave-uniform; idle waves still stage and meet the barriers
+    // the Q row is loaded unconditionally (clamped): a load inside a branch is followed by its own vmcnt(0), ten dependent
+    // round trips instead of one
+    u32x4 qraw[NKS];
+    {
+        const T* qp = qg + (int64_t)(qrow < P.Sq ? qrow : P.Sq - 1) * P.qrs + half * 8;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qraw[ks] = *reinterpret_cast<const u32x4*>(qp + ks * 16);
+    }
+    gload(vg, vreg);
+    lstore(Ks, KP, kreg);
+    Frag<T> qf[1][NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        float qv[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            qv[2 * i] = __uint_as_float(qraw[ks][i] << 16) * P.scale_log2;
+            qv[2 * i + 1] = __uint_as_float(qraw[ks][i] & 0xffff0000u) * P.scale_log2;
+        }
+        p_frag(qv, qf[0][ks]);
+    }
+    __syncthreads();
+
+    // ---- scores of the whole row, exact maximum, p = exp2(s - m) ---------------------------------------------------
+    Frag<T> pf[NB][2];
+    float m = 0.f, l_run = 0.f;
+    if (active) {
+        f32x16 s[NB];
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[blk][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)                 // k-step outermost: NB independent accumulators in flight
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                Frag<T> kf;
+                make_frag<T>(Ks + (blk * 32 + l31) * KP + ks * 16 + half * 8, kf);
+                mma32(kf, qf[0][ks], s[blk]);
+            }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+            if ((blk + 1) * 32 > P.Skv) {                // wave-uniform
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half >= P.Skv) s[blk][r] = -INFINITY;
+            }
+            mx = fold_max(s[blk], mx);
+        }
+        m = fmaxf(mx, __shfl_xor(mx, 32, 64));           // finite: key 0 always exists
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+            float p[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                p[r] = __builtin_amdgcn_exp2f(s[blk][r] - m);
+                l_run += p[r];
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float p8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) p8[i] = p[s2 * 8 + i];
+                p_frag(p8, pf[blk][s2]);
+            }
+        }
+    }
+    lstore(Vr, VPR, vreg);
+    __syncthreads();
+    if (!active) return;
+
+    // ---- O^T += V^T P^T -------------------------------------------------------------------------------------------
+    f32x16 oacc[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const T* vp = Vr + (blk * 32 + s2 * 16 + half * 4 + ((l31 & 15) >> 2)) * VPR + dt * 32 + (l31 >> 4) * 16 + (l31 & 3) * 4;
+                union { bf16x8 v; sa_s4 hh[2]; } rr;
+                rr.hh[0] = lds_tr16(vp);
+                rr.hh[1] = lds_tr16(vp + 8 * VPR);
+                Frag<T> vf;
+                vf.hi = rr.v;
+                mma32(vf, pf[blk][s2], oacc[dt]);
+            }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+    if (qrow < P.Sq) {
+        T* orow = og + (int64_t)qrow * P.ors;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                store4<T>(orow + dt * 32 + 8 * g + 4 * half, oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv,
+                          oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
+        if (P.lse && half == 0) P.lse[((int64_t)b * P.H + h) * P.Sq + qrow] = m * 0.6931471805599453f + logf(l_tot);
+    }
+}
+
+inline bool sa_small_ok(const SAParams& P) {     // FMC_SA_SMALL=0: the tiled kernel at the inner levels too (A/B)
+    static const bool on = [] {
+        const char* e = getenv("FMC_SA_SMALL");
+        return !e || atoi(e) != 0;
+    }();
+    return on && P.D == 160 && P.Skv <= 160;
+}
+template <int NB>
+void launch_sa_small_nb(const SAParams& P, hipStream_t st) {
+    const size_t lds = (size_t)NB * 32 * (10 * 16 + 8 + sa_vr_pitch<5>()) * 2;
+    if (lds > 64 * 1024) {
+        static FmcPerDeviceFlag raised;
+        if (!raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sa_small160_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL((sa_small160_kernel<NB>), dim3((unsigned)(P.B * P.H * P.nqblk)), dim3(320), lds, st, P);
+}
+inline void launch_sa_small(const SAParams& Pin, hipStream_t st) {
+    SAParams P = Pin;
+    P.nqblk = (P.Sq + 159) / 160;
+    if (P.Skv <= 96) launch_sa_small_nb<3>(P, st);
+    else launch_sa_small_nb<5>(P, st);
+}
+
 inline int sa_pipe_env() {            // FMC_SA_PIPE=0: the block-by-block kernel at d = 40 too (A/B); 4: persistent workgroups
     static const int v = [] {
         const char* e = getenv("FMC_SA_PIPE");
@@ -1234,6 +1441,11 @@ extern "C" int fmc_spatial_attn_fwd(const void* q, const void* k, const void* v,
     hipStream_t st = (hipStream_t)stream;
     if (dtype == FMC_BF16 && xattn40_ok(P)) {
         launch_xattn40(P, st);
+        FMC_CHECK_LAUNCH("fmc_spatial_attn_fwd");
+        return 0;
+    }
+    if (dtype == FMC_BF16 && sa_small_ok(P)) {
+        launch_sa_small(P, st);
         FMC_CHECK_LAUNCH("fmc_spatial_attn_fwd");
         return 0;
     }

@@ -137,7 +137,9 @@ def oracle_attention(q, k, v, heads):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,S,Skv,H,D", [(2, 160, 160, 8, 40), (2, 200, 200, 8, 80), (1, 130, 130, 8, 160),
                                          (2, 40, 40, 8, 160), (3, 300, 77, 8, 40), (2, 64, 77, 8, 160),
-                                         (2, 257, 257, 4, 8), (1, 2560, 2560, 8, 40), (2, 96, 96, 2, 64)])
+                                         (2, 257, 257, 4, 8), (1, 2560, 2560, 8, 40), (2, 96, 96, 2, 64),
+                                         # the whole-K/V kernel of the inner levels (d = 160, S_kv <= 160): several query blocks, ragged key counts
+                                         (2, 200, 77, 8, 160), (1, 330, 100, 8, 160), (3, 160, 160, 8, 160), (2, 33, 1, 8, 160)])
 def test_spatial_attention(K, dtype, B, S, Skv, H, D):
     C = H * D
     qo, qd = rnd((B, S, C), 10, dtype)
