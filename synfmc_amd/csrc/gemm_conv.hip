@@ -143,6 +143,7 @@ __device__ __forceinline__ void lin_to_tile(int lin, const GemmParams& P, int& t
 // hardware reciprocal and exp2 -- libdevice's erff costs ~3x as many VALU slots, and the level-0 GEGLU projection
 // evaluates 105 M of them per launch
 __device__ __forceinline__ float gelu_erf(float g) {
+    if (!FMC_GELU_EXACT) return fmc_gelu_fast(g);         // common.h: the sigmoid-form fit (2.6e-5 absolute), half the VALU work
     const float x = fabsf(g) * 0.70710678118654752f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.f));
     float p = fmaf(1.061405429f, t, -1.453152027f);

@@ -508,7 +508,8 @@ void temporal_block640_kernel(const T6Params P) {
 // streams each chunk's 640 weight rows in fragment order straight into registers (the projections of temporal_block640_kernel).  Weight rows are
 // permuted per wave to [v 0-15 | v 16-31 | v 32-39, g 32-39 | g 0-15 | g 16-31] (hip_ops.pack_geglu_frag80): value and gate of a column meet in one lane
 // for four of the five 16-row blocks, one v_permlane32_swap serves the fifth.
-__device__ __forceinline__ float t6_gelu_erf(float g) {       // Abramowitz & Stegun 7.1.26 (|error| < 1.5e-7), as gemm_conv.hip
+__device__ __forceinline__ float t6_gelu_erf(float g) {       // Abramowitz & Stegun 7.1.26 (|error| < 1.5e-7), as gemm_conv.hip; default: common.h's fast form
+    if (!FMC_GELU_EXACT) return fmc_gelu_fast(g);
     const float x = fabsf(g) * 0.70710678118654752f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.f));
     float p = fmaf(1.061405429f, t, -1.453152027f);
