@@ -402,6 +402,36 @@ def measure_temporal_block_roofline(device, dtype, iters=20):
     return out
 
 
+def torch_op_sites(fn, path):
+    """Diagnostic: device time of the torch (aten) ops of one eager call of `fn` by Python call site -> `path` (which lines still launch torch
+    elementwise / copy / cat kernels)."""
+    import collections
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+        fn()
+        torch.cuda.synchronize()
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for ev in prof.events():
+        if ev.device_type.name != "CPU" or not ev.name.startswith("aten::") or ev.cpu_parent is not None and ev.cpu_parent.name.startswith("aten::"):
+            continue
+        dev_us = sum(k.duration for k in ev.kernels) if ev.kernels else 0.0
+        if dev_us <= 0:
+            continue
+        frames = [f for f in (ev.stack or []) if "synfmc_amd" in f or "bench.py" in f][:3]
+        where = " <- ".join(fr.split("/")[-1] for fr in frames)
+        if not where:                                    # backward: no Python stack -- name the autograd node the op ran under
+            root = ev
+            while root.cpu_parent is not None:
+                root = root.cpu_parent
+            where = root.name
+        key = (ev.name, where)
+        agg[key][0] += dev_us
+        agg[key][1] += 1
+    with open(path, "w") as f:
+        for (name, where), (us, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:60]:
+            f.write(f"{us / 1e3:8.3f} ms {n:5d}x {name:28s} {where}\n")
+
+
 def in_step_trace(args, cfg, nsteps=4):
     """Per-launch kernel durations INSIDE the denoising step: this same command (fewer steps, no oracle, no roofline loops) run once more as a
     child process under `rocprofv3 --kernel-trace`, cut to the window of its last `nsteps` steps (between `cfg_ddim_kernel` dispatches).  The
@@ -889,33 +919,12 @@ def train_main(args):
     loss = None
 
     if getattr(args, "torch_profile", None):                 # diagnostic: which call sites launch the torch elementwise / copy kernels
-        from torch.profiler import profile, ProfilerActivity
         draw()
-        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+
+        def one():
             fwd_bwd()
             reducer.finish()
-            torch.cuda.synchronize()
-        import collections
-        agg = collections.defaultdict(lambda: [0.0, 0])
-        for ev in prof.events():
-            if ev.device_type.name != "CPU" or not ev.name.startswith("aten::") or ev.cpu_parent is not None and ev.cpu_parent.name.startswith("aten::"):
-                continue
-            dev_us = sum(k.duration for k in ev.kernels) if ev.kernels else 0.0
-            if dev_us <= 0:
-                continue
-            frames = [f for f in (ev.stack or []) if "synfmc_amd" in f or "bench.py" in f][:3]
-            where = " <- ".join(fr.split("/")[-1] for fr in frames)
-            if not where:                                    # backward: no Python stack -- name the autograd node the op ran under
-                root = ev
-                while root.cpu_parent is not None:
-                    root = root.cpu_parent
-                where = root.name
-            key = (ev.name, where)
-            agg[key][0] += dev_us
-            agg[key][1] += 1
-        with open(args.torch_profile, "w") as f:
-            for (name, where), (us, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:60]:
-                f.write(f"{us / 1e3:8.3f} ms {n:5d}x {name:28s} {where}\n")
+        torch_op_sites(one, args.torch_profile)
         reducer.zero_grad()
 
     def run(i):
@@ -981,7 +990,7 @@ def main():
     ap.add_argument("--grad-compress", default="none", choices=["none", "bf16"], help="train mode: gradient buckets on the wire")
     ap.add_argument("--fp8-temporal", action="store_true",
                     help="temporal attention on the fp8 path (e4m3 q|k|v from the QKV epilogue, fp8 MFMA): BASELINE configs[4]")
-    ap.add_argument("--torch-profile", default=None, help="train mode, diagnostic: write the device time of torch ops by call site (one eager step) to this file")
+    ap.add_argument("--torch-profile", default=None, help="diagnostic: write the device time of torch ops by call site (one eager step) to this file")
     ap.add_argument("--config", default="obj", choices=["obj", "cam", "lora", "train32"],
                     help="which BASELINE.json configuration: obj = configs[3], the metric's workload (default); cam = configs[2] (CMC only); "
                          "lora = configs[1] (Domain-LoRA only, 50-step DDIM loop); train32 = configs[4] (32x512x512 stage-3 training step, "
@@ -1143,6 +1152,7 @@ def main():
         # ineligible, and the order and shapes of the halo convolutions (to assign the in-step trace's launches to shapes)
         K.call_log = []
         d0 = {k: dict(v) for k, v in K.dispatch_calls.items()}
+        calls0 = {k: c for k, _, _, c in K.autotune_report()}
         with torch.no_grad():
             if args.no_graph:
                 unet_step(torch.cat([latents, latents]).to(dtype), ts[0])
@@ -1150,7 +1160,23 @@ def main():
                 runner._call()
         torch.cuda.synchronize()
         call_log, K.call_log = K.call_log, None
+        if os.environ.get("FMC_BENCH_SHAPES"):
+            # per-shape view of the step's autotuned front-end calls (GEMM / conv arms): calls per step, chosen arm, the tuner's own isolated time for it and
+            # for the vendor arm -- where the step's GEMM time sits, shape by shape (a side file, not part of the JSON line)
+            rows = []
+            for k, arm, ms, c in K.autotune_report():
+                n = c - calls0.get(k, 0)
+                if n > 0:
+                    rows.append({"shape": list(k), "calls_per_step": n, "arm": arm, "ms_arm": ms.get(arm), "ms_vendor": ms.get(0),
+                                 "ms_per_step": None if ms.get(arm) is None else round(n * ms[arm], 4)})
+            rows.sort(key=lambda r: -(r["ms_per_step"] or 0))
+            with open(os.environ["FMC_BENCH_SHAPES"], "w") as f:
+                for r in rows:
+                    f.write(json.dumps(r) + "\n")
         dispatch = {k: {a: K.dispatch_calls[k][a] - d0[k][a] for a in v} for k, v in K.dispatch_calls.items()}
+        if getattr(args, "torch_profile", None):
+            with torch.no_grad():
+                torch_op_sites((lambda: unet_step(torch.cat([latents, latents]).to(dtype), ts[0])) if args.no_graph else runner._call, args.torch_profile)
         K.save_autotune_table()                         # (the trace child reads the arm table this process tuned)
         roof = measure_attention_roofline(device, dtype) if bf else None
         roof_conv = measure_conv_roofline(device, dtype, 1) if bf else None

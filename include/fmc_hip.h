@@ -521,12 +521,14 @@ int fmc_xattn_pack_kv40(const void* kv, void* out, int batch, int S, int64_t ld_
  * out[M][cff] = (n W_v^T + b_v) * gelu(n W_g^T + b_g), n = LayerNorm(h): `GEGLU.forward` of diffusers' FeedForward behind norm3 / ff_norm
  * (fmc/models/motion_module.py:295-299; BasicTransformerBlock).  A workgroup keeps its 80 normalised rows in LDS and walks the cff / 320 column chunks
  * with the chunk's weight rows streamed in MFMA-fragment order (`hip_ops.pack_geglu_frag80`) -- replaces fmc_layernorm_fwd + fmc_linear_bf16(GEGLU).
- *   h bf16 [M][640], M % 80 == 0; out bf16 [M][cff] row-major, cff % 320 == 0; bias bf16 [2 cff] (value | gate) or NULL. */
+ *   h bf16 [M][640], M % 80 == 0; out bf16 [M][cff] row-major, cff % 320 == 0; bias bf16 [2 cff] (value | gate) or NULL.
+ *   out_blocked != 0 (M % 160 == 0): out is written tile-major, [M / 160][cff / 32][160][32] -- the layout fmc_linear_bf16_ffblk reads with x_blocked
+ *   (the intermediate is private to the feed-forward; its second GEMM then requests contiguous 10-KiB operand blocks). */
 int fmc_geglu640_ln_bf16(const void* h, void* out, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* w_packed, const void* bias,
-                         int64_t M, int cff, void* stream);
+                         int64_t M, int cff, int out_blocked, void* stream);
 /* The same at the 40x64 level: h bf16 [M][320], cff % 160 == 0; 4 waves and 77 KiB of LDS per workgroup, two workgroups per CU. */
 int fmc_geglu320_ln_bf16(const void* h, void* out, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* w_packed, const void* bias,
-                         int64_t M, int cff, void* stream);
+                         int64_t M, int cff, int out_blocked, void* stream);
 /* Diagnostic: `buf` = device buffer of [workgroups][4][8] int64 that receives s_memrealtime stamps (100 MHz) of wave 0 at the phase boundaries of
  * its first four tiles (tools/scratch/r04/probe_tb.py); NULL switches the stamps off (default). */
 int fmc_temporal_block_set_debug(void* buf);

@@ -101,8 +101,8 @@ SIGNATURES = {
     "fmc_xattn_block640_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                         c_float, c_void_p]),
     "fmc_xattn_pack_kv": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
-    "fmc_geglu320_ln_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
-    "fmc_geglu640_ln_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "fmc_geglu320_ln_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "fmc_geglu640_ln_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "fmc_xattn_pack_kv40": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "fmc_xattn_block320_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                         c_int, c_int, c_int, c_int, c_float, c_void_p]),

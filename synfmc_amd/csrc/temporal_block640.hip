@@ -526,6 +526,7 @@ struct G6Params {
     const bf16_t* w;                                       // [Cff / 320 chunks][8 waves][20 k-steps][5 blocks][lane][8]
     const bf16_t* bias;                                    // [2 Cff] (value | gate) or NULL
     int64_t M; int cff;
+    int out_blocked;                                       // out tile-major [M / 160][cff / 32][160][32] (GemmParams::a_blocked of the feed-forward's second GEMM)
 };
 
 // GC_ = 640 (8 waves, one tile per CU) | 320 (4 waves, 80 KiB: two workgroups per CU).  RH = 2 (GC_ = 320 only, round 5): ONE workgroup of 8 waves owns 160
@@ -714,7 +715,10 @@ void geglu_direct_kernel(const G6Params P) {
             const int c = tid + NT * it;
             if (it < 6 || tid < NT / 4) {
                 const int r = c / (GCOLS / 8), cc = c - r * (GCOLS / 8);
-                *reinterpret_cast<u32x4*>(P.out + (m0 + r) * (int64_t)P.cff + ch * GCOLS + cc * 8) = *reinterpret_cast<const u32x4*>(S + r * SP + cc * 8);
+                const int64_t m = m0 + r;
+                const int col = ch * GCOLS + cc * 8;
+                const int64_t dst = P.out_blocked ? (((m / 160) * (P.cff >> 5) + (col >> 5)) * 160 + m % 160) * 32 + (col & 31) : m * P.cff + col;
+                *reinterpret_cast<u32x4*>(P.out + dst) = *reinterpret_cast<const u32x4*>(S + r * SP + cc * 8);
             }
         }
         __syncthreads();                                          // the staging region is free again
@@ -830,15 +834,16 @@ extern "C" int fmc_xattn_pack_kv(const void* kv, void* out, int batch, int S, in
 // LayerNorm + GEGLU projection with the A operand resident (see geglu640_kernel): h bf16 [M][640] (M % 80 == 0), out bf16 [M][cff] row-major,
 // w_packed = hip_ops.pack_geglu_frag80 of the [2 cff, 640] projection (cff % 320 == 0), bias bf16 [2 cff] or NULL, ln_gamma / ln_beta fp32 [640].
 extern "C" int fmc_geglu640_ln_bf16(const void* h, void* out, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* w_packed, const void* bias,
-                                    int64_t M, int cff, void* stream) {
+                                    int64_t M, int cff, int out_blocked, void* stream) {
     if (!h || !out || !ln_gamma || !ln_beta || !w_packed) FMC_FAIL(FMC_E_NULL, "geglu640_ln_bf16: NULL tensor");
     if (M <= 0 || M % 80 || cff <= 0 || cff % 320 || M * 640 * 2 >= ((int64_t)1 << 31) || M * cff * 2 >= ((int64_t)1 << 40))
         FMC_FAIL(FMC_E_SHAPE, "geglu640_ln_bf16: M %% 80 == 0, cff %% 320 == 0 (got M=%lld cff=%d)", (long long)M, cff);
+    if (out_blocked && M % 160) FMC_FAIL(FMC_E_SHAPE, "geglu640_ln_bf16: the tile-major output needs M %% 160 == 0 (got M=%lld)", (long long)M);
     if (!fmc_aligned16(h) || !fmc_aligned16(out) || !fmc_aligned16(w_packed) || !fmc_aligned16(ln_gamma) || !fmc_aligned16(ln_beta) || (bias && ((uintptr_t)bias & 7)))
         FMC_FAIL(FMC_E_ALIGN, "geglu640_ln_bf16: tensors must be 16-byte aligned");
     G6Params P{};
     P.h = (const bf16_t*)h; P.out = (bf16_t*)out; P.ln_gamma = ln_gamma; P.ln_beta = ln_beta; P.ln_eps = ln_eps;
-    P.w = (const bf16_t*)w_packed; P.bias = (const bf16_t*)bias; P.M = M; P.cff = cff;
+    P.w = (const bf16_t*)w_packed; P.bias = (const bf16_t*)bias; P.M = M; P.cff = cff; P.out_blocked = out_blocked != 0;
     static FmcPerDeviceFlag raised;
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&geglu_direct_kernel<640>), hipFuncAttributeMaxDynamicSharedMemorySize, T6_LDS);
@@ -852,15 +857,16 @@ extern "C" int fmc_geglu640_ln_bf16(const void* h, void* out, const float* ln_ga
 // the same at the 40x64 level: h bf16 [M][320], w_packed = hip_ops.pack_geglu_frag80 of the [2 cff, 320] projection, cff % 160 == 0; 4 waves and 77 KiB of
 // LDS per workgroup, two workgroups per CU
 extern "C" int fmc_geglu320_ln_bf16(const void* h, void* out, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* w_packed, const void* bias,
-                                    int64_t M, int cff, void* stream) {
+                                    int64_t M, int cff, int out_blocked, void* stream) {
     if (!h || !out || !ln_gamma || !ln_beta || !w_packed) FMC_FAIL(FMC_E_NULL, "geglu320_ln_bf16: NULL tensor");
     if (M <= 0 || M % 80 || cff <= 0 || cff % 160 || M * 320 * 2 >= ((int64_t)1 << 31))
         FMC_FAIL(FMC_E_SHAPE, "geglu320_ln_bf16: M %% 80 == 0, cff %% 160 == 0 (got M=%lld cff=%d)", (long long)M, cff);
+    if (out_blocked && M % 160) FMC_FAIL(FMC_E_SHAPE, "geglu320_ln_bf16: the tile-major output needs M %% 160 == 0 (got M=%lld)", (long long)M);
     if (!fmc_aligned16(h) || !fmc_aligned16(out) || !fmc_aligned16(w_packed) || !fmc_aligned16(ln_gamma) || !fmc_aligned16(ln_beta) || (bias && ((uintptr_t)bias & 7)))
         FMC_FAIL(FMC_E_ALIGN, "geglu320_ln_bf16: tensors must be 16-byte aligned");
     G6Params P{};
     P.h = (const bf16_t*)h; P.out = (bf16_t*)out; P.ln_gamma = ln_gamma; P.ln_beta = ln_beta; P.ln_eps = ln_eps;
-    P.w = (const bf16_t*)w_packed; P.bias = (const bf16_t*)bias; P.M = M; P.cff = cff;
+    P.w = (const bf16_t*)w_packed; P.bias = (const bf16_t*)bias; P.M = M; P.cff = cff; P.out_blocked = out_blocked != 0;
     constexpr int lds = (80 * 320 + 80 * 168) * 2;
     static FmcPerDeviceFlag raised;
     if (!raised) {

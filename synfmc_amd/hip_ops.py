@@ -1134,16 +1134,32 @@ def geglu_ln_direct_ok(h: torch.Tensor, weight: torch.Tensor) -> bool:
     return (GEGLU_DIRECT_640 and C == 640 and (weight.shape[0] // 2) % 320 == 0) or (GEGLU_DIRECT_320 and C == 320 and (weight.shape[0] // 2) % 160 == 0)
 
 
+GEGLU_DIRECT_BLOCKED = os.environ.get("FMC_GEGLU_DIRECT_BLOCKED", "1") != "0"   # A/B switch: the level-0 feed-forward's intermediate tile-major (below)
+
+
+def geglu_direct_blocked_ok(h: torch.Tensor, w2: torch.Tensor, residual) -> bool:
+    """Level 0 (C = 320): `geglu_ln_direct(..., blocked=True)` + `linear_from_blocked` -- the second GEMM (K = 1280, N = 320) streams a 210-MB operand in
+    128-byte row pieces 2560 bytes apart when it is row-major; tile-major it requests contiguous 10-KiB blocks (113 -> 99 us isolated,
+    tools/scratch/r05/bench_ffblk.py).  No gain measured at C = 640 (74.6 / 75.2 us), so only this level takes it."""
+    C = h.shape[-1]
+    M = h.numel() // C
+    N2, Cff = w2.shape
+    return (GEGLU_DIRECT_BLOCKED and FF_BLOCKED and C == 320 and M % 160 == 0 and N2 % 320 == 0 and Cff % 32 == 0 and (M // 160) * (N2 // 320) > _cus(h.device)
+            and M * Cff * 2 < (1 << 31) and w2.dtype == torch.bfloat16 and w2.is_contiguous()
+            and (residual is None or (residual.is_contiguous() and residual.dtype == h.dtype)) and os.environ.get("FMC_G160_PERSIST", "1") != "0")
+
+
 def geglu_ln_direct(h: torch.Tensor, ln_gamma: torch.Tensor, ln_beta: torch.Tensor, ln_eps: float, w_packed: torch.Tensor, bias: Optional[torch.Tensor],
-                    cff: int) -> torch.Tensor:
-    """`GEGLU(LayerNorm(h))` in one launch (`fmc_geglu640_ln_bf16` / `fmc_geglu320_ln_bf16`): `[..., C] -> [..., cff]`."""
+                    cff: int, blocked: bool = False) -> torch.Tensor:
+    """`GEGLU(LayerNorm(h))` in one launch (`fmc_geglu640_ln_bf16` / `fmc_geglu320_ln_bf16`): `[..., C] -> [..., cff]`.  `blocked`: the result is laid
+    out tile-major `[M / 160][cff / 32][160][32]` for `linear_from_blocked` (same shape, private to the feed-forward)."""
     _dev(h, ln_gamma, ln_beta, w_packed, bias)
     C = h.shape[-1]
     M = h.numel() // C
     out = torch.empty(*h.shape[:-1], cff, dtype=h.dtype, device=h.device)
     fn = _lib.load().fmc_geglu640_ln_bf16 if C == 640 else _lib.load().fmc_geglu320_ln_bf16
-    _lib.check(fn(h.data_ptr(), out.data_ptr(), ln_gamma.data_ptr(), ln_beta.data_ptr(), float(ln_eps), w_packed.data_ptr(), _p(bias), M, cff, _stream()),
-               "fmc_geglu_ln_bf16")
+    _lib.check(fn(h.data_ptr(), out.data_ptr(), ln_gamma.data_ptr(), ln_beta.data_ptr(), float(ln_eps), w_packed.data_ptr(), _p(bias), M, cff, int(blocked),
+                  _stream()), "fmc_geglu_ln_bf16")
     return out
 
 

@@ -630,7 +630,10 @@ class FeedForward(nn.Module):
         if hit is None or hit[0] != key:
             hit = (key, K.pack_geglu_frag80(w))
             self.__dict__["_geglu_frag"] = hit
-        mid = K.geglu_ln_direct(h, f32_param(norm, "weight"), f32_param(norm, "bias"), norm.eps, hit[1], proj.proj.bias, w.shape[0] // 2)
+        blocked = K.geglu_direct_blocked_ok(h, out.weight, residual)
+        mid = K.geglu_ln_direct(h, f32_param(norm, "weight"), f32_param(norm, "bias"), norm.eps, hit[1], proj.proj.bias, w.shape[0] // 2, blocked=blocked)
+        if blocked:
+            return K.linear_from_blocked(mid, out.weight, out.bias, residual)
         return out(mid, residual=residual)
 
     def forward(self, hidden_states, scale: float = 1.0, residual: Optional[torch.Tensor] = None):

@@ -1743,7 +1743,7 @@ def _temporal_block_reference(h, gamma, beta, pe, eps, wqkv, wout, bout, heads, 
     return F.linear(o, wout, bout) + h
 
 
-@pytest.mark.parametrize("M,cff,C", [(80, 320, 640), (20480, 2560, 640), (240, 640, 640), (80, 160, 320), (81920, 1280, 320), (400, 480, 320)])
+@pytest.mark.parametrize("M,cff,C", [(80, 320, 640), (20480, 2560, 640), (240, 640, 640), (80, 160, 320), (81920, 1280, 320), (400, 480, 320), (320, 640, 320)])
 def test_geglu_ln_direct(K, M, cff, C):
     """`fmc_geglu640_ln_bf16` / `fmc_geglu320_ln_bf16`: LayerNorm + GEGLU projection with the A operand resident in LDS and the (value / gate row-permuted) weight streamed in
     fragment order; against fp32 (max norm), the same with the kernel's rounding points (element-wise bf16 bound), and deterministic."""
@@ -1769,6 +1769,18 @@ def test_geglu_ln_direct(K, M, cff, C):
     out_nb = K.geglu_ln_direct(hd, go.cuda(), bo.cuda(), 1e-5, K.pack_geglu_frag80(wd), None, cff)
     y = F.linear(F.layer_norm(ho, (C,), go, bo, 1e-5), wo)
     assert rel_inf(out_nb.float(), y[:, :cff] * F.gelu(y[:, cff:])) < 2e-2
+    if M % 160 == 0:
+        # tile-major output [M / 160][cff / 32][160][32] (the feed-forward's private intermediate): the same values, bit for bit, and the second GEMM
+        # reads them back as the row-major result (`linear_from_blocked` against the tuned front-end on the row-major tensor)
+        blk = K.geglu_ln_direct(hd, go.cuda(), bo.cuda(), 1e-5, K.pack_geglu_frag80(wd), bid, cff, blocked=True)
+        assert torch.equal(blk.view(M // 160, cff // 32, 160, 32).permute(0, 2, 1, 3).reshape(M, cff), out)
+        if C == 320 and M >= 81920:
+            w2o, w2d = rnd((C, cff), 6, dtype, scale=cff ** -0.5)
+            b2o, b2d = rnd((C,), 7, dtype, scale=0.3)
+            assert K.geglu_direct_blocked_ok(hd, w2d, hd)
+            got = K.linear_from_blocked(blk, w2d, b2d, hd)
+            ref2 = F.linear(out.float().cpu(), w2o, b2o) + ho
+            assert rel_inf(got.float(), ref2) < 1e-2
 
 
 @pytest.mark.parametrize("B,Fr,hw,S", [(1, 1, 160, 77), (2, 16, 2560, 77), (3, 2, 320, 80), (2, 3, 160, 5)])
