@@ -427,9 +427,31 @@ def torch_op_sites(fn, path):
         key = (ev.name, where)
         agg[key][0] += dev_us
         agg[key][1] += 1
+    # the profiler does not always hand back Python stacks (graph-runner calls under no_grad): a dispatch-mode pass names the call sites of the
+    # large elementwise / copy ops with their element counts
+    import traceback
+    from torch.utils._python_dispatch import TorchDispatchMode
+    sites = collections.defaultdict(lambda: [0, 0])
+
+    class Sites(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            out = func(*args, **(kwargs or {}))
+            name = func.__name__ if hasattr(func, "__name__") else str(func)
+            if isinstance(out, torch.Tensor) and out.is_cuda and out.numel() >= (1 << 20) and any(k in str(func) for k in ("add", "cat", "mul", "copy", "silu", "clone", "contiguous")):
+                st = [f"{os.path.basename(fr.filename)}:{fr.lineno}" for fr in traceback.extract_stack() if "synfmc_amd" in fr.filename and "hip_ops" not in fr.filename][-3:]
+                key = (str(func), " <- ".join(reversed(st)))
+                sites[key][0] += 1
+                sites[key][1] += out.numel()
+            return out
+    with Sites():
+        fn()
+        torch.cuda.synchronize()
     with open(path, "w") as f:
         for (name, where), (us, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:60]:
             f.write(f"{us / 1e3:8.3f} ms {n:5d}x {name:28s} {where}\n")
+        f.write("\ncall sites of the large elementwise / copy ops (dispatch mode): count, output elements\n")
+        for (name, where), (n, el) in sorted(sites.items(), key=lambda kv: -kv[1][1])[:60]:
+            f.write(f"{n:5d}x {el / 1e6:9.1f} M  {name:24s} {where}\n")
 
 
 def in_step_trace(args, cfg, nsteps=4):

@@ -337,6 +337,17 @@ int fmc_linear4_supported(int64_t M, int N, int K, int64_t ldx);
 int fmc_linear4_bf16(const void* x, const void* w, const void* bias, const void* residual, const void* residual2, void* out, int64_t M, int N, int K,
                      int64_t ldx, int64_t ldres, int64_t ldo, float alpha, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * The vendor arm of the token projections, called directly (csrc/vendor_gemm.hip, round 5): out = x W^T + bias + residual as ONE hipBLASLt launch
+ * (D = A B + beta C with the bias epilogue) -- nn.Linear + the residual add of attention to_out / the feed-forward output / proj_out
+ * (fmc/models/attention_processor.py:69, fmc/models/motion_module.py:228,299) where the per-shape choice is the library.  torch's F.linear cannot pass C and
+ * bias together and followed the GEMM with an elementwise add.  bf16; bias [N] | NULL; residual rows ldres apart | NULL; x rows ldx, out rows ldo apart;
+ * W [N, K] row-major.  `algo` indexes the heuristic's candidate list, 0 <= algo < fmc_vendor_linear_candidates(...) (0 = the library's first choice).
+ * The first call for a problem queries the heuristic and, per device, allocates a 64-MiB workspace: make it outside stream capture. */
+int fmc_vendor_linear_candidates(int64_t M, int N, int K, int64_t ldx, int64_t ldres, int64_t ldo, int has_bias, int has_residual);
+int fmc_vendor_linear_bf16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int N, int K,
+                           int64_t ldx, int64_t ldres, int64_t ldo, int algo, void* stream);
+
 /* The statistics pass of fmc_groupnorm_silu_fwd alone (x read once, nothing written but the sums): partials [N][splits][G][2] fp32 with
  * splits = fmc_groupnorm_partial_splits(HW, C); x2 / C1: two-source channel concat as for fmc_groupnorm_silu_fwd. */
 int fmc_groupnorm_partial_splits(int HW, int C);

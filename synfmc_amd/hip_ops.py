@@ -1177,6 +1177,45 @@ def _rows2d(t: torch.Tensor):
     return t.shape[0], t.stride(0)
 
 
+VENDOR_DIRECT = os.environ.get("FMC_VENDOR_DIRECT", "1") != "0"      # A/B switch: the vendor arm through fmc_vendor_linear_bf16 (bias + residual in the GEMM)
+VENDOR_ALGO = int(os.environ.get("FMC_VENDOR_ALGO", "0"))            # experiments: which heuristic candidate (clamped to the list)
+_vendor_seen = {}                                                     # problem -> candidate count (a first call plans: never under stream capture)
+vendor_direct_calls = {"direct": 0, "with_residual": 0}
+
+
+def vendor_linear_ok(x: torch.Tensor, weight: torch.Tensor, bias, residual) -> bool:
+    if not (VENDOR_DIRECT and x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.is_contiguous() and x.stride(-1) == 1
+            and (x.is_contiguous() or x.ndim == 2) and (bias is None or (bias.dtype == torch.bfloat16 and bias.is_contiguous()))
+            and (residual is None or (residual.dtype == torch.bfloat16 and residual.stride(-1) == 1 and (residual.is_contiguous() or residual.ndim == 2)))
+            and not torch.is_grad_enabled()):
+        return False
+    N, Kd = weight.shape
+    M, ldx = _rows2d(x)
+    key = (x.device.index, M, N, Kd, ldx, 0 if residual is None else _rows2d(residual)[1], bias is not None, residual is not None)
+    return key in _vendor_seen or not torch.cuda.is_current_stream_capturing()
+
+
+def vendor_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`x @ weight^T + bias + residual` as one hipBLASLt launch (`fmc_vendor_linear_bf16`): the library arm of `linear` without the separate torch add."""
+    _dev(x, weight, bias, residual)
+    N, Kd = weight.shape
+    M, ldx = _rows2d(x)
+    out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
+    ldres = 0 if residual is None else _rows2d(residual)[1]
+    key = (x.device.index, M, N, Kd, ldx, ldres, bias is not None, residual is not None)
+    n = _vendor_seen.get(key)
+    if n is None:
+        n = _lib.load().fmc_vendor_linear_candidates(M, N, Kd, ldx, ldres, N, int(bias is not None), int(residual is not None))
+        if n <= 0:
+            _lib.check(n if n < 0 else -1, "fmc_vendor_linear_candidates")
+        _vendor_seen[key] = n
+    _lib.check(_lib.load().fmc_vendor_linear_bf16(x.data_ptr(), weight.data_ptr(), _p(bias), _p(residual), out.data_ptr(), M, N, Kd, ldx, ldres, N,
+                                                  min(VENDOR_ALGO, n - 1), _stream()), "fmc_vendor_linear_bf16")
+    vendor_direct_calls["direct"] += 1
+    vendor_direct_calls["with_residual"] += residual is not None
+    return out
+
+
 def linear4_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
                  alpha: float = 1.0, residual2: Optional[torch.Tensor] = None) -> torch.Tensor:
     """`alpha * (x @ weight^T + bias) + residual [+ residual2]` on `fmc_linear4_bf16` (160 x 160 tiles, 4 waves, software-pipelined: the small-M
@@ -2002,6 +2041,9 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
 
     def lib():
         xin = x if x2 is None else torch.cat([x, x2], dim=-1)
+        if alpha == 1.0 and vendor_linear_ok(xin, weight, bias, residual):
+            y = vendor_linear(xin, weight, bias, residual)         # bias + residual inside the library's epilogue: no elementwise pass behind the GEMM
+            return y if residual2 is None else y + residual2
         y = F.linear(xin, weight, bias)
         if residual is not None:
             y = torch.add(residual, y, alpha=alpha)

@@ -1990,6 +1990,44 @@ def test_temporal_block_fused(K, merge, B, hw):
 
 
 @torch.no_grad()
+@pytest.mark.parametrize("M,N,Kd,extras", [(5120, 1280, 1280, 2), (1280, 1280, 5120, 2), (5120, 3840, 1280, 0), (5120, 1280, 1280, 1), (304, 200, 128, 2)])
+def test_vendor_linear_direct(K, M, N, Kd, extras):
+    """`fmc_vendor_linear_bf16` (csrc/vendor_gemm.hip): the library arm of the token projections as ONE hipBLASLt launch, `x W^T + b + r` with bias and
+    residual in the GEMM's epilogue (torch: F.linear + add).  Element-wise bf16 bound against the exact result; every heuristic candidate; strided rows; and
+    the front-end's vendor arm goes through it (no torch add behind the GEMM)."""
+    dtype = torch.bfloat16
+    xo, xd = rnd((M, Kd), 981, dtype)
+    wo, wd = rnd((N, Kd), 982, dtype, scale=Kd ** -0.5)
+    bo, bd = rnd((N,), 983, dtype) if extras >= 1 else (None, None)
+    ro, rd = rnd((M, N), 984, dtype) if extras >= 2 else (None, None)
+    ref = xo.double() @ wo.double().t()
+    mag = xo.abs().double() @ wo.abs().double().t()
+    if bo is not None:
+        ref, mag = ref + bo.double(), mag + bo.abs().double()
+    if ro is not None:
+        ref, mag = ref + ro.double(), mag + ro.abs().double()
+    got = K.vendor_linear(xd, wd, bd, rd)
+    assert_bf16_close(got, ref, mag, f"vendor_linear {(M, N, Kd)}")
+    n = K._lib.load().fmc_vendor_linear_candidates(M, N, Kd, Kd, N if rd is not None else 0, N, int(bd is not None), int(rd is not None))
+    assert n >= 1
+    lib = K._lib.load()
+    for algo in range(n):
+        out = torch.empty_like(got)
+        K._lib.check(lib.fmc_vendor_linear_bf16(xd.data_ptr(), wd.data_ptr(), bd.data_ptr() if bd is not None else None, rd.data_ptr() if rd is not None else None,
+                                                out.data_ptr(), M, N, Kd, Kd, N if rd is not None else 0, N, algo, torch.cuda.current_stream().cuda_stream), "vendor")
+        assert_bf16_close(out, ref, mag, f"vendor_linear candidate {algo}")
+    assert lib.fmc_vendor_linear_bf16(xd.data_ptr(), wd.data_ptr(), None, None, got.data_ptr(), M, N, Kd, Kd, 0, N, n, 0) != 0      # past the list: refused
+    wide = torch.cat([xd, xd.flip(0)], dim=1)                                # rows of a wider matrix (ldx > K)
+    assert_bf16_close(K.vendor_linear(wide[:, :Kd], wd, bd, rd), ref, mag, "vendor_linear strided")
+    if rd is not None:
+        K._choice[("lin", M, N, Kd, bd is not None, 1, 0)] = 0               # the front-end's vendor arm
+        before = dict(K.vendor_direct_calls)
+        y = K.linear(xd, wd, bd, residual=rd)
+        assert K.vendor_direct_calls["with_residual"] == before["with_residual"] + 1
+        assert_bf16_close(y, ref, mag, "linear -> vendor arm")
+
+
+@torch.no_grad()
 @pytest.mark.parametrize("M,N,Kd,extras", [(5120, 1280, 1280, 3), (1280, 1280, 1280, 2), (5120, 3840, 1280, 0), (5120, 1280, 5120, 1),
                                            (300, 200, 128, 3), (160, 160, 64, 0), (20480, 640, 640, 2)])
 def test_linear4_small_m_projection(K, M, N, Kd, extras):
