@@ -2088,8 +2088,10 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     use = _pick(key, hip, lib, Kd <= 640 and N <= 1024 and M >= 16384, split_arms(M, N, Kd) + small,
                 k320=(Kd == 320 and N % 320 == 0 and M % 64 == 0 and x2 is None and residual2 is None))
     if (use == 0 and lazy_residual and LAZY_RESIDUAL and residual is not None and residual2 is None and alpha == 1.0 and x2 is None
-            and N in (320, 640, 1280) and residual.is_contiguous() and not torch.is_grad_enabled()):
-        # vendor arm: the caller's next op is a LayerNorm of `y + residual` (LayerNorm.skip): it does the add in its own pass
+            and N in (320, 640, 1280) and residual.is_contiguous() and not torch.is_grad_enabled()
+            and not vendor_linear_ok(x, weight, bias, residual)):
+        # vendor arm through torch (FMC_VENDOR_DIRECT=0): the caller's next op is a LayerNorm of `y + residual` (LayerNorm.skip): it does the add in its
+        # own pass.  With the direct hipBLASLt call the residual rides in the GEMM's epilogue instead and the LayerNorm reads one tensor (-0.08 ms, same-box A/B)
         dispatch_calls["linear"]["vendor"] += 1
         y = F.linear(x, weight, bias)
         y._fmc_pending_add = residual
