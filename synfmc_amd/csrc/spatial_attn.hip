@@ -1247,6 +1247,184 @@ __global__ __launch_bounds__(320, 1) void sa_small160_kernel(const SAParams P) {
     }
 }
 
+// =====================================================================================================================
+// Big-tile kernel for the 20x32 level (bf16, D = 80, S_kv % 32 == 0): the self-attention of the 640-pixel feature maps.
+//
+// The tiled kernel above moves K / V in 64-key tiles with ONE tile of register prefetch; at d = 80 a tile is ~1400 cycles
+// of work per wave and the prefetch round trip is longer, so every one of the 10 tiles of S = 640 waits for its operands
+// (68 us for 33.5 GF = 0.20 of peak, 1280 workgroups of 4 waves).  Here a workgroup = 10 waves = 320 query rows and a
+// tile = 320 keys = 155 KiB of LDS (K row-major 88-element pitch, V row-major 160-element pitch read through
+// ds_read_b64_tr_b16: the layouts of the tiled kernel, so its block functions are used unchanged): S = 640 is TWO round
+// trips per workgroup instead of ten, each a single burst of clamped, unconditional loads.  Inside a tile the ten 32-key
+// blocks run back to back with no barrier -- QK^T of block b+1 is issued before the softmax of block b -- on the
+// fixed-reference softmax of the tiled kernel (reference = row maximum over the first 32 keys, redo pass with the exact
+// maxima if a row leaves the safe range).
+template <int NW>      // waves per workgroup = 32-query blocks: 10 (168 VGPRs: block loop rolled) | 8 (256 VGPRs: unrolled, QK^T of block b+1 before the softmax of b)
+__global__ __launch_bounds__(64 * NW, 1) void sa_big80_kernel(const SAParams P) {
+    typedef bf16_t T;
+    constexpr int NKS = 5, NDT = 3, KP = NKS * 16 + 8, VPR = sa_vr_pitch<NDT>(), CH = 10, BKT = 320, NBLK = BKT / 32, NT = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* Ks = reinterpret_cast<T*>(smem_raw);              // [BKT][KP]
+    T* Vr = Ks + BKT * KP;                               // [BKT][VPR] (columns 80..95 are read by the padded PV product: zeroed once)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    int bh, qblk;
+    {   // all query blocks AND heads of a batch entry on one XCD (the tiled kernel's map 2: a head's 160-byte row slices share lines with its neighbours)
+        const int id = blockIdx.x;
+        if (P.xcd_remap == 2) {
+            const int xcd = id & 7, within = id >> 3, per_b = P.H * P.nqblk, rem = within % per_b;
+            bh = ((within / per_b) * 8 + xcd) * P.H + rem / P.nqblk;
+            qblk = rem % P.nqblk;
+        } else {
+            bh = id / P.nqblk;
+            qblk = id - bh * P.nqblk;
+        }
+    }
+    const int b = bh / P.H, h = bh - b * P.H;
+    const T* qg = (const T*)P.q + (int64_t)b * P.qbs + (int64_t)h * 80;
+    const T* kg = (const T*)P.k + (int64_t)(b / P.kv_batch_div) * P.kbs + (int64_t)h * 80;
+    const T* vg = (const T*)P.v + (int64_t)(b / P.kv_batch_div) * P.kbs + (int64_t)h * 80;
+    T* og = (T*)P.o + (int64_t)b * P.obs + (int64_t)h * 80;
+
+    constexpr int NSLOT = (BKT * CH + NT - 1) / NT;      // 5 (6.25 -> 7 at 8 waves) sixteen-byte chunks per thread and operand
+    u32x4 kreg[NSLOT], vreg[NSLOT];
+    auto gload = [&](int kv0) {                          // rows past S_kv repeat the last key: their blocks are never visited (S_kv % 32 == 0)
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) {
+            const int c = min(tid + j * NT, BKT * CH - 1), row = c / CH, ch = c - row * CH;      // (the last slot of the 8-wave form repeats the last chunk)
+            const int kv = kv0 + row < P.Skv ? kv0 + row : P.Skv - 1;
+            kreg[j] = *reinterpret_cast<const u32x4*>(kg + (int64_t)kv * P.krs + ch * 8);
+            vreg[j] = *reinterpret_cast<const u32x4*>(vg + (int64_t)kv * P.krs + ch * 8);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) {
+            const int c = min(tid + j * NT, BKT * CH - 1), row = c / CH, ch = c - row * CH;
+            *reinterpret_cast<u32x4*>(Ks + row * KP + ch * 8) = kreg[j];
+            *reinterpret_cast<u32x4*>(Vr + row * VPR + ch * 8) = vreg[j];
+        }
+    };
+    gload(0);
+    const int qrow = (qblk * NW + wave) * 32 + l31;
+    const bool active = (qblk * NW + wave) * 32 < P.Sq;  // wave-uniform; idle waves still stage and meet the barriers
+    Frag<T> qf[1][NKS];
+    {
+        const T* qp = qg + (int64_t)(qrow < P.Sq ? qrow : P.Sq - 1) * P.qrs + half * 8;
+        u32x4 qraw[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qraw[ks] = *reinterpret_cast<const u32x4*>(qp + ks * 16);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            float qv[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                qv[2 * i] = __uint_as_float(qraw[ks][i] << 16) * P.scale_log2;
+                qv[2 * i + 1] = __uint_as_float(qraw[ks][i] & 0xffff0000u) * P.scale_log2;
+            }
+            p_frag(qv, qf[0][ks]);
+        }
+    }
+    for (int c = tid; c < BKT * 2; c += NT)              // V columns 80..94: zeros; column 95: ones -- O^T row 95 accumulates l = sum(p) in the PV
+        *reinterpret_cast<u32x4*>(Vr + (c >> 1) * VPR + 80 + (c & 1) * 8) = u32x4{0u, 0u, 0u, (c & 1) ? 0x3f800000u : 0u};      // products (the tiled kernel's LROW)
+    lstore();
+    __syncthreads();
+
+    const int ntiles = (P.Skv + BKT - 1) / BKT;
+    // reference: row maximum over the first 32 keys (in LDS now)
+    float m_ref[1];
+    f32x16 negm[1];
+    {
+        f32x16 zero16;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+        const float mx = fold_max(qk_block<T, NKS, false>(Ks, qf[0], zero16, 0, 0, P.Skv, l31, half), -INFINITY);
+        m_ref[0] = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[0][r] = -m_ref[0];
+    }
+    f32x16 oacc[1][NDT];
+    float l_run[1];
+    for (int pass = 0; pass < 2; ++pass) {
+        float worst[1] = {-INFINITY};
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[0][dt][r] = 0.f;
+        l_run[0] = 0.f;
+        for (int tile = 0; tile < ntiles; ++tile) {
+#ifndef SA_BIG_DBG
+#define SA_BIG_DBG 0
+#endif
+            if ((tile > 0 || pass > 0) && SA_BIG_DBG != 2) {                  // tile 0 of the first pass is resident
+                gload(tile * BKT);
+                __syncthreads();                         // the previous tile is consumed
+                lstore();
+                __syncthreads();
+            }
+            if (active && SA_BIG_DBG != 1) {
+                const int nblk = min(NBLK, (P.Skv - tile * BKT) >> 5);       // block-uniform
+                if (NW == 8 && nblk == NBLK) {
+                    f32x16 s[2][1];
+                    qk_scores<T, NKS, 1, false>(Ks, qf, negm, s[0], 0, l31, half);
+#pragma unroll
+                    for (int sb = 0; sb < NBLK; ++sb) {
+                        if (sb + 1 < NBLK) qk_scores<T, NKS, 1, false>(Ks, qf, negm, s[(sb + 1) & 1], sb + 1, l31, half);
+                        softmax_pv_perq<T, NKS, 1, true>(Vr, s[sb & 1], oacc, worst, l_run, sb, l31, half);
+                    }
+                } else {
+#pragma unroll 1
+                    for (int sb = 0; sb < nblk; ++sb)
+                        attn_block<T, NKS, 1, false, false, true>(Ks, Vr, qf, oacc, negm, worst, l_run, sb, tile * BKT + sb * 32, P.Skv, l31, half);
+                }
+            }
+        }
+        const bool bad = active && worst[0] > REF_LIMIT;
+        if (!__syncthreads_or(bad)) break;
+        m_ref[0] += fmaxf(worst[0], __shfl_xor(worst[0], 32, 64));          // now the exact row maximum
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[0][r] = -m_ref[0];
+    }
+    if (!active) return;
+    const float l_tot = __shfl(oacc[0][NDT - 1][15], l31 + 32, 64);          // row 95 lives in the upper half's register 15
+    const float inv = 1.f / l_tot;
+    if (qrow < P.Sq) {
+        T* orow = og + (int64_t)qrow * P.ors;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = dt * 32 + 8 * g + 4 * half;
+                if (d < 80)
+                    store4<T>(orow + d, oacc[0][dt][4 * g] * inv, oacc[0][dt][4 * g + 1] * inv, oacc[0][dt][4 * g + 2] * inv, oacc[0][dt][4 * g + 3] * inv);
+            }
+        if (P.lse && half == 0) P.lse[((int64_t)b * P.H + h) * P.Sq + qrow] = m_ref[0] * 0.6931471805599453f + logf(l_tot);
+    }
+}
+
+inline bool sa_big80_ok(const SAParams& P) {     // FMC_SA_BIG80=0: the tiled kernel at the 20x32 level too (A/B)
+    static const bool on = [] {
+        const char* e = getenv("FMC_SA_BIG80");
+        return !e || atoi(e) != 0;
+    }();
+    return on && P.D == 80 && P.Skv % 32 == 0 && P.Skv >= 256 && P.Sq >= 160;
+}
+inline void launch_sa_big80(const SAParams& Pin, hipStream_t st) {
+    SAParams P = Pin;
+    static const int nw = [] { const char* e = getenv("FMC_SA_BIG80_WAVES"); return e && atoi(e) == 8 ? 8 : 10; }();
+    P.nqblk = (P.Sq + 32 * nw - 1) / (32 * nw);
+    if (P.xcd_remap != 2) P.xcd_remap = 0;
+    const size_t lds = (size_t)320 * (5 * 16 + 8 + sa_vr_pitch<3>()) * 2;
+    static FmcPerDeviceFlag raised;
+    if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sa_big80_kernel<10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sa_big80_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        raised = true;
+    }
+    if (nw == 8) hipLaunchKernelGGL((sa_big80_kernel<8>), dim3((unsigned)(P.B * P.H * P.nqblk)), dim3(512), lds, st, P);
+    else hipLaunchKernelGGL((sa_big80_kernel<10>), dim3((unsigned)(P.B * P.H * P.nqblk)), dim3(640), lds, st, P);
+}
+
 inline bool sa_small_ok(const SAParams& P) {     // FMC_SA_SMALL=0: the tiled kernel at the inner levels too (A/B)
     static const bool on = [] {
         const char* e = getenv("FMC_SA_SMALL");
@@ -1441,6 +1619,11 @@ extern "C" int fmc_spatial_attn_fwd(const void* q, const void* k, const void* v,
     hipStream_t st = (hipStream_t)stream;
     if (dtype == FMC_BF16 && xattn40_ok(P)) {
         launch_xattn40(P, st);
+        FMC_CHECK_LAUNCH("fmc_spatial_attn_fwd");
+        return 0;
+    }
+    if (dtype == FMC_BF16 && sa_big80_ok(P)) {
+        launch_sa_big80(P, st);
         FMC_CHECK_LAUNCH("fmc_spatial_attn_fwd");
         return 0;
     }

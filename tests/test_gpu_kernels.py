@@ -139,7 +139,9 @@ def oracle_attention(q, k, v, heads):
                                          (2, 40, 40, 8, 160), (3, 300, 77, 8, 40), (2, 64, 77, 8, 160),
                                          (2, 257, 257, 4, 8), (1, 2560, 2560, 8, 40), (2, 96, 96, 2, 64),
                                          # the whole-K/V kernel of the inner levels (d = 160, S_kv <= 160): several query blocks, ragged key counts
-                                         (2, 200, 77, 8, 160), (1, 330, 100, 8, 160), (3, 160, 160, 8, 160), (2, 33, 1, 8, 160)])
+                                         (2, 200, 77, 8, 160), (1, 330, 100, 8, 160), (3, 160, 160, 8, 160), (2, 33, 1, 8, 160),
+                                         # the big-tile kernel of the 20x32 level (d = 80, S_kv % 32 == 0): two tiles, a partial last tile, ragged query blocks
+                                         (2, 640, 640, 8, 80), (1, 384, 384, 8, 80), (2, 500, 352, 8, 80), (1, 170, 256, 4, 80), (1, 1280, 960, 2, 80)])
 def test_spatial_attention(K, dtype, B, S, Skv, H, D):
     C = H * D
     qo, qd = rnd((B, S, C), 10, dtype)
@@ -188,7 +190,7 @@ def test_spatial_attention_softmax_stress(K):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("H,D", [(2, 40), (2, 160), (2, 64)])
+@pytest.mark.parametrize("H,D", [(2, 40), (2, 160), (2, 64), (2, 80)])          # d = 80, S = 320: the big-tile kernel
 def test_spatial_attention_reference_redo(K, dtype, H, D):
     """A late key whose logit exceeds the first-tile row maximum by more than the kernel's fixed-reference range
     (64 log2 units): the workgroup must redo its K/V sweep with the exact row maxima.  Rows without the spike in the
