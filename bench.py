@@ -544,7 +544,7 @@ def step_kernel_families(steps, call_log):
     if steps is None:
         return None
     fam = (("conv3x3 (conv_halo_kernel)", ("conv_halo_kernel", "conv_halo4_kernel", "conv_halo4_finish")), ("conv3x3 / linear (gemm*_kernel, sk_finish)", ("gemm", "sk_finish", "splitk")),
-           ("vendor GEMM (hipBLASLt Cijk_*)", ("Cijk_",)), ("geglu_direct", ("geglu_direct",)), ("spatial attention", ("sa40d", "spatial_attn")),
+           ("vendor GEMM (hipBLASLt Cijk_*)", ("Cijk_",)), ("geglu_direct", ("geglu_direct",)), ("spatial attention", ("sa40d", "spatial_attn", "sa_small160", "sa_big80")),
            ("temporal block / attention", ("temporal_block", "temporal_attn")), ("text cross-attention block", ("xattn",)),
            ("groupnorm", ("gn_",)), ("layernorm", ("layernorm",)), ("torch elementwise / copy / cat", ("at::", "elementwise", "CatArray")))
     tot = {k: 0.0 for k, _ in fam}

@@ -69,7 +69,7 @@ def main(path, nsteps=4):
             cat["conv (MIOpen)"] += d
         elif k.startswith("Cijk") or "Custom_Cijk" in k:
             cat["gemm (hipBLASLt)"] += d
-        elif "spatial_attn" in k or "sa40d_kernel" in k or "xattn40_kernel" in k:
+        elif "spatial_attn" in k or "sa40d_kernel" in k or "xattn40_kernel" in k or "sa_small160_kernel" in k or "sa_big80_kernel" in k:
             cat["spatial_attn (fmc)"] += d
         elif "temporal_attn" in k:
             cat["temporal_attn (fmc)"] += d
