@@ -211,6 +211,27 @@ def _time_launch(run, iters=20, warm=3):
     return e0.elapsed_time(e1) / iters
 
 
+def measure_attention_level_roofline(device, dtype, level, iters=50):
+    """Spatial self-attention of the 20x32 (`level` 1: 8 heads x 80, S = 640, `sa_big80_kernel`) or 10x16 level (2: 8 heads x 160, S = 160, `sa_small160_kernel`)
+    as the U-Net launches it: q | k | v slices of one fused projection, CFG batch 2 x 16 frames.  MFMA roofline like level 0; at level 2 a launch is 4.2 GF on
+    52 MB behind a launch + round-trip floor, so `frac` there measures latency, not the matrix pipe."""
+    from synfmc_amd import hip_ops as K
+    B, S, H, D = 2 * FRAMES, (HEIGHT // (8 << level)) * (WIDTH // (8 << level)), 8, WIDTHS[level] // 8
+    C = H * D
+    qkv = torch.randn(B, S, 3 * C, device=device, dtype=dtype)
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    ms = _time_launch(lambda: K.spatial_attention(q, k, v, H), iters=iters)
+    flops = 4.0 * B * H * S * S * D
+    achieved = flops / (ms * 1e-3) / 1e12
+    name = "sa_big80_kernel" if level == 1 else "sa_small160_kernel<5>"
+    what = ("320-key tiles resident in LDS, 10 waves = 320 query rows" if level == 1 else "all keys resident in LDS, exact softmax, one round trip")
+    out = {"bound": "mfma", "kernel": f"{name} ({what}; spatial self-attention, bf16, d={D}) [B*H={B * H},S={S}]", "achieved": round(achieved, 2),
+           "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "avg_launch_ms": round(ms, 4), "flops_per_launch": flops,
+           "traffic_algorithmic": 4.0 * B * S * H * D * 2, "traffic": None}
+    out["_match"] = ("name", name)
+    return out
+
+
 def measure_attention_bwd_roofline(device, dtype, iters=10):
     """Backward of the level-0 spatial self-attention of a training step (one clip: 16 frames x 8 heads, S = h w, d = 40) exactly as autograd
     issues it: `fmc_spatial_attn_bwd` = rowdot + dQ pass + dK / dV pass (flash-style recompute from the forward's log-sum-exp).  Algorithmic flops
@@ -1208,8 +1229,10 @@ def main():
         roof_proj = measure_proj_roofline(device, dtype) if bf else None
         roof_tb = measure_temporal_block_roofline(device, dtype) if bf else None
         roof_tb1 = measure_temporal_block_l1_roofline(device, dtype) if bf else None
+        roof_sa1 = measure_attention_level_roofline(device, dtype, 1) if bf else None
+        roof_sa2 = measure_attention_level_roofline(device, dtype, 2) if bf else None
         steps_tr, tr_note = (None, "skipped (--no-in-step / N > 1 / fp32)") if (args.no_in_step or world > 1 or not bf) else in_step_trace(args, cfg)
-        roofs = [roof, roof_conv, roof_conv0, roof_gn, roof_temp, roof_proj, roof_tb, roof_tb1]
+        roofs = [roof, roof_conv, roof_conv0, roof_gn, roof_temp, roof_proj, roof_tb, roof_tb1, roof_sa1, roof_sa2]
         for o in roofs:
             apply_in_step(o, steps_tr, call_log)
         families = step_kernel_families(steps_tr, call_log)
@@ -1243,6 +1266,7 @@ def main():
                                   f"({round(text_ms, 2)} ms); none of it runs inside a step"),
             "roofline": roof, "roofline_conv": roof_conv, "roofline_conv_l0": roof_conv0, "roofline_groupnorm": roof_gn, "roofline_temporal": roof_temp,
             "roofline_temporal_block": roof_tb, "roofline_temporal_block_l1": roof_tb1, "roofline_proj": roof_proj,
+            "roofline_attention_l1": roof_sa1, "roofline_attention_l2": roof_sa2,
             "in_step_source": tr_note, "in_step_kernel_families": families,
             "autotune": {"shapes_from_this_builds_cache": K.autotune_sources["cache"], "shapes_from_tracked_default_table": K.autotune_sources["defaults"],
                          "shapes_tuned_in_this_run": max(0, len(K._choice) - K.autotune_sources["cache"] - K.autotune_sources["defaults"]),
