@@ -1260,9 +1260,10 @@ __global__ __launch_bounds__(320, 1) void sa_small160_kernel(const SAParams P) {
 // fixed-reference softmax of the tiled kernel (reference = row maximum over the first 32 keys, redo pass with the exact
 // maxima if a row leaves the safe range).
 template <int NW>      // waves per workgroup = 32-query blocks: 10 (168 VGPRs: block loop rolled) | 8 (256 VGPRs: unrolled, QK^T of block b+1 before the softmax of b)
-__global__ __launch_bounds__(64 * NW, 1) void sa_big80_kernel(const SAParams P) {
+                       // | 5: 160 rows on 160-key tiles (77.5 KiB): TWO workgroups per CU, one staging while the other computes
+__device__ __forceinline__ void sa_big80_body(const SAParams& P) {
     typedef bf16_t T;
-    constexpr int NKS = 5, NDT = 3, KP = NKS * 16 + 8, VPR = sa_vr_pitch<NDT>(), CH = 10, BKT = 320, NBLK = BKT / 32, NT = 64 * NW;
+    constexpr int NKS = 5, NDT = 3, KP = NKS * 16 + 8, VPR = sa_vr_pitch<NDT>(), CH = 10, BKT = NW == 5 ? 160 : 320, NBLK = BKT / 32, NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* Ks = reinterpret_cast<T*>(smem_raw);              // [BKT][KP]
     T* Vr = Ks + BKT * KP;                               // [BKT][VPR] (columns 80..95 are read by the padded PV product: zeroed once)
@@ -1402,6 +1403,11 @@ __global__ __launch_bounds__(64 * NW, 1) void sa_big80_kernel(const SAParams P) 
     }
 }
 
+// one thin kernel per form (HIP: the second launch bound is the minimum number of WAVES PER SIMD; 10 waves per CU = three on one SIMD = 168 VGPRs)
+__global__ __launch_bounds__(640, 1) void sa_big80_kernel_w10(const SAParams P) { sa_big80_body<10>(P); }
+__global__ __launch_bounds__(512, 1) void sa_big80_kernel_w8(const SAParams P) { sa_big80_body<8>(P); }
+__global__ __launch_bounds__(320, 3) void sa_big80_kernel_w5(const SAParams P) { sa_big80_body<5>(P); }
+
 inline bool sa_big80_ok(const SAParams& P) {     // FMC_SA_BIG80=0: the tiled kernel at the 20x32 level too (A/B)
     static const bool on = [] {
         const char* e = getenv("FMC_SA_BIG80");
@@ -1411,18 +1417,20 @@ inline bool sa_big80_ok(const SAParams& P) {     // FMC_SA_BIG80=0: the tiled ke
 }
 inline void launch_sa_big80(const SAParams& Pin, hipStream_t st) {
     SAParams P = Pin;
-    static const int nw = [] { const char* e = getenv("FMC_SA_BIG80_WAVES"); return e && atoi(e) == 8 ? 8 : 10; }();
+    static const int nw = [] { const char* e = getenv("FMC_SA_BIG80_WAVES"); const int v = e ? atoi(e) : 10; return v == 8 || v == 5 ? v : 10; }();
     P.nqblk = (P.Sq + 32 * nw - 1) / (32 * nw);
     if (P.xcd_remap != 2) P.xcd_remap = 0;
-    const size_t lds = (size_t)320 * (5 * 16 + 8 + sa_vr_pitch<3>()) * 2;
+    const size_t lds = (size_t)(nw == 5 ? 160 : 320) * (5 * 16 + 8 + sa_vr_pitch<3>()) * 2;
     static FmcPerDeviceFlag raised;
     if (!raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sa_big80_kernel<10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sa_big80_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sa_big80_kernel_w10), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sa_big80_kernel_w8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sa_big80_kernel_w5), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         raised = true;
     }
-    if (nw == 8) hipLaunchKernelGGL((sa_big80_kernel<8>), dim3((unsigned)(P.B * P.H * P.nqblk)), dim3(512), lds, st, P);
-    else hipLaunchKernelGGL((sa_big80_kernel<10>), dim3((unsigned)(P.B * P.H * P.nqblk)), dim3(640), lds, st, P);
+    if (nw == 5) hipLaunchKernelGGL(sa_big80_kernel_w5, dim3((unsigned)(P.B * P.H * P.nqblk)), dim3(320), lds, st, P);
+    else if (nw == 8) hipLaunchKernelGGL(sa_big80_kernel_w8, dim3((unsigned)(P.B * P.H * P.nqblk)), dim3(512), lds, st, P);
+    else hipLaunchKernelGGL(sa_big80_kernel_w10, dim3((unsigned)(P.B * P.H * P.nqblk)), dim3(640), lds, st, P);
 }
 
 inline bool sa_small_ok(const SAParams& P) {     // FMC_SA_SMALL=0: the tiled kernel at the inner levels too (A/B)
