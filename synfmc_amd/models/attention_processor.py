@@ -26,6 +26,8 @@ from .layers import LoRALinearLayer, linear_op
 
 
 _POSE_TERM = os.environ.get("FMC_NO_POSE_TERM", "0") != "1"      # A/B switch for the pre-computed Camera-Adapter term
+_MERGE_FOLD = os.environ.get("FMC_MERGE_FOLD", "1") != "0"       # A/B switch: the Camera-Adapter merge folded into the q | k | v projection (un-fused chain)
+MERGE_FOLD_MIN_DIM = 1280                                        # ... at the levels where it was measured to pay (C = 1280; tests lower it to cover the path at small widths)
 
 
 def _tok(x: torch.Tensor) -> torch.Tensor:
@@ -38,10 +40,16 @@ def _tok(x: torch.Tensor) -> torch.Tensor:
 
 
 def _attention_core(attn, q_in: torch.Tensor, kv_in: Optional[torch.Tensor], temporal: bool, lora=None,
-                    lora_scale: float = 1.0, residual: Optional[torch.Tensor] = None, text_context: bool = False) -> torch.Tensor:
-    """Fused projection -> attention kernel -> output projection (bias, dropout p=0) [+ residual]."""
+                    lora_scale: float = 1.0, residual: Optional[torch.Tensor] = None, text_context: bool = False, qkv_fold=None) -> torch.Tensor:
+    """Fused projection -> attention kernel -> output projection (bias, dropout p=0) [+ residual].  `qkv_fold` = (W', term) of
+    `_PoseMerge._qkv_fold`: q | k | v = `q_in W'^T + term` (q_in = the UN-merged tokens)."""
     heads = attn.heads
     w_a, w_b, w_o = attn.fused_weights(lora, lora_scale)
+    if qkv_fold is not None:
+        assert kv_in is None
+        o = K.self_attention_qkv(linear_op(q_in, qkv_fold[0], None, qkv_fold[1]), heads, attn.scale, temporal)
+        return linear_op(o, w_o, attn.to_out[0].bias, residual, ln=attn.__dict__.get("_next_ln") if residual is not None else None,
+                         lazy_residual=residual is not None and bool(attn.__dict__.get("_lazy_res")))
     c = attn.inner_dim
     fp8 = attn.__dict__.get("_fp8_scales") if (temporal and kv_in is None) else None
     if (fp8 is not None and q_in.is_cuda and q_in.dtype == torch.bfloat16 and w_a.dtype == torch.bfloat16
@@ -194,6 +202,42 @@ def _pose_term_impl(self, pose_feature, w, b, s):
 _PoseMerge._pose_term = _pose_term_impl
 
 
+def _qkv_fold_impl(self, attn, x, pose_feature, s, lora=None, lora_scale: float = 1.0):
+    """The `qkv_merge` Camera-Adapter merge folded into the fused q | k | v projection of the un-fused chain (the 10x16 / 5x8 levels, C = 1280;
+    reference attention_processor.py:255-283: `m = s (W_m (h + pose) + b_m) + h`, then `to_q / to_k / to_v (m)`).  Both maps are linear and nothing
+    reads m but the three projections, so
+        q | k | v = W_qkv (s W_m + I) h + W_qkv (s (W_m pose + b_m)) = W' h + term:
+    W' [3C, C] once per set of weights (fp32 product, rounded once), `term` [.., 3C] once per clip from the cached pose term -- the merge GEMM (M x C x C
+    per block and step) and the round trip of m are gone: 96.9 -> 62.1 us at M = 5120, 47.5 -> 22.0 us at M = 1280 (tools/scratch/r05/bench_fold.py).
+    Returns (W', term) or None where the plain chain must run (training, fp32, fp8 projections, a layout mismatch, FMC_MERGE_FOLD=0).  The entry keeps
+    the tensors the graph runner refreshes in place for a new clip (`_GraphedUNet.set_conditioning`)."""
+    w, b = self.qkv_merge.weight, self.qkv_merge.bias
+    if not (_MERGE_FOLD and _POSE_TERM and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+            and pose_feature.shape == x.shape and pose_feature.dtype == torch.bfloat16 and x.is_contiguous()
+            and attn.inner_dim >= MERGE_FOLD_MIN_DIM and attn.__dict__.get("_fp8_scales") is None):
+        return None
+    w_a = attn.fused_weights(lora, lora_scale)[0]
+    if w_a.dtype != torch.bfloat16 or w_a.shape[1] != w.shape[0]:
+        return None
+    term_src = self._pose_term(pose_feature, w, b, s)
+    key = (w_a.data_ptr(), w_a._version, w.data_ptr(), w._version, float(s), term_src.data_ptr(), term_src._version, tuple(term_src.shape))
+    hit = self.__dict__.get("_qkv_fold_cache")
+    if hit is None or hit[0][:5] != key[:5]:
+        eye = torch.eye(w.shape[0], device=w.device, dtype=torch.float32)
+        w_f = (w_a.float() @ (float(s) * w.float() + eye)).to(torch.bfloat16).contiguous()
+        hit = None
+    else:
+        w_f = hit[1]
+    if hit is None or hit[0] != key:
+        wq = w_a if w_a.is_contiguous() else w_a.contiguous()
+        hit = (key, w_f, K.linear(term_src, wq), wq, term_src)
+        self.__dict__["_qkv_fold_cache"] = hit
+    return hit[1], hit[2]
+
+
+_PoseMerge._qkv_fold = _qkv_fold_impl
+
+
 def _pose_tokens(pose_feature, like):
     """Bring the pose feature to the token layout of `like` (`[B,F,P,C]`, `[N,F,C]` or `[B,S,C]`)."""
     if pose_feature.ndim == like.ndim and pose_feature.shape == like.shape:
@@ -231,7 +275,12 @@ class PoseAdaptorAttnProcessor(nn.Module, _PoseMerge):
         if self.query_condition and self.key_value_condition:
             assert encoder_hidden_states is None
         ctx = x if encoder_hidden_states is None else _tok(encoder_hidden_states)
-        q_in, kv_in = self._merge(x, ctx, _pose_tokens(pose_feature, x), s)
+        pose = _pose_tokens(pose_feature, x)
+        fold = self._qkv_fold(attn, x, pose, s) if (self.query_condition and self.key_value_condition) else None
+        if fold is not None:
+            out = _attention_core(attn, x, None, temporal, residual=_fusable(attn, _residual, shape4), qkv_fold=fold)
+            return _finish(attn, out, hidden_states, shape4)
+        q_in, kv_in = self._merge(x, ctx, pose, s)
         out = _attention_core(attn, q_in, kv_in, temporal, residual=_fusable(attn, _residual, shape4))
         return _finish(attn, out, hidden_states, shape4)
 
@@ -263,7 +312,12 @@ class LORAPoseAdaptorAttnProcessor(nn.Module, _PoseMerge):
         if self.query_condition and self.key_value_condition:
             assert encoder_hidden_states is None
         ctx = x if encoder_hidden_states is None else _tok(encoder_hidden_states)
-        q_in, kv_in = self._merge(x, ctx, _pose_tokens(pose_feature, x), self.scale)
+        pose = _pose_tokens(pose_feature, x)
+        fold = self._qkv_fold(attn, x, pose, self.scale, self, ls) if (self.query_condition and self.key_value_condition) else None
+        if fold is not None:
+            out = _attention_core(attn, x, None, temporal, lora=self, lora_scale=ls, residual=_fusable(attn, _residual, shape4), qkv_fold=fold)
+            return _finish(attn, out, hidden_states, shape4)
+        q_in, kv_in = self._merge(x, ctx, pose, self.scale)
         out = _attention_core(attn, q_in, kv_in, temporal, lora=self, lora_scale=ls,
                               residual=_fusable(attn, _residual, shape4))
         return _finish(attn, out, hidden_states, shape4)

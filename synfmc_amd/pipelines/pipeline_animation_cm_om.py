@@ -86,6 +86,8 @@ class _GraphedUNet:
         # graph reads them by address, so this runner keeps them alive and refreshes them in place for a new clip
         self._pose_terms = [(m, m.__dict__["_pose_term_cache"]) for m in self.unet.modules()
                             if m.__dict__.get("_pose_term_cache") is not None]
+        # (the inner levels read the pose term through the q | k | v projection: `_PoseMerge._qkv_fold` -- its per-clip tensor is kept and refreshed too)
+        self._qkv_folds = {id(m): m.__dict__["_qkv_fold_cache"] for m in self.unet.modules() if m.__dict__.get("_qkv_fold_cache") is not None}
         # ... and the text's k | v projections + fragment packs of the cross-attention layers (`Attention.text_kv`, once per clip): computed by the
         # warm-up calls from `self.text`, read by the graph by address, refreshed in place by `set_conditioning`
         self._text_kvs = [(m, m.__dict__["_text_kv"]) for m in self.unet.modules()
@@ -115,12 +117,17 @@ class _GraphedUNet:
         if not getattr(self, "_refillable", True):           # (pose terms were computed from private copies: capture again on the new buffers)
             for mod, _ in self._pose_terms:
                 mod.__dict__.pop("_pose_term_cache", None)
+                mod.__dict__.pop("_qkv_fold_cache", None)
             self.capture()
             return
         self._text_kvs = [(mod, mod.refresh_text_kv(entry)) for mod, entry in getattr(self, "_text_kvs", [])]
         for mod, (key, term, pose_view) in self._pose_terms:
             pf = pose_view if pose_view.is_contiguous() else pose_view.contiguous()
             term.copy_(K.linear(pf, mod.qkv_merge.weight, mod.qkv_merge.bias, None, key[-1]))
+            fold = getattr(self, "_qkv_folds", {}).get(id(mod))    # the merge folded into q | k | v (inner levels): its per-clip term follows the pose term
+            if fold is not None:
+                assert fold[4] is term, "internal: the folded q | k | v term was built from another pose term"
+                fold[2].copy_(K.linear(term, fold[3]))
 
     def __call__(self, x, t):
         self.x.copy_(x)

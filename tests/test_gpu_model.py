@@ -334,10 +334,14 @@ def test_animation_pipeline_multidiff_windows():
         pipe(None, 16, height=60, width=64, prompt_embeds=text2.cuda(), output_type="latent")
 
 
-def test_pipeline_graph_reuse_across_clips(stack, monkeypatch):
+@pytest.mark.parametrize("fold", [False, True])
+def test_pipeline_graph_reuse_across_clips(stack, monkeypatch, fold):
     """The captured HIP graphs stay on the pipeline: a second clip of the same shape refills the static text / camera /
-    OMC buffers and recomputes the Camera-Adapter pose terms in place (bf16 fast path), without a new capture."""
+    OMC buffers and recomputes the Camera-Adapter pose terms in place (bf16 fast path), without a new capture.  `fold`: with the merge folded into
+    the q | k | v projection on EVERY temporal block (the product does it at C = 1280 only): its per-clip term must follow the pose term."""
     from synfmc_amd.pipelines.pipeline_animation_cm_om import CameraObjCtrlPipeline
+    from synfmc_amd.models import attention_processor as AP
+    monkeypatch.setattr(AP, "MERGE_FOLD_MIN_DIM", 0 if fold else 1 << 30)
     from synfmc_amd.schedulers import DDIMScheduler
     kw = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1,
               clip_sample=False)
@@ -366,6 +370,8 @@ def test_pipeline_graph_reuse_across_clips(stack, monkeypatch):
     # the same clip through the same graph after another clip used it: bit-identical (no stale per-clip state)
     assert rel_inf(outs[3], outs[1]) < 1e-6
     assert rel_inf(outs[2], outs[0]) < 1e-6
+    n_fold = sum(m.__dict__.get("_qkv_fold_cache") is not None for m in pu.modules())
+    assert (n_fold > 0) == fold
 
 
 # ---- a11: LORAPoseAdaptorAttnProcessor (attention_processor.py:296-420) ------------------------------------------------
@@ -637,6 +643,60 @@ def test_basic_transformer_block_fused_text_cross_attention_equals_the_unfused_c
         ref = blk.float()(x.float(), encoder_hidden_states=text.float())
     assert rel_inf(fused, plain) < 2e-2
     e_f, e_p = rel_inf(fused, ref), rel_inf(plain, ref)
+    assert e_f < 2e-2 and e_f < 2.0 * e_p + 2e-3, (e_f, e_p)
+
+
+@pytest.mark.parametrize("lora", [False, True])
+def test_temporal_block_merge_folded_into_qkv_at_the_inner_levels(lora):
+    """C = 1280 (the 10x16 / 5x8 levels, no fused kernel): the Camera-Adapter `qkv_merge` is folded into the q | k | v projection,
+    `q | k | v = W_qkv (s W_m + I) h + W_qkv (s (W_m pose + b_m))` (`_PoseMerge._qkv_fold`; reference attention_processor.py:255-283 computes m first).  The block
+    must match the plain chain (merge GEMM, then the projection) on the same weights and be as close to the fp32 evaluation; a new pose feature (a new clip)
+    recomputes the per-clip term; with a LoRA on the projections (`LORAPoseAdaptorAttnProcessor`) the folded weight uses the merged ones."""
+    from synfmc_amd.models import motion_module as MM
+    from synfmc_amd.models import attention_processor as AP
+    torch.manual_seed(5)
+    C, H, Fr, B, P = 1280, 8, 16, 2, 40
+    blk = MM.TemporalTransformerBlock(dim=C, num_attention_heads=H, attention_head_dim=C // H, attention_block_types=("Temporal_Self", "Temporal_Self"),
+                                      temporal_position_encoding=True, temporal_position_encoding_max_len=32)
+    if lora:
+        proc = AP.LORAPoseAdaptorAttnProcessor(hidden_size=C, pose_feature_dim=C, query_condition=True, key_value_condition=True, scale=0.8, rank=16)
+    else:
+        proc = AP.PoseAdaptorAttnProcessor(hidden_size=C, pose_feature_dim=C, query_condition=True, key_value_condition=True, scale=0.8)
+    blk.attention_blocks[0].set_processor(proc)
+    blk.attention_blocks[1].set_processor(AP.AttnProcessor())
+    with torch.no_grad():
+        for p in list(blk.parameters()) + list(proc.parameters()):
+            if p.ndim >= 2:
+                p.normal_(0, p.shape[-1] ** -0.5)
+            else:
+                p.normal_(0, 0.2)
+        for n in list(blk.norms) + [blk.ff_norm]:
+            n.weight.add_(1.0)
+    blk = blk.to("cuda", torch.bfloat16).eval()
+    proc.to("cuda", torch.bfloat16).requires_grad_(False)
+    x = (torch.randn(B, Fr, P, C) * 1.2).to("cuda", torch.bfloat16)
+    pose = torch.randn(B, Fr, P, C).to("cuda", torch.bfloat16)
+    pose2 = torch.randn(B, Fr, P, C).to("cuda", torch.bfloat16)
+    with torch.no_grad():
+        assert not blk.fused_blocks_ok(x, None, {"pose_feature": pose})
+        folded = blk(x, cross_attention_kwargs={"pose_feature": pose})
+        entry = proc.__dict__.get("_qkv_fold_cache")
+        assert entry is not None and entry[1].shape == (3 * C, C) and entry[2].shape == (B, Fr, P, 3 * C)
+        assert torch.equal(folded, blk(x, cross_attention_kwargs={"pose_feature": pose}))       # cached: same tensors, same result
+        assert proc.__dict__["_qkv_fold_cache"] is entry
+        folded2 = blk(x, cross_attention_kwargs={"pose_feature": pose2})                        # a new clip: the term is rebuilt, the weight is kept
+        entry2 = proc.__dict__["_qkv_fold_cache"]
+        assert entry2 is not entry and entry2[1] is entry[1] and rel_inf(folded2, folded) > 1e-2
+        AP._MERGE_FOLD = False
+        try:
+            plain = blk(x, cross_attention_kwargs={"pose_feature": pose})
+            plain2 = blk(x, cross_attention_kwargs={"pose_feature": pose2})
+        finally:
+            AP._MERGE_FOLD = True
+        ref = blk.float()(x.float(), cross_attention_kwargs={"pose_feature": pose.float()})
+    assert rel_inf(folded, plain) < 2e-2 and rel_inf(folded2, plain2) < 2e-2
+    e_f, e_p = rel_inf(folded, ref), rel_inf(plain, ref)
+    print(f"merge fold (lora={lora}): folded vs fp32 {e_f:.3e}, chain vs fp32 {e_p:.3e}")
     assert e_f < 2e-2 and e_f < 2.0 * e_p + 2e-3, (e_f, e_p)
 
 
