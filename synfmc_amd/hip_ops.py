@@ -1178,7 +1178,7 @@ def _rows2d(t: torch.Tensor):
 
 
 VENDOR_DIRECT = os.environ.get("FMC_VENDOR_DIRECT", "1") != "0"      # A/B switch: the vendor arm through fmc_vendor_linear_bf16 (bias + residual in the GEMM)
-VENDOR_ALGO = int(os.environ.get("FMC_VENDOR_ALGO", "0"))            # experiments: which heuristic candidate (clamped to the list)
+VENDOR_ALGO = int(os.environ.get("FMC_VENDOR_ALGO", "-1"))           # >= 0: this heuristic candidate for every problem (clamped to the list); default: per problem, from the arm table
 _vendor_seen = {}                                                     # problem -> candidate count (a first call plans: never under stream capture)
 vendor_direct_calls = {"direct": 0, "with_residual": 0}
 
@@ -1209,8 +1209,39 @@ def vendor_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Te
         if n <= 0:
             _lib.check(n if n < 0 else -1, "fmc_vendor_linear_candidates")
         _vendor_seen[key] = n
+    # which of the heuristic's candidates: its first choice is not the fastest on every shape (5120 x 3840 x 1280: 62 us, the second candidate 52 us --
+    # tools/scratch/r05/bench_vendor_algos.py: 0.25 ms per step over the ten main shapes).  Chosen once per problem by timing, kept in the arm table
+    # (`("valgo", ...)` keys: the tracked default table holds them like the GEMM / conv arms, so a fresh box runs the measured candidates without tuning)
+    akey = ("valgo", M, N, Kd, ldx, ldres, bias is not None, residual is not None)
+    if not _cache_state["loaded"]:
+        load_autotune_table()
+    algo = VENDOR_ALGO if VENDOR_ALGO >= 0 else _choice.get(akey)
+    if algo is None:
+        if AUTOTUNE and n > 1 and not torch.cuda.is_current_stream_capturing():
+            times = {}
+            for a in range(n):
+                call = lambda a=a: _lib.load().fmc_vendor_linear_bf16(x.data_ptr(), weight.data_ptr(), _p(bias), _p(residual), out.data_ptr(), M, N, Kd, ldx,
+                                                                      ldres, N, a, _stream())
+                for _ in range(5):
+                    call()
+                best = float("inf")
+                for _ in range(3):                      # min of 3 event-bracketed bursts
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(10):
+                        call()
+                    e1.record()
+                    e1.synchronize()
+                    best = min(best, e0.elapsed_time(e1) / 10)
+                times[a] = round(best, 4)
+            algo = min(times, key=times.get)
+            _choice[akey] = algo
+            _tune_log[akey] = times
+            _cache_state["dirty"] = True
+        else:
+            algo = 0
     _lib.check(_lib.load().fmc_vendor_linear_bf16(x.data_ptr(), weight.data_ptr(), _p(bias), _p(residual), out.data_ptr(), M, N, Kd, ldx, ldres, N,
-                                                  min(VENDOR_ALGO, n - 1), _stream()), "fmc_vendor_linear_bf16")
+                                                  min(int(algo), n - 1), _stream()), "fmc_vendor_linear_bf16")
     vendor_direct_calls["direct"] += 1
     vendor_direct_calls["with_residual"] += residual is not None
     return out
