@@ -595,7 +595,6 @@ __global__ __launch_bounds__(256) void layernorm_g_kernel(const T* __restrict__ 
     // gamma / beta through LDS: requested together with the rows (read from global memory behind the statistics they were a second
     // memory round trip in the life of every wave, which is one load burst, a reduction and one store burst long)
     __shared__ __attribute__((aligned(16))) float sh_g[C], sh_b[C];
-    for (int i = threadIdx.x; i < C; i += 256) { sh_g[i] = gamma[i]; sh_b[i] = beta[i]; }
     // positional-encoding rows the same way: the 4 * RPW * U consecutive rows of a workgroup lie in at most two frames (pe_inner rows
     // per frame, >= the workgroup's rows whenever two frames suffice; otherwise the rows read pe from global memory as before)
     __shared__ __attribute__((aligned(16))) float sh_pe[2][C];
@@ -603,34 +602,75 @@ __global__ __launch_bounds__(256) void layernorm_g_kernel(const T* __restrict__ 
     const int64_t wg_f0 = pe ? wg_row0 / pe_inner : 0;
     const int64_t pe_next = (wg_f0 + 1) * pe_inner;           // first row of the workgroup's second frame
     const bool pe_lds = pe && pe_inner >= 4 * RPW * U && 4 * RPW * U >= 32;   // (8 rows per workgroup at C = 1280: staging two PE rows costs as much as the rows)
-    if (pe_lds) {
-        for (int i = threadIdx.x; i < 2 * C; i += 256) {
-            const int which = i / C, c = i - which * C;
-            sh_pe[which][c] = pe[(size_t)((wg_f0 + which) % pe_frames) * C + c];
-        }
-    }
     const int lane = threadIdx.x & 63, t = lane % LPR, g = lane / LPR;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t row0 = wave * (RPW * U) + g;               // this group's rows: row0 + RPW*u
     float v[U][NCH][8];
+    // every chunk of the rows requested in ONE burst from clamped addresses (rows past M repeat the last row and are never stored): a load inside
+    // `if (row < M)` is followed by its own s_waitcnt vmcnt(0) -- five dependent round trips, 9 of the 10.7 us this launch took at every size
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const int64_t row = row0 + RPW * u;
+        const int64_t row = row0 + RPW * u, rowc = row < M ? row : M - 1;
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            if (row < M) {
-                Vec8<T>::load(x + row * C + (j * LPR + t) * 8, v[u][j]);
-                if (addend) {
-                    float a8[8];
-                    Vec8<T>::load(addend + row * C + (j * LPR + t) * 8, a8);
+        for (int j = 0; j < NCH; ++j) Vec8<T>::load(x + rowc * C + (j * LPR + t) * 8, v[u][j]);
+    }
+    {   // gamma / beta / the two positional-encoding rows -> LDS, requested BEHIND the rows in the same burst (every value loaded before the first is
+        // stored: a rolled `sh[i] = g[i]` loop was one round trip per 256 elements, five of them at C = 1280, ahead of everything else)
+        constexpr int NI = (C + 255) / 256;
+        float gv[NI], bv[NI], pv[2 * NI];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[u][j][i] += a8[i];
-                    Vec8<T>::store(sum_out + row * C + (j * LPR + t) * 8, v[u][j]);
-                    round_as_stored<T>(v[u][j]);             // the norm sees the stored (rounded) sum, as a separate pass would
-                }
-            } else {
+        for (int i = 0; i < NI; ++i) {
+            const int idx = min((int)threadIdx.x + 256 * i, C - 1);
+            gv[i] = gamma[idx];
+            bv[i] = beta[idx];
+        }
+        if (pe_lds) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[u][j][i] = 0.f;
+            for (int i = 0; i < 2 * NI; ++i) {
+                const int idx = min((int)threadIdx.x + 256 * i, 2 * C - 1), which = idx / C, c = idx - which * C;
+                pv[i] = pe[(size_t)((wg_f0 + which) % pe_frames) * C + c];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int idx = (int)threadIdx.x + 256 * i;
+            if (idx < C) { sh_g[idx] = gv[i]; sh_b[idx] = bv[i]; }
+        }
+        if (pe_lds) {
+#pragma unroll
+            for (int i = 0; i < 2 * NI; ++i) {
+                const int idx = (int)threadIdx.x + 256 * i;
+                if (idx < 2 * C) sh_pe[idx / C][idx % C] = pv[i];
+            }
+        }
+    }
+    float pg[U][NCH][8];                                     // positional-encoding chunks of my rows where they do not come through LDS: same burst
+    if (pe && !pe_lds) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = row0 + RPW * u, rowc = row < M ? row : M - 1;
+            const float* prow = pe + (size_t)((rowc / pe_inner) % pe_frames) * C;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) Vec8<float>::load(prow + (j * LPR + t) * 8, pg[u][j]);
+        }
+    }
+    if (addend) {                                            // (kernel-uniform)
+        float a8[U][NCH][8];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = row0 + RPW * u, rowc = row < M ? row : M - 1;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) Vec8<T>::load(addend + rowc * C + (j * LPR + t) * 8, a8[u][j]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = row0 + RPW * u;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[u][j][i] += a8[u][j][i];
+                if (row < M) Vec8<T>::store(sum_out + row * C + (j * LPR + t) * 8, v[u][j]);
+                round_as_stored<T>(v[u][j]);                 // the norm sees the stored (rounded) sum, as a separate pass would
             }
         }
     }
@@ -665,8 +705,12 @@ __global__ __launch_bounds__(256) void layernorm_g_kernel(const T* __restrict__ 
             for (int i = 0; i < 8; ++i) o[i] = (v[u][j][i] - mean[u]) * rs[u] * gm[i] + bt[i];
             if (pe) {
                 float pv[8];
-                if (pe_lds) Vec8<float>::load(sh_pe[row >= pe_next ? 1 : 0] + (j * LPR + t) * 8, pv);   // (no 64-bit division per row)
-                else Vec8<float>::load(pe + (size_t)((row / pe_inner) % pe_frames) * C + (j * LPR + t) * 8, pv);
+                if (pe_lds) {
+                    Vec8<float>::load(sh_pe[row >= pe_next ? 1 : 0] + (j * LPR + t) * 8, pv);   // (no 64-bit division per row)
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) pv[i] = pg[u][j][i];
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o[i] += pv[i];
             }
