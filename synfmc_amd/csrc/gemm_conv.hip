@@ -1778,10 +1778,21 @@ void gemm160_kernel(const GemmParams P) {
         for (int rz = 0; rz < 2; ++rz) {
             const bf16_t* rp = rz == 0 ? P.res : P.res2;
             if (rp == nullptr) continue;                   // (uniform)
-            for (int c = tid; c < BM * CPR; c += NT) {
-                const int r = c / CPR, ch = c - r * CPR;
-                *reinterpret_cast<u32x4*>(Os + r * OP + ch * 8) =
-                    *reinterpret_cast<const u32x4*>(rp + min(m0 + r, P.M - 1) * P.ldres + n0 + ch * 8);
+            // four bursts of 4 loads per thread (160 x 40 chunks = 12.5 per thread) instead of a rolled load -> wait -> ds_write loop: thirteen dependent
+            // round trips per residual became four
+#pragma unroll 1
+            for (int h = 0; h < 4; ++h) {                  // (4 x 4: sixteen staging registers fit beside the accumulators; 2 x 7 spilled 43)
+                u32x4 rv[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int c = min(tid + (4 * h + it) * NT, BM * CPR - 1), r = c / CPR, ch = c - r * CPR;
+                    rv[it] = *reinterpret_cast<const u32x4*>(rp + min(m0 + r, P.M - 1) * P.ldres + n0 + ch * 8);
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int c = tid + (4 * h + it) * NT, r = c / CPR, ch = c - r * CPR;
+                    if (c < BM * CPR) *reinterpret_cast<u32x4*>(Os + r * OP + ch * 8) = rv[it];
+                }
             }
             __syncthreads();
 #pragma unroll
@@ -2127,10 +2138,27 @@ void gemm160p_kernel(const GemmParams P) {
                 for (int rz = 0; rz < 2; ++rz) {
                     const bf16_t* rp = rz == 0 ? P.res : P.res2;
                     if (rp == nullptr) continue;                       // (uniform)
-                    for (int c = tid; c < 80 * CPR; c += NT) {
-                        const int r = c / CPR, ch = c - r * CPR;
-                        *reinterpret_cast<u32x4*>(Os + r * OP + ch * 8) =
-                            *reinterpret_cast<const u32x4*>(rp + (m0 + pass * 80 + r) * P.ldres + n0 + ch * 8);
+                    {   // the 80 residual rows in ONE burst of 7 loads per thread (80 x 40 chunks = 6.25 per thread: the 7th repeats the 6th): rolled, the loop
+                        // was load -> s_waitcnt vmcnt(0) -> ds_write per iteration, seven dependent HBM round trips per wave row and residual
+                        constexpr int RB = LN == 1 ? 2 : 7;              // (the LayerNorm-writing variant has 2 free registers: 7 in flight spilled 18, 4 spilled 5)
+#pragma unroll
+                        for (int h = 0; h < (7 + RB - 1) / RB; ++h) {
+                            u32x4 rv[RB];
+#pragma unroll
+                            for (int it = 0; it < RB; ++it) {
+                                int c = tid + min(h * RB + it, 6) * NT;
+                                if (c >= 80 * CPR) c -= NT;
+                                const int r = c / CPR, ch = c - r * CPR;
+                                rv[it] = *reinterpret_cast<const u32x4*>(rp + (m0 + pass * 80 + r) * P.ldres + n0 + ch * 8);
+                            }
+#pragma unroll
+                            for (int it = 0; it < RB; ++it) {
+                                int c = tid + min(h * RB + it, 6) * NT;
+                                if (c >= 80 * CPR) c -= NT;
+                                const int r = c / CPR, ch = c - r * CPR;
+                                *reinterpret_cast<u32x4*>(Os + r * OP + ch * 8) = rv[it];
+                            }
+                        }
                     }
                     __syncthreads();
                     if (wr == pass) {
