@@ -281,30 +281,51 @@ void conv_halo_kernel(const CHParams P) {
     constexpr int CPR = BN / 8;                              // 20 sixteen-byte chunks per row
     const int vrows = min(TH, P.H - y0) * TW;                // (rows of a tile that hangs over the image's last row are not stored)
     auto row_pixel = [&](int r) -> int64_t { return ((int64_t)img * P.H + y0 + (r >> 5)) * P.W + x0 + (r & 31); };
-#pragma unroll
-    for (int nb = 0; nb < 5; ++nb) {
-        const int n = n0 + wc * 80 + nb * 16 + 4 * kq;
-        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+    {   // bias and time-embedding words of my five channel blocks: all requested before the first is used (one branch per block put each load behind its
+        // own s_waitcnt vmcnt(0): ten dependent round trips)
+        u32x2 bt[5], tt[5];
         if (P.bias) {
-            const u32x2 t = *reinterpret_cast<const u32x2*>(P.bias + n);
-            b4[0] = __uint_as_float(t[0] << 16); b4[1] = __uint_as_float(t[0] & 0xffff0000u);
-            b4[2] = __uint_as_float(t[1] << 16); b4[3] = __uint_as_float(t[1] & 0xffff0000u);
+#pragma unroll
+            for (int nb = 0; nb < 5; ++nb) bt[nb] = *reinterpret_cast<const u32x2*>(P.bias + n0 + wc * 80 + nb * 16 + 4 * kq);
         }
         if (P.temb) {
-            const u32x2 t = *reinterpret_cast<const u32x2*>(P.temb + (int64_t)(img / P.temb_div) * P.temb_ld + n);
-            b4[0] += __uint_as_float(t[0] << 16); b4[1] += __uint_as_float(t[0] & 0xffff0000u);
-            b4[2] += __uint_as_float(t[1] << 16); b4[3] += __uint_as_float(t[1] & 0xffff0000u);
+            const bf16_t* trow = P.temb + (int64_t)(img / P.temb_div) * P.temb_ld + n0 + wc * 80 + 4 * kq;
+#pragma unroll
+            for (int nb = 0; nb < 5; ++nb) tt[nb] = *reinterpret_cast<const u32x2*>(trow + nb * 16);
         }
 #pragma unroll
-        for (int mb = 0; mb < 5; ++mb)
+        for (int nb = 0; nb < 5; ++nb) {
+            float b4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (P.bias) {
+                b4[0] = __uint_as_float(bt[nb][0] << 16); b4[1] = __uint_as_float(bt[nb][0] & 0xffff0000u);
+                b4[2] = __uint_as_float(bt[nb][1] << 16); b4[3] = __uint_as_float(bt[nb][1] & 0xffff0000u);
+            }
+            if (P.temb) {
+                b4[0] += __uint_as_float(tt[nb][0] << 16); b4[1] += __uint_as_float(tt[nb][0] & 0xffff0000u);
+                b4[2] += __uint_as_float(tt[nb][1] << 16); b4[3] += __uint_as_float(tt[nb][1] & 0xffff0000u);
+            }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[mb][nb][j] += b4[j];
+            for (int mb = 0; mb < 5; ++mb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[mb][nb][j] += b4[j];
+        }
     }
     if (P.res) {
-        for (int cidx = tid; cidx < BM * CPR; cidx += 512) {
-            const int r = cidx / CPR, ch = cidx - r * CPR;
-            *reinterpret_cast<u32x4*>(Os + r * OP + ch * 8) =
-                *reinterpret_cast<const u32x4*>(P.res + row_pixel(r < vrows ? r : 0) * P.cout + n0 + ch * 8);
+        // the residual rows in two bursts of 7 loads per thread (320 x 20 chunks = 12.5 per thread) -- rolled, the loop was load -> s_waitcnt vmcnt(0) ->
+        // ds_write per iteration: thirteen dependent round trips per tile
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            u32x4 rv[7];
+#pragma unroll
+            for (int it = 0; it < 7; ++it) {
+                const int cidx = min(tid + (7 * h + it) * 512, BM * CPR - 1), r = cidx / CPR, ch = cidx - r * CPR;
+                rv[it] = *reinterpret_cast<const u32x4*>(P.res + row_pixel(r < vrows ? r : 0) * P.cout + n0 + ch * 8);
+            }
+#pragma unroll
+            for (int it = 0; it < 7; ++it) {
+                const int cidx = tid + (7 * h + it) * 512, r = cidx / CPR, ch = cidx - r * CPR;
+                if (cidx < BM * CPR) *reinterpret_cast<u32x4*>(Os + r * OP + ch * 8) = rv[it];
+            }
         }
         __syncthreads();
 #pragma unroll

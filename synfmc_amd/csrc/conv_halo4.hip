@@ -289,34 +289,60 @@ void conv_halo4_kernel(const C4Params P) {
         ok = rb < rb_total && y < P.H;
         return ((int64_t)img * P.H + y) * P.W + xb * TW + tx;
     };
-#pragma unroll
-    for (int nb = 0; nb < 5; ++nb) {
-        const int n = n0 + wn * 80 + nb * 16 + 4 * kq;
-        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+    {   // bias and time-embedding words of my outputs: every load of a kind issued before the first is used (one `if (P.temb)` per accumulator block put
+        // a load and its own s_waitcnt vmcnt(0) in each of 25 branches: 25 dependent round trips in the epilogue of every first conv of a ResNet block)
+        u32x2 bt[5], tt[5][5];
         if (P.bias) {
-            const u32x2 t = *reinterpret_cast<const u32x2*>(P.bias + n);
-            b4[0] = __uint_as_float(t[0] << 16); b4[1] = __uint_as_float(t[0] & 0xffff0000u);
-            b4[2] = __uint_as_float(t[1] << 16); b4[3] = __uint_as_float(t[1] & 0xffff0000u);
+#pragma unroll
+            for (int nb = 0; nb < 5; ++nb) bt[nb] = *reinterpret_cast<const u32x2*>(P.bias + n0 + wn * 80 + nb * 16 + 4 * kq);
+        }
+        if (P.temb) {                                        // (a tile spans several images: the row's own image)
+#pragma unroll
+            for (int mb = 0; mb < 5; ++mb) {
+                const int idx = wp * 80 + mb * 16 + l15, rb = min(rb0 + idx / RB, rb_total - 1), img = rb / tpi;
+                const bf16_t* trow = P.temb + (int64_t)(img / P.temb_div) * P.temb_ld + n0 + wn * 80 + 4 * kq;
+#pragma unroll
+                for (int nb = 0; nb < 5; ++nb) tt[mb][nb] = *reinterpret_cast<const u32x2*>(trow + nb * 16);
+            }
         }
 #pragma unroll
-        for (int mb = 0; mb < 5; ++mb) {
-            float t4[4] = {0.f, 0.f, 0.f, 0.f};
-            if (P.temb) {                                    // (a tile spans several images: the row's own image)
-                const int idx = wp * 80 + mb * 16 + l15, rb = min(rb0 + idx / RB, rb_total - 1), img = rb / tpi;
-                const u32x2 t = *reinterpret_cast<const u32x2*>(P.temb + (int64_t)(img / P.temb_div) * P.temb_ld + n);
-                t4[0] = __uint_as_float(t[0] << 16); t4[1] = __uint_as_float(t[0] & 0xffff0000u);
-                t4[2] = __uint_as_float(t[1] << 16); t4[3] = __uint_as_float(t[1] & 0xffff0000u);
+        for (int nb = 0; nb < 5; ++nb) {
+            float b4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (P.bias) {
+                b4[0] = __uint_as_float(bt[nb][0] << 16); b4[1] = __uint_as_float(bt[nb][0] & 0xffff0000u);
+                b4[2] = __uint_as_float(bt[nb][1] << 16); b4[3] = __uint_as_float(bt[nb][1] & 0xffff0000u);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[mb][nb][j] += b4[j] + t4[j];
+            for (int mb = 0; mb < 5; ++mb) {
+                float t4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (P.temb) {
+                    t4[0] = __uint_as_float(tt[mb][nb][0] << 16); t4[1] = __uint_as_float(tt[mb][nb][0] & 0xffff0000u);
+                    t4[2] = __uint_as_float(tt[mb][nb][1] << 16); t4[3] = __uint_as_float(tt[mb][nb][1] & 0xffff0000u);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[mb][nb][j] += b4[j] + t4[j];
+            }
         }
     }
     if (P.res) {
-        for (int cidx = tid; cidx < BM * CPR; cidx += NT) {
-            const int r = cidx / CPR, ch = cidx - r * CPR;
-            bool ok;
-            const int64_t m = row_pixel(r, ok);
-            *reinterpret_cast<u32x4*>(Os + r * OP + ch * 8) = ok ? *reinterpret_cast<const u32x4*>(P.res + m * P.cout + n0 + ch * 8) : u32x4{0u, 0u, 0u, 0u};
+        // the residual rows in bursts of RBU loads per thread (rows that are not stored read pixel 0: never used) -- rolled, the loop was
+        // load -> s_waitcnt vmcnt(0) -> ds_write per iteration: BM * CPR / NT (12.5 at 4 waves) dependent round trips
+        constexpr int NIT = (BM * CPR + NT - 1) / NT, RBU = 7;
+#pragma unroll
+        for (int h = 0; h < (NIT + RBU - 1) / RBU; ++h) {
+            u32x4 rv[RBU];
+#pragma unroll
+            for (int it = 0; it < RBU; ++it) {
+                const int cidx = min(tid + (h * RBU + it) * NT, BM * CPR - 1), r = cidx / CPR, ch = cidx - r * CPR;
+                bool ok;
+                const int64_t m = row_pixel(r, ok);
+                rv[it] = *reinterpret_cast<const u32x4*>(P.res + (ok ? m : 0) * P.cout + n0 + ch * 8);
+            }
+#pragma unroll
+            for (int it = 0; it < RBU; ++it) {
+                const int cidx = tid + (h * RBU + it) * NT, r = cidx / CPR, ch = cidx - r * CPR;
+                if (cidx < BM * CPR) *reinterpret_cast<u32x4*>(Os + r * OP + ch * 8) = rv[it];
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -402,30 +428,36 @@ __global__ __launch_bounds__(256) void conv_halo4_finish_kernel(const C4Params P
     for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
         const int64_t m = id / cpr;
         const int n = (int)(id - m * cpr) * 8;
+        // every operand of the chunk requested before the first is used: bias / temb / residual words, then the partial sums four splits at a time
+        // (one load -> wait -> add per split and per side operand was seven dependent round trips for a launch that moves 10 MB)
+        u32x4 tb = u32x4{0u, 0u, 0u, 0u}, tt = tb, tr = tb;
+        if (P.bias) tb = *reinterpret_cast<const u32x4*>(P.bias + n);
+        if (P.temb) tt = *reinterpret_cast<const u32x4*>(P.temb + ((m / ((int64_t)P.H * P.W)) / P.temb_div) * P.temb_ld + n);
+        if (P.res) tr = *reinterpret_cast<const u32x4*>(P.res + m * P.cout + n);
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int sp = 0; sp < P.splits; ++sp) {
-            const float* src = P.ws + ((int64_t)sp * mtot + m) * P.cout + n;
-            const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+        for (int sp0 = 0; sp0 < P.splits; sp0 += 4) {
+            f32x4 pa[4], pb[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { v[k] += a[k]; v[4 + k] += b[k]; }
-        }
-        float t[8];
-        if (P.bias) {
-            Vec8<bf16_t>::load(P.bias + n, t);
+            for (int k = 0; k < 4; ++k) {
+                const float* src = P.ws + ((int64_t)min(sp0 + k, P.splits - 1) * mtot + m) * P.cout + n;
+                pa[k] = *reinterpret_cast<const f32x4*>(src);
+                pb[k] = *reinterpret_cast<const f32x4*>(src + 4);
+            }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] += t[k];
-        }
-        if (P.temb) {
-            const int64_t img = m / ((int64_t)P.H * P.W);
-            Vec8<bf16_t>::load(P.temb + (img / P.temb_div) * P.temb_ld + n, t);
+            for (int k = 0; k < 4; ++k)                       // (fixed order: split 0, 1, 2, ...)
+                if (sp0 + k < P.splits) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] += t[k];
+                    for (int j = 0; j < 4; ++j) { v[j] += pa[k][j]; v[4 + j] += pb[k][j]; }
+                }
         }
-        if (P.res) {
-            Vec8<bf16_t>::load(P.res + m * P.cout + n, t);
+        const u32x4* side[3] = {&tb, &tt, &tr};
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] += t[k];
-        }
+        for (int q = 0; q < 3; ++q)                           // + bias, + temb, + residual, in the order of the one-pass epilogue (absent ones add zero words)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[2 * j] += __uint_as_float((*side[q])[j] << 16);
+                v[2 * j + 1] += __uint_as_float((*side[q])[j] & 0xffff0000u);
+            }
         Vec8<bf16_t>::store(P.out + m * P.cout + n, v);
     }
 }
