@@ -1750,13 +1750,19 @@ void gemm160_kernel(const GemmParams P) {
         constexpr int OP = BN + 8;                         // bf16 pitch of the staging rows (656 B: 16-byte aligned)
         bf16_t* Os = smem;                                 // [160][OP] = 104 960 B
         constexpr int CPR = BN / 8;                        // 40 chunks per row
-        // alpha * (acc + bias) (+ temb) in the accumulator registers
+        // alpha * (acc + bias) (+ temb) in the accumulator registers; the five bias words in one burst (a load inside each block's `if (P.bias)` was
+        // followed by its own s_waitcnt vmcnt(0): five dependent round trips per tile)
+        u32x2 bt[5];
+        if (P.bias) {
+#pragma unroll
+            for (int nb = 0; nb < 5; ++nb) bt[nb] = *reinterpret_cast<const u32x2*>(P.bias + n0 + wc * 80 + nb * 16 + 4 * kq);
+        }
 #pragma unroll
         for (int nb = 0; nb < 5; ++nb) {
             const int n = n0 + wc * 80 + nb * 16 + 4 * kq;
             float b4[4] = {0.f, 0.f, 0.f, 0.f};
             if (P.bias) {
-                const u32x2 t = *reinterpret_cast<const u32x2*>(P.bias + n);
+                const u32x2 t = bt[nb];
                 b4[0] = __uint_as_float(t[0] << 16); b4[1] = __uint_as_float(t[0] & 0xffff0000u);
                 b4[2] = __uint_as_float(t[1] << 16); b4[3] = __uint_as_float(t[1] & 0xffff0000u);
             }
@@ -2115,14 +2121,22 @@ void gemm160p_kernel(const GemmParams P) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) acc[mb][nb][j] = rs[mb] * (acc[mb][nb][j] - mu[mb] * c4[j]) + b4[j];
                 }
-            } else
-            // alpha * (acc + bias) in the accumulator registers
+            } else {
+            // alpha * (acc + bias) in the accumulator registers; the five bias words in one burst where the registers allow it (LN == 0: the
+            // LayerNorm-writing variants sit at the 256-register limit and keep the load beside its use)
+            u32x2 bt[5];
+            if (LN == 0 && P.bias) {
+#pragma unroll
+                for (int nb = 0; nb < 5; ++nb) bt[nb] = *reinterpret_cast<const u32x2*>(P.bias + n0 + wc * 80 + nb * 16 + 4 * kq);
+            }
 #pragma unroll
             for (int nb = 0; nb < 5; ++nb) {
                 const int n = n0 + wc * 80 + nb * 16 + 4 * kq;
                 float b4[4] = {0.f, 0.f, 0.f, 0.f};
                 if (P.bias) {
-                    const u32x2 t = *reinterpret_cast<const u32x2*>(P.bias + n);
+                    u32x2 t;
+                    if (LN == 0) t = bt[nb];
+                    else t = *reinterpret_cast<const u32x2*>(P.bias + n);
                     b4[0] = __uint_as_float(t[0] << 16); b4[1] = __uint_as_float(t[0] & 0xffff0000u);
                     b4[2] = __uint_as_float(t[1] << 16); b4[3] = __uint_as_float(t[1] & 0xffff0000u);
                 }
@@ -2130,6 +2144,7 @@ void gemm160p_kernel(const GemmParams P) {
                 for (int mb = 0; mb < 5; ++mb)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[mb][nb][j] = (acc[mb][nb][j] + b4[j]) * P.alpha;
+            }
             }
             float gs = 0.f, gss = 0.f;
 #pragma unroll 1
