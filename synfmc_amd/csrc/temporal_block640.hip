@@ -710,9 +710,13 @@ void geglu_direct_kernel(const G6Params P) {
         }
         __syncthreads();
         // ---- whole-row stores: 80 rows x GCOLS / 8 sixteen-byte chunks = 6.25 per thread ----
+        // (the per-thread row / column of the seven stores recomputed from an opaque copy of tid in every chunk: visible as loop invariants, hipcc
+        //  hoists the seven 64-bit row offsets out of the chunk loop, spills them -- 20 VGPRs -- and reloads each behind its own s_waitcnt vmcnt(0))
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
 #pragma unroll
         for (int it = 0; it < 7; ++it) {
-            const int c = tid + NT * it;
+            const int c = tq + NT * it;
             if (it < 6 || tid < NT / 4) {
                 const int r = c / (GCOLS / 8), cc = c - r * (GCOLS / 8);
                 const int64_t m = m0 + r;
