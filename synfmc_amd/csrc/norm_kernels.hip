@@ -478,7 +478,7 @@ __global__ void gn_apply_bwd_kernel(const T* __restrict__ dy, const T* __restric
 // loaded (16 B per lane per chunk) before the first reduction so that R*NCH loads are in flight per lane.
 // --------------------------------------------------------------------------------------------
 template <typename T, int NCH, int R>  // NCH = ceil(C/8/64) chunks of 8 per lane
-__global__ void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ gamma,
                                  const float* __restrict__ beta, const float* __restrict__ pe, int64_t M, int C,
                                  float eps, int pe_inner, int pe_frames) {
     const int lane = threadIdx.x & 63;
@@ -770,7 +770,7 @@ __global__ void geglu_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t
 // rows, then one fp32 atomicAdd per channel per wave (buffers zeroed by the caller).
 // --------------------------------------------------------------------------------------------
 template <typename T, int NCH>
-__global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
                                      T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                      int64_t M, int C, float eps, const T* __restrict__ addend = nullptr) {
     const int lane = threadIdx.x & 63;
