@@ -343,10 +343,18 @@ int fmc_linear4_bf16(const void* x, const void* w, const void* bias, const void*
  * (fmc/models/attention_processor.py:69, fmc/models/motion_module.py:228,299) where the per-shape choice is the library.  torch's F.linear cannot pass C and
  * bias together and followed the GEMM with an elementwise add.  bf16; bias [N] | NULL; residual rows ldres apart | NULL; x rows ldx, out rows ldo apart;
  * W [N, K] row-major.  `algo` indexes the heuristic's candidate list, 0 <= algo < fmc_vendor_linear_candidates(...) (0 = the library's first choice).
- * The first call for a problem queries the heuristic and, per device, allocates a 64-MiB workspace: make it outside stream capture. */
+ * Ownership (round 6): nothing here allocates device memory.  fmc_vendor_init() creates the library handle of the CURRENT device (idempotent),
+ * fmc_vendor_destroy() drops it together with the device's cached plans; every other entry point fails with FMC_E_NULL before init.  Split-K / stream-K
+ * candidates need scratch: the caller passes `workspace` (16-byte aligned, >= fmc_vendor_workspace_bytes() = the size candidates are planned for; one buffer
+ * per stream that issues these calls, NULL / 0 allowed for candidates that need none).  The first call for a problem queries the heuristic (host work):
+ * make it outside stream capture.  fmc_vendor_version() = hipblasLtGetVersion (candidate indices are only meaningful within one library version). */
+int fmc_vendor_init(void);
+int fmc_vendor_destroy(void);
+int fmc_vendor_version(void);
+int64_t fmc_vendor_workspace_bytes(void);
 int fmc_vendor_linear_candidates(int64_t M, int N, int K, int64_t ldx, int64_t ldres, int64_t ldo, int has_bias, int has_residual);
 int fmc_vendor_linear_bf16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int N, int K,
-                           int64_t ldx, int64_t ldres, int64_t ldo, int algo, void* stream);
+                           int64_t ldx, int64_t ldres, int64_t ldo, int algo, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* The statistics pass of fmc_groupnorm_silu_fwd alone (x read once, nothing written but the sums): partials [N][splits][G][2] fp32 with
  * splits = fmc_groupnorm_partial_splits(HW, C); x2 / C1: two-source channel concat as for fmc_groupnorm_silu_fwd. */

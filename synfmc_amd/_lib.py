@@ -73,7 +73,12 @@ SIGNATURES = {
                                        c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p]),
     "fmc_linear4_supported": (c_int, [c_int64, c_int, c_int, c_int64]),
     "fmc_vendor_linear_candidates": (c_int, [c_int64, c_int, c_int, c_int64, c_int64, c_int64, c_int, c_int]),
-    "fmc_vendor_linear_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_int64, c_int, c_void_p]),
+    "fmc_vendor_linear_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_int64, c_int, c_void_p,
+                                       c_int64, c_void_p]),
+    "fmc_vendor_init": (c_int, []),
+    "fmc_vendor_destroy": (c_int, []),
+    "fmc_vendor_version": (c_int, []),
+    "fmc_vendor_workspace_bytes": (c_int64, []),
     "fmc_linear4_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "fmc_groupnorm_coef": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "fmc_groupnorm_apply_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

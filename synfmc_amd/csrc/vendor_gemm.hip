@@ -9,6 +9,10 @@
 //
 // Row-major out[M][N] = x[M][K] w[N][K]^T is the column-major product D(N x M) = w^T(N x K) x(K x M): transA = T (lda = K), transB = N (ldb = ldx);
 // the bias vector runs along D's rows (= output features).
+//
+// Ownership (round 6; the header's convention "the caller owns every buffer" holds here too): the library handle lives between fmc_vendor_init() and
+// fmc_vendor_destroy() of a device, the split-K / stream-K scratch is the CALLER's (`workspace`, `workspace_bytes` per call -- one buffer per stream on the
+// host side, so two streams never share scratch); nothing in this file allocates device memory.
 #include <hip/hip_runtime.h>
 #include <hipblaslt/hipblaslt.h>
 
@@ -21,12 +25,11 @@
 
 namespace {
 
-constexpr size_t VG_WORKSPACE = 64u << 20;
+constexpr size_t VG_WORKSPACE = 64u << 20;          // the workspace size candidates are planned for (fmc_vendor_workspace_bytes)
 constexpr int VG_MAX_ALGOS = 8;
 
 struct VgDevice {
     hipblasLtHandle_t handle = nullptr;
-    void* workspace = nullptr;
 };
 
 struct VgPlan {
@@ -36,6 +39,15 @@ struct VgPlan {
 };
 
 typedef std::tuple<int, int64_t, int, int, int64_t, int64_t, int64_t, int, int> VgKey;   // device, M, N, K, ldx, ldres, ldo, bias?, residual?
+
+void vg_free_plan(VgPlan& p) {
+    if (p.a) (void)hipblasLtMatrixLayoutDestroy(p.a);
+    if (p.b) (void)hipblasLtMatrixLayoutDestroy(p.b);
+    if (p.c) (void)hipblasLtMatrixLayoutDestroy(p.c);
+    if (p.d) (void)hipblasLtMatrixLayoutDestroy(p.d);
+    if (p.desc) (void)hipblasLtMatmulDescDestroy(p.desc);
+    p = VgPlan();
+}
 
 std::mutex g_mu;
 VgDevice g_dev[64];
@@ -49,10 +61,7 @@ std::map<VgKey, VgPlan> g_plans;
 
 int vg_device(VgDevice*& out) {
     VgDevice& d = g_dev[fmc_device() & 63];
-    if (!d.handle) {
-        VG_CHECK(hipblasLtCreate(&d.handle), "hipblasLtCreate");
-        if (hipMalloc(&d.workspace, VG_WORKSPACE) != hipSuccess) FMC_FAIL(FMC_E_LAUNCH, "vendor_linear_bf16: no %zu-byte workspace", VG_WORKSPACE);
-    }
+    if (!d.handle) FMC_FAIL(FMC_E_NULL, "vendor_linear_bf16: fmc_vendor_init() has not been called on device %d", fmc_device());
     out = &d;
     return 0;
 }
@@ -98,6 +107,46 @@ int vg_plan(VgDevice& dev, const VgKey& key, int64_t M, int N, int K, int64_t ld
 
 }  // namespace
 
+extern "C" int64_t fmc_vendor_workspace_bytes(void) { return (int64_t)VG_WORKSPACE; }
+
+// hipBLASLt's version number (candidate indices of one library version mean other kernels in another: the arm table records it)
+extern "C" int fmc_vendor_version(void) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    VgDevice& d = g_dev[fmc_device() & 63];
+    if (!d.handle) FMC_FAIL(FMC_E_NULL, "vendor_version: fmc_vendor_init() has not been called on device %d", fmc_device());
+    int v = 0;
+    VG_CHECK(hipblasLtGetVersion(d.handle, &v), "hipblasLtGetVersion");
+    return v;
+}
+
+// library handle of the current device (idempotent); no device memory is allocated
+extern "C" int fmc_vendor_init(void) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    VgDevice& d = g_dev[fmc_device() & 63];
+    if (!d.handle) VG_CHECK(hipblasLtCreate(&d.handle), "hipblasLtCreate");
+    return 0;
+}
+
+// drops the current device's plans and its handle (idempotent)
+extern "C" int fmc_vendor_destroy(void) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    const int dev = fmc_device();
+    for (auto it = g_plans.begin(); it != g_plans.end();) {
+        if (std::get<0>(it->first) == dev) {
+            vg_free_plan(it->second);
+            it = g_plans.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    VgDevice& d = g_dev[dev & 63];
+    if (d.handle) {
+        (void)hipblasLtDestroy(d.handle);
+        d.handle = nullptr;
+    }
+    return 0;
+}
+
 // number of heuristic candidates for this problem (>= 1), or a negative error code
 extern "C" int fmc_vendor_linear_candidates(int64_t M, int N, int K, int64_t ldx, int64_t ldres, int64_t ldo, int has_bias, int has_residual) {
     if (M <= 0 || N <= 0 || K <= 0) FMC_FAIL(FMC_E_SHAPE, "vendor_linear_candidates: M=%lld N=%d K=%d", (long long)M, N, K);
@@ -111,7 +160,7 @@ extern "C" int fmc_vendor_linear_candidates(int64_t M, int N, int K, int64_t ldx
 }
 
 extern "C" int fmc_vendor_linear_bf16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int N, int K,
-                                      int64_t ldx, int64_t ldres, int64_t ldo, int algo, void* stream) {
+                                      int64_t ldx, int64_t ldres, int64_t ldo, int algo, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!x || !w || !out) FMC_FAIL(FMC_E_NULL, "vendor_linear_bf16: NULL tensor");
     if (M <= 0 || N <= 0 || K <= 0 || ldx < K || ldo < N || (residual && ldres < N))
         FMC_FAIL(FMC_E_SHAPE, "vendor_linear_bf16: M=%lld N=%d K=%d ldx=%lld ldres=%lld ldo=%lld", (long long)M, N, K, (long long)ldx, (long long)ldres, (long long)ldo);
@@ -125,10 +174,13 @@ extern "C" int fmc_vendor_linear_bf16(const void* x, const void* w, const void* 
     if (int rc = vg_plan(*dev, key, M, N, K, ldx, ldres, ldo, bias != nullptr, residual != nullptr, plan)) return rc;
     if (algo < 0 || algo >= (int)plan->algos.size())
         FMC_FAIL(FMC_E_SHAPE, "vendor_linear_bf16: candidate %d of %d", algo, (int)plan->algos.size());
+    const size_t need = plan->algos[algo].workspaceSize;
+    if (need && (!workspace || workspace_bytes < (int64_t)need || !fmc_aligned16(workspace)))
+        FMC_FAIL(FMC_E_NULL, "vendor_linear_bf16: candidate %d needs %zu bytes of 16-byte aligned workspace, got %lld", algo, need, (long long)workspace_bytes);
     if (bias) VG_CHECK(hipblasLtMatmulDescSetAttribute(plan->desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)), "BIAS_POINTER");
     const float alpha = 1.f, beta = residual ? 1.f : 0.f;
     VG_CHECK(hipblasLtMatmul(dev->handle, plan->desc, &alpha, w, plan->a, x, plan->b, &beta, residual ? residual : out, plan->c, out, plan->d,
-                             &plan->algos[algo].algo, dev->workspace, VG_WORKSPACE, (hipStream_t)stream),
+                             &plan->algos[algo].algo, need ? workspace : nullptr, need ? (size_t)workspace_bytes : 0, (hipStream_t)stream),
              "hipblasLtMatmul");
     return 0;
 }

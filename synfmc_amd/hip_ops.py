@@ -1183,6 +1183,49 @@ _vendor_seen = {}                                                     # problem 
 vendor_direct_calls = {"direct": 0, "with_residual": 0}
 
 
+_vendor_ws = {}                                                       # (device, stream handle) -> workspace tensor: two streams never share split-K scratch
+_vendor_inited = set()
+
+
+def _vendor_init(device_index: int) -> None:
+    """hipBLASLt handle of the device, created once through the ABI's explicit `fmc_vendor_init` and dropped at interpreter exit."""
+    if device_index not in _vendor_inited:
+        _lib.check(_lib.load().fmc_vendor_init(), "fmc_vendor_init")
+        if not _vendor_inited:
+            atexit.register(_vendor_shutdown)
+        _vendor_inited.add(device_index)
+
+
+def _vendor_shutdown() -> None:
+    _vendor_ws.clear()
+    try:
+        if _vendor_inited and torch.cuda.is_available():
+            cur = torch.cuda.current_device()
+            for d in sorted(_vendor_inited):
+                torch.cuda.set_device(d)
+                _lib.load().fmc_vendor_destroy()
+            torch.cuda.set_device(cur)
+    except Exception:                                                 # interpreter teardown: the driver frees what is left
+        pass
+    _vendor_inited.clear()
+
+
+def _vendor_workspace(device: torch.device):
+    """The caller-owned scratch `fmc_vendor_linear_bf16` wants: one torch allocation per (device, stream).  Under stream capture the buffer comes out
+    of the graph's private pool and lives as long as the graph's memory does; the entry is keyed by the capture stream, which eager work never uses."""
+    key = (device.index, _stream())
+    ws = _vendor_ws.get(key)
+    if ws is None:
+        ws = _vendor_ws[key] = torch.empty(int(_lib.load().fmc_vendor_workspace_bytes()), dtype=torch.uint8, device=device)
+    return ws
+
+
+def vendor_version() -> int:
+    """hipBLASLt's version number (the `("valgo", ...)` entries of an arm table index ITS heuristic's candidate list)."""
+    _vendor_init(torch.cuda.current_device())
+    return int(_lib.load().fmc_vendor_version())
+
+
 def vendor_linear_ok(x: torch.Tensor, weight: torch.Tensor, bias, residual) -> bool:
     if not (VENDOR_DIRECT and x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.is_contiguous() and x.stride(-1) == 1
             and (x.is_contiguous() or x.ndim == 2) and (bias is None or (bias.dtype == torch.bfloat16 and bias.is_contiguous()))
@@ -1191,7 +1234,17 @@ def vendor_linear_ok(x: torch.Tensor, weight: torch.Tensor, bias, residual) -> b
         return False
     N, Kd = weight.shape
     M, ldx = _rows2d(x)
-    key = (x.device.index, M, N, Kd, ldx, 0 if residual is None else _rows2d(residual)[1], bias is not None, residual is not None)
+    ldres = 0
+    if residual is not None:
+        # the library reads C as a full [M, N] matrix: a broadcastable residual ([1, S, N], [N]) must take the torch path, which broadcasts
+        if tuple(residual.shape) != (*x.shape[:-1], N):
+            return False
+        ldres = _rows2d(residual)[1]
+        if ldres % 8 or residual.data_ptr() % 16:
+            return False
+    if ldx % 8 or x.data_ptr() % 16 or weight.data_ptr() % 16 or (bias is not None and bias.data_ptr() % 2):
+        return False                                                  # un-aligned views: F.linear accepts them, the direct call would raise FMC_E_ALIGN
+    key = (x.device.index, M, N, Kd, ldx, ldres, bias is not None, residual is not None)
     return key in _vendor_seen or not torch.cuda.is_current_stream_capturing()
 
 
@@ -1200,7 +1253,9 @@ def vendor_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Te
     _dev(x, weight, bias, residual)
     N, Kd = weight.shape
     M, ldx = _rows2d(x)
+    _vendor_init(x.device.index)
     out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
+    ws = _vendor_workspace(x.device)
     ldres = 0 if residual is None else _rows2d(residual)[1]
     key = (x.device.index, M, N, Kd, ldx, ldres, bias is not None, residual is not None)
     n = _vendor_seen.get(key)
@@ -1221,7 +1276,7 @@ def vendor_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Te
             times = {}
             for a in range(n):
                 call = lambda a=a: _lib.load().fmc_vendor_linear_bf16(x.data_ptr(), weight.data_ptr(), _p(bias), _p(residual), out.data_ptr(), M, N, Kd, ldx,
-                                                                      ldres, N, a, _stream())
+                                                                      ldres, N, a, ws.data_ptr(), ws.numel(), _stream())
                 for _ in range(5):
                     call()
                 best = float("inf")
@@ -1241,7 +1296,7 @@ def vendor_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Te
         else:
             algo = 0
     _lib.check(_lib.load().fmc_vendor_linear_bf16(x.data_ptr(), weight.data_ptr(), _p(bias), _p(residual), out.data_ptr(), M, N, Kd, ldx, ldres, N,
-                                                  min(int(algo), n - 1), _stream()), "fmc_vendor_linear_bf16")
+                                                  min(int(algo), n - 1), ws.data_ptr(), ws.numel(), _stream()), "fmc_vendor_linear_bf16")
     vendor_direct_calls["direct"] += 1
     vendor_direct_calls["with_residual"] += residual is not None
     return out
@@ -1896,11 +1951,12 @@ def _cache_meta():
         with open(_lib.LIB_PATH, "rb") as f:
             sha = hashlib.sha256(f.read()).hexdigest()[:16]
         _cache_state["meta"] = {"lib_sha16": sha, "device": torch.cuda.get_device_name() if torch.cuda.is_available() else "cpu",
-                                "arms": list(GEMM_TILES)}
+                                "arms": list(GEMM_TILES), "hipblaslt": vendor_version() if torch.cuda.is_available() else 0}
     return _cache_state["meta"]
 
 
 DEFAULT_ARM_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "autotune_default_mi355x.json")
+stale_table_entries = [0]                          # table entries dropped by `_pick` because their arm is disabled / ineligible in this process
 autotune_sources = {"cache": 0, "defaults": 0}     # shapes taken from the per-build cache / from the tracked default table (bench.py reports them)
 
 
@@ -1922,6 +1978,8 @@ def _load_table_file(path: str, strict_meta: bool) -> int:
         n = 0
         for k, v in blob["choices"].items():
             key = ast.literal_eval(k)
+            if key[0] == "valgo" and meta.get("hipblaslt") != mine["hipblaslt"]:
+                continue                           # an index into ANOTHER hipBLASLt version's candidate list names other kernels: re-time on this one
             if key not in _choice:
                 _choice[key] = int(v["arm"])
                 _tune_log[key] = {int(a): ms for a, ms in v.get("ms", {}).items()}
@@ -2042,12 +2100,22 @@ def _pick(key, hip_fn, lib_fn, static_hip: bool, extra_arms=(), k320: bool = Fal
     use = _choice.get(key)
     _calls[key] = _calls.get(key, 0) + 1
     n320 = (key[5] if key[0] == "conv" else key[2]) % 320 == 0
+    # the arms THIS call may run: the enabled tile list (FMC_GEMM_ARMS / W_TILEMAJOR) + the caller's gated extras (split arms, small-M tiles, arm 700 only
+    # where LINEAR4 and its shape gate hold), minus the forms that exist for some shapes only
+    cands = tuple(t for t in GEMM_TILES + tuple(extra_arms)
+                  if (t != 15 or k320)    # (arm 15 exists for the K = 320 token projections only,
+                  and (not (ARM_160 <= t < ARM_160 + 5 or ARM_160B <= t < ARM_160B + 5 or t == ARM_256) or n320))  #  arm 16 for outputs whose width is a multiple of 320)
+    if use is not None and not (use in cands or (use == 0 and not no_lib) or (use == -1 and key not in _tune_log)):
+        # a table entry (tracked defaults, an older cache) naming an arm that is switched off or not eligible here: an A/B run must measure the arms it
+        # asked for, and a gated arm (700 on a strided x, 15 off its shape) must not be reached through the table -- drop the entry, re-tune below
+        _choice.pop(key, None)
+        _tune_log.pop(key, None)
+        stale_table_entries[0] += 1
+        use = None
     if use is None:
         if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
             return 0 if not (static_hip or no_lib) else -1          # -1: kernel's own geometry heuristic
-        times = ([] if no_lib else [(_time_ms(lib_fn), 0)]) + [(_time_ms(lambda t=t: hip_fn(t)), t) for t in GEMM_TILES + tuple(extra_arms)
-                                                                if (t != 15 or k320)    # (arm 15 exists for the K = 320 token projections only,
-                                                                and (not (ARM_160 <= t < ARM_160 + 5 or ARM_160B <= t < ARM_160B + 5 or t == ARM_256) or n320)]  #  arm 16 for outputs whose width is a multiple of 320)
+        times = ([] if no_lib else [(_time_ms(lib_fn), 0)]) + [(_time_ms(lambda t=t: hip_fn(t)), t) for t in cands]
         use = min(times)[1]
         _choice[key] = use
         _tune_log[key] = {arm: round(ms, 4) for ms, arm in times}

@@ -2013,12 +2013,23 @@ def test_vendor_linear_direct(K, M, N, Kd, extras):
     n = K._lib.load().fmc_vendor_linear_candidates(M, N, Kd, Kd, N if rd is not None else 0, N, int(bd is not None), int(rd is not None))
     assert n >= 1
     lib = K._lib.load()
+    ws = K._vendor_workspace(xd.device)                                       # the scratch is the caller's (one per stream), never the library's
+    assert ws.numel() == lib.fmc_vendor_workspace_bytes() and K.vendor_version() > 0
+    need_ws = 0
     for algo in range(n):
         out = torch.empty_like(got)
         K._lib.check(lib.fmc_vendor_linear_bf16(xd.data_ptr(), wd.data_ptr(), bd.data_ptr() if bd is not None else None, rd.data_ptr() if rd is not None else None,
-                                                out.data_ptr(), M, N, Kd, Kd, N if rd is not None else 0, N, algo, torch.cuda.current_stream().cuda_stream), "vendor")
+                                                out.data_ptr(), M, N, Kd, Kd, N if rd is not None else 0, N, algo, ws.data_ptr(), ws.numel(),
+                                                torch.cuda.current_stream().cuda_stream), "vendor")
         assert_bf16_close(out, ref, mag, f"vendor_linear candidate {algo}")
-    assert lib.fmc_vendor_linear_bf16(xd.data_ptr(), wd.data_ptr(), None, None, got.data_ptr(), M, N, Kd, Kd, 0, N, n, 0) != 0      # past the list: refused
+        # without a workspace a candidate either needs none (runs, same result) or is refused loudly -- it never allocates behind the caller's back
+        rc = lib.fmc_vendor_linear_bf16(xd.data_ptr(), wd.data_ptr(), bd.data_ptr() if bd is not None else None, rd.data_ptr() if rd is not None else None,
+                                        out.data_ptr(), M, N, Kd, Kd, N if rd is not None else 0, N, algo, None, 0, torch.cuda.current_stream().cuda_stream)
+        need_ws += rc != 0
+        if rc == 0:
+            assert_bf16_close(out, ref, mag, f"vendor_linear candidate {algo} without workspace")
+    assert need_ws < n or n == 1
+    assert lib.fmc_vendor_linear_bf16(xd.data_ptr(), wd.data_ptr(), None, None, got.data_ptr(), M, N, Kd, Kd, 0, N, n, ws.data_ptr(), ws.numel(), 0) != 0   # past the list: refused
     wide = torch.cat([xd, xd.flip(0)], dim=1)                                # rows of a wider matrix (ldx > K)
     assert_bf16_close(K.vendor_linear(wide[:, :Kd], wd, bd, rd), ref, mag, "vendor_linear strided")
     if rd is not None:
@@ -2027,6 +2038,9 @@ def test_vendor_linear_direct(K, M, N, Kd, extras):
         y = K.linear(xd, wd, bd, residual=rd)
         assert K.vendor_direct_calls["with_residual"] == before["with_residual"] + 1
         assert_bf16_close(y, ref, mag, "linear -> vendor arm")
+        # a broadcastable residual is not the library's full [M, N] C matrix: the arm must take the torch path (which broadcasts), not read out of bounds
+        assert not K.vendor_linear_ok(xd, wd, bd, rd[:1])
+        assert not K.vendor_linear_ok(xd[:, 4:], wd[:, 4:].contiguous(), None, None)       # rows 8 bytes off a 16-byte boundary: F.linear's business
 
 
 @torch.no_grad()

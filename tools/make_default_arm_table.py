@@ -4,6 +4,8 @@ default table `synfmc_amd/autotune_default_mi355x.json`: the per-shape choices a
 keyed by the library hash and dies with every rebuild).  Several inputs are merged; where they disagree the arm with the lower measured time wins.
 
     python tools/make_default_arm_table.py gpurun_out/<run>/autotune_cache.json [more.json ...]
+
+Feed it caches written by BENCH runs only (`FMC_AUTOTUNE_CACHE=<fresh file> python bench.py ...`): a cache a test run wrote holds test-suite shapes.
 """
 import json
 import os
@@ -13,9 +15,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {"meta": None, "choices": {}}
 for path in sys.argv[1:]:
     blob = json.load(open(path))
-    meta = {"arch": "gfx950", "arms": blob["meta"]["arms"], "made_from": []}      # (made on MI355X boxes: the caches carry no architecture field)
+    # (made on MI355X boxes: the caches carry no architecture field.)  "hipblaslt": the library version the ("valgo", ...) candidate indices belong to --
+    # the loader skips those keys on any other version
+    meta = {"arch": "gfx950", "arms": blob["meta"]["arms"], "hipblaslt": blob["meta"].get("hipblaslt", 0), "made_from": []}
     if out["meta"] is None:
         out["meta"] = meta
+    elif meta["hipblaslt"] != out["meta"]["hipblaslt"]:
+        sys.exit(f"{path}: hipBLASLt version {meta['hipblaslt']} differs from the first input's {out['meta']['hipblaslt']}")
     out["meta"]["made_from"].append(os.path.relpath(os.path.abspath(path), ROOT))
     for k, v in blob["choices"].items():
         old = out["choices"].get(k)
