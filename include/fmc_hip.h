@@ -356,6 +356,18 @@ int fmc_vendor_linear_candidates(int64_t M, int N, int K, int64_t ldx, int64_t l
 int fmc_vendor_linear_bf16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int N, int K,
                            int64_t ldx, int64_t ldres, int64_t ldo, int algo, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Multi-head attention for the steps either side of the denoising loop (csrc/attn_generic.hip, round 6): softmax(q k^T scale + mask) v
+ * for the shapes the hot-path kernels above do not take -- the VAE mid block's single head of width 512 (diffusers AutoencoderKL; reached from
+ * `decode_latents`, fmc/pipelines/pipeline_animation_cm_om.py:465-478, and `vae.encode`, train_cam_obj_ctrl.py:786) and CLIP's causal text self-attention
+ * (`_encode_prompt`, pipeline_animation_cm_om.py:480-568).  q [B, Sq, H D], k / v [B, Skv, H D] with batch / row strides in elements (slices of a fused
+ * projection are fine), o [B, Sq, H D]; D in {32, 64, 128, 256, 512}; `causal`: key j attends to query i only when j <= i; `key_keep` [B][Skv] bytes
+ * (1 = attend) or NULL; dtype FMC_BF16 or FMC_F32 (split-bf16 x3 products).  A fully masked row yields zeros. */
+int fmc_attention_supported(int D);
+int fmc_attention_fwd(const void* q, const void* k, const void* v, void* o, const unsigned char* key_keep, int B, int H, int Sq, int Skv, int D,
+                      int64_t q_batch_stride, int64_t q_row_stride, int64_t kv_batch_stride, int64_t kv_row_stride, int64_t o_batch_stride,
+                      int64_t o_row_stride, float scale, int causal, int dtype, void* stream);
+
 /* The statistics pass of fmc_groupnorm_silu_fwd alone (x read once, nothing written but the sums): partials [N][splits][G][2] fp32 with
  * splits = fmc_groupnorm_partial_splits(HW, C); x2 / C1: two-source channel concat as for fmc_groupnorm_silu_fwd. */
 int fmc_groupnorm_partial_splits(int HW, int C);

@@ -418,6 +418,37 @@ def _spatial_attention_raw(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, he
     return (o, lse) if return_lse else o
 
 
+def attention_ok(head_dim: int) -> bool:
+    return head_dim in (32, 64, 128, 256, 512)
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: Optional[float] = None, causal: bool = False,
+              key_keep: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """softmax(Q K^T scale + mask) V per (batch, head) on `fmc_attention_fwd` (csrc/attn_generic.hip): head widths 32 .. 512 and masked scores -- the VAE
+    mid block's single head of width 512 and CLIP's causal text attention (once per clip, no autograd).  q `[B, Sq, H D]`, k / v
+    `[B, Skv, H D]` (strided views of a fused projection are fine), `key_keep [B, Skv]` bool / uint8 (True = attend) or None."""
+    _dev(q, k, v, key_keep)
+    B, Sq, C = q.shape
+    Bk, Skv, _ = k.shape
+    assert C % heads == 0 and k.shape == v.shape and k.shape[2] == C and Bk == B and k.stride() == v.stride() and q.dtype == k.dtype == v.dtype
+    if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
+        raise NotImplementedError("hip_ops.attention is forward-only (VAE / text encoder are frozen in every FMC stage)")
+    D = C // heads
+    if not _lib.load().fmc_attention_supported(D):
+        raise ValueError(f"hip_ops.attention: head width {D} (supported: 32, 64, 128, 256, 512)")
+    scale = D ** -0.5 if scale is None else scale
+    o = torch.empty(B, Sq, C, dtype=q.dtype, device=q.device)
+    keep = None
+    if key_keep is not None:
+        keep = key_keep.to(torch.uint8).contiguous()
+        assert tuple(keep.shape) == (B, Skv)
+    qb, qr = _rows(q)
+    kb, kr = _rows(k)
+    _lib.check(_lib.load().fmc_attention_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), _p(keep), B, heads, Sq, Skv, D, qb, qr, kb, kr,
+                                             Sq * C, C, float(scale), int(causal), _dt(q), _stream()), "fmc_attention_fwd")
+    return o
+
+
 def _tstrides(t):
     if t.ndim == 4:
         return t.shape[0], t.shape[2], t.shape[1], t.stride(0), t.stride(1), t.stride(2)
@@ -1025,6 +1056,8 @@ def temporal_block(h: torch.Tensor, ln_gamma: torch.Tensor, ln_bpe: torch.Tensor
     assert pose_term is None or (pose_term.shape == h.shape and pose_term.is_contiguous() and pose_term.dtype == h.dtype)
     out = torch.empty_like(h)
     stats = torch.empty(B * F * hw, 2, dtype=torch.float32, device=h.device) if stats_eps is not None else None
+    _log_call("fused_block", ("temporal", B * F * hw, C, w_merge_tm is not None),
+              2.0 * B * F * hw * C * C * (5 if w_merge_tm is not None else 4) + 4.0 * B * F * hw * F * C)
     _lib.check(_lib.load().fmc_temporal_block_bf16(h.data_ptr(), out.data_ptr(), ln_gamma.data_ptr(), ln_bpe.data_ptr(), float(ln_eps), _p(w_merge_tm),
                                                    _p(pose_term), float(merge_scale), w_qkv_packed.data_ptr(), w_out_tm.data_ptr(), _p(b_out),
                                                    _p(stats), float(stats_eps or 0.0), B, F, hw, C, 8, float(scale), _stream()),
@@ -1088,6 +1121,7 @@ def xattn_block(h: torch.Tensor, ln_gamma: torch.Tensor, ln_btab: torch.Tensor, 
     assert C in (320, 640) and C2 == 2 * C and kv.stride(2) == 1 and kv.stride(1) == C2 and N % images_per_text == 0 and N // images_per_text == B
     out = torch.empty_like(h)
     L = _lib.load()
+    _log_call("fused_block", ("xattn", N * hw, C, S), 2.0 * N * hw * C * C * 2 + 4.0 * N * hw * S * C)
     if frag is None:
         frag = xattn_pack_kv(kv)
     assert frag.numel() == B * 8 * (12800 if C == 640 else 7680) and frag.dtype == h.dtype
@@ -1157,6 +1191,7 @@ def geglu_ln_direct(h: torch.Tensor, ln_gamma: torch.Tensor, ln_beta: torch.Tens
     C = h.shape[-1]
     M = h.numel() // C
     out = torch.empty(*h.shape[:-1], cff, dtype=h.dtype, device=h.device)
+    _log_call("geglu_direct", (M, 2 * cff, C), 2.0 * M * 2 * cff * C)
     fn = _lib.load().fmc_geglu640_ln_bf16 if C == 640 else _lib.load().fmc_geglu320_ln_bf16
     _lib.check(fn(h.data_ptr(), out.data_ptr(), ln_gamma.data_ptr(), ln_beta.data_ptr(), float(ln_eps), w_packed.data_ptr(), _p(bias), M, cff, int(blocked),
                   _stream()), "fmc_geglu_ln_bf16")
@@ -1299,6 +1334,7 @@ def vendor_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Te
                                                   min(int(algo), n - 1), ws.data_ptr(), ws.numel(), _stream()), "fmc_vendor_linear_bf16")
     vendor_direct_calls["direct"] += 1
     vendor_direct_calls["with_residual"] += residual is not None
+    _log_call("vendor", (M, N, Kd, bias is not None, residual is not None), 2.0 * M * N * Kd)
     return out
 
 
@@ -1317,6 +1353,7 @@ def linear4_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
         _, ldres = _rows2d(residual)
     if residual2 is not None:
         assert residual is not None and residual2.shape == out.shape and _rows2d(residual2)[1] == ldres
+    _log_call("own_linear", (M, N, Kd, "g4", (residual is not None) + (residual2 is not None)), 2.0 * M * N * Kd)
     _lib.check(_lib.load().fmc_linear4_bf16(x.data_ptr(), weight.data_ptr(), _p(bias), _p(residual), _p(residual2), out.data_ptr(), M, N, Kd, ldx, ldres,
                                             N, float(alpha), _stream()), "fmc_linear4_bf16")
     return out
@@ -1354,6 +1391,7 @@ def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     if residual2 is not None:
         assert residual is not None and residual2.shape == out.shape and _rows2d(residual2)[1] == ldres
     ws, ws_bytes = _splitk_workspace(x.device, split_k, M, N)
+    _log_call("own_linear", (M, N, Kd, "geglu" if geglu else f"t{tile}", (residual is not None) + (residual2 is not None)), 2.0 * M * N * Kd)
     _lib.check(_lib.load().fmc_linear_bf16(x.data_ptr(), weight.data_ptr(), _p(bias), _p(residual), out.data_ptr(), M, N,
                                            Kd, ldx, ldres, n_out, float(alpha), int(geglu), int(tile), int(split_k),
                                            ws, ws_bytes, _p(x2), ldx2, k_split, _p(residual2), _stream()),
@@ -1524,6 +1562,7 @@ def linear_lnc(x: torch.Tensor, weight: torch.Tensor, bias, pend, geglu: bool = 
     out = torch.empty(*x.shape[:-1], n_out, dtype=x.dtype, device=x.device)
     ln_epilogue_calls["consumed"] += 1
     wt = _w_tilemajor(wg) if W_TILEMAJOR else wg
+    _log_call("own_linear", (M, N, Kd, "lnc-geglu" if geglu else "lnc", 0), 2.0 * M * N * Kd)
     _lib.check(_lib.load().fmc_linear_bf16_lnc(x.data_ptr(), wt.data_ptr(), out.data_ptr(), M, N, Kd, ldx, n_out, int(geglu), stats.data_ptr(),
                                                c.data_ptr(), b.data_ptr(), int(W_TILEMAJOR), _stream()), "fmc_linear_bf16_lnc")
     return out
@@ -1543,6 +1582,7 @@ def linear_ln(x: torch.Tensor, weight: torch.Tensor, bias, residual, alpha: floa
     else:
         stats, ln_out = None, torch.empty_like(out)
     wt = _w_tilemajor(weight) if W_TILEMAJOR else weight
+    _log_call("own_linear", (M, N, Kd, "ln", (residual is not None) + (residual2 is not None)), 2.0 * M * N * Kd)
     _lib.check(_lib.load().fmc_linear_bf16_ln(x.data_ptr(), wt.data_ptr(), _p(bias), _p(residual), out.data_ptr(), M, N, Kd, ldx, ldres, N,
                                               float(alpha), _p(residual2), _p(ln_out), ln.gamma.data_ptr(), ln.beta.data_ptr(), float(ln.eps),
                                               _p(ln.pe), int(ln.pe_inner), int(ln.pe_frames), _p(stats), int(W_TILEMAJOR), _stream()),
@@ -1586,6 +1626,7 @@ def geglu_linear_blocked(x: torch.Tensor, weight_il160: torch.Tensor, bias_il160
         _dev(x, weight_il160, bias_il160)
         wt = _w_tilemajor(weight_il160) if W_TILEMAJOR else weight_il160
         args = (wt.data_ptr(), _p(bias_il160), None, out.data_ptr(), M, N, Kd, 0, 1.0, 1, 0, 1, None, None, None, int(W_TILEMAJOR))
+    _log_call("own_linear", (M, N, Kd, "geglu-blocked", 0), 2.0 * M * N * Kd)
     _lib.check(_lib.load().fmc_linear_bf16_ffblk(x.data_ptr(), *args, _stream()), "fmc_linear_bf16_ffblk")
     return out
 
@@ -1597,6 +1638,7 @@ def linear_from_blocked(xb: torch.Tensor, weight: torch.Tensor, bias, residual, 
     M = xb.numel() // Kd
     out = torch.empty(*xb.shape[:-1], N, dtype=xb.dtype, device=xb.device)
     wt = _w_tilemajor(weight) if W_TILEMAJOR else weight
+    _log_call("own_linear", (M, N, Kd, "from-blocked", int(residual is not None)), 2.0 * M * N * Kd)
     _lib.check(_lib.load().fmc_linear_bf16_ffblk(xb.data_ptr(), wt.data_ptr(), _p(bias), _p(residual), out.data_ptr(), M, N, Kd,
                                                  0 if residual is None else N, float(alpha), 0, 1, 0, None, None, None, int(W_TILEMAJOR), _stream()),
                "fmc_linear_bf16_ffblk")
@@ -1613,6 +1655,7 @@ def linear_gn(x: torch.Tensor, weight: torch.Tensor, bias, residual, alpha: floa
     ldres = 0 if residual is None else _rows2d(residual)[1]
     gn_epilogue_calls["emitted"] += 1
     wt = _w_tilemajor(weight) if W_TILEMAJOR else weight
+    _log_call("own_linear", (M, N, Kd, "gn", (residual is not None) + (residual2 is not None)), 2.0 * M * N * Kd)
     _lib.check(_lib.load().fmc_linear_bf16_gn(x.data_ptr(), wt.data_ptr(), _p(bias), _p(residual), out.data_ptr(), M, N, Kd, ldx, ldres, N,
                                               float(alpha), _p(residual2), part.data_ptr(), int(hw), int(W_TILEMAJOR), _stream()), "fmc_linear_bf16_gn")
     out._fmc_gn = (part, N)
@@ -2090,6 +2133,14 @@ dispatch_calls = {k: {"own": 0, "vendor": 0, "ineligible": 0} for k in ("linear"
 call_log = None                     # a list while bench.py records one eager step: (front-end, shape tuple, algorithmic flops) per launch
 
 
+def _log_call(family: str, shape: tuple, flops: float) -> None:
+    """One launch of a GEMM-shaped front-end into `call_log` (bench.py: flops per kernel family of the step, and -- by launch order within a
+    family -- the in-step duration of one SHAPE of a kernel that serves several).  Families: "own_linear" (one gemm* launch of this library),
+    "vendor" (one hipBLASLt launch), "geglu_direct", "fused_block" (temporal / text cross-attention block), "conv_halo", "conv_halo4"."""
+    if call_log is not None:
+        call_log.append((family, tuple(shape), float(flops)))
+
+
 def _pick(key, hip_fn, lib_fn, static_hip: bool, extra_arms=(), k320: bool = False, own_only: bool = False) -> int:
     """0 = vendor library arm, 1..6 = fused gfx950 kernel with that tile geometry (`hip_fn(tile)`)."""
     if not _cache_state["loaded"]:
@@ -2144,6 +2195,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
             y = vendor_linear(xin, weight, bias, residual)         # bias + residual inside the library's epilogue: no elementwise pass behind the GEMM
             return y if residual2 is None else y + residual2
         y = F.linear(xin, weight, bias)
+        _log_call("vendor", (xin.numel() // xin.shape[-1], weight.shape[0], weight.shape[1], bias is not None, False), 2.0 * xin.numel() * weight.shape[0])
         if residual is not None:
             y = torch.add(residual, y, alpha=alpha)
             return y if residual2 is None else y + residual2

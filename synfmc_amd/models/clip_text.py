@@ -15,6 +15,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .. import hip_ops as K
 from .layers import LayerNorm, Linear, linear_op
 
 
@@ -59,14 +60,18 @@ class _SelfAttention(nn.Module):
     def forward(self, x, residual, mask: Optional[torch.Tensor]):
         b, s, d = x.shape
         w, bias = self._fused()
-        qkv = linear_op(x, w, bias).view(b, s, 3, self.heads, d // self.heads)
-        q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))                  # [b, heads, s, dh]
-        if mask is None:
-            o = F.scaled_dot_product_attention(q, k, v, is_causal=True)
-        else:                                                                       # causal AND padding mask (use_attention_mask configs)
-            causal = torch.ones(s, s, dtype=torch.bool, device=x.device).tril()
-            o = F.scaled_dot_product_attention(q, k, v, attn_mask=causal[None, None] & mask[:, None, None, :].bool())
-        o = o.transpose(1, 2).reshape(b, s, d)
+        qkv = linear_op(x, w, bias)                                                  # [b, s, 3 d]: q | k | v
+        if qkv.is_cuda and K.attention_ok(d // self.heads):
+            # causal (+ key-padding, `use_attention_mask` configurations) softmax on `fmc_attention_fwd`, q / k / v read in place from the fused projection
+            o = K.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], self.heads, causal=True, key_keep=None if mask is None else mask.bool())
+        else:
+            q, k, v = (qkv.view(b, s, 3, self.heads, d // self.heads)[:, :, i].transpose(1, 2) for i in range(3))      # [b, heads, s, dh]
+            if mask is None:
+                o = F.scaled_dot_product_attention(q, k, v, is_causal=True)
+            else:                                                                       # causal AND padding mask
+                causal = torch.ones(s, s, dtype=torch.bool, device=x.device).tril()
+                o = F.scaled_dot_product_attention(q, k, v, attn_mask=causal[None, None] & mask[:, None, None, :].bool())
+            o = o.transpose(1, 2).reshape(b, s, d)
         return linear_op(o, self.out_proj.weight, self.out_proj.bias, residual)
 
 

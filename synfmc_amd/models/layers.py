@@ -678,8 +678,8 @@ class BasicTransformerBlock(nn.Module):
         return attn.fused_weights(lora, lora_scale)
 
     def prepare_text(self, text: torch.Tensor, cross_attention_kwargs=None) -> bool:
-        """The per-clip part of this block's text cross-attention -- k | v of the text and their fragment pack -- computed now (the pipelines call
-        this before the denoising loop; a step that finds nothing prepared computes and keeps it itself)."""
+        """The per-clip part of this block's text cross-attention -- k | v of the text and their fragment pack -- computed now (`UNet.prepare_text_conditioning`:
+        the pipelines' eager path and `bench.py` call it before the denoising loop; a step that finds nothing prepared computes and keeps it itself)."""
         from .attention_processor import AttnProcessor, LoRAAttnProcessor
         if self.attn2 is None or type(self.attn2.processor) not in (AttnProcessor, LoRAAttnProcessor) or torch.is_grad_enabled():
             return False

@@ -339,7 +339,9 @@ class UNet3DConditionModel(nn.Module):
         """Per-clip text conditioning: k | v of the text tokens for all 16 cross-attention layers and their MFMA-fragment
         packs, computed ONCE here instead of in every denoising step (the reference re-projects them per step and per frame,
         fmc/models/attention_processor.py:58-59; pipeline_animation_cm_om.py:679-720 passes the same `text_embeddings` to every step).
-        Returns the number of layers prepared.  Optional: a step that finds nothing prepared does the same on its first call."""
+        Returns the number of layers prepared.  `AnimationPipeline._runner` calls it once per clip on the eager path (the graph path prepares during its
+        warm-up calls and refreshes in place); `bench.py` calls it before the timed steps.  A step that finds nothing prepared does the same on its first
+        call.  Validity rests on the text tensor's (address, version) -- see `invalidate_text_conditioning`."""
         from .layers import BasicTransformerBlock
         n = 0
         with torch.no_grad():
@@ -348,6 +350,16 @@ class UNet3DConditionModel(nn.Module):
                 if isinstance(m, BasicTransformerBlock):
                     n += bool(m.prepare_text(text, cross_attention_kwargs))
         return n
+
+    def invalidate_text_conditioning(self) -> None:
+        """Drop every per-clip text product (`Attention.text_kv` entries, the dtype-converted text).  The entries are keyed on (storage address, tensor
+        version): a write that bypasses the version counter -- a text encoder replayed from a HIP graph into a static buffer, `.data` writes, raw kernels --
+        would otherwise be answered with the previous prompt's k | v.  The pipelines call this at the start of every clip, so the cache never outlives
+        the clip it was made for (graph runners keep and refresh their own entries: `_GraphedUNet.set_conditioning`)."""
+        self.__dict__.pop("_text_cast", None)
+        for m in self.modules():
+            if m.__dict__.get("_text_kv") is not None:
+                m.__dict__.pop("_text_kv", None)
 
     def _resnets_with_temb(self):
         rs = getattr(self, "_temb_resnets", None)

@@ -52,8 +52,11 @@ class VaeAttention(nn.Module):
         res = to_tokens(x)                                             # [n, h w, c]
         t = to_tokens(self.group_norm(x))
         q, k, v = self.to_q(t), self.to_k(t), self.to_v(t)
-        o = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None], scale=self.scale)[:, 0]
-        return from_tokens(linear_op(o.contiguous(), self.to_out[0].weight, self.to_out[0].bias, res), h, w)
+        if t.is_cuda and K.attention_ok(c):
+            o = K.attention(q, k, v, 1, self.scale)                    # single head of width c (512 in SD's VAE): `fmc_attention_fwd`
+        else:                                                          # widths outside {32 .. 512}: torch (no such VAE ships with FMC)
+            o = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None], scale=self.scale)[:, 0].contiguous()
+        return from_tokens(linear_op(o, self.to_out[0].weight, self.to_out[0].bias, res), h, w)
 
 
 class _MidBlock(nn.Module):

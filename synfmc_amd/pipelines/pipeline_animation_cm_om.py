@@ -228,6 +228,8 @@ class AnimationPipeline:
         if eta != 0.0:
             raise NotImplementedError("eta > 0 is never used by FMC")
         unet = self.unet
+        if hasattr(unet, "invalidate_text_conditioning"):
+            unet.invalidate_text_conditioning()     # a new clip: no text k | v of the previous prompt survives (they are re-made once below / by the runner)
         height = height or unet.config.sample_size * self.vae_scale_factor
         width = width or unet.config.sample_size * self.vae_scale_factor
         self.check_inputs(prompt, height, width, callback_steps)
@@ -255,6 +257,8 @@ class AnimationPipeline:
         shared = bool(getattr(self, "_cfg_shared", False)) and getattr(unet, "_accepts_cfg_shared_input", False)   # (a foreign U-Net never sees the keyword)
         skw = {"cfg_shared_input": True} if shared else {}
         if not use_graph:
+            if hasattr(unet, "prepare_text_conditioning") and not torch.is_grad_enabled():
+                unet.prepare_text_conditioning(text)     # once per clip, before the loop -- not inside step 1
             def eager(x, t):
                 kw = {}
                 if pose_feats is not None:

@@ -2071,3 +2071,56 @@ def test_linear4_small_m_projection(K, M, N, Kd, extras):
     if M % 2 == 0:                                                       # rows of a wider matrix (a column slice: ldx > K)
         wide = torch.cat([xd, xd.flip(0)], dim=1)
         assert torch.equal(K.linear4_bf16(wide[:, :Kd], wd, bd, rd, alpha, r2d), got)
+
+
+# ---- f4: attention either side of the loop (csrc/attn_generic.hip) -----------------------------------------------------------------------------------
+@torch.no_grad()
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1.5e-2)])
+@pytest.mark.parametrize("B,H,Sq,Skv,D,causal,keep", [
+    (2, 1, 300, 300, 512, False, False),       # the VAE mid block: one head of width 512, a ragged last query / key block
+    (1, 1, 2560, 2560, 512, False, False),     # ... at the 40x64 latent of the benchmarked clip
+    (3, 1, 384, 384, 128, False, False),       # the reduced VAE of the model tests
+    (2, 12, 77, 77, 64, True, False),          # CLIP-L text self-attention: causal
+    (4, 12, 77, 77, 64, True, True),           # ... with a key-padding mask (`use_attention_mask` configurations)
+    (2, 2, 70, 130, 32, False, True),          # cross shapes, narrow heads, keys masked
+    (1, 3, 200, 200, 256, True, False),
+])
+def test_attention_generic_against_exact_softmax(K, dtype, tol, B, H, Sq, Skv, D, causal, keep):
+    """`fmc_attention_fwd`: softmax(q k^T scale + mask) v for head widths up to 512 with causal / key-padding masks, against the same arithmetic in fp64 on
+    the same (rounded) inputs; q | k | v are slices of ONE fused projection (strided rows), as the text encoder issues them."""
+    C = H * D
+    g = torch.Generator().manual_seed(4100 + Sq + D)
+    qkv = (torch.randn(B, max(Sq, Skv), 3 * C, generator=g) * 1.5).to(dtype)
+    qd = qkv.cuda()
+    q, k, v = qd[:, :Sq, :C], qd[:, :Skv, C:2 * C], qd[:, :Skv, 2 * C:]
+    kk = None
+    if keep:
+        kk = torch.rand(B, Skv, generator=g) > 0.3
+        kk[:, 0] = True                                                  # (every causal row keeps at least key 0)
+    got = K.attention(q, k, v, H, causal=causal, key_keep=None if kk is None else kk.cuda())
+    q64, k64, v64 = (t.double().cpu().view(B, -1, H, D).transpose(1, 2) for t in (q, k, v))
+    s = q64 @ k64.transpose(-1, -2) * D ** -0.5
+    mask = torch.ones(Sq, Skv, dtype=torch.bool)
+    if causal:
+        mask = mask.tril()
+    mask = mask[None, None].expand(B, 1, Sq, Skv)
+    if kk is not None:
+        mask = mask & kk[:, None, None, :]
+    p = s.masked_fill(~mask, float("-inf")).softmax(-1)
+    want = (p @ v64).transpose(1, 2).reshape(B, Sq, C)
+    assert got.shape == (B, Sq, C) and got.dtype == dtype
+    err = rel_inf(got, want)
+    assert err < tol, f"attention {(B, H, Sq, Skv, D, causal, keep)} {dtype}: rel-inf {err:.3e}"
+    # element-wise too: a wrong tile cannot hide under the maximum (outputs are convex combinations of v rows)
+    bound = (2.0 ** -7 if dtype == torch.bfloat16 else 1e-5) * v64.abs().amax(dim=(1, 2, 3)).view(B, 1, 1) * 1.5
+    assert bool(((got.double().cpu() - want).abs() <= bound).all())
+
+
+def test_attention_generic_refuses_what_it_does_not_take(K):
+    q = torch.randn(1, 16, 80, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(ValueError):
+        K.attention(q, q, q, 2)                                          # head width 40: the hot-path kernels' shape, not this one's
+    with pytest.raises(NotImplementedError):
+        with torch.enable_grad():
+            qg = torch.randn(1, 16, 64, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+            K.attention(qg, qg, qg, 1)
