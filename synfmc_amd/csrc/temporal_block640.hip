@@ -520,6 +520,9 @@ __device__ __forceinline__ float t6_gelu_erf(float g) {       // Abramowitz & St
     return 0.5f * g + 0.5f * fabsf(g) * e;
 }
 
+#ifndef FMC_GEGLU320_ROWS160_DEFAULT
+#define FMC_GEGLU320_ROWS160_DEFAULT 0
+#endif
 struct G6Params {
     const bf16_t* h; bf16_t* out;                          // h [M][640]; out [M][Cff] row-major
     const float* ln_gamma; const float* ln_beta; float ln_eps;
@@ -531,12 +534,18 @@ struct G6Params {
 
 // GC_ = 640 (8 waves, one tile per CU) | 320 (4 waves, 80 KiB: two workgroups per CU).  RH = 2 (GC_ = 320 only, round 5): ONE workgroup of 8 waves owns 160
 // rows -- wave w and wave w + 4 run the same columns on the two 80-row halves in step (the per-chunk barriers keep them together), so the two requests for every
-// weight fragment reach the CU's vector cache together instead of from two unrelated workgroups
-template <int GC_, int RH = 1>
-__global__ __launch_bounds__(GC_ / 80 * 64 * RH, 2)
+// weight fragment reach the CU's vector cache together instead of from two unrelated workgroups.
+// SEQ (RH = 2, round 6): 4 waves own the 160 rows -- a wave runs BOTH 80-row halves against every weight fragment it loads (two accumulator sets, 200
+// registers, one wave per SIMD).  What bounds the 80-row forms is the CU's vector-memory path, not L2: a k-step is 5 one-KiB fragment loads per wave = 16
+// cycles each at 64 B / clk, 8 waves x 5 x 16 = 640 cycles per 800 cycles of MFMA (2 waves per SIMD x 25 MFMAs x 16), whether the fragments hit L1 (RH = 2
+// without SEQ: same instruction count, measured no gain) or not.  Reusing a loaded fragment for twice the rows halves that: 4 x 5 x 16 = 320 per 800.
+template <int GC_, int RH = 1, bool SEQ = false>
+__global__ __launch_bounds__(GC_ / 80 * 64 * (SEQ ? 1 : RH), SEQ ? 1 : 2)
 void geglu_direct_kernel(const G6Params P) {
-    constexpr int C = GC_, NW = C / 80, NT = 64 * NW * RH, ROWS = T6_ROWS * RH, CPR = C / 8, KS = C / 32, GCOLS = 40 * NW, LPR = CPR / 10, WAVE_W = KS * 5 * 512;
+    constexpr int RS = SEQ ? RH : 1;                             // 80-row halves a wave runs per loaded weight fragment
+    constexpr int C = GC_, NW = C / 80, NT = 64 * NW * (SEQ ? 1 : RH), ROWS = T6_ROWS * RH, CPR = C / 8, KS = C / 32, GCOLS = 40 * NW, LPR = CPR / 10, WAVE_W = KS * 5 * 512;
     constexpr int NRG = NT / CPR;                                // row groups of the in-place normalisation pass
+    constexpr int NWV = NT / 64;                                 // waves of the workgroup
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* X = reinterpret_cast<bf16_t*>(smem_raw);             // [80][640], chunk c of row r at chunk c ^ ((r >> 1) & 7)
     bf16_t* S = X + ROWS * C;                                    // staging [ROWS][GCOLS + 8]; phase A: (mean, rstd) x ROWS rows
@@ -544,15 +553,15 @@ void geglu_direct_kernel(const G6Params P) {
     constexpr int SP = GCOLS + 8;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave = wave_all % NW, rh = wave_all / NW;          // my column group / my 80-row half
+    const int wave = wave_all % NW, rh = SEQ ? 0 : wave_all / NW;   // my column group / my (first) 80-row half
     const int l15 = lane & 15, kq = lane >> 4;
     const int xsw = (l15 >> 1) & 7;
     const int64_t m0 = (int64_t)blockIdx.x * ROWS;
     const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)P.h, 0, (int)(P.M * C * 2), 0x00020000);
     // ---- phase A: rows -> X, LayerNorm in place ----
 #pragma unroll
-    for (int j = 0; j < 13; ++j) {
-        const int q = wave_all + NW * RH * j;
+    for (int j = 0; j < (ROWS * CPR / 64 + NWV - 1) / NWV; ++j) {
+        const int q = wave_all + NWV * j;
         if (q < ROWS * CPR / 64) {
             const int idx = 64 * q + lane, r = idx / CPR, pc = idx - r * CPR, c = pc ^ ((r >> 1) & 7);
             t6_dma(rsH, (unsigned)(((m0 + r) * C + c * 8) * 2), X + 64 * q * 8);
@@ -608,7 +617,7 @@ void geglu_direct_kernel(const G6Params P) {
     }
     __syncthreads();                                              // X = LayerNorm(h); the staging region is free
 
-    f32x4 acc[5][5];
+    f32x4 acc[RS][5][5];
     const int nchunks = P.cff / GCOLS;
     // one descriptor over the whole packed weight; the chunk's first two k-steps are requested BEFORE the previous chunk's gating / staging / stores
     // (the fragment registers are idle there: requested at the head of a chunk their L2 round trip was exposed once per chunk)
@@ -630,9 +639,11 @@ void geglu_direct_kernel(const G6Params P) {
 #pragma unroll 1
     for (int ch = 0; ch < nchunks; ++ch) {
 #pragma unroll
-        for (int a = 0; a < 5; ++a)
+        for (int s = 0; s < RS; ++s)
 #pragma unroll
-            for (int b = 0; b < 5; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int a = 0; a < 5; ++a)
+#pragma unroll
+                for (int b = 0; b < 5; ++b) acc[s][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
         auto step = [&](auto gc) {
             constexpr int g = decltype(gc)::value;
             if constexpr (g + 2 < KS) load_w(g + 2);
@@ -640,22 +651,24 @@ void geglu_direct_kernel(const G6Params P) {
             asm volatile("" : "+v"(kqx), "+v"(xrow_o));
             const int xo = xrow_o + ((g >> 1) * 8 + (((g & 1) * 4) ^ kqx)) * 8;
             __builtin_amdgcn_sched_barrier(0);
+            // the RS * 5 row blocks of my halves as one sequence (block i = half i / 5, block i % 5: X rows 16 i ..), fragments two blocks ahead
+            constexpr int NB_ = 5 * RS;
             u32x4 af3[3];
             af3[0] = *reinterpret_cast<const u32x4*>(X + 0 * 16 * C + xo);
             af3[1] = *reinterpret_cast<const u32x4*>(X + 1 * 16 * C + xo);
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
-            for (int mb = 0; mb < 5; ++mb) {
-                if (mb + 2 < 5) af3[(mb + 2) % 3] = *reinterpret_cast<const u32x4*>(X + (mb + 2) * 16 * C + xo);
+            for (int mb = 0; mb < NB_; ++mb) {
+                if (mb + 2 < NB_) af3[(mb + 2) % 3] = *reinterpret_cast<const u32x4*>(X + (mb + 2) * 16 * C + xo);
                 union { bf16x8 v; u32x4 u; } a;
                 a.u = af3[mb % 3];
 #pragma unroll
                 for (int nb = 0; nb < 5; ++nb) {
                     union { bf16x8 v; u32x4 u; } w;
                     w.u = wfr[g % 3][nb];
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, a.v, acc[mb][nb], 0, 0, 0);
+                    acc[mb / 5][mb % 5][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, a.v, acc[mb / 5][mb % 5][nb], 0, 0, 0);
                 }
-                if (mb + 2 < 5) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (mb + 2 < NB_) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
             }
         };
@@ -687,37 +700,40 @@ void geglu_direct_kernel(const G6Params P) {
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
+        for (int s = 0; s < RS; ++s)
+#pragma unroll
         for (int mb = 0; mb < 5; ++mb) {
-            bf16_t* Sr = S + (rh * T6_ROWS + mb * 16 + l15) * SP + wave * 40;
+            bf16_t* Sr = S + ((rh + s) * T6_ROWS + mb * 16 + l15) * SP + wave * 40;
 #pragma unroll
             for (int p = 0; p < 2; ++p) {                          // blocks (0, 3) and (1, 4): value and gate in the same lane
                 float o[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (acc[mb][p][j] + bv[p][j]) * t6_gelu_erf(acc[mb][3 + p][j] + bg[p][j]);
+                for (int j = 0; j < 4; ++j) o[j] = (acc[s][mb][p][j] + bv[p][j]) * t6_gelu_erf(acc[s][mb][3 + p][j] + bg[p][j]);
                 *reinterpret_cast<u32x2*>(Sr + 16 * p + 4 * kq) = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
             }
             {                                                     // block 2: lanes kq < 2 hold value columns 32 + 4 kq .., lanes kq >= 2 their gates
                 float o[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const unsigned own = __float_as_uint(acc[mb][2][j]);
+                    const unsigned own = __float_as_uint(acc[s][mb][2][j]);
                     const auto sw = __builtin_amdgcn_permlane32_swap(own, own, false, false);
                     const float gate = __uint_as_float((unsigned)sw[1]);          // (lanes 0-31 see lane + 32's value)
-                    o[j] = (acc[mb][2][j] + bv[2][j]) * t6_gelu_erf(gate + bg[2][j]);
+                    o[j] = (acc[s][mb][2][j] + bv[2][j]) * t6_gelu_erf(gate + bg[2][j]);
                 }
                 if (kq < 2) *reinterpret_cast<u32x2*>(Sr + 32 + 4 * kq) = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
             }
         }
         __syncthreads();
-        // ---- whole-row stores: 80 rows x GCOLS / 8 sixteen-byte chunks = 6.25 per thread ----
+        // ---- whole-row stores: ROWS rows x GCOLS / 8 sixteen-byte chunks = 6.25 per thread (12.5 with SEQ) ----
         // (the per-thread row / column of the seven stores recomputed from an opaque copy of tid in every chunk: visible as loop invariants, hipcc
         //  hoists the seven 64-bit row offsets out of the chunk loop, spills them -- 20 VGPRs -- and reloads each behind its own s_waitcnt vmcnt(0))
         int tq = tid;
         asm volatile("" : "+v"(tq));
+        constexpr int NCH = ROWS * (GCOLS / 8), NIT = (NCH + NT - 1) / NT;
 #pragma unroll
-        for (int it = 0; it < 7; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             const int c = tq + NT * it;
-            if (it < 6 || tid < NT / 4) {
+            if (it < NIT - 1 || c < NCH) {
                 const int r = c / (GCOLS / 8), cc = c - r * (GCOLS / 8);
                 const int64_t m = m0 + r;
                 const int col = ch * GCOLS + cc * 8;
@@ -876,12 +892,15 @@ extern "C" int fmc_geglu320_ln_bf16(const void* h, void* out, const float* ln_ga
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&geglu_direct_kernel<320>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&geglu_direct_kernel<320, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&geglu_direct_kernel<320, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * lds);
         raised = true;
     }
-    // A/B switch, default off: measured 215 - 225 us either way on 81920 x 2560 x 320 (gpurun_out/r05n/geglu_ab.txt) -- pairing the two 80-row halves in one
-    // workgroup does not reduce what bounds this launch, so the weight stream's L2 -> CU traffic is not it
-    static const int rows160 = [] { const char* e = getenv("FMC_GEGLU320_ROWS160"); return e ? atoi(e) : 0; }();
-    if (rows160 && M % 160 == 0) hipLaunchKernelGGL((geglu_direct_kernel<320, 2>), dim3((unsigned)(M / 160)), dim3(512), 2 * lds, (hipStream_t)stream, P);
+    // FMC_GEGLU320_ROWS160: 0 = 80-row workgroups of 4 waves, two per CU; 1 = 160 rows on 8 waves (round 5 A/B: 215 - 225 us either way on 81920 x 2560 x 320,
+    // gpurun_out/r05n/geglu_ab.txt -- pairing the halves in one workgroup leaves every wave's fragment loads in place); 2 = 160 rows on 4 waves, each weight
+    // fragment used for both halves (SEQ, round 6)
+    static const int rows160 = [] { const char* e = getenv("FMC_GEGLU320_ROWS160"); return e ? atoi(e) : FMC_GEGLU320_ROWS160_DEFAULT; }();
+    if (rows160 == 2 && M % 160 == 0) hipLaunchKernelGGL((geglu_direct_kernel<320, 2, true>), dim3((unsigned)(M / 160)), dim3(256), 2 * lds, (hipStream_t)stream, P);
+    else if (rows160 == 1 && M % 160 == 0) hipLaunchKernelGGL((geglu_direct_kernel<320, 2>), dim3((unsigned)(M / 160)), dim3(512), 2 * lds, (hipStream_t)stream, P);
     else hipLaunchKernelGGL(geglu_direct_kernel<320>, dim3((unsigned)(M / 80)), dim3(256), lds, (hipStream_t)stream, P);
     FMC_CHECK_LAUNCH("fmc_geglu320_ln_bf16");
     return 0;

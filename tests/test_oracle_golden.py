@@ -201,3 +201,19 @@ def test_g5_full_width_oracle_matches_reference_code(golden_dir):
                  traj_features=traj).sample
     ref = torch.from_numpy(g["out"])
     assert float((out - ref).abs().max() / ref.abs().max()) < 1e-5
+
+
+def test_g7_bf16_format_fixture_is_consistent_with_g7(golden_dir):
+    """`g7_bf16_format.npz` (the oracle of BASELINE configs[1] / configs[2] with every layer output and weight rounded to bf16) belongs to the G7 case: same
+    seeds / clip / timestep, same shapes, and the stored format errors are the distances of its tensors from G7's reference outputs."""
+    import numpy as np
+    g7 = np.load(os.path.join(golden_dir, "g7_lora_cam_steps.npz"))
+    gb = np.load(os.path.join(golden_dir, "g7_bf16_format.npz"))
+    for k in ("lora_seed", "cam_seed", "clip_seed", "uncond_seed", "t"):
+        assert int(g7[k]) == int(gb[k])
+    assert tuple(g7["hw"]) == tuple(gb["hw"])
+    for name in ("lora", "cam"):
+        ref, r16 = g7[f"{name}_eps"].astype(np.float64), gb[f"{name}_eps_bf16_rounded_oracle"].astype(np.float64)
+        assert ref.shape == r16.shape == (2, 4, 16, 40, 64)
+        fmt = np.abs(r16 - ref).max() / np.abs(ref).max()
+        assert abs(fmt - float(gb[f"{name}_bf16_format_err"])) < 1e-6 and 5e-3 < fmt < 4e-2
