@@ -1362,6 +1362,35 @@ def main():
         assert text_kv_in_loop == 0, f"{text_kv_in_loop} text k | v projections ran inside the timed steps"
         assert torch.isfinite(latents).all(), "non-finite latents"
 
+        call_log, dispatch = [], None
+        if rank == 0 and not args.trace_child:
+            # one EAGER step of exactly what the graph replays (right behind the timed steps: the 50-step pipeline below installs its own per-clip
+            # caches on the modules): which front-end calls went to an own kernel / the vendor arm / fell through as ineligible, and the order and
+            # shapes of every GEMM-shaped launch (to assign the in-step trace's launches to shapes)
+            K.call_log = []
+            d0 = {k: dict(v) for k, v in K.dispatch_calls.items()}
+            calls0 = {k: c for k, _, _, c in K.autotune_report()}
+            if args.no_graph:
+                unet_step(torch.cat([latents, latents]).to(dtype), ts[0])
+            else:
+                runner._call()
+            torch.cuda.synchronize()
+            call_log, K.call_log = K.call_log, None
+            if os.environ.get("FMC_BENCH_SHAPES"):
+                # per-shape view of the step's autotuned front-end calls (GEMM / conv arms): calls per step, chosen arm, the tuner's own isolated time for it and
+                # for the vendor arm -- where the step's GEMM time sits, shape by shape (a side file, not part of the JSON line)
+                rows = []
+                for k, arm, ms_, c in K.autotune_report():
+                    n = c - calls0.get(k, 0)
+                    if n > 0:
+                        rows.append({"shape": list(k), "calls_per_step": n, "arm": arm, "ms_arm": ms_.get(arm), "ms_vendor": ms_.get(0),
+                                     "ms_per_step": None if ms_.get(arm) is None else round(n * ms_[arm], 4)})
+                rows.sort(key=lambda r: -(r["ms_per_step"] or 0))
+                with open(os.environ["FMC_BENCH_SHAPES"], "w") as f:
+                    for r in rows:
+                        f.write(json.dumps(r) + "\n")
+            dispatch = {k: {a: K.dispatch_calls[k][a] - d0[k][a] for a in v} for k, v in K.dispatch_calls.items()}
+
         loop50_s = None
         if rank == 0 and not args.trace_child and not args.no_loop50:
             # the metric as the reference runs it: the configuration's own pipeline end to end -- `CameraObjCtrlPipeline.__call__`
@@ -1395,32 +1424,6 @@ def main():
         return
     if rank == 0:
         bf = dtype == torch.bfloat16
-        # one EAGER step of exactly what the graph replays: which front-end calls went to an own kernel / the vendor arm / fell through as
-        # ineligible, and the order and shapes of the halo convolutions (to assign the in-step trace's launches to shapes)
-        K.call_log = []
-        d0 = {k: dict(v) for k, v in K.dispatch_calls.items()}
-        calls0 = {k: c for k, _, _, c in K.autotune_report()}
-        with torch.no_grad():
-            if args.no_graph:
-                unet_step(torch.cat([latents, latents]).to(dtype), ts[0])
-            else:
-                runner._call()
-        torch.cuda.synchronize()
-        call_log, K.call_log = K.call_log, None
-        if os.environ.get("FMC_BENCH_SHAPES"):
-            # per-shape view of the step's autotuned front-end calls (GEMM / conv arms): calls per step, chosen arm, the tuner's own isolated time for it and
-            # for the vendor arm -- where the step's GEMM time sits, shape by shape (a side file, not part of the JSON line)
-            rows = []
-            for k, arm, ms, c in K.autotune_report():
-                n = c - calls0.get(k, 0)
-                if n > 0:
-                    rows.append({"shape": list(k), "calls_per_step": n, "arm": arm, "ms_arm": ms.get(arm), "ms_vendor": ms.get(0),
-                                 "ms_per_step": None if ms.get(arm) is None else round(n * ms[arm], 4)})
-            rows.sort(key=lambda r: -(r["ms_per_step"] or 0))
-            with open(os.environ["FMC_BENCH_SHAPES"], "w") as f:
-                for r in rows:
-                    f.write(json.dumps(r) + "\n")
-        dispatch = {k: {a: K.dispatch_calls[k][a] - d0[k][a] for a in v} for k, v in K.dispatch_calls.items()}
         if getattr(args, "torch_profile", None):
             with torch.no_grad():
                 torch_op_sites((lambda: unet_step(torch.cat([latents, latents]).to(dtype), ts[0])) if args.no_graph else runner._call, args.torch_profile)

@@ -368,6 +368,19 @@ int fmc_attention_fwd(const void* q, const void* k, const void* v, void* o, cons
                       int64_t q_batch_stride, int64_t q_row_stride, int64_t kv_batch_stride, int64_t kv_row_stride, int64_t o_batch_stride,
                       int64_t o_row_stride, float scale, int causal, int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * LayerNorm + GEGLU projection with the gate software-pipelined under the matrix work (csrc/geglu_pipe.hip, round 6): diffusers FeedForward's
+ * `GEGLU(norm(h))` (fmc/models/motion_module.py:295-299; BasicTransformerBlock.norm3 / ff) at C = 320 | 640 -- same function as fmc_geglu320_ln_bf16 /
+ * fmc_geglu640_ln_bf16: out [M, cff] = (n W_v^T + b_v) * gelu(n W_g^T + b_g), n = LayerNorm(h).  One wave per SIMD keeps two accumulator sets and gates
+ * chunk c - 1 in the shadow of chunk c's MFMAs; no staging tile, no barrier after the LayerNorm.  variant 0: 80-row tiles, 4 waves x 32 gated columns
+ * (C = 320 | 640, M % 80 == 0); variant 1: 160-row tiles, 8 waves x 16 gated columns (C = 320, M % 160 == 0: every weight fragment serves twice the rows).
+ * w_packed: `hip_ops.pack_geglu_frag(w, G)`, G = 32 (variant 0) | 16 (variant 1): [cff / G column groups][C / 32 k-steps][G / 8 blocks: value blocks, then gate
+ * blocks][lane][8]; bias [2 cff] (value | gate) or NULL; cff % 128 == 0; out_blocked: tile-major [M / 160][cff / 32][160][32] (the operand layout of the
+ * feed-forward's second GEMM; M % 160 == 0). */
+int fmc_geglu_pipe_supported(int64_t M, int cff, int C, int variant);
+int fmc_geglu_pipe_ln_bf16(const void* h, void* out, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* w_packed, const void* bias,
+                           int64_t M, int cff, int C, int out_blocked, int variant, void* stream);
+
 /* The statistics pass of fmc_groupnorm_silu_fwd alone (x read once, nothing written but the sums): partials [N][splits][G][2] fp32 with
  * splits = fmc_groupnorm_partial_splits(HW, C); x2 / C1: two-source channel concat as for fmc_groupnorm_silu_fwd. */
 int fmc_groupnorm_partial_splits(int HW, int C);

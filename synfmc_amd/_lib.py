@@ -75,6 +75,8 @@ SIGNATURES = {
     "fmc_vendor_linear_candidates": (c_int, [c_int64, c_int, c_int, c_int64, c_int64, c_int64, c_int, c_int]),
     "fmc_vendor_linear_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_int64, c_int, c_void_p,
                                        c_int64, c_void_p]),
+    "fmc_geglu_pipe_supported": (c_int, [c_int64, c_int, c_int, c_int]),
+    "fmc_geglu_pipe_ln_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "fmc_attention_supported": (c_int, [c_int]),
     "fmc_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64,
                                   c_int64, c_int64, c_float, c_int, c_int, c_void_p]),

@@ -520,6 +520,37 @@ __device__ __forceinline__ float t6_gelu_erf(float g) {       // Abramowitz & St
     return 0.5f * g + 0.5f * fabsf(g) * e;
 }
 
+// G6_KNOCK (diagnostic builds, tools/scratch/r06/knock.sh; results are wrong by construction): bit 0 = no weight-fragment loads inside the loop, bit 1 = no
+// A-fragment LDS reads, bit 2 = no gate / staging / stores (one dummy store keeps the accumulators alive)
+#ifndef G6_KNOCK
+#define G6_KNOCK 0
+#endif
+// G6_AF2 = 1: the A fragments of k-step g + 1 are read during k-step g into a second register set (20 VGPRs more) instead of two row blocks ahead inside the
+// step -- the knock-out builds above put the fragment reads at 85 of the launch's 208 us although the LDS array is ~20 % busy: their latency, not their bandwidth
+// G6_STAMP = 1 (diagnostic): wave 0 of workgroups 0 and 300 writes s_memtime stamps of its first 4 chunks over the head of `out` (results destroyed)
+#ifndef G6_STAMP
+#define G6_STAMP 0
+#endif
+#define G6_T(i)                                                                                                          \
+    do {                                                                                                                 \
+        if (G6_STAMP && tid == 0 && ch < 4 && (blockIdx.x == 0 || blockIdx.x == 300))                                    \
+            reinterpret_cast<long long*>(P.out)[(blockIdx.x ? 64 : 0) + ch * 8 + (i)] = (long long)__builtin_readcyclecounter(); \
+    } while (0)
+// A/B switches of round 6 (see NOTEBOOK.md): G6_PRIO = the gate / staging phase at s_setprio 1 (its VALU wins the arbitration against the co-resident
+// workgroup's main loop); G6_STAGGER = every second round of workgroups starts ~8000 cycles late (de-phases the two workgroups of a CU: one gates while
+// the other multiplies); G6_BIASPF = the next chunk's bias words are requested before the main loop instead of behind it
+#ifndef G6_PRIO
+#define G6_PRIO 0
+#endif
+#ifndef G6_STAGGER
+#define G6_STAGGER 0
+#endif
+#ifndef G6_BIASPF
+#define G6_BIASPF 0
+#endif
+#ifndef G6_AF2
+#define G6_AF2 0
+#endif
 #ifndef FMC_GEGLU320_ROWS160_DEFAULT
 #define FMC_GEGLU320_ROWS160_DEFAULT 0
 #endif
@@ -558,6 +589,10 @@ void geglu_direct_kernel(const G6Params P) {
     const int xsw = (l15 >> 1) & 7;
     const int64_t m0 = (int64_t)blockIdx.x * ROWS;
     const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)P.h, 0, (int)(P.M * C * 2), 0x00020000);
+    if (G6_STAGGER && ((blockIdx.x >> 8) & 1)) {
+#pragma unroll
+        for (int i = 0; i < G6_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     // ---- phase A: rows -> X, LayerNorm in place ----
 #pragma unroll
     for (int j = 0; j < (ROWS * CPR / 64 + NWV - 1) / NWV; ++j) {
@@ -636,8 +671,27 @@ void geglu_direct_kernel(const G6Params P) {
     wl = chunk_base(0);
     load_w(0);
     load_w(1);
+    if constexpr (G6_KNOCK & 1) load_w(2);                        // (diagnostic: every fragment register defined)
+    u32x4 afb[2][G6_AF2 ? 5 * RS : 1];
+    if constexpr (G6_AF2) {
+        int kqx = kq ^ xsw, xrow_o = (rh * T6_ROWS + l15) * C;
+        asm volatile("" : "+v"(kqx), "+v"(xrow_o));
+#pragma unroll
+        for (int mb = 0; mb < 5 * RS; ++mb) afb[0][mb] = *reinterpret_cast<const u32x4*>(X + mb * 16 * C + xrow_o + kqx * 8);
+    }
 #pragma unroll 1
     for (int ch = 0; ch < nchunks; ++ch) {
+        G6_T(0);
+        u32x2 bpf[2][3];
+        if constexpr (G6_BIASPF) {                                 // this chunk's bias words: in flight under the main loop (12 registers)
+            const int gcp = ch * GCOLS + wave * 40;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const int c0 = gcp + 16 * p + 4 * (p == 2 ? (kq & 1) : kq);
+                bpf[0][p] = P.bias ? *reinterpret_cast<const u32x2*>(P.bias + c0) : u32x2{0u, 0u};
+                bpf[1][p] = P.bias ? *reinterpret_cast<const u32x2*>(P.bias + P.cff + c0) : u32x2{0u, 0u};
+            }
+        }
 #pragma unroll
         for (int s = 0; s < RS; ++s)
 #pragma unroll
@@ -646,19 +700,45 @@ void geglu_direct_kernel(const G6Params P) {
                 for (int b = 0; b < 5; ++b) acc[s][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
         auto step = [&](auto gc) {
             constexpr int g = decltype(gc)::value;
-            if constexpr (g + 2 < KS) load_w(g + 2);
+            if constexpr (g + 2 < KS && !(G6_KNOCK & 1)) load_w(g + 2);
             int kqx = kq ^ xsw, xrow_o = (rh * T6_ROWS + l15) * C;
             asm volatile("" : "+v"(kqx), "+v"(xrow_o));
-            const int xo = xrow_o + ((g >> 1) * 8 + (((g & 1) * 4) ^ kqx)) * 8;
+            const int xo = (G6_KNOCK & 2) ? 0 : xrow_o + ((g >> 1) * 8 + (((g & 1) * 4) ^ kqx)) * 8;
             __builtin_amdgcn_sched_barrier(0);
             // the RS * 5 row blocks of my halves as one sequence (block i = half i / 5, block i % 5: X rows 16 i ..), fragments two blocks ahead
             constexpr int NB_ = 5 * RS;
+            if constexpr (G6_AF2) {
+                // this k-step's fragments are in afb[g & 1] (read during the previous step / chunk); read the NEXT step's (k-step 0 of the next chunk behind
+                // the last one: X is the same for every chunk) into the other set, one read in front of each block's MFMAs
+                constexpr int gn = (g + 1) % KS;
+                const int xn = xrow_o + ((gn >> 1) * 8 + (((gn & 1) * 4) ^ kqx)) * 8;
+#pragma unroll
+                for (int mb = 0; mb < NB_; ++mb) {
+                    afb[(g + 1) & 1][mb] = *reinterpret_cast<const u32x4*>(X + mb * 16 * C + xn);
+                    union { bf16x8 v; u32x4 u; } a;
+                    a.u = afb[g & 1][mb];
+#pragma unroll
+                    for (int nb = 0; nb < 5; ++nb) {
+                        union { bf16x8 v; u32x4 u; } w;
+                        w.u = wfr[g % 3][nb];
+                        acc[mb / 5][mb % 5][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, a.v, acc[mb / 5][mb % 5][nb], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+                }
+                return;
+            }
             u32x4 af3[3];
-            af3[0] = *reinterpret_cast<const u32x4*>(X + 0 * 16 * C + xo);
-            af3[1] = *reinterpret_cast<const u32x4*>(X + 1 * 16 * C + xo);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            if constexpr (G6_KNOCK & 2) {
+                af3[0] = af3[1] = af3[2] = u32x4{(unsigned)xo + 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+            } else {
+                af3[0] = *reinterpret_cast<const u32x4*>(X + 0 * 16 * C + xo);
+                af3[1] = *reinterpret_cast<const u32x4*>(X + 1 * 16 * C + xo);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
 #pragma unroll
             for (int mb = 0; mb < NB_; ++mb) {
+                if constexpr (!(G6_KNOCK & 2))
                 if (mb + 2 < NB_) af3[(mb + 2) % 3] = *reinterpret_cast<const u32x4*>(X + (mb + 2) * 16 * C + xo);
                 union { bf16x8 v; u32x4 u; } a;
                 a.u = af3[mb % 3];
@@ -668,7 +748,7 @@ void geglu_direct_kernel(const G6Params P) {
                     w.u = wfr[g % 3][nb];
                     acc[mb / 5][mb % 5][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, a.v, acc[mb / 5][mb % 5][nb], 0, 0, 0);
                 }
-                if (mb + 2 < NB_) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (!(G6_KNOCK & 2) && mb + 2 < NB_) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
             }
         };
@@ -677,6 +757,23 @@ void geglu_direct_kernel(const G6Params P) {
         if constexpr (KS == 20) { G6_G(10); G6_G(11); G6_G(12); G6_G(13); G6_G(14); G6_G(15); G6_G(16); G6_G(17); G6_G(18); G6_G(19); }
 #undef G6_G
         T6_SETTLE();
+        G6_T(1);
+        if constexpr (G6_KNOCK & 4) {
+            float keep = 0.f;
+#pragma unroll
+            for (int s_ = 0; s_ < RS; ++s_)
+#pragma unroll
+                for (int a = 0; a < 5; ++a)
+#pragma unroll
+                    for (int b = 0; b < 5; ++b) keep += acc[s_][a][b][0] + acc[s_][a][b][1] + acc[s_][a][b][2] + acc[s_][a][b][3];
+            if (keep == 12345.678f) P.out[tid] = (bf16_t)1;
+            if (ch + 1 < nchunks) {
+                wl = chunk_base(ch + 1);
+                load_w(0);
+                load_w(1);
+            }
+            continue;
+        }
         // ---- gate: my 40 gated columns gc0 .. gc0 + 39 of this chunk (the bias first: its loads must be OLDER than the weight prefetch below, or waiting
         //      for them waits for the prefetch too) ----
         const int gc0 = ch * GCOLS + wave * 40;
@@ -684,6 +781,10 @@ void geglu_direct_kernel(const G6Params P) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const int c0 = gc0 + 16 * p + 4 * (p == 2 ? (kq & 1) : kq);
+            if constexpr (G6_BIASPF) {
+                t6_unpack4(bpf[0][p], bv[p]);
+                t6_unpack4(bpf[1][p], bg[p]);
+            } else
             if (P.bias) {
                 t6_unpack4(*reinterpret_cast<const u32x2*>(P.bias + c0), bv[p]);
                 t6_unpack4(*reinterpret_cast<const u32x2*>(P.bias + P.cff + c0), bg[p]);
@@ -693,12 +794,14 @@ void geglu_direct_kernel(const G6Params P) {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        G6_T(2);
         if (ch + 1 < nchunks) {                                   // the next chunk's first two k-steps (stages 0, 1: the loop's last steps have left them)
             wl = chunk_base(ch + 1);
             load_w(0);
             load_w(1);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (G6_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < RS; ++s)
 #pragma unroll
@@ -723,7 +826,10 @@ void geglu_direct_kernel(const G6Params P) {
                 if (kq < 2) *reinterpret_cast<u32x2*>(Sr + 32 + 4 * kq) = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
             }
         }
+        if (G6_PRIO) __builtin_amdgcn_s_setprio(0);
+        G6_T(3);
         __syncthreads();
+        G6_T(4);
         // ---- whole-row stores: ROWS rows x GCOLS / 8 sixteen-byte chunks = 6.25 per thread (12.5 with SEQ) ----
         // (the per-thread row / column of the seven stores recomputed from an opaque copy of tid in every chunk: visible as loop invariants, hipcc
         //  hoists the seven 64-bit row offsets out of the chunk loop, spills them -- 20 VGPRs -- and reloads each behind its own s_waitcnt vmcnt(0))
@@ -741,7 +847,9 @@ void geglu_direct_kernel(const G6Params P) {
                 *reinterpret_cast<u32x4*>(P.out + dst) = *reinterpret_cast<const u32x4*>(S + r * SP + cc * 8);
             }
         }
+        G6_T(5);
         __syncthreads();                                          // the staging region is free again
+        G6_T(6);
     }
 }
 

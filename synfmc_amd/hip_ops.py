@@ -1160,6 +1160,54 @@ def pack_geglu_frag80(w: torch.Tensor) -> torch.Tensor:
     return wp.permute(0, 1, 4, 2, 5, 3, 6).contiguous().view(-1)
 
 
+GEGLU_PIPE = os.environ.get("FMC_GEGLU_PIPE", "1") != "0"        # A/B switch: the software-pipelined LayerNorm + GEGLU kernel (csrc/geglu_pipe.hip) where it applies
+GEGLU_PIPE_640 = os.environ.get("FMC_GEGLU_PIPE_640", "0") == "1"  # ... also at C = 640 (80-row form only: 130 vs 136 us isolated)
+
+
+def pack_geglu_frag(w: torch.Tensor, group: int = 32) -> torch.Tensor:
+    """GEGLU projection `[2 Cff, C]` (value rows, then gate rows) -> `fmc_geglu_pipe_ln_bf16`'s fragment order: per group of `group` (32 | 16) gated columns
+    the 2 x group weight rows [value blocks of 16 | gate blocks of 16] (value and gate of a column share a lane), as
+    [Cff / group][C / 32 k-steps][group / 8 blocks][lane = 16 kq + row][8]."""
+    two_cff, Kd = w.shape
+    cff, nb = two_cff // 2, group // 8
+    assert Kd % 32 == 0 and cff % group == 0 and group in (16, 32)
+    base = (torch.arange(cff // group, device=w.device) * group)[:, None]                                                            # [ng, 1]
+    r = torch.arange(group, device=w.device)
+    idx = torch.cat([base + r, cff + base + r], -1)                                                                                  # [ng, 2 group]
+    wp = w.detach()[idx.reshape(-1)].reshape(cff // group, nb, 16, Kd // 32, 4, 8)                                                   # [ng, block, row, ks, kq, 8]
+    return wp.permute(0, 3, 1, 4, 2, 5).contiguous().view(-1)
+
+
+def geglu_pipe_variant(M: int, C: int) -> int:
+    """1 = the 160-row form (C = 320, M % 160 == 0: each weight fragment serves twice the rows), else 0 = the 80-row form.  FMC_GEGLU_PIPE_VARIANT forces."""
+    env = os.environ.get("FMC_GEGLU_PIPE_VARIANT")
+    if env is not None:
+        return int(env)
+    return 1 if (C == 320 and M % 160 == 0) else 0
+
+
+def geglu_ln_pipe_ok(h: torch.Tensor, weight: torch.Tensor) -> bool:
+    C = h.shape[-1]
+    M = h.numel() // C
+    return bool(GEGLU_PIPE and h.is_cuda and h.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and h.is_contiguous() and weight.shape[1] == C
+                and not torch.is_grad_enabled()
+                and _lib.load().fmc_geglu_pipe_supported(M, weight.shape[0] // 2, C, geglu_pipe_variant(M, C)))
+
+
+def geglu_ln_pipe(h: torch.Tensor, ln_gamma: torch.Tensor, ln_beta: torch.Tensor, ln_eps: float, w_packed: torch.Tensor, bias: Optional[torch.Tensor],
+                  cff: int, blocked: bool = False, variant: int = 0) -> torch.Tensor:
+    """`GEGLU(LayerNorm(h))` on `fmc_geglu_pipe_ln_bf16` (the gate of chunk c - 1 in the shadow of chunk c's MFMAs): `[..., C] -> [..., cff]`, `w_packed` =
+    `pack_geglu_frag(weight, 32 if variant == 0 else 16)`.  `blocked`: tile-major `[M / 160][cff / 32][160][32]` for `linear_from_blocked`."""
+    _dev(h, ln_gamma, ln_beta, w_packed, bias)
+    C = h.shape[-1]
+    M = h.numel() // C
+    out = torch.empty(*h.shape[:-1], cff, dtype=h.dtype, device=h.device)
+    _log_call("geglu_direct", (M, 2 * cff, C), 2.0 * M * 2 * cff * C)
+    _lib.check(_lib.load().fmc_geglu_pipe_ln_bf16(h.data_ptr(), out.data_ptr(), ln_gamma.data_ptr(), ln_beta.data_ptr(), float(ln_eps), w_packed.data_ptr(),
+                                                  _p(bias), M, cff, C, int(blocked), int(variant), _stream()), "fmc_geglu_pipe_ln_bf16")
+    return out
+
+
 def geglu_ln_direct_ok(h: torch.Tensor, weight: torch.Tensor) -> bool:
     C = h.shape[-1]
     if not (h.is_cuda and h.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and h.is_contiguous() and weight.shape[1] == C

@@ -625,13 +625,20 @@ class FeedForward(nn.Module):
         if not K.geglu_ln_direct_ok(h, w) or getattr(h, "_fmc_pending_add", None) is not None or getattr(h, "_fmc_ln", None) is not None \
                 or getattr(h, "_fmc_pending_ln", None) is not None:
             return None
-        key = (w.data_ptr(), w._version)
+        M = h.numel() // h.shape[-1]
+        pipe = K.geglu_ln_pipe_ok(h, w) and (h.shape[-1] == 320 or K.GEGLU_PIPE_640)
+        var = K.geglu_pipe_variant(M, h.shape[-1]) if pipe else -1
+        key = (w.data_ptr(), w._version, var)
         hit = self.__dict__.get("_geglu_frag")
         if hit is None or hit[0] != key:
-            hit = (key, K.pack_geglu_frag80(w))
+            hit = (key, K.pack_geglu_frag(w, 16 if var == 1 else 32) if pipe else K.pack_geglu_frag80(w))
             self.__dict__["_geglu_frag"] = hit
         blocked = K.geglu_direct_blocked_ok(h, out.weight, residual)
-        mid = K.geglu_ln_direct(h, f32_param(norm, "weight"), f32_param(norm, "bias"), norm.eps, hit[1], proj.proj.bias, w.shape[0] // 2, blocked=blocked)
+        if pipe:      # the gate in the shadow of the next chunk's MFMAs (csrc/geglu_pipe.hip, round 6)
+            mid = K.geglu_ln_pipe(h, f32_param(norm, "weight"), f32_param(norm, "bias"), norm.eps, hit[1], proj.proj.bias, w.shape[0] // 2, blocked=blocked,
+                                  variant=var)
+        else:
+            mid = K.geglu_ln_direct(h, f32_param(norm, "weight"), f32_param(norm, "bias"), norm.eps, hit[1], proj.proj.bias, w.shape[0] // 2, blocked=blocked)
         if blocked:
             return K.linear_from_blocked(mid, out.weight, out.bias, residual)
         return out(mid, residual=residual)

@@ -2124,3 +2124,44 @@ def test_attention_generic_refuses_what_it_does_not_take(K):
         with torch.enable_grad():
             qg = torch.randn(1, 16, 64, device="cuda", dtype=torch.bfloat16, requires_grad=True)
             K.attention(qg, qg, qg, 1)
+
+
+@pytest.mark.parametrize("M,cff,C,variant", [(80, 128, 320, 0), (81920, 1280, 320, 0), (81920, 1280, 320, 1), (320, 384, 320, 1), (400, 256, 320, 0),
+                                             (20480, 2560, 640, 0), (240, 640, 640, 0), (160, 128, 320, 1)])
+def test_geglu_ln_pipe(K, M, cff, C, variant):
+    """`fmc_geglu_pipe_ln_bf16` (csrc/geglu_pipe.hip): LayerNorm + GEGLU projection with the gate of chunk c - 1 software-pipelined under the MFMAs of chunk c
+    (two accumulator sets, no staging tile, stores straight from registers), both tilings, odd and even chunk counts, row-major and tile-major output:
+    against fp32 (max norm), against the same arithmetic with the kernel's rounding points (element-wise bf16 bound), deterministic, and within bf16
+    rounding of `geglu_ln_direct` (same function, other summation / gate order)."""
+    dtype = torch.bfloat16
+    ho, hd = rnd((M, C), 1, dtype, scale=1.5, shift=0.2)
+    go, _ = rnd((C,), 2, torch.float32, scale=0.3, shift=1.0)
+    bo, _ = rnd((C,), 3, torch.float32, scale=0.2)
+    wo, wd = rnd((2 * cff, C), 4, dtype, scale=C ** -0.5)
+    bio, bid = rnd((2 * cff,), 5, dtype, scale=0.3)
+    wp = K.pack_geglu_frag(wd, 16 if variant == 1 else 32)
+    out = K.geglu_ln_pipe(hd, go.cuda(), bo.cuda(), 1e-5, wp, bid, cff, variant=variant)
+
+    def reference(round_bf16):
+        r = (lambda t: t.bfloat16().float()) if round_bf16 else (lambda t: t)
+        n = r(F.layer_norm(ho, (C,), go, bo, 1e-5))
+        y = F.linear(n, wo, bio)
+        return y[:, :cff] * F.gelu(y[:, cff:])
+    ref_r, ref_f = reference(True), reference(False)
+    assert rel_inf(out.float(), ref_f) < 2e-2
+    err = (out.float().cpu() - ref_r).abs()
+    bound = 2.0 ** -8 * ref_r.abs() + 0.02
+    assert not bool((err > bound).any()), f"{int((err > bound).sum())} / {err.numel()} beyond the bound, worst {float((err - bound).max()):.3e}"
+    assert torch.equal(out, K.geglu_ln_pipe(hd, go.cuda(), bo.cuda(), 1e-5, wp, bid, cff, variant=variant))
+    out_nb = K.geglu_ln_pipe(hd, go.cuda(), bo.cuda(), 1e-5, wp, None, cff, variant=variant)
+    y = F.linear(F.layer_norm(ho, (C,), go, bo, 1e-5), wo)
+    assert rel_inf(out_nb.float(), y[:, :cff] * F.gelu(y[:, cff:])) < 2e-2
+    if M % 160 == 0:
+        blk = K.geglu_ln_pipe(hd, go.cuda(), bo.cuda(), 1e-5, wp, bid, cff, blocked=True, variant=variant)
+        assert torch.equal(blk.view(M // 160, cff // 32, 160, 32).permute(0, 2, 1, 3).reshape(M, cff), out)
+    if cff % (160 if C == 320 else 320) == 0 and M % 80 == 0:
+        direct = K.geglu_ln_direct(hd, go.cuda(), bo.cuda(), 1e-5, K.pack_geglu_frag80(wd), bid, cff)
+        d = (out.float() - direct.float()).abs().cpu()
+        assert bool((d <= 2.0 ** -7 * ref_r.abs() + 1e-3).all())
+    with pytest.raises(ValueError):
+        K.geglu_ln_pipe(hd[:M - 8].contiguous(), go.cuda(), bo.cuda(), 1e-5, wp, bid, cff, variant=variant)

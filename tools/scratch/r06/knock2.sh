@@ -1,0 +1,6 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python tools/scratch/r05/bench_geglu.py 2>&1 | grep geglu | sed 's/^/full      /'
+for n in k1 k4 k5 k6 k7 af2 af2k4; do
+  FMC_HIP_LIB=$PWD/synfmc_amd/lib/knock/libfmc_hip_$n.so python tools/scratch/r05/bench_geglu.py 2>&1 | grep geglu | sed "s/^/$n     /"
+done
+FMC_HIP_LIB=$PWD/synfmc_amd/lib/knock/libfmc_hip_af2.so timeout 600 python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "geglu_ln_direct" 2>&1 | tail -2
