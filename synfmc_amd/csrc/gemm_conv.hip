@@ -2835,7 +2835,8 @@ void launch_gemm160(GemmParams& P, hipStream_t st) {
         static const int persist = getenv("FMC_G160_PERSIST") ? atoi(getenv("FMC_G160_PERSIST")) : 1;
         const int cus = fmc_cu_count() & ~7;
         // (FMC_G160_PERSIST=2: also launches of exactly one round -- tiles == CUs, the level-1 N = 640 projections -- A/B switch)
-        if (persist && !P.f32io && P.M % 160 == 0 && (persist == 2 ? P.tiles_m * P.tiles_n >= cus : P.tiles_m * P.tiles_n > cus) && cus >= 8) {
+        // (a tile-major A operand exists in the persistent form only: it also takes launches of exactly one round -- the two halves of a split feed-forward)
+        if (persist && !P.f32io && P.M % 160 == 0 && ((persist == 2 || P.a_blocked) ? P.tiles_m * P.tiles_n >= cus : P.tiles_m * P.tiles_n > cus) && cus >= 8) {
             constexpr size_t ldsp = (size_t)3 * (160 + 320) * 32 * sizeof(bf16_t) + 1024 + (EPI == 1 ? (size_t)160 * 168 * 2 + 4096 : (size_t)80 * 328 * 2 + 5120);
             static FmcPerDeviceFlag raisedp;
             if (!raisedp) {
@@ -3041,6 +3042,7 @@ static int linear_impl(const void* x, const void* w, const void* bias, const voi
         const int cus = fmc_cu_count() & ~7;
         if (f32io || tile != 16 || split_k != 1 || gn_partials || x2 || N % 320 || M % 160 || cus < 8 ||
             (out_blocked && (M / 160) * (N / 320) <= cus) ||                      // (the GEGLU epilogue that writes tile-major is the persistent form's)
+            (a_blocked && (M / 160) * (N / 320) < cus) ||
             (a_blocked && (epilogue != 0 || ldx != K || K % 32)) || (out_blocked && (epilogue != 1 || ldo != N / 2 || (N / 2) % 32)) ||
             (int64_t)M * (a_blocked ? K : N / 2) * 2 >= ((int64_t)1 << 31) || (getenv("FMC_G160_PERSIST") && atoi(getenv("FMC_G160_PERSIST")) == 0))
             FMC_FAIL(FMC_E_SHAPE, "linear_bf16: the tile-major feed-forward intermediate needs tile 16's persistent form (M %% 160 == 0, N %% 320 == 0, "

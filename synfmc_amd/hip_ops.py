@@ -1161,6 +1161,9 @@ def pack_geglu_frag80(w: torch.Tensor) -> torch.Tensor:
 
 
 GEGLU_PIPE = os.environ.get("FMC_GEGLU_PIPE", "1") != "0"        # A/B switch: the software-pipelined LayerNorm + GEGLU kernel (csrc/geglu_pipe.hip) where it applies
+# FMC_FF_SPLIT=n (A/B, round 6): the level-0 feed-forward in n row slices, GEGLU -> output projection per slice, so that the tile-major intermediate of a slice
+# (210 MB / n) is still in the 256-MB Infinity Cache when the second GEMM reads it (that GEMM: 80 us in a loop on warm operands, 134 us in the step)
+FF_SPLIT = int(os.environ.get("FMC_FF_SPLIT", "1"))
 GEGLU_PIPE_640 = os.environ.get("FMC_GEGLU_PIPE_640", "0") == "1"  # ... also at C = 640 (80-row form only: 130 vs 136 us isolated)
 
 
@@ -1679,12 +1682,14 @@ def geglu_linear_blocked(x: torch.Tensor, weight_il160: torch.Tensor, bias_il160
     return out
 
 
-def linear_from_blocked(xb: torch.Tensor, weight: torch.Tensor, bias, residual, alpha: float = 1.0) -> torch.Tensor:
-    """`alpha * (x @ weight^T + bias) + residual` for an x in the tile-major layout of `geglu_linear_blocked`."""
-    _dev(xb, weight, bias, residual)
+def linear_from_blocked(xb: torch.Tensor, weight: torch.Tensor, bias, residual, alpha: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`alpha * (x @ weight^T + bias) + residual` for an x in the tile-major layout of `geglu_linear_blocked`; `out`: a contiguous `[M, N]` destination."""
+    _dev(xb, weight, bias, residual, out)
     N, Kd = weight.shape
     M = xb.numel() // Kd
-    out = torch.empty(*xb.shape[:-1], N, dtype=xb.dtype, device=xb.device)
+    if out is None:
+        out = torch.empty(*xb.shape[:-1], N, dtype=xb.dtype, device=xb.device)
+    assert out.is_contiguous() and out.numel() == M * N and out.dtype == xb.dtype
     wt = _w_tilemajor(weight) if W_TILEMAJOR else weight
     _log_call("own_linear", (M, N, Kd, "from-blocked", int(residual is not None)), 2.0 * M * N * Kd)
     _lib.check(_lib.load().fmc_linear_bf16_ffblk(xb.data_ptr(), wt.data_ptr(), _p(bias), _p(residual), out.data_ptr(), M, N, Kd,
