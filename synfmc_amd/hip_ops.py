@@ -2205,6 +2205,7 @@ def _time_ms(fn, reps=8):
     return ms
 
 
+PREFER_K320 = os.environ.get("FMC_PREFER_K320", "0") == "1"   # A/B switch (round 6): arm 15 over the 160 x 320 arms on the level-0 K = 320 projections
 NO_VENDOR = os.environ.get("FMC_NO_VENDOR", "0") == "1"      # A/B switch: the vendor library (hipBLASLt / MIOpen) is never a candidate arm
 # where the calls of the three GEMM-shaped front-ends went (bench.py counts one eager step): "own" = a kernel of this library, "vendor" = the
 # autotuner chose the vendor arm, "ineligible" = the shape / dtype / layout is outside the own kernels and the call fell through to the library
@@ -2242,6 +2243,8 @@ def _pick(key, hip_fn, lib_fn, static_hip: bool, extra_arms=(), k320: bool = Fal
         _tune_log.pop(key, None)
         stale_table_entries[0] += 1
         use = None
+    if PREFER_K320 and k320 and use in (ARM_160, ARM_160B) and key[0] == "lin" and key[1] >= 40960:
+        use = 15                                                    # (experiment, round 6: the weight-stationary kernel wherever it is eligible)
     if use is None:
         if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
             return 0 if not (static_hip or no_lib) else -1          # -1: kernel's own geometry heuristic
