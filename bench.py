@@ -345,6 +345,36 @@ def measure_proj_roofline(device, dtype, iters=20):
     return out
 
 
+def measure_proj_l0_roofline(device, dtype, iters=20):
+    """The feed-forward input projection of the 40x64 level as the U-Net issues it since round 6: LayerNorm + GEGLU projection `[81920 tokens, 320] x
+    [2560, 320]^T` gated to 1280 columns, the gate software-pipelined under the next chunk's MFMAs (`fmc_geglu_pipe_ln_bf16`, 160-row tiles), tile-major
+    output for the second GEMM.  K = 320: ~15 gate instructions per 1280 matrix flops per output -- the VALU stream is as long as the MFMA stream."""
+    from synfmc_amd import hip_ops as K
+    M, Kd, N = 2 * FRAMES * (HEIGHT // 8) * (WIDTH // 8), WIDTHS[0], 8 * WIDTHS[0]
+    x = torch.randn(M, Kd, device=device, dtype=dtype)
+    w = torch.randn(N, Kd, device=device, dtype=dtype) * Kd ** -0.5
+    b = torch.randn(N, device=device, dtype=dtype)
+    g, beta = torch.randn(Kd, device=device) * 0.2 + 1, torch.randn(Kd, device=device)
+    with torch.no_grad():
+        pipe = K.geglu_ln_pipe_ok(x, w)
+        var = K.geglu_pipe_variant(M, Kd) if pipe else -1
+        wp = K.pack_geglu_frag(w, 16 if var == 1 else 32) if pipe else K.pack_geglu_frag80(w)
+
+        def run():
+            with torch.no_grad():
+                if pipe:
+                    return K.geglu_ln_pipe(x, g, beta, 1e-5, wp, b, N // 2, blocked=True, variant=var)
+                return K.geglu_ln_direct(x, g, beta, 1e-5, wp, b, N // 2, blocked=True)
+        ms = _time_launch(run, iters)
+    flops = 2.0 * M * N * Kd
+    achieved = flops / (ms * 1e-3) / 1e12
+    name = f"geglu_pipe_kernel<320, {'8 waves x 160 rows' if var == 1 else '4 waves x 80 rows'}>" if pipe else "geglu_direct_kernel<320>"
+    return {"bound": "mfma", "kernel": f"{name} (LayerNorm + GEGLU projection, A resident, gate pipelined under the MFMAs) [{M}x{N}x{Kd}]",
+            "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "avg_launch_ms": round(ms, 4),
+            "flops_per_launch": flops, "traffic_algorithmic": 2.0 * (M * Kd + N * Kd + M * N // 2), "traffic": None,
+            "_match": ("name", "geglu_pipe_kernel<320" if pipe else "geglu_direct_kernel<320")}
+
+
 def measure_linear_l0_roofline(device, dtype, iters=30):
     """One of the K = 320 token projections of the 40x64 level as the U-Net issues them 25 times per step (`to_out`, `proj_in` / `proj_out` of the spatial
     and temporal transformers: M = 81920 tokens, 320 -> 320, bias + residual), through the autotuned front-end.  16.8 GF on 157 MB: HBM bound
@@ -606,7 +636,7 @@ _FAMILY_KERNELS = {
     "conv_halo4": ("conv_halo4_kernel<",),
     "vendor": ("Cijk_",),
     "own_linear": ("gemm160p_kernel<", "gemm160_kernel<0", "gemm8_kernel<0", "gemm_kernel<0", "gemm_k320_kernel<", "gemm4_kernel"),
-    "geglu_direct": ("geglu_direct_kernel<",),
+    "geglu_direct": ("geglu_direct_kernel<", "geglu_pipe_kernel<"),
     "fused_block": ("temporal_block_kernel<", "temporal_block640_kernel<"),
 }
 
@@ -676,7 +706,7 @@ def step_kernel_families(steps, call_log):
     if steps is None:
         return None
     fam = (("conv3x3 (conv_halo_kernel)", ("conv_halo_kernel", "conv_halo4_kernel", "conv_halo4_finish")), ("conv3x3 / linear (gemm*_kernel, sk_finish)", ("gemm", "sk_finish", "splitk")),
-           ("vendor GEMM (hipBLASLt Cijk_*)", ("Cijk_",)), ("geglu_direct", ("geglu_direct",)), ("spatial attention", ("sa40d", "spatial_attn", "sa_small160", "sa_big80")),
+           ("vendor GEMM (hipBLASLt Cijk_*)", ("Cijk_",)), ("geglu_direct / geglu_pipe", ("geglu_direct", "geglu_pipe")), ("spatial attention", ("sa40d", "spatial_attn", "sa_small160", "sa_big80")),
            ("temporal block / attention", ("temporal_block", "temporal_attn")), ("text cross-attention block", ("xattn",)),
            ("groupnorm", ("gn_",)), ("layernorm", ("layernorm",)), ("torch elementwise / copy / cat", ("at::", "elementwise", "CatArray")))
     tot = {k: 0.0 for k, _ in fam}
@@ -1438,12 +1468,13 @@ def main():
         roof_tb1 = measure_temporal_block_l1_roofline(device, dtype) if bf else None
         roof_sa1 = measure_attention_level_roofline(device, dtype, 1) if bf else None
         roof_sa2 = measure_attention_level_roofline(device, dtype, 2) if bf else None
+        roof_proj0 = measure_proj_l0_roofline(device, dtype) if bf else None
         roof_lin0 = measure_linear_l0_roofline(device, dtype) if bf else None
         roof_ff2 = measure_ff2_roofline(device, dtype) if bf else None
         roof_vendor = measure_vendor_roofline(device, dtype) if bf else None
         roof_halo4 = measure_conv_halo4_roofline(device, dtype) if bf else None
         steps_tr, tr_note = (None, "skipped (--no-in-step / N > 1 / fp32)") if (args.no_in_step or world > 1 or not bf) else in_step_trace(args, cfg)
-        roofs = [roof, roof_conv, roof_conv0, roof_gn, roof_temp, roof_proj, roof_tb, roof_tb1, roof_sa1, roof_sa2, roof_lin0, roof_ff2, roof_vendor, roof_halo4]
+        roofs = [roof, roof_conv, roof_conv0, roof_gn, roof_temp, roof_proj, roof_tb, roof_tb1, roof_sa1, roof_sa2, roof_proj0, roof_lin0, roof_ff2, roof_vendor, roof_halo4]
         for o in roofs:
             apply_in_step(o, steps_tr, call_log)
         families = step_kernel_families(steps_tr, call_log)
@@ -1478,7 +1509,7 @@ def main():
             "roofline": roof, "roofline_conv": roof_conv, "roofline_conv_l0": roof_conv0, "roofline_groupnorm": roof_gn, "roofline_temporal": roof_temp,
             "roofline_temporal_block": roof_tb, "roofline_temporal_block_l1": roof_tb1, "roofline_proj": roof_proj,
             "roofline_attention_l1": roof_sa1, "roofline_attention_l2": roof_sa2,
-            "roofline_linear_l0": roof_lin0, "roofline_ff2": roof_ff2, "roofline_vendor_gemm": roof_vendor, "roofline_conv_halo4": roof_halo4,
+            "roofline_proj_l0": roof_proj0, "roofline_linear_l0": roof_lin0, "roofline_ff2": roof_ff2, "roofline_vendor_gemm": roof_vendor, "roofline_conv_halo4": roof_halo4,
             "in_step_source": tr_note, "in_step_kernel_families": families,
             "autotune": {"shapes_from_this_builds_cache": K.autotune_sources["cache"], "shapes_from_tracked_default_table": K.autotune_sources["defaults"],
                          "shapes_tuned_in_this_run": max(0, len(K._choice) - K.autotune_sources["cache"] - K.autotune_sources["defaults"]),

@@ -525,9 +525,8 @@ __device__ __forceinline__ float t6_gelu_erf(float g) {       // Abramowitz & St
 #ifndef G6_KNOCK
 #define G6_KNOCK 0
 #endif
-// G6_AF2 = 1: the A fragments of k-step g + 1 are read during k-step g into a second register set (20 VGPRs more) instead of two row blocks ahead inside the
-// step -- the knock-out builds above put the fragment reads at 85 of the launch's 208 us although the LDS array is ~20 % busy: their latency, not their bandwidth
-// G6_STAMP = 1 (diagnostic): wave 0 of workgroups 0 and 300 writes s_memtime stamps of its first 4 chunks over the head of `out` (results destroyed)
+// G6_STAMP = 1 (diagnostic): wave 0 of workgroups 0 and 300 writes s_memtime stamps of its first 4 chunks over the head of `out` (results destroyed;
+// tools/scratch/r06/stamp_geglu.py reads them back)
 #ifndef G6_STAMP
 #define G6_STAMP 0
 #endif
@@ -536,21 +535,6 @@ __device__ __forceinline__ float t6_gelu_erf(float g) {       // Abramowitz & St
         if (G6_STAMP && tid == 0 && ch < 4 && (blockIdx.x == 0 || blockIdx.x == 300))                                    \
             reinterpret_cast<long long*>(P.out)[(blockIdx.x ? 64 : 0) + ch * 8 + (i)] = (long long)__builtin_readcyclecounter(); \
     } while (0)
-// A/B switches of round 6 (see NOTEBOOK.md): G6_PRIO = the gate / staging phase at s_setprio 1 (its VALU wins the arbitration against the co-resident
-// workgroup's main loop); G6_STAGGER = every second round of workgroups starts ~8000 cycles late (de-phases the two workgroups of a CU: one gates while
-// the other multiplies); G6_BIASPF = the next chunk's bias words are requested before the main loop instead of behind it
-#ifndef G6_PRIO
-#define G6_PRIO 0
-#endif
-#ifndef G6_STAGGER
-#define G6_STAGGER 0
-#endif
-#ifndef G6_BIASPF
-#define G6_BIASPF 0
-#endif
-#ifndef G6_AF2
-#define G6_AF2 0
-#endif
 #ifndef FMC_GEGLU320_ROWS160_DEFAULT
 #define FMC_GEGLU320_ROWS160_DEFAULT 0
 #endif
@@ -589,10 +573,6 @@ void geglu_direct_kernel(const G6Params P) {
     const int xsw = (l15 >> 1) & 7;
     const int64_t m0 = (int64_t)blockIdx.x * ROWS;
     const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)P.h, 0, (int)(P.M * C * 2), 0x00020000);
-    if (G6_STAGGER && ((blockIdx.x >> 8) & 1)) {
-#pragma unroll
-        for (int i = 0; i < G6_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     // ---- phase A: rows -> X, LayerNorm in place ----
 #pragma unroll
     for (int j = 0; j < (ROWS * CPR / 64 + NWV - 1) / NWV; ++j) {
@@ -672,26 +652,9 @@ void geglu_direct_kernel(const G6Params P) {
     load_w(0);
     load_w(1);
     if constexpr (G6_KNOCK & 1) load_w(2);                        // (diagnostic: every fragment register defined)
-    u32x4 afb[2][G6_AF2 ? 5 * RS : 1];
-    if constexpr (G6_AF2) {
-        int kqx = kq ^ xsw, xrow_o = (rh * T6_ROWS + l15) * C;
-        asm volatile("" : "+v"(kqx), "+v"(xrow_o));
-#pragma unroll
-        for (int mb = 0; mb < 5 * RS; ++mb) afb[0][mb] = *reinterpret_cast<const u32x4*>(X + mb * 16 * C + xrow_o + kqx * 8);
-    }
 #pragma unroll 1
     for (int ch = 0; ch < nchunks; ++ch) {
         G6_T(0);
-        u32x2 bpf[2][3];
-        if constexpr (G6_BIASPF) {                                 // this chunk's bias words: in flight under the main loop (12 registers)
-            const int gcp = ch * GCOLS + wave * 40;
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                const int c0 = gcp + 16 * p + 4 * (p == 2 ? (kq & 1) : kq);
-                bpf[0][p] = P.bias ? *reinterpret_cast<const u32x2*>(P.bias + c0) : u32x2{0u, 0u};
-                bpf[1][p] = P.bias ? *reinterpret_cast<const u32x2*>(P.bias + P.cff + c0) : u32x2{0u, 0u};
-            }
-        }
 #pragma unroll
         for (int s = 0; s < RS; ++s)
 #pragma unroll
@@ -707,27 +670,6 @@ void geglu_direct_kernel(const G6Params P) {
             __builtin_amdgcn_sched_barrier(0);
             // the RS * 5 row blocks of my halves as one sequence (block i = half i / 5, block i % 5: X rows 16 i ..), fragments two blocks ahead
             constexpr int NB_ = 5 * RS;
-            if constexpr (G6_AF2) {
-                // this k-step's fragments are in afb[g & 1] (read during the previous step / chunk); read the NEXT step's (k-step 0 of the next chunk behind
-                // the last one: X is the same for every chunk) into the other set, one read in front of each block's MFMAs
-                constexpr int gn = (g + 1) % KS;
-                const int xn = xrow_o + ((gn >> 1) * 8 + (((gn & 1) * 4) ^ kqx)) * 8;
-#pragma unroll
-                for (int mb = 0; mb < NB_; ++mb) {
-                    afb[(g + 1) & 1][mb] = *reinterpret_cast<const u32x4*>(X + mb * 16 * C + xn);
-                    union { bf16x8 v; u32x4 u; } a;
-                    a.u = afb[g & 1][mb];
-#pragma unroll
-                    for (int nb = 0; nb < 5; ++nb) {
-                        union { bf16x8 v; u32x4 u; } w;
-                        w.u = wfr[g % 3][nb];
-                        acc[mb / 5][mb % 5][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, a.v, acc[mb / 5][mb % 5][nb], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
-                }
-                return;
-            }
             u32x4 af3[3];
             if constexpr (G6_KNOCK & 2) {
                 af3[0] = af3[1] = af3[2] = u32x4{(unsigned)xo + 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
@@ -781,10 +723,6 @@ void geglu_direct_kernel(const G6Params P) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const int c0 = gc0 + 16 * p + 4 * (p == 2 ? (kq & 1) : kq);
-            if constexpr (G6_BIASPF) {
-                t6_unpack4(bpf[0][p], bv[p]);
-                t6_unpack4(bpf[1][p], bg[p]);
-            } else
             if (P.bias) {
                 t6_unpack4(*reinterpret_cast<const u32x2*>(P.bias + c0), bv[p]);
                 t6_unpack4(*reinterpret_cast<const u32x2*>(P.bias + P.cff + c0), bg[p]);
@@ -801,7 +739,6 @@ void geglu_direct_kernel(const G6Params P) {
             load_w(1);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (G6_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < RS; ++s)
 #pragma unroll
@@ -826,7 +763,6 @@ void geglu_direct_kernel(const G6Params P) {
                 if (kq < 2) *reinterpret_cast<u32x2*>(Sr + 32 + 4 * kq) = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
             }
         }
-        if (G6_PRIO) __builtin_amdgcn_s_setprio(0);
         G6_T(3);
         __syncthreads();
         G6_T(4);

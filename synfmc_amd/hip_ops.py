@@ -1161,9 +1161,6 @@ def pack_geglu_frag80(w: torch.Tensor) -> torch.Tensor:
 
 
 GEGLU_PIPE = os.environ.get("FMC_GEGLU_PIPE", "1") != "0"        # A/B switch: the software-pipelined LayerNorm + GEGLU kernel (csrc/geglu_pipe.hip) where it applies
-# FMC_FF_SPLIT=n (A/B, round 6): the level-0 feed-forward in n row slices, GEGLU -> output projection per slice, so that the tile-major intermediate of a slice
-# (210 MB / n) is still in the 256-MB Infinity Cache when the second GEMM reads it (that GEMM: 80 us in a loop on warm operands, 134 us in the step)
-FF_SPLIT = int(os.environ.get("FMC_FF_SPLIT", "1"))
 GEGLU_PIPE_640 = os.environ.get("FMC_GEGLU_PIPE_640", "0") == "1"  # ... also at C = 640 (80-row form only: 130 vs 136 us isolated)
 
 
@@ -2147,22 +2144,6 @@ def autotune_report():
 
 
 _tune_stream = None
-# FMC_TUNE_COLD=1 (experiment, round 6): time every arm with the caches flushed between repetitions.  The default loop replays the SAME launch on the
-# SAME buffers: operands and weights sit in L2 / Infinity Cache, which ranks arms differently from the step, where a launch's operands were written
-# one or two kernels earlier and its weights were last touched a whole step ago (gemm160p on the K = 320 projections: 30 us in the loop, 57 us in the step).
-TUNE_COLD = os.environ.get("FMC_TUNE_COLD", "0") == "1"
-_thrash = {}
-
-
-def _thrash_fn():
-    """A pass over 512 MB (twice the Infinity Cache): what the next launch reads afterwards comes from HBM."""
-    dev = torch.cuda.current_device()
-    buf = _thrash.get(dev)
-    if buf is None:
-        buf = _thrash[dev] = torch.zeros(128 << 20, dtype=torch.int32, device="cuda")
-    buf.add_(1)
-
-
 def _graph_ms(body, reps):
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, stream=_tune_stream):
@@ -2193,19 +2174,11 @@ def _time_ms(fn, reps=8):
     with torch.cuda.stream(_tune_stream):
         fn()                                            # lazy initialisation (workspaces, library heuristics) outside capture
         _tune_stream.synchronize()
-        if TUNE_COLD:
-            _thrash_fn()
-            _tune_stream.synchronize()
-            if "base" not in _thrash:
-                _thrash["base"] = _graph_ms(_thrash_fn, reps)
-            ms = _graph_ms(lambda: (_thrash_fn(), fn()), reps) - _thrash["base"]
-        else:
-            ms = _graph_ms(fn, reps)
+        ms = _graph_ms(fn, reps)
     cur.wait_stream(_tune_stream)
     return ms
 
 
-PREFER_K320 = os.environ.get("FMC_PREFER_K320", "0") == "1"   # A/B switch (round 6): arm 15 over the 160 x 320 arms on the level-0 K = 320 projections
 NO_VENDOR = os.environ.get("FMC_NO_VENDOR", "0") == "1"      # A/B switch: the vendor library (hipBLASLt / MIOpen) is never a candidate arm
 # where the calls of the three GEMM-shaped front-ends went (bench.py counts one eager step): "own" = a kernel of this library, "vendor" = the
 # autotuner chose the vendor arm, "ineligible" = the shape / dtype / layout is outside the own kernels and the call fell through to the library
@@ -2243,8 +2216,6 @@ def _pick(key, hip_fn, lib_fn, static_hip: bool, extra_arms=(), k320: bool = Fal
         _tune_log.pop(key, None)
         stale_table_entries[0] += 1
         use = None
-    if PREFER_K320 and k320 and use in (ARM_160, ARM_160B) and key[0] == "lin" and key[1] >= 40960:
-        use = 15                                                    # (experiment, round 6: the weight-stationary kernel wherever it is eligible)
     if use is None:
         if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
             return 0 if not (static_hip or no_lib) else -1          # -1: kernel's own geometry heuristic

@@ -634,18 +634,6 @@ class FeedForward(nn.Module):
             hit = (key, K.pack_geglu_frag(w, 16 if var == 1 else 32) if pipe else K.pack_geglu_frag80(w))
             self.__dict__["_geglu_frag"] = hit
         blocked = K.geglu_direct_blocked_ok(h, out.weight, residual)
-        ns = K.FF_SPLIT
-        if (blocked and pipe and ns > 1 and residual is not None and M % (160 * ns) == 0 and (M // ns // 160) >= K._cus(h.device)
-                and (var == 0 or (M // ns) % 160 == 0)):
-            # row slices: each slice's tile-major intermediate is consumed while it is still cache resident (hip_ops.FF_SPLIT)
-            C = h.shape[-1]
-            h2, r2, res = h.reshape(M, C), residual.reshape(M, C), torch.empty_like(h)
-            o2, ms = res.view(M, C), M // ns
-            for i in range(ns):
-                mid = K.geglu_ln_pipe(h2[i * ms:(i + 1) * ms], f32_param(norm, "weight"), f32_param(norm, "bias"), norm.eps, hit[1], proj.proj.bias,
-                                      w.shape[0] // 2, blocked=True, variant=var)
-                K.linear_from_blocked(mid, out.weight, out.bias, r2[i * ms:(i + 1) * ms], out=o2[i * ms:(i + 1) * ms])
-            return res
         if pipe:      # the gate in the shadow of the next chunk's MFMAs (csrc/geglu_pipe.hip, round 6)
             mid = K.geglu_ln_pipe(h, f32_param(norm, "weight"), f32_param(norm, "bias"), norm.eps, hit[1], proj.proj.bias, w.shape[0] // 2, blocked=blocked,
                                   variant=var)
