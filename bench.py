@@ -416,24 +416,35 @@ def measure_ff2_roofline(device, dtype, iters=20):
             "_match": ("own_linear", lambda sh, M=M, N=N, Kd=Kd: sh[:4] == (M, N, Kd, "from-blocked"))}
 
 
-def measure_vendor_roofline(device, dtype, iters=30):
-    """The largest problem the per-shape choice still hands to hipBLASLt: q | k | v of the 10x16 level (`[5120, 1280] x [3840, 1280]^T`, 10 calls per step),
-    through the same front-end (`hip_ops.linear` -> `fmc_vendor_linear_bf16` with the candidate the arm table holds).  MFMA bound: 50.3 GF per launch."""
+def measure_vendor_roofline(device, dtype, call_log, iters=30):
+    """The problem on which the step spends most of its hipBLASLt time (from the recorded call order of one eager step: the vendor-arm shape with the largest
+    calls x flops -- at the time of writing `[5120, 1280] x [1280, 1280]^T + bias + residual`, the out-projections of the 10x16 level), through the same
+    front-end (`hip_ops.linear` -> `fmc_vendor_linear_bf16` with the candidate the arm table holds).  MFMA bound."""
     from synfmc_amd import hip_ops as K
-    M, N, Kd = 2 * FRAMES * (HEIGHT // 32) * (WIDTH // 32), 3 * WIDTHS[2], WIDTHS[2]
+    tot = {}
+    for fe, shape, fl in call_log or []:
+        if fe == "vendor":
+            tot[shape] = tot.get(shape, 0.0) + fl
+    if tot:
+        (M, N, Kd, has_b, has_r) = max(tot, key=tot.get)
+    else:
+        (M, N, Kd, has_b, has_r) = (2 * FRAMES * (HEIGHT // 32) * (WIDTH // 32), 3 * WIDTHS[2], WIDTHS[2], False, False)
     x = torch.randn(M, Kd, device=device, dtype=dtype)
     w = torch.randn(N, Kd, device=device, dtype=dtype) * Kd ** -0.5
+    b = torch.randn(N, device=device, dtype=dtype) if has_b else None
+    r = torch.randn(M, N, device=device, dtype=dtype) if has_r else None
     v0 = K.vendor_direct_calls["direct"]
-    ms = _time_launch(lambda: K.linear(x, w), iters)
+    ms = _time_launch(lambda: K.linear(x, w, b, residual=r), iters)
     vendor = K.vendor_direct_calls["direct"] > v0
-    arm = K._choice.get(("lin", M, N, Kd, False, 0, 0))
+    arm = K._choice.get(("lin", M, N, Kd, bool(has_b), int(bool(has_r)), 0))
     flops = 2.0 * M * N * Kd
     achieved = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": (f"hipBLASLt through fmc_vendor_linear_bf16 (candidate {K._choice.get(('valgo', M, N, Kd, Kd, 0, False, False))})" if vendor
-                                        else f"fmc_linear_bf16 arm {arm}") + f" [{M}x{N}x{Kd}]",
+    return {"bound": "mfma", "kernel": (f"hipBLASLt through fmc_vendor_linear_bf16 (candidate {K._choice.get(('valgo', M, N, Kd, Kd, N if has_r else 0, bool(has_b), bool(has_r)))})"
+                                        if vendor else f"fmc_linear_bf16 arm {arm}") + f" [{M}x{N}x{Kd}{' + bias' if has_b else ''}{' + residual' if has_r else ''}]",
+            "calls_per_step": sum(1 for fe, sh, _ in call_log or [] if fe == "vendor" and sh == (M, N, Kd, has_b, has_r)),
             "autotuned_arm": arm, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
             "avg_launch_ms": round(ms, 4), "flops_per_launch": flops, "traffic_algorithmic": 2.0 * (M * Kd + N * Kd + M * N), "traffic": None,
-            "_match": ("vendor" if vendor else "own_linear", lambda sh, M=M, N=N, Kd=Kd: sh[:3] == (M, N, Kd))}
+            "_match": ("vendor", (M, N, Kd, has_b, has_r)) if vendor else ("own_linear", lambda sh, M=M, N=N, Kd=Kd: sh[:3] == (M, N, Kd))}
 
 
 def measure_conv_halo4_roofline(device, dtype, iters=20):
@@ -692,7 +703,7 @@ def apply_in_step(obj, steps, call_log):
     ms = sum(us) / len(us) / 1e3
     obj["in_step_avg_ms"] = round(ms, 4)
     obj["in_step_calls_per_step"] = round(len(us) / len(steps), 2)
-    work = obj.get("flops_per_launch", obj.get("bytes_per_launch"))
+    work = obj["flops_per_launch"] if obj["unit"] == "TFLOP/s" else obj["bytes_per_launch"]     # (HBM-bound objects may quote their flops too)
     scale = 1e12 if obj["unit"] == "TFLOP/s" else 1e9
     obj["frac_isolated"] = obj["frac"]
     obj["achieved_isolated"] = obj["achieved"]
@@ -1471,7 +1482,7 @@ def main():
         roof_proj0 = measure_proj_l0_roofline(device, dtype) if bf else None
         roof_lin0 = measure_linear_l0_roofline(device, dtype) if bf else None
         roof_ff2 = measure_ff2_roofline(device, dtype) if bf else None
-        roof_vendor = measure_vendor_roofline(device, dtype) if bf else None
+        roof_vendor = measure_vendor_roofline(device, dtype, call_log) if bf else None
         roof_halo4 = measure_conv_halo4_roofline(device, dtype) if bf else None
         steps_tr, tr_note = (None, "skipped (--no-in-step / N > 1 / fp32)") if (args.no_in_step or world > 1 or not bf) else in_step_trace(args, cfg)
         roofs = [roof, roof_conv, roof_conv0, roof_gn, roof_temp, roof_proj, roof_tb, roof_tb1, roof_sa1, roof_sa2, roof_proj0, roof_lin0, roof_ff2, roof_vendor, roof_halo4]
