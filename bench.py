@@ -385,7 +385,8 @@ def measure_linear_l0_roofline(device, dtype, iters=30):
     r = torch.randn(M, N, device=device, dtype=dtype)
     w = torch.randn(N, Kd, device=device, dtype=dtype) * Kd ** -0.5
     b = torch.randn(N, device=device, dtype=dtype)
-    ms = _time_launch(lambda: K.linear(x, w, b, residual=r), iters)
+    with torch.no_grad():
+        ms = _time_launch(lambda: K.linear(x, w, b, residual=r), iters)
     arm = K._choice.get(("lin", M, N, Kd, True, 1, 0))
     nbytes = 2.0 * (M * Kd + 2 * M * N + N * Kd)
     gbs = nbytes / (ms * 1e-3) / 1e9
@@ -407,7 +408,8 @@ def measure_ff2_roofline(device, dtype, iters=20):
     b = torch.randn(N, device=device, dtype=dtype)
     if not K.geglu_direct_blocked_ok(xb[:, :N].contiguous(), w, r):
         return None
-    ms = _time_launch(lambda: K.linear_from_blocked(xb, w, b, r), iters)
+    with torch.no_grad():
+        ms = _time_launch(lambda: K.linear_from_blocked(xb, w, b, r), iters)
     nbytes = 2.0 * (M * Kd + 2 * M * N + N * Kd)
     gbs = nbytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": f"gemm160p_kernel<blocked A> (feed-forward output projection + bias + residual, tile-major intermediate) [{M}x{N}x{Kd}]",
@@ -434,7 +436,8 @@ def measure_vendor_roofline(device, dtype, call_log, iters=30):
     b = torch.randn(N, device=device, dtype=dtype) if has_b else None
     r = torch.randn(M, N, device=device, dtype=dtype) if has_r else None
     v0 = K.vendor_direct_calls["direct"]
-    ms = _time_launch(lambda: K.linear(x, w, b, residual=r), iters)
+    with torch.no_grad():                                                   # (the direct library call is the inference path's)
+        ms = _time_launch(lambda: K.linear(x, w, b, residual=r), iters)
     vendor = K.vendor_direct_calls["direct"] > v0
     arm = K._choice.get(("lin", M, N, Kd, bool(has_b), int(bool(has_r)), 0))
     flops = 2.0 * M * N * Kd
@@ -900,7 +903,7 @@ def oracle_step(unet, enc, ada, clip, text2, latents, t, want_config1=True, conf
     del ou, oe, oa
     base = {"value": round(1.0 / t_step, 6), "unit": "denoising steps/s", "cores": cores, "host_cpus": os.cpu_count(),
             "kind": "port",
-            "sample": f"ONE real step of the benchmarked configuration ({config}), not extrapolated: oracle (fp32 restatement; the reference "
+            "sample": f"{'the mean of three real steps' if full else 'ONE real step'} of the benchmarked configuration ({config}), not extrapolated: oracle (fp32 restatement; the reference "
                       f"needs diffusers) U-Net{'' if config == 'lora' else '+CMC'}{'+OMC' if config == 'obj' else ''} forward at CFG "
                       f"batch 2 on the 16x320x512 clip = {t_step:.2f} s on "
                       f"{cores} threads (thread policy: min(cpu_count, 16), oneDNN scaling collapses beyond; "
