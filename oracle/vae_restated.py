@@ -1,7 +1,9 @@
 """TEST INFRASTRUCTURE ONLY (see oracle/__init__.py): plain-PyTorch fp32 restatement of the DECODER of diffusers 0.24.0's
 `AutoencoderKL` as SD-1.5 configures it (`vae/config.json`: block_out_channels 128/256/512/512, layers_per_block 2, norm_num_groups 32,
 latent_channels 4; `fmc/pipelines/pipeline_animation_cm_om.py:465-478` calls `self.vae.decode(latents).sample`).
-PARITY UNPINNED: diffusers is not installed in the build container and the reference holds no vector for it; the module layout and
+PARITY UNPINNED against diffusers' outputs (diffusers is not installed in the build container and the reference holds no vector for it) -- cross-checked
+instead (tests/test_cpu_misc.py::test_vae_restatement_*): every primitive against torch built-ins and against the U-Net restatement's classes on the same
+weights, the tree against the published SD-1.5 VAE (83,653,863 parameters, checkpoint key names / shapes).  The module layout and
 arithmetic below restate the published implementation (models/vae.py `Decoder`, models/unet_2d_blocks.py `UNetMidBlock2D` /
 `UpDecoderBlock2D`, models/resnet.py `ResnetBlock2D(temb_channels=None)` / `Upsample2D`, models/attention_processor.py `Attention` with
 `residual_connection=True`, one head, `norm_num_groups=32`).  The CLIP text encoder needs no restatement: `transformers` is installed and
