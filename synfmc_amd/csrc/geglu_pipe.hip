@@ -68,6 +68,10 @@ __device__ __forceinline__ f32x2_t gp_gate2(f32x2_t v, f32x2_t g) {
 #ifndef GP_VPM8
 #define GP_VPM8 2
 #endif
+// A-fragment lookahead of the two-waves-per-SIMD form, in row blocks (3 and 4 measured the same as 2 once the order is pinned, see `step`)
+#ifndef GP_AFD8
+#define GP_AFD8 2
+#endif
 
 // GC_ = channels; NW_ waves; MB_ = 16-row blocks of the resident tile (every wave runs all of them); NBK_ = 16-row weight blocks per wave and chunk (half
 // values, half gates): <C, 4, 5, 4> = 80 rows, one wave per SIMD, 32 gated columns per wave; <320, 8, 10, 2> = 160 rows, two waves per SIMD, 16 gated columns
@@ -236,10 +240,11 @@ void geglu_pipe_kernel(const GPParams P) {
         __builtin_amdgcn_sched_barrier(0);
         // gate units of this k-step: unit u runs in k-step (u * KS) / NU
         constexpr int u_lo = (g * NU + KS - 1) / KS, u_hi = ((g + 1) * NU + KS - 1) / KS;      // units u with u_lo <= u < u_hi (at most one)
-        u32x4 af3[3];
+        constexpr int AFD = GP_AFD8;
+        u32x4 af3[AFD + 1];
         if constexpr (mma && !AF2) {
-            af3[0] = *reinterpret_cast<const u32x4*>(X + 0 * 16 * C + xo);
-            af3[1] = *reinterpret_cast<const u32x4*>(X + 1 * 16 * C + xo);
+#pragma unroll
+            for (int i = 0; i < AFD; ++i) af3[i] = *reinterpret_cast<const u32x4*>(X + i * 16 * C + xo);
         }
         if constexpr (mma) {
 #pragma unroll
@@ -249,8 +254,13 @@ void geglu_pipe_kernel(const GPParams P) {
                     afb[(S + 1) & 1][mb] = *reinterpret_cast<const u32x4*>(X + mb * 16 * C + xn);
                     a.u = afb[S & 1][mb];
                 } else {
-                    if (mb + 2 < MB) af3[(mb + 2) % 3] = *reinterpret_cast<const u32x4*>(X + (mb + 2) * 16 * C + xo);
-                    a.u = af3[mb % 3];
+                    if (mb + AFD < MB) af3[(mb + AFD) % (AFD + 1)] = *reinterpret_cast<const u32x4*>(X + (mb + AFD) * 16 * C + xo);
+                    // pin the fragment pipeline: LDS reads and MFMAs may not cross this point (VALU / SALU / transcendentals -- the gate -- may).  Left to the
+                    // scheduler's register-pressure heuristic the ring collapsed into ONE register quad: read, lgkmcnt(0), two MFMAs, read, ... -- a full
+                    // LDS round trip per row block (found in the ISA: 75 `s_waitcnt lgkmcnt(0)` per chunk; 161 -> 153 us once pinned).  Carrying the ring
+                    // across k-step boundaries as well costs 47 spilled registers: not done.
+                    __builtin_amdgcn_sched_barrier(0x406);
+                    a.u = af3[mb % (AFD + 1)];
                 }
 #pragma unroll
                 for (int nb = 0; nb < NBK; ++nb) {
@@ -259,6 +269,7 @@ void geglu_pipe_kernel(const GPParams P) {
                     if constexpr (g == 0) acc[par][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, a.v, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                     else acc[par][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, a.v, acc[par][mb][nb], 0, 0, 0);
                 }
+                if constexpr (!AF2) __builtin_amdgcn_sched_barrier(0x406);
             }
         }
         if constexpr (gate) {
@@ -270,10 +281,10 @@ void geglu_pipe_kernel(const GPParams P) {
         // MFMA GP_VPM gate instructions in its shadow.
         constexpr int NUS = gate ? u_hi - u_lo : 0, VPM = NUS == 0 ? 0 : VPMG;
         if constexpr (mma) {
-            if constexpr (!AF2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            if constexpr (!AF2) __builtin_amdgcn_sched_group_barrier(0x100, AFD, 0);
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
-                if (AF2 || mb + 2 < MB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (AF2 || mb + AFD < MB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
                 for (int nb = 0; nb < NBK; ++nb) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
