@@ -60,13 +60,14 @@ __device__ __forceinline__ f32x2_t gp_gate2(f32x2_t v, f32x2_t g) {
 #ifndef GP_WD
 #define GP_WD 3              // weight prefetch distance in k-steps (4-stage ring: at most 3)
 #endif
-// the 8-wave form lives on 256 registers per wave (2 x 80 accumulators): distance 1 and two gate instructions per MFMA are what fits without scratch
-// (distance 2: 38 spilled registers, 3: 62); its partner wave on the SIMD covers the shorter prefetch
+// the 8-wave form lives on 256 registers per wave (2 x 80 accumulators): a weight prefetch distance of 1 is what fits without scratch (distance 2: 38 spilled
+// registers, 3: 62; neither faster in a build without the gate); its partner wave on the SIMD covers the shorter prefetch.  Three gate instructions per MFMA
+// slot (since the accumulators start from the bias the gate is ~45 instructions per unit): 145 us against 150 with two
 #ifndef GP_WD8
 #define GP_WD8 1
 #endif
 #ifndef GP_VPM8
-#define GP_VPM8 2
+#define GP_VPM8 3
 #endif
 // A-fragment lookahead of the two-waves-per-SIMD form, in row blocks (3 and 4 measured the same as 2 once the order is pinned, see `step`)
 #ifndef GP_AFD8
@@ -164,8 +165,8 @@ void geglu_pipe_kernel(const GPParams P) {
     f32x4 acc[2][MB][NBK];
     u32x4 wfr[4][NBK];
     u32x4 afb[2][AF2 ? MB : 1];                                   // (AF2) A fragments: this k-step's and the next one's
-    u32x2 braw[2][2][NP];
-    f32x2_t bf[2][NP][2];                                         // bias of the chunk being gated, unpacked once: [value | gate][p][pair]
+    u32x2 braw[2][NP];                                            // bias words [value | gate][p] of the NEXT chunk (requested one chunk ahead)
+    f32x4 bq[NBK];                                                // ... of the chunk whose MFMAs are starting: its accumulators start from them
     int ooff[NP];                                                 // store offsets of the chunk being gated: (row l15, column 16 p + 4 kq) of my group                                          // [chunk parity][value | gate][block p]: bias words of the chunk whose MFMAs run in that parity
     auto wbase = [&](int ch) {
         int v = lane * 16 + (ch * NW + wave) * (WAVE_W * 2);
@@ -180,26 +181,31 @@ void geglu_pipe_kernel(const GPParams P) {
         const int ob = (blk_base + (col >> 5) * (160 * 32) + (mrow0 + r) * 32 + (col & 31)) * 2, orm = ((m0i + r) * P.cff + col) * 2;
         return blocked ? ob : orm;
     };
-    auto load_bias = [&](int par, int ch) {
+    // the accumulators START from the bias (the first k-step's MFMAs take it as their C operand: lane (row l15, kq) holds columns 4 kq .. + 3 of a block, the
+    // same four words for every row block), so the gate adds nothing: ~40 packed adds per chunk less, and no bias registers alive during the gate
+    auto load_bias = [&](int ch) {
         const int gc0 = ch * GCOLS + wave * GW;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int c0 = gc0 + 16 * p + 4 * kq;
-            braw[par][0][p] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsB, c0 * 2, 0, 0));
-            braw[par][1][p] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsB, (P.cff + c0) * 2, 0, 0));
+            braw[0][p] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsB, c0 * 2, 0, 0));
+            braw[1][p] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsB, (P.cff + c0) * 2, 0, 0));
         }
     };
-    // per gated chunk, once: the bias words as floats and the store offsets of row block 0 (row blocks are `rstep` bytes apart)
+    auto take_bias = [&]() {
+#pragma unroll
+        for (int nb = 0; nb < NBK; ++nb) {
+            const u32x2 w2 = braw[nb / NP][nb % NP];
+            const f32x2_t lo = gp_unpack2(w2[0]), hi = gp_unpack2(w2[1]);
+            bq[nb] = f32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+    };
+    // per gated chunk, once: the store offsets of row block 0 (row blocks are `rstep` bytes apart)
     const int rstep = blocked ? 16 * 32 * 2 : 16 * P.cff * 2;
-    auto unpack_bias = [&](auto par_c, int ch) {
-        constexpr int par = decltype(par_c)::value;
+    auto gate_setup = [&](int ch) {
         const int gc0 = ch * GCOLS + wave * GW;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            bf[0][p][0] = gp_unpack2(braw[par][0][p][0]); bf[0][p][1] = gp_unpack2(braw[par][0][p][1]);
-            bf[1][p][0] = gp_unpack2(braw[par][1][p][0]); bf[1][p][1] = gp_unpack2(braw[par][1][p][1]);
-            ooff[p] = out_off(l15, gc0 + 16 * p + 4 * kq);
-        }
+        for (int p = 0; p < NP; ++p) ooff[p] = out_off(l15, gc0 + 16 * p + 4 * kq);
     };
     // gate unit u = (row block mb = u / NP, column block p = u % NP) out of accumulator set `par`: 4 values of my lane -> one 8-byte store
     auto gate_unit = [&](auto par_c, auto u_c, int ch) {
@@ -209,8 +215,8 @@ void geglu_pipe_kernel(const GPParams P) {
 #ifdef GP_NOGATE   // diagnostic build: the MFMA stream with the cheapest possible consumer (wrong results)
         const f32x2_t o01 = v01 + g01, o23 = v23 + g23;
 #else
-        const f32x2_t o01 = gp_gate2(v01 + bf[0][p][0], g01 + bf[1][p][0]);
-        const f32x2_t o23 = gp_gate2(v23 + bf[0][p][1], g23 + bf[1][p][1]);
+        const f32x2_t o01 = gp_gate2(v01, g01);
+        const f32x2_t o23 = gp_gate2(v23, g23);
 #endif
         const u32x2 o = u32x2{pack_bf2(o01[0], o01[1]), pack_bf2(o23[0], o23[1])};
         __builtin_amdgcn_raw_buffer_store_b64(o, rsO, ooff[p], mb * rstep, 0);
@@ -227,8 +233,11 @@ void geglu_pipe_kernel(const GPParams P) {
 #pragma unroll
             for (int nb = 0; nb < NBK; ++nb) wfr[S2 % 4][nb] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wl, (g2 * NBK + nb) * 1024, 0);
         }
-        if constexpr (g == 0 && mma) load_bias(par, ch);          // used KS steps from now, by this chunk's gate
-        if constexpr (g == 0 && gate) unpack_bias(std::integral_constant<int, 1 - par>{}, ch - 1);
+        if constexpr (g == 0 && mma) {
+            take_bias();                                          // (requested a whole chunk ago)
+            load_bias(ch + 1);                                    // past the last chunk: out of range, zeros
+        }
+        if constexpr (g == 0 && gate) gate_setup(ch - 1);
         int kqx = kq ^ xsw, xrow_o = l15 * C;
         asm volatile("" : "+v"(kqx), "+v"(xrow_o));
         // AF2: the A fragments of THIS k-step were read during the previous one (afb[S & 1]); the next k-step's (k-step 0 again behind the last: X is the same
@@ -266,7 +275,7 @@ void geglu_pipe_kernel(const GPParams P) {
                 for (int nb = 0; nb < NBK; ++nb) {
                     union { bf16x8 v; u32x4 u; } w;
                     w.u = wfr[S % 4][nb];
-                    if constexpr (g == 0) acc[par][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, a.v, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    if constexpr (g == 0) acc[par][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, a.v, bq[nb], 0, 0, 0);
                     else acc[par][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, a.v, acc[par][mb][nb], 0, 0, 0);
                 }
                 if constexpr (!AF2) __builtin_amdgcn_sched_barrier(0x406);
@@ -294,6 +303,7 @@ void geglu_pipe_kernel(const GPParams P) {
         }
     };
 
+    load_bias(0);
     int wl0 = wbase(0), wl1 = wbase(1), wl2 = wbase(2);
 #pragma unroll
     for (int st = 0; st < WD; ++st)

@@ -385,6 +385,8 @@ class UNet3DConditionModel(nn.Module):
             cache = (key, w, b)
             object.__setattr__(self, "_temb_cat", cache)
         t_all = F.linear(F.silu(emb), cache[1], cache[2])               # [clips, sum Cout]
+        from .. import hip_ops as K
+        K._log_call("vendor", (emb.shape[0], cache[1].shape[0], cache[1].shape[1], True, False), 2.0 * emb.shape[0] * cache[1].numel())
         off = 0
         for r in rs:
             co = r.time_emb_proj.weight.shape[0]
