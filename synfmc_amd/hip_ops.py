@@ -2287,7 +2287,10 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     small = (ARM_SMALLM, ARM_SMALLM + 2) if (M <= 2560 and x2 is None and residual2 is None) else ()      # 64 x 128 tiles: 200-400 workgroups where 128 x 128 gives 100-200
     # the software-pipelined 160 x 160 kernel: a candidate wherever its tiles are at most two rounds of the chip (the inner levels' projections)
     t160 = ((M + 159) // 160) * ((N + 159) // 160)
-    if LINEAR4 and x2 is None and weight.is_contiguous() and 48 <= t160 <= 640 and Kd >= 320:
+    if (LINEAR4 and x2 is None and weight.is_contiguous() and 48 <= t160 <= 640 and Kd >= 320
+            and _lib.load().fmc_linear4_supported(M, N, Kd, _rows2d(x)[1])                       # (a strided x with ldx % 8 != 0 must not reach the tuner's timing loop)
+            and (residual is None or _rows2d(residual)[1] % 8 == 0)
+            and (residual2 is None or (residual is not None and _rows2d(residual2)[1] == _rows2d(residual)[1]))):
         small = small + (ARM_G4,)
     use = _pick(key, hip, lib, Kd <= 640 and N <= 1024 and M >= 16384, split_arms(M, N, Kd) + small,
                 k320=(Kd == 320 and N % 320 == 0 and M % 64 == 0 and x2 is None and residual2 is None))
