@@ -561,6 +561,17 @@ def test_fragment_order_weight_packers():
             base = 40 * NW * c + 40 * wv
             src = [base + row, base + 16 + row, (base + 32 + row) if row < 8 else (cff + base + 32 + row - 8), cff + base + row, cff + base + 16 + row][nb]
             assert frag(p, (((c * NW + wv) * KS + ks) * 5 + nb) * 512, lane, e) == w[src, 32 * ks + 8 * kq + e]
+    # pack_geglu_frag (csrc/geglu_pipe.hip): per group of G = 32 | 16 gated columns the rows [value blocks of 16 | gate blocks of 16], [group][k-step][block][lane][8]
+    for C, cff, G in ((320, 256, 16), (320, 256, 32), (640, 384, 32)):
+        w = torch.randn(2 * cff, C, generator=g)
+        p = K.pack_geglu_frag(w, G)
+        KS, NBK = C // 32, G // 8
+        assert p.numel() == w.numel()
+        for (grp, ks, nb, lane, e) in [(0, 0, 0, 0, 0), (cff // G - 1, KS - 1, NBK - 1, 63, 7), (1, 3, 1, 22, 5), (2, 1, NBK // 2, 9, 2)]:
+            row, kq = lane & 15, lane >> 4
+            half = NBK // 2
+            src = (G * grp + 16 * nb + row) if nb < half else (cff + G * grp + 16 * (nb - half) + row)      # value blocks first, then gate blocks
+            assert frag(p, ((grp * KS + ks) * NBK + nb) * 512, lane, e) == w[src, 32 * ks + 8 * kq + e]
 
 
 # ---- f4: the VAE restatement (oracle/vae_restated.py) cross-checked the only way this image allows: every primitive against torch
