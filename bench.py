@@ -397,25 +397,38 @@ def measure_linear_l0_roofline(device, dtype, iters=30):
 
 
 def measure_ff2_roofline(device, dtype, iters=20):
-    """The feed-forward's OUTPUT projection of the 40x64 level as the U-Net issues it behind `geglu_direct_kernel<320>`: `[81920, 1280] x [320, 1280]^T +
-    bias + residual`, the 210-MB intermediate in the tile-major layout the GEGLU kernel leaves (`linear_from_blocked`).  67 GF on 315 MB: arithmetic
-    intensity 213 flop / B, below the chip's ridge (312): HBM bound."""
+    """The feed-forward's OUTPUT projection of the 40x64 level as the U-Net issues it behind the LayerNorm + GEGLU kernel.  Round 6: folded with the
+    transformer's proj_out into ONE product (`hip_ops.ff_tail`): `[g | h] [Wp W2 | Wp]^T + b' + x`, `[81920, 1600] x [320, 1600]^T`, the 210-MB g in the
+    tile-major layout the GEGLU kernel leaves, h / x / out row-major: 84 GF on 367 MB, arithmetic intensity 229 flop / B, below the chip's ridge (312):
+    HBM bound.  (`FMC_FF_TAIL=0`: the un-folded `linear_from_blocked`, 67 GF on 315 MB, followed by a separate proj_out launch of 157 MB.)"""
     from synfmc_amd import hip_ops as K
     M, N, Kd = 2 * FRAMES * (HEIGHT // 8) * (WIDTH // 8), WIDTHS[0], 4 * WIDTHS[0]
     xb = torch.randn(M, Kd, device=device, dtype=dtype)
+    h = torch.randn(M, N, device=device, dtype=dtype)
     r = torch.randn(M, N, device=device, dtype=dtype)
     w = torch.randn(N, Kd, device=device, dtype=dtype) * Kd ** -0.5
     b = torch.randn(N, device=device, dtype=dtype)
-    if not K.geglu_direct_blocked_ok(xb[:, :N].contiguous(), w, r):
+    if not K.geglu_direct_blocked_ok(h, w, r):
         return None
+    wp = torch.randn(N, N, device=device, dtype=dtype) * N ** -0.5
     with torch.no_grad():
-        ms = _time_launch(lambda: K.linear_from_blocked(xb, w, b, r), iters)
-    nbytes = 2.0 * (M * Kd + 2 * M * N + N * Kd)
+        tail = K.ff_tail_ok(h, w, wp, r)
+        if tail:
+            wc, bc = K.fold_ff_tail(w, b, wp, b)
+            ms = _time_launch(lambda: K.ff_tail(xb, h, wc, bc, r, gn_hw=(HEIGHT // 8) * (WIDTH // 8)), iters)
+            Kd2 = Kd + N
+            nbytes, flops = 2.0 * (M * Kd + 3 * M * N + N * Kd2), 2.0 * M * N * Kd2
+            what, tag = "feed-forward output projection folded with proj_out + bias + residual + GroupNorm partials, two-segment reduction", "ff-tail"
+        else:
+            ms = _time_launch(lambda: K.linear_from_blocked(xb, w, b, r), iters)
+            Kd2 = Kd
+            nbytes, flops = 2.0 * (M * Kd + 2 * M * N + N * Kd), 2.0 * M * N * Kd
+            what, tag = "feed-forward output projection + bias + residual", "from-blocked"
     gbs = nbytes / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": f"gemm160p_kernel<blocked A> (feed-forward output projection + bias + residual, tile-major intermediate) [{M}x{N}x{Kd}]",
+    return {"bound": "hbm", "kernel": f"gemm160p_kernel<blocked A> ({what}, tile-major intermediate) [{M}x{N}x{Kd2}]",
             "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "avg_launch_ms": round(ms, 5), "bytes_per_launch": nbytes,
-            "flops_per_launch": 2.0 * M * N * Kd, "mfma_frac_isolated": round(2.0 * M * N * Kd / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None,
-            "_match": ("own_linear", lambda sh, M=M, N=N, Kd=Kd: sh[:4] == (M, N, Kd, "from-blocked"))}
+            "flops_per_launch": flops, "mfma_frac_isolated": round(flops / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "_match": ("own_linear", lambda sh, M=M, N=N, Kd2=Kd2, tag=tag: sh[:4] == (M, N, Kd2, tag))}
 
 
 def measure_vendor_roofline(device, dtype, call_log, iters=30):

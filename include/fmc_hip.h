@@ -305,6 +305,17 @@ int fmc_linear_bf16_lnc(const void* x, const void* w_gamma, void* out, int64_t M
 int fmc_linear_bf16_ffblk(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int N, int K,
                           int64_t ldres, float alpha, int epilogue, int x_blocked, int out_blocked, const float* ln_stats, const float* ln_c,
                           const float* ln_bias, int w_tilemajor, void* stream);
+/* The feed-forward's output projection and the transformer's proj_out as ONE product (diffusers BasicTransformerBlock `ff(norm3(h)) + h` followed by
+ * Transformer2DModel.proj_out + residual, fmc/models/unet_blocks.py:323-333; the motion module's `ff(ff_norm(h)) + h` followed by
+ * TemporalTransformer3DModel.proj_out + residual, fmc/models/motion_module.py:130-134,295-299):
+ *   proj_out(ff2(g) + b2 + h) + bp + x  =  [g | h] [Wp W2 | Wp]^T + (Wp b2 + bp) + x
+ * x_blocked = the gated intermediate g, tile-major [M / 160][k_split / 32][160][32] (fmc_geglu*_ln_bf16 / fmc_geglu_pipe_ln_bf16 with out_blocked);
+ * x2 = h, row-major [M, K - k_split] with rows ldx2 apart; w = the folded weight [N, K] (the caller folds it once per weight version, in fp32, and
+ * rounds once), tile-major if w_tilemajor; gn_partials (may be NULL) as fmc_linear_bf16_gn.  One launch and two HBM passes less than the pair; the
+ * block's output before proj_out is never rounded to bf16.  Tile 16's persistent form only: M % 160 == 0, N % 320 == 0, at least as many tiles as CUs,
+ * k_split % 64 == 0. */
+int fmc_linear_bf16_fftail(const void* x_blocked, const void* x2, const void* w, const void* bias, const void* residual, void* out, int64_t M,
+                           int N, int K, int k_split, int64_t ldx2, int64_t ldres, float* gn_partials, int gn_hw, int w_tilemajor, void* stream);
 int fmc_conv3x3_bf16_gn(const void* x, const void* w, const void* bias, const void* temb, const void* residual, void* out, int n_img,
                         int H, int W, int Cin, int Cout, int64_t temb_row_stride, int temb_img_div, int upsample2x,
                         float* gn_partials, int w_tilemajor, void* stream);

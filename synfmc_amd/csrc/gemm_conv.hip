@@ -1855,7 +1855,11 @@ void gemm160_kernel(const GemmParams P) {
 // `(v - mean) * rstd * gamma + (beta + pe row)` in place by (8-column chunk, row group) threads that keep their gamma / beta in registers,
 // whole-row stores.  (Statistics and normalisation straight from the accumulator registers -- the first form -- cost 110-200 spilled
 // registers, reloaded inside the main loop.)  The separate LayerNorm launch and its read of the tensor disappear.
-template <int EPI, int MB, int LN = 0, int LNC = 0>
+// A2 = 1 (plain epilogue, tile-major A): the reduction has a SECOND segment -- columns [ksplit, K) of A are rows of the row-major tensor a2 (lda2 apart).
+// The feed-forward's output projection and the transformer's proj_out as ONE product: out = [gated | h] [Wp W2 | Wp]^T + b' + x (hip_ops.ff_tail); the
+// stream's A requests of a sub-tile past ksplit / 32 go to a2 with ONE per-lane offset (row in piece, 16-byte chunk) and the piece / k position in the
+// scalar offset, so the variant costs one register over the plain one.
+template <int EPI, int MB, int LN = 0, int LNC = 0, int A2 = 0>
 __global__ __launch_bounds__(512, 2)
 void gemm160p_kernel(const GemmParams P) {
     constexpr int BM = 32 * MB, BN = 320, BK = 32, NT = 512, NBUF = 3;
@@ -1880,6 +1884,7 @@ void gemm160p_kernel(const GemmParams P) {
     const int prow = lane >> 2, pch = lane & 3;
     const int psrc = pch ^ (3 * ((prow >> 3) & 1));
     const int nks = P.K / BK;
+    const int nksA = A2 ? P.ksplit / BK : nks;       // sub-tiles (= 10-KiB blocks per row tile) of the first A segment
     const int total = P.tiles_m * P.tiles_n;
     auto tile_of = [&](int id, int& tm, int& tn) {
         const int q = total >> 3, r = total & 7, x = id & 7;
@@ -1890,6 +1895,9 @@ void gemm160p_kernel(const GemmParams P) {
     constexpr unsigned OOB = 0x80000000u;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)P.a, 0, (int)P.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)P.w, 0, (int)((int64_t)P.N * P.K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(A2 ? P.a2 : P.a), 0, A2 ? (int)(((P.M - 1) * P.lda2 + (P.K - P.ksplit)) * 2) : 0, 0x00020000);
+    const unsigned lane_a2 = A2 ? (unsigned)((prow * P.lda2 + psrc * 8) * 2) : 0u;
+    int s_m0 = 0;                                     // first row of the stream's current tile (A2), < 0 past the last tile
     // ---- the operand stream: entry i = 4 wave + e; i < 20: W piece i, 20 <= i < 30: A piece i - 20, else a dummy ---------------------
     unsigned e_vo[NE];
     int e_lds[NE];
@@ -1904,6 +1912,7 @@ void gemm160p_kernel(const GemmParams P) {
         int tm = 0, tn = 0;
         const bool live = s_tile < total;
         if (live) tile_of(s_tile, tm, tn);
+        if (A2) s_m0 = live ? tm * BM : -1;
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const int i = NE * wave + e;
@@ -1914,7 +1923,7 @@ void gemm160p_kernel(const GemmParams P) {
                                  : (unsigned)(((int64_t)n * P.K + psrc * 8) * 2);
             } else if (live && i < 20 + BM / 16) {
                 const int64_t m = (int64_t)tm * BM + 16 * (i - 20) + prow;
-                vo = P.a_blocked ? (unsigned)((((int64_t)tm * nks) * (BM * BK) + (16 * (i - 20) + prow) * BK + psrc * 8) * 2)
+                vo = P.a_blocked ? (unsigned)((((int64_t)tm * nksA) * (BM * BK) + (16 * (i - 20) + prow) * BK + psrc * 8) * 2)
                                  : (unsigned)((m * P.lda + psrc * 8) * 2);
             }
             e_vo[e] = vo;
@@ -1923,10 +1932,21 @@ void gemm160p_kernel(const GemmParams P) {
     auto issue = [&]() {
         const int soff = w_wave ? (P.w_blocked ? it_s * (BN * BK * 2) : it_s * BK * 2)          // (tile-major operands: the next sub-tile is the next block)
                                 : (P.a_blocked ? it_s * (BM * BK * 2) : it_s * BK * 2);
+        if (A2 && !w_wave && it_s >= nksA) {          // second A segment: piece i - 20 of rows s_m0 ... of a2, k position (it_s - nksA) * 32   (wave-uniform branch)
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const int i = NE * wave + e;
+                const bool real = s_m0 >= 0 && i < 20 + BM / 16;
+                const int dst = e_lds[e] == NBUF * SUB_ELEMS ? NBUF * SUB_ELEMS : it_buf * SUB_ELEMS + e_lds[e];
+                const int so2 = real ? (int)((((int64_t)s_m0 + 16 * (i - 20)) * P.lda2 + (it_s - nksA) * BK) * 2) : 0;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (__attribute__((address_space(3))) void*)(lds0 + 2 * dst), 16, real ? (int)lane_a2 : (int)OOB, so2, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int e = 0; e < NE; ++e) {                // (LDS destinations as wave-uniform 32-bit offsets: they travel through M0)
             const int dst = e_lds[e] == NBUF * SUB_ELEMS ? NBUF * SUB_ELEMS : it_buf * SUB_ELEMS + e_lds[e];
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_wave ? rsW : rsA, (__attribute__((address_space(3))) void*)(lds0 + 2 * dst), 16, (int)e_vo[e], soff, 0, 0);
+        }
         }
         it_buf = it_buf + 1 == NBUF ? 0 : it_buf + 1;
         if (++it_s == nks) {
@@ -2800,7 +2820,7 @@ void launch_gemm_k320(GemmParams& P, hipStream_t st) {
 
 // tile 16: plain grid only (whole rounds are the point); N must be a multiple of 320 (GEGLU: weight rows per 16 = [8 value | 8 gate])
 bool gemm160_ok(const GemmParams& P) {
-    return P.N % 320 == 0 && !P.sk && !P.a2;           // (split_k > 1: plain epilogue only -- set_split_k has checked)
+    return P.N % 320 == 0 && !P.sk && (!P.a2 || P.a_blocked);   // (split_k > 1: plain epilogue only -- set_split_k has checked; a2: the persistent form's A2 variant, linear_impl has checked)
 }
 template <int MODE, int EPI>
 void launch_gemm160(GemmParams& P, hipStream_t st) {
@@ -2847,6 +2867,17 @@ void launch_gemm160(GemmParams& P, hipStream_t st) {
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm160p_kernel<0, 5, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
                 }
                 raisedp = true;
+            }
+            if constexpr (EPI == 0) {
+                if (P.a2) {                                   // two-segment reduction (linear_impl has checked: tile-major first segment, plain epilogue)
+                    static FmcPerDeviceFlag raised2;
+                    if (!raised2) {
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm160p_kernel<0, 5, 0, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+                        raised2 = true;
+                    }
+                    hipLaunchKernelGGL((gemm160p_kernel<0, 5, 0, 0, 1>), dim3((unsigned)cus), dim3(512), ldsp, st, P);
+                    return;
+                }
             }
             if (P.lnc_stats) {                                // this GEMM applies the LayerNorm of its input rows (linear_impl has checked the rest)
                 hipLaunchKernelGGL((gemm160p_kernel<EPI, 5, 0, 1>), dim3((unsigned)cus), dim3(512), ldsp, st, P);
@@ -2900,9 +2931,9 @@ void launch_gemm256p(GemmParams& P, hipStream_t st) {
 bool gemm8_ok(GemmParams& P) {
     // operand sizes as the buffer descriptors see them (conv: the whole input tensor; token: up to the end of the last row)
     const int64_t a_elems = P.hw > 1 ? (P.ups == 1 ? (P.M / 4) * (int64_t)P.cin : P.M * (int64_t)P.cin * (P.ups == 2 ? 4 : 1))
-                                     : (P.M - 1) * P.lda + P.K;
+                                     : (P.a2 && P.a_blocked ? P.M * (int64_t)P.ksplit : (P.M - 1) * P.lda + P.K);
     P.a_bytes = a_elems * 2;
-    return P.split_k == 1 && !P.a2 && P.a_bytes < ((int64_t)1 << 31) && (int64_t)P.N * P.K * 2 < ((int64_t)1 << 31);
+    return P.split_k == 1 && (!P.a2 || P.a_blocked) && P.a_bytes < ((int64_t)1 << 31) && (int64_t)P.N * P.K * 2 < ((int64_t)1 << 31);
 }
 
 // tile arms (fmc_hip.h): geometry x k-tile depth x ring depth
@@ -3024,7 +3055,7 @@ static int linear_impl(const void* x, const void* w, const void* bias, const voi
     P.M = M; P.N = N; P.K = K; P.lda = ldx; P.ldres = ldres; P.ldo = ldo;
     P.img_h = P.img_w = P.cin = 0; P.hw = 1; P.alpha = alpha; P.temb_ld = 0; P.temb_div = 1; P.ups = 0;
     P.f32io = f32io;
-    if (gn_partials && (f32io || epilogue != 0 || tile != 16 || split_k != 1 || gn_hw <= 0 || gn_hw % 160 || M % gn_hw || N % 320 || x2 ||
+    if (gn_partials && (f32io || epilogue != 0 || tile != 16 || split_k != 1 || gn_hw <= 0 || gn_hw % 160 || M % gn_hw || N % 320 || (x2 && !a_blocked) ||
                         ((M - 1) * ldx + K) * 2 >= ((int64_t)1 << 31) || (int64_t)N * K * 2 >= ((int64_t)1 << 31)))
         FMC_FAIL(FMC_E_SHAPE, "linear_bf16: GroupNorm partials come out of tile 16's plain bf16 epilogue only (N %% 320 == 0, pixels per image %% 160 == 0)");
     P.gn_part = (float*)gn_partials; P.gn_hw = gn_hw;
@@ -3040,10 +3071,13 @@ static int linear_impl(const void* x, const void* w, const void* bias, const voi
     P.lnc_stats = lnc_stats; P.lnc_c = lnc_c; P.lnc_bias = lnc_bias;
     if (a_blocked || out_blocked) {                           // tile-major intermediate of the feed-forward: persistent form of tile 16 only
         const int cus = fmc_cu_count() & ~7;
-        if (f32io || tile != 16 || split_k != 1 || gn_partials || x2 || N % 320 || M % 160 || cus < 8 ||
+        // (x2 with a tile-major x: the reduction's second segment [k_split, K) comes from row-major x2 -- gemm160p_kernel's A2 variant, plain epilogue,
+        //  GroupNorm partials allowed: fmc_linear_bf16_fftail)
+        if (f32io || tile != 16 || split_k != 1 || (gn_partials && !(a_blocked && x2 && !out_blocked)) || (x2 && (!a_blocked || out_blocked)) || N % 320 || M % 160 || cus < 8 ||
             (out_blocked && (M / 160) * (N / 320) <= cus) ||                      // (the GEGLU epilogue that writes tile-major is the persistent form's)
             (a_blocked && (M / 160) * (N / 320) < cus) ||
-            (a_blocked && (epilogue != 0 || ldx != K || K % 32)) || (out_blocked && (epilogue != 1 || ldo != N / 2 || (N / 2) % 32)) ||
+            (a_blocked && (epilogue != 0 || ldx != (x2 ? k_split : K) || K % 32)) ||
+            (x2 && (ln_out || ln_stats || lnc_stats || ((M - 1) * ldx2 + (K - k_split)) * 2 >= ((int64_t)1 << 31))) || (out_blocked && (epilogue != 1 || ldo != N / 2 || (N / 2) % 32)) ||
             (int64_t)M * (a_blocked ? K : N / 2) * 2 >= ((int64_t)1 << 31) || (getenv("FMC_G160_PERSIST") && atoi(getenv("FMC_G160_PERSIST")) == 0))
             FMC_FAIL(FMC_E_SHAPE, "linear_bf16: the tile-major feed-forward intermediate needs tile 16's persistent form (M %% 160 == 0, N %% 320 == 0, "
                                   "more tiles than CUs, dense rows)");
@@ -3068,7 +3102,7 @@ static int linear_impl(const void* x, const void* w, const void* bias, const voi
     if (tile < 0 || tile > GEMM_TILE_MAX) FMC_FAIL(FMC_E_SHAPE, "linear_bf16: tile %d", tile);
     P.w_blocked = 0;
     if (w_tilemajor) {                                        // no other kernel can read that weight: everything that would leave tile 16 is an error
-        if (tile != 16 || f32io || N % 320 || x2 || split_k < 1 || ((M - 1) * ldx + K) * 2 >= ((int64_t)1 << 31) || (int64_t)N * K * 2 >= ((int64_t)1 << 31))
+        if (tile != 16 || f32io || N % 320 || (x2 && !a_blocked) || split_k < 1 || ((M - 1) * ldx + K) * 2 >= ((int64_t)1 << 31) || (int64_t)N * K * 2 >= ((int64_t)1 << 31))
             FMC_FAIL(FMC_E_SHAPE, "linear_bf16: a tile-major weight (tile 18) needs bf16, N %% 320 == 0, no two-source operand, no stream-K, operands < 2 GiB");
         P.w_blocked = 1;
     }
@@ -3118,6 +3152,13 @@ extern "C" int fmc_linear_bf16_ffblk(const void* x, const void* w, const void* b
     const int n_out = epilogue == 1 ? N / 2 : N;
     return linear_impl(x, w, bias, residual, out, M, N, K, K, ldres, n_out, alpha, epilogue, 16, 1, nullptr, 0, nullptr, 0, 0, nullptr, stream, 0,
                        nullptr, 0, nullptr, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr, ln_stats, ln_c, ln_bias, x_blocked, out_blocked, w_tilemajor);
+}
+
+extern "C" int fmc_linear_bf16_fftail(const void* x_blocked, const void* x2, const void* w, const void* bias, const void* residual, void* out, int64_t M,
+                                      int N, int K, int k_split, int64_t ldx2, int64_t ldres, float* gn_partials, int gn_hw, int w_tilemajor, void* stream) {
+    if (!x2) FMC_FAIL(FMC_E_NULL, "linear_bf16_fftail: NULL x2 (use fmc_linear_bf16_ffblk)");
+    return linear_impl(x_blocked, w, bias, residual, out, M, N, K, k_split, ldres, N, 1.f, 0, 16, 1, nullptr, 0, x2, ldx2, k_split, nullptr, stream, 0,
+                       gn_partials, gn_hw, nullptr, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr, nullptr, nullptr, nullptr, 1, 0, w_tilemajor);
 }
 
 extern "C" int fmc_linear_x3_f32(const void* x3, const void* w3, const float* bias, const float* residual, float* out, int64_t M,

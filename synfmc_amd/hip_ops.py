@@ -1695,6 +1695,59 @@ def linear_from_blocked(xb: torch.Tensor, weight: torch.Tensor, bias, residual, 
     return out
 
 
+FF_TAIL = os.environ.get("FMC_FF_TAIL", "1") != "0"             # A/B switch: feed-forward output projection + proj_out as one product (below)
+
+
+def ff_tail_ok(h: torch.Tensor, w2: torch.Tensor, wp: torch.Tensor, tail_residual: Optional[torch.Tensor]) -> bool:
+    """`proj_out(ff2(g) + b2 + h) + bp + x` as ONE launch on the tile-major intermediate (`ff_tail`): the level-0 transformers, where both GEMMs are
+    HBM passes (K = 1280 and K = 320 on 81 920 rows) -- the folded product reads g, h and x once and writes once, the block's output is never stored."""
+    C = h.shape[-1]
+    M = h.numel() // C
+    return (FF_TAIL and not torch.is_grad_enabled() and h.dtype == torch.bfloat16 and h.is_contiguous() and wp.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16
+            and wp.ndim == 2 and wp.shape[1] == w2.shape[0] == C and wp.shape[0] % 320 == 0 and C % 64 == 0 and w2.shape[1] % 64 == 0
+            and M % 160 == 0 and (M // 160) * (wp.shape[0] // 320) >= _cus(h.device) and M * max(w2.shape[1], C) * 2 < (1 << 31)
+            and tail_residual is not None and tail_residual.dtype == h.dtype and tail_residual.is_contiguous()
+            and tail_residual.numel() == M * wp.shape[0] and os.environ.get("FMC_G160_PERSIST", "1") != "0")
+
+
+def fold_ff_tail(w2: torch.Tensor, b2: Optional[torch.Tensor], wp: torch.Tensor, bp: Optional[torch.Tensor]):
+    """([Wp W2 | Wp] as bf16 [N, Cff + C], Wp b2 + bp as bf16 [N] or None): folded in fp32, rounded once."""
+    with torch.no_grad():
+        wpf = wp.detach().float()
+        wc = torch.cat([wpf @ w2.detach().float(), wpf], dim=1).to(torch.bfloat16).contiguous()
+        bc = None
+        if b2 is not None or bp is not None:
+            bc = (wpf @ b2.detach().float()) if b2 is not None else torch.zeros(wp.shape[0], dtype=torch.float32, device=wp.device)
+            if bp is not None:
+                bc = bc + bp.detach().float()
+            bc = bc.to(torch.bfloat16).contiguous()
+    return wc, bc
+
+
+def ff_tail(mid_blocked: torch.Tensor, h: torch.Tensor, w_cat: torch.Tensor, b_cat: Optional[torch.Tensor], tail_residual: torch.Tensor,
+            gn_hw: int = 0) -> torch.Tensor:
+    """`[g | h] @ w_cat^T + b_cat + tail_residual` (`fmc_linear_bf16_fftail`): g = `mid_blocked`, the tile-major gated intermediate; `h` row-major `[M, C]`.
+    With `gn_hw` the 160-row tiles also leave the consumer GroupNorm's partial sums (as `linear_gn`).  Returns `[..., N]` in `tail_residual`'s shape."""
+    _dev(mid_blocked, h, w_cat, b_cat, tail_residual)
+    N, Kd = w_cat.shape
+    C = h.shape[-1]
+    M = h.numel() // C
+    assert mid_blocked.numel() == M * (Kd - C) and tail_residual.numel() == M * N
+    out = torch.empty_like(tail_residual)
+    part = None
+    if gn_hw and gn_emit_ok(M, N, Kd, gn_hw, h.dtype):
+        part = torch.empty(M // gn_hw, gn_hw // 160, 32, 2, dtype=torch.float32, device=h.device)
+        gn_epilogue_calls["emitted"] += 1
+    wt = _w_tilemajor(w_cat) if W_TILEMAJOR else w_cat
+    _log_call("own_linear", (M, N, Kd, "ff-tail", 1), 2.0 * M * N * Kd)
+    _lib.check(_lib.load().fmc_linear_bf16_fftail(mid_blocked.data_ptr(), h.data_ptr(), wt.data_ptr(), _p(b_cat), tail_residual.data_ptr(), out.data_ptr(),
+                                                  M, N, Kd, Kd - C, C, N, _p(part), int(gn_hw if part is not None else 0), int(W_TILEMAJOR), _stream()),
+               "fmc_linear_bf16_fftail")
+    if part is not None:
+        out._fmc_gn = (part, N)
+    return out
+
+
 def linear_gn(x: torch.Tensor, weight: torch.Tensor, bias, residual, alpha: float, residual2, hw: int):
     """`linear_bf16` on the 160 x 320 kernel + the GroupNorm partial sums of the output: (out, partials [M / hw, hw / 160, 32, 2])."""
     _dev(x, weight, bias, residual)

@@ -618,8 +618,20 @@ class FeedForward(nn.Module):
         self.net = nn.ModuleList([GEGLU(dim, inner), nn.Dropout(dropout),
                                   Linear(inner, dim if dim_out is None else dim_out)])
 
-    def forward_ln(self, h, norm, residual):
-        """`ff(norm(h)) + residual` with LayerNorm + GEGLU projection as one launch where `hip_ops.geglu_ln_direct` exists (the 20x32 level), else None."""
+    def _tail_weights(self, wp, bp):
+        """The output projection folded into the transformer's proj_out (`hip_ops.fold_ff_tail`), cached per weight version."""
+        out = self.net[2]
+        ts = [out.weight, out.bias, wp, bp]
+        key = tuple((t.data_ptr(), t._version) if t is not None else None for t in ts)
+        hit = self.__dict__.get("_tail_fold")
+        if hit is None or hit[0] != key:
+            hit = (key, K.fold_ff_tail(out.weight, out.bias, wp, bp), ts)      # (the entry keeps the tensors alive: an equal pointer means the same storage)
+            self.__dict__["_tail_fold"] = hit
+        return hit[1]
+
+    def forward_ln(self, h, norm, residual, tail=None):
+        """`ff(norm(h)) + residual` with LayerNorm + GEGLU projection as one launch where `hip_ops.geglu_ln_direct` exists (the 20x32 level), else None.
+        `tail = (W_p, b_p, x, gn_hw)`: the caller's next op is `proj_out(.) + x` -- where `hip_ops.ff_tail_ok` holds the result is THAT (tagged `_fmc_tail`)."""
         proj, out = self.net[0], self.net[2]
         w = proj.proj.weight
         if not K.geglu_ln_direct_ok(h, w) or getattr(h, "_fmc_pending_add", None) is not None or getattr(h, "_fmc_ln", None) is not None \
@@ -639,6 +651,11 @@ class FeedForward(nn.Module):
                                   variant=var)
         else:
             mid = K.geglu_ln_direct(h, f32_param(norm, "weight"), f32_param(norm, "bias"), norm.eps, hit[1], proj.proj.bias, w.shape[0] // 2, blocked=blocked)
+        if blocked and tail is not None and residual is h and K.ff_tail_ok(h, out.weight, tail[0], tail[2]):
+            wc, bc = self._tail_weights(tail[0], tail[1])
+            y = K.ff_tail(mid, h, wc, bc, tail[2], tail[3])
+            y._fmc_tail = True
+            return y
         if blocked:
             return K.linear_from_blocked(mid, out.weight, out.bias, residual)
         return out(mid, residual=residual)
@@ -729,7 +746,8 @@ class BasicTransformerBlock(nn.Module):
 
     def forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, timestep=None, cross_attention_kwargs=None, class_labels=None,
-                cfg_expand: bool = False):
+                cfg_expand: bool = False, tail=None):
+        """`tail`: see `FeedForward.forward_ln` (the enclosing transformer's proj_out, taken into the feed-forward's last launch where that exists)."""
         kw = dict(cross_attention_kwargs) if cross_attention_kwargs is not None else {}
         kw.pop("gligen", None)
         # the LayerNorm behind each attention leaves its output projection's epilogue where the tile holds whole rows (hip_ops.linear_ln)
@@ -778,7 +796,7 @@ class BasicTransformerBlock(nn.Module):
             hidden_states = self.attn2(n, encoder_hidden_states=encoder_hidden_states, attention_mask=encoder_attention_mask,
                                        _residual=hidden_states, **kw)
         if not torch.is_grad_enabled():
-            y = self.ff.forward_ln(hidden_states, self.norm3, hidden_states)
+            y = self.ff.forward_ln(hidden_states, self.norm3, hidden_states, tail=tail)
             if y is not None:
                 return y
         hidden_states, n = self.norm3.skip(hidden_states, defer=True)
@@ -829,14 +847,18 @@ class Transformer2DModel(nn.Module):
         x = linear_op(x, self.proj_in.weight.view(self.proj_in.out_channels, c), self.proj_in.bias,
                       ln=None if torch.is_grad_enabled() else self.transformer_blocks[0].norm1.ln_spec(
                           stats_only=type(self.transformer_blocks[0].attn1.processor).__name__ in ("AttnProcessor", "LoRAAttnProcessor")))
+        if cfg_expand:
+            residual = torch.cat([residual, residual], dim=0)
+        wp = self.proj_out.weight.view(c, self.proj_out.in_channels)
+        last = len(self.transformer_blocks) - 1
         for bi, blk in enumerate(self.transformer_blocks):
             x = blk(x, attention_mask=attention_mask, encoder_hidden_states=encoder_hidden_states,
                     encoder_attention_mask=encoder_attention_mask, timestep=timestep,
                     cross_attention_kwargs=cross_attention_kwargs, class_labels=class_labels,
-                    **({"cfg_expand": True} if (cfg_expand and bi == 0) else {}))
-        if cfg_expand:
-            residual = torch.cat([residual, residual], dim=0)
-        x = linear_op(x, self.proj_out.weight.view(c, self.proj_out.in_channels), self.proj_out.bias, residual,
-                      gn_hw=h * w)                                   # (the motion module / next ResNet block opens with a GroupNorm)
+                    **({"cfg_expand": True} if (cfg_expand and bi == 0) else {}),
+                    # (the last block's feed-forward may take proj_out + residual into its own last launch: hip_ops.ff_tail)
+                    **({"tail": (wp, self.proj_out.bias, residual, h * w)} if (bi == last and not torch.is_grad_enabled()) else {}))
+        if not getattr(x, "_fmc_tail", False):
+            x = linear_op(x, wp, self.proj_out.bias, residual, gn_hw=h * w)      # (the motion module / next ResNet block opens with a GroupNorm)
         out = from_tokens(x, h, w)
         return Transformer2DModelOutput(out) if return_dict else (out,)

@@ -217,7 +217,7 @@ class TemporalTransformerBlock(nn.Module):
             proc.__dict__["_fused_wm"] = hit
         return hit[1]
 
-    def _forward_fused(self, hidden_states, cross_attention_kwargs):
+    def _forward_fused(self, hidden_states, cross_attention_kwargs, tail=None):
         frames = hidden_states.shape[1]
         h = hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()
         n_blocks = len(self.attention_blocks)
@@ -252,16 +252,16 @@ class TemporalTransformerBlock(nn.Module):
             K.ln_epilogue_calls["emitted"] += 1
             h._fmc_ln = (stats, self.ff_norm._ln_key(None, 1, 1), True)
         if stats is None:
-            y = self.ff.forward_ln(h, self.ff_norm, h)       # (the 20x32 level: LayerNorm + GEGLU projection as one launch)
+            y = self.ff.forward_ln(h, self.ff_norm, h, tail=tail)       # (LayerNorm + GEGLU projection as one launch; `tail`: + proj_out, hip_ops.ff_tail)
             if y is not None:
                 return y
         hidden_states, n = self.ff_norm.skip(h, defer=True)
         return self.ff(n, residual=hidden_states)
 
     def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None,
-                cross_attention_kwargs: Dict[str, Any] = {}):
+                cross_attention_kwargs: Dict[str, Any] = {}, tail=None):
         if not torch.is_grad_enabled() and self.fused_blocks_ok(hidden_states, attention_mask, cross_attention_kwargs):
-            return self._forward_fused(hidden_states, cross_attention_kwargs)
+            return self._forward_fused(hidden_states, cross_attention_kwargs, tail)
         if hidden_states.ndim == 4:
             frames, inner = hidden_states.shape[1], hidden_states.shape[2]
         else:
@@ -344,10 +344,14 @@ class TemporalTransformer3DModel(nn.Module):
             ln0 = blk0.norms[0].ln_spec() if enc0 is None else blk0.norms[0].ln_spec(enc0.table(), h * w, f)
         x = linear_op(x, self.proj_in.weight, self.proj_in.bias, ln=ln0)
         x = K.carry_ln(x, x.view(b, f, h * w, -1))
-        for block in self.transformer_blocks:
+        last = len(self.transformer_blocks) - 1
+        for bi, block in enumerate(self.transformer_blocks):
             x = block(x, encoder_hidden_states=encoder_hidden_states, attention_mask=attention_mask,
-                      cross_attention_kwargs=cross_attention_kwargs)
-        x = linear_op(x.view(b * f, h * w, -1), self.proj_out.weight, self.proj_out.bias, residual, gn_hw=h * w)
+                      cross_attention_kwargs=cross_attention_kwargs,
+                      # (the last block's feed-forward may take proj_out + residual into its own last launch: hip_ops.ff_tail)
+                      **({"tail": (self.proj_out.weight, self.proj_out.bias, residual, h * w)} if (bi == last and not torch.is_grad_enabled()) else {}))
+        if not getattr(x, "_fmc_tail", False):
+            x = linear_op(x.view(b * f, h * w, -1), self.proj_out.weight, self.proj_out.bias, residual, gn_hw=h * w)
         return K.carry_gn(x, x.view(b, f, h, w, c).permute(0, 4, 1, 2, 3))   # (the next ResNet block / conv_norm_out opens with a GroupNorm)
 
 

@@ -2165,3 +2165,53 @@ def test_geglu_ln_pipe(K, M, cff, C, variant):
         assert bool((d <= 2.0 ** -7 * ref_r.abs() + 1e-3).all())
     with pytest.raises(ValueError):
         K.geglu_ln_pipe(hd[:M - 8].contiguous(), go.cuda(), bo.cuda(), 1e-5, wp, bid, cff, variant=variant)
+
+
+@pytest.mark.parametrize("M,cff,C,hw", [(81920, 1280, 320, 2560), (40960, 1280, 320, 0), (46080, 640, 320, 2560)])
+def test_ff_tail_folded_output_projection_and_proj_out(K, M, cff, C, hw):
+    """`fmc_linear_bf16_fftail` (gemm160p_kernel's two-segment reduction): `proj_out(ff2(g) + b2 + h) + bp + x` as ONE product `[g | h] [Wp W2 | Wp]^T + b' + x`
+    on the tile-major g -- against the un-folded fp32 chain on the same rounded inputs (the fold re-rounds the weight once: bf16 noise, not bit equality),
+    element-wise against the folded product in fp64 (one rounding of an fp32 accumulator), the GroupNorm partial sums against the rounded output, and
+    deterministic.  The tile-major operand is built in torch: independent of the GEGLU kernels."""
+    dtype = torch.bfloat16
+    go, gd = rnd((M, cff), 1, dtype, scale=0.7)
+    ho, hd = rnd((M, C), 2, dtype, scale=1.2, shift=0.1)
+    xo, xd = rnd((M, C), 3, dtype, scale=1.0, shift=-0.2)
+    w2o, w2d = rnd((C, cff), 4, dtype, scale=cff ** -0.5)
+    b2o, b2d = rnd((C,), 5, dtype, scale=0.2)
+    wpo, wpd = rnd((C, C), 6, dtype, scale=C ** -0.5)
+    bpo, bpd = rnd((C,), 7, dtype, scale=0.2)
+    blk = gd.view(M // 160, 160, cff // 32, 32).permute(0, 2, 1, 3).contiguous()
+    wc, bc = K.fold_ff_tail(w2d, b2d, wpd, bpd)
+    assert wc.shape == (C, cff + C) and wc.dtype == dtype and torch.equal(wc[:, cff:], wpd)
+    blk = blk.view(M, cff)                                   # (same shape as the row-major tensor, private layout: as the GEGLU kernels return it)
+    xres = xd.view(M // hw, hw, C) if hw else xd
+    with torch.no_grad():                                    # (the GroupNorm partials are an inference-path epilogue)
+        got = K.ff_tail(blk, hd, wc, bc, xres, gn_hw=hw)
+    assert got.shape == xres.shape and got.dtype == dtype
+    chain = F.linear(F.linear(go, w2o, b2o) + ho, wpo, bpo) + xo
+    assert rel_inf(got.view(M, C), chain) < 1e-2
+    a64 = torch.cat([go, ho], dim=1).double()
+    folded = a64 @ wc.double().cpu().t() + bc.double().cpu() + xo.double()
+    mag = a64.abs() @ wc.double().cpu().abs().t() + bc.double().cpu().abs() + xo.double().abs()
+    assert_bf16_close(got.view(M, C), folded, mag, "ff_tail")
+    with torch.no_grad():
+        assert torch.equal(got, K.ff_tail(blk, hd, wc, bc, xres, gn_hw=hw))
+    if hw:
+        part, n = got._fmc_gn
+        assert n == C and part.shape == (M // hw, hw // 160, 32, 2)
+        v = got.float().view(M // hw, hw // 160, 160, 32, C // 32)
+        assert rel_inf(part[..., 0], v.sum(dim=(2, 4))) < 1e-4 and rel_inf(part[..., 1], (v * v).sum(dim=(2, 4))) < 1e-4
+    else:
+        assert getattr(got, "_fmc_gn", None) is None
+    # no bias anywhere
+    wc0, bc0 = K.fold_ff_tail(w2d, None, wpd, None)
+    assert bc0 is None
+    with torch.no_grad():
+        got0 = K.ff_tail(blk, hd, wc0, None, xres)
+    assert rel_inf(got0.view(M, C), F.linear(F.linear(go, w2o) + ho, wpo) + xo) < 1e-2
+    # the model-level switch: the pair of launches it replaces gives the same values to bf16 rounding of the intermediate
+    with torch.no_grad():
+        pair = K.linear(K.linear_from_blocked(blk, w2d, b2d, hd), wpd, bpd, xd)
+    d = (got.view(M, C).float() - pair.float()).abs().cpu()
+    assert bool((d <= 2.0 ** -6 * chain.abs() + 0.05).all())
