@@ -59,6 +59,7 @@ struct C4Params {
     int splits; float* ws;                                  // split-K: the 64-channel chunks are dealt to `splits` workgroups per tile, which leave fp32 partial
                                                             //   sums in ws[split][pixel][Cout]; conv_halo4_finish_kernel adds them (fixed order) and runs the epilogue
     int64_t x_bytes, x2_bytes, w_bytes;
+    int xcd_pc;                                             // tile order: the 8 XCDs as xcd_pc filter-slice groups x 8 / xcd_pc pixel groups (launch_c4), 0 = contiguous ranges
 };
 
 template <int I> using IC = std::integral_constant<int, I>;
@@ -84,16 +85,30 @@ void conv_halo4_kernel(const C4Params P) {
     const int wp = wave & 3, wn = wave >> 2;                 // my 80 pixels / my 80 channels of the tile
     const bool clsA = wave < G::WPIECES - NWV;               // these waves issue two W pieces per sub-tile (w and NWV + w), the others one
 
-    // ---- my tile: XCD x owns a contiguous range; the channel tiles of a pixel tile are neighbours (its halos come from that XCD's L2 once) --------
+    // ---- my tile.  Workgroup id -> XCD id & 7 (round robin).  The filter of these levels (29.5 MB at 1280 -> 1280) is larger than the input (13 MB at
+    // 10x16, 3.3 MB at 5x8) and every pixel tile streams its channel tile's slice of it, so WHICH tiles share an XCD (and its L2) decides how often the
+    // filter crosses the fabric: contiguous tile ranges (two pixel tiles x all 16 channel tiles per XCD at 10x16) bring the WHOLE filter into every L2 --
+    // 302 MB fetched per launch for 56 MB of operands (profiles/r06fin_step_hbm_traffic_by_kernel.md).  xcd_pc > 0: the XCDs form a grid of xcd_pc
+    // filter-slice groups x 8 / xcd_pc pixel groups; launch_c4 picks the split that minimises filter * pixel groups + input * slice groups. ----------
     int tile_p, tile_n, split;
     {
         const int total = P.tiles_p * P.tiles_n * P.splits;
-        const int id = blockIdx.x, q = total >> 3, r = total & 7, xcd = id & 7;
-        int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-        split = lin % P.splits;                              // (the splits of a tile are neighbours)
-        lin /= P.splits;
-        tile_p = lin / P.tiles_n;
-        tile_n = lin - tile_p * P.tiles_n;
+        const int id = blockIdx.x, xcd = id & 7;
+        if (P.xcd_pc > 0) {
+            const int j = id >> 3, pc = P.xcd_pc;
+            const int tnl = P.tiles_n * P.splits / pc, tpl = P.tiles_p / (8 / pc);      // (filter slice = (channel tile, split)) per slice group, pixel tiles per pixel group
+            const int tnv = (xcd % pc) * tnl + j % tnl;
+            tile_p = (xcd / pc) * tpl + j / tnl;
+            split = tnv % P.splits;
+            tile_n = tnv / P.splits;
+        } else {
+            const int q = total >> 3, r = total & 7;
+            int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+            split = lin % P.splits;                          // (the splits of a tile are neighbours)
+            lin /= P.splits;
+            tile_p = lin / P.tiles_n;
+            tile_n = lin - tile_p * P.tiles_n;
+        }
     }
     const int n0 = tile_n * BN;
     const int nchunk_all = P.cin >> 6;
@@ -467,6 +482,19 @@ template <int TW, int NWV> int launch_c4(C4Params& P, hipStream_t st) {
     P.tiles_y = (P.H + G::TH - 1) / G::TH;
     P.tiles_x = P.W / TW;
     P.tiles_p = (P.n_img * P.tiles_y * P.tiles_x + G::NB - 1) / G::NB;
+    {   // XCD grid (see the kernel): FMC_C4_XCD = 0 contiguous ranges (rounds 5's order), 1 / 2 / 4 / 8 forced where it divides, unset = least fabric traffic
+        static const int forced = getenv("FMC_C4_XCD") ? atoi(getenv("FMC_C4_XCD")) : -1;
+        const int tnv = P.tiles_n * P.splits;
+        double best = 0.;
+        P.xcd_pc = 0;
+        if (forced != 0 && (P.tiles_p * tnv) % 8 == 0) {
+            for (int pc = 1; pc <= 8; pc *= 2) {
+                if (tnv % pc || P.tiles_p % (8 / pc) || (forced > 0 && pc != forced)) continue;
+                const double cost = (double)P.w_bytes * (8 / pc) + (double)(P.x_bytes + P.x2_bytes) * pc;
+                if (!P.xcd_pc || cost < best) { best = cost; P.xcd_pc = pc; }
+            }
+        }
+    }
     static FmcPerDeviceFlag raised;
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo4_kernel<TW, NWV>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
