@@ -305,6 +305,19 @@ int fmc_linear_bf16_lnc(const void* x, const void* w_gamma, void* out, int64_t M
 int fmc_linear_bf16_ffblk(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int N, int K,
                           int64_t ldres, float alpha, int epilogue, int x_blocked, int out_blocked, const float* ln_stats, const float* ln_c,
                           const float* ln_bias, int w_tilemajor, void* stream);
+/* The GroupNorm in front of a transformer's proj_in folded INTO the projection (diffusers Transformer2DModel.norm -> proj_in, fmc/models/unet_blocks.py:323-333;
+ * TemporalTransformer3DModel.norm -> proj_in, fmc/models/motion_module.py:124-129: no activation between the two):
+ *   proj(GN(x))[m, :] = W'_img x[m, :] + bias'_img,   W'_img = W diag(rstd[img, g(c)] gamma[c]),   bias'_img = bias + W beta - W'_img mean[img, g(.)]
+ * fmc_groupnorm_fold_linear: partials [n_img, part_splits, G, 2] (sum, sum of squares per image, split and group, as fmc_groupnorm_apply_fwd takes them:
+ *   the producer's epilogue wrote them) -> w_out bf16 [n_img][N][C] (each image's matrix tile-major [N / 320][C / 32][320][32] if w_tilemajor) and
+ *   bias_out fp32 [n_img][N], computed from the ROUNDED W'_img so that the mean term cancels against W'_img x exactly.
+ * fmc_linear_bf16_imgw: out[m, :] = w_img[m / img_rows] x[m, :] + bias_img[m / img_rows] on tile 16's persistent form (M % 160 == 0, img_rows % 160 == 0,
+ *   N % 320 == 0, more tiles than CUs); ln_stats != NULL (N == 320): also the rows' LayerNorm (mean, rstd) -> ln_stats[M][2], as fmc_linear_bf16_ln.
+ * The normalised tensor is neither written nor read: one HBM pass over x less per transformer. */
+int fmc_groupnorm_fold_linear(const float* partials, int part_splits, const float* gamma, const float* beta, const void* w, const void* bias,
+                              void* w_out, float* bias_out, int n_img, int HW, int C, int G, int N, float eps, int w_tilemajor, void* stream);
+int fmc_linear_bf16_imgw(const void* x, const void* w_img, const float* bias_img, void* out, int64_t M, int N, int K, int64_t ldx, int64_t ldo,
+                         int img_rows, float* ln_stats, float ln_eps, int w_tilemajor, void* stream);
 /* The feed-forward's output projection and the transformer's proj_out as ONE product (diffusers BasicTransformerBlock `ff(norm3(h)) + h` followed by
  * Transformer2DModel.proj_out + residual, fmc/models/unet_blocks.py:323-333; the motion module's `ff(ff_norm(h)) + h` followed by
  * TemporalTransformer3DModel.proj_out + residual, fmc/models/motion_module.py:130-134,295-299):

@@ -55,6 +55,10 @@ SIGNATURES = {
                                     c_int, c_void_p]),
     "fmc_linear_bf16_ffblk": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_float, c_int, c_int, c_int,
                                       c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "fmc_groupnorm_fold_linear": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                          c_float, c_int, c_void_p]),
+    "fmc_linear_bf16_imgw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_void_p, c_float, c_int,
+                                     c_void_p]),
     "fmc_linear_bf16_fftail": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_int64,
                                        c_void_p, c_int, c_int, c_void_p]),
     "fmc_conv3x3_bf16_gn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

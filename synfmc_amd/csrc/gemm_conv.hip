@@ -85,6 +85,9 @@ struct GemmParams {
     float* ln_stats;                  // ... or only the rows' (mean, rstd) -> ln_stats[M][2], for a consumer GEMM that applies the LayerNorm itself:
     const float* lnc_stats; const float* lnc_c; const float* lnc_bias;  // gemm160p_kernel as that consumer (W pre-scaled by gamma): out = rstd[m] (acc -
                                       //   mean[m] c[n]) + lnc_bias[n], c[n] = sum_k W'[n, k], lnc_bias = W beta + bias (fp32 [N]); alpha 1, no bf16 bias
+    const float* bias_img; int64_t w_img_stride; int img_rows;   // gemm160p_kernel<IMG = 1>: every img_rows rows of A (one image, a multiple of 160) have their
+                                      //   OWN weight (w + image * w_img_stride elements, same layout) and fp32 bias row (bias_img + image * N): the
+                                      //   GroupNorm in front of the layer folded into it per image (fmc_groupnorm_fold_linear, fmc_linear_bf16_imgw)
     int f32io;                        // fp32-storage ("parity") mode: A / W are split-bf16 x3 operands (fmc_split_bf16x3), bias / temb /
                                       // residual(s) / out are FP32 tensors (the bf16_t pointers above are reinterpreted), see epi_f32_*
 };
@@ -1859,7 +1862,8 @@ void gemm160_kernel(const GemmParams P) {
 // The feed-forward's output projection and the transformer's proj_out as ONE product: out = [gated | h] [Wp W2 | Wp]^T + b' + x (hip_ops.ff_tail); the
 // stream's A requests of a sub-tile past ksplit / 32 go to a2 with ONE per-lane offset (row in piece, 16-byte chunk) and the piece / k position in the
 // scalar offset, so the variant costs one register over the plain one.
-template <int EPI, int MB, int LN = 0, int LNC = 0, int A2 = 0>
+// IMG = 1 (plain epilogue): per-image weights and fp32 bias rows, see GemmParams::bias_img.
+template <int EPI, int MB, int LN = 0, int LNC = 0, int A2 = 0, int IMG = 0>
 __global__ __launch_bounds__(512, 2)
 void gemm160p_kernel(const GemmParams P) {
     constexpr int BM = 32 * MB, BN = 320, BK = 32, NT = 512, NBUF = 3;
@@ -1894,7 +1898,7 @@ void gemm160p_kernel(const GemmParams P) {
 
     constexpr unsigned OOB = 0x80000000u;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)P.a, 0, (int)P.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)P.w, 0, (int)((int64_t)P.N * P.K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)P.w, 0, (int)(IMG ? (P.M / P.img_rows) * P.w_img_stride * 2 : (int64_t)P.N * P.K * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(A2 ? P.a2 : P.a), 0, A2 ? (int)(((P.M - 1) * P.lda2 + (P.K - P.ksplit)) * 2) : 0, 0x00020000);
     const unsigned lane_a2 = A2 ? (unsigned)((prow * P.lda2 + psrc * 8) * 2) : 0u;
     int s_m0 = 0;                                     // first row of the stream's current tile (A2), < 0 past the last tile
@@ -1921,6 +1925,7 @@ void gemm160p_kernel(const GemmParams P) {
                 const int n = tn * BN + 16 * i + prow;
                 vo = P.w_blocked ? (unsigned)((((int64_t)tn * nks) * (BN * BK) + (16 * i + prow) * BK + psrc * 8) * 2)
                                  : (unsigned)(((int64_t)n * P.K + psrc * 8) * 2);
+                if (IMG) vo += (unsigned)(((int64_t)tm * BM / P.img_rows) * P.w_img_stride * 2);       // this tile's image's weight
             } else if (live && i < 20 + BM / 16) {
                 const int64_t m = (int64_t)tm * BM + 16 * (i - 20) + prow;
                 vo = P.a_blocked ? (unsigned)((((int64_t)tm * nksA) * (BM * BK) + (16 * (i - 20) + prow) * BK + psrc * 8) * 2)
@@ -2145,7 +2150,7 @@ void gemm160p_kernel(const GemmParams P) {
             // alpha * (acc + bias) in the accumulator registers; the five bias words in one burst where the registers allow it (LN == 0: the
             // LayerNorm-writing variants sit at the 256-register limit and keep the load beside its use)
             u32x2 bt[5];
-            if (LN == 0 && P.bias) {
+            if (LN == 0 && !IMG && P.bias) {
 #pragma unroll
                 for (int nb = 0; nb < 5; ++nb) bt[nb] = *reinterpret_cast<const u32x2*>(P.bias + n0 + wc * 80 + nb * 16 + 4 * kq);
             }
@@ -2153,6 +2158,10 @@ void gemm160p_kernel(const GemmParams P) {
             for (int nb = 0; nb < 5; ++nb) {
                 const int n = n0 + wc * 80 + nb * 16 + 4 * kq;
                 float b4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (IMG) {                                               // fp32 bias row of this tile's image
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(P.bias_img + (m0 / P.img_rows) * P.N + n);
+                    b4[0] = t[0]; b4[1] = t[1]; b4[2] = t[2]; b4[3] = t[3];
+                } else
                 if (P.bias) {
                     u32x2 t;
                     if (LN == 0) t = bt[nb];
@@ -2869,6 +2878,17 @@ void launch_gemm160(GemmParams& P, hipStream_t st) {
                 raisedp = true;
             }
             if constexpr (EPI == 0) {
+                if (P.bias_img) {                             // per-image weights / fp32 bias rows (linear_impl has checked; with or without the LayerNorm statistics)
+                    static FmcPerDeviceFlag raised3;
+                    if (!raised3) {
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm160p_kernel<0, 5, 0, 0, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm160p_kernel<0, 5, 2, 0, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+                        raised3 = true;
+                    }
+                    if (P.ln_stats) hipLaunchKernelGGL((gemm160p_kernel<0, 5, 2, 0, 0, 1>), dim3((unsigned)cus), dim3(512), ldsp, st, P);
+                    else hipLaunchKernelGGL((gemm160p_kernel<0, 5, 0, 0, 0, 1>), dim3((unsigned)cus), dim3(512), ldsp, st, P);
+                    return;
+                }
                 if (P.a2) {                                   // two-segment reduction (linear_impl has checked: tile-major first segment, plain epilogue)
                     static FmcPerDeviceFlag raised2;
                     if (!raised2) {
@@ -3036,7 +3056,7 @@ static int linear_impl(const void* x, const void* w, const void* bias, const voi
                        void* ln_out = nullptr, const float* ln_gamma = nullptr, const float* ln_beta = nullptr, float ln_eps = 0.f,
                        const float* ln_pe = nullptr, int ln_pe_inner = 1, int ln_pe_frames = 1, float* ln_stats = nullptr,
                        const float* lnc_stats = nullptr, const float* lnc_c = nullptr, const float* lnc_bias = nullptr, int a_blocked = 0,
-                       int out_blocked = 0, int w_tilemajor = 0) {
+                       int out_blocked = 0, int w_tilemajor = 0, const float* bias_img = nullptr, int img_rows = 0) {
     if (!x || !w || !out) FMC_FAIL(FMC_E_NULL, "linear_bf16: NULL tensor");
     if (tile == 18) { tile = 16; w_tilemajor = 1; }           // tile 18 = tile 16 on a weight pre-packed tile-major (fmc_hip.h)
     if (M <= 0 || N <= 0 || K <= 0 || K % BK_MAX || N % 8 || ldx % 8 || ldo % (f32io ? 4 : 8) || (residual && ldres % (f32io ? 4 : 8)))
@@ -3083,6 +3103,17 @@ static int linear_impl(const void* x, const void* w, const void* bias, const voi
                                   "more tiles than CUs, dense rows)");
     }
     P.a_blocked = a_blocked; P.out_blocked = out_blocked;
+    P.bias_img = nullptr; P.w_img_stride = 0; P.img_rows = 0;
+    if (bias_img) {                                           // per-image weights (a GroupNorm folded in): persistent form of tile 16, plain epilogue
+        const int cus = fmc_cu_count() & ~7;
+        if (f32io || epilogue != 0 || tile != 16 || split_k != 1 || gn_partials || x2 || bias || residual || residual2 || alpha != 1.f || ln_out || lnc_stats ||
+            a_blocked || out_blocked || N % 320 || M % 160 || (M / 160) * (N / 320) <= cus || cus < 8 || img_rows < 160 || img_rows % 160 || M % img_rows ||
+            ((uintptr_t)bias_img & 15) || ((M - 1) * ldx + K) * 2 >= ((int64_t)1 << 31) || (M / img_rows) * (int64_t)N * K * 2 >= ((int64_t)1 << 31) ||
+            (getenv("FMC_G160_PERSIST") && atoi(getenv("FMC_G160_PERSIST")) == 0))
+            FMC_FAIL(FMC_E_SHAPE, "linear_bf16_imgw: tile 16's persistent form only (bf16, N %% 320 == 0, M %% 160 == 0, more tiles than CUs, images of a multiple "
+                                  "of 160 rows, no bf16 bias / residual, all weights < 2 GiB)");
+        P.bias_img = bias_img; P.w_img_stride = (int64_t)N * K; P.img_rows = img_rows;
+    }
     if (ln_out || ln_stats) {
         const int cus = fmc_cu_count() & ~7;
         if ((ln_out != nullptr) == (ln_stats != nullptr)) FMC_FAIL(FMC_E_NULL, "linear_bf16_ln: exactly one of ln_out / ln_stats");
@@ -3152,6 +3183,13 @@ extern "C" int fmc_linear_bf16_ffblk(const void* x, const void* w, const void* b
     const int n_out = epilogue == 1 ? N / 2 : N;
     return linear_impl(x, w, bias, residual, out, M, N, K, K, ldres, n_out, alpha, epilogue, 16, 1, nullptr, 0, nullptr, 0, 0, nullptr, stream, 0,
                        nullptr, 0, nullptr, nullptr, nullptr, 0.f, nullptr, 1, 1, nullptr, ln_stats, ln_c, ln_bias, x_blocked, out_blocked, w_tilemajor);
+}
+
+extern "C" int fmc_linear_bf16_imgw(const void* x, const void* w_img, const float* bias_img, void* out, int64_t M, int N, int K, int64_t ldx, int64_t ldo,
+                                    int img_rows, float* ln_stats, float ln_eps, int w_tilemajor, void* stream) {
+    if (!bias_img) FMC_FAIL(FMC_E_NULL, "linear_bf16_imgw: NULL bias_img");
+    return linear_impl(x, w_img, nullptr, nullptr, out, M, N, K, ldx, 0, ldo, 1.f, 0, 16, 1, nullptr, 0, nullptr, 0, 0, nullptr, stream, 0,
+                       nullptr, 0, nullptr, nullptr, nullptr, ln_eps, nullptr, 1, 1, ln_stats, nullptr, nullptr, nullptr, 0, 0, w_tilemajor, bias_img, img_rows);
 }
 
 extern "C" int fmc_linear_bf16_fftail(const void* x_blocked, const void* x2, const void* w, const void* bias, const void* residual, void* out, int64_t M,

@@ -979,6 +979,112 @@ extern "C" int fmc_groupnorm_apply_fwd(const void* x, void* y, const float* gamm
     return 0;
 }
 
+// --------------------------------------------------------------------------------------------
+// GroupNorm folded into the linear layer behind it (no activation in between: the norm in front of a transformer's proj_in).
+//   proj(GN(x))[m, n] = sum_c W[n, c] (x[m, c] a_c + b_c) + bias[n],   a_c = rstd[img, g(c)] gamma[c],  b_c = beta[c] - mean[img, g(c)] a_c
+//                     = sum_c W'_img[n, c] x[m, c] + bias'_img[n]
+// One workgroup = 8 weight rows of one image x 8-channel chunks: W'_img = bf16(W a) (row-major, or tile-major [N / 320][C / 32][320][32] as tile 18 reads
+// it) and, in fp32 and FROM THE ROUNDED W', bias'_img[n] = bias[n] + sum_c (W[n, c] beta[c] - W'_img[n, c] mean[img, g(c)]): the mean term then cancels
+// against sum_c W' x exactly as (x - mean) would, whatever |mean| / std is -- the only new rounding is W a to bf16, in place of GN(x) to bf16.
+// --------------------------------------------------------------------------------------------
+constexpr int GNF_ROWS = 8, GNF_PASSES = 5;                  // a workgroup = 40 weight rows of one image: 8 rows x 64 chunk lanes per pass
+__global__ __launch_bounds__(512) void gn_fold_linear_kernel(const float* __restrict__ part, int nsplit, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const bf16_t* __restrict__ w, const bf16_t* __restrict__ bias,
+                                                              bf16_t* __restrict__ w_out, float* __restrict__ b_out, int HW, int C, int G, int N, float eps,
+                                                              int tilemajor) {
+    __shared__ float sh_mean[GN_MAX_G], sh_rstd[GN_MAX_G];
+    __shared__ float sh_part[GN_MAX_SPLIT * GN_MAX_G * 2];
+    const int img = blockIdx.y, n0 = blockIdx.x * (GNF_ROWS * GNF_PASSES), tid = threadIdx.x;
+    const int cpg = C / G, nch = C / 8;
+    const int r = tid >> 6, cc = tid & 63;                     // row n0 + 8 pass + r, chunks cc, cc + 64, ...
+    // everything that does not depend on the statistics is requested first: my weight chunks of the five passes, gamma / beta of my first chunk column
+    Vec8<bf16_t>::raw_t wraw[GNF_PASSES];
+    float gm[8], bt[8];
+    const bool has = cc < nch;
+#pragma unroll
+    for (int p = 0; p < GNF_PASSES; ++p) {
+        const int n = n0 + p * GNF_ROWS + r;
+        wraw[p] = Vec8<bf16_t>::load_raw(w + (size_t)(has && n < N ? n : 0) * C + (has ? cc * 8 : 0));
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { gm[i] = 0.f; bt[i] = 0.f; }
+    if (has) {
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + cc * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + cc * 8 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + cc * 8), b1 = *reinterpret_cast<const f32x4*>(beta + cc * 8 + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { gm[i] = g0[i]; gm[4 + i] = g1[i]; bt[i] = b0[i]; bt[4 + i] = b1[i]; }
+    }
+    for (int i = tid; i < nsplit * G * 2; i += blockDim.x) sh_part[i] = part[(size_t)img * nsplit * G * 2 + i];
+    __syncthreads();
+    for (int g = tid; g < G; g += blockDim.x) {               // (as gn_apply_fwd_kernel: fixed order, double)
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < nsplit; ++k) {
+            const float* p = sh_part + ((size_t)k * G + g) * 2;
+            a += (double)p[0];
+            b += (double)p[1];
+        }
+        const double cnt = (double)HW * cpg, mean = a / cnt;
+        double var = b / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        sh_mean[g] = (float)mean;
+        sh_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    // per-lane constants of my first chunk column (the only one at C <= 512): a_c = rstd gamma and the group mean -- one integer division per channel, not per row
+    float ac[8], mu[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int g = has ? (cc * 8 + i) / cpg : 0;
+        ac[i] = sh_rstd[g] * gm[i];
+        mu[i] = sh_mean[g];
+    }
+#pragma unroll
+    for (int p = 0; p < GNF_PASSES; ++p) {
+        const int n = n0 + p * GNF_ROWS + r;                       // (wave-uniform: a wave = one weight row)
+        float acc = 0.f;
+        if (n < N) {
+            for (int ch = cc; ch < nch; ch += 64) {
+                const int c0 = ch * 8;
+                float wv[8], o[8];
+                if (ch == cc) Vec8<bf16_t>::unpack(wraw[p], wv);
+                else Vec8<bf16_t>::load(w + (size_t)n * C + c0, wv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float a_c = ac[i], m_c = mu[i], be = bt[i];
+                    if (ch != cc) {
+                        const int c = c0 + i, g = c / cpg;
+                        a_c = sh_rstd[g] * gamma[c]; m_c = sh_mean[g]; be = beta[c];
+                    }
+                    const float wr = bf2f(f2bf(wv[i] * a_c));
+                    o[i] = wr;
+                    acc += wv[i] * be - wr * m_c;
+                }
+                const size_t dst = tilemajor ? ((size_t)(n / 320) * (C / 32) + c0 / 32) * (320 * 32) + (size_t)(n % 320) * 32 + (c0 % 32)
+                                             : (size_t)n * C + c0;
+                Vec8<bf16_t>::store(w_out + (size_t)img * N * C + dst, o);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);          // fixed tree: deterministic
+        if (cc == 0 && n < N) b_out[(size_t)img * N + n] = acc + (bias ? bf2f(bias[n]) : 0.f);
+    }
+}
+
+extern "C" int fmc_groupnorm_fold_linear(const float* partials, int part_splits, const float* gamma, const float* beta, const void* w, const void* bias,
+                                         void* w_out, float* bias_out, int n_img, int HW, int C, int G, int N, float eps, int w_tilemajor, void* stream) {
+    if (!partials || !gamma || !beta || !w || !w_out || !bias_out) FMC_FAIL(FMC_E_NULL, "groupnorm_fold_linear: NULL argument");
+    if (n_img < 1 || HW < 1 || C < 8 || C % 8 || G < 1 || G > GN_MAX_G || C % G || N < 1 || (w_tilemajor && (N % 320 || C % 32)))
+        FMC_FAIL(FMC_E_SHAPE, "groupnorm_fold_linear: C %% 8, C %% G, G <= %d (tile-major: N %% 320, C %% 32) (C=%d G=%d N=%d)", GN_MAX_G, C, G, N);
+    if (part_splits < 1 || part_splits > GN_MAX_SPLIT) FMC_FAIL(FMC_E_SHAPE, "groupnorm_fold_linear: part_splits %d (1..%d)", part_splits, GN_MAX_SPLIT);
+    if (!fmc_aligned16(w) || !fmc_aligned16(w_out) || !fmc_aligned16(gamma) || !fmc_aligned16(beta))
+        FMC_FAIL(FMC_E_ALIGN, "groupnorm_fold_linear: w / w_out / gamma / beta must be 16-byte aligned");
+    dim3 grid((unsigned)((N + GNF_ROWS * GNF_PASSES - 1) / (GNF_ROWS * GNF_PASSES)), (unsigned)n_img);
+    hipLaunchKernelGGL(gn_fold_linear_kernel, grid, dim3(512), 0, (hipStream_t)stream, partials, part_splits, gamma, beta, (const bf16_t*)w,
+                       (const bf16_t*)bias, (bf16_t*)w_out, bias_out, HW, C, G, N, eps, w_tilemajor);
+    FMC_CHECK_LAUNCH("fmc_groupnorm_fold_linear");
+    return 0;
+}
+
 extern "C" int fmc_groupnorm_silu_bwd_add(const void* dy, const void* x, void* dx, const float* gamma, const float* beta,
                                           const float* stats, void* workspace, int N, int HW, int C, int G, int act,
                                           const void* addend, int dtype, void* stream) {

@@ -1639,6 +1639,54 @@ def linear_ln(x: torch.Tensor, weight: torch.Tensor, bias, residual, alpha: floa
     return out
 
 
+GN_FOLD = os.environ.get("FMC_GN_FOLD", "1") != "0"             # A/B switch: the GroupNorm in front of a transformer's proj_in folded into per-image weights (below)
+GN_FOLD_MAX_BYTES = 8 << 20                                       # ... while the per-image weights stay small next to the tensor (level 0: 32 x 200 KB)
+
+
+def gn_fold_ok(x: torch.Tensor, gn_tag, groups: int, weight: torch.Tensor, ln: Optional[LnSpec]) -> bool:
+    """`proj(GroupNorm(x))` without the normalised tensor (`linear_gnfold`): x `[n_img, hw, C]` whose producer left the GroupNorm partial sums (`gn_tag`)."""
+    if not GN_FOLD or gn_tag is None or torch.is_grad_enabled() or x.ndim != 3 or weight.ndim != 2:
+        return False
+    n_img, hw, C = x.shape
+    N = weight.shape[0]
+    M = n_img * hw
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and weight.dtype == torch.bfloat16 and weight.is_contiguous() and weight.shape[1] == C
+            and groups == 32 and gn_tag[1] == C and gn_tag[0].shape[0] == n_img and gn_tag[0].shape[1] <= 64 and gn_tag[0].shape[2] == groups
+            and hw % 160 == 0 and C % 64 == 0 and N % 320 == 0 and (M // 160) * (N // 320) > _cus(x.device) and n_img * N * C * 2 <= GN_FOLD_MAX_BYTES
+            and M * max(C, N) * 2 < (1 << 31) and (ln is None or (LN_EPILOGUE and ln.stats_only and N == 320))
+            and os.environ.get("FMC_G160_PERSIST", "1") != "0")
+
+
+def linear_gnfold(x: torch.Tensor, gn_tag, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, weight: torch.Tensor, bias,
+                  ln: Optional[LnSpec] = None) -> torch.Tensor:
+    """`GroupNorm(x) @ weight^T + bias` with the norm folded into per-image weights: `fmc_groupnorm_fold_linear` turns the producer's partial sums into
+    `W'_img = W diag(rstd_img gamma)` (bf16) and an fp32 bias row per image (built from the ROUNDED W': the mean cancels exactly), `fmc_linear_bf16_imgw`
+    runs the projection on the raw tensor -- the apply pass (read + write of x) disappears.  `ln` (statistics only): as `linear_ln`."""
+    part = gn_tag[0]
+    _dev(x, part, gamma, beta, weight, bias)
+    n_img, hw, C = x.shape
+    N = weight.shape[0]
+    M = n_img * hw
+    lib = _lib.load()
+    w_img = torch.empty(n_img, N, C, dtype=torch.bfloat16, device=x.device)
+    b_img = torch.empty(n_img, N, dtype=torch.float32, device=x.device)
+    gn_epilogue_calls["consumed"] += 1
+    _lib.check(lib.fmc_groupnorm_fold_linear(part.data_ptr(), int(part.shape[1]), gamma.data_ptr(), beta.data_ptr(), weight.data_ptr(), _p(bias),
+                                             w_img.data_ptr(), b_img.data_ptr(), n_img, hw, C, int(groups), N, float(eps), int(W_TILEMAJOR), _stream()),
+               "fmc_groupnorm_fold_linear")
+    out = torch.empty(n_img, hw, N, dtype=x.dtype, device=x.device)
+    stats = None
+    if ln is not None:
+        stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+        ln_epilogue_calls["emitted"] += 1
+    _log_call("own_linear", (M, N, C, "gn-fold", 0), 2.0 * M * N * C)
+    _lib.check(lib.fmc_linear_bf16_imgw(x.data_ptr(), w_img.data_ptr(), b_img.data_ptr(), out.data_ptr(), M, N, C, C, N, hw, _p(stats),
+                                        float(ln.eps) if ln is not None else 0.0, int(W_TILEMAJOR), _stream()), "fmc_linear_bf16_imgw")
+    if ln is not None:
+        out._fmc_ln = (stats, ln.key, True)
+    return out
+
+
 FF_BLOCKED = os.environ.get("FMC_FF_BLOCKED", "1") != "0"        # A/B switch: tile-major intermediate between the two GEMMs of a feed-forward
 
 

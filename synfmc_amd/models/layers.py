@@ -842,11 +842,20 @@ class Transformer2DModel(nn.Module):
             residual, x = K.groupnorm_silu_skip(residual if residual.is_contiguous() else residual.contiguous(), f32_param(self.norm, "weight"),
                                                 f32_param(self.norm, "bias"), self.norm.num_groups, self.norm.eps, False)
         else:
-            x = K.groupnorm_silu(residual, f32_param(self.norm, "weight"), f32_param(self.norm, "bias"),
-                                 self.norm.num_groups, self.norm.eps, False, gn_tag=getattr(hidden_states, "_fmc_gn", None))
-        x = linear_op(x, self.proj_in.weight.view(self.proj_in.out_channels, c), self.proj_in.bias,
-                      ln=None if torch.is_grad_enabled() else self.transformer_blocks[0].norm1.ln_spec(
-                          stats_only=type(self.transformer_blocks[0].attn1.processor).__name__ in ("AttnProcessor", "LoRAAttnProcessor")))
+            x = None
+        w_in = self.proj_in.weight.view(self.proj_in.out_channels, c)
+        ln_in = None if torch.is_grad_enabled() else self.transformer_blocks[0].norm1.ln_spec(
+            stats_only=type(self.transformer_blocks[0].attn1.processor).__name__ in ("AttnProcessor", "LoRAAttnProcessor"))
+        tag = getattr(hidden_states, "_fmc_gn", None)
+        if x is None and K.gn_fold_ok(residual, tag, self.norm.num_groups, w_in, ln_in):
+            # the norm folded into per-image weights of proj_in: the normalised tensor is neither written nor read (hip_ops.linear_gnfold)
+            x = K.linear_gnfold(residual, tag, f32_param(self.norm, "weight"), f32_param(self.norm, "bias"), self.norm.num_groups, self.norm.eps,
+                                w_in, self.proj_in.bias, ln_in)
+        else:
+            if x is None:
+                x = K.groupnorm_silu(residual, f32_param(self.norm, "weight"), f32_param(self.norm, "bias"),
+                                     self.norm.num_groups, self.norm.eps, False, gn_tag=tag)
+            x = linear_op(x, w_in, self.proj_in.bias, ln=ln_in)
         if cfg_expand:
             residual = torch.cat([residual, residual], dim=0)
         wp = self.proj_out.weight.view(c, self.proj_out.in_channels)

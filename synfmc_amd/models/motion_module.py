@@ -331,18 +331,26 @@ class TemporalTransformer3DModel(nn.Module):
             residual, x = K.groupnorm_silu_skip(residual, f32_param(self.norm, "weight"), f32_param(self.norm, "bias"),
                                                 self.norm.num_groups, self.norm.eps, False)
         else:
-            x = K.groupnorm_silu(residual, f32_param(self.norm, "weight"), f32_param(self.norm, "bias"),
-                                 self.norm.num_groups, self.norm.eps, False, gn_tag=getattr(hidden_states, "_fmc_gn", None))
+            x = None
         blk0 = self.transformer_blocks[0]
         ln0 = None
-        # (the fused attention blocks normalise their input themselves: proj_in then has no LayerNorm to emit; x stands in for its output here --
+        # (the fused attention blocks normalise their input themselves: proj_in then has no LayerNorm to emit; the residual stands in for its output here --
         #  same shape / dtype / device when the inner width equals the channel count, the only case the fused block takes)
-        will_fuse = (not torch.is_grad_enabled() and c == self.proj_in.out_features and x.is_contiguous()
-                     and blk0.fused_blocks_ok(x.view(b, f, h * w, c), attention_mask, cross_attention_kwargs))
+        will_fuse = (not torch.is_grad_enabled() and c == self.proj_in.out_features and residual.is_contiguous()
+                     and blk0.fused_blocks_ok(residual.view(b, f, h * w, c), attention_mask, cross_attention_kwargs))
         if not torch.is_grad_enabled() and not will_fuse:   # the first block's first norm (+ PE) leaves proj_in's epilogue
             enc0 = blk0.attention_blocks[0].pos_encoder
             ln0 = blk0.norms[0].ln_spec() if enc0 is None else blk0.norms[0].ln_spec(enc0.table(), h * w, f)
-        x = linear_op(x, self.proj_in.weight, self.proj_in.bias, ln=ln0)
+        tag = getattr(hidden_states, "_fmc_gn", None)
+        if x is None and K.gn_fold_ok(residual, tag, self.norm.num_groups, self.proj_in.weight, ln0):
+            # the norm folded into per-image weights of proj_in: the normalised tensor is neither written nor read (hip_ops.linear_gnfold)
+            x = K.linear_gnfold(residual, tag, f32_param(self.norm, "weight"), f32_param(self.norm, "bias"), self.norm.num_groups, self.norm.eps,
+                                self.proj_in.weight, self.proj_in.bias, ln0)
+        else:
+            if x is None:
+                x = K.groupnorm_silu(residual, f32_param(self.norm, "weight"), f32_param(self.norm, "bias"),
+                                     self.norm.num_groups, self.norm.eps, False, gn_tag=tag)
+            x = linear_op(x, self.proj_in.weight, self.proj_in.bias, ln=ln0)
         x = K.carry_ln(x, x.view(b, f, h * w, -1))
         last = len(self.transformer_blocks) - 1
         for bi, block in enumerate(self.transformer_blocks):

@@ -2215,3 +2215,49 @@ def test_ff_tail_folded_output_projection_and_proj_out(K, M, cff, C, hw):
         pair = K.linear(K.linear_from_blocked(blk, w2d, b2d, hd), wpd, bpd, xd)
     d = (got.view(M, C).float() - pair.float()).abs().cpu()
     assert bool((d <= 2.0 ** -6 * chain.abs() + 0.05).all())
+
+
+@pytest.mark.parametrize("n_img,hw,C,N,splits,with_ln", [(32, 2560, 320, 320, 16, True), (32, 2560, 320, 320, 8, False), (18, 2560, 320, 640, 16, False)])
+def test_linear_gnfold_groupnorm_folded_into_per_image_weights(K, n_img, hw, C, N, splits, with_ln):
+    """`fmc_groupnorm_fold_linear` + `fmc_linear_bf16_imgw`: `proj(GroupNorm(x))` from the producer's partial sums without the normalised tensor -- groups
+    with |mean| up to 6 sigma (the mean must cancel against the fp32 bias row built from the ROUNDED per-image weights), against fp32 GroupNorm -> linear
+    (max norm), element-wise against the folded product in fp64 on the weights the kernel wrote, the LayerNorm statistics of the rounded rows, deterministic."""
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(11)
+    base = torch.randn(n_img, hw, C, generator=g) * (0.5 + torch.rand(n_img, 1, C, generator=g))
+    shift = (torch.rand(n_img, 1, 32, generator=g) * 12.0 - 6.0).repeat_interleave(C // 32, dim=2)       # per (image, group) offsets of up to 6 sigma
+    xo = (base + shift).to(dtype).float()
+    xd = xo.to(dtype).cuda()
+    gam, _ = rnd((C,), 2, torch.float32, scale=0.3, shift=1.0)
+    bet, _ = rnd((C,), 3, torch.float32, scale=0.3)
+    wo, wd = rnd((N, C), 4, dtype, scale=C ** -0.5)
+    bo, bd = rnd((N,), 5, dtype, scale=0.2)
+    v = xo.view(n_img, splits, hw // splits, 32, C // 32)
+    part = torch.stack([v.sum(dim=(2, 4)), (v * v).sum(dim=(2, 4))], dim=-1).contiguous()                # [n_img, splits, 32, 2]
+    ln = None
+    if with_ln:
+        lg, lb = torch.ones(N, device="cuda"), torch.zeros(N, device="cuda")
+        ln = K.LnSpec(gamma=lg, beta=lb, eps=1e-5, pe=None, pe_inner=1, pe_frames=1, key=("t",), stats_only=True)
+    with torch.no_grad():
+        assert K.gn_fold_ok(xd, (part.cuda(), C), 32, wd, ln)
+        got = K.linear_gnfold(xd, (part.cuda(), C), gam.cuda(), bet.cuda(), 32, 1e-6, wd, bd, ln)
+        again = K.linear_gnfold(xd, (part.cuda(), C), gam.cuda(), bet.cuda(), 32, 1e-6, wd, bd, ln)
+    assert got.shape == (n_img, hw, N) and torch.equal(got, again)
+    want = F.linear(F.group_norm(xo.transpose(1, 2), 32, gam, bet, 1e-6).transpose(1, 2), wo, bo)
+    assert rel_inf(got, want) < 1.2e-2
+    # element-wise: the folded product in fp64 with W' rounded as the kernel rounds it (statistics in fp64 from the same partial sums)
+    s = part.double().sum(dim=1)
+    cnt = hw * (C // 32)
+    mean = s[..., 0] / cnt
+    rstd = 1.0 / torch.sqrt((s[..., 1] / cnt - mean * mean).clamp_min(0) + 1e-6)
+    a = (rstd.float().repeat_interleave(C // 32, dim=1) * gam[None, :])                                  # [n_img, C] as the kernel forms it (fp32)
+    wq = (wo[None] * a[:, None, :]).to(dtype).double()                                                   # [n_img, N, C]
+    xc = xo.double() - mean.repeat_interleave(C // 32, dim=1)[:, None, :]
+    folded = torch.einsum("imc,inc->imn", xc, wq) + (wo.double() @ bet.double() + bo.double())[None, None, :]
+    mag = torch.einsum("imc,inc->imn", xc.abs(), wq.abs()) + (wo.double().abs() @ bet.double().abs() + bo.double().abs())[None, None, :]
+    assert_bf16_close(got, folded, mag * 4, "linear_gnfold")            # (x4: a weight whose fp32 scale differs by an ulp may round the other way)
+    if with_ln:
+        stats, key, only = got._fmc_ln
+        assert only and key == ("t",)
+        r = got.float().cpu().view(-1, N)
+        assert rel_inf(stats[:, 0], r.mean(dim=1)) < 1e-3 and rel_inf(stats[:, 1], (r.var(dim=1, unbiased=False) + 1e-5).rsqrt()) < 1e-3
