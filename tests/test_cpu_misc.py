@@ -635,3 +635,50 @@ def test_vae_restatement_is_the_published_sd15_vae_tree():
         mean, logvar = small.encode_moments(x)
         assert mean.shape == logvar.shape == (1, 4, 4, 6) and float(logvar.max()) <= 20.0 and float(logvar.min()) >= -30.0
         assert small.decode(mean).shape == (1, 3, 32, 48)
+
+
+def test_ff_tail_fold_is_the_two_layer_chain():
+    """`hip_ops.fold_ff_tail`: `[g | h] [Wp W2 | Wp]^T + (Wp b2 + bp)` equals `proj_out(ff2(g) + b2 + h) + bp` (fp64 chain on the same bf16 inputs; the fold rounds
+    the product weight once), with and without biases -- the algebra `fmc_linear_bf16_fftail` relies on (motion_module.py:130-134,295-299, unet_blocks.py:323-333)."""
+    import torch
+    from synfmc_amd import hip_ops as K
+    g = torch.Generator().manual_seed(5)
+    M, C, cff = 96, 64, 256
+    bf = lambda t: t.to(torch.bfloat16)
+    gd, h = bf(torch.randn(M, cff, generator=g)), bf(torch.randn(M, C, generator=g))
+    w2, wp = bf(torch.randn(C, cff, generator=g) * cff ** -0.5), bf(torch.randn(C, C, generator=g) * C ** -0.5)
+    b2, bp = bf(torch.randn(C, generator=g) * 0.2), bf(torch.randn(C, generator=g) * 0.2)
+    for with_b in (True, False):
+        wc, bc = K.fold_ff_tail(w2, b2 if with_b else None, wp, bp if with_b else None)
+        assert wc.shape == (C, cff + C) and wc.dtype == torch.bfloat16 and torch.equal(wc[:, cff:], wp) and (bc is None) == (not with_b)
+        chain = (gd.double() @ w2.double().t() + (b2.double() if with_b else 0) + h.double()) @ wp.double().t() + (bp.double() if with_b else 0)
+        folded = torch.cat([gd, h], 1).double() @ wc.double().t() + (bc.double() if with_b else 0)
+        assert ((folded - chain).abs().max() / chain.abs().max()).item() < 6e-3          # bf16 rounding of the folded weight (2^-9 per element, summed at random)
+
+
+def test_groupnorm_fold_algebra_cancels_the_mean():
+    """The arithmetic of `fmc_groupnorm_fold_linear` restated in torch: per-image weights `bf16(W rstd gamma)` and the fp32 bias row built from the ROUNDED weights
+    give `proj(GroupNorm(x))` to bf16 weight rounding even when a group's mean is 50 sigma -- a bias row built from the un-rounded weights does not."""
+    import torch
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(9)
+    n, hw, C, N, G = 2, 64, 64, 32, 32
+    x = torch.randn(n, hw, C, generator=g) * 0.3 + 15.0                                  # |mean| = 50 sigma
+    x = x.to(torch.bfloat16).double()
+    gam, bet = torch.rand(C, generator=g).double() + 0.5, torch.randn(C, generator=g).double() * 0.3
+    w, b = (torch.randn(N, C, generator=g) * C ** -0.5).to(torch.bfloat16).double(), torch.randn(N, generator=g).double() * 0.1
+    want = F.linear(F.group_norm(x.transpose(1, 2), G, gam, bet, 1e-6).transpose(1, 2), w, b)
+    v = x.view(n, hw, G, C // G)
+    mean = v.mean(dim=(1, 3))
+    rstd = (v.var(dim=(1, 3), unbiased=False) + 1e-6).rsqrt()
+    a = rstd.repeat_interleave(C // G, 1) * gam[None]                                     # [n, C]
+    mu = mean.repeat_interleave(C // G, 1)
+    w_exact = w[None] * a[:, None, :]
+    w_img = w_exact.to(torch.bfloat16).double()                                           # what the GEMM multiplies with
+    bias_rounded = b[None] + (w @ bet)[None] - torch.einsum("inc,ic->in", w_img, mu)      # the kernel's bias row
+    bias_exact = b[None] + (w @ bet)[None] - torch.einsum("inc,ic->in", w_exact, mu)      # the tempting one
+    got = torch.einsum("imc,inc->imn", x, w_img) + bias_rounded[:, None, :]
+    bad = torch.einsum("imc,inc->imn", x, w_img) + bias_exact[:, None, :]
+    scale = want.abs().max()
+    assert ((got - want).abs().max() / scale).item() < 1e-2
+    assert ((bad - want).abs().max() / scale).item() > 5 * ((got - want).abs().max() / scale).item()
