@@ -312,7 +312,7 @@ int fmc_linear_bf16_ffblk(const void* x, const void* w, const void* bias, const 
  *   the producer's epilogue wrote them) -> w_out bf16 [n_img][N][C] (each image's matrix tile-major [N / 320][C / 32][320][32] if w_tilemajor) and
  *   bias_out fp32 [n_img][N], computed from the ROUNDED W'_img so that the mean term cancels against W'_img x exactly.
  * fmc_linear_bf16_imgw: out[m, :] = w_img[m / img_rows] x[m, :] + bias_img[m / img_rows] on tile 16's persistent form (M % 160 == 0, img_rows % 160 == 0,
- *   N % 320 == 0, more tiles than CUs); ln_stats != NULL (N == 320): also the rows' LayerNorm (mean, rstd) -> ln_stats[M][2], as fmc_linear_bf16_ln.
+ *   N % 320 == 0, at least as many tiles as CUs); ln_stats != NULL (N == 320): also the rows' LayerNorm (mean, rstd) -> ln_stats[M][2], as fmc_linear_bf16_ln.
  * The normalised tensor is neither written nor read: one HBM pass over x less per transformer. */
 int fmc_groupnorm_fold_linear(const float* partials, int part_splits, const float* gamma, const float* beta, const void* w, const void* bias,
                               void* w_out, float* bias_out, int n_img, int HW, int C, int G, int N, float eps, int w_tilemajor, void* stream);

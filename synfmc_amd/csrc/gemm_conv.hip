@@ -2865,7 +2865,7 @@ void launch_gemm160(GemmParams& P, hipStream_t st) {
         const int cus = fmc_cu_count() & ~7;
         // (FMC_G160_PERSIST=2: also launches of exactly one round -- tiles == CUs, the level-1 N = 640 projections -- A/B switch)
         // (a tile-major A operand exists in the persistent form only: it also takes launches of exactly one round -- the two halves of a split feed-forward)
-        if (persist && !P.f32io && P.M % 160 == 0 && ((persist == 2 || P.a_blocked) ? P.tiles_m * P.tiles_n >= cus : P.tiles_m * P.tiles_n > cus) && cus >= 8) {
+        if (persist && !P.f32io && P.M % 160 == 0 && ((persist == 2 || P.a_blocked || P.bias_img) ? P.tiles_m * P.tiles_n >= cus : P.tiles_m * P.tiles_n > cus) && cus >= 8) {
             constexpr size_t ldsp = (size_t)3 * (160 + 320) * 32 * sizeof(bf16_t) + 1024 + (EPI == 1 ? (size_t)160 * 168 * 2 + 4096 : (size_t)80 * 328 * 2 + 5120);
             static FmcPerDeviceFlag raisedp;
             if (!raisedp) {
@@ -3107,17 +3107,17 @@ static int linear_impl(const void* x, const void* w, const void* bias, const voi
     if (bias_img) {                                           // per-image weights (a GroupNorm folded in): persistent form of tile 16, plain epilogue
         const int cus = fmc_cu_count() & ~7;
         if (f32io || epilogue != 0 || tile != 16 || split_k != 1 || gn_partials || x2 || bias || residual || residual2 || alpha != 1.f || ln_out || lnc_stats ||
-            a_blocked || out_blocked || N % 320 || M % 160 || (M / 160) * (N / 320) <= cus || cus < 8 || img_rows < 160 || img_rows % 160 || M % img_rows ||
+            a_blocked || out_blocked || N % 320 || M % 160 || (M / 160) * (N / 320) < cus || cus < 8 || img_rows < 160 || img_rows % 160 || M % img_rows ||
             ((uintptr_t)bias_img & 15) || ((M - 1) * ldx + K) * 2 >= ((int64_t)1 << 31) || (M / img_rows) * (int64_t)N * K * 2 >= ((int64_t)1 << 31) ||
             (getenv("FMC_G160_PERSIST") && atoi(getenv("FMC_G160_PERSIST")) == 0))
-            FMC_FAIL(FMC_E_SHAPE, "linear_bf16_imgw: tile 16's persistent form only (bf16, N %% 320 == 0, M %% 160 == 0, more tiles than CUs, images of a multiple "
+            FMC_FAIL(FMC_E_SHAPE, "linear_bf16_imgw: tile 16's persistent form only (bf16, N %% 320 == 0, M %% 160 == 0, at least as many tiles as CUs, images of a multiple "
                                   "of 160 rows, no bf16 bias / residual, all weights < 2 GiB)");
         P.bias_img = bias_img; P.w_img_stride = (int64_t)N * K; P.img_rows = img_rows;
     }
     if (ln_out || ln_stats) {
         const int cus = fmc_cu_count() & ~7;
         if ((ln_out != nullptr) == (ln_stats != nullptr)) FMC_FAIL(FMC_E_NULL, "linear_bf16_ln: exactly one of ln_out / ln_stats");
-        if (f32io || epilogue != 0 || tile != 16 || split_k != 1 || gn_partials || x2 || N != 320 || M % 160 || M / 160 <= cus || cus < 8 ||
+        if (f32io || epilogue != 0 || tile != 16 || split_k != 1 || gn_partials || x2 || N != 320 || M % 160 || (bias_img ? M / 160 < cus : M / 160 <= cus) || cus < 8 ||
             (ln_out && (!ln_gamma || !ln_beta || !fmc_aligned16(ln_out))) || (ln_stats && ((uintptr_t)ln_stats & 7)) || (ln_pe && (ln_pe_inner <= 0 || ln_pe_inner % 160 || ln_pe_frames <= 0)) ||
             ((M - 1) * ldx + K) * 2 >= ((int64_t)1 << 31) || (getenv("FMC_G160_PERSIST") && atoi(getenv("FMC_G160_PERSIST")) == 0))
             FMC_FAIL(FMC_E_SHAPE, "linear_bf16_ln: the LayerNorm output comes out of tile 16's persistent form only (bf16, N == 320, M %% 160 == 0, "

@@ -1652,7 +1652,7 @@ def gn_fold_ok(x: torch.Tensor, gn_tag, groups: int, weight: torch.Tensor, ln: O
     M = n_img * hw
     return (x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and weight.dtype == torch.bfloat16 and weight.is_contiguous() and weight.shape[1] == C
             and groups == 32 and gn_tag[1] == C and gn_tag[0].shape[0] == n_img and gn_tag[0].shape[1] <= 64 and gn_tag[0].shape[2] == groups
-            and hw % 160 == 0 and C % 64 == 0 and N % 320 == 0 and (M // 160) * (N // 320) > _cus(x.device) and n_img * N * C * 2 <= GN_FOLD_MAX_BYTES
+            and hw % 160 == 0 and C % 64 == 0 and N % 320 == 0 and (M // 160) * (N // 320) >= _cus(x.device) and n_img * N * C * 2 <= GN_FOLD_MAX_BYTES
             and M * max(C, N) * 2 < (1 << 31) and (ln is None or (LN_EPILOGUE and ln.stats_only and N == 320))
             and os.environ.get("FMC_G160_PERSIST", "1") != "0")
 

@@ -2217,7 +2217,8 @@ def test_ff_tail_folded_output_projection_and_proj_out(K, M, cff, C, hw):
     assert bool((d <= 2.0 ** -6 * chain.abs() + 0.05).all())
 
 
-@pytest.mark.parametrize("n_img,hw,C,N,splits,with_ln", [(32, 2560, 320, 320, 16, True), (32, 2560, 320, 320, 8, False), (18, 2560, 320, 640, 16, False)])
+@pytest.mark.parametrize("n_img,hw,C,N,splits,with_ln", [(32, 2560, 320, 320, 16, True), (32, 2560, 320, 320, 8, False), (18, 2560, 320, 640, 16, False),
+                                                            (16, 2560, 320, 320, 16, True)])      # (the last: exactly one round of tiles, the CFG-shared half batch)
 def test_linear_gnfold_groupnorm_folded_into_per_image_weights(K, n_img, hw, C, N, splits, with_ln):
     """`fmc_groupnorm_fold_linear` + `fmc_linear_bf16_imgw`: `proj(GroupNorm(x))` from the producer's partial sums without the normalised tensor -- groups
     with |mean| up to 6 sigma (the mean must cancel against the fp32 bias row built from the ROUNDED per-image weights), against fp32 GroupNorm -> linear
