@@ -137,7 +137,8 @@ _KERNEL_SOURCES = {"conv_halo_l0": ("conv_halo.hip", "common.h"), "conv_halo_l1"
                    "conv": ("gemm_conv.hip", "common.h"),
                    "proj": ("temporal_block640.hip", "gemm_conv.hip", "common.h"),
                    "tblock": ("temporal_block.hip", "common.h"),
-                   "tblock640": ("temporal_block640.hip", "common.h")}
+                   "tblock640": ("temporal_block640.hip", "common.h"),
+                   "proj_l0": ("geglu_pipe.hip", "common.h"), "ff2": ("gemm_conv.hip", "common.h"), "conv_halo4": ("conv_halo4.hip", "common.h")}
 
 
 def kernel_source_sha(kernel: str) -> str:
@@ -369,10 +370,13 @@ def measure_proj_l0_roofline(device, dtype, iters=20):
     flops = 2.0 * M * N * Kd
     achieved = flops / (ms * 1e-3) / 1e12
     name = f"geglu_pipe_kernel<320, {'8 waves x 160 rows' if var == 1 else '4 waves x 80 rows'}>" if pipe else "geglu_direct_kernel<320>"
-    return {"bound": "mfma", "kernel": f"{name} (LayerNorm + GEGLU projection, A resident, gate pipelined under the MFMAs) [{M}x{N}x{Kd}]",
-            "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "avg_launch_ms": round(ms, 4),
-            "flops_per_launch": flops, "traffic_algorithmic": 2.0 * (M * Kd + N * Kd + M * N // 2), "traffic": None,
-            "_match": ("name", "geglu_pipe_kernel<320" if pipe else "geglu_direct_kernel<320")}
+    out = {"bound": "mfma", "kernel": f"{name} (LayerNorm + GEGLU projection, A resident, gate pipelined under the MFMAs) [{M}x{N}x{Kd}]",
+           "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "avg_launch_ms": round(ms, 4),
+           "flops_per_launch": flops, "traffic_algorithmic": 2.0 * (M * Kd + N * Kd + M * N // 2), "traffic": None,
+           "_match": ("name", "geglu_pipe_kernel<320" if pipe else "geglu_direct_kernel<320")}
+    if pipe and var == 1:
+        out.update(recorded_counters("proj_l0"))
+    return out
 
 
 def measure_linear_l0_roofline(device, dtype, iters=30):
@@ -425,10 +429,13 @@ def measure_ff2_roofline(device, dtype, iters=20):
             nbytes, flops = 2.0 * (M * Kd + 2 * M * N + N * Kd), 2.0 * M * N * Kd
             what, tag = "feed-forward output projection + bias + residual", "from-blocked"
     gbs = nbytes / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": f"gemm160p_kernel<blocked A> ({what}, tile-major intermediate) [{M}x{N}x{Kd2}]",
-            "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "avg_launch_ms": round(ms, 5), "bytes_per_launch": nbytes,
-            "flops_per_launch": flops, "mfma_frac_isolated": round(flops / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None,
-            "_match": ("own_linear", lambda sh, M=M, N=N, Kd2=Kd2, tag=tag: sh[:4] == (M, N, Kd2, tag))}
+    out = {"bound": "hbm", "kernel": f"gemm160p_kernel<blocked A> ({what}, tile-major intermediate) [{M}x{N}x{Kd2}]",
+           "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "avg_launch_ms": round(ms, 5), "bytes_per_launch": nbytes,
+           "flops_per_launch": flops, "mfma_frac_isolated": round(flops / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None,
+           "_match": ("own_linear", lambda sh, M=M, N=N, Kd2=Kd2, tag=tag: sh[:4] == (M, N, Kd2, tag))}
+    if tail:
+        out.update(recorded_counters("ff2"))
+    return out
 
 
 def measure_vendor_roofline(device, dtype, call_log, iters=30):
@@ -476,11 +483,14 @@ def measure_conv_halo4_roofline(device, dtype, iters=20):
     K.call_log = log0
     flops = 2.0 * n * h * w * 9 * ci * co
     achieved = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": ("conv_halo4_kernel<16> (input halo resident, 4 waves, software-pipelined)" if halo4 else "fmc_conv3x3_bf16 (autotuned arm)")
-                                       + f" [{n}x{h}x{w}, {ci}->{co}]",
-            "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "avg_launch_ms": round(ms, 4),
-            "flops_per_launch": flops, "traffic_algorithmic": 2.0 * (n * h * w * (ci + co) + 9 * ci * co), "traffic": None,
-            "_match": ("conv_halo4", (n, h, w, ci, co, False)) if halo4 else None}
+    out = {"bound": "mfma", "kernel": ("conv_halo4_kernel<16> (input halo resident, 4 waves, software-pipelined)" if halo4 else "fmc_conv3x3_bf16 (autotuned arm)")
+                                      + f" [{n}x{h}x{w}, {ci}->{co}]",
+           "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "avg_launch_ms": round(ms, 4),
+           "flops_per_launch": flops, "traffic_algorithmic": 2.0 * (n * h * w * (ci + co) + 9 * ci * co), "traffic": None,
+           "_match": ("conv_halo4", (n, h, w, ci, co, False)) if halo4 else None}
+    if halo4:
+        out.update(recorded_counters("conv_halo4"))
+    return out
 
 
 def measure_temporal_block_l1_roofline(device, dtype, iters=20):

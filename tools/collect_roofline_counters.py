@@ -22,7 +22,8 @@ sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "gpurun_out", "roofline_pmc")
 GROUPS = ["FETCH_SIZE", "WRITE_SIZE", "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE"]
 KERNELS = {"sa40d": "sa40d_kernel", "temporal": "temporal_attn_kernel", "conv": "gemm", "conv_halo_l1": "conv_halo_kernel", "conv_halo_l0": "conv_halo_kernel",
-           "proj": "gemm160p", "tblock": "temporal_block_kernel", "tblock640": "temporal_block640_kernel"}
+           "proj": "gemm160p", "tblock": "temporal_block_kernel", "tblock640": "temporal_block640_kernel",
+           "proj_l0": "geglu_pipe_kernel", "ff2": "gemm160p_kernel<0, 5, 0, 0, 1", "conv_halo4": "conv_halo4_kernel<16"}
 # (the conv probe is the only gemm* launch with MODE 1, the GEGLU projection probe the only one with MODE 0)
 
 
@@ -34,6 +35,12 @@ def which(name, row=None):
                 gs = int(row[key])
                 break
         return {256 * 512: "conv_halo_l1", 512 * 512: "conv_halo_l0"}.get(gs)
+    if "geglu_pipe_kernel" in name:                # round 6: the level-0 LayerNorm + GEGLU projection, the folded feed-forward tail, the 4-wave halo conv
+        return "proj_l0"
+    if "gemm160p_kernel<0, 5, 0, 0, 1" in name:
+        return "ff2"
+    if "conv_halo4_kernel<16" in name:
+        return "conv_halo4"
     if "sa40d_kernel" in name:
         return "sa40d"
     if "temporal_attn_kernel" in name:

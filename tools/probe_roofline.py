@@ -12,7 +12,8 @@ import bench
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 for fn in (bench.measure_attention_roofline, bench.measure_temporal_roofline, bench.measure_proj_roofline,
-           bench.measure_temporal_block_roofline, bench.measure_temporal_block_l1_roofline):
+           bench.measure_temporal_block_roofline, bench.measure_temporal_block_l1_roofline,
+           bench.measure_proj_l0_roofline, bench.measure_ff2_roofline, bench.measure_conv_halo4_roofline):
     fn(dev, torch.bfloat16, iters=12)
 bench.measure_conv_roofline(dev, torch.bfloat16, 1, iters=12)
 bench.measure_conv_roofline(dev, torch.bfloat16, 0, iters=12)
